@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — views/sec of the GVCNN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--shapes S] [--exchange allgather|scores]
+
+Workload (BASELINE.json configs[1]): ModelNet-shaped synthetic views, 12 views x 224x224 x 3 per
+shape, Inception-v3 backbone, num_groups = 7, fp32, forward only (inference BatchNorm).  One "step"
+is one pass of the whole hot path — folded backbone over all views, scorer, device-side group
+assignment, view pooling + group fusion, classifier — over one batch that is already resident in
+HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed.run); per-GPU work is fixed
+(weak scaling) and the ranks exchange scorer responses and final view descriptors over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                                    # noqa: E402
+import torch.distributed as dist                # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+V, H, W, G, C = 12, 224, 224, 7, 10             # configs[1]; ModelNet10 -> 10 classes
+BACKBONE = "inception_v3"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shapes", type=int, default=32, help="shapes per GPU per step (x12 views)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "scores"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def roofline(eng, x, iters=5):
+    """Per-launch hipEvent timing (on the launch stream) of every implicit-GEMM conv launch of one
+    step; achieved = algorithmic conv FLOPs of the step / summed conv kernel time."""
+    plan = eng.plan
+    flops = t_ms = 0.0
+    n = 0
+    worst = None
+    for i, op in enumerate(plan.ops):
+        if op["kind"] != "conv":
+            continue
+        ms = plan.time_range(x, i, 1, iters)
+        flops += op["flops"]
+        t_ms += ms
+        n += 1
+        tf = op["flops"] / (ms * 1e-3) / 1e12
+        if worst is None or ms > worst[1]:
+            worst = (op["name"], ms, tf)
+    achieved = flops / (t_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_f32<*> (%d launches/step)" % n,
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "flops_per_step": flops, "avg_launch_us": round(t_ms * 1e3 / n, 2),
+            "conv_ms_per_step": round(t_ms, 3),
+            "longest_launch": {"name": worst[0], "ms": round(worst[1], 4), "tflops": round(worst[2], 2)}}
+
+
+def cpu_baseline(P, Hd, seconds):
+    """The CPU oracle (a port of the reference graph; TensorFlow itself cannot run here) timed on
+    this box's host cores on a bounded sample of the same workload: 1 shape x 12 views per pass,
+    reference-shaped (V sequential backbone calls, nets/model.py:129-141)."""
+    from oracle import model as OM
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = torch.rand(1, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5
+    t0 = time.time()
+    passes = 0
+    while True:
+        OM.gvcnn(x, C, P, Hd, G, BACKBONE, num_bins=G)
+        passes += 1
+        if time.time() - t0 >= seconds or passes >= 50:
+            break
+    dt = time.time() - t0
+    return {"value": round(passes * V / dt, 2), "unit": "views/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d passes of 1 shape x %d views %dx%d %s, torch-CPU fp32 oracle, %.1f s"
+                      % (passes, V, H, W, BACKBONE, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import gvcnn_tf_amd as gv
+    from gvcnn_tf_amd.sharding import ShardedGVCNN
+
+    N = a.shapes
+    eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
+    eng.plan.bind(P)
+    eng.set_head(Hd)
+    sh = ShardedGVCNN(eng, exchange=a.exchange)
+    x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(rank)) - 0.5).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sh.forward(x, check=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sh.forward(x, check=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.check_status()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        views_per_step = N * V * world
+        ms = dt / a.steps * 1e3
+        out = {
+            "metric": "views/sec", "value": round(views_per_step / (ms * 1e-3), 1), "unit": "views/s",
+            "shapes_per_sec": round(N * world / (ms * 1e-3), 2),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: ModelNet10-shaped, 12 views x 224x224x3, "
+                                   "Inception-v3 backbone (raw tap Mixed_6e, final tap Mixed_7c), "
+                                   "num_groups=7, fp32, forward only",
+                       "shapes_per_gpu": N, "views_per_gpu": N * V, "global_views": views_per_step,
+                       "num_groups": G, "num_classes": C,
+                       "exchange": a.exchange if world > 1 else "none",
+                       "gflop_per_view": round(eng.plan.total_flops / (N * V) / 1e9, 3)},
+        }
+        step_tflops = eng.plan.total_flops / (ms * 1e-3) / 1e12
+        out["step_tflops_per_gpu"] = round(step_tflops, 2)
+        if not a.no_roofline:
+            out["roofline"] = roofline(eng, x)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, Hd, a.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

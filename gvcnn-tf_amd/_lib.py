@@ -1,0 +1,114 @@
+"""ctypes binding of libgvcnn_hip.so (the C ABI declared in include/gvcnn_hip.h).
+
+The HIP library is the only compute path of this package: if it cannot be loaded the import
+fails loudly — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
+
+GV_F32, GV_BF16 = 0, 1
+GV_CONV_RELU, GV_CONV_RELU2 = 1, 2
+GV_POOL_MAX, GV_POOL_AVG = 0, 1
+GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
+GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
+GV_ABI_VERSION = 1
+
+
+class GvError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__("%s failed with code %d: %s" % (what, code, error_string(code)))
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nb", "ih", "iw", "cin", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
+        "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype")]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nb", "ih", "iw", "c", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
+        "oh", "ow", "y_ld", "mode", "dtype")]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_F = C.c_float
+
+# name -> (restype, argtypes); every symbol include/gvcnn_hip.h declares
+SIGNATURES = {
+    "gv_abi_version": (C.c_int, []),
+    "gv_error_string": (C.c_char_p, [C.c_int]),
+    "gv_packed_filter_elems": (_L, [_I, _I, _I, _I]),
+    "gv_pack_filter_hwio": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "gv_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_pool2d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
+    "gv_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
+    "gv_global_avg_pool": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "gv_view_score_partial": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P]),
+    "gv_view_score_finalize": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "gv_group_assign": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gv_group_weight": (C.c_int, [_P, _I, _I, _P, _P]),
+    "gv_view_pool_fuse_fwd": (C.c_int, [_P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _F, _P, _P, _I, _P]),
+    "gv_dense_fwd": (C.c_int, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "gv_plan_create": (C.c_int, [C.POINTER(_P)]),
+    "gv_plan_destroy": (None, [_P]),
+    "gv_plan_num_ops": (C.c_int, [_P]),
+    "gv_plan_add_conv": (C.c_int, [_P, C.POINTER(ConvDesc), _I, _L, _I, _L, _I, _L, _L, _I, _L, _I, _L,
+                                   _I, _L, _L, _L]),
+    "gv_plan_add_pool": (C.c_int, [_P, C.POINTER(PoolDesc), _I, _L, _I, _L]),
+    "gv_plan_add_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _L, _I, _L, _L, _I, _L]),
+    "gv_plan_run": (C.c_int, [_P, C.POINTER(_P), _I, _P]),
+    "gv_plan_run_range": (C.c_int, [_P, _I, _I, C.POINTER(_P), _I, _P]),
+    "gv_conv2d_time": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, C.POINTER(_F), _P]),
+    "gv_plan_time": (C.c_int, [_P, _I, _I, C.POINTER(_P), _I, _I, C.POINTER(_F), _P]),
+}
+# tuning hooks (exported, not part of the drop-in surface)
+TUNING = {
+    "gv_conv2d_set_tile_override": (None, [C.c_int]),
+    "gv_conv2d_num_tile_cfgs": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libgvcnn_hip.so is not built (%s). Run `python gvcnn-tf_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for table in (SIGNATURES, TUNING):
+        for name, (res, args) in table.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise ImportError("libgvcnn_hip.so does not export %s — rebuild it" % name)
+            fn.restype = res
+            fn.argtypes = args
+    if lib.gv_abi_version() != GV_ABI_VERSION:
+        raise ImportError("libgvcnn_hip.so ABI version %d != %d — rebuild it"
+                          % (lib.gv_abi_version(), GV_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def error_string(code):
+    try:
+        return load().gv_error_string(int(code)).decode()
+    except Exception:
+        return "?"
+
+
+def check(code, what):
+    if code != 0:
+        raise GvError(code, what)

@@ -1,0 +1,563 @@
+"""The two per-view backbones as launch plans for the HIP library.
+
+Mirrors the structure (and slim variable names) of the reference's
+`nets/inception_v3.py:29-410` and `nets/resnet_v2.py:52-248` /
+`nets/resnet_utils.py:54-195`, but instead of building V TensorFlow graph copies
+(nets/model.py:129-141) it emits ONE ordered list of kernel launches over the
+whole folded view batch [N*V, H, W, 3]:
+
+  * every slim.conv2d (+BatchNorm +ReLU | +bias) is one implicit-GEMM launch with
+    the BN folded into the epilogue's per-channel scale/shift;
+  * the branches of an Inception block write straight into channel slices of the
+    block's output buffer (pixel stride = concat width), so no tf.concat copy
+    exists (inception_v3.py:155,181,204,222,...);
+  * a ResNet unit's `shortcut + residual` (resnet_v2.py:91) is the residual input
+    of the conv3 launch, and the NEXT unit's pre-activation BN+ReLU
+    (resnet_v2.py:75) is that launch's second output;
+  * activations live in a small set of reusable device buffers assigned by
+    liveness (288 GB of HBM would hold everything, but reuse keeps the working
+    set inside the 256 MiB Infinity Cache for small batches).
+
+Nothing here computes: it describes.  `BackbonePlan.bind()` uploads parameters and
+`BackbonePlan.run()` enqueues the launches through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+INCEPTION_BN_EPS = 0.001   # nets/inception_utils.py:33
+RESNET_BN_EPS = 1e-5       # nets/resnet_utils.py:200
+
+INCEPTION_ENDPOINTS = [
+    "Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3", "MaxPool_3a_3x3", "Conv2d_3b_1x1",
+    "Conv2d_4a_3x3", "MaxPool_5a_3x3", "Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b",
+    "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b", "Mixed_7c"]
+
+SLOT_INPUT, SLOT_WEIGHTS, SLOT_SS, SLOT_ACT0 = 0, 1, 2, 3
+
+
+def _same_pads(in_size, k, s):
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return out, total // 2
+
+
+def _out_size(in_size, k, s, padding):
+    """padding: 'SAME' | 'VALID' | (before, after) explicit (resnet_utils.py:94-105)."""
+    if padding == "SAME":
+        return _same_pads(in_size, k, s)
+    if padding == "VALID":
+        return (in_size - k) // s + 1, 0
+    before, after = padding
+    return (in_size + before + after - k) // s + 1, before
+
+
+class TRef:
+    """A [nb,h,w,c] NHWC tensor inside a (virtual) buffer: element offset + pixel stride."""
+    __slots__ = ("vbuf", "off", "nb", "h", "w", "c", "ld")
+
+    def __init__(self, vbuf, off, nb, h, w, c, ld):
+        self.vbuf, self.off, self.nb, self.h, self.w, self.c, self.ld = vbuf, off, nb, h, w, c, ld
+
+    def channels(self, lo, hi):
+        assert 0 <= lo < hi <= self.c
+        return TRef(self.vbuf, self.off + lo, self.nb, self.h, self.w, hi - lo, self.ld)
+
+    @property
+    def npix(self):
+        return self.nb * self.h * self.w
+
+    def __repr__(self):
+        return "TRef(v%d+%d [%d,%d,%d,%d] ld=%d)" % (self.vbuf, self.off, self.nb, self.h, self.w,
+                                                      self.c, self.ld)
+
+
+class BackbonePlan:
+    """Collects ops symbolically, then lowers them to a native gv_plan."""
+
+    def __init__(self, nb, height, width, dtype=_lib.GV_F32):
+        self.lib = _lib.load()
+        self.nb, self.height, self.width, self.dtype = nb, height, width, dtype
+        self.ops = []            # dict records
+        self.vbufs = []          # [size_elems, persistent]
+        self.filters = []        # (weights_name, kh, kw, cin, cout, w_off)
+        self.ss_specs = []       # (kind, name, c, eps, has_gamma, scale_off, shift_off)
+        self._ss_cache = {}
+        self.w_elems = 0
+        self.ss_elems = 0
+        self.end_points = {}
+        self.input = TRef(-1, 0, nb, height, width, 3, 3)    # vbuf -1 = SLOT_INPUT
+        self._plan = None
+        self._phys = None
+        self._bufs = None
+        self._ptrs = None
+        self.keepalive = []
+
+    # ---- symbolic construction ----------------------------------------------------------------
+    def new_tensor(self, nb, h, w, c, persistent=False):
+        self.vbufs.append([nb * h * w * c, persistent])
+        return TRef(len(self.vbufs) - 1, 0, nb, h, w, c, c)
+
+    def keep(self, t):
+        if t.vbuf >= 0:
+            self.vbufs[t.vbuf][1] = True
+        return t
+
+    def _filter(self, name, kh, kw, cin, cout):
+        n = int(self.lib.gv_packed_filter_elems(kh, kw, cin, cout))
+        off = self.w_elems
+        self.filters.append((name, kh, kw, cin, cout, off))
+        self.w_elems += (n + 63) // 64 * 64          # keep every filter 256-byte aligned
+        return off
+
+    def _scale_shift(self, kind, name, c, eps=0.0, has_gamma=False):
+        key = (kind, name)
+        if key in self._ss_cache:
+            return self._ss_cache[key]
+        cpad = (c + 3) // 4 * 4
+        so, ho = self.ss_elems, self.ss_elems + cpad
+        self.ss_elems += 2 * cpad
+        self.ss_specs.append((kind, name, c, eps, has_gamma, so, ho))
+        self._ss_cache[key] = (so, ho)
+        return so, ho
+
+    def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
+             residual=None, next_preact=None):
+        """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
+        norm = None -> biases, no BN (normalizer_fn=None).  next_preact = (bn_scope, eps) adds the
+        second output relu(bn(out)) and returns (out, preact)."""
+        kh, kw = (k, k) if isinstance(k, int) else k
+        oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
+        ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
+        if out is None:
+            out = self.new_tensor(x.nb, oh, ow, cout)
+        assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, cout), (scope, out, oh, ow, cout)
+        w_off = self._filter(scope + "/weights", kh, kw, x.c, cout)
+        if norm is not None:
+            so, ho = self._scale_shift("bn", scope + "/BatchNorm", cout, norm[1], norm[2])
+        else:
+            so, ho = self._scale_shift("bias", scope + "/biases", cout)
+        y2 = None
+        s2 = h2 = 0
+        if next_preact is not None:
+            y2 = self.new_tensor(x.nb, oh, ow, cout)
+            s2, h2 = self._scale_shift("bn", next_preact[0], cout, next_preact[1], True)
+        if residual is not None:
+            assert (residual.nb, residual.h, residual.w, residual.c) == (x.nb, oh, ow, cout)
+        self.ops.append(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
+                             scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
+                             kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
+                             flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
+                             bytes=4.0 * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout)))
+        return (out, y2) if next_preact is not None else out
+
+    def pool(self, x, k, stride, padding, mode, out=None, name="pool"):
+        oh, pad_t = _out_size(x.h, k, stride, padding)
+        ow, pad_l = _out_size(x.w, k, stride, padding)
+        if out is None:
+            out = self.new_tensor(x.nb, oh, ow, x.c)
+        assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, x.c)
+        self.ops.append(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t,
+                             pad_l=pad_l, mode=mode, flops=0.0,
+                             bytes=4.0 * (x.npix * x.c + out.npix * out.c)))
+        return out
+
+    def bn_relu(self, x, bn_scope, eps, name):
+        """Stand-alone slim.batch_norm(activation_fn=relu) (resnet_v2.py:75, first unit only)."""
+        out = self.new_tensor(x.nb, x.h, x.w, x.c)
+        so, ho = self._scale_shift("bn", bn_scope, x.c, eps, True)
+        self.ops.append(dict(kind="ssa", name=name, x=x, y=out, scale_off=so, shift_off=ho, relu=True,
+                             flops=0.0, bytes=8.0 * x.npix * x.c))
+        return out
+
+    # ---- lowering ----------------------------------------------------------------------------
+    def _assign_buffers(self):
+        last_use = {}
+        first_def = {}
+        for i, op in enumerate(self.ops):
+            for key in ("x", "y", "y2", "res"):
+                t = op.get(key)
+                if t is not None and t.vbuf >= 0:
+                    last_use[t.vbuf] = i
+                    first_def.setdefault(t.vbuf, i)
+        phys_sizes = []
+        free = []                  # physical ids
+        vmap = {}
+        for i, op in enumerate(self.ops):
+            for key in ("y", "y2"):
+                t = op.get(key)
+                if t is None or t.vbuf in vmap:
+                    continue
+                need = self.vbufs[t.vbuf][0]
+                cand = [p for p in free if phys_sizes[p] >= need]
+                if cand:
+                    p = min(cand, key=lambda q: phys_sizes[q])
+                    free.remove(p)
+                else:
+                    grow = [p for p in free]
+                    if grow:                       # enlarge the biggest free buffer instead of adding one
+                        p = max(grow, key=lambda q: phys_sizes[q])
+                        free.remove(p)
+                        phys_sizes[p] = need
+                    else:
+                        p = len(phys_sizes)
+                        phys_sizes.append(need)
+                vmap[t.vbuf] = p
+            for v, lu in list(last_use.items()):
+                if lu == i and v in vmap and not self.vbufs[v][1]:
+                    free.append(vmap[v])
+                    del last_use[v]
+        return vmap, phys_sizes
+
+    def lower(self, device):
+        """Create the native plan and the device buffers."""
+        assert self._plan is None
+        lib = self.lib
+        vmap, phys_sizes = self._assign_buffers()
+        self._phys = vmap
+        plan = C.c_void_p()
+        _lib.check(lib.gv_plan_create(C.byref(plan)), "gv_plan_create")
+        self._plan = plan
+
+        def ref(t):
+            if t is None:
+                return -1, 0
+            if t.vbuf < 0:
+                return SLOT_INPUT, t.off
+            return SLOT_ACT0 + vmap[t.vbuf], t.off
+
+        for op in self.ops:
+            x, y = op["x"], op["y"]
+            xs, xo = ref(x)
+            ys, yo = ref(y)
+            if op["kind"] == "conv":
+                y2, res = op["y2"], op["res"]
+                flags = (_lib.GV_CONV_RELU if op["relu"] else 0) | (_lib.GV_CONV_RELU2 if y2 is not None else 0)
+                d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
+                                  op["pad_t"], op["pad_l"], y.h, y.w, y.c, y.ld,
+                                  res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
+                                  flags, self.dtype)
+                rs, ro = ref(res)
+                y2s, y2o = ref(y2)
+                _lib.check(lib.gv_plan_add_conv(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"],
+                                                SLOT_SS, op["scale_off"], op["shift_off"], rs, ro,
+                                                ys, yo, y2s, y2o, op["scale2_off"], op["shift2_off"]),
+                           "gv_plan_add_conv(%s)" % op["name"])
+            elif op["kind"] == "pool":
+                d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"],
+                                  op["pad_t"], op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dtype)
+                _lib.check(lib.gv_plan_add_pool(plan, C.byref(d), xs, xo, ys, yo),
+                           "gv_plan_add_pool(%s)" % op["name"])
+            else:
+                _lib.check(lib.gv_plan_add_scale_shift_act(plan, x.npix, x.c, x.ld, y.ld, 1, self.dtype,
+                                                           xs, xo, SLOT_SS, op["scale_off"],
+                                                           op["shift_off"], ys, yo),
+                           "gv_plan_add_scale_shift_act(%s)" % op["name"])
+        tdtype = torch.float32
+        self.weights = torch.zeros(max(self.w_elems, 4), dtype=tdtype, device=device)
+        self.ss = torch.zeros(max(self.ss_elems, 4), dtype=torch.float32, device=device)
+        self.act = [torch.empty(n, dtype=tdtype, device=device) for n in phys_sizes]
+        self._bufs = [None, self.weights, self.ss] + self.act
+        self.act_bytes = sum(phys_sizes) * 4
+        return self
+
+    def view(self, t):
+        """torch view [nb,h,w,c] of a plan tensor (strided when it is a channel slice)."""
+        base = self._bufs[SLOT_ACT0 + self._phys[t.vbuf]]
+        return torch.as_strided(base, (t.nb, t.h, t.w, t.c), (t.h * t.w * t.ld, t.w * t.ld, t.ld, 1),
+                                t.off)
+
+    # ---- parameters ----------------------------------------------------------------------------
+    def bind(self, params, stream=None):
+        """Upload slim-named parameters: pack HWIO filters on device, fold BN into scale/shift.
+        params: dict name -> array-like (numpy / torch, any device), fp32."""
+        dev = self.weights.device
+        st = _stream_ptr(stream)
+        for name, kh, kw, cin, cout, off in self.filters:
+            w = torch.as_tensor(params[name]).to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(w.shape) == (kh, kw, cin, cout), (name, tuple(w.shape), (kh, kw, cin, cout))
+            _lib.check(self.lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout,
+                                                    self.weights.data_ptr() + 4 * off, self.dtype, st),
+                       "gv_pack_filter_hwio(%s)" % name)
+            self.keepalive.append(w)
+        host = np.zeros(max(self.ss_elems, 4), dtype=np.float32)
+
+        def arr(n):
+            return np.asarray(torch.as_tensor(params[n]).detach().cpu(), dtype=np.float64)
+
+        for kind, name, c, eps, has_gamma, so, ho in self.ss_specs:
+            if kind == "bias":
+                host[so:so + c] = 1.0
+                host[ho:ho + c] = arr(name)
+            else:
+                inv = 1.0 / np.sqrt(arr(name + "/moving_variance") + eps)
+                if has_gamma:
+                    inv = inv * arr(name + "/gamma")
+                host[so:so + c] = inv
+                host[ho:ho + c] = arr(name + "/beta") - arr(name + "/moving_mean") * inv
+        self.ss.copy_(torch.from_numpy(host))
+        torch.cuda.synchronize(dev)
+        self.keepalive.clear()
+        return self
+
+    def param_shapes(self):
+        """slim variable name -> shape, for every variable the plan reads."""
+        shapes = {}
+        for name, kh, kw, cin, cout, _ in self.filters:
+            shapes[name] = (kh, kw, cin, cout)
+        for kind, name, c, eps, has_gamma, _, _ in self.ss_specs:
+            if kind == "bias":
+                shapes[name] = (c,)
+            else:
+                for leaf in ("beta", "moving_mean", "moving_variance") + (("gamma",) if has_gamma else ()):
+                    shapes[name + "/" + leaf] = (c,)
+        return shapes
+
+    # ---- execution ----------------------------------------------------------------------------
+    def _ptr_table(self, x):
+        assert x.is_contiguous() and x.dtype == torch.float32
+        assert x.numel() == self.nb * self.height * self.width * 3, (tuple(x.shape), self.nb)
+        if self._ptrs is None:
+            self._ptrs = (C.c_void_p * len(self._bufs))()
+            for i, b in enumerate(self._bufs):
+                self._ptrs[i] = b.data_ptr() if b is not None else 0
+        self._ptrs[SLOT_INPUT] = x.data_ptr()
+        return self._ptrs
+
+    def run(self, x, stream=None):
+        """Enqueue the whole backbone on `stream` (default: torch's current stream)."""
+        ptrs = self._ptr_table(x)
+        _lib.check(self.lib.gv_plan_run(self._plan, ptrs, len(self._bufs), _stream_ptr(stream)),
+                   "gv_plan_run")
+
+    def run_range(self, x, first, count, stream=None):
+        ptrs = self._ptr_table(x)
+        _lib.check(self.lib.gv_plan_run_range(self._plan, first, count, ptrs, len(self._bufs),
+                                              _stream_ptr(stream)), "gv_plan_run_range")
+
+    def time_range(self, x, first, count, iters, stream=None):
+        """Average ms of ops [first, first+count) via hipEvents on the launch stream."""
+        ptrs = self._ptr_table(x)
+        ms = C.c_float(0)
+        _lib.check(self.lib.gv_plan_time(self._plan, first, count, ptrs, len(self._bufs), iters,
+                                         C.byref(ms), _stream_ptr(stream)), "gv_plan_time")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                self.lib.gv_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    @property
+    def total_flops(self):
+        return sum(op["flops"] for op in self.ops)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------
+# Inception-v3 base — nets/inception_v3.py:93-410 under inception_arg_scope (inception_utils.py:52-78):
+# every conv = conv(no bias) -> BN(no gamma, eps 1e-3) -> ReLU.
+# ------------------------------------------------------------------------------------------------
+def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c"), scope="InceptionV3"):
+    if final_endpoint not in INCEPTION_ENDPOINTS:
+        raise ValueError("Unknown final endpoint %s" % final_endpoint)       # inception_v3.py:410
+    BN = ("bn", INCEPTION_BN_EPS, False)
+    MAX, AVG = _lib.GV_POOL_MAX, _lib.GV_POOL_AVG
+
+    def conv(x, name, cout, k, stride=1, padding="SAME", out=None):
+        return b.conv(x, scope + "/" + name, cout, k, stride, padding, out=out, norm=BN, relu=True)
+
+    def done(name, t):
+        b.end_points[name] = t
+        if name in keep:
+            b.keep(t)
+        return name == final_endpoint
+
+    net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
+    if done("Conv2d_1a_3x3", net): return net
+    net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID")
+    if done("Conv2d_2a_3x3", net): return net
+    net = conv(net, "Conv2d_2b_3x3", 64, 3, 1, "SAME")
+    if done("Conv2d_2b_3x3", net): return net
+    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_3a_3x3")
+    if done("MaxPool_3a_3x3", net): return net
+    net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID")
+    if done("Conv2d_3b_1x1", net): return net
+    net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID")
+    if done("Conv2d_4a_3x3", net): return net
+    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3")
+    if done("MaxPool_5a_3x3", net): return net
+
+    def mixed5(x, name, b1a, b1b, pool_depth):                  # inception_v3.py:137-204
+        s = name + "/"
+        out = b.new_tensor(x.nb, x.h, x.w, 64 + 64 + 96 + pool_depth)
+        conv(x, s + "Branch_0/Conv2d_0a_1x1", 64, 1, out=out.channels(0, 64))
+        t = conv(x, s + "Branch_1/" + b1a, 48, 1)
+        conv(t, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
+        t = conv(x, s + "Branch_2/Conv2d_0a_1x1", 64, 1)
+        t = conv(t, s + "Branch_2/Conv2d_0b_3x3", 96, 3)
+        conv(t, s + "Branch_2/Conv2d_0c_3x3", 96, 3, out=out.channels(128, 224))
+        t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+        conv(t, s + "Branch_3/Conv2d_0b_1x1", pool_depth, 1, out=out.channels(224, 224 + pool_depth))
+        return out
+
+    net = mixed5(net, "Mixed_5b", "Conv2d_0a_1x1", "Conv2d_0b_5x5", 32)
+    if done("Mixed_5b", net): return net
+    net = mixed5(net, "Mixed_5c", "Conv2d_0b_1x1", "Conv_1_0c_5x5", 64)
+    if done("Mixed_5c", net): return net
+    net = mixed5(net, "Mixed_5d", "Conv2d_0a_1x1", "Conv2d_0b_5x5", 64)
+    if done("Mixed_5d", net): return net
+
+    # Mixed_6a — inception_v3.py:207-223
+    s = "Mixed_6a/"
+    oh = (net.h - 3) // 2 + 1
+    ow = (net.w - 3) // 2 + 1
+    out = b.new_tensor(net.nb, oh, ow, 384 + 96 + net.c)
+    conv(net, s + "Branch_0/Conv2d_1a_1x1", 384, 3, 2, "VALID", out=out.channels(0, 384))
+    t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 64, 1)
+    t = conv(t, s + "Branch_1/Conv2d_0b_3x3", 96, 3)
+    conv(t, s + "Branch_1/Conv2d_1a_1x1", 96, 3, 2, "VALID", out=out.channels(384, 480))
+    b.pool(net, 3, 2, "VALID", MAX, out=out.channels(480, 480 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
+    net = out
+    if done("Mixed_6a", net): return net
+
+    def mixed6(x, name, d):                                     # inception_v3.py:226-338
+        s = name + "/"
+        out = b.new_tensor(x.nb, x.h, x.w, 768)
+        conv(x, s + "Branch_0/Conv2d_0a_1x1", 192, 1, out=out.channels(0, 192))
+        t = conv(x, s + "Branch_1/Conv2d_0a_1x1", d, 1)
+        t = conv(t, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
+        conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), out=out.channels(192, 384))
+        t = conv(x, s + "Branch_2/Conv2d_0a_1x1", d, 1)
+        t = conv(t, s + "Branch_2/Conv2d_0b_7x1", d, (7, 1))
+        t = conv(t, s + "Branch_2/Conv2d_0c_1x7", d, (1, 7))
+        t = conv(t, s + "Branch_2/Conv2d_0d_7x1", d, (7, 1))
+        conv(t, s + "Branch_2/Conv2d_0e_1x7", 192, (1, 7), out=out.channels(384, 576))
+        t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+        conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(576, 768))
+        return out
+
+    for name, d in (("Mixed_6b", 128), ("Mixed_6c", 160), ("Mixed_6d", 160), ("Mixed_6e", 192)):
+        net = mixed6(net, name, d)
+        if done(name, net): return net
+
+    # Mixed_7a — inception_v3.py:341-360
+    s = "Mixed_7a/"
+    oh = (net.h - 3) // 2 + 1
+    ow = (net.w - 3) // 2 + 1
+    out = b.new_tensor(net.nb, oh, ow, 320 + 192 + net.c)
+    t = conv(net, s + "Branch_0/Conv2d_0a_1x1", 192, 1)
+    conv(t, s + "Branch_0/Conv2d_1a_3x3", 320, 3, 2, "VALID", out=out.channels(0, 320))
+    t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 192, 1)
+    t = conv(t, s + "Branch_1/Conv2d_0b_1x7", 192, (1, 7))
+    t = conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1))
+    conv(t, s + "Branch_1/Conv2d_1a_3x3", 192, 3, 2, "VALID", out=out.channels(320, 512))
+    b.pool(net, 3, 2, "VALID", MAX, out=out.channels(512, 512 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
+    net = out
+    if done("Mixed_7a", net): return net
+
+    def mixed7(x, name, b1_3x1, b2_names):                      # inception_v3.py:362-409
+        s = name + "/"
+        out = b.new_tensor(x.nb, x.h, x.w, 2048)
+        conv(x, s + "Branch_0/Conv2d_0a_1x1", 320, 1, out=out.channels(0, 320))
+        t = conv(x, s + "Branch_1/Conv2d_0a_1x1", 384, 1)
+        conv(t, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
+        conv(t, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
+        t = conv(x, s + "Branch_2/Conv2d_0a_1x1", 448, 1)
+        t = conv(t, s + "Branch_2/Conv2d_0b_3x3", 384, 3)
+        conv(t, s + "Branch_2/" + b2_names[0], 384, (1, 3), out=out.channels(1088, 1472))
+        conv(t, s + "Branch_2/" + b2_names[1], 384, (3, 1), out=out.channels(1472, 1856))
+        t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+        conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(1856, 2048))
+        return out
+
+    net = mixed7(net, "Mixed_7b", "Conv2d_0b_3x1", ("Conv2d_0c_1x3", "Conv2d_0d_3x1"))
+    if done("Mixed_7b", net): return net
+    net = mixed7(net, "Mixed_7c", "Conv2d_0c_3x1", ("Conv2d_0c_1x3", "Conv2d_0d_3x1"))
+    done("Mixed_7c", net)
+    return net
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet-v2-50 up to block4 — nets/resnet_v2.py:163-189,230-248; postnorm/pool5/logits are never
+# fetched by nets/model.py:144-149 and are not built.
+# ------------------------------------------------------------------------------------------------
+RESNET50_BLOCKS = (("block1", 64, 3, 2), ("block2", 128, 4, 2), ("block3", 256, 6, 2),
+                   ("block4", 512, 3, 1))
+
+
+def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), scope="resnet_v2_50"):
+    BN = ("bn", RESNET_BN_EPS, True)
+    MAX = _lib.GV_POOL_MAX
+    # conv1: explicit pad 3 + VALID, bias, no BN/ReLU (resnet_v2.py:178-180, resnet_utils.py:94-105)
+    net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False)
+    b.end_points[scope + "/conv1"] = net
+    net = b.pool(net, 3, 2, "SAME", MAX, name=scope + "/pool1")                    # resnet_v2.py:181
+    units = []
+    for bname, base, n_units, bstride in RESNET50_BLOCKS:
+        for u in range(n_units):
+            units.append((bname, base, u, n_units, bstride if u == n_units - 1 else 1))
+    first_sc = "%s/%s/unit_1/bottleneck_v2" % (scope, units[0][0])
+    preact = b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact")
+    for i, (bname, base, u, n_units, stride) in enumerate(units):
+        sc = "%s/%s/unit_%d/bottleneck_v2" % (scope, bname, u + 1)
+        depth, depth_in = base * 4, net.c
+        if depth == depth_in:                                                      # resnet_v2.py:76-77
+            shortcut = net if stride == 1 else b.pool(net, 1, stride, "VALID", MAX, name=sc + "/shortcut")
+        else:                                                                      # resnet_v2.py:79-81
+            shortcut = b.conv(preact, sc + "/shortcut", depth, 1, stride, "VALID", norm=None, relu=False)
+        r = b.conv(preact, sc + "/conv1", base, 1, 1, "SAME", norm=BN, relu=True)  # :83-84
+        pad = "SAME" if stride == 1 else ((1, 1), (1, 1))                          # resnet_utils.py:94-105
+        r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
+        nxt = None
+        if i + 1 < len(units):
+            nb_, _, nu, _, _ = units[i + 1]
+            nxt = ("%s/%s/unit_%d/bottleneck_v2/preact" % (scope, nb_, nu + 1), RESNET_BN_EPS)
+        res = b.conv(r, sc + "/conv3", depth, 1, 1, "SAME", norm=None, relu=False,
+                     residual=shortcut, next_preact=nxt)                           # :87-91
+        net, preact = res if nxt is not None else (res, None)
+        b.end_points[sc] = net
+        if u == n_units - 1:
+            b.end_points["%s/%s" % (scope, bname)] = net                           # resnet_utils.py:181
+            if "%s/%s" % (scope, bname) in keep:
+                b.keep(net)
+    return net
+
+
+BACKBONES = {"inception_v3": build_inception_v3, "resnet_v2_50": build_resnet_v2_50}
+# (raw-descriptor tap, final-descriptor tap): nets/model.py:144,149 for ResNet; for Inception only the
+# final tap is written in the reference (model.py:193), the raw tap defaults to the stride-16 stage.
+TAPS = {"resnet_v2_50": ("resnet_v2_50/block3", "resnet_v2_50/block4"),
+        "inception_v3": ("Mixed_6e", "Mixed_7c")}
+
+
+def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32):
+    b = BackbonePlan(nb, height, width, dtype)
+    raw_tap = raw_tap or TAPS[backbone][0]
+    final_tap = final_tap or TAPS[backbone][1]
+    if backbone == "inception_v3":
+        build_inception_v3(b, final_endpoint=final_tap if final_tap in INCEPTION_ENDPOINTS else "Mixed_7c",
+                           keep=(raw_tap, final_tap))
+    elif backbone == "resnet_v2_50":
+        build_resnet_v2_50(b, keep=(raw_tap, final_tap))
+    else:
+        raise ValueError("unknown backbone %r" % backbone)
+    for t in (raw_tap, final_tap):
+        if t not in b.end_points:
+            raise ValueError("end point %r not in backbone %s" % (t, backbone))
+        b.keep(b.end_points[t])
+    b.raw_tap, b.final_tap = raw_tap, final_tap
+    return b.lower(device)

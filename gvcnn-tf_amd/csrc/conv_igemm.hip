@@ -1,0 +1,393 @@
+// conv_igemm.hip — NHWC convolution as an implicit GEMM on the CDNA4 matrix cores (fp32 path).
+//
+//   M = nb*oh*ow (output pixels of the whole folded view batch), N = cout, K = kh*kw*cin
+//   A[m][k] = x[n, oy*stride + r - pad_t, ox*stride + s - pad_l, c]   (gathered on the fly, zero outside)
+//   B[n][k] = packed filter [cout][Kpad]                               (k = (r*kw+s)*cin + c)
+//
+// Replaces slim.conv2d (+BN+ReLU / +bias / +residual) of the reference: nets/inception_v3.py:97-405,
+// nets/resnet_v2.py:79-91, nets/resnet_utils.py:94-105.
+//
+// Kernel structure (one workgroup = 4 waves = 256 threads, wave64):
+//   * block tile BM x BN, K-step 16; wave tile (TM x TN) MFMA tiles of 32x32 on
+//     v_mfma_f32_32x32x2_f32 (exact fp32: bit-for-bit a k-ordered fmaf chain);
+//   * A and B k-tiles are staged global -> registers -> LDS (issue-early / write-late: the
+//     next tile's global loads are in flight while the current tile is multiplied), LDS is
+//     double buffered, one barrier per k-tile;
+//   * LDS image is [row][16 + 4 pad] fp32 (80-byte rows): 16-byte ds_write_b128 from the loader,
+//     conflict-free ds_read_b128 by the MFMA lanes (row stride 20 dwords = 5 x 16 B, 5 odd).
+//     Lane (i = lane&31, h = lane>>5) reads 16-byte chunks {h, h+2} of its row, so one read feeds
+//     four MFMAs; A and B use the SAME k permutation, which leaves the sum over k unchanged;
+//   * epilogue straight from the accumulators: y = act(acc*scale[c] + shift[c] (+ residual)),
+//     written at a channel offset of a wider (concat) buffer through y_ld — this is what removes
+//     the tf.concat copies of nets/inception_v3.py:155,...; optional second output
+//     y2 = act2(v*scale2 + shift2) (the next ResNet unit's pre-activation, nets/resnet_v2.py:75);
+//   * 1-D grid, n-tiles fastest, remapped so that each XCD (private L2) gets a contiguous chunk
+//     of tile ids: the n-tiles that re-read one A panel run on one L2.
+#include "gv_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    float* y2;
+    const float* scale2;
+    const float* shift2;
+    int nb, ih, iw, cin, x_ld;
+    int kh, kw, stride, pad_t, pad_l;
+    int oh, ow, cout, y_ld, res_ld, y2_ld;
+    int M, K, Kpad, ktiles;
+    int relu, relu2;
+    int tiles_n;
+};
+
+constexpr int BK = 16;       // k-tile depth (fp32 elements); every cin on the path except 3 is a multiple
+constexpr int LDS_LD = 20;   // padded LDS row length in floats (80 B)
+
+template <int WM, int WN, int TM, int TN, bool GENERIC>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int A_LOADS = (BM * 4 + 255) / 256;
+    constexpr int B_LOADS = (BN * 4 + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                        // [2][BM][LDS_LD]
+    float* sB = smem + 2 * BM * LDS_LD;      // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % a.tiles_n;
+    const int tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- loader state -----------------------------------------------------------------------
+    int a_img[A_LOADS], a_iy0[A_LOADS], a_ix0[A_LOADS];
+    const int ohow = a.oh * a.ow;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 2;
+        const int m = m0 + row;
+        if (row < BM && m < a.M) {
+            const int n = m / ohow;
+            const int rem = m - n * ohow;
+            const int oy = rem / a.ow;
+            const int ox = rem - oy * a.ow;
+            a_img[i] = n * a.ih;
+            a_iy0[i] = oy * a.stride - a.pad_t;
+            a_ix0[i] = ox * a.stride - a.pad_l;
+        } else {
+            a_img[i] = 0;
+            a_iy0[i] = -(1 << 28);           // fails every bounds check below -> zeros
+            a_ix0[i] = 0;
+        }
+    }
+    const float* b_ptr[B_LOADS];
+    bool b_ok[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 2;
+        const int n = n0 + row;
+        b_ok[i] = (row < BN) && (n < a.cout);
+        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * (idx & 3);
+    }
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    int fr = 0, fs = 0, fc = 0;               // filter tap (r, s) and channel base of the current k-tile
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int kq = (tid + i * 256) & 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!GENERIC) {
+                const int iy = a_iy0[i] + fr;
+                const int ix = a_ix0[i] + fs;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) {
+                    const float* p = a.x + ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + fc + 4 * kq;
+                    v = *reinterpret_cast<const f32x4*>(p);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 4 * kq + j;
+                    if (k < a.K) {
+                        const int rs = k / a.cin;
+                        const int c = k - rs * a.cin;
+                        const int r = rs / a.kw;
+                        const int s = rs - r * a.kw;
+                        const int iy = a_iy0[i] + r;
+                        const int ix = a_ix0[i] + s;
+                        if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
+                            v[j] = a.x[((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + c];
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[i]) v = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
+            rb[i] = v;
+        }
+    };
+    auto advance_tap = [&]() {                 // (r, s, c) of the next k-tile; cin % 16 == 0 here
+        fc += BK;
+        if (fc >= a.cin) {
+            fc = 0;
+            if (++fs == a.kw) { fs = 0; ++fr; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int idx = tid + i * 256;
+            if (A_LOADS * 256 == BM * 4 || idx < BM * 4)
+                *reinterpret_cast<f32x4*>(sA + buf * BM * LDS_LD + (idx >> 2) * LDS_LD + 4 * (idx & 3)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * 256;
+            if (B_LOADS * 256 == BN * 4 || idx < BN * 4)
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDS_LD + (idx >> 2) * LDS_LD + 4 * (idx & 3)) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * LDS_LD + 4 * (lane >> 5);
+    const float* a_frag = sA + (wm * TM * 32) * LDS_LD + frag_off;
+    const float* b_frag = sB + (wn * TN * 32) * LDS_LD + frag_off;
+
+    // ---- main loop ----------------------------------------------------------------------------
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < a.ktiles; ++kt) {
+        const int buf = kt & 1;
+        const bool more = (kt + 1 < a.ktiles);
+        if (more) {
+            if constexpr (!GENERIC) advance_tap();
+            load_tile(kt + 1);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(a_frag + buf * BM * LDS_LD + i * 32 * LDS_LD + 8 * q);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(b_frag + buf * BN * LDS_LD + j * 32 * LDS_LD + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + col_l;
+        if (col >= a.cout) continue;
+        const float sc = a.scale[col], sh = a.shift[col];
+        float sc2 = 0.f, sh2 = 0.f;
+        if (a.y2) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + (wm * TM + i) * 32 + row_h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res) v += a.res[(size_t)m * a.res_ld + col];
+                if (a.y2) {
+                    float v2 = v * sc2 + sh2;
+                    if (a.relu2) v2 = fmaxf(v2, 0.f);
+                    a.y2[(size_t)m * a.y2_ld + col] = v2;
+                }
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.y[(size_t)m * a.y_ld + col] = v;
+            }
+        }
+    }
+}
+
+// [kh][kw][cin][cout] fp32 -> [cout][Kpad] fp32, zero padded
+__global__ void pack_filter_hwio_f32(const float* __restrict__ w, int K, int Kpad, int cout,
+                                     float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)cout * Kpad) return;
+    const int n = (int)(i / Kpad);
+    const int k = (int)(i - (int64_t)n * Kpad);
+    out[i] = (k < K) ? w[(size_t)k * cout + n] : 0.f;
+}
+
+int g_tile_override = -1;   // tuning hook: force a tile configuration (see gv_conv2d_set_tile_override)
+
+struct TileCfg { int bm, bn; };
+constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {128, 96}, {128, 32}, {64, 64}, {64, 128}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    ConvArgs a = a0;
+    a.tiles_n = gv_ceil_div(a.cout, BN);
+    const int tiles_m = gv_ceil_div(a.M, BM);
+    const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
+    if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(float);
+    if (generic)
+        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, false>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+int pick_tile(int M, int N) {
+    if (g_tile_override >= 0 && g_tile_override < kNumTiles) return g_tile_override;
+    // least padded N first, then the larger tile (fewer re-reads of the A panel)
+    int best = 0;
+    double best_cost = 1e30;
+    const int order[] = {0, 2, 1, 3};                 // 128x{128,96,64,32}
+    const double pen[] = {1.00, 1.02, 1.05, 1.15};
+    for (int t = 0; t < 4; ++t) {
+        const int bn = kTiles[order[t]].bn;
+        const double cost = (double)gv_ceil_div(N, bn) * bn * pen[t];
+        if (cost < best_cost) { best_cost = cost; best = order[t]; }
+    }
+    // small problems: halve BM so the grid still covers the chip
+    const int64_t blocks = (int64_t)gv_ceil_div(M, 128) * gv_ceil_div(N, kTiles[best].bn);
+    if (blocks < 512) {
+        if (kTiles[best].bn == 128) return 5;
+        if (kTiles[best].bn == 64) return 4;
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" void gv_conv2d_set_tile_override(int cfg) { g_tile_override = cfg; }
+extern "C" int gv_conv2d_num_tile_cfgs(void) { return kNumTiles; }
+
+extern "C" int64_t gv_packed_filter_elems(int32_t kh, int32_t kw, int32_t cin, int32_t cout) {
+    if (kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
+    const int64_t K = (int64_t)kh * kw * cin;
+    return (int64_t)cout * ((K + BK - 1) / BK * BK);
+}
+
+extern "C" int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin,
+                                   int32_t cout, void* w_packed, int32_t dtype, void* stream) {
+    if (!w_hwio || !w_packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
+    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const int K = kh * kw * cin;
+    const int Kpad = (K + BK - 1) / BK * BK;
+    const int64_t total = (int64_t)cout * Kpad;
+    hipLaunchKernelGGL(pack_filter_hwio_f32, dim3((unsigned)gv_ceil_div(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, w_hwio, K, Kpad, cout, (float*)w_packed);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
+                             const float* scale, const float* shift, const void* residual,
+                             void* y, void* y2, const float* scale2, const float* shift2,
+                             void* stream) {
+    if (!d || !x || !w_packed || !scale || !shift || !y) return GV_E_BADARG;
+    if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 ||
+        d->kw <= 0 || d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
+        return GV_E_BADARG;
+    if (d->x_ld < d->cin || d->y_ld < d->cout) return GV_E_BADARG;
+    if (residual && d->res_ld < d->cout) return GV_E_BADARG;
+    if (y2 && (!scale2 || !shift2 || d->y2_ld < d->cout)) return GV_E_BADARG;
+    // the window of the last output must start inside the padded input
+    if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
+        return GV_E_BADARG;
+    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const int64_t M64 = (int64_t)d->nb * d->oh * d->ow;
+    if (M64 > 0x7fffffff || (int64_t)d->nb * d->ih * d->iw > 0x7fffffff) return GV_E_UNSUPPORTED;
+    if (!gv_aligned16(w_packed)) return GV_E_ALIGN;
+
+    ConvArgs a;
+    a.x = (const float*)x; a.w = (const float*)w_packed; a.scale = scale; a.shift = shift;
+    a.res = (const float*)residual; a.y = (float*)y; a.y2 = (float*)y2;
+    a.scale2 = scale2; a.shift2 = shift2;
+    a.nb = d->nb; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin; a.x_ld = d->x_ld;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.oh = d->oh; a.ow = d->ow; a.cout = d->cout; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
+    a.y2_ld = d->y2_ld;
+    a.M = (int)M64; a.K = d->kh * d->kw * d->cin; a.Kpad = (a.K + BK - 1) / BK * BK;
+    a.ktiles = a.Kpad / BK;
+    a.relu = (d->flags & GV_CONV_RELU) ? 1 : 0;
+    a.relu2 = (d->flags & GV_CONV_RELU2) ? 1 : 0;
+    a.tiles_n = 0;
+
+    // vector loader needs 16-channel k-tiles inside one filter tap and 16-byte aligned pixels
+    const bool generic = (d->cin % BK != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
+    hipStream_t st = (hipStream_t)stream;
+    switch (pick_tile(a.M, a.cout)) {
+        case 0: return launch_cfg<2, 2, 2, 2>(a, generic, st);
+        case 1: return launch_cfg<2, 2, 2, 1>(a, generic, st);
+        case 2: return launch_cfg<4, 1, 1, 3>(a, generic, st);
+        case 3: return launch_cfg<4, 1, 1, 1>(a, generic, st);
+        case 4: return launch_cfg<2, 2, 1, 1>(a, generic, st);
+        case 5: return launch_cfg<2, 2, 1, 2>(a, generic, st);
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+extern "C" int gv_conv2d_time(const gv_conv_desc* d, const void* x, const void* w_packed,
+                              const float* scale, const float* shift, void* y, int32_t iters,
+                              float* ms_avg_host, void* stream) {
+    if (!ms_avg_host || iters <= 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    GV_HIP_CHECK(hipEventCreate(&e0));
+    GV_HIP_CHECK(hipEventCreate(&e1));
+    int rc = gv_conv2d_fwd(d, x, w_packed, scale, shift, nullptr, y, nullptr, nullptr, nullptr, stream);  // warm
+    if (rc == GV_OK) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == GV_OK; ++i)
+            rc = gv_conv2d_fwd(d, x, w_packed, scale, shift, nullptr, y, nullptr, nullptr, nullptr, stream);
+        (void)hipEventRecord(e1, st);
+        hipError_t e = hipEventSynchronize(e1);
+        if (rc == GV_OK && e != hipSuccess) rc = (int)e;
+        float ms = 0.f;
+        if (rc == GV_OK) { (void)hipEventElapsedTime(&ms, e0, e1); *ms_avg_host = ms / (float)iters; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

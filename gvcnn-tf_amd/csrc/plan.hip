@@ -1,0 +1,206 @@
+// plan.hip — native launch sequence for the per-view backbone ("plan") + ABI housekeeping.
+//
+// The reference builds V unrolled copies of the backbone graph, one per view at batch N
+// (nets/model.py:129-141), and lets the TF executor schedule them.  Here the whole view batch
+// is folded into one image axis and the backbone is an ordered list of kernel launches held in
+// native code: building it is host-only work done once; running it only enqueues kernels on
+// the caller's stream (no allocation, no synchronisation), so a run can be captured into a
+// hipGraph by the caller.
+#include <new>
+#include <vector>
+
+#include "gv_common.h"
+
+namespace {
+
+enum OpKind { OP_CONV = 0, OP_POOL = 1, OP_SSA = 2 };
+
+struct Ref {
+    int32_t slot;
+    int64_t off;   // element offset (fp32 elements for scale/shift, `dtype` elements otherwise)
+};
+
+struct Op {
+    OpKind kind;
+    gv_conv_desc conv;
+    gv_pool_desc pool;
+    // scale_shift_act
+    int64_t npix;
+    int32_t c, x_ld, y_ld, relu, dtype;
+    Ref x, w, scale, shift, res, y, y2, scale2, shift2;
+};
+
+inline size_t elem_size(int dtype) { return dtype == GV_BF16 ? 2 : 4; }
+
+}  // namespace
+
+struct gv_plan {
+    std::vector<Op> ops;
+    int32_t max_slot = -1;
+};
+
+namespace {
+
+inline void note(gv_plan* p, const Ref& r) {
+    if (r.slot > p->max_slot) p->max_slot = r.slot;
+}
+
+inline void* at(void* const* bufs, const Ref& r, size_t esz) {
+    if (r.slot < 0) return nullptr;
+    return (void*)((char*)bufs[r.slot] + (size_t)r.off * esz);
+}
+
+int run_op(const Op& o, void* const* bufs, void* stream) {
+    switch (o.kind) {
+        case OP_CONV: {
+            const size_t es = elem_size(o.conv.dtype);
+            return gv_conv2d_fwd(&o.conv, at(bufs, o.x, es), at(bufs, o.w, es),
+                                 (const float*)at(bufs, o.scale, 4), (const float*)at(bufs, o.shift, 4),
+                                 at(bufs, o.res, es), at(bufs, o.y, es), at(bufs, o.y2, es),
+                                 (const float*)at(bufs, o.scale2, 4),
+                                 (const float*)at(bufs, o.shift2, 4), stream);
+        }
+        case OP_POOL: {
+            const size_t es = elem_size(o.pool.dtype);
+            return gv_pool2d_fwd(&o.pool, at(bufs, o.x, es), at(bufs, o.y, es), stream);
+        }
+        case OP_SSA: {
+            const size_t es = elem_size(o.dtype);
+            return gv_scale_shift_act(at(bufs, o.x, es), o.npix, o.c, o.x_ld,
+                                      (const float*)at(bufs, o.scale, 4),
+                                      (const float*)at(bufs, o.shift, 4), o.relu, at(bufs, o.y, es),
+                                      o.y_ld, o.dtype, stream);
+        }
+    }
+    return GV_E_PLAN;
+}
+
+}  // namespace
+
+extern "C" int gv_abi_version(void) { return GV_ABI_VERSION; }
+
+extern "C" const char* gv_error_string(int code) {
+    switch (code) {
+        case GV_OK: return "ok";
+        case GV_E_BADARG: return "gvcnn: bad argument (null pointer, non-positive size or inconsistent descriptor)";
+        case GV_E_UNSUPPORTED: return "gvcnn: unsupported request (dtype or size cap)";
+        case GV_E_ALIGN: return "gvcnn: pointer or stride not aligned for the vector path";
+        case GV_E_PLAN: return "gvcnn: plan misuse (bad slot index or null plan)";
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "gvcnn: unknown error code";
+}
+
+extern "C" int gv_plan_create(gv_plan** out) {
+    if (!out) return GV_E_BADARG;
+    *out = new (std::nothrow) gv_plan();
+    return *out ? GV_OK : GV_E_PLAN;
+}
+
+extern "C" void gv_plan_destroy(gv_plan* p) { delete p; }
+
+extern "C" int gv_plan_num_ops(const gv_plan* p) { return p ? (int)p->ops.size() : GV_E_PLAN; }
+
+extern "C" int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d, int32_t x_slot, int64_t x_off,
+                                int32_t w_slot, int64_t w_off, int32_t ss_slot, int64_t scale_off,
+                                int64_t shift_off, int32_t res_slot, int64_t res_off, int32_t y_slot,
+                                int64_t y_off, int32_t y2_slot, int64_t y2_off, int64_t scale2_off,
+                                int64_t shift2_off) {
+    if (!p) return GV_E_PLAN;
+    if (!d || x_slot < 0 || w_slot < 0 || ss_slot < 0 || y_slot < 0) return GV_E_BADARG;
+    Op o{};
+    o.kind = OP_CONV;
+    o.conv = *d;
+    o.x = {x_slot, x_off};
+    o.w = {w_slot, w_off};
+    o.scale = {ss_slot, scale_off};
+    o.shift = {ss_slot, shift_off};
+    o.res = {res_slot, res_off};
+    o.y = {y_slot, y_off};
+    o.y2 = {y2_slot, y2_off};
+    o.scale2 = {y2_slot >= 0 ? ss_slot : -1, scale2_off};
+    o.shift2 = {y2_slot >= 0 ? ss_slot : -1, shift2_off};
+    for (const Ref* r : {&o.x, &o.w, &o.scale, &o.res, &o.y, &o.y2}) note(p, *r);
+    p->ops.push_back(o);
+    return GV_OK;
+}
+
+extern "C" int gv_plan_add_pool(gv_plan* p, const gv_pool_desc* d, int32_t x_slot, int64_t x_off,
+                                int32_t y_slot, int64_t y_off) {
+    if (!p) return GV_E_PLAN;
+    if (!d || x_slot < 0 || y_slot < 0) return GV_E_BADARG;
+    Op o{};
+    o.kind = OP_POOL;
+    o.pool = *d;
+    o.x = {x_slot, x_off};
+    o.y = {y_slot, y_off};
+    o.w = o.scale = o.shift = o.res = o.y2 = o.scale2 = o.shift2 = {-1, 0};
+    note(p, o.x);
+    note(p, o.y);
+    p->ops.push_back(o);
+    return GV_OK;
+}
+
+extern "C" int gv_plan_add_scale_shift_act(gv_plan* p, int64_t npix, int32_t c, int32_t x_ld,
+                                           int32_t y_ld, int32_t relu, int32_t dtype, int32_t x_slot,
+                                           int64_t x_off, int32_t ss_slot, int64_t scale_off,
+                                           int64_t shift_off, int32_t y_slot, int64_t y_off) {
+    if (!p) return GV_E_PLAN;
+    if (x_slot < 0 || ss_slot < 0 || y_slot < 0) return GV_E_BADARG;
+    Op o{};
+    o.kind = OP_SSA;
+    o.npix = npix; o.c = c; o.x_ld = x_ld; o.y_ld = y_ld; o.relu = relu; o.dtype = dtype;
+    o.x = {x_slot, x_off};
+    o.scale = {ss_slot, scale_off};
+    o.shift = {ss_slot, shift_off};
+    o.y = {y_slot, y_off};
+    o.w = o.res = o.y2 = o.scale2 = o.shift2 = {-1, 0};
+    note(p, o.x); note(p, o.scale); note(p, o.y);
+    p->ops.push_back(o);
+    return GV_OK;
+}
+
+extern "C" int gv_plan_run_range(const gv_plan* p, int32_t first, int32_t count,
+                                 void* const* buffers_host, int32_t num_slots, void* stream) {
+    if (!p) return GV_E_PLAN;
+    if (!buffers_host || first < 0 || count < 0 || (size_t)first + (size_t)count > p->ops.size())
+        return GV_E_BADARG;
+    if (num_slots <= p->max_slot) return GV_E_PLAN;
+    for (int32_t i = 0; i <= p->max_slot; ++i)
+        if (!buffers_host[i]) return GV_E_BADARG;
+    for (int32_t i = first; i < first + count; ++i) {
+        const int rc = run_op(p->ops[(size_t)i], buffers_host, stream);
+        if (rc != GV_OK) return rc;
+    }
+    return GV_OK;
+}
+
+extern "C" int gv_plan_run(const gv_plan* p, void* const* buffers_host, int32_t num_slots,
+                           void* stream) {
+    if (!p) return GV_E_PLAN;
+    return gv_plan_run_range(p, 0, (int32_t)p->ops.size(), buffers_host, num_slots, stream);
+}
+
+extern "C" int gv_plan_time(const gv_plan* p, int32_t first, int32_t count, void* const* buffers_host,
+                            int32_t num_slots, int32_t iters, float* ms_avg_host, void* stream) {
+    if (!p) return GV_E_PLAN;
+    if (!ms_avg_host || iters <= 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    GV_HIP_CHECK(hipEventCreate(&e0));
+    GV_HIP_CHECK(hipEventCreate(&e1));
+    int rc = gv_plan_run_range(p, first, count, buffers_host, num_slots, stream);   // warm
+    if (rc == GV_OK) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters && rc == GV_OK; ++i)
+            rc = gv_plan_run_range(p, first, count, buffers_host, num_slots, stream);
+        (void)hipEventRecord(e1, st);
+        const hipError_t e = hipEventSynchronize(e1);
+        if (rc == GV_OK && e != hipSuccess) rc = (int)e;
+        float ms = 0.f;
+        if (rc == GV_OK) { (void)hipEventElapsedTime(&ms, e0, e1); *ms_avg_host = ms / (float)iters; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}

@@ -1,0 +1,182 @@
+// pool.hip — HBM-bound NHWC window ops of the per-view backbone (fp32 path).
+//   * max / average pooling (slim.max_pool2d / slim.avg_pool2d: nets/inception_v3.py:112,127,152,
+//     219,355; nets/resnet_v2.py:181; `subsample`, nets/resnet_utils.py:64-67)
+//   * per-channel scale/shift(+ReLU)  (stand-alone slim.batch_norm, nets/resnet_v2.py:75)
+//   * global average pool              (tf.keras GlobalAveragePooling2D, nets/model.py:144,163)
+// One thread per (output pixel, 4-channel group): 16-byte loads/stores, consecutive lanes on
+// consecutive channels, so every wave instruction moves whole 128-byte lines.  Input and output
+// carry an explicit pixel stride so a pool can read/write a channel slice of a concat buffer
+// (Mixed_6a / Mixed_7a max-pool branches write straight into the block's output).
+#include <math.h>
+
+#include "gv_common.h"
+
+namespace {
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> { using type = f32x4; };
+template <>
+struct VecT<1> { using type = float; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, float* __restrict__ y,
+                                                  int nb, int ih, int iw, int c, int x_ld, int kh,
+                                                  int kw, int stride, int pad_t, int pad_l, int oh,
+                                                  int ow, int y_ld, int mode) {
+    using V = typename VecT<VEC>::type;
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * oh * ow * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int ox = (int)(pix % ow);
+        const int64_t t = pix / ow;
+        const int oy = (int)(t % oh);
+        const int n = (int)(t / oh);
+        V acc;
+        if constexpr (VEC == 4) acc = mode == GV_POOL_MAX ? V{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : V{0.f, 0.f, 0.f, 0.f};
+        else acc = mode == GV_POOL_MAX ? -INFINITY : 0.f;
+        int cnt = 0;
+        for (int r = 0; r < kh; ++r) {
+            const int iy = oy * stride + r - pad_t;
+            if ((unsigned)iy >= (unsigned)ih) continue;
+            for (int s = 0; s < kw; ++s) {
+                const int ix = ox * stride + s - pad_l;
+                if ((unsigned)ix >= (unsigned)iw) continue;
+                const V v = *reinterpret_cast<const V*>(x + ((size_t)(n * ih + iy) * iw + ix) * x_ld + g * VEC);
+                if (mode == GV_POOL_MAX) {
+                    if constexpr (VEC == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], v[e]);
+                    } else {
+                        acc = fmaxf(acc, v);
+                    }
+                } else {
+                    acc += v;
+                }
+                ++cnt;
+            }
+        }
+        if (mode == GV_POOL_AVG) {
+            const float inv = (float)cnt;     // divisor = number of valid taps (TF SAME semantics)
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = acc[e] / inv;
+            } else {
+                acc = acc / inv;
+            }
+        }
+        *reinterpret_cast<V*>(y + (size_t)pix * y_ld + g * VEC) = acc;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void scale_shift_act_f32(const float* __restrict__ x, int64_t npix,
+                                                           int c, int x_ld,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           float* __restrict__ y, int y_ld) {
+    using V = typename VecT<VEC>::type;
+    const int cg = c / VEC;
+    const int64_t total = npix * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        V v = *reinterpret_cast<const V*>(x + (size_t)pix * x_ld + g * VEC);
+        const V sc = *reinterpret_cast<const V*>(scale + g * VEC);
+        const V sh = *reinterpret_cast<const V*>(shift + g * VEC);
+        v = v * sc + sh;
+        if (relu) {
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else {
+                v = fmaxf(v, 0.f);
+            }
+        }
+        *reinterpret_cast<V*>(y + (size_t)pix * y_ld + g * VEC) = v;
+    }
+}
+
+// y[b][c] = mean_p x[b][p][c]; thread per (b, c): lanes walk consecutive channels.
+__global__ __launch_bounds__(256) void global_avg_pool_f32(const float* __restrict__ x, int nb, int hw,
+                                                           int c, int x_ld, float* __restrict__ y) {
+    const int64_t total = (int64_t)nb * c;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % c);
+    const int b = (int)(idx / c);
+    const float* p = x + (size_t)b * hw * x_ld + ch;
+    float s = 0.f;
+    for (int i = 0; i < hw; ++i) s += p[(size_t)i * x_ld];
+    y[idx] = s / (float)hw;
+}
+
+inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = 256 * 16;            // 16 blocks per CU, grid-stride the rest
+    return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void* stream) {
+    if (!d || !x || !y) return GV_E_BADARG;
+    if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->c <= 0 || d->kh <= 0 || d->kw <= 0 ||
+        d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
+        return GV_E_BADARG;
+    if (d->x_ld < d->c || d->y_ld < d->c) return GV_E_BADARG;
+    if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG) return GV_E_BADARG;
+    if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
+        return GV_E_BADARG;                   // an output whose window holds no valid tap
+    if (d->pad_t >= d->kh || d->pad_l >= d->kw) return GV_E_BADARG;
+    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const bool vec = (d->c % 4 == 0) && (d->x_ld % 4 == 0) && (d->y_ld % 4 == 0) && gv_aligned16(x) &&
+                     gv_aligned16(y);
+    const int64_t total = (int64_t)d->nb * d->oh * d->ow * (vec ? d->c / 4 : d->c);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(pool2d_f32<4>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x,
+                           (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->kh, d->kw, d->stride,
+                           d->pad_t, d->pad_l, d->oh, d->ow, d->y_ld, d->mode);
+    else
+        hipLaunchKernelGGL(pool2d_f32<1>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x,
+                           (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->kh, d->kw, d->stride,
+                           d->pad_t, d->pad_l, d->oh, d->ow, d->y_ld, d->mode);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_scale_shift_act(const void* x, int64_t npix, int32_t c, int32_t x_ld,
+                                  const float* scale, const float* shift, int32_t relu, void* y,
+                                  int32_t y_ld, int32_t dtype, void* stream) {
+    if (!x || !y || !scale || !shift || npix <= 0 || c <= 0 || x_ld < c || y_ld < c) return GV_E_BADARG;
+    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const bool vec = (c % 4 == 0) && (x_ld % 4 == 0) && (y_ld % 4 == 0) && gv_aligned16(x) &&
+                     gv_aligned16(y) && gv_aligned16(scale) && gv_aligned16(shift);
+    const int64_t total = npix * (vec ? c / 4 : c);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(scale_shift_act_f32<4>, dim3(grid_for(total)), dim3(256), 0, st,
+                           (const float*)x, npix, c, x_ld, scale, shift, relu, (float*)y, y_ld);
+    else
+        hipLaunchKernelGGL(scale_shift_act_f32<1>, dim3(grid_for(total)), dim3(256), 0, st,
+                           (const float*)x, npix, c, x_ld, scale, shift, relu, (float*)y, y_ld);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_global_avg_pool(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
+                                  float* y, int32_t dtype, void* stream) {
+    if (!x || !y || nb <= 0 || hw <= 0 || c <= 0 || x_ld < c) return GV_E_BADARG;
+    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const int64_t total = (int64_t)nb * c;
+    hipLaunchKernelGGL(global_avg_pool_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)x, nb, hw, c, x_ld, y);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}

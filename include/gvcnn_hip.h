@@ -1,0 +1,212 @@
+/* gvcnn_hip.h — C ABI of the MI355X-native GVCNN hot path (libgvcnn_hip.so).
+ *
+ * Drop-in boundary for the path BASELINE.json:north_star names: the per-view
+ * backbone + grouping module of ace19-dev/gvcnn-tf.  The reference has no
+ * FFI/plugin layer (it is Python on TensorFlow 1.x), so each entry point cites
+ * the reference CALL SITE whose arithmetic it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer would
+ * add on the reference side.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a positive hipError_t value on a HIP
+ *    failure, or a negative GV_E_* code; nothing throws;
+ *  - every pointer is CALLER-OWNED DEVICE memory unless the name ends in
+ *    `_host`; no hidden allocation, no hidden synchronisation;
+ *  - `stream` is a hipStream_t passed as void*; launches are asynchronous and
+ *    re-entrant across streams (safe to capture into a hipGraph);
+ *  - activations are NHWC with an explicit pixel stride `ld` (in elements), so
+ *    a tensor can be a channel slice of a wider (concat) buffer;
+ *  - written for gfx950 only.
+ */
+#ifndef GVCNN_HIP_H
+#define GVCNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GV_ABI_VERSION 1
+
+/* error codes */
+#define GV_OK 0
+#define GV_E_BADARG (-1)      /* null pointer / non-positive size / inconsistent descriptor */
+#define GV_E_UNSUPPORTED (-2) /* valid request the library does not implement (dtype, size cap) */
+#define GV_E_ALIGN (-3)       /* pointer / stride not aligned as the vector path requires */
+#define GV_E_PLAN (-4)        /* plan misuse (bad slot index, destroyed plan) */
+
+/* element types (arithmetic type of the path; accumulation is always fp32) */
+#define GV_F32 0
+#define GV_BF16 1
+
+/* gv_conv_desc.flags */
+#define GV_CONV_RELU 1        /* ReLU after scale/shift(/residual)   */
+#define GV_CONV_RELU2 2       /* ReLU on the second output           */
+
+/* pooling modes */
+#define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
+#define GV_POOL_AVG 1         /* divisor = number of VALID taps (slim.avg_pool2d, SAME) */
+
+/* view-pooling modes */
+#define GV_VIEWPOOL_MAX 0     /* tf.reduce_max  — nets/model.py:72   */
+#define GV_VIEWPOOL_MEAN 1    /* tf.reduce_mean — unit_test.py:30    */
+
+/* image order of a flattened view batch */
+#define GV_ORDER_SHAPE_MAJOR 0 /* image b = n*V + v  (the [N,V,H,W,3] input as stored, model.py:121) */
+#define GV_ORDER_VIEW_MAJOR 1  /* image b = v*N + n  (after the transpose of model.py:128)            */
+
+/* ------------------------------------------------------------------------
+ * Convolution descriptor (implicit GEMM: M = nb*oh*ow, N = cout, K = kh*kw*cin)
+ * ---------------------------------------------------------------------- */
+typedef struct gv_conv_desc {
+    int32_t nb, ih, iw, cin;   /* input  [nb, ih, iw, cin], pixel stride x_ld */
+    int32_t x_ld;
+    int32_t kh, kw;            /* filter window */
+    int32_t stride;            /* same in h and w (all call sites) */
+    int32_t pad_t, pad_l;      /* zero padding before; after-padding is implied by oh/ow */
+    int32_t oh, ow, cout;      /* output [nb, oh, ow, cout], pixel stride y_ld */
+    int32_t y_ld;
+    int32_t res_ld;            /* pixel stride of the residual input (ignored when residual == NULL) */
+    int32_t y2_ld;             /* pixel stride of the optional second output */
+    int32_t flags;             /* GV_CONV_* */
+    int32_t dtype;             /* GV_F32 | GV_BF16: type of x, w_packed, residual, y, y2 */
+} gv_conv_desc;
+
+typedef struct gv_pool_desc {
+    int32_t nb, ih, iw, c;
+    int32_t x_ld;
+    int32_t kh, kw, stride;
+    int32_t pad_t, pad_l;
+    int32_t oh, ow;
+    int32_t y_ld;
+    int32_t mode;              /* GV_POOL_* */
+    int32_t dtype;
+} gv_pool_desc;
+
+int gv_abi_version(void);
+/* Human-readable text for a code returned by any function below. */
+const char* gv_error_string(int code);
+
+/* ---- filters ------------------------------------------------------------
+ * Packed filter layout consumed by gv_conv2d_fwd: [cout][Kpad], k = (r*kw+s)*cin + c,
+ * Kpad = K rounded up to 16, zero filled.  Source is TensorFlow's HWIO
+ * [kh,kw,cin,cout] fp32 variable (slim `.../weights`). */
+int64_t gv_packed_filter_elems(int32_t kh, int32_t kw, int32_t cin, int32_t cout);
+int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin, int32_t cout,
+                        void* w_packed, int32_t dtype, void* stream);
+
+/* ---- convolution ---------------------------------------------------------
+ * y  = act( conv(x, w) * scale[c] + shift[c] (+ residual) )
+ * y2 = act2( (that pre-activation value) * scale2[c] + shift2[c] )       (optional)
+ *
+ * Replaces slim.conv2d (+ slim.batch_norm + ReLU, folded into scale/shift) at
+ * nets/inception_v3.py:97-405 (94 call sites), nets/resnet_v2.py:79-89,
+ * nets/resnet_utils.py:94-105 (explicit pad + VALID), and `shortcut + residual`
+ * at nets/resnet_v2.py:91 (residual), and the next unit's `preact`
+ * slim.batch_norm at nets/resnet_v2.py:75 (second output).
+ * scale/shift: fp32 [cout] (BN fold: scale = gamma*rsqrt(var+eps), shift = beta - mean*scale;
+ * bias-only conv: scale = 1, shift = bias).  residual/y2/scale2/shift2 may be NULL. */
+int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
+                  const float* scale, const float* shift, const void* residual,
+                  void* y, void* y2, const float* scale2, const float* shift2, void* stream);
+
+/* ---- pooling -------------------------------------------------------------
+ * slim.max_pool2d / slim.avg_pool2d: nets/inception_v3.py:112,127,152,219,355,...;
+ * nets/resnet_v2.py:181 (3x3/2 SAME, pad (0,1)); nets/resnet_utils.py:64-67
+ * (`subsample` = 1x1 max-pool with stride). */
+int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void* stream);
+
+/* y[p,c] = act(x[p,c]*scale[c] + shift[c]) over npix pixels — slim.batch_norm (+ReLU)
+ * used stand-alone: the `preact` of the first unit, nets/resnet_v2.py:75. */
+int gv_scale_shift_act(const void* x, int64_t npix, int32_t c, int32_t x_ld, const float* scale,
+                       const float* shift, int32_t relu, void* y, int32_t y_ld, int32_t dtype,
+                       void* stream);
+
+/* Global average pool over h*w: x [nb, hw, c] (pixel stride x_ld) -> y fp32 [nb, c].
+ * tf.keras.layers.GlobalAveragePooling2D at nets/model.py:144,163. */
+int gv_global_avg_pool(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld, float* y,
+                       int32_t dtype, void* stream);
+
+/* ---- grouping module ------------------------------------------------------
+ * Scorer, nets/model.py:144-145: r_img[b] = GAP(raw[b]) . kernel[v(b)] + bias[v(b)],
+ * one Dense(1) per view.  raw [nb, hw, cr] (pixel stride raw_ld), kernel fp32 [V, cr],
+ * bias fp32 [V]; v(b) from `order` (GV_ORDER_*), nb = N*V.  r_img fp32 [nb]. */
+int gv_view_score_partial(const void* raw, int32_t nb, int32_t hw, int32_t cr, int32_t raw_ld,
+                          const float* kernel, const float* bias, int32_t num_views,
+                          int32_t order, float* r_img, int32_t dtype, void* stream);
+
+/* nets/model.py:146-147: score[v] = sigmoid(log(|mean_n r_img[b(n,v)]|)), fixed summation
+ * order (n ascending) so every rank of a multi-GPU job gets identical scores. */
+int gv_view_score_finalize(const float* r_img, int32_t num_shapes, int32_t num_views,
+                           int32_t order, float* scores, void* stream);
+
+/* nets/model.py:16-41 (`group_scheme` + `group_weight`) on device:
+ * gidx[v] = (int)(scores[v] * (float)num_bins)  — fp32 product, truncation (model.py:23 uses 10);
+ * scheme [G,V] one-hot int32; weight[g] = 1 + #views in g (fp32).
+ * status (device int32): 0 ok; 1 some gidx >= G or < 0 (the reference raises IndexError
+ * there); 2 a score is NaN.  Outputs for in-range views are still written. */
+int gv_group_assign(const float* scores, int32_t num_views, int32_t num_groups, int32_t num_bins,
+                    int32_t* gidx, int32_t* scheme, float* weight, int32_t* status, void* stream);
+
+/* nets/model.py:28-41 (`group_weight`) alone, for an arbitrary 0/1 scheme fed by the caller:
+ * weight[g] = 1 + #{v : scheme[g,v] == 1}. */
+int gv_group_weight(const int32_t* scheme, int32_t num_groups, int32_t num_views, float* weight,
+                    void* stream);
+
+/* nets/model.py:44-102 (`view_pooling` + `group_fusion`) fused, one pass over the views:
+ *   D[g] = pool_{v: scheme[g,v] != 0} F[v]      (empty group -> `empty_fill`: 1 in model.py:63)
+ *   S    = sum_g weight[g]*D[g] / sum_g weight[g]
+ * F element (v, n, e) at F + v*view_stride + n*shape_stride + e, e < E = h*w*C.
+ * D (nullable) [G, N, E], S (nullable) [N, E].  scheme int32 [G,V] and weight fp32 [G] are
+ * device arrays (they never visit the host on the fused path). V <= 64, G <= 64. */
+int gv_view_pool_fuse_fwd(const void* F, int32_t num_views, int32_t num_shapes, int64_t E,
+                          int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
+                          int32_t num_groups, const float* weight, int32_t mode, float empty_fill,
+                          void* D, void* S, int32_t dtype, void* stream);
+
+/* tf.keras.layers.Dense at nets/model.py:164: y[n,:] = x[n,:] @ kernel[F,C] + bias (fp32). */
+int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel, const float* bias,
+                 int32_t c, float* y, void* stream);
+
+/* ---- plan: the per-view backbone as one native launch sequence -------------
+ * A plan is an ordered list of the ops above whose operands are (slot, element offset)
+ * pairs into a caller-supplied table of device base pointers, so that one plan runs
+ * on any set of buffers of the right size.  Building is host-only work; gv_plan_run
+ * only launches (capturable).  Replaces the V unrolled copies of the backbone graph
+ * that nets/model.py:129-141 builds, folded to one batch of N*V images. */
+typedef struct gv_plan gv_plan;
+int gv_plan_create(gv_plan** out);
+void gv_plan_destroy(gv_plan* p);
+int gv_plan_num_ops(const gv_plan* p);
+int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d,
+                     int32_t x_slot, int64_t x_off, int32_t w_slot, int64_t w_off,
+                     int32_t ss_slot, int64_t scale_off, int64_t shift_off,
+                     int32_t res_slot, int64_t res_off, int32_t y_slot, int64_t y_off,
+                     int32_t y2_slot, int64_t y2_off, int64_t scale2_off, int64_t shift2_off);
+int gv_plan_add_pool(gv_plan* p, const gv_pool_desc* d, int32_t x_slot, int64_t x_off,
+                     int32_t y_slot, int64_t y_off);
+int gv_plan_add_scale_shift_act(gv_plan* p, int64_t npix, int32_t c, int32_t x_ld, int32_t y_ld,
+                                int32_t relu, int32_t dtype, int32_t x_slot, int64_t x_off,
+                                int32_t ss_slot, int64_t scale_off, int64_t shift_off,
+                                int32_t y_slot, int64_t y_off);
+/* buffers_host: host array of `num_slots` device base pointers. */
+int gv_plan_run(const gv_plan* p, void* const* buffers_host, int32_t num_slots, void* stream);
+/* Run ops [first, first+count) only (per-layer timing / profiling). */
+int gv_plan_run_range(const gv_plan* p, int32_t first, int32_t count, void* const* buffers_host,
+                      int32_t num_slots, void* stream);
+
+/* ---- timing helper ---------------------------------------------------------
+ * Average duration (ms) of `iters` back-to-back gv_conv2d_fwd launches measured with
+ * hipEvents on `stream` (the stream the kernel is launched on); used by bench.py for the
+ * roofline line.  Synchronises the stream. */
+int gv_conv2d_time(const gv_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                   const float* shift, void* y, int32_t iters, float* ms_avg_host, void* stream);
+/* Same for a whole plan (or a range of it). */
+int gv_plan_time(const gv_plan* p, int32_t first, int32_t count, void* const* buffers_host,
+                 int32_t num_slots, int32_t iters, float* ms_avg_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVCNN_HIP_H */

@@ -1,0 +1,150 @@
+"""End-to-end parity of the HIP path against the CPU oracle (reference-shaped: V sequential
+backbone calls at batch N, host numpy grouping), for both backbones, plus size-independent
+properties at BASELINE.json's full sizes.
+
+Tolerance: 1e-3 on descriptors / logits (north_star, fp32); group indices bit-exact given the
+scores (the synthetic scorer keeps scores >= 1e-3 away from bin edges, SURVEY hard part (v))."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvcnn_tf_amd as gv                       # noqa: E402
+from oracle import backbone as OB                # noqa: E402
+from oracle import grouping as OG                # noqa: E402
+from oracle import model as OM                   # noqa: E402
+
+DEV = "cuda:0"
+TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+def make_engine(backbone, N, V, H, W, C, G, **kw):
+    eng = gv.GVCNN(backbone, N, V, H, W, C, G, device=DEV, **kw)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
+    eng.plan.bind(P)
+    eng.set_head(Hd)
+    return eng, P, Hd
+
+
+def views(N, V, H, W, seed=0):
+    return torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(seed)) - 0.5   # train_data.py:101
+
+
+@pytest.mark.parametrize("backbone,size", [("inception_v3", 75), ("inception_v3", 107), ("resnet_v2_50", 64),
+                                           ("resnet_v2_50", 97)])
+def test_backbone_endpoints_vs_oracle(backbone, size):
+    """Every kept tap of the folded backbone equals the oracle's per-image result."""
+    N, V = 2, 3
+    eng, P, _ = make_engine(backbone, N, V, size, size, 10, 10)
+    x = views(N, V, size, size)
+    eng.run_backbone(x.to(DEV))
+    torch.cuda.synchronize()
+    ep = OM.folded_backbone(x, P, backbone)
+    raw_o, fin_o = ep[eng.plan.raw_tap].numpy(), ep[eng.plan.final_tap].numpy()
+    raw = eng.raw_view_descriptors().reshape(raw_o.shape).cpu().numpy()
+    fin = eng.final_view_descriptors().reshape(fin_o.shape).cpu().numpy()
+    assert np.isfinite(fin).all() and np.abs(fin_o).max() > 1e-3
+    np.testing.assert_allclose(raw, raw_o, **TOL)
+    np.testing.assert_allclose(fin, fin_o, **TOL)
+
+
+@pytest.mark.parametrize("backbone,size,G", [("resnet_v2_50", 64, 10), ("inception_v3", 75, 10)])
+def test_gvcnn_fused_vs_reference_shaped_oracle(backbone, size, G):
+    N, V, C = 2, 6, 10
+    eng, P, Hd = make_engine(backbone, N, V, size, size, C, G)
+    x = views(N, V, size, size, seed=1)
+    scores, S, logits = eng.forward(x.to(DEV))
+    o_scores, o_S, o_logits, o_scheme, o_weight = OM.gvcnn(x, C, P, Hd, G, backbone)
+    np.testing.assert_allclose(scores.cpu().numpy(), np.array(o_scores), rtol=1e-3, atol=1e-4)
+    assert eng.scheme.cpu().numpy().tolist() == o_scheme.tolist()           # integer path: exact
+    assert eng.weight.cpu().numpy().tolist() == o_weight.tolist()
+    assert len(set(eng.gidx.cpu().tolist())) > 1                            # scores spread over bins
+    np.testing.assert_allclose(S.cpu().numpy(), o_S, **TOL)
+    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, **TOL)
+
+    # the two-phase protocol of train.py:264-288 with the reference-shaped host functions
+    sc = eng.forward_phase1(x.to(DEV))
+    host_scores = [np.array(sc.cpu().numpy())]
+    g_scheme = gv.group_scheme(host_scores, G, V)
+    g_weight = gv.group_weight(g_scheme)
+    assert g_scheme.tolist() == o_scheme.tolist() and g_weight.tolist() == o_weight.tolist()
+    S2, logits2 = eng.forward_phase2(g_scheme, g_weight)
+    np.testing.assert_array_equal(S2.cpu().numpy(), S.cpu().numpy())
+    np.testing.assert_array_equal(logits2.cpu().numpy(), logits.cpu().numpy())
+
+
+def test_functional_surface_and_basic():
+    """nets/model.py-shaped calls: gvcnn(inputs, num_classes, group_scheme, group_weight, ...), basic()."""
+    N, V, size, C, G = 2, 4, 64, 5, 10
+    eng, P, Hd = make_engine("resnet_v2_50", N, V, size, size, C, G)
+    gv.configure(backbone="resnet_v2_50", backbone_params=P, head_params=Hd)
+    x = views(N, V, size, size, seed=2)
+    o_scores, o_S, o_logits, o_scheme, o_weight = OM.gvcnn(x, C, P, Hd, G, "resnet_v2_50")
+    scores, S, logits = gv.gvcnn(x.to(DEV), C, o_scheme, o_weight, is_training=False)
+    assert isinstance(scores, list) and len(scores) == V and scores[0].dim() == 0
+    np.testing.assert_allclose(S.cpu().numpy(), o_S, **TOL)
+    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, **TOL)
+    Sb, Lb = gv.basic(x.to(DEV), C, is_training=False)
+    oSb, oLb = OM.basic(x, C, P, Hd, "resnet_v2_50")
+    np.testing.assert_allclose(Sb.cpu().numpy(), oSb, **TOL)
+    np.testing.assert_allclose(Lb.cpu().numpy(), oLb, **TOL)
+    s3, S3, L3 = gv.gvcnn_fused(x.to(DEV), C, G)
+    np.testing.assert_allclose(S3.cpu().numpy(), o_S, **TOL)
+    with pytest.raises(NotImplementedError):
+        gv.gvcnn(x.to(DEV), C, o_scheme, o_weight)                      # is_training defaults to True
+    with pytest.raises(IndexError):                                      # G=5 with scores up to 0.9 (D6)
+        gv.gvcnn_fused(x.to(DEV), C, 5)
+
+
+def test_config_c1_plumbing_case():
+    """BASELINE.json configs[0]: ModelNet10, 6 views, 224x224, Inception-v3, batch 2 (CPU-runnable
+    reference case).  num_groups=5 with the literal x10 binning overflows, so the bins
+    here are num_bins=G=5 sub-ranges on both sides."""
+    N, V, size, C, G = 2, 6, 224, 10, 5
+    eng, P, Hd = make_engine("inception_v3", N, V, size, size, C, G, num_bins=G)
+    x = views(N, V, size, size, seed=3)
+    scores, S, logits = eng.forward(x.to(DEV))
+    o_scores, o_S, o_logits, o_scheme, _ = OM.gvcnn(x, C, P, Hd, G, "inception_v3", num_bins=G)
+    assert eng.scheme.cpu().numpy().tolist() == o_scheme.tolist()
+    np.testing.assert_allclose(S.cpu().numpy(), o_S, **TOL)
+    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, **TOL)
+    assert tuple(S.shape) == (N, 5, 5, 2048)
+
+
+def test_full_size_properties_config_c2():
+    """configs[1] (12 views, 224, Inception-v3, G=7) at a size the oracle cannot finish in seconds:
+    size-independent properties instead of element-wise comparison."""
+    N, V, size, C, G = 8, 12, 224, 10, 7
+    eng, P, Hd = make_engine("inception_v3", N, V, size, size, C, G, num_bins=G)
+    x = views(N, V, size, size, seed=4).to(DEV)
+    scores, S, logits = eng.forward(x)
+    S1, L1 = S.clone(), logits.clone()
+    F = eng.final_view_descriptors().clone()                   # [N,V,5,5,2048]
+    # (1) determinism / idempotence: same input, bitwise same output
+    scores2, S2, L2 = eng.forward(x)
+    assert torch.equal(S1, S2) and torch.equal(L1, L2)
+    # (2) batch independence of the backbone: image b alone gives the same descriptor rows
+    eng1, _, _ = make_engine("inception_v3", 1, V, size, size, C, G, num_bins=G)
+    eng1.run_backbone(x[3:4].contiguous())
+    np.testing.assert_allclose(eng1.final_view_descriptors()[0].cpu().numpy(), F[3].cpu().numpy(),
+                               rtol=1e-5, atol=1e-5)
+    # (3) fusion bounds: S lies between min(min_v F, 1) and max(max_v F, 1) (convex combination of
+    #     group maxima and the all-ones dummy of model.py:63)
+    lo = torch.minimum(F.min(dim=1).values, torch.ones_like(S1))
+    hi = torch.maximum(F.max(dim=1).values, torch.ones_like(S1))
+    assert bool((S1 >= lo - 1e-5).all()) and bool((S1 <= hi + 1e-5).all())
+    # (4) Σw = G + V  (model.py:33-39)
+    assert float(eng.weight.sum()) == G + V
+    # (5) permuting the shapes permutes the outputs (grouping is per batch via the mean score, so use
+    #     the SAME scheme through phase 2)
+    perm = torch.tensor([7, 6, 5, 4, 3, 2, 1, 0], device=DEV)
+    Sp, Lp = eng.pool_fuse_classify(eng.scheme, eng.weight, F=F[perm])
+    np.testing.assert_array_equal(Sp.cpu().numpy(), S1[perm].cpu().numpy())
+    # (6) the oracle's grouping head on the device descriptors (cheap on CPU) matches
+    oS, oL = OG.grouping_head([F[:, v].cpu().numpy() for v in range(V)], eng.scheme.cpu().numpy(),
+                              eng.weight.cpu().numpy(), Hd["dense_%d/kernel" % V].numpy(),
+                              Hd["dense_%d/bias" % V].numpy())
+    np.testing.assert_allclose(S1.cpu().numpy(), oS, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(L1.cpu().numpy(), oL, rtol=1e-4, atol=1e-4)

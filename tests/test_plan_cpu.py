@@ -1,0 +1,111 @@
+"""Host logic of the product (no GPU): the launch plans describe the same networks as the oracle's
+independent procedural statement, buffers assigned by liveness never alias a live tensor, and the
+analytic work matches SURVEY §6."""
+import pytest
+import torch
+
+import gvcnn_tf_amd as gv
+from gvcnn_tf_amd import backbones
+from oracle import backbone as OB
+
+
+def _plan(name, nb, size):
+    return backbones.make_plan(name, nb, size, size, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name,size", [("inception_v3", 224), ("resnet_v2_50", 224)])
+def test_param_names_and_shapes_match_oracle(name, size):
+    p = _plan(name, 1, size)
+    assert p.param_shapes() == OB.trace_param_shapes(name)
+
+
+@pytest.mark.parametrize("name,size,gflop", [("inception_v3", 224, 5.672), ("inception_v3", 299, 11.422),
+                                              ("resnet_v2_50", 224, 6.960)])
+def test_flops_per_view_match_survey(name, size, gflop):
+    p = _plan(name, 1, size)
+    assert abs(p.total_flops / 1e9 - gflop) < 0.002 * gflop
+    n_conv = sum(1 for op in p.ops if op["kind"] == "conv")
+    assert n_conv == (94 if name == "inception_v3" else 53)
+
+
+def test_end_point_shapes():
+    p = _plan("inception_v3", 2, 299)
+    ep = p.end_points
+    for k, (hw, c) in {"Conv2d_1a_3x3": (149, 32), "MaxPool_3a_3x3": (73, 64), "MaxPool_5a_3x3": (35, 192),
+                       "Mixed_5b": (35, 256), "Mixed_5d": (35, 288), "Mixed_6a": (17, 768),
+                       "Mixed_6e": (17, 768), "Mixed_7a": (8, 1280), "Mixed_7c": (8, 2048)}.items():
+        assert (ep[k].nb, ep[k].h, ep[k].w, ep[k].c) == (2, hw, hw, c), k
+    assert list(ep) == backbones.INCEPTION_ENDPOINTS
+    p = _plan("resnet_v2_50", 2, 224)
+    assert (p.end_points["resnet_v2_50/block3"].h, p.end_points["resnet_v2_50/block3"].c) == (7, 1024)
+    assert (p.end_points["resnet_v2_50/block4"].h, p.end_points["resnet_v2_50/block4"].c) == (7, 2048)
+    with pytest.raises(ValueError):
+        backbones.build_inception_v3(backbones.BackbonePlan(1, 75, 75), final_endpoint="Mixed_8a")
+
+
+@pytest.mark.parametrize("name,size", [("inception_v3", 75), ("resnet_v2_50", 64)])
+def test_buffer_assignment_never_aliases_live_tensors(name, size):
+    p = _plan(name, 2, size)
+    vmap = p._phys
+    # replay: a physical buffer written by op i must not hold a tensor that is read at or after i
+    last_read = {}
+    for i, op in enumerate(p.ops):
+        for key in ("x", "res"):
+            t = op.get(key)
+            if t is not None and t.vbuf >= 0:
+                last_read[t.vbuf] = i
+    persistent = {v for v, (_, keep) in enumerate(p.vbufs) if keep}
+    owner = {}                       # phys -> vbuf currently stored
+    for i, op in enumerate(p.ops):
+        for key in ("y", "y2"):
+            t = op.get(key)
+            if t is None:
+                continue
+            ph = vmap[t.vbuf]
+            prev = owner.get(ph)
+            if prev is not None and prev != t.vbuf:
+                assert prev not in persistent, (op["name"], "overwrites a kept end point")
+                assert last_read.get(prev, -1) < i, (op["name"], "overwrites a live tensor")
+            owner[ph] = t.vbuf
+        for key in ("x", "res"):
+            t = op.get(key)
+            if t is not None and t.vbuf >= 0:
+                assert owner.get(vmap[t.vbuf]) == t.vbuf, (op["name"], "reads a recycled buffer")
+        # in/out of one op never share a physical buffer
+        outs = {vmap[op[k].vbuf] for k in ("y", "y2") if op.get(k) is not None}
+        ins = {vmap[op[k].vbuf] for k in ("x", "res") if op.get(k) is not None and op[k].vbuf >= 0}
+        assert not (outs & ins), op["name"]
+    # reuse actually happens
+    assert len(set(vmap.values())) < len(p.vbufs) / 2
+
+
+def test_concat_slices_cover_block_outputs():
+    """Every channel of an Inception block output is written by exactly one producer (no tf.concat)."""
+    p = _plan("inception_v3", 1, 75)
+    cover = {}
+    for op in p.ops:
+        y = op["y"]
+        cover.setdefault(y.vbuf, []).append((y.off % y.ld, y.off % y.ld + y.c, y.ld))
+    for name in ("Mixed_5b", "Mixed_6a", "Mixed_6e", "Mixed_7a", "Mixed_7c"):
+        t = p.end_points[name]
+        spans = sorted(cover[t.vbuf])
+        assert spans[0][0] == 0 and spans[-1][1] == t.c
+        for (a0, a1, _), (b0, b1, _) in zip(spans, spans[1:]):
+            assert a1 == b0, (name, spans)
+
+
+def test_resnet_fusions():
+    """shortcut+residual is the conv3 epilogue; the next unit's preact is its second output."""
+    p = _plan("resnet_v2_50", 1, 64)
+    conv3 = [op for op in p.ops if op["name"].endswith("/conv3")]
+    assert len(conv3) == 16 and all(op["res"] is not None for op in conv3)
+    assert sum(op["y2"] is not None for op in conv3) == 15          # last unit has no successor
+    assert sum(1 for op in p.ops if op["kind"] == "ssa") == 1       # only the very first preact
+    assert sum(1 for op in p.ops if op["kind"] == "pool") == 1 + 3  # pool1 + 3 strided identity shortcuts
+
+
+def test_head_param_names():
+    H = gv.params.init_head_params(3, 16, 32, 5)
+    assert sorted(H) == sorted(["dense/kernel", "dense/bias", "dense_1/kernel", "dense_1/bias",
+                                "dense_2/kernel", "dense_2/bias", "dense_3/kernel", "dense_3/bias"])
+    assert H["dense_3/kernel"].shape == (32, 5) and H["dense/kernel"].shape == (16, 1)
