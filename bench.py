@@ -74,15 +74,21 @@ def cpu_baseline(P, Hd, seconds):
     this box's host cores on a bounded sample of the same workload: 1 shape x 12 views per pass,
     reference-shaped (V sequential backbone calls, nets/model.py:129-141)."""
     from oracle import model as OM
-    cores = os.cpu_count() or 1
+    # 16 threads: on a 256-thread host the oneDNN convs of a batch-1 view stop scaling (and
+    # collapse from oversubscription) well before that; `cores` reports what was actually used.
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     x = torch.rand(1, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5
     t0 = time.time()
+    OM.gvcnn_scores(x[:, :2].contiguous(), P, Hd, BACKBONE)               # page in, size the sample
+    per_pass = (time.time() - t0) * V / 2
+    max_passes = 1 if per_pass > seconds else 50     # a cold estimate; the loop below is time-bound
+    t0 = time.time()
     passes = 0
-    while True:
+    while passes < max_passes:
         OM.gvcnn(x, C, P, Hd, G, BACKBONE, num_bins=G)
         passes += 1
-        if time.time() - t0 >= seconds or passes >= 50:
+        if time.time() - t0 >= seconds:
             break
     dt = time.time() - t0
     return {"value": round(passes * V / dt, 2), "unit": "views/s", "cores": torch.get_num_threads(),

@@ -55,6 +55,8 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, residual=None, y_ld
     y2d = torch.full((nb, oh, ow, cout), -55.0, device=DEV) if second else None
     wp = pack_filter(w)
     sc, sh = scale.to(DEV), shift.to(DEV)
+    sc2 = second[0].to(DEV) if second else None          # keep the device copies alive over the launch
+    sh2 = second[1].to(DEV) if second else None
     rd = residual.to(DEV).contiguous() if residual is not None else None
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
@@ -65,8 +67,8 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, residual=None, y_ld
         rc = lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr() + 4 * x_off, wp.data_ptr(), sc.data_ptr(),
                                  sh.data_ptr(), rd.data_ptr() if rd is not None else None,
                                  yd.data_ptr() + 4 * y_off, y2d.data_ptr() if second else None,
-                                 second[0].to(DEV).data_ptr() if second else None,
-                                 second[1].to(DEV).data_ptr() if second else None, st())
+                                 sc2.data_ptr() if second else None,
+                                 sh2.data_ptr() if second else None, st())
     finally:
         lib().gv_conv2d_set_tile_override(-1)
     _lib.check(rc, "gv_conv2d_fwd")
@@ -207,8 +209,9 @@ def test_scale_shift_act_and_gap():
     x = torch.randn(3, 7, 7, 64, generator=g)
     sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
     xd, yd = x.to(DEV), torch.empty(3, 7, 7, 64, device=DEV)
-    _lib.check(lib().gv_scale_shift_act(xd.data_ptr(), 3 * 49, 64, 64, sc.to(DEV).data_ptr(),
-                                        sh.to(DEV).data_ptr(), 1, yd.data_ptr(), 64, _lib.GV_F32, st()), "ssa")
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    _lib.check(lib().gv_scale_shift_act(xd.data_ptr(), 3 * 49, 64, 64, scd.data_ptr(),
+                                        shd.data_ptr(), 1, yd.data_ptr(), 64, _lib.GV_F32, st()), "ssa")
     np.testing.assert_allclose(yd.cpu().numpy(), torch.relu(x * sc + sh).numpy(), rtol=1e-6, atol=1e-6)
     gd = torch.empty(3, 64, device=DEV)
     _lib.check(lib().gv_global_avg_pool(xd.data_ptr(), 3, 49, 64, 64, gd.data_ptr(), _lib.GV_F32, st()), "gap")
@@ -302,8 +305,9 @@ def test_view_score_and_dense():
     bias = torch.randn(V, generator=g)
     rd = raw.reshape(N * V, 16, cr).to(DEV).contiguous()
     r_img = torch.empty(N * V, device=DEV)
-    _lib.check(lib().gv_view_score_partial(rd.data_ptr(), N * V, 16, cr, cr, kern.to(DEV).data_ptr(),
-                                           bias.to(DEV).data_ptr(), V, _lib.GV_ORDER_SHAPE_MAJOR,
+    kd, bd = kern.to(DEV), bias.to(DEV)
+    _lib.check(lib().gv_view_score_partial(rd.data_ptr(), N * V, 16, cr, cr, kd.data_ptr(),
+                                           bd.data_ptr(), V, _lib.GV_ORDER_SHAPE_MAJOR,
                                            r_img.data_ptr(), _lib.GV_F32, st()), "score_partial")
     sc = torch.empty(V, device=DEV)
     _lib.check(lib().gv_view_score_finalize(r_img.data_ptr(), N, V, _lib.GV_ORDER_SHAPE_MAJOR,
@@ -312,8 +316,8 @@ def test_view_score_and_dense():
     np.testing.assert_allclose(sc.cpu().numpy(), np.array(want), rtol=2e-5, atol=1e-6)
     # view-major order gives the same scores
     rd2 = raw.permute(1, 0, 2, 3, 4).reshape(N * V, 16, cr).to(DEV).contiguous()
-    _lib.check(lib().gv_view_score_partial(rd2.data_ptr(), N * V, 16, cr, cr, kern.to(DEV).data_ptr(),
-                                           bias.to(DEV).data_ptr(), V, _lib.GV_ORDER_VIEW_MAJOR,
+    _lib.check(lib().gv_view_score_partial(rd2.data_ptr(), N * V, 16, cr, cr, kd.data_ptr(),
+                                           bd.data_ptr(), V, _lib.GV_ORDER_VIEW_MAJOR,
                                            r_img.data_ptr(), _lib.GV_F32, st()), "score_partial")
     sc2 = torch.empty(V, device=DEV)
     _lib.check(lib().gv_view_score_finalize(r_img.data_ptr(), N, V, _lib.GV_ORDER_VIEW_MAJOR,
@@ -327,6 +331,7 @@ def test_view_score_and_dense():
     x = torch.randn(5, 2048, generator=g)
     Wk, b = torch.randn(2048, 40, generator=g) * 0.02, torch.randn(40, generator=g)
     yd = torch.empty(5, 40, device=DEV)
-    _lib.check(lib().gv_dense_fwd(x.to(DEV).data_ptr(), 5, 2048, Wk.to(DEV).data_ptr(),
-                                  b.to(DEV).data_ptr(), 40, yd.data_ptr(), st()), "dense")
+    xdd, Wd, bdd = x.to(DEV), Wk.to(DEV), b.to(DEV)
+    _lib.check(lib().gv_dense_fwd(xdd.data_ptr(), 5, 2048, Wd.data_ptr(),
+                                  bdd.data_ptr(), 40, yd.data_ptr(), st()), "dense")
     np.testing.assert_allclose(yd.cpu().numpy(), OG.dense(x.numpy(), Wk.numpy(), b.numpy()), rtol=1e-4, atol=1e-4)
