@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
 
 GV_F32, GV_BF16 = 0, 1
-GV_CONV_RELU, GV_CONV_RELU2 = 1, 2
+GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT = 1, 2, 4
 GV_POOL_MAX, GV_POOL_AVG = 0, 1
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
@@ -26,7 +26,7 @@ class GvError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "cin", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
-        "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype")]
+        "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype", "split_col", "tile_cfg")]
 
 
 class PoolDesc(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "gv_plan_num_ops": (C.c_int, [_P]),
     "gv_plan_add_conv": (C.c_int, [_P, C.POINTER(ConvDesc), _I, _L, _I, _L, _I, _L, _L, _I, _L, _I, _L,
                                    _I, _L, _L, _L]),
+    "gv_plan_set_conv_tile": (C.c_int, [_P, _I, _I]),
     "gv_plan_add_pool": (C.c_int, [_P, C.POINTER(PoolDesc), _I, _L, _I, _L]),
     "gv_plan_add_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _L, _I, _L, _L, _I, _L]),
     "gv_plan_run": (C.c_int, [_P, C.POINTER(_P), _I, _P]),
@@ -71,6 +72,7 @@ SIGNATURES = {
 # tuning hooks (exported, not part of the drop-in surface)
 TUNING = {
     "gv_conv2d_set_tile_override": (None, [C.c_int]),
+    "gv_conv2d_set_debug": (None, [C.c_int]),
     "gv_conv2d_num_tile_cfgs": (C.c_int, []),
 }
 

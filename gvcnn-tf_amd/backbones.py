@@ -124,6 +124,42 @@ class BackbonePlan:
         self._ss_cache[key] = (so, ho)
         return so, ho
 
+    def conv_siblings(self, x, branches, first_out, norm, relu=True):
+        """Several 1x1/stride-1 slim.conv2d that read the SAME input, as ONE implicit GEMM over their
+        concatenated filters (GV_CONV_SPLIT): the first branch's columns land in `first_out` (a slice
+        of the block's concat buffer), the others side by side in one scratch tensor whose channel
+        slices are returned.  branches = [(scope, cout), ...] in reference order."""
+        couts = [c for _, c in branches]
+        total = sum(couts)
+        rest = total - couts[0]
+        assert (first_out.nb, first_out.h, first_out.w, first_out.c) == (x.nb, x.h, x.w, couts[0])
+        n_each = [int(self.lib.gv_packed_filter_elems(1, 1, x.c, c)) for c in couts]
+        w_off = self.w_elems
+        off = w_off
+        for (scope, c), n in zip(branches, n_each):
+            self.filters.append((scope + "/weights", 1, 1, x.c, c, off))
+            off += n
+        self.w_elems = (off + 63) // 64 * 64
+        cpad = (total + 3) // 4 * 4
+        so, ho = self.ss_elems, self.ss_elems + cpad
+        self.ss_elems += 2 * cpad
+        cum = 0
+        for scope, c in branches:
+            self.ss_specs.append(("bn", scope + "/BatchNorm", c, norm[1], norm[2], so + cum, ho + cum))
+            cum += c
+        scratch = self.new_tensor(x.nb, x.h, x.w, rest)
+        self.ops.append(dict(kind="conv", name="+".join(sc for sc, _ in branches), x=x, y=first_out,
+                             y2=scratch, res=None, w_off=w_off, scale_off=so, shift_off=ho,
+                             scale2_off=0, shift2_off=0, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+                             relu=relu, split=couts[0], cout=total,
+                             flops=2.0 * x.npix * total * x.c,
+                             bytes=4.0 * (x.npix * x.c + x.c * total + x.npix * total)))
+        outs, lo = [], 0
+        for c in couts[1:]:
+            outs.append(scratch.channels(lo, lo + c))
+            lo += c
+        return outs
+
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
              residual=None, next_preact=None):
         """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
@@ -150,6 +186,7 @@ class BackbonePlan:
         self.ops.append(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
+                             split=0, cout=cout,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
                              bytes=4.0 * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout)))
         return (out, y2) if next_preact is not None else out
@@ -235,11 +272,16 @@ class BackbonePlan:
             ys, yo = ref(y)
             if op["kind"] == "conv":
                 y2, res = op["y2"], op["res"]
-                flags = (_lib.GV_CONV_RELU if op["relu"] else 0) | (_lib.GV_CONV_RELU2 if y2 is not None else 0)
+                split = op["split"]
+                flags = _lib.GV_CONV_RELU if op["relu"] else 0
+                if split:
+                    flags |= _lib.GV_CONV_SPLIT
+                elif y2 is not None:
+                    flags |= _lib.GV_CONV_RELU2
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
-                                  op["pad_t"], op["pad_l"], y.h, y.w, y.c, y.ld,
+                                  op["pad_t"], op["pad_l"], y.h, y.w, op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
-                                  flags, self.dtype)
+                                  flags, self.dtype, split, op.get("tile", 0))
                 rs, ro = ref(res)
                 y2s, y2o = ref(y2)
                 _lib.check(lib.gv_plan_add_conv(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"],
@@ -338,6 +380,36 @@ class BackbonePlan:
         _lib.check(self.lib.gv_plan_run_range(self._plan, first, count, ptrs, len(self._bufs),
                                               _stream_ptr(stream)), "gv_plan_run_range")
 
+    def autotune(self, x, iters=3, verbose=False):
+        """Pick, per conv launch, the fastest tile configuration by timing each on this device with
+        the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
+        chain sums k in the same order under every configuration, so results are bitwise unchanged."""
+        lib = self.lib
+        ncfg = lib.gv_conv2d_num_tile_cfgs()
+        self.run(x)
+        chosen = {}
+        try:
+            for i, op in enumerate(self.ops):
+                if op["kind"] != "conv":
+                    continue
+                best, best_ms = 0, float("inf")
+                for t in range(ncfg):
+                    lib.gv_conv2d_set_tile_override(t)
+                    try:
+                        ms = self.time_range(x, i, 1, iters)
+                    except _lib.GvError:
+                        continue
+                    if ms < best_ms:
+                        best, best_ms = t, ms
+                op["tile"] = best + 1
+                chosen[op["name"]] = (best, best_ms)
+                _lib.check(lib.gv_plan_set_conv_tile(self._plan, i, best + 1), "gv_plan_set_conv_tile")
+                if verbose:
+                    print("autotune %-60s cfg %2d  %.4f ms" % (op["name"][-60:], best, best_ms))
+        finally:
+            lib.gv_conv2d_set_tile_override(-1)
+        return chosen
+
     def time_range(self, x, first, count, iters, stream=None):
         """Average ms of ops [first, first+count) via hipEvents on the launch stream."""
         ptrs = self._ptr_table(x)
@@ -371,7 +443,8 @@ def _stream_ptr(stream):
 # Inception-v3 base — nets/inception_v3.py:93-410 under inception_arg_scope (inception_utils.py:52-78):
 # every conv = conv(no bias) -> BN(no gamma, eps 1e-3) -> ReLU.
 # ------------------------------------------------------------------------------------------------
-def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c"), scope="InceptionV3"):
+def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c"), scope="InceptionV3",
+                       fuse_siblings=True):
     if final_endpoint not in INCEPTION_ENDPOINTS:
         raise ValueError("Unknown final endpoint %s" % final_endpoint)       # inception_v3.py:410
     BN = ("bn", INCEPTION_BN_EPS, False)
@@ -379,6 +452,17 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
 
     def conv(x, name, cout, k, stride=1, padding="SAME", out=None):
         return b.conv(x, scope + "/" + name, cout, k, stride, padding, out=out, norm=BN, relu=True)
+
+    def siblings(x, branches, first_out):
+        """The 1x1 convs of one block that read the block input (e.g. inception_v3.py:140,142,146)."""
+        if not fuse_siblings:
+            outs = []
+            for i, (name, c) in enumerate(branches):
+                t = conv(x, name, c, 1, out=first_out if i == 0 else None)
+                if i:
+                    outs.append(t)
+            return outs
+        return b.conv_siblings(x, [(scope + "/" + n, c) for n, c in branches], first_out, BN)
 
     def done(name, t):
         b.end_points[name] = t
@@ -404,11 +488,10 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     def mixed5(x, name, b1a, b1b, pool_depth):                  # inception_v3.py:137-204
         s = name + "/"
         out = b.new_tensor(x.nb, x.h, x.w, 64 + 64 + 96 + pool_depth)
-        conv(x, s + "Branch_0/Conv2d_0a_1x1", 64, 1, out=out.channels(0, 64))
-        t = conv(x, s + "Branch_1/" + b1a, 48, 1)
-        conv(t, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
-        t = conv(x, s + "Branch_2/Conv2d_0a_1x1", 64, 1)
-        t = conv(t, s + "Branch_2/Conv2d_0b_3x3", 96, 3)
+        t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 64), (s + "Branch_1/" + b1a, 48),
+                              (s + "Branch_2/Conv2d_0a_1x1", 64)], out.channels(0, 64))
+        conv(t1, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
+        t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 96, 3)
         conv(t, s + "Branch_2/Conv2d_0c_3x3", 96, 3, out=out.channels(128, 224))
         t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
         conv(t, s + "Branch_3/Conv2d_0b_1x1", pool_depth, 1, out=out.channels(224, 224 + pool_depth))
@@ -437,12 +520,11 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     def mixed6(x, name, d):                                     # inception_v3.py:226-338
         s = name + "/"
         out = b.new_tensor(x.nb, x.h, x.w, 768)
-        conv(x, s + "Branch_0/Conv2d_0a_1x1", 192, 1, out=out.channels(0, 192))
-        t = conv(x, s + "Branch_1/Conv2d_0a_1x1", d, 1)
-        t = conv(t, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
+        t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 192), (s + "Branch_1/Conv2d_0a_1x1", d),
+                              (s + "Branch_2/Conv2d_0a_1x1", d)], out.channels(0, 192))
+        t = conv(t1, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
         conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), out=out.channels(192, 384))
-        t = conv(x, s + "Branch_2/Conv2d_0a_1x1", d, 1)
-        t = conv(t, s + "Branch_2/Conv2d_0b_7x1", d, (7, 1))
+        t = conv(t2, s + "Branch_2/Conv2d_0b_7x1", d, (7, 1))
         t = conv(t, s + "Branch_2/Conv2d_0c_1x7", d, (1, 7))
         t = conv(t, s + "Branch_2/Conv2d_0d_7x1", d, (7, 1))
         conv(t, s + "Branch_2/Conv2d_0e_1x7", 192, (1, 7), out=out.channels(384, 576))
@@ -472,12 +554,11 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     def mixed7(x, name, b1_3x1, b2_names):                      # inception_v3.py:362-409
         s = name + "/"
         out = b.new_tensor(x.nb, x.h, x.w, 2048)
-        conv(x, s + "Branch_0/Conv2d_0a_1x1", 320, 1, out=out.channels(0, 320))
-        t = conv(x, s + "Branch_1/Conv2d_0a_1x1", 384, 1)
-        conv(t, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
-        conv(t, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
-        t = conv(x, s + "Branch_2/Conv2d_0a_1x1", 448, 1)
-        t = conv(t, s + "Branch_2/Conv2d_0b_3x3", 384, 3)
+        t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 320), (s + "Branch_1/Conv2d_0a_1x1", 384),
+                              (s + "Branch_2/Conv2d_0a_1x1", 448)], out.channels(0, 320))
+        conv(t1, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
+        conv(t1, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
+        t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 384, 3)
         conv(t, s + "Branch_2/" + b2_names[0], 384, (1, 3), out=out.channels(1088, 1472))
         conv(t, s + "Branch_2/" + b2_names[1], 384, (3, 1), out=out.channels(1472, 1856))
         t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")

@@ -8,19 +8,25 @@
 // nets/resnet_v2.py:79-91, nets/resnet_utils.py:94-105.
 //
 // Kernel structure (one workgroup = 4 waves = 256 threads, wave64):
-//   * block tile BM x BN, K-step 16; wave tile (TM x TN) MFMA tiles of 32x32 on
-//     v_mfma_f32_32x32x2_f32 (exact fp32: bit-for-bit a k-ordered fmaf chain);
-//   * A and B k-tiles are staged global -> registers -> LDS (issue-early / write-late: the
-//     next tile's global loads are in flight while the current tile is multiplied), LDS is
-//     double buffered, one barrier per k-tile;
-//   * LDS image is [row][16 + 4 pad] fp32 (80-byte rows): 16-byte ds_write_b128 from the loader,
-//     conflict-free ds_read_b128 by the MFMA lanes (row stride 20 dwords = 5 x 16 B, 5 odd).
-//     Lane (i = lane&31, h = lane>>5) reads 16-byte chunks {h, h+2} of its row, so one read feeds
-//     four MFMAs; A and B use the SAME k permutation, which leaves the sum over k unchanged;
+//   * block tile BM x BN, k-tile = NCH chunks of 16 (BK = 16 or 32); wave tile (TM x TN) MFMA tiles
+//     of 32x32 on v_mfma_f32_32x32x2_f32 (exact fp32: bit-for-bit a k-ordered fmaf chain, so every
+//     tile configuration returns bitwise the same result);
+//   * a 16-channel chunk never straddles a filter tap (every cin on the path except the 3-channel
+//     stems is a multiple of 16), so the gather is one 16-byte load per lane per chunk quarter with a
+//     wave-uniform (r, s, c) position per chunk;
+//   * A and B k-tiles are staged global -> registers -> LDS (issue-early / write-late: the next
+//     tile's global loads are in flight while the current tile is multiplied), LDS double buffered,
+//     one barrier per k-tile;
+//   * LDS image is [row][BK + 4 pad] fp32 (80- or 144-byte rows: an odd number of 16-byte slots):
+//     16-byte ds_write_b128 from the loader, conflict-free ds_read_b128 by the MFMA lanes.
+//     Lane (i = lane&31, h = lane>>5) reads 16-byte slots {h, h+2, ...} of its row, so one read
+//     feeds four MFMAs; A and B use the SAME k permutation, which leaves each MFMA's k pair intact;
 //   * epilogue straight from the accumulators: y = act(acc*scale[c] + shift[c] (+ residual)),
 //     written at a channel offset of a wider (concat) buffer through y_ld — this is what removes
-//     the tf.concat copies of nets/inception_v3.py:155,...; optional second output
-//     y2 = act2(v*scale2 + shift2) (the next ResNet unit's pre-activation, nets/resnet_v2.py:75);
+//     the tf.concat copies of nets/inception_v3.py:155,...; the second destination y2 is either
+//     a second activation of the same value (next ResNet unit's pre-activation,
+//     nets/resnet_v2.py:75) or, with GV_CONV_SPLIT, the home of output columns >= split_col, so
+//     sibling 1x1 convs that read the same input run as ONE GEMM (input read once);
 //   * 1-D grid, n-tiles fastest, remapped so that each XCD (private L2) gets a contiguous chunk
 //     of tile ids: the n-tiles that re-read one A panel run on one L2.
 #include "gv_common.h"
@@ -41,20 +47,25 @@ struct ConvArgs {
     int kh, kw, stride, pad_t, pad_l;
     int oh, ow, cout, y_ld, res_ld, y2_ld;
     int M, K, Kpad, ktiles;
-    int relu, relu2;
+    int relu, relu2, split;     // split > 0: columns >= split go to y2 (same scale/shift/relu)
     int tiles_n;
+    int dbg;                    // ablation bits (timing experiments only): 1 no global loads after tile 0,
+                                // 2 no LDS writes/barriers after tile 0, 4 no epilogue stores
 };
 
-constexpr int BK = 16;       // k-tile depth (fp32 elements); every cin on the path except 3 is a multiple
-constexpr int LDS_LD = 20;   // padded LDS row length in floats (80 B)
+constexpr int CH = 16;        // channels per chunk (fp32)
+constexpr int KPAD_ALIGN = 32;
 
-template <int WM, int WN, int TM, int TN, bool GENERIC>
+template <int WM, int WN, int TM, int TN, int NCH, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int A_LOADS = (BM * 4 + 255) / 256;
-    constexpr int B_LOADS = (BN * 4 + 255) / 256;
+    constexpr int BKT = CH * NCH;              // k-tile depth
+    constexpr int LDS_LD = BKT + 4;            // padded row (floats): (BKT+4)/4 is odd
+    constexpr int QPR = BKT / 4;               // 16-byte quarters per row
+    constexpr int A_LOADS = (BM * QPR + 255) / 256;
+    constexpr int B_LOADS = (BN * QPR + 255) / 256;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                        // [2][BM][LDS_LD]
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int idx = tid + i * 256;
-        const int row = idx >> 2;
+        const int row = idx / QPR;
         const int m = m0 + row;
         if (row < BM && m < a.M) {
             const int n = m / ohow;
@@ -99,26 +110,47 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int idx = tid + i * 256;
-        const int row = idx >> 2;
+        const int row = idx / QPR;
         const int n = n0 + row;
         b_ok[i] = (row < BN) && (n < a.cout);
-        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * (idx & 3);
+        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * (idx % QPR);
     }
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
-    int fr = 0, fs = 0, fc = 0;               // filter tap (r, s) and channel base of the current k-tile
+    // wave-uniform position of each 16-channel chunk of the NEXT tile to load: filter tap (r, s),
+    // channel base c, and whether the chunk lies below K (the zero padding of Kpad is skipped)
+    int fr[NCH], fs[NCH], fc[NCH];
+    auto step_chunk = [&](int& r, int& s, int& c) {
+        c += CH;
+        if (c >= a.cin) {
+            c = 0;
+            if (++s == a.kw) { s = 0; ++r; }
+        }
+    };
+    if constexpr (!GENERIC) {
+        fr[0] = fs[0] = fc[0] = 0;
+#pragma unroll
+        for (int j = 1; j < NCH; ++j) {
+            fr[j] = fr[j - 1]; fs[j] = fs[j - 1]; fc[j] = fc[j - 1];
+            step_chunk(fr[j], fs[j], fc[j]);
+        }
+    }
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int kq = (tid + i * 256) & 3;
+            const int kq = (tid + i * 256) % QPR;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (!GENERIC) {
-                const int iy = a_iy0[i] + fr;
-                const int ix = a_ix0[i] + fs;
-                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) {
-                    const float* p = a.x + ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + fc + 4 * kq;
+                int r = fr[0], s = fs[0], c = fc[0];
+                if constexpr (NCH == 2) {
+                    if (kq >= 4) { r = fr[1]; s = fs[1]; c = fc[1]; }
+                }
+                const int iy = a_iy0[i] + r;
+                const int ix = a_ix0[i] + s;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw && r < a.kh) {
+                    const float* p = a.x + ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + c + 4 * (kq & 3);
                     v = *reinterpret_cast<const f32x4*>(p);
                 }
             } else {
@@ -146,25 +178,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
             rb[i] = v;
         }
     };
-    auto advance_tap = [&]() {                 // (r, s, c) of the next k-tile; cin % 16 == 0 here
-        fc += BK;
-        if (fc >= a.cin) {
-            fc = 0;
-            if (++fs == a.kw) { fs = 0; ++fr; }
+    auto advance_taps = [&]() {
+        if constexpr (!GENERIC) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int t = 0; t < NCH; ++t) step_chunk(fr[j], fs[j], fc[j]);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int idx = tid + i * 256;
-            if (A_LOADS * 256 == BM * 4 || idx < BM * 4)
-                *reinterpret_cast<f32x4*>(sA + buf * BM * LDS_LD + (idx >> 2) * LDS_LD + 4 * (idx & 3)) = ra[i];
+            if (A_LOADS * 256 == BM * QPR || idx < BM * QPR)
+                *reinterpret_cast<f32x4*>(sA + buf * BM * LDS_LD + (idx / QPR) * LDS_LD + 4 * (idx % QPR)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + i * 256;
-            if (B_LOADS * 256 == BN * 4 || idx < BN * 4)
-                *reinterpret_cast<f32x4*>(sB + buf * BN * LDS_LD + (idx >> 2) * LDS_LD + 4 * (idx & 3)) = rb[i];
+            if (B_LOADS * 256 == BN * QPR || idx < BN * QPR)
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDS_LD + (idx / QPR) * LDS_LD + 4 * (idx % QPR)) = rb[i];
         }
     };
 
@@ -185,14 +218,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < a.ktiles; ++kt) {
-        const int buf = kt & 1;
+        const int buf = (a.dbg & 2) ? 0 : (kt & 1);
         const bool more = (kt + 1 < a.ktiles);
         if (more) {
-            if constexpr (!GENERIC) advance_tap();
-            load_tile(kt + 1);
+            advance_taps();
+            if (!(a.dbg & 1)) load_tile(kt + 1);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 2 * NCH; ++q) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -208,11 +241,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
+        if (!(a.dbg & 2)) {
+            if (more) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
+    if (a.dbg & 4) {
+        // keep the accumulators live without storing the tile
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 1.2345e-30f) a.y[0] = t;
+        return;
+    }
     const int col_l = lane & 31;
     const int row_h = 4 * (lane >> 5);
 #pragma unroll
@@ -220,8 +267,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
         const int col = n0 + (wn * TN + j) * 32 + col_l;
         if (col >= a.cout) continue;
         const float sc = a.scale[col], sh = a.shift[col];
+        const bool to_second = a.split > 0 && col >= a.split;
+        const bool dual = a.y2 != nullptr && a.split == 0;
         float sc2 = 0.f, sh2 = 0.f;
-        if (a.y2) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
+        if (dual) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
+        float* ybase = to_second ? a.y2 + (col - a.split) : a.y + col;
+        const int yld = to_second ? a.y2_ld : a.y_ld;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rbase = m0 + (wm * TM + i) * 32 + row_h;
@@ -231,13 +282,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] * sc + sh;
                 if (a.res) v += a.res[(size_t)m * a.res_ld + col];
-                if (a.y2) {
+                if (dual) {
                     float v2 = v * sc2 + sh2;
                     if (a.relu2) v2 = fmaxf(v2, 0.f);
                     a.y2[(size_t)m * a.y2_ld + col] = v2;
                 }
                 if (a.relu) v = fmaxf(v, 0.f);
-                a.y[(size_t)m * a.y_ld + col] = v;
+                ybase[(size_t)m * yld] = v;
             }
         }
     }
@@ -254,58 +305,92 @@ __global__ void pack_filter_hwio_f32(const float* __restrict__ w, int K, int Kpa
 }
 
 int g_tile_override = -1;   // tuning hook: force a tile configuration (see gv_conv2d_set_tile_override)
+int g_debug = 0;            // ablation bits, see ConvArgs::dbg
 
-struct TileCfg { int bm, bn; };
-constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {128, 96}, {128, 32}, {64, 64}, {64, 128}};
+struct TileCfg { int bm, bn, nch; };
+constexpr TileCfg kTiles[] = {{128, 128, 1}, {128, 64, 1}, {128, 96, 1}, {128, 32, 1}, {64, 64, 1}, {64, 128, 1},
+                              {128, 128, 2}, {128, 64, 2}, {128, 96, 2}, {128, 32, 2}, {64, 64, 2}, {64, 128, 2}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NCH>
 int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     ConvArgs a = a0;
     a.tiles_n = gv_ceil_div(a.cout, BN);
+    a.ktiles = a.Kpad / (CH * NCH);
     const int tiles_m = gv_ceil_div(a.M, BM);
     const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * BM + 2 * BN) * LDS_LD * sizeof(float);
-    if (generic)
-        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, false>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    const size_t lds = (size_t)(2 * BM + 2 * BN) * (CH * NCH + 4) * sizeof(float);
+    if constexpr (NCH == 1) {
+        if (generic) {
+            hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, 1, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+            GV_LAUNCH_CHECK();
+            return GV_OK;
+        }
+    }
+    if (lds > 64 * 1024) {
+        static bool once = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, NCH, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        }();
+        if (!once) return GV_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, NCH, false>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
 
-int pick_tile(int M, int N) {
-    if (g_tile_override >= 0 && g_tile_override < kNumTiles) return g_tile_override;
-    // least padded N first, then the larger tile (fewer re-reads of the A panel)
-    int best = 0;
+int launch_tile(int cfg, const ConvArgs& a, bool generic, hipStream_t st) {
+    if (generic && cfg >= 6) cfg -= 6;     // the scalar-gather loader exists for 16-deep k-tiles only
+    switch (cfg) {
+        case 0: return launch_cfg<2, 2, 2, 2, 1>(a, generic, st);
+        case 1: return launch_cfg<2, 2, 2, 1, 1>(a, generic, st);
+        case 2: return launch_cfg<4, 1, 1, 3, 1>(a, generic, st);
+        case 3: return launch_cfg<4, 1, 1, 1, 1>(a, generic, st);
+        case 4: return launch_cfg<2, 2, 1, 1, 1>(a, generic, st);
+        case 5: return launch_cfg<2, 2, 1, 2, 1>(a, generic, st);
+        case 6: return launch_cfg<2, 2, 2, 2, 2>(a, generic, st);
+        case 7: return launch_cfg<2, 2, 2, 1, 2>(a, generic, st);
+        case 8: return launch_cfg<4, 1, 1, 3, 2>(a, generic, st);
+        case 9: return launch_cfg<4, 1, 1, 1, 2>(a, generic, st);
+        case 10: return launch_cfg<2, 2, 1, 1, 2>(a, generic, st);
+        case 11: return launch_cfg<2, 2, 1, 2, 2>(a, generic, st);
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+// Default choice when the descriptor does not name a tile (plans normally carry a measured one):
+// least padded N first, then the larger tile (fewer re-reads of the A panel).
+int pick_tile(int M, int N, int K) {
+    int best = 1;
     double best_cost = 1e30;
-    const int order[] = {0, 2, 1, 3};                 // 128x{128,96,64,32}
-    const double pen[] = {1.00, 1.02, 1.05, 1.15};
+    const int order[] = {0, 2, 1, 3};                 // 128 x {128, 96, 64, 32}
+    const double pen[] = {1.00, 1.00, 1.03, 1.10};
     for (int t = 0; t < 4; ++t) {
         const int bn = kTiles[order[t]].bn;
         const double cost = (double)gv_ceil_div(N, bn) * bn * pen[t];
         if (cost < best_cost) { best_cost = cost; best = order[t]; }
     }
-    // small problems: halve BM so the grid still covers the chip
     const int64_t blocks = (int64_t)gv_ceil_div(M, 128) * gv_ceil_div(N, kTiles[best].bn);
-    if (blocks < 512) {
-        if (kTiles[best].bn == 128) return 5;
-        if (kTiles[best].bn == 64) return 4;
+    if (blocks < 1024) {                              // small problems: halve BM so the grid covers the chip
+        if (kTiles[best].bn == 128) best = 5;
+        else if (kTiles[best].bn == 64) best = 4;
     }
+    if (K >= 64) best += 6;                           // 32-deep k-tiles: half the barriers
     return best;
 }
 
 }  // namespace
 
 extern "C" void gv_conv2d_set_tile_override(int cfg) { g_tile_override = cfg; }
+extern "C" void gv_conv2d_set_debug(int bits) { g_debug = bits; }
 extern "C" int gv_conv2d_num_tile_cfgs(void) { return kNumTiles; }
 
 extern "C" int64_t gv_packed_filter_elems(int32_t kh, int32_t kw, int32_t cin, int32_t cout) {
     if (kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
     const int64_t K = (int64_t)kh * kw * cin;
-    return (int64_t)cout * ((K + BK - 1) / BK * BK);
+    return (int64_t)cout * ((K + KPAD_ALIGN - 1) / KPAD_ALIGN * KPAD_ALIGN);
 }
 
 extern "C" int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin,
@@ -313,7 +398,7 @@ extern "C" int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, 
     if (!w_hwio || !w_packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
     if (dtype != GV_F32) return GV_E_UNSUPPORTED;
     const int K = kh * kw * cin;
-    const int Kpad = (K + BK - 1) / BK * BK;
+    const int Kpad = (K + KPAD_ALIGN - 1) / KPAD_ALIGN * KPAD_ALIGN;
     const int64_t total = (int64_t)cout * Kpad;
     hipLaunchKernelGGL(pack_filter_hwio_f32, dim3((unsigned)gv_ceil_div(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, w_hwio, K, Kpad, cout, (float*)w_packed);
@@ -329,13 +414,21 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 ||
         d->kw <= 0 || d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
         return GV_E_BADARG;
-    if (d->x_ld < d->cin || d->y_ld < d->cout) return GV_E_BADARG;
+    const bool split = (d->flags & GV_CONV_SPLIT) != 0;
+    if (split) {
+        if (!y2 || d->split_col <= 0 || d->split_col >= d->cout) return GV_E_BADARG;
+        if (d->y_ld < d->split_col || d->y2_ld < d->cout - d->split_col) return GV_E_BADARG;
+    } else {
+        if (d->y_ld < d->cout) return GV_E_BADARG;
+        if (y2 && (!scale2 || !shift2 || d->y2_ld < d->cout)) return GV_E_BADARG;
+    }
+    if (d->x_ld < d->cin) return GV_E_BADARG;
     if (residual && d->res_ld < d->cout) return GV_E_BADARG;
-    if (y2 && (!scale2 || !shift2 || d->y2_ld < d->cout)) return GV_E_BADARG;
     // the window of the last output must start inside the padded input
     if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
         return GV_E_BADARG;
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (d->tile_cfg < 0 || d->tile_cfg > kNumTiles) return GV_E_BADARG;
     const int64_t M64 = (int64_t)d->nb * d->oh * d->ow;
     if (M64 > 0x7fffffff || (int64_t)d->nb * d->ih * d->iw > 0x7fffffff) return GV_E_UNSUPPORTED;
     if (!gv_aligned16(w_packed)) return GV_E_ALIGN;
@@ -348,24 +441,20 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.oh = d->oh; a.ow = d->ow; a.cout = d->cout; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
     a.y2_ld = d->y2_ld;
-    a.M = (int)M64; a.K = d->kh * d->kw * d->cin; a.Kpad = (a.K + BK - 1) / BK * BK;
-    a.ktiles = a.Kpad / BK;
+    a.M = (int)M64; a.K = d->kh * d->kw * d->cin;
+    a.Kpad = (a.K + KPAD_ALIGN - 1) / KPAD_ALIGN * KPAD_ALIGN;
+    a.ktiles = 0;
     a.relu = (d->flags & GV_CONV_RELU) ? 1 : 0;
     a.relu2 = (d->flags & GV_CONV_RELU2) ? 1 : 0;
+    a.split = split ? d->split_col : 0;
     a.tiles_n = 0;
+    a.dbg = g_debug;
 
-    // vector loader needs 16-channel k-tiles inside one filter tap and 16-byte aligned pixels
-    const bool generic = (d->cin % BK != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
-    hipStream_t st = (hipStream_t)stream;
-    switch (pick_tile(a.M, a.cout)) {
-        case 0: return launch_cfg<2, 2, 2, 2>(a, generic, st);
-        case 1: return launch_cfg<2, 2, 2, 1>(a, generic, st);
-        case 2: return launch_cfg<4, 1, 1, 3>(a, generic, st);
-        case 3: return launch_cfg<4, 1, 1, 1>(a, generic, st);
-        case 4: return launch_cfg<2, 2, 1, 1>(a, generic, st);
-        case 5: return launch_cfg<2, 2, 1, 2>(a, generic, st);
-    }
-    return GV_E_UNSUPPORTED;
+    // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
+    const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
+    int cfg = g_tile_override >= 0 && g_tile_override < kNumTiles ? g_tile_override
+              : (d->tile_cfg > 0 ? d->tile_cfg - 1 : pick_tile(a.M, a.cout, a.K));
+    return launch_tile(cfg, a, generic, (hipStream_t)stream);
 }
 
 extern "C" int gv_conv2d_time(const gv_conv_desc* d, const void* x, const void* w_packed,

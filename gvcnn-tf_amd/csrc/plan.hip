@@ -125,6 +125,15 @@ extern "C" int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d, int32_t x_slo
     return GV_OK;
 }
 
+extern "C" int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg) {
+    if (!p) return GV_E_PLAN;
+    if (op_index < 0 || (size_t)op_index >= p->ops.size() || tile_cfg < 0) return GV_E_BADARG;
+    Op& o = p->ops[(size_t)op_index];
+    if (o.kind != OP_CONV) return GV_E_BADARG;
+    o.conv.tile_cfg = tile_cfg;
+    return GV_OK;
+}
+
 extern "C" int gv_plan_add_pool(gv_plan* p, const gv_pool_desc* d, int32_t x_slot, int64_t x_off,
                                 int32_t y_slot, int64_t y_off) {
     if (!p) return GV_E_PLAN;

@@ -43,6 +43,8 @@ extern "C" {
 /* gv_conv_desc.flags */
 #define GV_CONV_RELU 1        /* ReLU after scale/shift(/residual)   */
 #define GV_CONV_RELU2 2       /* ReLU on the second output           */
+#define GV_CONV_SPLIT 4       /* y2 is not a second activation but the destination of output
+                                 columns >= split_col (sibling convs fused into one GEMM) */
 
 /* pooling modes */
 #define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
@@ -71,6 +73,10 @@ typedef struct gv_conv_desc {
     int32_t y2_ld;             /* pixel stride of the optional second output */
     int32_t flags;             /* GV_CONV_* */
     int32_t dtype;             /* GV_F32 | GV_BF16: type of x, w_packed, residual, y, y2 */
+    int32_t split_col;         /* GV_CONV_SPLIT: columns [0,split_col) -> y, [split_col,cout) -> y2 at
+                                  column (c - split_col), pixel stride y2_ld; same scale/shift/act */
+    int32_t tile_cfg;          /* 0 = library heuristic; k >= 1 = tile configuration k-1 (a speed choice
+                                  only: every configuration returns bitwise the same result) */
 } gv_conv_desc;
 
 typedef struct gv_pool_desc {
@@ -90,7 +96,7 @@ const char* gv_error_string(int code);
 
 /* ---- filters ------------------------------------------------------------
  * Packed filter layout consumed by gv_conv2d_fwd: [cout][Kpad], k = (r*kw+s)*cin + c,
- * Kpad = K rounded up to 16, zero filled.  Source is TensorFlow's HWIO
+ * Kpad = K rounded up to 32, zero filled.  Source is TensorFlow's HWIO
  * [kh,kw,cin,cout] fp32 variable (slim `.../weights`). */
 int64_t gv_packed_filter_elems(int32_t kh, int32_t kw, int32_t cin, int32_t cout);
 int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin, int32_t cout,
@@ -99,6 +105,9 @@ int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin
 /* ---- convolution ---------------------------------------------------------
  * y  = act( conv(x, w) * scale[c] + shift[c] (+ residual) )
  * y2 = act2( (that pre-activation value) * scale2[c] + shift2[c] )       (optional)
+ * or, with GV_CONV_SPLIT, y receives columns [0, split_col) and y2 columns [split_col, cout): the
+ * 1x1 convs of one Inception block that read the same input (nets/inception_v3.py:140-146,...)
+ * run as one GEMM over their concatenated filters and the input is read once.
  *
  * Replaces slim.conv2d (+ slim.batch_norm + ReLU, folded into scale/shift) at
  * nets/inception_v3.py:97-405 (94 call sites), nets/resnet_v2.py:79-89,
@@ -184,6 +193,8 @@ int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d,
                      int32_t ss_slot, int64_t scale_off, int64_t shift_off,
                      int32_t res_slot, int64_t res_off, int32_t y_slot, int64_t y_off,
                      int32_t y2_slot, int64_t y2_off, int64_t scale2_off, int64_t shift2_off);
+/* Set gv_conv_desc.tile_cfg of conv op `op_index` (plan-time autotuning; speed only). */
+int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg);
 int gv_plan_add_pool(gv_plan* p, const gv_pool_desc* d, int32_t x_slot, int64_t x_off,
                      int32_t y_slot, int64_t y_off);
 int gv_plan_add_scale_shift_act(gv_plan* p, int64_t npix, int32_t c, int32_t x_ld, int32_t y_ld,

@@ -60,7 +60,7 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, residual=None, y_ld
     rd = residual.to(DEV).contiguous() if residual is not None else None
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
-                      cout if residual is not None else 0, cout if second else 0, flags, _lib.GV_F32)
+                      cout if residual is not None else 0, cout if second else 0, flags, _lib.GV_F32, 0, 0)
     if tile is not None:
         lib().gv_conv2d_set_tile_override(tile)
     try:
@@ -125,7 +125,7 @@ def test_conv_combos_vs_oracle(k, stride, padding, cin, cout):
     np.testing.assert_allclose(y, ref.numpy(), rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", list(range(12)))
 @pytest.mark.parametrize("cout", [32, 48, 80, 192, 200])
 def test_conv_every_tile_config(tile, cout):
     """All tile shapes give the same answer, incl. ragged M and N not a multiple of 32."""
@@ -136,6 +136,55 @@ def test_conv_every_tile_config(tile, cout):
     ref = oracle_conv(x, w, 1, "SAME", scale, shift, False)
     y = run_conv(x, w, 1, (1, 1), (13, 11), scale, shift, False, tile=tile)
     np.testing.assert_allclose(y, ref.numpy(), rtol=2e-4, atol=2e-4)
+    # fp32 MFMA sums k in the same order under every configuration: bitwise identical results
+    y0 = run_conv(x, w, 1, (1, 1), (13, 11), scale, shift, False, tile=1)
+    np.testing.assert_array_equal(y, y0)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 7, 8, 10])
+@pytest.mark.parametrize("cin", [48, 80, 96])
+def test_conv_deep_ktile_tap_straddle(tile, cin):
+    """32-deep k-tiles hold two 16-channel chunks that may sit on different filter taps (cin=48, 80)
+    and K that is not a multiple of 32 leaves a zero chunk at the end."""
+    g = torch.Generator().manual_seed(tile * 10 + cin)
+    x = torch.randn(2, 10, 9, cin, generator=g)
+    w = torch.randn(5, 5, cin, 64, generator=g) * 0.03
+    scale, shift = torch.ones(64), torch.zeros(64)
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, True)
+    y = run_conv(x, w, 1, (2, 2), (10, 9), scale, shift, True, tile=tile)
+    np.testing.assert_allclose(y, ref.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_conv_split_output_fused_siblings():
+    """GV_CONV_SPLIT: three sibling 1x1 convs as one GEMM; first goes to a concat slice, the rest to
+    a scratch tensor (nets/inception_v3.py:140-146)."""
+    g = torch.Generator().manual_seed(21)
+    nb, h, wd, cin = 2, 7, 9, 64
+    couts = [64, 48, 96]
+    total = sum(couts)
+    x = torch.randn(nb, h, wd, cin, generator=g)
+    ws = [torch.randn(1, 1, cin, c, generator=g) * 0.1 for c in couts]
+    scale = torch.rand(total, generator=g) + 0.5
+    shift = torch.randn(total, generator=g) * 0.1
+    wcat = torch.cat(ws, dim=3)
+    ref = oracle_conv(x, wcat, 1, "SAME", scale, shift, True).numpy()
+    xd = x.to(DEV)
+    wp = pack_filter(wcat)
+    # packing the three filters separately and back to back gives the same packed image
+    parts = torch.cat([pack_filter(wi) for wi in ws])
+    assert torch.equal(parts, wp)
+    yd = torch.full((nb, h, wd, 256), -7.0, device=DEV)
+    y2d = torch.full((nb, h, wd, total - couts[0]), -5.0, device=DEV)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    d = _lib.ConvDesc(nb, h, wd, cin, cin, 1, 1, 1, 0, 0, h, wd, total, 256, 0, total - couts[0],
+                      _lib.GV_CONV_RELU | _lib.GV_CONV_SPLIT, _lib.GV_F32, couts[0], 0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                   None, yd.data_ptr() + 4 * 32, y2d.data_ptr(), None, None, st()), "conv split")
+    torch.cuda.synchronize()
+    y, y2 = yd.cpu().numpy(), y2d.cpu().numpy()
+    np.testing.assert_allclose(y[..., 32:32 + 64], ref[..., :64], rtol=2e-4, atol=2e-4)
+    assert (y[..., :32] == -7.0).all() and (y[..., 96:] == -7.0).all()
+    np.testing.assert_allclose(y2, ref[..., 64:], rtol=2e-4, atol=2e-4)
 
 
 def test_conv_naive_c_crosscheck():

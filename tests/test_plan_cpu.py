@@ -24,8 +24,9 @@ def test_param_names_and_shapes_match_oracle(name, size):
 def test_flops_per_view_match_survey(name, size, gflop):
     p = _plan(name, 1, size)
     assert abs(p.total_flops / 1e9 - gflop) < 0.002 * gflop
-    n_conv = sum(1 for op in p.ops if op["kind"] == "conv")
-    assert n_conv == (94 if name == "inception_v3" else 53)
+    assert len(p.filters) == (94 if name == "inception_v3" else 53)          # slim.conv2d call sites
+    n_launch = sum(1 for op in p.ops if op["kind"] == "conv")
+    assert n_launch == (94 - 2 * 9 if name == "inception_v3" else 53)       # 9 blocks fuse 3 sibling 1x1s
 
 
 def test_end_point_shapes():
@@ -86,6 +87,9 @@ def test_concat_slices_cover_block_outputs():
     for op in p.ops:
         y = op["y"]
         cover.setdefault(y.vbuf, []).append((y.off % y.ld, y.off % y.ld + y.c, y.ld))
+        if op.get("split"):                                  # fused siblings: the rest go to scratch
+            y2 = op["y2"]
+            assert op["cout"] == y.c + y2.c and op["split"] == y.c
     for name in ("Mixed_5b", "Mixed_6a", "Mixed_6e", "Mixed_7a", "Mixed_7c"):
         t = p.end_points[name]
         spans = sorted(cover[t.vbuf])
@@ -109,3 +113,13 @@ def test_head_param_names():
     assert sorted(H) == sorted(["dense/kernel", "dense/bias", "dense_1/kernel", "dense_1/bias",
                                 "dense_2/kernel", "dense_2/bias", "dense_3/kernel", "dense_3/bias"])
     assert H["dense_3/kernel"].shape == (32, 5) and H["dense/kernel"].shape == (16, 1)
+
+
+def test_sibling_fusion_is_optional_and_equivalent_in_work():
+    a = backbones.BackbonePlan(1, 75, 75)
+    backbones.build_inception_v3(a, fuse_siblings=False)
+    b = backbones.BackbonePlan(1, 75, 75)
+    backbones.build_inception_v3(b, fuse_siblings=True)
+    assert sum(1 for op in a.ops if op["kind"] == "conv") == 94
+    assert abs(a.total_flops - b.total_flops) < 1e-6 * a.total_flops
+    assert a.param_shapes() == b.param_shapes()
