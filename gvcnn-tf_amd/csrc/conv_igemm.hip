@@ -49,8 +49,7 @@ struct ConvArgs {
     int M, K, Kpad, ktiles;
     int relu, relu2, split;     // split > 0: columns >= split go to y2 (same scale/shift/relu)
     int tiles_n;
-    int dbg;                    // ablation bits (timing experiments only): 1 no global loads after tile 0,
-                                // 2 no LDS writes/barriers after tile 0, 4 no epilogue stores
+    int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
 };
 
 constexpr int CH = 16;        // channels per chunk (fp32)
@@ -84,12 +83,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
     const int n0 = tile_n * BN;
 
     // ---- loader state -----------------------------------------------------------------------
+    // Load slot idx -> (row, 16-byte quarter).  With 16-deep tiles (80-byte LDS rows) a ds_write_b128
+    // is serviced 8 lanes at a time: pairing row R (lanes 0-3) with row R+4 (lanes 4-7) makes the two
+    // rows' 4-bank slots disjoint (20*4 = 80 = 16 mod 32).  With 32-deep tiles 8 lanes are one row.
+    auto slot_row = [](int idx) -> int {
+        if constexpr (NCH == 1) {
+            const int g = idx >> 3;
+            return (g >> 2) * 8 + (g & 3) + 4 * ((idx >> 2) & 1);
+        } else {
+            return idx / QPR;
+        }
+    };
+    auto slot_q = [](int idx) -> int { return idx % QPR; };
     int a_img[A_LOADS], a_iy0[A_LOADS], a_ix0[A_LOADS];
     const int ohow = a.oh * a.ow;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int idx = tid + i * 256;
-        const int row = idx / QPR;
+        const int row = slot_row(idx);
         const int m = m0 + row;
         if (row < BM && m < a.M) {
             const int n = m / ohow;
@@ -110,10 +121,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int idx = tid + i * 256;
-        const int row = idx / QPR;
+        const int row = slot_row(idx);
         const int n = n0 + row;
         b_ok[i] = (row < BN) && (n < a.cout);
-        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * (idx % QPR);
+        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * slot_q(idx);
     }
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
         const int k0 = kt * BKT;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int kq = (tid + i * 256) % QPR;
+            const int kq = slot_q(tid + i * 256);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (!GENERIC) {
                 int r = fr[0], s = fs[0], c = fc[0];
@@ -191,13 +202,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
         for (int i = 0; i < A_LOADS; ++i) {
             const int idx = tid + i * 256;
             if (A_LOADS * 256 == BM * QPR || idx < BM * QPR)
-                *reinterpret_cast<f32x4*>(sA + buf * BM * LDS_LD + (idx / QPR) * LDS_LD + 4 * (idx % QPR)) = ra[i];
+                *reinterpret_cast<f32x4*>(sA + buf * BM * LDS_LD + slot_row(idx) * LDS_LD + 4 * slot_q(idx)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + i * 256;
             if (B_LOADS * 256 == BN * QPR || idx < BN * QPR)
-                *reinterpret_cast<f32x4*>(sB + buf * BN * LDS_LD + (idx / QPR) * LDS_LD + 4 * (idx % QPR)) = rb[i];
+                *reinterpret_cast<f32x4*>(sB + buf * BN * LDS_LD + slot_row(idx) * LDS_LD + 4 * slot_q(idx)) = rb[i];
         }
     };
 
@@ -214,37 +225,63 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
     const float* b_frag = sB + (wn * TN * 32) * LDS_LD + frag_off;
 
     // ---- main loop ----------------------------------------------------------------------------
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < a.ktiles; ++kt) {
-        const int buf = (a.dbg & 2) ? 0 : (kt & 1);
-        const bool more = (kt + 1 < a.ktiles);
-        if (more) {
-            advance_taps();
-            if (!(a.dbg & 1)) load_tile(kt + 1);
-        }
+    // Software pipeline (per wave):  fragments are double buffered in registers and read one
+    // sub-step (8 k) ahead of the MFMAs that consume them; the k-tile barrier sits between the last
+    // two MFMA groups of a tile, so the LDS latency of the next tile's first fragments is covered by
+    // this wave's own MFMAs instead of by luck with its neighbours; global loads run two k-tiles
+    // ahead of their ds_write (registers are re-filled right after they are written to LDS).
+    constexpr int NQ = 2 * NCH;                 // sub-steps per k-tile
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int set, int buf, int q) {
 #pragma unroll
-        for (int q = 0; q < 2 * NCH; ++q) {
-            f32x4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i)
+            fa[set][i] = *reinterpret_cast<const f32x4*>(a_frag + buf * BM * LDS_LD + i * 32 * LDS_LD + 8 * q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fb[set][j] = *reinterpret_cast<const f32x4*>(b_frag + buf * BN * LDS_LD + j * 32 * LDS_LD + 8 * q);
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(a_frag + buf * BM * LDS_LD + i * 32 * LDS_LD + 8 * q);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(b_frag + buf * BN * LDS_LD + j * 32 * LDS_LD + 8 * q);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+    };
+
+    load_tile(0);
+    store_tile(0);
+    if (a.ktiles > 1) {
+        advance_taps();
+        load_tile(1);
+    }
+    __syncthreads();
+    read_frags(0, 0, 0);
+    for (int kt = 0; kt + 1 < a.ktiles; ++kt) {
+        const int buf = kt & 1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        for (int q = 0; q + 1 < NQ; ++q) {
+            read_frags((q + 1) & 1, buf, q + 1);
+            mfma_group(q & 1);
         }
-        if (!(a.dbg & 2)) {
-            if (more) store_tile(buf ^ 1);
-            __syncthreads();
+        store_tile(buf ^ 1);                                       // registers hold tile kt+1
+        if (kt + 2 < a.ktiles) {
+            advance_taps();
+            load_tile(kt + 2);                                     // refill them: two tiles ahead
         }
+        __syncthreads();
+        read_frags(0, buf ^ 1, 0);
+        mfma_group((NQ - 1) & 1);
+    }
+    {                                                              // last k-tile (peeled: no barrier)
+        const int buf = (a.ktiles - 1) & 1;
+#pragma unroll
+        for (int q = 0; q + 1 < NQ; ++q) {
+            read_frags((q + 1) & 1, buf, q + 1);
+            mfma_group(q & 1);
+        }
+        mfma_group((NQ - 1) & 1);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------

@@ -58,14 +58,14 @@ for i, op in enumerate(plan.ops):
             row["tile_ms"] = tt
         if a.ablate:
             ab = []
-            for bits in (1, 3, 4, 7):
+            for bits in (4,):
                 lib.gv_conv2d_set_debug(bits)
                 ab.append(round(plan.time_range(x, i, 1, 3), 4))
             lib.gv_conv2d_set_debug(0)
             row["ablate_ms"] = ab
         print("%3d conv %-52s M=%8d N=%4d K=%5d %8.4f ms %7.2f TF/s %7.1f GB/s %s" % (
             i, op["name"][-52:], row["M"], row["N"], row["K"], ms, row["tflops"], row["gbs"],
-            str(row.get("tile_ms", "")) + (" ablate[noload,noload+nolds,nostore,all]=%s" % row["ablate_ms"] if a.ablate else "") + (" tile=%d" % (op.get("tile", 0) - 1))))
+            str(row.get("tile_ms", "")) + (" ablate[nostore]=%s" % row["ablate_ms"] if a.ablate else "") + (" tile=%d" % (op.get("tile", 0) - 1))))
     else:
         row.update(gbs=op["bytes"] / ms / 1e6)
         print("%3d %-4s %-52s %8.4f ms %7.1f GB/s" % (i, op["kind"], op["name"][-52:], ms, row["gbs"]))
