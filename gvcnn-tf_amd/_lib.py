@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
 
 GV_F32, GV_BF16 = 0, 1
 GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT = 1, 2, 4
+GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
 GV_POOL_MAX, GV_POOL_AVG = 0, 1
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
@@ -26,7 +27,8 @@ class GvError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "cin", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
-        "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype", "split_col", "tile_cfg")]
+        "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype", "split_col", "tile_cfg",
+        "math_mode")]
 
 
 class PoolDesc(C.Structure):
@@ -44,8 +46,8 @@ _F = C.c_float
 SIGNATURES = {
     "gv_abi_version": (C.c_int, []),
     "gv_error_string": (C.c_char_p, [C.c_int]),
-    "gv_packed_filter_elems": (_L, [_I, _I, _I, _I]),
-    "gv_pack_filter_hwio": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "gv_packed_filter_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "gv_pack_filter_hwio": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gv_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gv_pool2d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
     "gv_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
@@ -73,7 +75,7 @@ SIGNATURES = {
 TUNING = {
     "gv_conv2d_set_tile_override": (None, [C.c_int]),
     "gv_conv2d_set_debug": (None, [C.c_int]),
-    "gv_conv2d_num_tile_cfgs": (C.c_int, []),
+    "gv_conv2d_num_tile_cfgs": (C.c_int, [C.c_int]),
 }
 
 _lib = None

@@ -78,9 +78,10 @@ class TRef:
 class BackbonePlan:
     """Collects ops symbolically, then lowers them to a native gv_plan."""
 
-    def __init__(self, nb, height, width, dtype=_lib.GV_F32):
+    def __init__(self, nb, height, width, dtype=_lib.GV_F32, math_mode=_lib.GV_MATH_F32):
         self.lib = _lib.load()
         self.nb, self.height, self.width, self.dtype = nb, height, width, dtype
+        self.math_mode = math_mode
         self.ops = []            # dict records
         self.vbufs = []          # [size_elems, persistent]
         self.filters = []        # (weights_name, kh, kw, cin, cout, w_off)
@@ -106,8 +107,14 @@ class BackbonePlan:
             self.vbufs[t.vbuf][1] = True
         return t
 
+    def _packed_elems(self, kh, kw, cin, cout):
+        """Size of a packed filter in 4-byte units of the weights arena."""
+        nbytes = int(self.lib.gv_packed_filter_bytes(kh, kw, cin, cout, self.dtype, self.math_mode))
+        assert nbytes > 0 and nbytes % 4 == 0
+        return nbytes // 4
+
     def _filter(self, name, kh, kw, cin, cout):
-        n = int(self.lib.gv_packed_filter_elems(kh, kw, cin, cout))
+        n = self._packed_elems(kh, kw, cin, cout)
         off = self.w_elems
         self.filters.append((name, kh, kw, cin, cout, off))
         self.w_elems += (n + 63) // 64 * 64          # keep every filter 256-byte aligned
@@ -133,7 +140,7 @@ class BackbonePlan:
         total = sum(couts)
         rest = total - couts[0]
         assert (first_out.nb, first_out.h, first_out.w, first_out.c) == (x.nb, x.h, x.w, couts[0])
-        n_each = [int(self.lib.gv_packed_filter_elems(1, 1, x.c, c)) for c in couts]
+        n_each = [self._packed_elems(1, 1, x.c, c) for c in couts]
         w_off = self.w_elems
         off = w_off
         for (scope, c), n in zip(branches, n_each):
@@ -281,7 +288,7 @@ class BackbonePlan:
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], y.h, y.w, op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
-                                  flags, self.dtype, split, op.get("tile", 0))
+                                  flags, self.dtype, split, op.get("tile", 0), self.math_mode)
                 rs, ro = ref(res)
                 y2s, y2o = ref(y2)
                 _lib.check(lib.gv_plan_add_conv(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"],
@@ -322,7 +329,8 @@ class BackbonePlan:
             w = torch.as_tensor(params[name]).to(device=dev, dtype=torch.float32).contiguous()
             assert tuple(w.shape) == (kh, kw, cin, cout), (name, tuple(w.shape), (kh, kw, cin, cout))
             _lib.check(self.lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout,
-                                                    self.weights.data_ptr() + 4 * off, self.dtype, st),
+                                                    self.weights.data_ptr() + 4 * off, self.dtype,
+                                                    self.math_mode, st),
                        "gv_pack_filter_hwio(%s)" % name)
             self.keepalive.append(w)
         host = np.zeros(max(self.ss_elems, 4), dtype=np.float32)
@@ -385,7 +393,7 @@ class BackbonePlan:
         the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
         chain sums k in the same order under every configuration, so results are bitwise unchanged."""
         lib = self.lib
-        ncfg = lib.gv_conv2d_num_tile_cfgs()
+        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode)
         self.run(x)
         chosen = {}
         try:
@@ -625,8 +633,13 @@ TAPS = {"resnet_v2_50": ("resnet_v2_50/block3", "resnet_v2_50/block4"),
         "inception_v3": ("Mixed_6e", "Mixed_7c")}
 
 
-def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32):
-    b = BackbonePlan(nb, height, width, dtype)
+MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": _lib.GV_MATH_BF16X2,
+              "bf16x1": _lib.GV_MATH_BF16X1}
+
+
+def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
+              math="f32"):
+    b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     raw_tap = raw_tap or TAPS[backbone][0]
     final_tap = final_tap or TAPS[backbone][1]
     if backbone == "inception_v3":

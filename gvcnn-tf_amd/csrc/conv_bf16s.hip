@@ -1,0 +1,416 @@
+// conv_bf16s.hip — the same implicit-GEMM convolution as conv_igemm.hip, with the fp32 operands split
+// into NP bf16 "planes" so the products run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16,
+// 16x the fp32 MFMA rate per instruction):
+//
+//     a = a0 + a1 + a2,   a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)      (exact for fp32 a)
+//     a*b ~= a0*b0 + a0*b1 + a1*b0 + a1*b1 + a0*b2 + a2*b0                             (NP = 3: 6 MFMAs)
+//
+// Every bf16 x bf16 product is exact in the fp32 accumulator; the dropped terms (a1*b2, a2*b1, a2*b2)
+// are <= 2^-24 relative to the product, i.e. the result has fp32-level accuracy (it is NOT bitwise the
+// fp32 MFMA result: the summation order inside an MFMA differs).  NP = 2 keeps 3 products (2^-16),
+// NP = 1 is plain bf16 compute on fp32 storage.  Activations stay fp32 in HBM; the split is done by
+// the loader between the global load and the LDS write, filters are split once at pack time.
+//
+// Structure (4 waves, wave tile TM x TN MFMA tiles of 32x32, k-tile = 16):
+//   * LDS row = NP planes x 32 B (16 bf16) + 16 B pad -> an odd number of 16-byte slots: ds_write_b128
+//     from the loader (rows R, R+2, R+4, R+6 per 8-lane group) and ds_read_b128 of the MFMA fragments
+//     (lane (r = lane&31, h = lane>>5) reads k = 8h..8h+7 of row r) are both conflict-free;
+//   * global loads run two k-tiles ahead of their LDS write; fragments are double buffered in
+//     registers; the k-tile barrier sits between the two halves of a tile's MFMAs so the next tile's
+//     fragment reads are covered by this wave's own MFMAs;
+//   * epilogue, XCD-aware tile order, split/dual outputs: shared with the fp32 kernel (conv_common.h).
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+using gvconv::ConvArgs;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KT = 16;                      // k-tile depth
+
+// (plane of A, plane of B) of the t-th product, small terms first
+__host__ __device__ constexpr int prod_count(int np) { return np == 3 ? 6 : (np == 2 ? 3 : 1); }
+__host__ __device__ constexpr int prod_pa(int np, int t) {
+    return np == 3 ? (t == 0 ? 2 : (t == 2 || t == 3 ? 1 : 0)) : (np == 2 ? (t == 0 ? 1 : 0) : 0);
+}
+__host__ __device__ constexpr int prod_pb(int np, int t) {
+    return np == 3 ? (t == 1 ? 2 : (t == 2 || t == 4 ? 1 : 0)) : (np == 2 ? (t == 1 ? 1 : 0) : 0);
+}
+
+// 8 consecutive fp32 -> NP x (8 bf16 packed in 16 bytes)
+template <int NP>
+__device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, u32x4 (&out)[NP]) {
+    float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x2 pr = {(__bf16)x[2 * q], (__bf16)x[2 * q + 1]};
+            out[p][q] = __builtin_bit_cast(unsigned, pr);
+            if (p + 1 < NP) {
+                x[2 * q] -= (float)pr[0];
+                x[2 * q + 1] -= (float)pr[1];
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int NP, bool GENERIC>
+__global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int RB = NP * 32 + 16;                 // LDS row bytes
+    constexpr int A_SLOTS = (BM * 2 + 255) / 256;    // (row, half) slots: 8 fp32 each
+    constexpr int B_SLOTS = (BN * 2 + 255) / 256;
+    constexpr int NMF = TM * TN * prod_count(NP);              // MFMAs per k-tile
+    constexpr int HALF = (NMF + 1) / 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sA = smem_raw;                             // [2][BM][RB]
+    char* sB = smem_raw + 2 * BM * RB;               // [2][BN][RB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % a.tiles_n;
+    const int tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // slot -> (row, half): an 8-lane ds_write group covers rows R, R+2, R+4, R+6 x both halves
+    auto slot_row = [](int idx) -> int {
+        const int g = idx >> 3;
+        return (g >> 1) * 8 + (g & 1) + 2 * ((idx >> 1) & 3);
+    };
+
+    int a_img[A_SLOTS], a_iy0[A_SLOTS], a_ix0[A_SLOTS];
+    const int ohow = a.oh * a.ow;
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int idx = tid + i * 256;
+        const int row = slot_row(idx);
+        const int m = m0 + row;
+        if (row < BM && m < a.M) {
+            const int n = m / ohow;
+            const int rem = m - n * ohow;
+            const int oy = rem / a.ow;
+            const int ox = rem - oy * a.ow;
+            a_img[i] = n * a.ih;
+            a_iy0[i] = oy * a.stride - a.pad_t;
+            a_ix0[i] = ox * a.stride - a.pad_l;
+        } else {
+            a_img[i] = 0;
+            a_iy0[i] = -(1 << 28);
+            a_ix0[i] = 0;
+        }
+    }
+    const char* b_ptr[B_SLOTS];
+    bool b_ok[B_SLOTS];
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) {
+        const int idx = tid + i * 256;
+        const int row = slot_row(idx);
+        const int n = n0 + row;
+        b_ok[i] = (row < BN) && (n < a.cout);
+        // packed filter: [n][k-tile][plane][16 bf16]
+        b_ptr[i] = (const char*)a.w + (size_t)(b_ok[i] ? n : 0) * a.ktiles * (NP * 32) + 16 * (idx & 1);
+    }
+
+    f32x4 ra[A_SLOTS][2];
+    u32x4 rb[B_SLOTS][NP];
+    int fr = 0, fs = 0, fc = 0;                       // filter tap / channel base of the NEXT tile to load
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int half = (tid + i * 256) & 1;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!GENERIC) {
+                const int iy = a_iy0[i] + fr;
+                const int ix = a_ix0[i] + fs;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw && fr < a.kh) {
+                    const float* p = a.x + ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + fc + 8 * half;
+                    v0 = *reinterpret_cast<const f32x4*>(p);
+                    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kt * KT + 8 * half + j;
+                    float e = 0.f;
+                    if (k < a.K) {
+                        const int rs = k / a.cin;
+                        const int c = k - rs * a.cin;
+                        const int r = rs / a.kw;
+                        const int s = rs - r * a.kw;
+                        const int iy = a_iy0[i] + r;
+                        const int ix = a_ix0[i] + s;
+                        if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
+                            e = a.x[((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + c];
+                    }
+                    if (j < 4) v0[j] = e; else v1[j - 4] = e;
+                }
+            }
+            ra[i][0] = v0;
+            ra[i][1] = v1;
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (b_ok[i]) v = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)kt * (NP * 32) + p * 32);
+                rb[i][p] = v;
+            }
+        }
+    };
+    auto advance_tap = [&]() {
+        if constexpr (!GENERIC) {
+            fc += KT;
+            if (fc >= a.cin) {
+                fc = 0;
+                if (++fs == a.kw) { fs = 0; ++fr; }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int idx = tid + i * 256;
+            if (A_SLOTS * 256 == BM * 2 || idx < BM * 2) {
+                u32x4 pl[NP];
+                split8<NP>(ra[i][0], ra[i][1], pl);
+                char* dst = sA + buf * BM * RB + slot_row(idx) * RB + 16 * (idx & 1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = pl[p];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int idx = tid + i * 256;
+            if (B_SLOTS * 256 == BN * 2 || idx < BN * 2) {
+                char* dst = sB + buf * BN * RB + slot_row(idx) * RB + 16 * (idx & 1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = rb[i][p];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * RB + 16 * (lane >> 5);
+    const char* a_frag = sA + (wm * TM * 32) * RB + frag_off;
+    const char* b_frag = sB + (wn * TN * 32) * RB + frag_off;
+
+    u32x4 fa[2][TM][NP], fb[2][TN][NP];
+    auto read_frags = [&](auto setc, int buf) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                fa[S][i][p] = *reinterpret_cast<const u32x4*>(a_frag + buf * BM * RB + i * 32 * RB + p * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                fb[S][j][p] = *reinterpret_cast<const u32x4*>(b_frag + buf * BN * RB + j * 32 * RB + p * 32);
+    };
+    // MFMAs [lo, hi) of the flat list (product-major: small terms of every tile first)
+    auto mfma_range = [&](auto setc, auto loc, auto hic) {
+        constexpr int S = decltype(setc)::value;
+        constexpr int LO = decltype(loc)::value, HI = decltype(hic)::value;
+#pragma unroll
+        for (int t = LO; t < HI; ++t) {
+            const int pr = t / (TM * TN);
+            const int ij = t % (TM * TN);
+            const int i = ij / TN, j = ij % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fa[S][i][prod_pa(NP, pr)]), __builtin_bit_cast(bf16x8, fb[S][j][prod_pb(NP, pr)]),
+                acc[i][j], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IH = std::integral_constant<int, HALF>;
+    using IN = std::integral_constant<int, NMF>;
+
+    // one k-tile with a successor: first half of its MFMAs, hand tile kt+1 to LDS, barrier, fetch the
+    // successor's fragments into the other register set, second half of the MFMAs
+    auto step = [&](auto setc, int kt) {
+        constexpr int S = decltype(setc)::value;
+        using IS = std::integral_constant<int, S>;
+        using IO = std::integral_constant<int, S ^ 1>;
+        const int buf = kt & 1;
+        mfma_range(IS{}, I0{}, IH{});
+        store_tile(buf ^ 1);                                   // registers hold tile kt+1
+        if (kt + 2 < a.ktiles) {
+            advance_tap();
+            load_tile(kt + 2);                                 // refill them: two tiles ahead
+        }
+        __syncthreads();
+        read_frags(IO{}, buf ^ 1);
+        mfma_range(IS{}, IH{}, IN{});
+    };
+
+    load_tile(0);
+    store_tile(0);
+    if (a.ktiles > 1) {
+        advance_tap();
+        load_tile(1);
+    }
+    __syncthreads();
+    read_frags(I0{}, 0);
+    int kt = 0;
+    for (; kt + 2 < a.ktiles; kt += 2) {
+        step(I0{}, kt);
+        step(I1{}, kt + 1);
+    }
+    if (a.ktiles - kt == 2) {
+        step(I0{}, kt);
+        mfma_range(I1{}, I0{}, IN{});
+    } else {
+        mfma_range(I0{}, I0{}, IN{});
+    }
+
+    gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
+}
+
+// [kh][kw][cin][cout] fp32 -> [cout][k-tile][plane][16 bf16]
+template <int NP>
+__global__ void pack_filter_bf16s(const float* __restrict__ w, int K, int ktiles, int cout,
+                                  unsigned short* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)cout * ktiles * KT;
+    if (i >= total) return;
+    const int n = (int)(i / (ktiles * KT));
+    const int k = (int)(i - (int64_t)n * ktiles * KT);
+    float x = (k < K) ? w[(size_t)k * cout + n] : 0.f;
+    unsigned short* dst = out + ((size_t)n * ktiles + k / KT) * (NP * 16) + (k % KT);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const __bf16 h = (__bf16)x;
+        dst[p * 16] = __builtin_bit_cast(unsigned short, h);
+        x -= (float)h;
+    }
+}
+
+struct TileCfg { int bm, bn; };
+constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <int WM, int WN, int TM, int TN, int NP>
+int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    ConvArgs a = a0;
+    a.tiles_n = gv_ceil_div(a.cout, BN);
+    const int tiles_m = gv_ceil_div(a.M, BM);
+    const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
+    if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * BM + 2 * BN) * (NP * 32 + 16);
+    if (generic) {
+        if (lds > 64 * 1024) {
+            static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            if (!ok) return GV_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    } else {
+        if (lds > 64 * 1024) {
+            static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            if (!ok) return GV_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, false>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    }
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <int NP>
+int launch_np(int cfg, const ConvArgs& a, bool generic, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_cfg<2, 2, 2, 2, NP>(a, generic, st);
+        case 1: return launch_cfg<2, 2, 2, 1, NP>(a, generic, st);
+        case 2: return launch_cfg<2, 2, 1, 1, NP>(a, generic, st);
+        case 3: return launch_cfg<4, 1, 1, 3, NP>(a, generic, st);
+        case 4: return launch_cfg<2, 2, 1, 2, NP>(a, generic, st);
+        case 5: return launch_cfg<4, 1, 1, 1, NP>(a, generic, st);
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+namespace gvconv {
+
+int bf16s_num_cfgs() { return kNumTiles; }
+
+int bf16s_pick_tile(int /*planes*/, int M, int N, int /*K*/) {
+    int best = 0;
+    double best_cost = 1e30;
+    const int order[] = {0, 3, 1, 5};                 // 128 x {128, 96, 64, 32}
+    const double pen[] = {1.00, 1.02, 1.05, 1.20};
+    for (int t = 0; t < 4; ++t) {
+        const int bn = kTiles[order[t]].bn;
+        const double cost = (double)gv_ceil_div(N, bn) * bn * pen[t];
+        if (cost < best_cost) { best_cost = cost; best = order[t]; }
+    }
+    const int64_t blocks = (int64_t)gv_ceil_div(M, 128) * gv_ceil_div(N, kTiles[best].bn);
+    if (blocks < 1024) {
+        if (kTiles[best].bn == 128) best = 4;
+        else if (kTiles[best].bn == 64) best = 2;
+    }
+    return best;
+}
+
+int bf16s_launch(int planes, int cfg, const ConvArgs& a0, bool generic, hipStream_t st) {
+    ConvArgs a = a0;
+    a.Kpad = (a.K + KT - 1) / KT * KT;
+    a.ktiles = a.Kpad / KT;
+    switch (planes) {
+        case 3: return launch_np<3>(cfg, a, generic, st);
+        case 2: return launch_np<2>(cfg, a, generic, st);
+        case 1: return launch_np<1>(cfg, a, generic, st);
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+int64_t bf16s_packed_bytes(int kh, int kw, int cin, int cout, int planes) {
+    const int64_t K = (int64_t)kh * kw * cin;
+    return (int64_t)cout * ((K + KT - 1) / KT) * planes * 32;
+}
+
+int bf16s_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int planes, void* out,
+                      hipStream_t st) {
+    const int K = kh * kw * cin;
+    const int ktiles = (K + KT - 1) / KT;
+    const int64_t total = (int64_t)cout * ktiles * KT;
+    const dim3 grid((unsigned)gv_ceil_div(total, 256));
+    switch (planes) {
+        case 3: hipLaunchKernelGGL(pack_filter_bf16s<3>, grid, dim3(256), 0, st, w_hwio, K, ktiles, cout, (unsigned short*)out); break;
+        case 2: hipLaunchKernelGGL(pack_filter_bf16s<2>, grid, dim3(256), 0, st, w_hwio, K, ktiles, cout, (unsigned short*)out); break;
+        case 1: hipLaunchKernelGGL(pack_filter_bf16s<1>, grid, dim3(256), 0, st, w_hwio, K, ktiles, cout, (unsigned short*)out); break;
+        default: return GV_E_UNSUPPORTED;
+    }
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+}  // namespace gvconv

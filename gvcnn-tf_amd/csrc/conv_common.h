@@ -1,0 +1,86 @@
+// Shared pieces of the two implicit-GEMM convolution kernels (conv_igemm.hip: fp32 MFMA;
+// conv_bf16s.hip: fp32 data split into bf16 planes on the bf16 MFMA).
+#pragma once
+#include "gv_common.h"
+
+namespace gvconv {
+
+struct ConvArgs {
+    const float* x;
+    const void* w;              // packed filter (layout depends on the math mode)
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    float* y2;
+    const float* scale2;
+    const float* shift2;
+    int nb, ih, iw, cin, x_ld;
+    int kh, kw, stride, pad_t, pad_l;
+    int oh, ow, cout, y_ld, res_ld, y2_ld;
+    int M, K, Kpad, ktiles;
+    int relu, relu2, split;     // split > 0: columns >= split go to y2 (same scale/shift/relu)
+    int tiles_n;
+    int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
+};
+
+// Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:
+// col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):
+//   y = act(acc*scale[c] + shift[c] (+ residual)); y2 = second activation or split destination.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0,
+                                              int n0, int wm, int wn, int lane) {
+    if (a.dbg & 4) {            // keep the accumulators live without storing the tile
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 1.2345e-30f) a.y[0] = t;
+        return;
+    }
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + col_l;
+        if (col >= a.cout) continue;
+        const float sc = a.scale[col], sh = a.shift[col];
+        const bool to_second = a.split > 0 && col >= a.split;
+        const bool dual = a.y2 != nullptr && a.split == 0;
+        float sc2 = 0.f, sh2 = 0.f;
+        if (dual) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
+        float* ybase = to_second ? a.y2 + (col - a.split) : a.y + col;
+        const int yld = to_second ? a.y2_ld : a.y_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + (wm * TM + i) * 32 + row_h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res) v += a.res[(size_t)m * a.res_ld + col];
+                if (dual) {
+                    float v2 = v * sc2 + sh2;
+                    if (a.relu2) v2 = fmaxf(v2, 0.f);
+                    a.y2[(size_t)m * a.y2_ld + col] = v2;
+                }
+                if (a.relu) v = fmaxf(v, 0.f);
+                ybase[(size_t)m * yld] = v;
+            }
+        }
+    }
+}
+
+// conv_bf16s.hip
+int bf16s_num_cfgs();
+int bf16s_pick_tile(int planes, int M, int N, int K);
+int bf16s_launch(int planes, int cfg, const ConvArgs& a, bool generic, hipStream_t st);
+int bf16s_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int planes, void* out,
+                      hipStream_t st);
+int64_t bf16s_packed_bytes(int kh, int kw, int cin, int cout, int planes);
+
+}  // namespace gvconv

@@ -29,28 +29,11 @@
 //     sibling 1x1 convs that read the same input run as ONE GEMM (input read once);
 //   * 1-D grid, n-tiles fastest, remapped so that each XCD (private L2) gets a contiguous chunk
 //     of tile ids: the n-tiles that re-read one A panel run on one L2.
-#include "gv_common.h"
+#include "conv_common.h"
 
 namespace {
 
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* res;
-    float* y;
-    float* y2;
-    const float* scale2;
-    const float* shift2;
-    int nb, ih, iw, cin, x_ld;
-    int kh, kw, stride, pad_t, pad_l;
-    int oh, ow, cout, y_ld, res_ld, y2_ld;
-    int M, K, Kpad, ktiles;
-    int relu, relu2, split;     // split > 0: columns >= split go to y2 (same scale/shift/relu)
-    int tiles_n;
-    int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
-};
+using gvconv::ConvArgs;
 
 constexpr int CH = 16;        // channels per chunk (fp32)
 constexpr int KPAD_ALIGN = 32;
@@ -124,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
         const int row = slot_row(idx);
         const int n = n0 + row;
         b_ok[i] = (row < BN) && (n < a.cout);
-        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * slot_q(idx);
+        b_ptr[i] = (const float*)a.w + (size_t)(b_ok[i] ? n : 0) * a.Kpad + 4 * slot_q(idx);
     }
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
@@ -285,50 +268,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a) {
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
-    if (a.dbg & 4) {
-        // keep the accumulators live without storing the tile
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 1.2345e-30f) a.y[0] = t;
-        return;
-    }
-    const int col_l = lane & 31;
-    const int row_h = 4 * (lane >> 5);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + col_l;
-        if (col >= a.cout) continue;
-        const float sc = a.scale[col], sh = a.shift[col];
-        const bool to_second = a.split > 0 && col >= a.split;
-        const bool dual = a.y2 != nullptr && a.split == 0;
-        float sc2 = 0.f, sh2 = 0.f;
-        if (dual) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
-        float* ybase = to_second ? a.y2 + (col - a.split) : a.y + col;
-        const int yld = to_second ? a.y2_ld : a.y_ld;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rbase = m0 + (wm * TM + i) * 32 + row_h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = rbase + (r & 3) + 8 * (r >> 2);
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] * sc + sh;
-                if (a.res) v += a.res[(size_t)m * a.res_ld + col];
-                if (dual) {
-                    float v2 = v * sc2 + sh2;
-                    if (a.relu2) v2 = fmaxf(v2, 0.f);
-                    a.y2[(size_t)m * a.y2_ld + col] = v2;
-                }
-                if (a.relu) v = fmaxf(v, 0.f);
-                ybase[(size_t)m * yld] = v;
-            }
-        }
-    }
+    gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
 }
 
 // [kh][kw][cin][cout] fp32 -> [cout][Kpad] fp32, zero padded
@@ -422,18 +362,40 @@ int pick_tile(int M, int N, int K) {
 
 extern "C" void gv_conv2d_set_tile_override(int cfg) { g_tile_override = cfg; }
 extern "C" void gv_conv2d_set_debug(int bits) { g_debug = bits; }
-extern "C" int gv_conv2d_num_tile_cfgs(void) { return kNumTiles; }
+static int planes_of(int math_mode) {
+    switch (math_mode) {
+        case GV_MATH_F32: return 0;
+        case GV_MATH_BF16X3: return 3;
+        case GV_MATH_BF16X2: return 2;
+        case GV_MATH_BF16X1: return 1;
+    }
+    return -1;
+}
 
-extern "C" int64_t gv_packed_filter_elems(int32_t kh, int32_t kw, int32_t cin, int32_t cout) {
+extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
+    const int np = planes_of(math_mode);
+    return np < 0 ? GV_E_BADARG : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs());
+}
+
+extern "C" int64_t gv_packed_filter_bytes(int32_t kh, int32_t kw, int32_t cin, int32_t cout,
+                                          int32_t dtype, int32_t math_mode) {
     if (kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
+    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const int np = planes_of(math_mode);
+    if (np < 0) return GV_E_BADARG;
+    if (np > 0) return gvconv::bf16s_packed_bytes(kh, kw, cin, cout, np);
     const int64_t K = (int64_t)kh * kw * cin;
-    return (int64_t)cout * ((K + KPAD_ALIGN - 1) / KPAD_ALIGN * KPAD_ALIGN);
+    return 4 * (int64_t)cout * ((K + KPAD_ALIGN - 1) / KPAD_ALIGN * KPAD_ALIGN);
 }
 
 extern "C" int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin,
-                                   int32_t cout, void* w_packed, int32_t dtype, void* stream) {
+                                   int32_t cout, void* w_packed, int32_t dtype, int32_t math_mode,
+                                   void* stream) {
     if (!w_hwio || !w_packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
     if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    const int np = planes_of(math_mode);
+    if (np < 0) return GV_E_BADARG;
+    if (np > 0) return gvconv::bf16s_pack_filter(w_hwio, kh, kw, cin, cout, np, w_packed, (hipStream_t)stream);
     const int K = kh * kw * cin;
     const int Kpad = (K + KPAD_ALIGN - 1) / KPAD_ALIGN * KPAD_ALIGN;
     const int64_t total = (int64_t)cout * Kpad;
@@ -465,13 +427,16 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
         return GV_E_BADARG;
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
-    if (d->tile_cfg < 0 || d->tile_cfg > kNumTiles) return GV_E_BADARG;
+    const int np = planes_of(d->math_mode);
+    if (np < 0) return GV_E_BADARG;
+    const int ncfg = np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs();
+    if (d->tile_cfg < 0 || d->tile_cfg > ncfg) return GV_E_BADARG;
     const int64_t M64 = (int64_t)d->nb * d->oh * d->ow;
     if (M64 > 0x7fffffff || (int64_t)d->nb * d->ih * d->iw > 0x7fffffff) return GV_E_UNSUPPORTED;
     if (!gv_aligned16(w_packed)) return GV_E_ALIGN;
 
     ConvArgs a;
-    a.x = (const float*)x; a.w = (const float*)w_packed; a.scale = scale; a.shift = shift;
+    a.x = (const float*)x; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.res = (const float*)residual; a.y = (float*)y; a.y2 = (float*)y2;
     a.scale2 = scale2; a.shift2 = shift2;
     a.nb = d->nb; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin; a.x_ld = d->x_ld;
@@ -489,8 +454,13 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
 
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
     const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
-    int cfg = g_tile_override >= 0 && g_tile_override < kNumTiles ? g_tile_override
-              : (d->tile_cfg > 0 ? d->tile_cfg - 1 : pick_tile(a.M, a.cout, a.K));
+    if (np > 0) {
+        const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
+                        : (d->tile_cfg > 0 ? d->tile_cfg - 1 : gvconv::bf16s_pick_tile(np, a.M, a.cout, a.K));
+        return gvconv::bf16s_launch(np, cfg, a, generic, (hipStream_t)stream);
+    }
+    const int cfg = g_tile_override >= 0 && g_tile_override < kNumTiles ? g_tile_override
+                    : (d->tile_cfg > 0 ? d->tile_cfg - 1 : pick_tile(a.M, a.cout, a.K));
     return launch_tile(cfg, a, generic, (hipStream_t)stream);
 }
 

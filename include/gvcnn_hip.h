@@ -46,6 +46,13 @@ extern "C" {
 #define GV_CONV_SPLIT 4       /* y2 is not a second activation but the destination of output
                                  columns >= split_col (sibling convs fused into one GEMM) */
 
+/* gv_conv_desc.math_mode: how an fp32 convolution is evaluated on the matrix cores */
+#define GV_MATH_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                         */
+#define GV_MATH_BF16X3 1      /* operands split into 3 bf16 planes, 6 bf16 MFMAs per product block:
+                                 fp32-level accuracy (dropped terms <= 2^-24 relative), ~2.7x the rate */
+#define GV_MATH_BF16X2 2      /* 2 planes, 3 MFMAs: ~2^-16 relative                                     */
+#define GV_MATH_BF16X1 3      /* plain bf16 products, fp32 accumulate                                   */
+
 /* pooling modes */
 #define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
 #define GV_POOL_AVG 1         /* divisor = number of VALID taps (slim.avg_pool2d, SAME) */
@@ -77,6 +84,7 @@ typedef struct gv_conv_desc {
                                   column (c - split_col), pixel stride y2_ld; same scale/shift/act */
     int32_t tile_cfg;          /* 0 = library heuristic; k >= 1 = tile configuration k-1 (a speed choice
                                   only: every configuration returns bitwise the same result) */
+    int32_t math_mode;         /* GV_MATH_*; w_packed must have been packed for the same mode */
 } gv_conv_desc;
 
 typedef struct gv_pool_desc {
@@ -95,12 +103,14 @@ int gv_abi_version(void);
 const char* gv_error_string(int code);
 
 /* ---- filters ------------------------------------------------------------
- * Packed filter layout consumed by gv_conv2d_fwd: [cout][Kpad], k = (r*kw+s)*cin + c,
- * Kpad = K rounded up to 32, zero filled.  Source is TensorFlow's HWIO
+ * Packed filter layout consumed by gv_conv2d_fwd, GV_MATH_F32: [cout][Kpad], k = (r*kw+s)*cin + c,
+ * Kpad = K rounded up to 32, zero filled; GV_MATH_BF16X*: [cout][K/16][plane][16 bf16] (the filter is
+ * split into its bf16 planes once, here).  Source is TensorFlow's HWIO
  * [kh,kw,cin,cout] fp32 variable (slim `.../weights`). */
-int64_t gv_packed_filter_elems(int32_t kh, int32_t kw, int32_t cin, int32_t cout);
+int64_t gv_packed_filter_bytes(int32_t kh, int32_t kw, int32_t cin, int32_t cout, int32_t dtype,
+                               int32_t math_mode);
 int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin, int32_t cout,
-                        void* w_packed, int32_t dtype, void* stream);
+                        void* w_packed, int32_t dtype, int32_t math_mode, void* stream);
 
 /* ---- convolution ---------------------------------------------------------
  * y  = act( conv(x, w) * scale[c] + shift[c] (+ residual) )

@@ -50,7 +50,7 @@ def test_abi_version_and_error_strings(lib):
 
 def test_bad_arguments_return_codes(lib):
     from gvcnn_tf_amd import _lib
-    d = _lib.ConvDesc(1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 8, 8, 16, 16, 0, 0, 0, _lib.GV_F32, 0, 0)
+    d = _lib.ConvDesc(1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 8, 8, 16, 16, 0, 0, 0, _lib.GV_F32, 0, 0, 0)
     assert lib.gv_conv2d_fwd(C.byref(d), None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.gv_conv2d_fwd(None, 16, 16, 16, 16, None, 16, None, None, None, None) == -1
     d.cout = 0
@@ -62,6 +62,9 @@ def test_bad_arguments_return_codes(lib):
     d.flags = _lib.GV_CONV_SPLIT                 # split without a second destination
     assert lib.gv_conv2d_fwd(C.byref(d), 16, 16, 16, 16, None, 16, None, None, None, None) == -1
     d.flags = 0
+    d.math_mode = 9
+    assert lib.gv_conv2d_fwd(C.byref(d), 16, 16, 16, 16, None, 16, None, None, None, None) == -1
+    d.math_mode = 0
     d.dtype = 7
     assert lib.gv_conv2d_fwd(C.byref(d), 16, 16, 16, 16, None, 16, None, None, None, None) == -2
     d.dtype = _lib.GV_F32
@@ -73,9 +76,11 @@ def test_bad_arguments_return_codes(lib):
     assert lib.gv_group_assign(16, 65, 10, 10, 16, 16, 16, 16, None) == -2        # V > 64
     assert lib.gv_view_pool_fuse_fwd(16, 6, 2, 64, 64, 384, 16, 10, 16, 9, 1.0, None, 16, 0, None) == -1
     assert lib.gv_view_pool_fuse_fwd(16, 6, 2, 64, 64, 384, 16, 10, 16, 0, 1.0, None, None, 0, None) == -1
-    assert lib.gv_packed_filter_elems(3, 3, 3, 32) == 32 * 32        # K=27 -> Kpad 32
-    assert lib.gv_packed_filter_elems(1, 1, 64, 80) == 80 * 64
-    assert lib.gv_packed_filter_elems(3, 3, 80, 192) == 192 * 736     # K=720 -> Kpad 736
+    assert lib.gv_packed_filter_bytes(3, 3, 3, 32, 0, 0) == 4 * 32 * 32        # K=27 -> Kpad 32
+    assert lib.gv_packed_filter_bytes(1, 1, 64, 80, 0, 0) == 4 * 80 * 64
+    assert lib.gv_packed_filter_bytes(3, 3, 80, 192, 0, 0) == 4 * 192 * 736    # K=720 -> Kpad 736
+    assert lib.gv_packed_filter_bytes(3, 3, 80, 192, 0, 1) == 192 * 45 * 3 * 32  # 45 k-tiles x 3 bf16 planes
+    assert lib.gv_packed_filter_bytes(3, 3, 80, 192, 0, 9) == -1
     assert lib.gv_plan_run(None, None, 0, None) == -4
     plan = C.c_void_p()
     assert lib.gv_plan_create(C.byref(plan)) == 0

@@ -29,19 +29,19 @@ def st():
     return torch.cuda.current_stream().cuda_stream
 
 
-def pack_filter(w_hwio):
+def pack_filter(w_hwio, math=0):
     kh, kw, cin, cout = w_hwio.shape
-    n = lib().gv_packed_filter_elems(kh, kw, cin, cout)
+    n = lib().gv_packed_filter_bytes(kh, kw, cin, cout, _lib.GV_F32, math) // 4
     out = torch.empty(n, dtype=torch.float32, device=DEV)
     wd = w_hwio.to(DEV).contiguous()
-    _lib.check(lib().gv_pack_filter_hwio(wd.data_ptr(), kh, kw, cin, cout, out.data_ptr(), _lib.GV_F32, st()),
-               "pack")
+    _lib.check(lib().gv_pack_filter_hwio(wd.data_ptr(), kh, kw, cin, cout, out.data_ptr(), _lib.GV_F32, math,
+                                         st()), "pack")
     torch.cuda.synchronize()
     return out
 
 
 def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, residual=None, y_ld=None, y_off=0,
-             x_ld=None, x_off=0, second=None, tile=None):
+             x_ld=None, x_off=0, second=None, tile=None, math=0):
     """x [nb,ih,iw,cin] cpu tensor.  Returns y [nb,oh,ow,cout] (and y2) as numpy."""
     nb, ih, iw, cin = x.shape
     kh, kw, _, cout = w.shape
@@ -53,14 +53,14 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, residual=None, y_ld
     xd = xb.to(DEV)
     yd = torch.full((nb, oh, ow, y_ld), -77.0, device=DEV)
     y2d = torch.full((nb, oh, ow, cout), -55.0, device=DEV) if second else None
-    wp = pack_filter(w)
+    wp = pack_filter(w, math)
     sc, sh = scale.to(DEV), shift.to(DEV)
     sc2 = second[0].to(DEV) if second else None          # keep the device copies alive over the launch
     sh2 = second[1].to(DEV) if second else None
     rd = residual.to(DEV).contiguous() if residual is not None else None
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
-                      cout if residual is not None else 0, cout if second else 0, flags, _lib.GV_F32, 0, 0)
+                      cout if residual is not None else 0, cout if second else 0, flags, _lib.GV_F32, 0, 0, math)
     if tile is not None:
         lib().gv_conv2d_set_tile_override(tile)
     try:
@@ -177,7 +177,7 @@ def test_conv_split_output_fused_siblings():
     y2d = torch.full((nb, h, wd, total - couts[0]), -5.0, device=DEV)
     sc, sh = scale.to(DEV), shift.to(DEV)
     d = _lib.ConvDesc(nb, h, wd, cin, cin, 1, 1, 1, 0, 0, h, wd, total, 256, 0, total - couts[0],
-                      _lib.GV_CONV_RELU | _lib.GV_CONV_SPLIT, _lib.GV_F32, couts[0], 0)
+                      _lib.GV_CONV_RELU | _lib.GV_CONV_SPLIT, _lib.GV_F32, couts[0], 0, 0)
     _lib.check(lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                    None, yd.data_ptr() + 4 * 32, y2d.data_ptr(), None, None, st()), "conv split")
     torch.cuda.synchronize()
@@ -384,3 +384,59 @@ def test_view_score_and_dense():
     _lib.check(lib().gv_dense_fwd(xdd.data_ptr(), 5, 2048, Wd.data_ptr(),
                                   bdd.data_ptr(), 40, yd.data_ptr(), st()), "dense")
     np.testing.assert_allclose(yd.cpu().numpy(), OG.dense(x.numpy(), Wk.numpy(), b.numpy()), rtol=1e-4, atol=1e-4)
+
+
+# ---- fp32 evaluated through bf16 planes (GV_MATH_BF16X*) ----------------------------------------
+BF16S_TOL = {1: 2e-5, 2: 2e-3, 3: 3e-2}          # x3: fp32-level; x2: ~2^-16; x1: plain bf16 products
+
+
+@pytest.mark.parametrize("math", [1, 2, 3])
+@pytest.mark.parametrize("k,stride,padding,cin,cout", [c for c in COMBOS if c[3] in (3, 32, 48, 80, 128, 384)])
+def test_conv_bf16_split_vs_oracle(math, k, stride, padding, cin, cout):
+    g = torch.Generator().manual_seed(hash((k, stride, cin, cout)) % 1000)
+    ih, iw = (23, 20) if cin <= 64 else (9, 10)
+    x = torch.randn(3, ih, iw, cin, generator=g)
+    w = torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = oracle_conv(x, w, stride, padding, scale, shift, True)
+    if isinstance(padding, str):
+        pads = (tf_pads(ih, k[0], stride, padding), tf_pads(iw, k[1], stride, padding))
+    else:
+        pads = (padding[0], padding[2])
+    y = run_conv(x, w, stride, pads, ref.shape[1:3], scale, shift, True, math=math)
+    tol = BF16S_TOL[math]
+    np.testing.assert_allclose(y, ref.numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("tile", list(range(6)))
+@pytest.mark.parametrize("cout", [32, 80, 200])
+def test_conv_bf16x3_every_tile_config(tile, cout):
+    g = torch.Generator().manual_seed(tile * 100 + cout)
+    x = torch.randn(2, 13, 11, 32, generator=g)
+    w = torch.randn(3, 3, 32, cout, generator=g) * 0.06
+    scale, shift = torch.ones(cout), torch.zeros(cout)
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, False)
+    y = run_conv(x, w, 1, (1, 1), (13, 11), scale, shift, False, tile=tile, math=1)
+    np.testing.assert_allclose(y, ref.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_conv_bf16x3_small_integers_exact_and_split_outputs():
+    """Integers up to 2^8 fit one bf16 plane, products are exact in fp32: the split path must be exact."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(-3, 4, (1, 8, 8, 16), generator=g).float()
+    w = torch.randint(-2, 3, (3, 3, 16, 96), generator=g).float()
+    ref = oracle_conv(x, w, 1, "SAME", torch.ones(96), torch.zeros(96), False)
+    y = run_conv(x, w, 1, (1, 1), (8, 8), torch.ones(96), torch.zeros(96), False, math=1)
+    np.testing.assert_array_equal(y, ref.numpy())
+    # residual + second output + channel-slice in/out on the split-bf16 path
+    x = torch.randn(2, 9, 9, 32, generator=g)
+    w = torch.randn(1, 1, 32, 64, generator=g) * 0.2
+    scale, shift = torch.ones(64), torch.randn(64, generator=g)
+    res = torch.randn(2, 9, 9, 64, generator=g)
+    s2, h2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    pre = oracle_conv(x, w, 1, "SAME", scale, shift, False, residual=res)
+    y, y2 = run_conv(x, w, 1, (0, 0), (9, 9), scale, shift, False, residual=res, y_ld=192, y_off=96,
+                     x_ld=80, x_off=16, second=(s2, h2), math=1)
+    np.testing.assert_allclose(y, pre.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(y2, torch.relu(pre * s2 + h2).numpy(), rtol=2e-5, atol=2e-5)

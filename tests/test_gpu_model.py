@@ -157,3 +157,22 @@ def test_full_size_properties_config_c2():
                               Hd["dense_%d/bias" % V].numpy())
     np.testing.assert_allclose(S1.cpu().numpy(), oS, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(L1.cpu().numpy(), oL, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("backbone,size", [("inception_v3", 75), ("resnet_v2_50", 64)])
+def test_bf16x3_math_matches_oracle_at_fp32_tolerance(backbone, size):
+    """GV_MATH_BF16X3 (fp32 split into three bf16 planes on the bf16 MFMA) keeps fp32-level accuracy
+    end to end: same oracle, same tolerance as the exact fp32 MFMA path."""
+    N, V, C, G = 2, 6, 10, 10
+    eng, P, Hd = make_engine(backbone, N, V, size, size, C, G, math="bf16x3")
+    x = views(N, V, size, size, seed=1)
+    scores, S, logits = eng.forward(x.to(DEV))
+    o_scores, o_S, o_logits, o_scheme, o_weight = OM.gvcnn(x, C, P, Hd, G, backbone)
+    assert eng.scheme.cpu().numpy().tolist() == o_scheme.tolist()
+    assert_close(S.cpu().numpy(), o_S)
+    assert_close(logits.cpu().numpy(), o_logits)
+    eng32, _, _ = make_engine(backbone, N, V, size, size, C, G)
+    _, S32, _ = eng32.forward(x.to(DEV))
+    err_x3 = float(np.abs(S.cpu().numpy() - o_S).max())
+    err_32 = float(np.abs(S32.cpu().numpy() - o_S).max())
+    assert err_x3 < 4 * err_32 + 1e-6 * float(np.abs(o_S).max())      # same error class as exact fp32
