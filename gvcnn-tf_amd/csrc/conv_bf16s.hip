@@ -15,8 +15,8 @@
 //   * LDS row = NP planes x 32 B (16 bf16) + 16 B pad -> an odd number of 16-byte slots: ds_write_b128
 //     from the loader (rows R, R+2, R+4, R+6 per 8-lane group) and ds_read_b128 of the MFMA fragments
 //     (lane (r = lane&31, h = lane>>5) reads k = 8h..8h+7 of row r) are both conflict-free;
-//   * global loads run two k-tiles ahead of their LDS write; fragments are double buffered in
-//     registers; the k-tile barrier sits between the two halves of a tile's MFMAs so the next tile's
+//   * two k-tiles of global loads are in flight per workgroup (two register staging sets, each
+//     refilled right after it is written to LDS); fragments are double buffered in registers; the k-tile barrier sits between the two halves of a tile's MFMAs so the next tile's
 //     fragment reads are covered by this wave's own MFMAs;
 //   * epilogue, XCD-aware tile order, split/dual outputs: shared with the fp32 kernel (conv_common.h).
 #include <type_traits>
@@ -44,8 +44,10 @@ __host__ __device__ constexpr int prod_pb(int np, int t) {
 
 // 8 consecutive fp32 -> NP x (8 bf16 packed in 16 bytes)
 template <int NP>
-__device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, u32x4 (&out)[NP]) {
+__device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, bool ok, u32x4 (&out)[NP]) {
     float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = ok ? x[j] : 0.f;          // zero padding taps (loads are unconditional)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -121,29 +123,40 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
         const int idx = tid + i * 256;
         const int row = slot_row(idx);
         const int n = n0 + row;
-        b_ok[i] = (row < BN) && (n < a.cout);
-        // packed filter: [n][k-tile][plane][16 bf16]
-        b_ptr[i] = (const char*)a.w + (size_t)(b_ok[i] ? n : 0) * a.ktiles * (NP * 32) + 16 * (idx & 1);
+        b_ok[i] = (row < BN);
+        // packed filter: [n][k-tile][plane][16 bf16].  Rows past cout re-read the last filter: their
+        // accumulator columns are never stored, so no zeroing (and no divergent branch) is needed.
+        const int nc = n < a.cout ? n : a.cout - 1;
+        b_ptr[i] = (const char*)a.w + (size_t)nc * a.ktiles * (NP * 32) + 16 * (idx & 1);
     }
 
-    f32x4 ra[A_SLOTS][2];
-    u32x4 rb[B_SLOTS][NP];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    f32x4 ra[2][A_SLOTS][2];                          // tile t is staged in register set t & 1
+    u32x4 rb[2][B_SLOTS][NP];
+    bool aok[2][A_SLOTS];
     int fr = 0, fs = 0, fc = 0;                       // filter tap / channel base of the NEXT tile to load
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](auto rsc, int kt) {
+        constexpr int RS = decltype(rsc)::value;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int half = (tid + i * 256) & 1;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (!GENERIC) {
+                // unconditional loads from a clamped (always valid) address; padding taps and rows past
+                // M are zeroed / ignored later.  No divergent branch => the compiler can count vmcnt and
+                // leave the younger tile's loads in flight.
                 const int iy = a_iy0[i] + fr;
                 const int ix = a_ix0[i] + fs;
-                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw && fr < a.kh) {
-                    const float* p = a.x + ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + fc + 8 * half;
-                    v0 = *reinterpret_cast<const f32x4*>(p);
-                    v1 = *reinterpret_cast<const f32x4*>(p + 4);
-                }
+                aok[RS][i] = (unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw && fr < a.kh;
+                const int iyc = min(max(iy, 0), a.ih - 1);
+                const int ixc = min(max(ix, 0), a.iw - 1);
+                const float* p = a.x + ((size_t)(a_img[i] + iyc) * a.iw + ixc) * a.x_ld + fc + 8 * half;
+                v0 = *reinterpret_cast<const f32x4*>(p);
+                v1 = *reinterpret_cast<const f32x4*>(p + 4);
             } else {
+                aok[RS][i] = true;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = kt * KT + 8 * half + j;
@@ -161,16 +174,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
                     if (j < 4) v0[j] = e; else v1[j - 4] = e;
                 }
             }
-            ra[i][0] = v0;
-            ra[i][1] = v1;
+            ra[RS][i][0] = v0;
+            ra[RS][i][1] = v1;
         }
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (b_ok[i]) v = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)kt * (NP * 32) + p * 32);
-                rb[i][p] = v;
+                const int ktc = kt < a.ktiles ? kt : a.ktiles - 1;      // prefetch past the end re-reads the last tile
+                rb[RS][i][p] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)ktc * (NP * 32) + p * 32);
             }
         }
     };
@@ -183,13 +195,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto rsc, int buf) {
+        constexpr int RS = decltype(rsc)::value;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int idx = tid + i * 256;
             if (A_SLOTS * 256 == BM * 2 || idx < BM * 2) {
                 u32x4 pl[NP];
-                split8<NP>(ra[i][0], ra[i][1], pl);
+                split8<NP>(ra[RS][i][0], ra[RS][i][1], aok[RS][i], pl);
                 char* dst = sA + buf * BM * RB + slot_row(idx) * RB + 16 * (idx & 1);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = pl[p];
@@ -198,10 +211,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const int idx = tid + i * 256;
-            if (B_SLOTS * 256 == BN * 2 || idx < BN * 2) {
+            if (B_SLOTS * 256 == BN * 2 || b_ok[i]) {
                 char* dst = sB + buf * BN * RB + slot_row(idx) * RB + 16 * (idx & 1);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = rb[i][p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = rb[RS][i][p];
             }
         }
     };
@@ -246,8 +259,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
                 acc[i][j], 0, 0, 0);
         }
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
     using IH = std::integral_constant<int, HALF>;
     using IN = std::integral_constant<int, NMF>;
 
@@ -259,22 +270,20 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
         using IO = std::integral_constant<int, S ^ 1>;
         const int buf = kt & 1;
         mfma_range(IS{}, I0{}, IH{});
-        store_tile(buf ^ 1);                                   // registers hold tile kt+1
-        if (kt + 2 < a.ktiles) {
-            advance_tap();
-            load_tile(kt + 2);                                 // refill them: two tiles ahead
-        }
+        store_tile(IO{}, buf ^ 1);                             // register set S^1 holds tile kt+1
+        advance_tap();
+        load_tile(IO{}, kt + 3);                               // refill it (clamped past the end); tile kt+2 stays in flight in set S
         __syncthreads();
         read_frags(IO{}, buf ^ 1);
         mfma_range(IS{}, IH{}, IN{});
     };
 
-    load_tile(0);
-    store_tile(0);
-    if (a.ktiles > 1) {
-        advance_tap();
-        load_tile(1);
-    }
+    load_tile(I0{}, 0);
+    store_tile(I0{}, 0);
+    advance_tap();
+    load_tile(I1{}, 1);
+    advance_tap();
+    load_tile(I0{}, 2);
     __syncthreads();
     read_frags(I0{}, 0);
     int kt = 0;
