@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
     return ap.parse_args()
@@ -121,7 +122,7 @@ def main():
     from gvcnn_tf_amd.sharding import ShardedGVCNN
 
     N = a.shapes
-    eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math)
+    eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math, lanes=not a.no_lanes)
     P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
     Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
     eng.plan.bind(P)

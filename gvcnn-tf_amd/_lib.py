@@ -64,6 +64,7 @@ SIGNATURES = {
     "gv_plan_add_conv": (C.c_int, [_P, C.POINTER(ConvDesc), _I, _L, _I, _L, _I, _L, _L, _I, _L, _I, _L,
                                    _I, _L, _L, _L]),
     "gv_plan_set_conv_tile": (C.c_int, [_P, _I, _I]),
+    "gv_plan_set_schedule": (C.c_int, [_P, _I, _I, C.POINTER(_I), _I]),
     "gv_plan_add_pool": (C.c_int, [_P, C.POINTER(PoolDesc), _I, _L, _I, _L]),
     "gv_plan_add_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _L, _I, _L, _L, _I, _L]),
     "gv_plan_run": (C.c_int, [_P, C.POINTER(_P), _I, _P]),

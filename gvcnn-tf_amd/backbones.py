@@ -96,8 +96,27 @@ class BackbonePlan:
         self._bufs = None
         self._ptrs = None
         self.keepalive = []
+        self.cur_lane = 0
+        self.use_lanes = True
 
     # ---- symbolic construction ----------------------------------------------------------------
+    def lane(self, k):
+        """Context manager: ops recorded inside go to launch lane k (gv_plan_set_schedule)."""
+        plan = self
+
+        class _Lane:
+            def __enter__(self_inner):
+                self_inner.prev = plan.cur_lane
+                plan.cur_lane = k
+
+            def __exit__(self_inner, *exc):
+                plan.cur_lane = self_inner.prev
+        return _Lane()
+
+    def _record(self, op):
+        op["lane"] = self.cur_lane
+        self.ops.append(op)
+
     def new_tensor(self, nb, h, w, c, persistent=False):
         self.vbufs.append([nb * h * w * c, persistent])
         return TRef(len(self.vbufs) - 1, 0, nb, h, w, c, c)
@@ -155,7 +174,7 @@ class BackbonePlan:
             self.ss_specs.append(("bn", scope + "/BatchNorm", c, norm[1], norm[2], so + cum, ho + cum))
             cum += c
         scratch = self.new_tensor(x.nb, x.h, x.w, rest)
-        self.ops.append(dict(kind="conv", name="+".join(sc for sc, _ in branches), x=x, y=first_out,
+        self._record(dict(kind="conv", name="+".join(sc for sc, _ in branches), x=x, y=first_out,
                              y2=scratch, res=None, w_off=w_off, scale_off=so, shift_off=ho,
                              scale2_off=0, shift2_off=0, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
                              relu=relu, split=couts[0], cout=total,
@@ -190,7 +209,7 @@ class BackbonePlan:
             s2, h2 = self._scale_shift("bn", next_preact[0], cout, next_preact[1], True)
         if residual is not None:
             assert (residual.nb, residual.h, residual.w, residual.c) == (x.nb, oh, ow, cout)
-        self.ops.append(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
+        self._record(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
                              split=0, cout=cout,
@@ -204,7 +223,7 @@ class BackbonePlan:
         if out is None:
             out = self.new_tensor(x.nb, oh, ow, x.c)
         assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, x.c)
-        self.ops.append(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t,
+        self._record(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t,
                              pad_l=pad_l, mode=mode, flops=0.0,
                              bytes=4.0 * (x.npix * x.c + out.npix * out.c)))
         return out
@@ -213,7 +232,7 @@ class BackbonePlan:
         """Stand-alone slim.batch_norm(activation_fn=relu) (resnet_v2.py:75, first unit only)."""
         out = self.new_tensor(x.nb, x.h, x.w, x.c)
         so, ho = self._scale_shift("bn", bn_scope, x.c, eps, True)
-        self.ops.append(dict(kind="ssa", name=name, x=x, y=out, scale_off=so, shift_off=ho, relu=True,
+        self._record(dict(kind="ssa", name=name, x=x, y=out, scale_off=so, shift_off=ho, relu=True,
                              flops=0.0, bytes=8.0 * x.npix * x.c))
         return out
 
@@ -221,38 +240,46 @@ class BackbonePlan:
     def _assign_buffers(self):
         last_use = {}
         first_def = {}
+        lanes_of = {}
         for i, op in enumerate(self.ops):
             for key in ("x", "y", "y2", "res"):
                 t = op.get(key)
                 if t is not None and t.vbuf >= 0:
                     last_use[t.vbuf] = i
                     first_def.setdefault(t.vbuf, i)
+                    lanes_of.setdefault(t.vbuf, set()).add(op.get("lane", 0))
         phys_sizes = []
-        free = []                  # physical ids
+        free = []                  # (physical id, op index at which it was released, lanes that touched it)
         vmap = {}
+        # A buffer released by one lane is not handed to ANOTHER lane for REUSE_DELAY ops: immediate
+        # reuse would order the independent branches behind each other (a write-after-read hazard the
+        # schedule then has to honour).  Memory is not the constraint here (288 GB of HBM).
+        REUSE_DELAY = 16 if self.use_lanes else 0
         for i, op in enumerate(self.ops):
+            lane = op.get("lane", 0)
             for key in ("y", "y2"):
                 t = op.get(key)
                 if t is None or t.vbuf in vmap:
                     continue
                 need = self.vbufs[t.vbuf][0]
-                cand = [p for p in free if phys_sizes[p] >= need]
+                ok = [f for f in free if f[2] == {lane} or f[1] <= i - REUSE_DELAY]
+                cand = [f for f in ok if phys_sizes[f[0]] >= need]
                 if cand:
-                    p = min(cand, key=lambda q: phys_sizes[q])
-                    free.remove(p)
+                    f = min(cand, key=lambda q: phys_sizes[q[0]])
+                    free.remove(f)
+                    p = f[0]
+                elif ok:                           # enlarge the biggest reusable buffer instead of adding one
+                    f = max(ok, key=lambda q: phys_sizes[q[0]])
+                    free.remove(f)
+                    p = f[0]
+                    phys_sizes[p] = need
                 else:
-                    grow = [p for p in free]
-                    if grow:                       # enlarge the biggest free buffer instead of adding one
-                        p = max(grow, key=lambda q: phys_sizes[q])
-                        free.remove(p)
-                        phys_sizes[p] = need
-                    else:
-                        p = len(phys_sizes)
-                        phys_sizes.append(need)
+                    p = len(phys_sizes)
+                    phys_sizes.append(need)
                 vmap[t.vbuf] = p
             for v, lu in list(last_use.items()):
                 if lu == i and v in vmap and not self.vbufs[v][1]:
-                    free.append(vmap[v])
+                    free.append((vmap[v], i, lanes_of[v]))
                     del last_use[v]
         return vmap, phys_sizes
 
@@ -305,6 +332,7 @@ class BackbonePlan:
                                                            xs, xo, SLOT_SS, op["scale_off"],
                                                            op["shift_off"], ys, yo),
                            "gv_plan_add_scale_shift_act(%s)" % op["name"])
+        self._schedule(vmap)
         tdtype = torch.float32
         self.weights = torch.zeros(max(self.w_elems, 4), dtype=tdtype, device=device)
         self.ss = torch.zeros(max(self.ss_elems, 4), dtype=torch.float32, device=device)
@@ -312,6 +340,50 @@ class BackbonePlan:
         self._bufs = [None, self.weights, self.ss] + self.act
         self.act_bytes = sum(phys_sizes) * 4
         return self
+
+    def _schedule(self, vmap):
+        """Cross-lane dependencies: an op waits for every earlier op whose access to the same physical
+        buffer conflicts with its own (read-after-write, write-after-read, write-after-write);
+        accesses to disjoint channel slices of one tensor do not conflict."""
+        lanes = sorted({op["lane"] for op in self.ops})
+        self.lanes_used = len(lanes)
+        if not self.use_lanes or len(lanes) == 1:
+            return
+        history = {}                      # phys -> [(op, is_write, vbuf, lo, hi)]
+        hb = []                           # hb[i]: ops known complete before op i starts
+        last_on_lane = {}
+        for i, op in enumerate(self.ops):
+            acc = []
+            for key, is_w in (("x", False), ("res", False), ("y", True), ("y2", True)):
+                t = op.get(key)
+                if t is not None and t.vbuf >= 0:
+                    lo = t.off % t.ld
+                    acc.append((vmap[t.vbuf], is_w, t.vbuf, lo, lo + t.c))
+            need = set()
+            for ph, is_w, vb, lo, hi in acc:
+                for (j, jw, jvb, jlo, jhi) in history.get(ph, ()):
+                    if not (is_w or jw):
+                        continue
+                    if jvb == vb and (hi <= jlo or jhi <= lo):
+                        continue
+                    need.add(j)
+            prev = last_on_lane.get(op["lane"])
+            known = set() if prev is None else (hb[prev] | {prev})
+            deps = []
+            for j in sorted(need, reverse=True):          # latest first: it usually implies the older ones
+                if j in known:
+                    continue
+                assert self.ops[j]["lane"] != op["lane"]
+                deps.append(j)
+                known |= hb[j] | {j}
+            hb.append(known)
+            last_on_lane[op["lane"]] = i
+            for ph, is_w, vb, lo, hi in acc:
+                history.setdefault(ph, []).append((i, is_w, vb, lo, hi))
+            op["deps"] = sorted(deps)
+            arr = (C.c_int32 * max(len(deps), 1))(*sorted(deps))
+            _lib.check(self.lib.gv_plan_set_schedule(self._plan, i, op["lane"], arr, len(deps)),
+                       "gv_plan_set_schedule(%s)" % op["name"])
 
     def view(self, t):
         """torch view [nb,h,w,c] of a plan tensor (strided when it is a channel slice)."""
@@ -498,11 +570,13 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         out = b.new_tensor(x.nb, x.h, x.w, 64 + 64 + 96 + pool_depth)
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 64), (s + "Branch_1/" + b1a, 48),
                               (s + "Branch_2/Conv2d_0a_1x1", 64)], out.channels(0, 64))
-        conv(t1, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
+        with b.lane(1):
+            conv(t1, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
         t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 96, 3)
         conv(t, s + "Branch_2/Conv2d_0c_3x3", 96, 3, out=out.channels(128, 224))
-        t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-        conv(t, s + "Branch_3/Conv2d_0b_1x1", pool_depth, 1, out=out.channels(224, 224 + pool_depth))
+        with b.lane(2):
+            t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+            conv(t, s + "Branch_3/Conv2d_0b_1x1", pool_depth, 1, out=out.channels(224, 224 + pool_depth))
         return out
 
     net = mixed5(net, "Mixed_5b", "Conv2d_0a_1x1", "Conv2d_0b_5x5", 32)
@@ -518,10 +592,12 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     ow = (net.w - 3) // 2 + 1
     out = b.new_tensor(net.nb, oh, ow, 384 + 96 + net.c)
     conv(net, s + "Branch_0/Conv2d_1a_1x1", 384, 3, 2, "VALID", out=out.channels(0, 384))
-    t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 64, 1)
-    t = conv(t, s + "Branch_1/Conv2d_0b_3x3", 96, 3)
-    conv(t, s + "Branch_1/Conv2d_1a_1x1", 96, 3, 2, "VALID", out=out.channels(384, 480))
-    b.pool(net, 3, 2, "VALID", MAX, out=out.channels(480, 480 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
+    with b.lane(1):
+        t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 64, 1)
+        t = conv(t, s + "Branch_1/Conv2d_0b_3x3", 96, 3)
+        conv(t, s + "Branch_1/Conv2d_1a_1x1", 96, 3, 2, "VALID", out=out.channels(384, 480))
+    with b.lane(2):
+        b.pool(net, 3, 2, "VALID", MAX, out=out.channels(480, 480 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
     net = out
     if done("Mixed_6a", net): return net
 
@@ -530,14 +606,16 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         out = b.new_tensor(x.nb, x.h, x.w, 768)
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 192), (s + "Branch_1/Conv2d_0a_1x1", d),
                               (s + "Branch_2/Conv2d_0a_1x1", d)], out.channels(0, 192))
-        t = conv(t1, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
-        conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), out=out.channels(192, 384))
+        with b.lane(1):
+            t = conv(t1, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
+            conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), out=out.channels(192, 384))
         t = conv(t2, s + "Branch_2/Conv2d_0b_7x1", d, (7, 1))
         t = conv(t, s + "Branch_2/Conv2d_0c_1x7", d, (1, 7))
         t = conv(t, s + "Branch_2/Conv2d_0d_7x1", d, (7, 1))
         conv(t, s + "Branch_2/Conv2d_0e_1x7", 192, (1, 7), out=out.channels(384, 576))
-        t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-        conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(576, 768))
+        with b.lane(2):
+            t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+            conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(576, 768))
         return out
 
     for name, d in (("Mixed_6b", 128), ("Mixed_6c", 160), ("Mixed_6d", 160), ("Mixed_6e", 192)):
@@ -551,11 +629,13 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     out = b.new_tensor(net.nb, oh, ow, 320 + 192 + net.c)
     t = conv(net, s + "Branch_0/Conv2d_0a_1x1", 192, 1)
     conv(t, s + "Branch_0/Conv2d_1a_3x3", 320, 3, 2, "VALID", out=out.channels(0, 320))
-    t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 192, 1)
-    t = conv(t, s + "Branch_1/Conv2d_0b_1x7", 192, (1, 7))
-    t = conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1))
-    conv(t, s + "Branch_1/Conv2d_1a_3x3", 192, 3, 2, "VALID", out=out.channels(320, 512))
-    b.pool(net, 3, 2, "VALID", MAX, out=out.channels(512, 512 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
+    with b.lane(1):
+        t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 192, 1)
+        t = conv(t, s + "Branch_1/Conv2d_0b_1x7", 192, (1, 7))
+        t = conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1))
+        conv(t, s + "Branch_1/Conv2d_1a_3x3", 192, 3, 2, "VALID", out=out.channels(320, 512))
+    with b.lane(2):
+        b.pool(net, 3, 2, "VALID", MAX, out=out.channels(512, 512 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
     net = out
     if done("Mixed_7a", net): return net
 
@@ -564,13 +644,15 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         out = b.new_tensor(x.nb, x.h, x.w, 2048)
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 320), (s + "Branch_1/Conv2d_0a_1x1", 384),
                               (s + "Branch_2/Conv2d_0a_1x1", 448)], out.channels(0, 320))
-        conv(t1, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
-        conv(t1, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
+        with b.lane(1):
+            conv(t1, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
+            conv(t1, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
         t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 384, 3)
         conv(t, s + "Branch_2/" + b2_names[0], 384, (1, 3), out=out.channels(1088, 1472))
         conv(t, s + "Branch_2/" + b2_names[1], 384, (3, 1), out=out.channels(1472, 1856))
-        t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-        conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(1856, 2048))
+        with b.lane(2):
+            t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+            conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(1856, 2048))
         return out
 
     net = mixed7(net, "Mixed_7b", "Conv2d_0b_3x1", ("Conv2d_0c_1x3", "Conv2d_0d_3x1"))
@@ -638,8 +720,9 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32"):
+              math="f32", lanes=True):
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
+    b.use_lanes = bool(lanes)
     raw_tap = raw_tap or TAPS[backbone][0]
     final_tap = final_tap or TAPS[backbone][1]
     if backbone == "inception_v3":

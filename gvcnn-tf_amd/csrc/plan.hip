@@ -28,6 +28,11 @@ struct Op {
     int64_t npix;
     int32_t c, x_ld, y_ld, relu, dtype;
     Ref x, w, scale, shift, res, y, y2, scale2, shift2;
+    // schedule: launch lane (0 = the caller's stream) and the earlier ops on OTHER lanes this op
+    // must wait for (data or buffer-reuse hazards); same-lane order is stream order.
+    int32_t lane = 0;
+    std::vector<int32_t> deps;
+    bool signal = false;        // some later op on another lane waits for this one
 };
 
 inline size_t elem_size(int dtype) { return dtype == GV_BF16 ? 2 : 4; }
@@ -37,6 +42,18 @@ inline size_t elem_size(int dtype) { return dtype == GV_BF16 ? 2 : 4; }
 struct gv_plan {
     std::vector<Op> ops;
     int32_t max_slot = -1;
+    int32_t num_lanes = 1;
+    // lazily created on the first multi-lane run (the plan is then not re-entrant across streams)
+    std::vector<hipStream_t> lane_streams;      // [0] unused (caller's stream)
+    std::vector<hipEvent_t> op_events;          // one per op with `signal`
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
+    ~gv_plan() {
+        for (size_t i = 1; i < lane_streams.size(); ++i) if (lane_streams[i]) (void)hipStreamDestroy(lane_streams[i]);
+        for (hipEvent_t e : op_events) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_join) if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+    }
 };
 
 namespace {
@@ -134,6 +151,24 @@ extern "C" int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_
     return GV_OK;
 }
 
+extern "C" int gv_plan_set_schedule(gv_plan* p, int32_t op_index, int32_t lane, const int32_t* deps,
+                                    int32_t num_deps) {
+    if (!p) return GV_E_PLAN;
+    if (op_index < 0 || (size_t)op_index >= p->ops.size() || lane < 0 || lane >= 8 || num_deps < 0 ||
+        (num_deps > 0 && !deps))
+        return GV_E_BADARG;
+    if (!p->lane_streams.empty()) return GV_E_PLAN;          // schedule is frozen after the first run
+    Op& o = p->ops[(size_t)op_index];
+    o.lane = lane;
+    o.deps.clear();
+    for (int32_t i = 0; i < num_deps; ++i) {
+        if (deps[i] < 0 || deps[i] >= op_index) return GV_E_BADARG;   // only earlier ops
+        o.deps.push_back(deps[i]);
+    }
+    if (lane + 1 > p->num_lanes) p->num_lanes = lane + 1;
+    return GV_OK;
+}
+
 extern "C" int gv_plan_add_pool(gv_plan* p, const gv_pool_desc* d, int32_t x_slot, int64_t x_off,
                                 int32_t y_slot, int64_t y_off) {
     if (!p) return GV_E_PLAN;
@@ -169,6 +204,44 @@ extern "C" int gv_plan_add_scale_shift_act(gv_plan* p, int64_t npix, int32_t c, 
     return GV_OK;
 }
 
+// Fork/join over the plan's lanes: lane 0 is the caller's stream, the others are plan-owned streams
+// that wait for the caller's stream at the start and are joined back at the end, so from outside
+// the run is ordered on `stream` like a single-stream run (and can be captured into a hipGraph).
+static int run_lanes(gv_plan* p, void* const* bufs, hipStream_t main) {
+    const int nl = p->num_lanes;
+    if (p->lane_streams.empty()) {
+        p->lane_streams.assign((size_t)nl, nullptr);
+        p->ev_join.assign((size_t)nl, nullptr);
+        for (int l = 1; l < nl; ++l) {
+            GV_HIP_CHECK(hipStreamCreateWithFlags(&p->lane_streams[(size_t)l], hipStreamNonBlocking));
+            GV_HIP_CHECK(hipEventCreateWithFlags(&p->ev_join[(size_t)l], hipEventDisableTiming));
+        }
+        GV_HIP_CHECK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        p->op_events.assign(p->ops.size(), nullptr);
+        for (size_t i = 0; i < p->ops.size(); ++i)
+            for (int32_t d : p->ops[i].deps)
+                if (p->ops[(size_t)d].lane != p->ops[i].lane) p->ops[(size_t)d].signal = true;
+        for (size_t i = 0; i < p->ops.size(); ++i)
+            if (p->ops[i].signal) GV_HIP_CHECK(hipEventCreateWithFlags(&p->op_events[i], hipEventDisableTiming));
+    }
+    GV_HIP_CHECK(hipEventRecord(p->ev_fork, main));
+    for (int l = 1; l < nl; ++l) GV_HIP_CHECK(hipStreamWaitEvent(p->lane_streams[(size_t)l], p->ev_fork, 0));
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const Op& o = p->ops[i];
+        hipStream_t st = o.lane == 0 ? main : p->lane_streams[(size_t)o.lane];
+        for (int32_t d : o.deps)
+            if (p->ops[(size_t)d].lane != o.lane) GV_HIP_CHECK(hipStreamWaitEvent(st, p->op_events[(size_t)d], 0));
+        const int rc = run_op(o, bufs, (void*)st);
+        if (rc != GV_OK) return rc;
+        if (o.signal) GV_HIP_CHECK(hipEventRecord(p->op_events[i], st));
+    }
+    for (int l = 1; l < nl; ++l) {
+        GV_HIP_CHECK(hipEventRecord(p->ev_join[(size_t)l], p->lane_streams[(size_t)l]));
+        GV_HIP_CHECK(hipStreamWaitEvent(main, p->ev_join[(size_t)l], 0));
+    }
+    return GV_OK;
+}
+
 extern "C" int gv_plan_run_range(const gv_plan* p, int32_t first, int32_t count,
                                  void* const* buffers_host, int32_t num_slots, void* stream) {
     if (!p) return GV_E_PLAN;
@@ -177,6 +250,8 @@ extern "C" int gv_plan_run_range(const gv_plan* p, int32_t first, int32_t count,
     if (num_slots <= p->max_slot) return GV_E_PLAN;
     for (int32_t i = 0; i <= p->max_slot; ++i)
         if (!buffers_host[i]) return GV_E_BADARG;
+    if (p->num_lanes > 1 && first == 0 && (size_t)count == p->ops.size())
+        return run_lanes(const_cast<gv_plan*>(p), buffers_host, (hipStream_t)stream);
     for (int32_t i = first; i < first + count; ++i) {
         const int rc = run_op(p->ops[(size_t)i], buffers_host, stream);
         if (rc != GV_OK) return rc;

@@ -73,6 +73,55 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
     }
 }
 
+// 3x3 / stride 1 / SAME average pool (slim.avg_pool2d under the Inception arg-scope,
+// nets/inception_v3.py:152,...): one thread produces 4 horizontally adjacent outputs of a 4-channel
+// group from a 3x6 input patch (column sums are shared), i.e. 18 16-byte loads for 4 outputs
+// instead of 36 — the generic kernel is L2-request bound on this op (2.4 TB/s).
+__global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __restrict__ x,
+                                                             float* __restrict__ y, int nb, int ih,
+                                                             int iw, int c, int x_ld, int y_ld) {
+    const int cg = c >> 2;
+    const int wg = (iw + 3) >> 2;
+    const int64_t total = (int64_t)nb * ih * wg * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int xg = (int)(t % wg);
+        t /= wg;
+        const int oy = (int)(t % ih);
+        const int n = (int)(t / ih);
+        const int ox0 = xg * 4;
+        f32x4 col[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) col[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int rows = 0;
+#pragma unroll
+        for (int r = -1; r <= 1; ++r) {
+            const int iy = oy + r;
+            if ((unsigned)iy >= (unsigned)ih) continue;
+            ++rows;
+            const float* rowp = x + ((size_t)(n * ih + iy) * iw) * x_ld + g * 4;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = ox0 - 1 + j;
+                if ((unsigned)ix < (unsigned)iw) col[j] += *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * x_ld);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = ox0 + j;
+            if (ox >= iw) break;
+            const int cols = 1 + (ox > 0 ? 1 : 0) + (ox + 1 < iw ? 1 : 0);
+            const float inv = (float)(rows * cols);           // valid taps only (TF SAME semantics)
+            f32x4 v = col[j] + col[j + 1] + col[j + 2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / inv;
+            *reinterpret_cast<f32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 4) = v;
+        }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void scale_shift_act_f32(const float* __restrict__ x, int64_t npix,
                                                            int c, int x_ld,
@@ -139,6 +188,14 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
                      gv_aligned16(y);
     const int64_t total = (int64_t)d->nb * d->oh * d->ow * (vec ? d->c / 4 : d->c);
     hipStream_t st = (hipStream_t)stream;
+    if (vec && d->mode == GV_POOL_AVG && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
+        d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
+        const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
+        hipLaunchKernelGGL(avgpool3x3s1_row4_f32, dim3(grid_for(tot4)), dim3(256), 0, st, (const float*)x,
+                           (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     if (vec)
         hipLaunchKernelGGL(pool2d_f32<4>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x,
                            (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->kh, d->kw, d->stride,

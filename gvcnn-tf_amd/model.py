@@ -180,7 +180,7 @@ class GVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=1, num_views=12, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, seed=2,
-                 math="f32"):
+                 math="f32", lanes=True):
         self.lib = _lib.load()
         self.device = _dev(device)
         self.backbone = backbone
@@ -191,7 +191,7 @@ class GVCNN:
             raise ValueError("num_views and num_group are limited to 64")
         with torch.cuda.device(self.device):
             self.plan = backbones.make_plan(backbone, num_shapes * num_views, height, width,
-                                            self.device, raw_tap, final_tap, math=math)
+                                            self.device, raw_tap, final_tap, math=math, lanes=lanes)
             self.raw = self.plan.end_points[self.plan.raw_tap]
             self.final = self.plan.end_points[self.plan.final_tap]
             if backbone_params is None:

@@ -205,6 +205,14 @@ int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d,
                      int32_t y2_slot, int64_t y2_off, int64_t scale2_off, int64_t shift2_off);
 /* Set gv_conv_desc.tile_cfg of conv op `op_index` (plan-time autotuning; speed only). */
 int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg);
+/* Branch-level concurrency: put op `op_index` on launch lane `lane` (0 = the caller's stream, 1..7 =
+ * plan-owned streams) and name the EARLIER ops it must wait for (producers of its inputs, and ops
+ * still using a buffer it overwrites).  A whole-plan run then forks the lanes off `stream` and joins
+ * them back, so the independent branches of an Inception block (nets/inception_v3.py:139-155) overlap
+ * and one kernel's tail is filled by another's workgroups.  Partial runs stay single-lane.  A plan
+ * with lanes owns its streams/events: do not run it from two host threads at once. */
+int gv_plan_set_schedule(gv_plan* p, int32_t op_index, int32_t lane, const int32_t* deps,
+                         int32_t num_deps);
 int gv_plan_add_pool(gv_plan* p, const gv_pool_desc* d, int32_t x_slot, int64_t x_off,
                      int32_t y_slot, int64_t y_off);
 int gv_plan_add_scale_shift_act(gv_plan* p, int64_t npix, int32_t c, int32_t x_ld, int32_t y_ld,
