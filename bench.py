@@ -26,6 +26,14 @@ import torch                                    # noqa: E402
 import torch.distributed as dist                # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0                  # MI355X_MICROARCH.md: bf16 MFMA dense (spec)
+# fp32 products evaluated as N bf16 MFMA passes (GV_MATH_*): the ceiling in ALGORITHMIC fp32 FLOPs
+MATH = {"f32": ("conv_igemm_f32", PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 (exact fp32 chain)"),
+        "bf16x3": ("conv_igemm_bf16s<NP=3>", PEAK_BF16_MFMA_TFLOPS / 6,
+                   "fp32 operands split into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per product block, "
+                   "fp32 accumulate: fp32-level accuracy (dropped terms <= 2^-24 relative); peak = bf16 dense / 6"),
+        "bf16x2": ("conv_igemm_bf16s<NP=2>", PEAK_BF16_MFMA_TFLOPS / 3, "2 bf16 planes, 3 MFMAs (~2^-16 relative)"),
+        "bf16x1": ("conv_igemm_bf16s<NP=1>", PEAK_BF16_MFMA_TFLOPS, "plain bf16 products, fp32 accumulate")}
 V, H, W, G, C = 12, 224, 224, 7, 10             # configs[1]; ModelNet10 -> 10 classes
 BACKBONE = "inception_v3"
 
@@ -39,14 +47,15 @@ def parse():
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "scores"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32-MFMA reference run")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
+    ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
     return ap.parse_args()
 
 
-def roofline(eng, x, iters=5):
+def roofline(eng, x, math, iters=5):
     """Per-launch hipEvent timing (on the launch stream) of every implicit-GEMM conv launch of one
     step; achieved = algorithmic conv FLOPs of the step / summed conv kernel time."""
     plan = eng.plan
@@ -64,9 +73,10 @@ def roofline(eng, x, iters=5):
         if worst is None or ms > worst[1]:
             worst = (op["name"], ms, tf)
     achieved = flops / (t_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_f32<*> (%d launches/step)" % n,
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+    kname, peak, how = MATH[math]
+    return {"bound": "mfma", "kernel": "%s<*> (%d launches/step)" % (kname, n), "math": how,
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
             "flops_per_step": flops, "avg_launch_us": round(t_ms * 1e3 / n, 2),
             "conv_ms_per_step": round(t_ms, 3),
             "longest_launch": {"name": worst[0], "ms": round(worst[1], 4), "tflops": round(worst[2], 2)}}
@@ -171,7 +181,30 @@ def main():
         step_tflops = eng.plan.total_flops / (ms * 1e-3) / 1e12
         out["step_tflops_per_gpu"] = round(step_tflops, 2)
         if not a.no_roofline:
-            out["roofline"] = roofline(eng, x)
+            out["roofline"] = roofline(eng, x.view(N * V, H, W, 3), a.math)
+        out["config"]["math"] = a.math + ": " + MATH[a.math][2]
+        out["config"]["branch_lanes"] = eng.plan.lanes_used if not a.no_lanes else 1
+        if world == 1 and a.math != "f32" and not a.no_exact:
+            # the same step on the exact fp32 MFMA path, for reference (short run, same inputs)
+            e32 = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math="f32", lanes=not a.no_lanes)
+            e32.plan.bind(P)
+            e32.set_head(Hd)
+            e32.plan.autotune(x.view(N * V, H, W, 3))
+            for _ in range(2):
+                e32.forward(x, check=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                e32.forward(x, check=False)
+            torch.cuda.synchronize()
+            ms32 = (time.perf_counter() - t1) / 5 * 1e3
+            r32 = roofline(e32, x.view(N * V, H, W, 3), "f32", iters=3)
+            dS = float((e32.shape_descriptor - eng.shape_descriptor).abs().max() /
+                       e32.shape_descriptor.abs().max())
+            out["exact_f32_mfma"] = {"views_per_sec": round(N * V / (ms32 * 1e-3), 1), "ms_per_step": round(ms32, 3),
+                                     "roofline_frac": r32["frac"], "achieved_tflops": r32["achieved"],
+                                     "max_rel_diff_shape_descriptor_vs_default_math": dS}
+            del e32
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, Hd, a.cpu_seconds)
     if world > 1:

@@ -63,13 +63,14 @@ __device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, bool ok, u32x4 (&out)
 }
 
 template <int WM, int WN, int TM, int TN, int NP, bool GENERIC>
-__global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs a) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    constexpr int NT = WM * WN * 64;                 // threads
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int RB = NP * 32 + 16;                 // LDS row bytes
-    constexpr int A_SLOTS = (BM * 2 + 255) / 256;    // (row, half) slots: 8 fp32 each
-    constexpr int B_SLOTS = (BN * 2 + 255) / 256;
+    constexpr int A_SLOTS = (BM * 2 + NT - 1) / NT;  // (row, half) slots: 8 fp32 each
+    constexpr int B_SLOTS = (BN * 2 + NT - 1) / NT;
     constexpr int NMF = TM * TN * prod_count(NP);              // MFMAs per k-tile
     constexpr int HALF = (NMF + 1) / 2;
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
     const int ohow = a.oh * a.ow;
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         const int row = slot_row(idx);
         const int m = m0 + row;
         if (row < BM && m < a.M) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
     bool b_ok[B_SLOTS];
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         const int row = slot_row(idx);
         const int n = n0 + row;
         b_ok[i] = (row < BN);
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
         constexpr int RS = decltype(rsc)::value;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
-            const int half = (tid + i * 256) & 1;
+            const int half = (tid + i * NT) & 1;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (!GENERIC) {
                 // unconditional loads from a clamped (always valid) address; padding taps and rows past
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
         constexpr int RS = decltype(rsc)::value;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
-            const int idx = tid + i * 256;
-            if (A_SLOTS * 256 == BM * 2 || idx < BM * 2) {
+            const int idx = tid + i * NT;
+            if (A_SLOTS * NT == BM * 2 || idx < BM * 2) {
                 u32x4 pl[NP];
                 split8<NP>(ra[RS][i][0], ra[RS][i][1], aok[RS][i], pl);
                 char* dst = sA + buf * BM * RB + slot_row(idx) * RB + 16 * (idx & 1);
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16s(const ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
-            const int idx = tid + i * 256;
-            if (B_SLOTS * 256 == BN * 2 || b_ok[i]) {
+            const int idx = tid + i * NT;
+            if (B_SLOTS * NT == BN * 2 || b_ok[i]) {
                 char* dst = sB + buf * BN * RB + slot_row(idx) * RB + 16 * (idx & 1);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = rb[RS][i][p];
@@ -321,7 +322,8 @@ __global__ void pack_filter_bf16s(const float* __restrict__ w, int K, int ktiles
 }
 
 struct TileCfg { int bm, bn; };
-constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32}};
+constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32},
+                              {256, 128}, {128, 256}, {256, 64}};   // the last three: 8 waves
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int WM, int WN, int TM, int TN, int NP>
@@ -339,14 +341,14 @@ int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             if (!ok) return GV_E_UNSUPPORTED;
         }
-        hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, true>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
     } else {
         if (lds > 64 * 1024) {
             static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
             if (!ok) return GV_E_UNSUPPORTED;
         }
-        hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, false>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, false>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
     }
     GV_LAUNCH_CHECK();
     return GV_OK;
@@ -361,6 +363,9 @@ int launch_np(int cfg, const ConvArgs& a, bool generic, hipStream_t st) {
         case 3: return launch_cfg<4, 1, 1, 3, NP>(a, generic, st);
         case 4: return launch_cfg<2, 2, 1, 2, NP>(a, generic, st);
         case 5: return launch_cfg<4, 1, 1, 1, NP>(a, generic, st);
+        case 6: return launch_cfg<4, 2, 2, 2, NP>(a, generic, st);
+        case 7: return launch_cfg<2, 4, 2, 2, NP>(a, generic, st);
+        case 8: return launch_cfg<4, 2, 2, 1, NP>(a, generic, st);
     }
     return GV_E_UNSUPPORTED;
 }

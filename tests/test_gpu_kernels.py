@@ -409,7 +409,7 @@ def test_conv_bf16_split_vs_oracle(math, k, stride, padding, cin, cout):
     np.testing.assert_allclose(y, ref.numpy(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("tile", list(range(6)))
+@pytest.mark.parametrize("tile", list(range(9)))
 @pytest.mark.parametrize("cout", [32, 80, 200])
 def test_conv_bf16x3_every_tile_config(tile, cout):
     g = torch.Generator().manual_seed(tile * 100 + cout)
