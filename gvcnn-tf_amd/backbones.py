@@ -460,6 +460,13 @@ class BackbonePlan:
         _lib.check(self.lib.gv_plan_run_range(self._plan, first, count, ptrs, len(self._bufs),
                                               _stream_ptr(stream)), "gv_plan_run_range")
 
+    def apply_tiles(self, table):
+        """Install a previously measured {op name: tile configuration} table (no launches)."""
+        for i, op in enumerate(self.ops):
+            if op["kind"] == "conv" and op["name"] in table:
+                op["tile"] = int(table[op["name"]]) + 1
+                _lib.check(self.lib.gv_plan_set_conv_tile(self._plan, i, op["tile"]), "gv_plan_set_conv_tile")
+
     def autotune(self, x, iters=3, verbose=False):
         """Pick, per conv launch, the fastest tile configuration by timing each on this device with
         the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
