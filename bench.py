@@ -8,7 +8,9 @@ shape, Inception-v3 backbone, num_groups = 7, fp32, forward only (inference Batc
 is one pass of the whole hot path — folded backbone over all views, scorer, device-side group
 assignment, view pooling + group fusion, classifier — over one batch that is already resident in
 HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed.run); per-GPU work is fixed
-(weak scaling) and the ranks exchange scorer responses and final view descriptors over RCCL.
+(weak scaling): the batch is cut on shape boundaries, the ranks all-gather the scorer responses over
+RCCL (the batch-mean score of nets/model.py:146 is the only coupling), and each rank pools the shapes
+it owns; --exchange allgather additionally all-gathers the final view descriptors.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,7 +46,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shapes", type=int, default=32, help="shapes per GPU per step (x12 views)")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "scores"])
+    ap.add_argument("--exchange", default="scores", choices=["allgather", "scores"],
+                    help="multi-GPU: 'scores' exchanges only the scorer responses (each rank pools the shapes it "
+                         "owns); 'allgather' also all-gathers the final view descriptors (north_star form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tile-cache", default=None, help="JSON file with measured per-launch tile choices")
