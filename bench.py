@@ -38,6 +38,9 @@ MATH = {"f32": ("conv_igemm_f32", PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 
         "bf16x1": ("conv_igemm_bf16s<NP=1>", PEAK_BF16_MFMA_TFLOPS, "plain bf16 products, fp32 accumulate")}
 V, H, W, G, C = 12, 224, 224, 7, 10             # configs[1]; ModelNet10 -> 10 classes
 BACKBONE = "inception_v3"
+# other BASELINE.json configs, fp32 forward variants (parity-test cases; not the bench line)
+PRESETS = {"c2": ("inception_v3", 12, 224, 7, 10), "c4": ("resnet_v2_50", 12, 224, 10, 40),
+           "c5": ("inception_v3", 20, 299, 10, 40)}
 
 
 def parse():
@@ -54,6 +57,7 @@ def parse():
     ap.add_argument("--tile-cache", default=None, help="JSON file with measured per-launch tile choices")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32-MFMA reference run")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--preset", default="c2", choices=sorted(PRESETS), help="c2 = BASELINE.json configs[1] (the bench line)")
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
     ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
@@ -116,7 +120,10 @@ def cpu_baseline(P, Hd, seconds):
 
 
 def main():
+    global BACKBONE, V, H, W, G, C
     a = parse()
+    BACKBONE, V, H, G, C = PRESETS[a.preset]
+    W = H
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,9 +189,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: ModelNet10-shaped, 12 views x 224x224x3, "
-                                   "Inception-v3 backbone (raw tap Mixed_6e, final tap Mixed_7c), "
-                                   "num_groups=7, fp32, forward only",
+            "config": {"workload": ("BASELINE.json configs[1]: " if a.preset == "c2" else "preset %s (fp32 forward variant): " % a.preset)
+                                   + "ModelNet-shaped, %d views x %dx%dx3, %s backbone (raw tap %s, final tap %s), "
+                                     "num_groups=%d, fp32, forward only" % (V, H, W, BACKBONE, eng.plan.raw_tap,
+                                                                            eng.plan.final_tap, G),
                        "shapes_per_gpu": N, "views_per_gpu": N * V, "global_views": views_per_step,
                        "num_groups": G, "num_classes": C,
                        "exchange": a.exchange if world > 1 else "none",

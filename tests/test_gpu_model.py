@@ -176,3 +176,30 @@ def test_bf16x3_math_matches_oracle_at_fp32_tolerance(backbone, size):
     err_x3 = float(np.abs(S.cpu().numpy() - o_S).max())
     err_32 = float(np.abs(S32.cpu().numpy() - o_S).max())
     assert err_x3 < 4 * err_32 + 1e-6 * float(np.abs(o_S).max())      # same error class as exact fp32
+
+
+@pytest.mark.parametrize("backbone,V,size,G,math", [("inception_v3", 20, 299, 10, "bf16x3"),
+                                                     ("resnet_v2_50", 12, 224, 10, "bf16x3"),
+                                                     ("resnet_v2_50", 12, 224, 10, "f32")])
+def test_other_baseline_configs_properties(backbone, V, size, G, math):
+    """BASELINE.json configs[3]/[4] geometries (ResNet-v2-50 12x224; Inception 20 views x 299, G=10) in
+    fp32: size-independent checks, plus the oracle backbone on ONE image of the batch."""
+    N, C = 2, 40
+    eng, P, Hd = make_engine(backbone, N, V, size, size, C, G, math=math)
+    x = views(N, V, size, size, seed=5)
+    scores, S, logits = eng.forward(x.to(DEV))
+    F = eng.final_view_descriptors().clone()
+    assert tuple(F.shape[2:]) == ((8, 8, 2048) if size == 299 else (7, 7, 2048))
+    assert float(eng.weight.sum()) == G + V and torch.isfinite(logits).all()
+    # one image through the CPU oracle backbone (folded == per-view in inference mode)
+    b = 7
+    ep = OM.run_backbone(backbone, x.reshape(N * V, size, size, 3)[b:b + 1], P)
+    assert_close(F.reshape(N * V, *F.shape[2:])[b].cpu().numpy(), ep[eng.plan.final_tap][0].numpy())
+    assert_close(eng.raw_view_descriptors().reshape(N * V, *eng.raw_view_descriptors().shape[2:])[b].cpu().numpy(),
+                 ep[eng.plan.raw_tap][0].numpy())
+    # oracle grouping head on the device descriptors
+    oS, oL = OG.grouping_head([F[:, v].cpu().numpy() for v in range(V)], eng.scheme.cpu().numpy(),
+                              eng.weight.cpu().numpy(), Hd["dense_%d/kernel" % V].numpy(),
+                              Hd["dense_%d/bias" % V].numpy())
+    np.testing.assert_allclose(S.cpu().numpy(), oS, rtol=1e-6, atol=1e-6 * float(np.abs(oS).max()))
+    assert_close(logits.cpu().numpy(), oL)
