@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "cin", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
         "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype", "split_col", "tile_cfg",
-        "math_mode")]
+        "math_mode", "in_dilation")]
 
 
 class PoolDesc(C.Structure):
@@ -58,6 +58,19 @@ SIGNATURES = {
     "gv_group_weight": (C.c_int, [_P, _I, _I, _P, _P]),
     "gv_view_pool_fuse_fwd": (C.c_int, [_P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _F, _P, _P, _I, _P]),
     "gv_dense_fwd": (C.c_int, [_P, _I, _I, _P, _P, _I, _P, _P]),
+    "gv_bn_stats_grouped": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_scale_shift_act_grouped": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P]),
+    "gv_bn_relu_bwd_grouped": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P,
+                                         _P, _P]),
+    "gv_accumulate": (C.c_int, [_P, _I, _P, _I, _L, _I, _P]),
+    "gv_bias_grad": (C.c_int, [_P, _I, _L, _I, _P, _P, _P]),
+    "gv_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
+    "gv_pool2d_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _I, _P, _I, _P]),
+    "gv_view_pool_fuse_bwd": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P]),
+    "gv_global_avg_pool_bwd": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
+    "gv_softmax_ce": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
+    "gv_dense_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "gv_sgd_momentum": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _P]),
     "gv_plan_create": (C.c_int, [C.POINTER(_P)]),
     "gv_plan_destroy": (None, [_P]),
     "gv_plan_num_ops": (C.c_int, [_P]),

@@ -148,9 +148,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
                 // unconditional loads from a clamped (always valid) address; padding taps and rows past
                 // M are zeroed / ignored later.  No divergent branch => the compiler can count vmcnt and
                 // leave the younger tile's loads in flight.
-                const int iy = a_iy0[i] + fr;
-                const int ix = a_ix0[i] + fs;
-                aok[RS][i] = (unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw && fr < a.kh;
+                const int iyn = a_iy0[i] + fr;
+                const int ixn = a_ix0[i] + fs;
+                // zero-dilated input (data gradient of a strided conv): only positions that are multiples of
+                // the dilation exist, at index >> dil_shift
+                const int dmask = (1 << a.dil_shift) - 1;
+                const int iy = iyn >> a.dil_shift;
+                const int ix = ixn >> a.dil_shift;
+                aok[RS][i] = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw &&
+                             fr < a.kh;
                 const int iyc = min(max(iy, 0), a.ih - 1);
                 const int ixc = min(max(ix, 0), a.iw - 1);
                 const float* p = a.x + ((size_t)(a_img[i] + iyc) * a.iw + ixc) * a.x_ld + fc + 8 * half;

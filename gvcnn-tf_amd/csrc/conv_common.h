@@ -21,6 +21,7 @@ struct ConvArgs {
     int M, K, Kpad, ktiles;
     int relu, relu2, split;     // split > 0: columns >= split go to y2 (same scale/shift/relu)
     int tiles_n;
+    int dil_shift;              // 0: plain; 1: input read as zero-dilated by 2 (stride-2 data gradient)
     int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
 };
 

@@ -424,8 +424,12 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     if (d->x_ld < d->cin) return GV_E_BADARG;
     if (residual && d->res_ld < d->cout) return GV_E_BADARG;
     // the window of the last output must start inside the padded input
-    if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
-        return GV_E_BADARG;
+    {
+        // (a data-gradient launch may legitimately have output rows no window reaches: they get zeros)
+        if (d->in_dilation != 2 && ((d->oh - 1) * d->stride - d->pad_t >= d->ih ||
+                                    (d->ow - 1) * d->stride - d->pad_l >= d->iw))
+            return GV_E_BADARG;
+    }
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
     const int np = planes_of(d->math_mode);
     if (np < 0) return GV_E_BADARG;
@@ -451,6 +455,9 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.split = split ? d->split_col : 0;
     a.tiles_n = 0;
     a.dbg = g_debug;
+    if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) return GV_E_BADARG;
+    a.dil_shift = d->in_dilation == 2 ? 1 : 0;
+    if (a.dil_shift && (np == 0 || (d->cin % CH != 0) || d->stride != 1)) return GV_E_UNSUPPORTED;
 
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
     const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);

@@ -1,0 +1,592 @@
+// train.hip — kernels that exist only for the training step of the hot path:
+// batch-statistics BatchNorm grouped by view (the reference builds one graph copy per view, so every
+// BN normalises over the N*h*w values of ONE view: nets/model.py:129-141 + slim.batch_norm with
+// is_training=True), the backward of every forward op, the loss (train.py:145) and the Momentum
+// update (train.py:171).  fp32 storage; reductions accumulate in fp64 (HBM-bound kernels, the fp64
+// adds are free) so that per-(view, channel) sums over up to 1.5e5 pixels are reproducible to fp32.
+#include <math.h>
+
+#include "gv_common.h"
+
+namespace {
+
+// dst[p][c] += src[p][c]  (gradient fan-in of the residual add, nets/resnet_v2.py:91)
+__global__ __launch_bounds__(256) void accumulate_f32(const float* __restrict__ src, int src_ld,
+                                                      float* __restrict__ dst, int dst_ld, int64_t npix, int c) {
+    const int64_t total = npix * c;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        const int64_t pix = idx / c;
+        dst[pix * dst_ld + ch] += src[pix * src_ld + ch];
+    }
+}
+
+// ---- grouped per-(group, channel) sums -----------------------------------------------------------
+// acc[g][c][0] += sum u,  acc[g][c][1] += sum u*w   over the pixels of images b with b % G == g.
+//   MODE 0 (BN forward stats):  u = z,            w = z                       -> sum z, sum z^2
+//   MODE 1 (BN backward):       u = dy*[y>0],     w = (z-mean)*inv            -> sum g, sum g*zhat
+//   MODE 2 (bias gradient):     u = dz,           w = 0
+// Thread layout: 64 consecutive channels x 4 pixel lanes; grid (channel blocks, pixel splits, G).
+template <int MODE>
+__global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict__ z, int z_ld,
+                                                        const float* __restrict__ dy, int dy_ld,
+                                                        const float* __restrict__ y, int y_ld,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ inv, int nb, int hw, int c,
+                                                        int G, double* __restrict__ acc) {
+    const int cl = threadIdx.x & 63;
+    const int pl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl;
+    const int g = blockIdx.z;
+    const int nimg = (nb - g + G - 1) / G;                 // images of this group
+    const int64_t npix = (int64_t)nimg * hw;
+    const int64_t per = (npix + gridDim.y - 1) / gridDim.y;
+    const int64_t p0 = (int64_t)blockIdx.y * per;
+    const int64_t p1 = p0 + per < npix ? p0 + per : npix;
+    double s0 = 0.0, s1 = 0.0;
+    if (ch < c) {
+        float mu = 0.f, iv = 0.f;
+        if (MODE == 1) { mu = mean[g * c + ch]; iv = inv[g * c + ch]; }
+        for (int64_t p = p0 + pl; p < p1; p += 4) {
+            const int k = (int)(p / hw);
+            const int64_t pix = (int64_t)(k * G + g) * hw + (p - (int64_t)k * hw);
+            if (MODE == 0) {
+                const float v = z[pix * z_ld + ch];
+                s0 += v;
+                s1 += (double)v * v;
+            } else if (MODE == 1) {
+                float gr = dy[pix * dy_ld + ch];
+                if (y && !(y[pix * y_ld + ch] > 0.f)) gr = 0.f;
+                s0 += gr;
+                s1 += (double)gr * ((z[pix * z_ld + ch] - mu) * iv);
+            } else {
+                s0 += dy[pix * dy_ld + ch];
+            }
+        }
+    }
+    __shared__ double red[2][4][64];
+    red[0][pl][cl] = s0;
+    red[1][pl][cl] = s1;
+    __syncthreads();
+    if (pl == 0 && ch < c) {
+        s0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        s1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        atomicAdd(&acc[((size_t)g * c + ch) * 2], s0);
+        if (MODE != 2) atomicAdd(&acc[((size_t)g * c + ch) * 2 + 1], s1);
+    }
+}
+
+// mean/var (biased) + folded scale/shift per (group, channel)
+__global__ void bn_finalize_grouped(const double* __restrict__ acc, int G, int c, const int* __restrict__ counts,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                    float* __restrict__ mean, float* __restrict__ var, float* __restrict__ inv,
+                                    float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * c) return;
+    const int g = i / c, ch = i - g * c;
+    const double m = (double)counts[g];
+    const double mu = acc[(size_t)i * 2] / m;
+    double v = acc[(size_t)i * 2 + 1] / m - mu * mu;
+    if (v < 0.0) v = 0.0;
+    const float iv = (float)(1.0 / sqrt(v + (double)eps));
+    const float ga = gamma ? gamma[ch] : 1.f;
+    mean[i] = (float)mu;
+    var[i] = (float)v;
+    inv[i] = iv;
+    scale[i] = iv * ga;
+    shift[i] = beta[ch] - (float)mu * iv * ga;
+}
+
+// y = act(x*scale[g][c] + shift[g][c]),  g = image % G
+__global__ __launch_bounds__(256) void scale_shift_act_grouped_f32(const float* __restrict__ x, int nb, int hw,
+                                                                   int c, int x_ld,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, int G,
+                                                                   int relu, float* __restrict__ y, int y_ld) {
+    const int cg = c >> 2;
+    const int64_t total = (int64_t)nb * hw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int g = (int)((pix / hw) % G);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * x_ld + 4 * q);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (size_t)g * c + 4 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (size_t)g * c + 4 * q);
+        v = v * sc + sh;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + pix * y_ld + 4 * q) = v;
+    }
+}
+
+// dz += gamma*inv * (g - s1/m - zhat*s2/m),  g = dy*[y>0]   (train-mode BN + ReLU backward)
+__global__ __launch_bounds__(256) void bn_bwd_apply_grouped_f32(
+    const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld, const float* __restrict__ z,
+    int z_ld, const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ gamma,
+    const double* __restrict__ acc, const int* __restrict__ counts, int nb, int hw, int c, int G,
+    float* __restrict__ dz, int dz_ld) {
+    const int64_t total = (int64_t)nb * hw * c;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        const int64_t pix = idx / c;
+        const int g = (int)((pix / hw) % G);
+        const int gi = g * c + ch;
+        float gr = dy[pix * dy_ld + ch];
+        if (y && !(y[pix * y_ld + ch] > 0.f)) gr = 0.f;
+        const float iv = inv[gi];
+        const float zh = (z[pix * z_ld + ch] - mean[gi]) * iv;
+        const float m = (float)counts[g];
+        const float s1 = (float)acc[(size_t)gi * 2], s2 = (float)acc[(size_t)gi * 2 + 1];
+        const float coef = (gamma ? gamma[ch] : 1.f) * iv;
+        dz[pix * dz_ld + ch] += coef * (gr - s1 / m - zh * s2 / m);
+    }
+}
+
+// per-channel parameter gradients: dbeta[c] += sum_g acc[g][c][0], dgamma[c] += sum_g acc[g][c][1]
+__global__ void bn_param_grads(const double* __restrict__ acc, int G, int c, float* __restrict__ dbeta,
+                               float* __restrict__ dgamma) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double a = 0.0, b = 0.0;
+    for (int g = 0; g < G; ++g) { a += acc[((size_t)g * c + ch) * 2]; b += acc[((size_t)g * c + ch) * 2 + 1]; }
+    if (dbeta) dbeta[ch] += (float)a;
+    if (dgamma) dgamma[ch] += (float)b;
+}
+
+// ---- pooling backward ------------------------------------------------------------------------------
+// max: the gradient of a window goes to its first maximum in scan order (tf MaxPoolGrad / torch);
+// scatter with atomics because 3x3/2 windows overlap.  avg: dy / (#valid taps) to every valid tap.
+__global__ __launch_bounds__(256) void pool2d_bwd_f32(const float* __restrict__ x, int x_ld,
+                                                      const float* __restrict__ dy, int dy_ld, int nb, int ih,
+                                                      int iw, int c, int kh, int kw, int stride, int pad_t,
+                                                      int pad_l, int oh, int ow, int mode,
+                                                      float* __restrict__ dx, int dx_ld) {
+    const int64_t total = (int64_t)nb * oh * ow * c;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        const int64_t pix = idx / c;
+        const int ox = (int)(pix % ow);
+        const int64_t t = pix / ow;
+        const int oy = (int)(t % oh);
+        const int n = (int)(t / oh);
+        const float g = dy[pix * dy_ld + ch];
+        if (mode == GV_POOL_MAX) {
+            float best = -INFINITY;
+            int64_t arg = -1;
+            for (int r = 0; r < kh; ++r) {
+                const int iy = oy * stride + r - pad_t;
+                if ((unsigned)iy >= (unsigned)ih) continue;
+                for (int s = 0; s < kw; ++s) {
+                    const int ix = ox * stride + s - pad_l;
+                    if ((unsigned)ix >= (unsigned)iw) continue;
+                    const int64_t ip = ((int64_t)n * ih + iy) * iw + ix;
+                    const float v = x[ip * x_ld + ch];
+                    if (v > best || arg < 0) { best = v; arg = ip; }
+                }
+            }
+            if (arg >= 0) atomicAdd(&dx[arg * dx_ld + ch], g);
+        } else {
+            int cnt = 0;
+            for (int r = 0; r < kh; ++r) {
+                const int iy = oy * stride + r - pad_t;
+                if ((unsigned)iy >= (unsigned)ih) continue;
+                for (int s = 0; s < kw; ++s) cnt += (unsigned)(ox * stride + s - pad_l) < (unsigned)iw;
+            }
+            const float gv = g / (float)cnt;
+            for (int r = 0; r < kh; ++r) {
+                const int iy = oy * stride + r - pad_t;
+                if ((unsigned)iy >= (unsigned)ih) continue;
+                for (int s = 0; s < kw; ++s) {
+                    const int ix = ox * stride + s - pad_l;
+                    if ((unsigned)ix >= (unsigned)iw) continue;
+                    atomicAdd(&dx[(((int64_t)n * ih + iy) * iw + ix) * dx_ld + ch], gv);
+                }
+            }
+        }
+    }
+}
+
+// ---- grouping module backward (nets/model.py:44-102) ------------------------------------------------
+// dF[v] += w_g/sum(w) * dS / (#views of g tied at the maximum) for every view of g attaining the maximum
+// (tf.reduce_max splits the gradient equally among ties); mean pooling: w_g/sum(w) * dS / |g|.
+__global__ __launch_bounds__(256) void view_pool_fuse_bwd_f32(
+    const float* __restrict__ F, const float* __restrict__ dS, int V, int N, int64_t E, int64_t view_stride,
+    int64_t shape_stride, const int* __restrict__ scheme, int G, const float* __restrict__ weight, int mode,
+    float* __restrict__ dF) {
+    __shared__ unsigned long long s_mask[64];
+    __shared__ float s_w[64];
+    __shared__ float s_wsum;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        unsigned long long m = 0;
+        for (int v = 0; v < V; ++v)
+            if (scheme[g * V + v] != 0) m |= 1ull << v;
+        s_mask[g] = m;
+        s_w[g] = weight[g];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ws = 0.f;
+        for (int g = 0; g < G; ++g) ws += s_w[g];
+        s_wsum = ws;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)N * E;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / E);
+        const int64_t e = idx - (int64_t)n * E;
+        const size_t base = (size_t)n * shape_stride + e;
+        const float ds = dS[idx];
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long m0 = s_mask[g];
+            if (m0 == 0) continue;
+            const float coef = s_w[g] / s_wsum * ds;
+            if (mode == GV_VIEWPOOL_MEAN) {
+                const float each = coef / (float)__popcll(m0);
+                for (unsigned long long m = m0; m; m &= m - 1)
+                    dF[base + (size_t)(__ffsll((long long)m) - 1) * view_stride] += each;
+            } else {
+                float best = -INFINITY;
+                for (unsigned long long m = m0; m; m &= m - 1)
+                    best = fmaxf(best, F[base + (size_t)(__ffsll((long long)m) - 1) * view_stride]);
+                int ties = 0;
+                for (unsigned long long m = m0; m; m &= m - 1)
+                    ties += F[base + (size_t)(__ffsll((long long)m) - 1) * view_stride] == best;
+                const float each = coef / (float)ties;
+                for (unsigned long long m = m0; m; m &= m - 1) {
+                    const size_t a = base + (size_t)(__ffsll((long long)m) - 1) * view_stride;
+                    if (F[a] == best) dF[a] += each;
+                }
+            }
+        }
+    }
+}
+
+// dx[b][p][c] += dgap[b][c] / hw
+__global__ __launch_bounds__(256) void global_avg_pool_bwd_f32(const float* __restrict__ dgap, int nb, int hw,
+                                                               int c, float* __restrict__ dx, int dx_ld) {
+    const int64_t total = (int64_t)nb * hw * c;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        const int64_t pix = idx / c;
+        dx[pix * dx_ld + ch] += dgap[(pix / hw) * c + ch] / (float)hw;
+    }
+}
+
+// mean sparse-softmax cross-entropy (train.py:145): loss, dlogits = (softmax - onehot)/N; one block
+__global__ __launch_bounds__(256) void softmax_ce_f32(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                      int n, int c, float* __restrict__ loss,
+                                                      float* __restrict__ dlogits) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float* l = logits + (size_t)i * c;
+        float mx = -INFINITY;
+        for (int j = 0; j < c; ++j) mx = fmaxf(mx, l[j]);
+        float se = 0.f;
+        for (int j = 0; j < c; ++j) se += expf(l[j] - mx);
+        const float lse = logf(se) + mx;
+        const int lab = (int)labels[i];
+        acc += lse - l[lab];
+        for (int j = 0; j < c; ++j)
+            dlogits[(size_t)i * c + j] = (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)n;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = part[0] / (float)n;
+}
+
+// Dense backward: dx[n][f] = sum_c dy[n][c] W[f][c];  dW[f][c] += sum_n x[n][f] dy[n][c];  db[c] += sum_n dy[n][c]
+__global__ __launch_bounds__(256) void dense_bwd_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ W, int n, int f, int c,
+                                                     float* __restrict__ dx, float* __restrict__ dW,
+                                                     float* __restrict__ db) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)n * f) {
+        const int row = (int)(i / f), col = (int)(i % f);
+        float s = 0.f;
+        for (int j = 0; j < c; ++j) s += dy[(size_t)row * c + j] * W[(size_t)col * c + j];
+        dx[i] = s;
+    }
+    if (i < (int64_t)f * c) {
+        const int ff = (int)(i / c), cc = (int)(i % c);
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += x[(size_t)r * f + ff] * dy[(size_t)r * c + cc];
+        dW[i] += s;
+    }
+    if (i < c) {
+        float s = 0.f;
+        for (int r = 0; r < n; ++r) s += dy[(size_t)r * c + i];
+        db[i] += s;
+    }
+}
+
+// MomentumOptimizer(lr, 0.9), non-Nesterov, with the slim L2 term wd*w added to the gradient
+// (train.py:171, train_utils.py:121-161):  m = mu*m + (g + wd*w);  w -= lr*m
+__global__ void sgd_momentum_f32(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                 int64_t n, float lr, float mu, float wd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mm = mu * m[i] + (g[i] + wd * w[i]);
+    m[i] = mm;
+    w[i] -= lr * mm;
+}
+
+// ---- filter gradient: dW[r][s][ci][co] += sum_m X[shift_{r,s}(m)][ci] * dZ[m][co] -------------------
+// One TN GEMM per filter tap between two pixel-major matrices (the shifted input and dZ), reduction
+// over the output pixels, on the exact fp32 MFMA (32x32x2).  A workgroup owns a 64(ci) x 64(co) tile of
+// one tap and a slice of the pixels; slices are combined with fp32 atomic adds (the tile is 16 KB).
+// LDS keeps both operands pixel-major, which is exactly the k-major image the 32x32x2 operand map
+// wants (lane i reads element i of pixel row m): conflict-free ds_read_b32, no transposes.
+__global__ __launch_bounds__(256) void conv_wgrad_f32(const float* __restrict__ x, int x_ld,
+                                                      const float* __restrict__ dz, int dz_ld, int nb, int ih,
+                                                      int iw, int cin, int kh, int kw, int stride, int pad_t,
+                                                      int pad_l, int oh, int ow, int cout, int64_t M,
+                                                      int64_t m_per_block, float* __restrict__ dw) {
+    constexpr int PT = 32;                              // pixels per LDS tile
+    __shared__ __attribute__((aligned(16))) float sX[PT][64 + 4];
+    __shared__ __attribute__((aligned(16))) float sZ[PT][64 + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;            // 2x2 waves, 32x32 each
+    const int ntile_co = (cout + 63) / 64, ntile_ci = (cin + 63) / 64;
+    int b = blockIdx.x;
+    const int tco = b % ntile_co; b /= ntile_co;
+    const int tci = b % ntile_ci; b /= ntile_ci;
+    const int tap = b;                                  // r*kw + s
+    const int fr = tap / kw, fs = tap - fr * kw;
+    const int ci0 = tci * 64, co0 = tco * 64;
+    const int64_t m0 = (int64_t)blockIdx.y * m_per_block;
+    const int64_t m1 = m0 + m_per_block < M ? m0 + m_per_block : M;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ohow = oh * ow;
+    // loader: thread -> (pixel row p = tid/16 (+16), 4 channels q = tid%16)
+    const int lp = tid >> 4, lq = (tid & 15) * 4;
+    for (int64_t mt = m0; mt < m1; mt += PT) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = lp + 16 * h;
+            const int64_t m = mt + p;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
+            if (m < m1) {
+                const int n = (int)(m / ohow);
+                const int rem = (int)(m - (int64_t)n * ohow);
+                const int oy = rem / ow, ox = rem - oy * ow;
+                const int iy = oy * stride + fr - pad_t, ix = ox * stride + fs - pad_l;
+                if ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) {
+                    const float* xp = x + (((size_t)n * ih + iy) * iw + ix) * x_ld + ci0 + lq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (ci0 + lq + e < cin) xv[e] = xp[e];
+                }
+                const float* zp = dz + (size_t)m * dz_ld + co0 + lq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (co0 + lq + e < cout) zv[e] = zp[e];
+            }
+            *reinterpret_cast<f32x4*>(&sX[p][lq]) = xv;
+            *reinterpret_cast<f32x4*>(&sZ[p][lq]) = zv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PT; k += 2) {
+            const float av = sX[k + (lane >> 5)][wi * 32 + (lane & 31)];
+            const float bv = sZ[k + (lane >> 5)][wj * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = co0 + wj * 32 + (lane & 31);
+    if (col < cout) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (ci < cin) atomicAdd(&dw[((size_t)tap * cin + ci) * cout + col], acc[r]);
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = 256 * 16;
+    return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
+                                   int32_t num_groups, const int32_t* counts, const float* gamma,
+                                   const float* beta, float eps, double* accum, float* mean, float* var,
+                                   float* inv, float* scale, float* shift, void* stream) {
+    if (!z || !counts || !beta || !accum || !mean || !var || !inv || !scale || !shift) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || z_ld < c || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
+    const int64_t npix = (int64_t)(nb / num_groups) * hw;
+    int splits = (int)((npix + 2047) / 2048);
+    if (splits > 256) splits = 256;
+    hipLaunchKernelGGL(grouped_sums_f32<0>, dim3((c + 63) / 64, splits, num_groups), dim3(256), 0, st, z, z_ld,
+                       (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr,
+                       (const float*)nullptr, nb, hw, c, num_groups, accum);
+    hipLaunchKernelGGL(bn_finalize_grouped, dim3((num_groups * c + 255) / 256), dim3(256), 0, st, accum,
+                       num_groups, c, counts, gamma, beta, eps, mean, var, inv, scale, shift);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
+                                          const float* scale, const float* shift, int32_t num_groups,
+                                          int32_t relu, float* y, int32_t y_ld, void* stream) {
+    if (!x || !y || !scale || !shift || nb <= 0 || hw <= 0 || c <= 0 || x_ld < c || y_ld < c || num_groups <= 0)
+        return GV_E_BADARG;
+    if ((c & 3) || (x_ld & 3) || (y_ld & 3) || !gv_aligned16(x) || !gv_aligned16(y) || !gv_aligned16(scale) ||
+        !gv_aligned16(shift))
+        return GV_E_ALIGN;
+    hipLaunchKernelGGL(scale_shift_act_grouped_f32, dim3(grid_for((int64_t)nb * hw * (c / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, nb, hw, c, x_ld, scale, shift, num_groups, relu, y, y_ld);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
+                                      const float* z, int32_t z_ld, const float* mean, const float* inv,
+                                      const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
+                                      int32_t c, int32_t num_groups, double* accum, float* dz, int32_t dz_ld,
+                                      float* dbeta, float* dgamma, void* stream) {
+    if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
+    const int64_t npix = (int64_t)(nb / num_groups) * hw;
+    int splits = (int)((npix + 2047) / 2048);
+    if (splits > 256) splits = 256;
+    hipLaunchKernelGGL(grouped_sums_f32<1>, dim3((c + 63) / 64, splits, num_groups), dim3(256), 0, st, z, z_ld, dy,
+                       dy_ld, y, y_ld, mean, inv, nb, hw, c, num_groups, accum);
+    hipLaunchKernelGGL(bn_bwd_apply_grouped_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, dy, dy_ld,
+                       y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw, c, num_groups, dz, dz_ld);
+    if (dbeta || dgamma)
+        hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
+                           dgamma);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_accumulate(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix,
+                             int32_t c, void* stream) {
+    if (!src || !dst || npix <= 0 || c <= 0 || src_ld < c || dst_ld < c) return GV_E_BADARG;
+    hipLaunchKernelGGL(accumulate_f32, dim3(grid_for(npix * c)), dim3(256), 0, (hipStream_t)stream, src, src_ld,
+                       dst, dst_ld, npix, c);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum,
+                            float* dbias, void* stream) {
+    if (!dz || !accum || !dbias || npix <= 0 || c <= 0 || dz_ld < c || npix > 0x7fffffff) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)c, st));
+    int splits = (int)((npix + 2047) / 2048);
+    if (splits > 1024) splits = 1024;
+    hipLaunchKernelGGL(grouped_sums_f32<2>, dim3((c + 63) / 64, splits, 1), dim3(256), 0, st, (const float*)nullptr,
+                       0, dz, dz_ld, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
+                       (int)npix, 1, c, 1, accum);
+    hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, 1, c, dbias, (float*)nullptr);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_pool2d_bwd(const gv_pool_desc* d, const float* x, const float* dy, int32_t dy_ld, float* dx,
+                             int32_t dx_ld, void* stream) {
+    if (!d || !dy || !dx || (d->mode == GV_POOL_MAX && !x)) return GV_E_BADARG;
+    if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG) return GV_E_BADARG;
+    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(pool2d_bwd_f32, dim3(grid_for((int64_t)d->nb * d->oh * d->ow * d->c)), dim3(256), 0,
+                       (hipStream_t)stream, x, d->x_ld, dy, dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw,
+                       d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->mode, dx, dx_ld);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes,
+                                     int64_t E, int64_t view_stride, int64_t shape_stride,
+                                     const int32_t* scheme, int32_t num_groups, const float* weight,
+                                     int32_t mode, float* dF, void* stream) {
+    if (!F || !dS || !scheme || !weight || !dF) return GV_E_BADARG;
+    if (num_views <= 0 || num_shapes <= 0 || E <= 0 || num_groups <= 0) return GV_E_BADARG;
+    if (num_views > 64 || num_groups > 64) return GV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(view_pool_fuse_bwd_f32, dim3(grid_for((int64_t)num_shapes * E)), dim3(256), 0,
+                       (hipStream_t)stream, F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme,
+                       num_groups, weight, mode, dF);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_global_avg_pool_bwd(const float* dgap, int32_t nb, int32_t hw, int32_t c, float* dx,
+                                      int32_t dx_ld, void* stream) {
+    if (!dgap || !dx || nb <= 0 || hw <= 0 || c <= 0 || dx_ld < c) return GV_E_BADARG;
+    hipLaunchKernelGGL(global_avg_pool_bwd_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0,
+                       (hipStream_t)stream, dgap, nb, hw, c, dx, dx_ld);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_softmax_ce(const float* logits, const int64_t* labels, int32_t n, int32_t c, float* loss,
+                             float* dlogits, void* stream) {
+    if (!logits || !labels || !loss || !dlogits || n <= 0 || c <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(softmax_ce_f32, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, n, c, loss,
+                       dlogits);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_dense_bwd(const float* x, const float* dy, const float* kernel, int32_t n, int32_t f,
+                            int32_t c, float* dx, float* dkernel, float* dbias, void* stream) {
+    if (!x || !dy || !kernel || !dx || !dkernel || !dbias || n <= 0 || f <= 0 || c <= 0) return GV_E_BADARG;
+    int64_t total = (int64_t)n * f;
+    if ((int64_t)f * c > total) total = (int64_t)f * c;
+    hipLaunchKernelGGL(dense_bwd_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       dy, kernel, n, f, c, dx, dkernel, dbias);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_sgd_momentum(float* w, const float* g, float* m, int64_t n, float lr, float mu, float wd,
+                               void* stream) {
+    if (!w || !g || !m || n <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(sgd_momentum_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, g,
+                       m, n, lr, mu, wd);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const float* dz, int32_t dz_ld,
+                               float* dw_hwio, void* stream) {
+    if (!d || !x || !dz || !dw_hwio) return GV_E_BADARG;
+    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (d->nb <= 0 || d->cin <= 0 || d->cout <= 0 || dz_ld < d->cout || d->x_ld < d->cin) return GV_E_BADARG;
+    const int64_t M = (int64_t)d->nb * d->oh * d->ow;
+    const int tiles = d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
+    int64_t splits = (4096 + tiles - 1) / tiles;                // ~4k workgroups in flight
+    const int64_t max_splits = (M + 255) / 256;                 // at least 256 pixels per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    int64_t per = (M + splits - 1) / splits;
+    per = (per + 31) / 32 * 32;
+    splits = (M + per - 1) / per;
+    hipLaunchKernelGGL(conv_wgrad_f32, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, (hipStream_t)stream, x,
+                       d->x_ld, dz, dz_ld, d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t,
+                       d->pad_l, d->oh, d->ow, d->cout, M, per, dw_hwio);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}

@@ -1,0 +1,378 @@
+"""Training step of the hot path: forward in train mode + loss + backward + Momentum.
+
+What the reference does per step (train.py:259-288, utils/train_utils.py:217-259):
+  partial_run #1  backbone with is_training=True (BatchNorm on BATCH statistics, one graph copy per view
+                  => statistics over the N*h*w values of one view) -> the V view scores
+  host            group_scheme / group_weight (constants of the backward pass: fed placeholders)
+  partial_run #2  view pooling + group fusion + classifier -> mean sparse-softmax CE (+ L2), gradients
+                  wrt every backbone variable (shared by the V views => summed), BN beta/gamma, the
+                  classifier; the V scorer Dense(1) layers receive no gradient; MomentumOptimizer(lr, 0.9).
+
+Here: the same op list as the inference plan, built by the same builder functions, but kept un-fused
+(conv -> z, train-mode BN -> y) with every tensor retained for the backward pass; each op's backward is
+one or two launches of libgvcnn_hip.so, executed in reverse order with accumulate semantics.
+The data gradient of a convolution is the forward implicit-GEMM kernel itself on dZ with the filter
+flipped/transposed (stride-2 layers: zero-dilated input); the filter gradient is its own kernel.
+fp32 storage throughout.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import backbones
+from . import params as _params
+from .backbones import TRef, _out_size
+from .model import _st, _dev, _raise_for_status
+
+
+class TrainPlan(backbones.BackbonePlan):
+    """Symbolic op list for training: un-fused, nothing recycled."""
+
+    def __init__(self, nb, height, width, math_mode):
+        super().__init__(nb, height, width, _lib.GV_F32, math_mode)
+        self.use_lanes = False
+
+    def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
+             residual=None, next_preact=None):
+        kh, kw = (k, k) if isinstance(k, int) else k
+        oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
+        ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
+        if norm is None and out is not None:
+            z = out
+        else:
+            z = self.new_tensor(x.nb, oh, ow, cout)
+        self.ops.append(dict(kind="conv", name=scope, x=x, y=z, res=residual, kh=kh, kw=kw, stride=stride,
+                             pad_t=pad_t, pad_l=pad_l, bias=None if norm is not None else scope + "/biases",
+                             flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c))
+        result = z
+        if norm is not None:
+            a = out if out is not None else self.new_tensor(x.nb, oh, ow, cout)
+            self.ops.append(dict(kind="bn", name=scope + "/BatchNorm", x=z, y=a, eps=norm[1], has_gamma=norm[2],
+                                 relu=relu))
+            result = a
+        if next_preact is not None:
+            pre = self.new_tensor(x.nb, oh, ow, cout)
+            self.ops.append(dict(kind="bn", name=next_preact[0], x=result, y=pre, eps=next_preact[1],
+                                 has_gamma=True, relu=True))
+            return result, pre
+        return result
+
+    def conv_siblings(self, x, branches, first_out, norm, relu=True):
+        outs = []
+        for i, (scope, c) in enumerate(branches):
+            t = self.conv(x, scope, c, 1, out=first_out if i == 0 else None, norm=norm, relu=relu)
+            if i:
+                outs.append(t)
+        return outs
+
+    def pool(self, x, k, stride, padding, mode, out=None, name="pool"):
+        oh, pad_t = _out_size(x.h, k, stride, padding)
+        ow, pad_l = _out_size(x.w, k, stride, padding)
+        if out is None:
+            out = self.new_tensor(x.nb, oh, ow, x.c)
+        self.ops.append(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t, pad_l=pad_l,
+                             mode=mode))
+        return out
+
+    def bn_relu(self, x, bn_scope, eps, name):
+        out = self.new_tensor(x.nb, x.h, x.w, x.c)
+        self.ops.append(dict(kind="bn", name=bn_scope, x=x, y=out, eps=eps, has_gamma=True, relu=True))
+        return out
+
+    def param_shapes(self):
+        shapes = {}
+        for op in self.ops:
+            if op["kind"] == "conv":
+                shapes[op["name"] + "/weights"] = (op["kh"], op["kw"], op["x"].c, op["y"].c)
+                if op["bias"]:
+                    shapes[op["bias"]] = (op["y"].c,)
+            elif op["kind"] == "bn":
+                c = op["x"].c
+                for leaf in ("beta", "moving_mean", "moving_variance") + (("gamma",) if op["has_gamma"] else ()):
+                    shapes[op["name"] + "/" + leaf] = (c,)
+        return shapes
+
+
+class TrainGVCNN:
+    """One training step of GVCNN for a fixed batch geometry (views [N, V, H, W, 3] on the device)."""
+
+    def __init__(self, backbone="resnet_v2_50", num_shapes=2, num_views=6, height=224, width=224,
+                 num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
+                 raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2):
+        self.lib = _lib.load()
+        self.device = dev = _dev(device)
+        self.backbone = backbone
+        self.N, self.V, self.H, self.W = num_shapes, num_views, height, width
+        self.num_classes, self.G, self.num_bins = num_classes, num_group, num_bins
+        self.pool_mode = {"max": _lib.GV_VIEWPOOL_MAX, "mean": _lib.GV_VIEWPOOL_MEAN}[pool]
+        self.empty_fill = float(empty_fill)
+        self.math_mode = backbones.MATH_MODES[math]
+        if self.math_mode == _lib.GV_MATH_F32:
+            raise ValueError("training uses the bf16-plane convolution kernels (math='bf16x3')")
+        nb = num_shapes * num_views
+        p = TrainPlan(nb, height, width, self.math_mode)
+        raw_tap = raw_tap or backbones.TAPS[backbone][0]
+        final_tap = final_tap or backbones.TAPS[backbone][1]
+        if backbone == "inception_v3":
+            backbones.build_inception_v3(p, keep=(raw_tap, final_tap), fuse_siblings=False)
+        else:
+            backbones.build_resnet_v2_50(p, keep=(raw_tap, final_tap))
+        self.plan = p
+        self.raw, self.final = p.end_points[raw_tap], p.end_points[final_tap]
+        f32 = torch.float32
+        with torch.cuda.device(dev):
+            self.act = [torch.empty(n, dtype=f32, device=dev) for n, _ in p.vbufs]
+            self.grad = [None] * len(p.vbufs)
+            shapes = p.param_shapes()
+            if backbone_params is None:
+                backbone_params = _params.init_backbone_params(shapes, seed=seed)
+            self.params = {k: torch.as_tensor(backbone_params[k], dtype=f32).to(dev).contiguous().clone()
+                           for k in shapes}
+            self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()
+                          if not k.endswith(("moving_mean", "moving_variance"))}
+            if head_params is None:
+                head_params = _params.init_head_params(num_views, self.raw.c, self.final.c, num_classes, seed=seed + 1)
+            ks, bs = [], []
+            for v in range(num_views):
+                kn, bn = _params.scorer_names(v)
+                ks.append(torch.as_tensor(head_params[kn], dtype=f32).reshape(-1))
+                bs.append(torch.as_tensor(head_params[bn], dtype=f32).reshape(-1)[:1])
+            self.score_kernel = torch.stack(ks).to(dev).contiguous()
+            self.score_bias = torch.cat(bs).to(dev).contiguous()
+            kn, bn = _params.classifier_names(num_views)
+            self.cls_names = (kn, bn)
+            self.params[kn] = torch.as_tensor(head_params[kn], dtype=f32).to(dev).contiguous().clone()
+            self.params[bn] = torch.as_tensor(head_params[bn], dtype=f32).to(dev).contiguous().clone()
+            self.grads[kn] = torch.zeros_like(self.params[kn])
+            self.grads[bn] = torch.zeros_like(self.params[bn])
+            self.momentum = {k: torch.zeros_like(v) for k, v in self.grads.items()}
+            # per-op device state
+            cmax = max(op["x"].c for op in p.ops if op["kind"] == "bn") if any(o["kind"] == "bn" for o in p.ops) else 4
+            cmax = max(cmax, max(op["y"].c for op in p.ops if op["kind"] == "conv"))
+            self.accum = torch.zeros(2 * num_views * cmax, dtype=torch.float64, device=dev)
+            self.ones = torch.ones(cmax, dtype=f32, device=dev)
+            self.zeros = torch.zeros(cmax, dtype=f32, device=dev)
+            self._counts = {}
+            for op in p.ops:
+                if op["kind"] == "bn":
+                    c = op["x"].c
+                    op["stat"] = {k: torch.empty((num_views, c), dtype=f32, device=dev)
+                                  for k in ("mean", "var", "inv", "scale", "shift")}
+                elif op["kind"] == "conv":
+                    w = self.params[op["name"] + "/weights"]
+                    kh, kw, cin, cout = w.shape
+                    nf = self.lib.gv_packed_filter_bytes(kh, kw, cin, cout, _lib.GV_F32, self.math_mode) // 4
+                    nd = self.lib.gv_packed_filter_bytes(kh, kw, cout, cin, _lib.GV_F32, self.math_mode) // 4
+                    op["w_fwd"] = torch.empty(nf, dtype=f32, device=dev)
+                    op["w_dgrad"] = torch.empty(nd, dtype=f32, device=dev) if op["x"].vbuf >= 0 else None
+            nbv = nb
+            self.r_img = torch.empty(nbv, dtype=f32, device=dev)
+            self.scores = torch.empty(num_views, dtype=f32, device=dev)
+            self.gidx = torch.empty(num_views, dtype=torch.int32, device=dev)
+            self.scheme = torch.empty((num_group, num_views), dtype=torch.int32, device=dev)
+            self.weight = torch.empty(num_group, dtype=f32, device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+            f = self.final
+            self.S = torch.empty((num_shapes, f.h, f.w, f.c), dtype=f32, device=dev)
+            self.dS = torch.empty_like(self.S)
+            self.gap = torch.empty((num_shapes, f.c), dtype=f32, device=dev)
+            self.dgap = torch.empty_like(self.gap)
+            self.logits = torch.empty((num_shapes, num_classes), dtype=f32, device=dev)
+            self.dlogits = torch.empty_like(self.logits)
+            self.loss = torch.zeros(1, dtype=f32, device=dev)
+        self._packed_dirty = True
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    def _ptr(self, t, grad=False):
+        if t.vbuf < 0:
+            assert not grad
+            return self._x.data_ptr() + 4 * t.off
+        if grad:
+            if self.grad[t.vbuf] is None:
+                self.grad[t.vbuf] = torch.zeros_like(self.act[t.vbuf])
+            return self.grad[t.vbuf].data_ptr() + 4 * t.off
+        return self.act[t.vbuf].data_ptr() + 4 * t.off
+
+    def view(self, t, grad=False):
+        base = self.grad[t.vbuf] if grad else self.act[t.vbuf]
+        return torch.as_strided(base, (t.nb, t.h, t.w, t.c), (t.h * t.w * t.ld, t.w * t.ld, t.ld, 1), t.off)
+
+    def _count(self, hw):
+        if hw not in self._counts:
+            self._counts[hw] = torch.full((self.V,), self.N * hw, dtype=torch.int32, device=self.device)
+        return self._counts[hw]
+
+    def _conv_desc(self, op, dgrad=False):
+        x, y = op["x"], op["y"]
+        if not dgrad:
+            return _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"], op["pad_t"],
+                                 op["pad_l"], y.h, y.w, y.c, y.ld, op["res"].ld if op["res"] is not None else 0,
+                                 0, 0, _lib.GV_F32, 0, 0, self.math_mode, 0)
+        # data gradient: dX = conv(dilate(dZ, stride), flip(W)^T), pad' = k-1-pad, accumulate into dX
+        return _lib.ConvDesc(y.nb, y.h, y.w, y.c, y.ld, op["kh"], op["kw"], 1, op["kh"] - 1 - op["pad_t"],
+                             op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, _lib.GV_F32, 0, 0,
+                             self.math_mode, op["stride"] if op["stride"] > 1 else 0)
+
+    def repack(self):
+        """Refresh the packed filters from the trainable HWIO variables (after an optimizer step)."""
+        lib = self.lib
+        keep = []
+        for op in self.plan.ops:
+            if op["kind"] != "conv":
+                continue
+            w = self.params[op["name"] + "/weights"]
+            kh, kw, cin, cout = w.shape
+            _lib.check(lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout, op["w_fwd"].data_ptr(),
+                                               _lib.GV_F32, self.math_mode, _st()), "gv_pack_filter_hwio")
+            if op["w_dgrad"] is not None:
+                wt = torch.flip(w, (0, 1)).permute(0, 1, 3, 2).contiguous()      # [kh,kw,cout,cin]
+                keep.append(wt)
+                _lib.check(lib.gv_pack_filter_hwio(wt.data_ptr(), kh, kw, cout, cin, op["w_dgrad"].data_ptr(),
+                                                   _lib.GV_F32, self.math_mode, _st()), "gv_pack_filter_hwio")
+        torch.cuda.synchronize(self.device)
+        self._packed_dirty = False
+
+    # -- forward (train mode) ----------------------------------------------------------------------------
+    def forward(self, views, labels=None, g_scheme=None, g_weight=None, check=True):
+        """Phase 1 + phase 2 of train.py:264-288.  Returns (scores [V], shape_descriptor, logits, loss)."""
+        lib = self.lib
+        assert tuple(views.shape) == (self.N, self.V, self.H, self.W, 3) and views.is_cuda
+        self._x = views.to(torch.float32).contiguous()
+        if self._packed_dirty:
+            self.repack()
+        V = self.V
+        for op in self.plan.ops:
+            x, y = op["x"], op["y"]
+            if op["kind"] == "conv":
+                d = self._conv_desc(op)
+                shift = self.params[op["bias"]] if op["bias"] else self.zeros
+                res = op["res"]
+                _lib.check(lib.gv_conv2d_fwd(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
+                                             shift.data_ptr(), self._ptr(res) if res is not None else None,
+                                             self._ptr(y), None, None, None, _st()), "conv " + op["name"])
+            elif op["kind"] == "bn":
+                st = op["stat"]
+                gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
+                beta = self.params[op["name"] + "/beta"]
+                hw = x.h * x.w
+                _lib.check(lib.gv_bn_stats_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, V, self._count(hw).data_ptr(),
+                                                   gamma.data_ptr() if gamma is not None else None, beta.data_ptr(),
+                                                   float(op["eps"]), self.accum.data_ptr(), st["mean"].data_ptr(),
+                                                   st["var"].data_ptr(), st["inv"].data_ptr(), st["scale"].data_ptr(),
+                                                   st["shift"].data_ptr(), _st()), "bn stats " + op["name"])
+                _lib.check(lib.gv_scale_shift_act_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
+                                                          st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
+                                                          y.ld, _st()), "bn apply " + op["name"])
+            else:
+                d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
+                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], _lib.GV_F32)
+                _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
+        # scorer (no gradient flows through it: scores leave the graph in partial_run #1)
+        r = self.raw
+        _lib.check(lib.gv_view_score_partial(self._ptr(r), r.nb, r.h * r.w, r.c, r.ld, self.score_kernel.data_ptr(),
+                                             self.score_bias.data_ptr(), V, _lib.GV_ORDER_SHAPE_MAJOR,
+                                             self.r_img.data_ptr(), _lib.GV_F32, _st()), "score")
+        _lib.check(lib.gv_view_score_finalize(self.r_img.data_ptr(), self.N, V, _lib.GV_ORDER_SHAPE_MAJOR,
+                                              self.scores.data_ptr(), _st()), "score finalize")
+        if g_scheme is None:
+            _lib.check(lib.gv_group_assign(self.scores.data_ptr(), V, self.G, self.num_bins, self.gidx.data_ptr(),
+                                           self.scheme.data_ptr(), self.weight.data_ptr(), self.status.data_ptr(),
+                                           _st()), "assign")
+            if check:
+                _raise_for_status(int(self.status.item()), self.gidx, self.G)
+        else:
+            self.scheme.copy_(torch.as_tensor(np.asarray(g_scheme), dtype=torch.int32))
+            self.weight.copy_(torch.as_tensor(np.asarray(g_weight), dtype=torch.float32))
+        f = self.final
+        E = f.h * f.w * f.c
+        _lib.check(lib.gv_view_pool_fuse_fwd(self._ptr(f), V, self.N, E, E, V * E, self.scheme.data_ptr(), self.G,
+                                             self.weight.data_ptr(), self.pool_mode, self.empty_fill, None,
+                                             self.S.data_ptr(), _lib.GV_F32, _st()), "pool_fuse")
+        _lib.check(lib.gv_global_avg_pool(self.S.data_ptr(), self.N, f.h * f.w, f.c, f.c, self.gap.data_ptr(),
+                                          _lib.GV_F32, _st()), "gap")
+        kn, bn = self.cls_names
+        _lib.check(lib.gv_dense_fwd(self.gap.data_ptr(), self.N, f.c, self.params[kn].data_ptr(),
+                                    self.params[bn].data_ptr(), self.num_classes, self.logits.data_ptr(), _st()),
+                   "dense")
+        if labels is not None:
+            self._labels = labels.to(device=self.device, dtype=torch.int64).contiguous()
+            _lib.check(lib.gv_softmax_ce(self.logits.data_ptr(), self._labels.data_ptr(), self.N, self.num_classes,
+                                         self.loss.data_ptr(), self.dlogits.data_ptr(), _st()), "softmax_ce")
+        return self.scores, self.S, self.logits, self.loss
+
+    # -- backward ----------------------------------------------------------------------------------------
+    def backward(self):
+        """Gradients of the mean CE loss (forward(labels=...) must have run).  Fills self.grads."""
+        lib, V = self.lib, self.V
+        for g in self.grads.values():
+            g.zero_()
+        for g in self.grad:
+            if g is not None:
+                g.zero_()
+        f = self.final
+        E = f.h * f.w * f.c
+        kn, bn = self.cls_names
+        _lib.check(lib.gv_dense_bwd(self.gap.data_ptr(), self.dlogits.data_ptr(), self.params[kn].data_ptr(), self.N,
+                                    f.c, self.num_classes, self.dgap.data_ptr(), self.grads[kn].data_ptr(),
+                                    self.grads[bn].data_ptr(), _st()), "dense_bwd")
+        self.dS.zero_()
+        _lib.check(lib.gv_global_avg_pool_bwd(self.dgap.data_ptr(), self.N, f.h * f.w, f.c, self.dS.data_ptr(), f.c,
+                                              _st()), "gap_bwd")
+        _lib.check(lib.gv_view_pool_fuse_bwd(self._ptr(f), self.dS.data_ptr(), V, self.N, E, E, V * E,
+                                             self.scheme.data_ptr(), self.G, self.weight.data_ptr(), self.pool_mode,
+                                             self._ptr(f, grad=True), _st()), "pool_fuse_bwd")
+        for op in reversed(self.plan.ops):
+            x, y = op["x"], op["y"]
+            if y.vbuf < 0 or self.grad[y.vbuf] is None:
+                continue                                  # nothing downstream of the final tap reaches it
+            if op["kind"] == "bn":
+                st = op["stat"]
+                hw = x.h * x.w
+                gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
+                _lib.check(lib.gv_bn_relu_bwd_grouped(
+                    self._ptr(y, True), y.ld, self._ptr(y) if op["relu"] else None, y.ld, self._ptr(x), x.ld,
+                    st["mean"].data_ptr(), st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                    self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
+                    self.grads[op["name"] + "/beta"].data_ptr(),
+                    self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None, _st()),
+                    "bn_bwd " + op["name"])
+            elif op["kind"] == "conv":
+                dz = self._ptr(y, True)
+                if op["bias"]:
+                    _lib.check(lib.gv_bias_grad(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
+                                                self.grads[op["bias"]].data_ptr(), _st()), "bias_grad")
+                if op["res"] is not None:
+                    r = op["res"]
+                    _lib.check(lib.gv_accumulate(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, _st()), "res grad")
+                d = self._conv_desc(op)
+                _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld,
+                                               self.grads[op["name"] + "/weights"].data_ptr(), _st()),
+                           "wgrad " + op["name"])
+                if x.vbuf >= 0:
+                    dd = self._conv_desc(op, dgrad=True)
+                    dx = self._ptr(x, True)
+                    _lib.check(lib.gv_conv2d_fwd(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
+                                                 self.zeros.data_ptr(), dx, dx, None, None, None, _st()),
+                               "dgrad " + op["name"])
+            else:
+                d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
+                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], _lib.GV_F32)
+                _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
+                                             x.ld, _st()), "pool_bwd " + op["name"])
+        return self.grads
+
+    def apply_momentum(self, lr, mu=0.9, weight_decay=0.0):
+        """tf.train.MomentumOptimizer(lr, 0.9); the slim L2 term (wd * w) applies to conv weights only."""
+        for k, g in self.grads.items():
+            wd = weight_decay if k.endswith("/weights") else 0.0
+            _lib.check(self.lib.gv_sgd_momentum(self.params[k].data_ptr(), g.data_ptr(), self.momentum[k].data_ptr(),
+                                                g.numel(), float(lr), float(mu), float(wd), _st()), "sgd")
+        self._packed_dirty = True
+
+    def train_step(self, views, labels, lr=1e-3, mu=0.9, weight_decay=0.0):
+        self.forward(views, labels, check=False)
+        self.backward()
+        self.apply_momentum(lr, mu, weight_decay)
+        return self.loss

@@ -85,6 +85,9 @@ typedef struct gv_conv_desc {
     int32_t tile_cfg;          /* 0 = library heuristic; k >= 1 = tile configuration k-1 (a speed choice
                                   only: every configuration returns bitwise the same result) */
     int32_t math_mode;         /* GV_MATH_*; w_packed must have been packed for the same mode */
+    int32_t in_dilation;       /* 0/1: plain convolution.  2: the input tensor is read as if zero-dilated by 2
+                                  (only even tap positions exist, at index/2) — the data gradient of a stride-2
+                                  convolution is a stride-1 convolution of the dilated dZ (GV_MATH_BF16X* only) */
 } gv_conv_desc;
 
 typedef struct gv_pool_desc {
@@ -187,6 +190,61 @@ int gv_view_pool_fuse_fwd(const void* F, int32_t num_views, int32_t num_shapes, 
 /* tf.keras.layers.Dense at nets/model.py:164: y[n,:] = x[n,:] @ kernel[F,C] + bias (fp32). */
 int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel, const float* bias,
                  int32_t c, float* y, void* stream);
+
+/* ---- training step (train.py:145,166-187, utils/train_utils.py:217-259) -----------
+ * fp32.  Gradient outputs ACCUMULATE (+=) into caller-zeroed buffers, because a tensor that feeds several
+ * consumers (an Inception block input, a ResNet shortcut) sums their gradients.
+ *
+ * Data gradient of a convolution = gv_conv2d_fwd on dZ with the filter flipped and transposed
+ * (W'[r',s',co,ci] = W[kh-1-r',kw-1-s',ci,co]), pad' = k-1-pad, stride 1, in_dilation = forward stride,
+ * residual = dX (accumulate).  Filter gradient: gv_conv2d_wgrad. */
+
+/* Batch statistics per (group, channel), group of image b = b % num_groups (one group per view: the
+ * reference normalises each view's graph copy over its own N*h*w values).  counts[g] = pixels of group g.
+ * Writes mean/var(biased)/inv = rsqrt(var+eps) and the folded scale = inv*gamma, shift = beta - mean*scale,
+ * all [num_groups, c].  accum: workspace double [num_groups, c, 2].  gamma may be NULL (Inception). */
+int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld, int32_t num_groups,
+                        const int32_t* counts, const float* gamma, const float* beta, float eps,
+                        double* accum, float* mean, float* var, float* inv, float* scale, float* shift,
+                        void* stream);
+/* y = act(x*scale[g][c] + shift[g][c]), g = image % num_groups. */
+int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
+                               const float* scale, const float* shift, int32_t num_groups, int32_t relu,
+                               float* y, int32_t y_ld, void* stream);
+/* Backward of y = relu(BN_train(z)) (y == NULL: no ReLU): dz += gamma*inv*(g - mean_g(g) - zhat*mean_g(g*zhat)),
+ * g = dy*[y>0]; dbeta[c] += sum g, dgamma[c] += sum g*zhat (either may be NULL). */
+int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld, const float* z,
+                           int32_t z_ld, const float* mean, const float* inv, const float* gamma,
+                           const int32_t* counts, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
+                           double* accum, float* dz, int32_t dz_ld, float* dbeta, float* dgamma, void* stream);
+/* dst[p][c] += src[p][c]: gradient fan-in of `shortcut + residual` (nets/resnet_v2.py:91). */
+int gv_accumulate(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                  void* stream);
+/* dbias[c] += sum over pixels of dz (bias-only convolutions, nets/resnet_v2.py:79-89,178-180). */
+int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum, float* dbias,
+                 void* stream);
+/* dW_hwio[r,s,ci,co] += sum_pixels x[shifted pixel, ci] * dz[pixel, co]  (descriptor of the FORWARD conv). */
+int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const float* dz, int32_t dz_ld, float* dw_hwio,
+                    void* stream);
+/* Pool backward (descriptor of the forward pool): max -> first maximum of each window (tf MaxPoolGrad),
+ * avg -> dy / #valid taps.  x is the forward input (max only). */
+int gv_pool2d_bwd(const gv_pool_desc* d, const float* x, const float* dy, int32_t dy_ld, float* dx,
+                  int32_t dx_ld, void* stream);
+/* Backward of gv_view_pool_fuse_fwd: dF += ... (tf.reduce_max splits equally among ties). */
+int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
+                          int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
+                          int32_t num_groups, const float* weight, int32_t mode, float* dF, void* stream);
+int gv_global_avg_pool_bwd(const float* dgap, int32_t nb, int32_t hw, int32_t c, float* dx, int32_t dx_ld,
+                           void* stream);
+/* Mean sparse-softmax cross-entropy (train.py:145): loss (device scalar) and dlogits = (softmax-onehot)/n. */
+int gv_softmax_ce(const float* logits, const int64_t* labels, int32_t n, int32_t c, float* loss,
+                  float* dlogits, void* stream);
+/* Dense backward: dx = dy W^T (overwritten); dkernel += x^T dy; dbias += sum dy. */
+int gv_dense_bwd(const float* x, const float* dy, const float* kernel, int32_t n, int32_t f, int32_t c,
+                 float* dx, float* dkernel, float* dbias, void* stream);
+/* tf.train.MomentumOptimizer(lr, mu) with the slim L2 term: m = mu*m + (g + wd*w); w -= lr*m. */
+int gv_sgd_momentum(float* w, const float* g, float* m, int64_t n, float lr, float mu, float wd,
+                    void* stream);
 
 /* ---- plan: the per-view backbone as one native launch sequence -------------
  * A plan is an ordered list of the ops above whose operands are (slot, element offset)

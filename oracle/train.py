@@ -1,0 +1,57 @@
+"""Oracle for the training step — TEST INFRASTRUCTURE, see oracle/__init__.py.
+
+Loss and gradients of the reference graph by torch autograd on CPU through the oracle's own forward:
+per-view backbone call in train mode (batch-statistics BN over the N images of ONE view,
+nets/model.py:129-141), scores -> host group_scheme/group_weight (constants of the backward pass,
+train.py:277-288), reduce_max view pooling (gradient split equally among ties, like tf.reduce_max),
+group fusion, GAP, Dense, mean sparse-softmax cross-entropy (train.py:145).  PARITY UNPINNED (float).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import backbone as B
+from . import grouping as G
+from . import model as M
+
+
+def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num_bins=10,
+                   raw_tap=None, final_tap=None):
+    """inputs [N,V,H,W,3] float32, labels [N] int64.  Returns dict(loss, grads{name: tensor}, scores, scheme,
+    weight, logits, shape_descriptor)."""
+    n_views = inputs.shape[1]
+    raw_tap = raw_tap or M.TAPS[backbone][0]
+    final_tap = final_tap or M.TAPS[backbone][1]
+    Pg = {k: v.clone().requires_grad_(not k.endswith(("moving_mean", "moving_variance"))) for k, v in P.items()}
+    kn, bn = "dense_%d/kernel" % n_views, "dense_%d/bias" % n_views
+    Wc = H[kn].clone().requires_grad_(True)
+    bc = H[bn].clone().requires_grad_(True)
+    views = inputs.permute(1, 0, 2, 3, 4)
+    finals, scores = [], []
+    for v in range(n_views):
+        mode = B._BNMode(True, groups=[0] * views[v].shape[0])
+        ep = M.run_backbone(backbone, views[v], Pg, mode)
+        nm = "dense" if v == 0 else "dense_%d" % v
+        s = G.view_score(ep[raw_tap].detach().numpy(), H[nm + "/kernel"].numpy(), float(H[nm + "/bias"][0]))
+        scores.append(np.float32(s))
+        finals.append(ep[final_tap])
+    scheme = G.group_scheme([np.array(scores, dtype=np.float32)], num_group, n_views, num_bins)
+    weight = G.group_weight(scheme)
+    stacked = torch.stack(finals, dim=0)                                   # [V,N,h,w,C]
+    acc = None
+    for g in range(num_group):
+        idx = np.nonzero(scheme[g])[0]
+        if idx.size:
+            d = torch.amax(stacked[torch.as_tensor(idx)], dim=0)           # even split among ties
+        else:
+            d = torch.ones_like(stacked[0])
+        term = float(weight[g]) * d
+        acc = term if acc is None else acc + term
+    S = acc / float(weight.sum())
+    logits = S.mean(dim=(1, 2)) @ Wc + bc
+    loss = F.cross_entropy(logits, torch.as_tensor(labels, dtype=torch.long))
+    loss.backward()
+    grads = {k: v.grad for k, v in Pg.items() if v.requires_grad and v.grad is not None}
+    grads[kn], grads[bn] = Wc.grad, bc.grad
+    return dict(loss=float(loss), grads=grads, scores=scores, scheme=scheme, weight=weight,
+                logits=logits.detach().numpy(), shape_descriptor=S.detach().numpy())

@@ -1,0 +1,243 @@
+"""Training step: every backward kernel against torch autograd through the CPU oracle's
+forward ops, then the whole step (train-mode forward, loss, all gradients, Momentum) against
+oracle/train.py.  fp32; tolerance relative to each tensor's scale (BatchNorm on batch statistics
+amplifies rounding noise by 1/sigma, so gradients are held to 2e-3 of their scale)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvcnn_tf_amd as gv                          # noqa: E402
+from gvcnn_tf_amd import _lib                       # noqa: E402
+from gvcnn_tf_amd.training import TrainGVCNN        # noqa: E402
+from oracle import backbone as OB                   # noqa: E402
+from oracle import train as OT                      # noqa: E402
+
+DEV = "cuda:0"
+
+
+def lib():
+    return _lib.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def close(a, d, tol=2e-3):
+    a, d = np.asarray(a, dtype=np.float64), np.asarray(d, dtype=np.float64)
+    scale = max(float(np.abs(d).max()), 1e-30)
+    err = float(np.abs(a - d).max())
+    assert err <= tol * scale, "max|diff| %.3e vs scale %.3e (%.2e rel)" % (err, scale, err / scale)
+
+
+def test_bn_train_forward_and_backward_grouped():
+    g = torch.Generator().manual_seed(0)
+    N, V, h, w, c = 3, 4, 5, 6, 32
+    z = torch.randn(N * V, h, w, c, generator=g) * 2 + 0.5
+    beta, gamma = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    dy = torch.randn(N * V, h, w, c, generator=g)
+    groups = [b % V for b in range(N * V)]
+    for gm in (None, gamma):
+        zz = z.clone().requires_grad_(True)
+        be = beta.clone().requires_grad_(True)
+        ga = gm.clone().requires_grad_(True) if gm is not None else None
+        y_ref, mean_ref, var_ref = OB.batch_norm_train_grouped(zz, be, ga, 1e-3, groups)
+        y_ref = torch.relu(y_ref)
+        y_ref.backward(dy)
+        zd = z.to(DEV)
+        counts = torch.full((V,), N * h * w, dtype=torch.int32, device=DEV)
+        accum = torch.zeros(2 * V * c, dtype=torch.float64, device=DEV)
+        stt = {k: torch.empty(V, c, device=DEV) for k in ("mean", "var", "inv", "scale", "shift")}
+        bd, gd = beta.to(DEV), (gm.to(DEV) if gm is not None else None)
+        _lib.check(lib().gv_bn_stats_grouped(zd.data_ptr(), N * V, h * w, c, c, V, counts.data_ptr(),
+                                             gd.data_ptr() if gd is not None else None, bd.data_ptr(), 1e-3,
+                                             accum.data_ptr(), stt["mean"].data_ptr(), stt["var"].data_ptr(),
+                                             stt["inv"].data_ptr(), stt["scale"].data_ptr(), stt["shift"].data_ptr(),
+                                             st()), "stats")
+        yd = torch.empty_like(zd)
+        _lib.check(lib().gv_scale_shift_act_grouped(zd.data_ptr(), N * V, h * w, c, c, stt["scale"].data_ptr(),
+                                                    stt["shift"].data_ptr(), V, 1, yd.data_ptr(), c, st()), "apply")
+        close(stt["mean"].cpu(), mean_ref.detach(), 1e-5)
+        close(stt["var"].cpu(), var_ref.detach(), 1e-5)
+        close(yd.cpu(), y_ref.detach(), 1e-5)
+        dyd = dy.to(DEV)
+        dz = torch.zeros_like(zd)
+        dbeta = torch.zeros(c, device=DEV)
+        dgamma = torch.zeros(c, device=DEV)
+        _lib.check(lib().gv_bn_relu_bwd_grouped(dyd.data_ptr(), c, yd.data_ptr(), c, zd.data_ptr(), c,
+                                                stt["mean"].data_ptr(), stt["inv"].data_ptr(),
+                                                gd.data_ptr() if gd is not None else None, counts.data_ptr(), N * V,
+                                                h * w, c, V, accum.data_ptr(), dz.data_ptr(), c, dbeta.data_ptr(),
+                                                dgamma.data_ptr() if gd is not None else None, st()), "bn_bwd")
+        close(dz.cpu(), zz.grad, 1e-4)
+        close(dbeta.cpu(), be.grad, 1e-5)
+        if gm is not None:
+            close(dgamma.cpu(), ga.grad, 1e-4)
+
+
+@pytest.mark.parametrize("k,stride,padding,mode", [(3, 2, "VALID", "max"), (3, 2, "SAME", "max"),
+                                                    (3, 1, "SAME", "avg"), (1, 2, "VALID", "max")])
+def test_pool_backward(k, stride, padding, mode):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 9, 8, 16, generator=g).requires_grad_(True)
+    y = OB.max_pool2d(x, k, stride, padding) if mode == "max" else OB.avg_pool2d_same3(x)
+    dy = torch.randn(*y.shape, generator=g)
+    y.backward(dy)
+    pt = OB.same_pads(9, k, stride)[0] if padding == "SAME" else 0
+    pl = OB.same_pads(8, k, stride)[0] if padding == "SAME" else 0
+    d = _lib.PoolDesc(2, 9, 8, 16, 16, k, k, stride, pt, pl, y.shape[1], y.shape[2], 16,
+                      _lib.GV_POOL_MAX if mode == "max" else _lib.GV_POOL_AVG, _lib.GV_F32)
+    xd, dyd = x.detach().to(DEV), dy.to(DEV)
+    dx = torch.zeros_like(xd)
+    _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dyd.data_ptr(), 16, dx.data_ptr(), 16, st()), "pool_bwd")
+    close(dx.cpu(), x.grad, 1e-5)
+
+
+@pytest.mark.parametrize("k,stride,padding,cin,cout", [((3, 3), 1, "SAME", 32, 48), ((3, 3), 2, "VALID", 32, 64),
+                                                       ((1, 7), 1, "SAME", 48, 32), ((5, 5), 1, "SAME", 48, 64),
+                                                       ((3, 3), 1, "VALID", 80, 96), ((1, 1), 1, "SAME", 96, 32),
+                                                       ((3, 3), 2, (1, 1, 1, 1), 64, 64), ((1, 1), 2, "VALID", 64, 128),
+                                                       ((3, 3), 2, "VALID", 3, 32)])
+def test_conv_dgrad_and_wgrad_vs_autograd(k, stride, padding, cin, cout):
+    g = torch.Generator().manual_seed(hash((k, stride, cin)) % 997)
+    nb, ih, iw = 3, 12, 11
+    x = torch.randn(nb, ih, iw, cin, generator=g).requires_grad_(True)
+    w = (torch.randn(k[0], k[1], cin, cout, generator=g) * 0.1).requires_grad_(True)
+    z = OB.conv2d(x, w, stride, padding)
+    dz = torch.randn(*z.shape, generator=g)
+    z.backward(dz)
+    oh, ow = z.shape[1:3]
+    if isinstance(padding, str):
+        pt = OB.same_pads(ih, k[0], stride)[0] if padding == "SAME" else 0
+        pl = OB.same_pads(iw, k[1], stride)[0] if padding == "SAME" else 0
+    else:
+        pt, pl = padding[0], padding[2]
+    math = _lib.GV_MATH_BF16X3
+    xd, dzd = x.detach().to(DEV), dz.to(DEV)
+    # filter gradient
+    dw = torch.zeros(k[0], k[1], cin, cout, device=DEV)
+    d = _lib.ConvDesc(nb, ih, iw, cin, cin, k[0], k[1], stride, pt, pl, oh, ow, cout, cout, 0, 0, 0, _lib.GV_F32,
+                      0, 0, math, 0)
+    _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), cout, dw.data_ptr(), st()), "wgrad")
+    close(dw.cpu(), w.grad, 2e-5)
+    if cin % 16:
+        return                                            # the stem's input image needs no data gradient
+    # data gradient = forward kernel on dilated dZ with the flipped/transposed filter, accumulating
+    wt = torch.flip(w.detach(), (0, 1)).permute(0, 1, 3, 2).contiguous().to(DEV)
+    n = lib().gv_packed_filter_bytes(k[0], k[1], cout, cin, _lib.GV_F32, math) // 4
+    wp = torch.empty(n, device=DEV)
+    _lib.check(lib().gv_pack_filter_hwio(wt.data_ptr(), k[0], k[1], cout, cin, wp.data_ptr(), _lib.GV_F32, math, st()),
+               "pack")
+    dx = torch.full((nb, ih, iw, cin), 0.25, device=DEV)          # pre-existing gradient: must be accumulated into
+    ones, zeros = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+    dd = _lib.ConvDesc(nb, oh, ow, cout, cout, k[0], k[1], 1, k[0] - 1 - pt, k[1] - 1 - pl, ih, iw, cin, cin, cin, 0,
+                       0, _lib.GV_F32, 0, 0, math, stride if stride > 1 else 0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(dd), dzd.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(),
+                                   dx.data_ptr(), dx.data_ptr(), None, None, None, st()), "dgrad")
+    close(dx.cpu() - 0.25, x.grad, 2e-5)
+
+
+def test_view_pool_fuse_backward_ties_and_empty_groups():
+    g = torch.Generator().manual_seed(3)
+    V, N, G = 6, 2, 5
+    F = torch.randint(-2, 3, (N, V, 3, 3, 8), generator=g).float()         # small integers => many ties
+    scheme = np.zeros((G, V), dtype=np.int32)
+    scheme[0, [0, 3]] = 1
+    scheme[2, [1, 2, 4]] = 1
+    scheme[4, 5] = 1
+    weight = np.array([3, 1, 4, 1, 2], dtype=np.float32)
+    for mode in ("max", "mean"):
+        Fr = F.clone().requires_grad_(True)
+        acc = 0
+        for gi in range(G):
+            idx = np.nonzero(scheme[gi])[0]
+            if idx.size:
+                sel = Fr[:, torch.as_tensor(idx)]
+                d = torch.amax(sel, dim=1) if mode == "max" else sel.mean(dim=1)
+            else:
+                d = torch.ones_like(Fr[:, 0])
+            acc = acc + float(weight[gi]) * d
+        S = acc / float(weight.sum())
+        dS = torch.randn(*S.shape, generator=g)
+        S.backward(dS)
+        Fd, dSd = F.to(DEV).contiguous(), dS.to(DEV).contiguous()
+        dF = torch.zeros_like(Fd)
+        E = 3 * 3 * 8
+        sch = torch.from_numpy(scheme).to(DEV)
+        wd = torch.from_numpy(weight).to(DEV)
+        _lib.check(lib().gv_view_pool_fuse_bwd(Fd.data_ptr(), dSd.data_ptr(), V, N, E, E, V * E, sch.data_ptr(), G,
+                                               wd.data_ptr(), 0 if mode == "max" else 1, dF.data_ptr(), st()), "vp_bwd")
+        close(dF.cpu(), Fr.grad, 1e-5)
+
+
+def test_loss_dense_gap_and_momentum():
+    g = torch.Generator().manual_seed(4)
+    n, f, c = 5, 64, 7
+    gap = torch.randn(n, f, generator=g).requires_grad_(True)
+    Wk = (torch.randn(f, c, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(c, generator=g).requires_grad_(True)
+    labels = torch.randint(0, c, (n,), generator=g)
+    logits = gap @ Wk + b
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    ld = logits.detach().to(DEV)
+    lossd, dl = torch.zeros(1, device=DEV), torch.empty(n, c, device=DEV)
+    lab = labels.to(DEV)
+    _lib.check(lib().gv_softmax_ce(ld.data_ptr(), lab.data_ptr(), n, c, lossd.data_ptr(), dl.data_ptr(), st()), "ce")
+    close(lossd.cpu(), [float(loss)], 1e-5)
+    gd, Wd = gap.detach().to(DEV), Wk.detach().to(DEV)
+    dgap, dW, db = torch.empty(n, f, device=DEV), torch.zeros(f, c, device=DEV), torch.zeros(c, device=DEV)
+    _lib.check(lib().gv_dense_bwd(gd.data_ptr(), dl.data_ptr(), Wd.data_ptr(), n, f, c, dgap.data_ptr(), dW.data_ptr(),
+                                  db.data_ptr(), st()), "dense_bwd")
+    close(dgap.cpu(), gap.grad, 1e-5)
+    close(dW.cpu(), Wk.grad, 1e-5)
+    close(db.cpu(), b.grad, 1e-5)
+    dx = torch.zeros(n, 6, f, device=DEV)
+    _lib.check(lib().gv_global_avg_pool_bwd(dgap.data_ptr(), n, 6, f, dx.data_ptr(), f, st()), "gap_bwd")
+    close(dx.cpu(), (gap.grad / 6)[:, None, :].expand(n, 6, f), 1e-5)
+    # Momentum (train.py:171) with the slim L2 term
+    w0, g0, m0 = torch.randn(100, generator=g), torch.randn(100, generator=g), torch.randn(100, generator=g)
+    wd_, gd_, md_ = w0.to(DEV), g0.to(DEV), m0.to(DEV)
+    _lib.check(lib().gv_sgd_momentum(wd_.data_ptr(), gd_.data_ptr(), md_.data_ptr(), 100, 0.01, 0.9, 1e-4, st()), "sgd")
+    m1 = 0.9 * m0 + (g0 + 1e-4 * w0)
+    close(md_.cpu(), m1, 1e-6)
+    close(wd_.cpu(), w0 - 0.01 * m1, 1e-6)
+
+
+@pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 139, 3, 2), ("resnet_v2_50", 97, 3, 2)])
+def test_training_step_vs_oracle(backbone, size, N, V):
+    C_, G = 5, 10
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    shapes = eng.plan.param_shapes()
+    assert shapes == OB.trace_param_shapes(backbone)
+    P = gv.params.init_backbone_params(shapes, seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
+    x = torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5
+    labels = torch.tensor([1, 4, 2][:N])
+    ref = OT.loss_and_grads(x, labels.numpy(), P, Hd, G, backbone)
+    scores, S, logits, loss = eng.forward(x.to(DEV), labels)
+    assert eng.scheme.cpu().numpy().tolist() == ref["scheme"].tolist()
+    close(S.cpu(), ref["shape_descriptor"], 1e-3)
+    close(logits.cpu(), ref["logits"], 1e-3)
+    assert abs(float(loss) - ref["loss"]) <= 1e-3 * max(1.0, abs(ref["loss"]))
+    grads = eng.backward()
+    torch.cuda.synchronize()
+    worst = []
+    for name, gref in ref["grads"].items():
+        a, d = grads[name].cpu().numpy().astype(np.float64), gref.numpy().astype(np.float64)
+        scale = max(float(np.abs(d).max()), 1e-30)
+        worst.append((float(np.abs(a - d).max()) / scale, name))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 5e-3, worst[:5]
+    # scorer layers and unused variables get no gradient: every other variable got one
+    assert set(ref["grads"]) <= set(grads)
+    # one Momentum step moves the loss down on the same batch
+    l0 = float(loss)
+    eng.apply_momentum(lr=1e-2, mu=0.9, weight_decay=1e-4)
+    _, _, _, loss1 = eng.forward(x.to(DEV), labels, g_scheme=ref["scheme"], g_weight=ref["weight"])
+    assert float(loss1) < l0
