@@ -150,7 +150,7 @@ class TrainGVCNN:
             self.momentum = {k: torch.zeros_like(v) for k, v in self.grads.items()}
             # per-op device state
             cmax = max(op["x"].c for op in p.ops if op["kind"] == "bn") if any(o["kind"] == "bn" for o in p.ops) else 4
-            cmax = max(cmax, max(op["y"].c for op in p.ops if op["kind"] == "conv"))
+            cmax = max(cmax, max(max(op["y"].c, op["x"].c) for op in p.ops if op["kind"] == "conv"))
             self.accum = torch.zeros(2 * num_views * cmax, dtype=torch.float64, device=dev)
             self.ones = torch.ones(cmax, dtype=f32, device=dev)
             self.zeros = torch.zeros(cmax, dtype=f32, device=dev)
@@ -323,10 +323,15 @@ class TrainGVCNN:
         _lib.check(lib.gv_view_pool_fuse_bwd(self._ptr(f), self.dS.data_ptr(), V, self.N, E, E, V * E,
                                              self.scheme.data_ptr(), self.G, self.weight.data_ptr(), self.pool_mode,
                                              self._ptr(f, grad=True), _st()), "pool_fuse_bwd")
+        import os
+        dbg = bool(os.environ.get("GV_SYNC_DEBUG"))
         for op in reversed(self.plan.ops):
             x, y = op["x"], op["y"]
             if y.vbuf < 0 or self.grad[y.vbuf] is None:
                 continue                                  # nothing downstream of the final tap reaches it
+            if dbg:
+                torch.cuda.synchronize()
+                print("bwd", op["kind"], op["name"], flush=True)
             if op["kind"] == "bn":
                 st = op["stat"]
                 hw = x.h * x.w

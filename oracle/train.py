@@ -34,6 +34,7 @@ def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num
         nm = "dense" if v == 0 else "dense_%d" % v
         s = G.view_score(ep[raw_tap].detach().numpy(), H[nm + "/kernel"].numpy(), float(H[nm + "/bias"][0]))
         scores.append(np.float32(s))
+        ep[final_tap].retain_grad()
         finals.append(ep[final_tap])
     scheme = G.group_scheme([np.array(scores, dtype=np.float32)], num_group, n_views, num_bins)
     weight = G.group_weight(scheme)
@@ -53,5 +54,6 @@ def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num
     loss.backward()
     grads = {k: v.grad for k, v in Pg.items() if v.requires_grad and v.grad is not None}
     grads[kn], grads[bn] = Wc.grad, bc.grad
-    return dict(loss=float(loss), grads=grads, scores=scores, scheme=scheme, weight=weight,
+    return dict(finals=[f.detach() for f in finals], final_grads=[f.grad for f in finals],
+                loss=float(loss.detach()), grads=grads, scores=scores, scheme=scheme, weight=weight,
                 logits=logits.detach().numpy(), shape_descriptor=S.detach().numpy())
