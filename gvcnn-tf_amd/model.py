@@ -373,6 +373,7 @@ def configure(backbone=None, backbone_params=None, head_params=None, raw_tap=Non
         if v is not None:
             _CONFIG[k] = v
     _ENGINES.clear()
+    _TRAIN_ENGINES.clear()
 
 
 def _engine(inputs, num_classes, num_group):
@@ -387,11 +388,20 @@ def _engine(inputs, num_classes, num_group):
     return _ENGINES[key]
 
 
-def _reject_training(is_training):
-    if is_training:
-        raise NotImplementedError(
-            "is_training=True (batch-statistics BatchNorm + backward) is not built yet; "
-            "pass is_training=False (the eval.py protocol)")
+_TRAIN_ENGINES = {}
+
+
+def _train_engine(inputs, num_classes, num_group):
+    """Engine for is_training=True: batch-statistics BatchNorm per view (and the backward pass,
+    gvcnn-tf_amd/training.py).  Shares the variable store of configure()."""
+    from .training import TrainGVCNN
+    N, V, H, W, _ = inputs.shape
+    key = (_CONFIG["backbone"], N, V, H, W, num_classes, num_group, str(inputs.device))
+    if key not in _TRAIN_ENGINES:
+        _TRAIN_ENGINES[key] = TrainGVCNN(_CONFIG["backbone"], N, V, H, W, num_classes, num_group,
+                                         _CONFIG["backbone_params"], _CONFIG["head_params"], inputs.device,
+                                         _CONFIG["raw_tap"], _CONFIG["final_tap"])
+    return _TRAIN_ENGINES[key]
 
 
 def gvcnn(inputs, num_classes, group_scheme, group_weight, is_training=True,
@@ -400,9 +410,15 @@ def gvcnn(inputs, num_classes, group_scheme, group_weight, is_training=True,
     shape_descriptor [N,h,w,C], logits [N,num_classes]).  group_scheme [G,V] / group_weight [G] are the
     fed placeholders of train.py:127-128 (host arrays or device tensors).  dropout_keep_prob is
     accepted and has no effect, as in the reference (it only reaches heads that are never fetched).
-    Variables are created on first use and reused afterwards (AUTO_REUSE)."""
-    _reject_training(is_training)
+    Variables are created on first use and reused afterwards (AUTO_REUSE).  is_training=True (the
+    reference default) normalises with batch statistics per view, like the V graph copies of the reference."""
     G = (group_scheme.shape[0] if hasattr(group_scheme, "shape") else len(group_scheme))
+    if is_training:
+        teng = _train_engine(inputs, num_classes, G)
+        scores, S, logits, _ = teng.forward(inputs, None, g_scheme=np.asarray(
+            group_scheme.cpu() if torch.is_tensor(group_scheme) else group_scheme), g_weight=np.asarray(
+            group_weight.cpu() if torch.is_tensor(group_weight) else group_weight))
+        return [scores[v] for v in range(teng.V)], S, logits
     eng = _engine(inputs, num_classes, G)
     scores = eng.forward_phase1(inputs)
     S, logits = eng.forward_phase2(group_scheme, group_weight)
@@ -411,7 +427,11 @@ def gvcnn(inputs, num_classes, group_scheme, group_weight, is_training=True,
 
 def basic(inputs, num_classes, is_training=True, dropout_keep_prob=0.8, reuse=AUTO_REUSE):
     """nets/model.py:169-206."""
-    _reject_training(is_training)
+    if is_training:                                   # max over all views == one group holding every view
+        teng = _train_engine(inputs, num_classes, 1)
+        _, S, logits, _ = teng.forward(inputs, None, g_scheme=np.ones((1, inputs.shape[1]), np.int32),
+                                       g_weight=np.ones(1, np.float32))
+        return S, logits
     eng = _engine(inputs, num_classes, 1)
     return eng.forward_basic(inputs)
 

@@ -101,8 +101,11 @@ def test_functional_surface_and_basic():
     assert_close(Lb.cpu().numpy(), oLb)
     s3, S3, L3 = gv.gvcnn_fused(x.to(DEV), C, G)
     assert_close(S3.cpu().numpy(), o_S)
-    with pytest.raises(NotImplementedError):
-        gv.gvcnn(x.to(DEV), C, o_scheme, o_weight)                      # is_training defaults to True
+    # is_training defaults to True (model.py:105): batch-statistics BN per view, like the reference graph
+    tr = OM.gvcnn(x, C, P, Hd, G, "resnet_v2_50", is_training=True)
+    ts, tS, tL = gv.gvcnn(x.to(DEV), C, tr[3], tr[4])
+    assert_close(tS.cpu().numpy(), tr[1], rtol=5e-3, atol_rel=1e-3)
+    assert_close(np.array([float(v) for v in ts]), np.array(tr[0]), rtol=5e-3, atol_rel=1e-3)
     with pytest.raises(IndexError):                                      # G=5 with scores up to 0.9 (D6)
         gv.gvcnn_fused(x.to(DEV), C, 5)
 
