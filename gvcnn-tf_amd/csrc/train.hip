@@ -27,55 +27,94 @@ __global__ __launch_bounds__(256) void accumulate_f32(const float* __restrict__ 
 //   MODE 0 (BN forward stats):  u = z,            w = z                       -> sum z, sum z^2
 //   MODE 1 (BN backward):       u = dy*[y>0],     w = (z-mean)*inv            -> sum g, sum g*zhat
 //   MODE 2 (bias gradient):     u = dz,           w = 0
-// Thread layout: 64 consecutive channels x 4 pixel lanes; grid (channel blocks, pixel splits, G).
-template <int MODE>
+// Thread layout: VEC consecutive channels per thread (16-byte loads when VEC = 4), 64/VEC... threads span
+// 64 channels, the remaining threads of the 256 are pixel lanes; grid (channel blocks, pixel splits, G).
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict__ z, int z_ld,
                                                         const float* __restrict__ dy, int dy_ld,
                                                         const float* __restrict__ y, int y_ld,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ inv, int nb, int hw, int c,
                                                         int G, double* __restrict__ acc) {
-    const int cl = threadIdx.x & 63;
-    const int pl = threadIdx.x >> 6;
-    const int ch = blockIdx.x * 64 + cl;
+    constexpr int TPC = 64 / VEC;                          // threads across the 64-channel block
+    constexpr int PL = 256 / TPC;                          // pixel lanes
+    const int cl = threadIdx.x % TPC;
+    const int pl = threadIdx.x / TPC;
+    const int ch = blockIdx.x * 64 + cl * VEC;
     const int g = blockIdx.z;
     const int nimg = (nb - g + G - 1) / G;                 // images of this group
     const int64_t npix = (int64_t)nimg * hw;
     const int64_t per = (npix + gridDim.y - 1) / gridDim.y;
     const int64_t p0 = (int64_t)blockIdx.y * per;
     const int64_t p1 = p0 + per < npix ? p0 + per : npix;
-    double s0 = 0.0, s1 = 0.0;
-    if (ch < c) {
-        float mu = 0.f, iv = 0.f;
-        if (MODE == 1) { mu = mean[g * c + ch]; iv = inv[g * c + ch]; }
-        for (int64_t p = p0 + pl; p < p1; p += 4) {
+    double s0[VEC], s1[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.0;
+    if (ch < c) {                                          // c % VEC == 0 (checked by the launcher)
+        float mu[VEC], iv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
+            iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
+        }
+        for (int64_t p = p0 + pl; p < p1; p += PL) {
             const int k = (int)(p / hw);
             const int64_t pix = (int64_t)(k * G + g) * hw + (p - (int64_t)k * hw);
-            if (MODE == 0) {
-                const float v = z[pix * z_ld + ch];
-                s0 += v;
-                s1 += (double)v * v;
-            } else if (MODE == 1) {
-                float gr = dy[pix * dy_ld + ch];
-                if (y && !(y[pix * y_ld + ch] > 0.f)) gr = 0.f;
-                s0 += gr;
-                s1 += (double)gr * ((z[pix * z_ld + ch] - mu) * iv);
+            float zv[VEC], gv[VEC], yv[VEC];
+            if constexpr (VEC == 4) {
+                if (MODE != 2) *reinterpret_cast<f32x4*>(zv) = *reinterpret_cast<const f32x4*>(z + pix * z_ld + ch);
+                if (MODE != 0) *reinterpret_cast<f32x4*>(gv) = *reinterpret_cast<const f32x4*>(dy + pix * dy_ld + ch);
+                if (MODE == 1 && y) *reinterpret_cast<f32x4*>(yv) = *reinterpret_cast<const f32x4*>(y + pix * y_ld + ch);
             } else {
-                s0 += dy[pix * dy_ld + ch];
+                if (MODE != 2) zv[0] = z[pix * z_ld + ch];
+                if (MODE != 0) gv[0] = dy[pix * dy_ld + ch];
+                if (MODE == 1 && y) yv[0] = y[pix * y_ld + ch];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (MODE == 0) {
+                    s0[e] += zv[e];
+                    s1[e] += (double)zv[e] * zv[e];
+                } else if (MODE == 1) {
+                    float gr = gv[e];
+                    if (y && !(yv[e] > 0.f)) gr = 0.f;
+                    s0[e] += gr;
+                    s1[e] += (double)gr * ((zv[e] - mu[e]) * iv[e]);
+                } else {
+                    s0[e] += gv[e];
+                }
             }
         }
     }
-    __shared__ double red[2][4][64];
-    red[0][pl][cl] = s0;
-    red[1][pl][cl] = s1;
+    __shared__ double red[2][PL][64];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        red[0][pl][cl * VEC + e] = s0[e];
+        red[1][pl][cl * VEC + e] = s1[e];
+    }
     __syncthreads();
-    if (pl == 0 && ch < c) {
-        s0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        s1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-        atomicAdd(&acc[((size_t)g * c + ch) * 2], s0);
-        if (MODE != 2) atomicAdd(&acc[((size_t)g * c + ch) * 2 + 1], s1);
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < c) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
+        const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
+        atomicAdd(&acc[o], a);
+        if (MODE != 2) atomicAdd(&acc[o + 1], b);
     }
 }
+
+template <int MODE>
+void launch_grouped_sums(dim3 grid, hipStream_t st, bool vec, const float* z, int z_ld, const float* dy, int dy_ld,
+                         const float* y, int y_ld, const float* mean, const float* inv, int nb, int hw, int c, int G,
+                         double* acc) {
+    if (vec)
+        hipLaunchKernelGGL((grouped_sums_f32<MODE, 4>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv,
+                           nb, hw, c, G, acc);
+    else
+        hipLaunchKernelGGL((grouped_sums_f32<MODE, 1>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv,
+                           nb, hw, c, G, acc);
+}
+
+inline bool vec_ok(const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15u) == 0 && (ld & 3) == 0); }
 
 // mean/var (biased) + folded scale/shift per (group, channel)
 __global__ void bn_finalize_grouped(const double* __restrict__ acc, int G, int c, const int* __restrict__ counts,
@@ -372,6 +411,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int ohow = oh * ow;
+    const bool xvec = (x_ld & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);      // 16-byte loads when rows are aligned
+    const bool zvec = (dz_ld & 3) == 0 && ((((uintptr_t)dz) & 15u) == 0);
     // loader: thread -> (pixel row p = tid/16 (+16), 4 channels q = tid%16)
     const int lp = tid >> 4, lq = (tid & 15) * 4;
     for (int64_t mt = m0; mt < m1; mt += PT) {
@@ -387,12 +428,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float* __restrict__ 
                 const int iy = oy * stride + fr - pad_t, ix = ox * stride + fs - pad_l;
                 if ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) {
                     const float* xp = x + (((size_t)n * ih + iy) * iw + ix) * x_ld + ci0 + lq;
+                    if (xvec && ci0 + lq + 3 < cin) {
+                        xv = *reinterpret_cast<const f32x4*>(xp);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (ci0 + lq + e < cin) xv[e] = xp[e];
+                        for (int e = 0; e < 4; ++e) if (ci0 + lq + e < cin) xv[e] = xp[e];
+                    }
                 }
                 const float* zp = dz + (size_t)m * dz_ld + co0 + lq;
+                if (zvec && co0 + lq + 3 < cout) {
+                    zv = *reinterpret_cast<const f32x4*>(zp);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (co0 + lq + e < cout) zv[e] = zp[e];
+                    for (int e = 0; e < 4; ++e) if (co0 + lq + e < cout) zv[e] = zp[e];
+                }
             }
             *reinterpret_cast<f32x4*>(&sX[p][lq]) = xv;
             *reinterpret_cast<f32x4*>(&sZ[p][lq]) = zv;
@@ -435,9 +484,8 @@ extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32
     const int64_t npix = (int64_t)(nb / num_groups) * hw;
     int splits = (int)((npix + 2047) / 2048);
     if (splits > 256) splits = 256;
-    hipLaunchKernelGGL(grouped_sums_f32<0>, dim3((c + 63) / 64, splits, num_groups), dim3(256), 0, st, z, z_ld,
-                       (const float*)nullptr, 0, (const float*)nullptr, 0, (const float*)nullptr,
-                       (const float*)nullptr, nb, hw, c, num_groups, accum);
+    launch_grouped_sums<0>(dim3((c + 63) / 64, splits, num_groups), st, (c & 3) == 0 && vec_ok(z, z_ld), z, z_ld,
+                           nullptr, 0, nullptr, 0, nullptr, nullptr, nb, hw, c, num_groups, accum);
     hipLaunchKernelGGL(bn_finalize_grouped, dim3((num_groups * c + 255) / 256), dim3(256), 0, st, accum,
                        num_groups, c, counts, gamma, beta, eps, mean, var, inv, scale, shift);
     GV_LAUNCH_CHECK();
@@ -470,8 +518,9 @@ extern "C" int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const floa
     const int64_t npix = (int64_t)(nb / num_groups) * hw;
     int splits = (int)((npix + 2047) / 2048);
     if (splits > 256) splits = 256;
-    hipLaunchKernelGGL(grouped_sums_f32<1>, dim3((c + 63) / 64, splits, num_groups), dim3(256), 0, st, z, z_ld, dy,
-                       dy_ld, y, y_ld, mean, inv, nb, hw, c, num_groups, accum);
+    launch_grouped_sums<1>(dim3((c + 63) / 64, splits, num_groups), st,
+                           (c & 3) == 0 && vec_ok(z, z_ld) && vec_ok(dy, dy_ld) && vec_ok(y, y_ld), z, z_ld, dy, dy_ld, y,
+                           y_ld, mean, inv, nb, hw, c, num_groups, accum);
     hipLaunchKernelGGL(bn_bwd_apply_grouped_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, dy, dy_ld,
                        y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw, c, num_groups, dz, dz_ld);
     if (dbeta || dgamma)
@@ -497,9 +546,8 @@ extern "C" int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)c, st));
     int splits = (int)((npix + 2047) / 2048);
     if (splits > 1024) splits = 1024;
-    hipLaunchKernelGGL(grouped_sums_f32<2>, dim3((c + 63) / 64, splits, 1), dim3(256), 0, st, (const float*)nullptr,
-                       0, dz, dz_ld, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr,
-                       (int)npix, 1, c, 1, accum);
+    launch_grouped_sums<2>(dim3((c + 63) / 64, splits, 1), st, (c & 3) == 0 && vec_ok(dz, dz_ld), nullptr, 0, dz, dz_ld,
+                           nullptr, 0, nullptr, nullptr, (int)npix, 1, c, 1, accum);
     hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, 1, c, dbias, (float*)nullptr);
     GV_LAUNCH_CHECK();
     return GV_OK;
