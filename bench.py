@@ -35,7 +35,10 @@ MATH = {"f32": ("conv_igemm_f32", PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 
                    "fp32 operands split into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per product block, "
                    "fp32 accumulate: fp32-level accuracy (dropped terms <= 2^-24 relative); peak = bf16 dense / 6"),
         "bf16x2": ("conv_igemm_bf16s<NP=2>", PEAK_BF16_MFMA_TFLOPS / 3, "2 bf16 planes, 3 MFMAs (~2^-16 relative)"),
-        "bf16x1": ("conv_igemm_bf16s<NP=1>", PEAK_BF16_MFMA_TFLOPS, "plain bf16 products, fp32 accumulate")}
+        "bf16x1": ("conv_igemm_bf16s<NP=1>", PEAK_BF16_MFMA_TFLOPS, "plain bf16 products, fp32 accumulate"),
+        # 16-bit STORAGE (configs c3-c5; not the bench line, which is fp32): --storage bf16 | f16
+        "bf16": ("conv_igemm_lp<bf16>", PEAK_BF16_MFMA_TFLOPS, "bf16 activations/filters in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate + epilogue"),
+        "f16": ("conv_igemm_lp<f16>", PEAK_BF16_MFMA_TFLOPS, "fp16 activations/filters in HBM, v_mfma_f32_32x32x16_f16, fp32 accumulate + epilogue")}
 V, H, W, G, C = 12, 224, 224, 7, 10             # configs[1]; ModelNet10 -> 10 classes
 BACKBONE = "inception_v3"
 # other BASELINE.json configs, fp32 forward variants (parity-test cases; not the bench line)
@@ -61,7 +64,13 @@ def parse():
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
     ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
-    return ap.parse_args()
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f16"],
+                    help="activation/filter storage type; f32 is BASELINE.json configs[1] (the bench line), bf16/f16 are "
+                         "the dtypes of configs[2..4]")
+    a = ap.parse_args()
+    if a.storage != "f32":
+        a.math = a.storage
+    return a
 
 
 def roofline(eng, x, math, iters=5):
@@ -144,7 +153,8 @@ def main():
     from gvcnn_tf_amd.sharding import ShardedGVCNN
 
     N = a.shapes
-    eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math, lanes=not a.no_lanes)
+    eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math if a.storage == "f32" else "f32",
+                   lanes=not a.no_lanes, storage=a.storage)
     P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
     Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
     eng.plan.bind(P)
@@ -187,12 +197,13 @@ def main():
             "metric": "views/sec", "value": round(views_per_step / (ms * 1e-3), 1), "unit": "views/s",
             "shapes_per_sec": round(N * world / (ms * 1e-3), 2),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.storage,
             "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: " if a.preset == "c2" else "preset %s (fp32 forward variant): " % a.preset)
+            "config": {"workload": ("BASELINE.json configs[1]: " if a.preset == "c2" and a.storage == "f32"
+                                    else "preset %s (%s forward variant): " % (a.preset, a.storage))
                                    + "ModelNet-shaped, %d views x %dx%dx3, %s backbone (raw tap %s, final tap %s), "
-                                     "num_groups=%d, fp32, forward only" % (V, H, W, BACKBONE, eng.plan.raw_tap,
-                                                                            eng.plan.final_tap, G),
+                                     "num_groups=%d, %s, forward only" % (V, H, W, BACKBONE, eng.plan.raw_tap,
+                                                                          eng.plan.final_tap, G, a.storage),
                        "shapes_per_gpu": N, "views_per_gpu": N * V, "global_views": views_per_step,
                        "num_groups": G, "num_classes": C,
                        "exchange": a.exchange if world > 1 else "none",
@@ -219,7 +230,7 @@ def main():
             torch.cuda.synchronize()
             ms32 = (time.perf_counter() - t1) / 5 * 1e3
             r32 = roofline(e32, x.view(N * V, H, W, 3), "f32", iters=3)
-            dS = float((e32.shape_descriptor - eng.shape_descriptor).abs().max() /
+            dS = float((e32.shape_descriptor - eng.shape_descriptor.float()).abs().max() /
                        e32.shape_descriptor.abs().max())
             out["exact_f32_mfma"] = {"views_per_sec": round(N * V / (ms32 * 1e-3), 1), "ms_per_step": round(ms32, 3),
                                      "roofline_frac": r32["frac"], "achieved_tflops": r32["achieved"],

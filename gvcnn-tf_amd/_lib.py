@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
 
-GV_F32, GV_BF16 = 0, 1
-GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT = 1, 2, 4
+GV_F32, GV_BF16, GV_F16 = 0, 1, 2
+GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT, GV_CONV_X_F32 = 1, 2, 4, 8
 GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
 GV_POOL_MAX, GV_POOL_AVG = 0, 1
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1

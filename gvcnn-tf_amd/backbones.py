@@ -81,6 +81,7 @@ class BackbonePlan:
     def __init__(self, nb, height, width, dtype=_lib.GV_F32, math_mode=_lib.GV_MATH_F32):
         self.lib = _lib.load()
         self.nb, self.height, self.width, self.dtype = nb, height, width, dtype
+        self.esz = 4 if dtype == _lib.GV_F32 else 2          # bytes per stored activation / filter element
         self.math_mode = math_mode
         self.ops = []            # dict records
         self.vbufs = []          # [size_elems, persistent]
@@ -214,7 +215,7 @@ class BackbonePlan:
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
                              split=0, cout=cout,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
-                             bytes=4.0 * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout)))
+                             bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout)))
         return (out, y2) if next_preact is not None else out
 
     def pool(self, x, k, stride, padding, mode, out=None, name="pool"):
@@ -225,7 +226,7 @@ class BackbonePlan:
         assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, x.c)
         self._record(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t,
                              pad_l=pad_l, mode=mode, flops=0.0,
-                             bytes=4.0 * (x.npix * x.c + out.npix * out.c)))
+                             bytes=float(self.esz) * (x.npix * x.c + out.npix * out.c)))
         return out
 
     def bn_relu(self, x, bn_scope, eps, name):
@@ -233,7 +234,7 @@ class BackbonePlan:
         out = self.new_tensor(x.nb, x.h, x.w, x.c)
         so, ho = self._scale_shift("bn", bn_scope, x.c, eps, True)
         self._record(dict(kind="ssa", name=name, x=x, y=out, scale_off=so, shift_off=ho, relu=True,
-                             flops=0.0, bytes=8.0 * x.npix * x.c))
+                             flops=0.0, bytes=2.0 * self.esz * x.npix * x.c))
         return out
 
     # ---- lowering ----------------------------------------------------------------------------
@@ -300,6 +301,8 @@ class BackbonePlan:
                 return SLOT_INPUT, t.off
             return SLOT_ACT0 + vmap[t.vbuf], t.off
 
+        lowp = self.dtype != _lib.GV_F32
+        wmul = 2 if lowp else 1                               # arena offsets are 4-byte units; plan offsets are elements
         for op in self.ops:
             x, y = op["x"], op["y"]
             xs, xo = ref(x)
@@ -312,13 +315,15 @@ class BackbonePlan:
                     flags |= _lib.GV_CONV_SPLIT
                 elif y2 is not None:
                     flags |= _lib.GV_CONV_RELU2
+                if lowp and x.vbuf < 0:
+                    flags |= _lib.GV_CONV_X_F32               # the images stay fp32; the stem's loader rounds them
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], y.h, y.w, op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
                                   flags, self.dtype, split, op.get("tile", 0), self.math_mode)
                 rs, ro = ref(res)
                 y2s, y2o = ref(y2)
-                _lib.check(lib.gv_plan_add_conv(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"],
+                _lib.check(lib.gv_plan_add_conv(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"] * wmul,
                                                 SLOT_SS, op["scale_off"], op["shift_off"], rs, ro,
                                                 ys, yo, y2s, y2o, op["scale2_off"], op["shift2_off"]),
                            "gv_plan_add_conv(%s)" % op["name"])
@@ -333,12 +338,12 @@ class BackbonePlan:
                                                            op["shift_off"], ys, yo),
                            "gv_plan_add_scale_shift_act(%s)" % op["name"])
         self._schedule(vmap)
-        tdtype = torch.float32
-        self.weights = torch.zeros(max(self.w_elems, 4), dtype=tdtype, device=device)
+        self.tdtype = TORCH_DTYPES[self.dtype]
+        self.weights = torch.zeros(max(self.w_elems, 4), dtype=torch.float32, device=device)   # 4-byte units
         self.ss = torch.zeros(max(self.ss_elems, 4), dtype=torch.float32, device=device)
-        self.act = [torch.empty(n, dtype=tdtype, device=device) for n in phys_sizes]
+        self.act = [torch.empty((n + 7) // 8 * 8, dtype=self.tdtype, device=device) for n in phys_sizes]
         self._bufs = [None, self.weights, self.ss] + self.act
-        self.act_bytes = sum(phys_sizes) * 4
+        self.act_bytes = sum(phys_sizes) * self.esz
         return self
 
     def _schedule(self, vmap):
@@ -472,7 +477,8 @@ class BackbonePlan:
         the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
         chain sums k in the same order under every configuration, so results are bitwise unchanged."""
         lib = self.lib
-        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode)
+        # the 16-bit storage kernel has the tile table of the split-bf16 kernel
+        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dtype == _lib.GV_F32 else _lib.GV_MATH_BF16X1)
         self.run(x)
         chosen = {}
         try:
@@ -722,12 +728,15 @@ TAPS = {"resnet_v2_50": ("resnet_v2_50/block3", "resnet_v2_50/block4"),
         "inception_v3": ("Mixed_6e", "Mixed_7c")}
 
 
+DTYPES = {"f32": _lib.GV_F32, "bf16": _lib.GV_BF16, "f16": _lib.GV_F16}
+TORCH_DTYPES = {_lib.GV_F32: torch.float32, _lib.GV_BF16: torch.bfloat16, _lib.GV_F16: torch.float16}
 MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": _lib.GV_MATH_BF16X2,
               "bf16x1": _lib.GV_MATH_BF16X1}
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
               math="f32", lanes=True):
+    dtype = DTYPES[dtype] if isinstance(dtype, str) else dtype
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     b.use_lanes = bool(lanes)
     raw_tap = raw_tap or TAPS[backbone][0]

@@ -380,6 +380,7 @@ extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
 extern "C" int64_t gv_packed_filter_bytes(int32_t kh, int32_t kw, int32_t cin, int32_t cout,
                                           int32_t dtype, int32_t math_mode) {
     if (kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
+    if (dtype == GV_BF16 || dtype == GV_F16) return gvconv::lp_packed_bytes(kh, kw, cin, cout);
     if (dtype != GV_F32) return GV_E_UNSUPPORTED;
     const int np = planes_of(math_mode);
     if (np < 0) return GV_E_BADARG;
@@ -392,6 +393,8 @@ extern "C" int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, 
                                    int32_t cout, void* w_packed, int32_t dtype, int32_t math_mode,
                                    void* stream) {
     if (!w_hwio || !w_packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return GV_E_BADARG;
+    if (dtype == GV_BF16 || dtype == GV_F16)
+        return gvconv::lp_pack_filter(w_hwio, kh, kw, cin, cout, dtype, w_packed, (hipStream_t)stream);
     if (dtype != GV_F32) return GV_E_UNSUPPORTED;
     const int np = planes_of(math_mode);
     if (np < 0) return GV_E_BADARG;
@@ -430,10 +433,12 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
                                     (d->ow - 1) * d->stride - d->pad_l >= d->iw))
             return GV_E_BADARG;
     }
-    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
-    const int np = planes_of(d->math_mode);
+    const bool lp = d->dtype == GV_BF16 || d->dtype == GV_F16;
+    if (d->dtype != GV_F32 && !lp) return GV_E_UNSUPPORTED;
+    if ((d->flags & GV_CONV_X_F32) && !lp) return GV_E_BADARG;
+    const int np = lp ? 1 : planes_of(d->math_mode);
     if (np < 0) return GV_E_BADARG;
-    const int ncfg = np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs();
+    const int ncfg = lp ? gvconv::lp_num_cfgs() : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs());
     if (d->tile_cfg < 0 || d->tile_cfg > ncfg) return GV_E_BADARG;
     const int64_t M64 = (int64_t)d->nb * d->oh * d->ow;
     if (M64 > 0x7fffffff || (int64_t)d->nb * d->ih * d->iw > 0x7fffffff) return GV_E_UNSUPPORTED;
@@ -459,6 +464,15 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.dil_shift = d->in_dilation == 2 ? 1 : 0;
     if (a.dil_shift && (np == 0 || (d->cin % CH != 0) || d->stride != 1)) return GV_E_UNSUPPORTED;
 
+    if (lp) {
+        // vector loader: 8-channel (16-byte) chunks inside one filter tap, 16-byte aligned pixels
+        const bool xf32 = (d->flags & GV_CONV_X_F32) != 0;
+        const bool generic = xf32 || (d->cin % 8 != 0) || (d->x_ld % 8 != 0) || !gv_aligned16(x);
+        if (a.dil_shift && generic) return GV_E_UNSUPPORTED;
+        const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
+                        : (d->tile_cfg > 0 ? d->tile_cfg - 1 : gvconv::lp_pick_tile(a.M, a.cout, a.K));
+        return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
+    }
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
     const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
     if (np > 0) {

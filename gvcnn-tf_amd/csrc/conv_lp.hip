@@ -1,0 +1,423 @@
+// conv_lp.hip — implicit-GEMM convolution on 16-bit storage (GV_BF16 / GV_F16 tensors, fp32 accumulate):
+// the path of configs c3-c5.  Activations, residual, outputs and the packed filter are
+// 16-bit in HBM; products run on v_mfma_f32_32x32x16_{bf16,f16}; the BN fold (scale/shift), residual
+// add and ReLU are applied to the fp32 accumulator before the single rounding to the storage type.
+//
+// Structure (4 or 8 waves, wave tile TM x TN MFMA tiles of 32x32, k-tile = 32):
+//   * LDS row = 64 B (32 values) + 16 B pad = 5 sixteen-byte slots (odd): the ds_read_b128 fragment reads
+//     (lane (r = lane&31, h = lane>>5) reads k = 16s+8h .. +7 of row r) hit 16 distinct 4-bank groups in
+//     every 16-lane service group; the loader's ds_write_b128 (4 lanes per row) overlap by one chunk in
+//     8, inside the store's register-transfer time;
+//   * a loader lane owns one 16-byte chunk (8 channels of one filter tap) per slot; its tap position
+//     (r, s, c) advances incrementally, loads are unconditional from a clamped address and zeroed by a
+//     select, so the compiler counts vmcnt and keeps two k-tiles of global loads in flight;
+//   * fragments are double buffered in registers; the k-tile barrier sits between the two halves of a
+//     tile's MFMAs;
+//   * GENERIC variant (cin % 8 != 0: the stems' cin = 3) gathers element-wise, optionally straight from the
+//     fp32 network input (GV_CONV_X_F32), so no separate cast pass over the images exists.
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+using gvconv::ConvArgs;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KT = 32;                      // k-tile depth
+constexpr int RB = 2 * KT + 16;             // LDS row bytes
+
+template <typename T>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (std::is_same<T, __bf16>::value)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned short to_bits(float v) {
+    const T h = (T)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+template <typename T>
+__device__ __forceinline__ float from_bits(unsigned short b) {
+    return (float)__builtin_bit_cast(T, b);
+}
+
+// y = act(acc*scale + shift (+ residual)) rounded once to T; y2 = second activation or split destination
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void lp_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                            int wm, int wn, int lane) {
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    const unsigned short* res = reinterpret_cast<const unsigned short*>(a.res);
+    unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
+    unsigned short* y2 = reinterpret_cast<unsigned short*>(a.y2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + col_l;
+        if (col >= a.cout) continue;
+        const float sc = a.scale[col], sh = a.shift[col];
+        const bool to_second = a.split > 0 && col >= a.split;
+        const bool dual = y2 != nullptr && a.split == 0;
+        float sc2 = 0.f, sh2 = 0.f;
+        if (dual) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
+        unsigned short* ybase = to_second ? y2 + (col - a.split) : y + col;
+        const int yld = to_second ? a.y2_ld : a.y_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + (wm * TM + i) * 32 + row_h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + (r & 3) + 8 * (r >> 2);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (res) v += from_bits<T>(res[(size_t)m * a.res_ld + col]);
+                if (dual) {
+                    float v2 = v * sc2 + sh2;
+                    if (a.relu2) v2 = fmaxf(v2, 0.f);
+                    y2[(size_t)m * a.y2_ld + col] = to_bits<T>(v2);
+                }
+                if (a.relu) v = fmaxf(v, 0.f);
+                ybase[(size_t)m * yld] = to_bits<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) {
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    static_assert(GENERIC || !XF32, "fp32 input only on the gather path");
+    constexpr int NT = WM * WN * 64;                 // threads
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int A_SLOTS = (BM * 4 + NT - 1) / NT;  // (row, chunk) slots: 8 values each
+    constexpr int B_SLOTS = (BN * 4 + NT - 1) / NT;
+    constexpr int NMF = TM * TN * 2;                 // MFMAs per k-tile
+    constexpr int HALF = NMF / 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sA = smem_raw;                             // [2][BM][RB]
+    char* sB = smem_raw + 2 * BM * RB;               // [2][BN][RB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % a.tiles_n;
+    const int tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int q = tid & 3;                           // this thread's 16-byte chunk of every row it loads
+    const unsigned short* xs = reinterpret_cast<const unsigned short*>(a.x);
+
+    int a_img[A_SLOTS], a_iy0[A_SLOTS], a_ix0[A_SLOTS];
+    const int ohow = a.oh * a.ow;
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int row = (tid + i * NT) >> 2;
+        const int m = m0 + row;
+        if (row < BM && m < a.M) {
+            const int n = m / ohow;
+            const int rem = m - n * ohow;
+            const int oy = rem / a.ow;
+            const int ox = rem - oy * a.ow;
+            a_img[i] = n * a.ih;
+            a_iy0[i] = oy * a.stride - a.pad_t;
+            a_ix0[i] = ox * a.stride - a.pad_l;
+        } else {
+            a_img[i] = 0;
+            a_iy0[i] = -(1 << 28);
+            a_ix0[i] = 0;
+        }
+    }
+    const char* b_ptr[B_SLOTS];
+    bool b_ok[B_SLOTS];
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) {
+        const int row = (tid + i * NT) >> 2;
+        const int n = n0 + row;
+        b_ok[i] = (row < BN);
+        // rows past cout re-read the last filter: their accumulator columns are never stored
+        const int nc = n < a.cout ? n : a.cout - 1;
+        b_ptr[i] = (const char*)a.w + ((size_t)nc * a.Kpad + 8 * q) * 2;
+    }
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    u32x4 ra[2][A_SLOTS];                             // tile t is staged in register set t & 1
+    u32x4 rb[2][B_SLOTS];
+    // filter tap / channel of this thread's chunk in the NEXT tile to load
+    int fc = 8 * q, fs = 0, fr = 0;
+    if constexpr (!GENERIC) {
+        while (fc >= a.cin) { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } }
+    }
+
+    auto load_tile = [&](auto rsc, int kt) {
+        constexpr int RS = decltype(rsc)::value;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if constexpr (!GENERIC) {
+                const int iyn = a_iy0[i] + fr;
+                const int ixn = a_ix0[i] + fs;
+                const int dmask = (1 << a.dil_shift) - 1;     // zero-dilated input: see conv_bf16s.hip
+                const int iy = iyn >> a.dil_shift;
+                const int ix = ixn >> a.dil_shift;
+                const bool ok = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw &&
+                                fr < a.kh;
+                const int iyc = min(max(iy, 0), a.ih - 1);
+                const int ixc = min(max(ix, 0), a.iw - 1);
+                const unsigned short* p = xs + ((size_t)(a_img[i] + iyc) * a.iw + ixc) * a.x_ld + fc;
+                const u32x4 ld = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? ld[j] : 0u;
+            } else {
+                unsigned short e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = kt * KT + 8 * q + j;
+                    e[j] = 0;
+                    if (k < a.K) {
+                        const int rs = k / a.cin;
+                        const int c = k - rs * a.cin;
+                        const int r = rs / a.kw;
+                        const int s = rs - r * a.kw;
+                        const int iy = a_iy0[i] + r;
+                        const int ix = a_ix0[i] + s;
+                        if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) {
+                            const size_t off = ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + c;
+                            if constexpr (XF32) e[j] = to_bits<T>(a.x[off]);
+                            else e[j] = xs[off];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16);
+            }
+            ra[RS][i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int ktc = kt < a.ktiles ? kt : a.ktiles - 1;          // prefetch past the end re-reads the last tile
+            rb[RS][i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (size_t)ktc * (KT * 2));
+        }
+    };
+    auto advance_tap = [&]() {
+        if constexpr (!GENERIC) {
+            fc += KT;
+            while (fc >= a.cin) { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } }
+        }
+    };
+    auto store_tile = [&](auto rsc, int buf) {
+        constexpr int RS = decltype(rsc)::value;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int idx = tid + i * NT;
+            if (A_SLOTS * NT == BM * 4 || idx < BM * 4)
+                *reinterpret_cast<u32x4*>(sA + buf * BM * RB + (idx >> 2) * RB + 16 * q) = ra[RS][i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int idx = tid + i * NT;
+            if (B_SLOTS * NT == BN * 4 || b_ok[i])
+                *reinterpret_cast<u32x4*>(sB + buf * BN * RB + (idx >> 2) * RB + 16 * q) = rb[RS][i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * RB + 16 * (lane >> 5);
+    const char* a_frag = sA + (wm * TM * 32) * RB + frag_off;
+    const char* b_frag = sB + (wn * TN * 32) * RB + frag_off;
+
+    u32x4 fa[2][TM][2], fb[2][TN][2];
+    auto read_frags = [&](auto setc, int buf) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[S][i][s] = *reinterpret_cast<const u32x4*>(a_frag + buf * BM * RB + i * 32 * RB + s * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[S][j][s] = *reinterpret_cast<const u32x4*>(b_frag + buf * BN * RB + j * 32 * RB + s * 32);
+        }
+    };
+    auto mfma_range = [&](auto setc, auto loc, auto hic) {
+        constexpr int S = decltype(setc)::value;
+        constexpr int LO = decltype(loc)::value, HI = decltype(hic)::value;
+#pragma unroll
+        for (int t = LO; t < HI; ++t) {
+            const int s = t / (TM * TN);
+            const int ij = t % (TM * TN);
+            const int i = ij / TN, j = ij % TN;
+            acc[i][j] = mfma16<T>(fa[S][i][s], fb[S][j][s], acc[i][j]);
+        }
+    };
+    using IH = std::integral_constant<int, HALF>;
+    using IN = std::integral_constant<int, NMF>;
+
+    auto step = [&](auto setc, int kt) {
+        constexpr int S = decltype(setc)::value;
+        using IS = std::integral_constant<int, S>;
+        using IO = std::integral_constant<int, S ^ 1>;
+        const int buf = kt & 1;
+        mfma_range(IS{}, I0{}, IH{});
+        store_tile(IO{}, buf ^ 1);                             // register set S^1 holds tile kt+1
+        advance_tap();
+        load_tile(IO{}, kt + 3);                               // refill it; tile kt+2 stays in flight in set S
+        __syncthreads();
+        read_frags(IO{}, buf ^ 1);
+        mfma_range(IS{}, IH{}, IN{});
+    };
+
+    load_tile(I0{}, 0);
+    store_tile(I0{}, 0);
+    advance_tap();
+    load_tile(I1{}, 1);
+    advance_tap();
+    load_tile(I0{}, 2);
+    __syncthreads();
+    read_frags(I0{}, 0);
+    int kt = 0;
+    for (; kt + 2 < a.ktiles; kt += 2) {
+        step(I0{}, kt);
+        step(I1{}, kt + 1);
+    }
+    if (a.ktiles - kt == 2) {
+        step(I0{}, kt);
+        mfma_range(I1{}, I0{}, IN{});
+    } else {
+        mfma_range(I0{}, I0{}, IN{});
+    }
+
+    lp_epilogue<T, TM, TN>(a, acc, m0, n0, wm, wn, lane);
+}
+
+// [kh][kw][cin][cout] fp32 -> [cout][Kpad] T, k = (r*kw+s)*cin + c, zero filled to a multiple of 32
+template <typename T>
+__global__ void pack_filter_lp(const float* __restrict__ w, int K, int Kpad, int cout,
+                               unsigned short* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)cout * Kpad) return;
+    const int n = (int)(i / Kpad);
+    const int k = (int)(i - (int64_t)n * Kpad);
+    out[i] = to_bits<T>(k < K ? w[(size_t)k * cout + n] : 0.f);
+}
+
+struct TileCfg { int bm, bn; };
+constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32},
+                              {256, 128}, {128, 256}, {256, 64}};   // the last three: 8 waves
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
+int launch_one(const ConvArgs& a, int64_t nwg, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!ok) return GV_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T, int WM, int WN, int TM, int TN>
+int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    ConvArgs a = a0;
+    a.tiles_n = gv_ceil_div(a.cout, BN);
+    const int tiles_m = gv_ceil_div(a.M, BM);
+    const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
+    if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * BM + 2 * BN) * RB;
+    if (xf32) return launch_one<T, WM, WN, TM, TN, true, true>(a, nwg, lds, st);
+    if (generic) return launch_one<T, WM, WN, TM, TN, true, false>(a, nwg, lds, st);
+    return launch_one<T, WM, WN, TM, TN, false, false>(a, nwg, lds, st);
+}
+
+template <typename T>
+int launch_t(int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_cfg<T, 2, 2, 2, 2>(a, generic, xf32, st);
+        case 1: return launch_cfg<T, 2, 2, 2, 1>(a, generic, xf32, st);
+        case 2: return launch_cfg<T, 2, 2, 1, 1>(a, generic, xf32, st);
+        case 3: return launch_cfg<T, 4, 1, 1, 3>(a, generic, xf32, st);
+        case 4: return launch_cfg<T, 2, 2, 1, 2>(a, generic, xf32, st);
+        case 5: return launch_cfg<T, 4, 1, 1, 1>(a, generic, xf32, st);
+        case 6: return launch_cfg<T, 4, 2, 2, 2>(a, generic, xf32, st);
+        case 7: return launch_cfg<T, 2, 4, 2, 2>(a, generic, xf32, st);
+        case 8: return launch_cfg<T, 4, 2, 2, 1>(a, generic, xf32, st);
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+namespace gvconv {
+
+int lp_num_cfgs() { return kNumTiles; }
+
+int lp_pick_tile(int M, int N, int /*K*/) {
+    int best = 0;
+    double best_cost = 1e30;
+    const int order[] = {0, 3, 1, 5};                 // 128 x {128, 96, 64, 32}
+    const double pen[] = {1.00, 1.02, 1.05, 1.20};
+    for (int t = 0; t < 4; ++t) {
+        const int bn = kTiles[order[t]].bn;
+        const double cost = (double)gv_ceil_div(N, bn) * bn * pen[t];
+        if (cost < best_cost) { best_cost = cost; best = order[t]; }
+    }
+    const int64_t blocks = (int64_t)gv_ceil_div(M, 128) * gv_ceil_div(N, kTiles[best].bn);
+    if (blocks < 1024) {
+        if (kTiles[best].bn == 128) best = 4;
+        else if (kTiles[best].bn == 64) best = 2;
+    }
+    return best;
+}
+
+int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
+    ConvArgs a = a0;
+    a.Kpad = (a.K + KT - 1) / KT * KT;
+    a.ktiles = a.Kpad / KT;
+    if (dtype == GV_BF16) return launch_t<__bf16>(cfg, a, generic, xf32, st);
+    if (dtype == GV_F16) return launch_t<_Float16>(cfg, a, generic, xf32, st);
+    return GV_E_UNSUPPORTED;
+}
+
+int64_t lp_packed_bytes(int kh, int kw, int cin, int cout) {
+    const int64_t K = (int64_t)kh * kw * cin;
+    return (int64_t)cout * ((K + KT - 1) / KT * KT) * 2;
+}
+
+int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int dtype, void* out, hipStream_t st) {
+    const int K = kh * kw * cin;
+    const int Kpad = (K + KT - 1) / KT * KT;
+    const dim3 grid((unsigned)gv_ceil_div((int64_t)cout * Kpad, 256));
+    if (dtype == GV_BF16)
+        hipLaunchKernelGGL(pack_filter_lp<__bf16>, grid, dim3(256), 0, st, w_hwio, K, Kpad, cout, (unsigned short*)out);
+    else if (dtype == GV_F16)
+        hipLaunchKernelGGL(pack_filter_lp<_Float16>, grid, dim3(256), 0, st, w_hwio, K, Kpad, cout, (unsigned short*)out);
+    else
+        return GV_E_UNSUPPORTED;
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+}  // namespace gvconv

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "gv_common.h"
+#include "lowp.h"
 
 namespace {
 
@@ -235,7 +236,9 @@ extern "C" int gv_view_score_partial(const void* raw, int32_t nb, int32_t hw, in
         num_views <= 0 || nb % num_views != 0)
         return GV_E_BADARG;
     if (order != GV_ORDER_SHAPE_MAJOR && order != GV_ORDER_VIEW_MAJOR) return GV_E_BADARG;
-    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (dtype != GV_F32)
+        return gvlp::view_score_partial(dtype, raw, nb, hw, cr, raw_ld, kernel, bias, num_views, order, r_img,
+                                        (hipStream_t)stream);
     hipLaunchKernelGGL(view_score_partial_f32, dim3(nb), dim3(256), 0, (hipStream_t)stream,
                        (const float*)raw, hw, cr, raw_ld, kernel, bias, num_views, nb / num_views,
                        order, r_img);
@@ -285,7 +288,9 @@ extern "C" int gv_view_pool_fuse_fwd(const void* F, int32_t num_views, int32_t n
         return GV_E_BADARG;
     if (mode != GV_VIEWPOOL_MAX && mode != GV_VIEWPOOL_MEAN) return GV_E_BADARG;
     if (num_views > 64 || num_groups > 64) return GV_E_UNSUPPORTED;
-    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (dtype != GV_F32)
+        return gvlp::view_pool_fuse(dtype, F, num_views, num_shapes, E, view_stride, shape_stride, scheme, num_groups,
+                                    weight, mode, empty_fill, D, S, (hipStream_t)stream);
     const bool vec = (E % 4 == 0) && (view_stride % 4 == 0) && (shape_stride % 4 == 0) &&
                      gv_aligned16(F) && (!D || gv_aligned16(D)) && (!S || gv_aligned16(S));
     const int64_t total = (int64_t)num_shapes * (vec ? E / 4 : E);

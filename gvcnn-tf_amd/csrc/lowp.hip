@@ -1,0 +1,407 @@
+// lowp.hip — the HBM-bound ops of the path on 16-bit storage (GV_BF16 / GV_F16, configs c3-c5):
+// pools, stand-alone scale/shift/ReLU, global average pool, the scorer's GAP.Dense(1) and the fused
+// view pooling + group fusion.  Same algorithms as pool.hip / grouping.hip; a thread owns 8 consecutive
+// channels (one 16-byte load), arithmetic is fp32 and every output is rounded to the storage type
+// exactly once (max pooling is rounding-free).
+#include <math.h>
+
+#include <type_traits>
+
+#include "lowp.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ float up(unsigned short b) { return (float)__builtin_bit_cast(T, b); }
+template <typename T>
+__device__ __forceinline__ unsigned short down(float v) { const T h = (T)v; return __builtin_bit_cast(unsigned short, h); }
+
+template <typename T>
+__device__ __forceinline__ void unpack8(u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = up<T>((unsigned short)(v[j] & 0xffffu));
+        f[2 * j + 1] = up<T>((unsigned short)(v[j] >> 16));
+    }
+}
+template <typename T>
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (unsigned)down<T>(f[2 * j]) | ((unsigned)down<T>(f[2 * j + 1]) << 16);
+    return v;
+}
+
+// load / store VEC (8 or 1) consecutive elements as fp32
+template <typename T, int VEC>
+__device__ __forceinline__ void load_v(const unsigned short* p, float (&f)[8]) {
+    if constexpr (VEC == 8) unpack8<T>(*reinterpret_cast<const u32x4*>(p), f);
+    else f[0] = up<T>(*p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_v(unsigned short* p, const float (&f)[8]) {
+    if constexpr (VEC == 8) *reinterpret_cast<u32x4*>(p) = pack8<T>(f);
+    else *p = down<T>(f[0]);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void pool2d_lp(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                 int nb, int ih, int iw, int c, int x_ld, int kh, int kw,
+                                                 int stride, int pad_t, int pad_l, int oh, int ow, int y_ld,
+                                                 int mode) {
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * oh * ow * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int ox = (int)(pix % ow);
+        const int64_t t = pix / ow;
+        const int oy = (int)(t % oh);
+        const int n = (int)(t / oh);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = mode == GV_POOL_MAX ? -INFINITY : 0.f;
+        int cnt = 0;
+        for (int r = 0; r < kh; ++r) {
+            const int iy = oy * stride + r - pad_t;
+            if ((unsigned)iy >= (unsigned)ih) continue;
+            for (int s = 0; s < kw; ++s) {
+                const int ix = ox * stride + s - pad_l;
+                if ((unsigned)ix >= (unsigned)iw) continue;
+                float v[8];
+                load_v<T, VEC>(x + ((size_t)(n * ih + iy) * iw + ix) * x_ld + g * VEC, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = mode == GV_POOL_MAX ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
+                ++cnt;
+            }
+        }
+        if (mode == GV_POOL_AVG) {
+            const float inv = (float)cnt;             // divisor = number of valid taps (TF SAME semantics)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = acc[e] / inv;
+        }
+        store_v<T, VEC>(y + (size_t)pix * y_ld + g * VEC, acc);
+    }
+}
+
+// 3x3 / stride 1 / SAME average pool: 4 horizontally adjacent outputs of an 8-channel group per thread
+// (shared column sums), see avgpool3x3s1_row4_f32 in pool.hip.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3x3s1_row4_lp(const unsigned short* __restrict__ x,
+                                                            unsigned short* __restrict__ y, int nb, int ih, int iw,
+                                                            int c, int x_ld, int y_ld) {
+    const int cg = c >> 3;
+    const int wg = (iw + 3) >> 2;
+    const int64_t total = (int64_t)nb * ih * wg * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int xg = (int)(t % wg);
+        t /= wg;
+        const int oy = (int)(t % ih);
+        const int n = (int)(t / ih);
+        const int ox0 = xg * 4;
+        float col[6][8];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) col[j][e] = 0.f;
+        int rows = 0;
+#pragma unroll
+        for (int r = -1; r <= 1; ++r) {
+            const int iy = oy + r;
+            if ((unsigned)iy >= (unsigned)ih) continue;
+            ++rows;
+            const unsigned short* rowp = x + ((size_t)(n * ih + iy) * iw) * x_ld + g * 8;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = ox0 - 1 + j;
+                if ((unsigned)ix < (unsigned)iw) {
+                    float v[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(rowp + (size_t)ix * x_ld), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) col[j][e] += v[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = ox0 + j;
+            if (ox >= iw) break;
+            const int cols = 1 + (ox > 0 ? 1 : 0) + (ox + 1 < iw ? 1 : 0);
+            const float inv = (float)(rows * cols);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (col[j][e] + col[j + 1][e] + col[j + 2][e]) / inv;
+            *reinterpret_cast<u32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 8) = pack8<T>(v);
+        }
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void scale_shift_act_lp(const unsigned short* __restrict__ x, int64_t npix, int c,
+                                                          int x_ld, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu,
+                                                          unsigned short* __restrict__ y, int y_ld) {
+    const int cg = c / VEC;
+    const int64_t total = npix * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        float v[8];
+        load_v<T, VEC>(x + (size_t)pix * x_ld + g * VEC, v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[e] = v[e] * scale[g * VEC + e] + shift[g * VEC + e];
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        store_v<T, VEC>(y + (size_t)pix * y_ld + g * VEC, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void global_avg_pool_lp(const unsigned short* __restrict__ x, int nb, int hw, int c,
+                                                          int x_ld, float* __restrict__ y) {
+    const int64_t total = (int64_t)nb * c;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % c);
+    const int b = (int)(idx / c);
+    const unsigned short* p = x + (size_t)b * hw * x_ld + ch;
+    float s = 0.f;
+    for (int i = 0; i < hw; ++i) s += up<T>(p[(size_t)i * x_ld]);
+    y[idx] = s / (float)hw;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// nets/model.py:144-145 on a 16-bit raw map; fixed reduction tree => bitwise reproducible
+template <typename T>
+__global__ __launch_bounds__(256) void view_score_partial_lp(const unsigned short* __restrict__ raw, int hw, int cr,
+                                                             int raw_ld, const float* __restrict__ kernel,
+                                                             const float* __restrict__ bias, int num_views,
+                                                             int num_shapes, int order, float* __restrict__ r_img) {
+    const int b = blockIdx.x;
+    const int v = order == GV_ORDER_SHAPE_MAJOR ? b % num_views : b / num_shapes;
+    const float* kv = kernel + (size_t)v * cr;
+    const unsigned short* xb = raw + (size_t)b * hw * raw_ld;
+    float s = 0.f;
+    if ((cr & 7) == 0 && (raw_ld & 7) == 0 && (((uintptr_t)raw) & 15) == 0) {
+        const int cg = cr >> 3;
+        const int total = hw * cg;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int p = i / cg, g = i - p * cg;
+            float x[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(xb + (size_t)p * raw_ld + 8 * g), x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[e] * kv[8 * g + e];
+        }
+    } else {
+        const int total = hw * cr;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int p = i / cr, c = i - p * cr;
+            s += up<T>(xb[(size_t)p * raw_ld + c]) * kv[c];
+        }
+    }
+    __shared__ float part[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) r_img[b] = (part[0] + part[1] + part[2] + part[3]) / (float)hw + bias[v];
+}
+
+// nets/model.py:44-102 fused, one read of every descriptor element (view_pool_fuse_f32 in grouping.hip)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void view_pool_fuse_lp(const unsigned short* __restrict__ F, int V, int N, int64_t E,
+                                                         int64_t view_stride, int64_t shape_stride,
+                                                         const int* __restrict__ scheme, int G,
+                                                         const float* __restrict__ weight, int mode, float fill,
+                                                         unsigned short* __restrict__ D, unsigned short* __restrict__ S) {
+    __shared__ unsigned long long s_mask[64];
+    __shared__ float s_w[64];
+    __shared__ float s_wsum;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        unsigned long long m = 0;
+        for (int v = 0; v < V; ++v)
+            if (scheme[g * V + v] != 0) m |= 1ull << v;
+        s_mask[g] = m;
+        s_w[g] = weight[g];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ws = 0.f;
+        for (int g = 0; g < G; ++g) ws = __fadd_rn(ws, s_w[g]);
+        s_wsum = ws;
+    }
+    __syncthreads();
+    const float wsum = s_wsum;
+    const int64_t eg = E / VEC;
+    const int64_t total = (int64_t)N * eg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / eg);
+        const int64_t e = (idx - (int64_t)n * eg) * VEC;
+        const unsigned short* base = F + (size_t)n * shape_stride + e;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int g = 0; g < G; ++g) {
+            unsigned long long m = s_mask[g];
+            float d[8];
+            if (m == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = fill;
+            } else {
+                const int cnt = __popcll(m);
+                int v = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                load_v<T, VEC>(base + (size_t)v * view_stride, d);
+                while (m) {
+                    v = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    float x[8];
+                    load_v<T, VEC>(base + (size_t)v * view_stride, x);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) d[k] = mode == GV_VIEWPOOL_MAX ? fmaxf(d[k], x[k]) : d[k] + x[k];
+                }
+                if (mode == GV_VIEWPOOL_MEAN) {
+                    const float c = (float)cnt;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) d[k] = d[k] / c;
+                }
+            }
+            if (D) store_v<T, VEC>(D + ((size_t)g * N + n) * E + e, d);
+            const float w = s_w[g];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = __fadd_rn(acc[k], __fmul_rn(w, d[k]));
+        }
+        if (S) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = __fdiv_rn(acc[k], wsum);
+            store_v<T, VEC>(S + (size_t)n * E + e, acc);
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = 256 * 16;
+    return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+template <typename T>
+int pool2d_t(const gv_pool_desc* d, const unsigned short* x, unsigned short* y, hipStream_t st) {
+    const bool vec = (d->c % 8 == 0) && (d->x_ld % 8 == 0) && (d->y_ld % 8 == 0) && gv_aligned16(x) && gv_aligned16(y);
+    if (vec && d->mode == GV_POOL_AVG && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
+        d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
+        const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
+        hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
+                           d->iw, d->c, d->x_ld, d->y_ld);
+    } else if (vec) {
+        const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 8);
+        hipLaunchKernelGGL((pool2d_lp<T, 8>), dim3(grid_for(total)), dim3(256), 0, st, x, y, d->nb, d->ih, d->iw,
+                           d->c, d->x_ld, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->y_ld, d->mode);
+    } else {
+        const int64_t total = (int64_t)d->nb * d->oh * d->ow * d->c;
+        hipLaunchKernelGGL((pool2d_lp<T, 1>), dim3(grid_for(total)), dim3(256), 0, st, x, y, d->nb, d->ih, d->iw,
+                           d->c, d->x_ld, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->y_ld, d->mode);
+    }
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
+int ssa_t(const unsigned short* x, int64_t npix, int c, int x_ld, const float* scale, const float* shift, int relu,
+          unsigned short* y, int y_ld, hipStream_t st) {
+    const bool vec = (c % 8 == 0) && (x_ld % 8 == 0) && (y_ld % 8 == 0) && gv_aligned16(x) && gv_aligned16(y);
+    if (vec)
+        hipLaunchKernelGGL((scale_shift_act_lp<T, 8>), dim3(grid_for(npix * (c / 8))), dim3(256), 0, st, x, npix, c,
+                           x_ld, scale, shift, relu, y, y_ld);
+    else
+        hipLaunchKernelGGL((scale_shift_act_lp<T, 1>), dim3(grid_for(npix * c)), dim3(256), 0, st, x, npix, c, x_ld,
+                           scale, shift, relu, y, y_ld);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
+int fuse_t(const unsigned short* F, int V, int N, int64_t E, int64_t vs, int64_t ss, const int* scheme, int G,
+           const float* weight, int mode, float fill, unsigned short* D, unsigned short* S, hipStream_t st) {
+    const bool vec = (E % 8 == 0) && (vs % 8 == 0) && (ss % 8 == 0) && gv_aligned16(F) && (!D || gv_aligned16(D)) &&
+                     (!S || gv_aligned16(S));
+    const int64_t total = (int64_t)N * (vec ? E / 8 : E);
+    if (vec)
+        hipLaunchKernelGGL((view_pool_fuse_lp<T, 8>), dim3(grid_for(total)), dim3(256), 0, st, F, V, N, E, vs, ss,
+                           scheme, G, weight, mode, fill, D, S);
+    else
+        hipLaunchKernelGGL((view_pool_fuse_lp<T, 1>), dim3(grid_for(total)), dim3(256), 0, st, F, V, N, E, vs, ss,
+                           scheme, G, weight, mode, fill, D, S);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+}  // namespace
+
+namespace gvlp {
+
+int pool2d(const gv_pool_desc* d, const void* x, void* y, hipStream_t st) {
+    if (d->dtype == GV_BF16) return pool2d_t<__bf16>(d, (const unsigned short*)x, (unsigned short*)y, st);
+    if (d->dtype == GV_F16) return pool2d_t<_Float16>(d, (const unsigned short*)x, (unsigned short*)y, st);
+    return GV_E_UNSUPPORTED;
+}
+
+int scale_shift_act(int dtype, const void* x, int64_t npix, int c, int x_ld, const float* scale, const float* shift,
+                    int relu, void* y, int y_ld, hipStream_t st) {
+    if (dtype == GV_BF16) return ssa_t<__bf16>((const unsigned short*)x, npix, c, x_ld, scale, shift, relu, (unsigned short*)y, y_ld, st);
+    if (dtype == GV_F16) return ssa_t<_Float16>((const unsigned short*)x, npix, c, x_ld, scale, shift, relu, (unsigned short*)y, y_ld, st);
+    return GV_E_UNSUPPORTED;
+}
+
+int global_avg_pool(int dtype, const void* x, int nb, int hw, int c, int x_ld, float* y, hipStream_t st) {
+    const int64_t total = (int64_t)nb * c;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == GV_BF16)
+        hipLaunchKernelGGL(global_avg_pool_lp<__bf16>, grid, dim3(256), 0, st, (const unsigned short*)x, nb, hw, c, x_ld, y);
+    else if (dtype == GV_F16)
+        hipLaunchKernelGGL(global_avg_pool_lp<_Float16>, grid, dim3(256), 0, st, (const unsigned short*)x, nb, hw, c, x_ld, y);
+    else
+        return GV_E_UNSUPPORTED;
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+int view_score_partial(int dtype, const void* raw, int nb, int hw, int cr, int raw_ld, const float* kernel,
+                       const float* bias, int num_views, int order, float* r_img, hipStream_t st) {
+    if (dtype == GV_BF16)
+        hipLaunchKernelGGL(view_score_partial_lp<__bf16>, dim3(nb), dim3(256), 0, st, (const unsigned short*)raw, hw, cr,
+                           raw_ld, kernel, bias, num_views, nb / num_views, order, r_img);
+    else if (dtype == GV_F16)
+        hipLaunchKernelGGL(view_score_partial_lp<_Float16>, dim3(nb), dim3(256), 0, st, (const unsigned short*)raw, hw,
+                           cr, raw_ld, kernel, bias, num_views, nb / num_views, order, r_img);
+    else
+        return GV_E_UNSUPPORTED;
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+int view_pool_fuse(int dtype, const void* F, int V, int N, int64_t E, int64_t vs, int64_t ss, const int* scheme,
+                   int G, const float* weight, int mode, float fill, void* D, void* S, hipStream_t st) {
+    if (dtype == GV_BF16)
+        return fuse_t<__bf16>((const unsigned short*)F, V, N, E, vs, ss, scheme, G, weight, mode, fill,
+                              (unsigned short*)D, (unsigned short*)S, st);
+    if (dtype == GV_F16)
+        return fuse_t<_Float16>((const unsigned short*)F, V, N, E, vs, ss, scheme, G, weight, mode, fill,
+                                (unsigned short*)D, (unsigned short*)S, st);
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace gvlp

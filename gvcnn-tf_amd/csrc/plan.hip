@@ -35,7 +35,7 @@ struct Op {
     bool signal = false;        // some later op on another lane waits for this one
 };
 
-inline size_t elem_size(int dtype) { return dtype == GV_BF16 ? 2 : 4; }
+inline size_t elem_size(int dtype) { return dtype == GV_F32 ? 4 : 2; }
 
 }  // namespace
 
@@ -71,7 +71,8 @@ int run_op(const Op& o, void* const* bufs, void* stream) {
     switch (o.kind) {
         case OP_CONV: {
             const size_t es = elem_size(o.conv.dtype);
-            return gv_conv2d_fwd(&o.conv, at(bufs, o.x, es), at(bufs, o.w, es),
+            const size_t xes = (o.conv.flags & GV_CONV_X_F32) ? 4 : es;      // fp32 network input
+            return gv_conv2d_fwd(&o.conv, at(bufs, o.x, xes), at(bufs, o.w, es),
                                  (const float*)at(bufs, o.scale, 4), (const float*)at(bufs, o.shift, 4),
                                  at(bufs, o.res, es), at(bufs, o.y, es), at(bufs, o.y2, es),
                                  (const float*)at(bufs, o.scale2, 4),

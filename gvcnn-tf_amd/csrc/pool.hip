@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include "gv_common.h"
+#include "lowp.h"
 
 namespace {
 
@@ -183,7 +184,7 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
     if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
         return GV_E_BADARG;                   // an output whose window holds no valid tap
     if (d->pad_t >= d->kh || d->pad_l >= d->kw) return GV_E_BADARG;
-    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (d->dtype != GV_F32) return gvlp::pool2d(d, x, y, (hipStream_t)stream);
     const bool vec = (d->c % 4 == 0) && (d->x_ld % 4 == 0) && (d->y_ld % 4 == 0) && gv_aligned16(x) &&
                      gv_aligned16(y);
     const int64_t total = (int64_t)d->nb * d->oh * d->ow * (vec ? d->c / 4 : d->c);
@@ -212,7 +213,8 @@ extern "C" int gv_scale_shift_act(const void* x, int64_t npix, int32_t c, int32_
                                   const float* scale, const float* shift, int32_t relu, void* y,
                                   int32_t y_ld, int32_t dtype, void* stream) {
     if (!x || !y || !scale || !shift || npix <= 0 || c <= 0 || x_ld < c || y_ld < c) return GV_E_BADARG;
-    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (dtype != GV_F32)
+        return gvlp::scale_shift_act(dtype, x, npix, c, x_ld, scale, shift, relu, y, y_ld, (hipStream_t)stream);
     const bool vec = (c % 4 == 0) && (x_ld % 4 == 0) && (y_ld % 4 == 0) && gv_aligned16(x) &&
                      gv_aligned16(y) && gv_aligned16(scale) && gv_aligned16(shift);
     const int64_t total = npix * (vec ? c / 4 : c);
@@ -230,7 +232,7 @@ extern "C" int gv_scale_shift_act(const void* x, int64_t npix, int32_t c, int32_
 extern "C" int gv_global_avg_pool(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
                                   float* y, int32_t dtype, void* stream) {
     if (!x || !y || nb <= 0 || hw <= 0 || c <= 0 || x_ld < c) return GV_E_BADARG;
-    if (dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (dtype != GV_F32) return gvlp::global_avg_pool(dtype, x, nb, hw, c, x_ld, y, (hipStream_t)stream);
     const int64_t total = (int64_t)nb * c;
     hipLaunchKernelGGL(global_avg_pool_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)x, nb, hw, c, x_ld, y);

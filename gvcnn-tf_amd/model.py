@@ -180,8 +180,12 @@ class GVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=1, num_views=12, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, seed=2,
-                 math="f32", lanes=True):
+                 math="f32", lanes=True, storage="f32"):
+        """storage: 'f32' (configs c1/c2), 'bf16' (c3/c4) or 'f16' (c5): the type activations, filters and
+        descriptors are kept in; accumulation and every epilogue are fp32 (`math` applies to 'f32' only)."""
         self.lib = _lib.load()
+        self.dtype = backbones.DTYPES[storage]
+        self.tdtype = backbones.TORCH_DTYPES[self.dtype]
         self.device = _dev(device)
         self.backbone = backbone
         self.N, self.V, self.H, self.W = num_shapes, num_views, height, width
@@ -191,7 +195,8 @@ class GVCNN:
             raise ValueError("num_views and num_group are limited to 64")
         with torch.cuda.device(self.device):
             self.plan = backbones.make_plan(backbone, num_shapes * num_views, height, width,
-                                            self.device, raw_tap, final_tap, math=math, lanes=lanes)
+                                            self.device, raw_tap, final_tap, dtype=self.dtype, math=math,
+                                            lanes=lanes)
             self.raw = self.plan.end_points[self.plan.raw_tap]
             self.final = self.plan.end_points[self.plan.final_tap]
             if backbone_params is None:
@@ -210,7 +215,7 @@ class GVCNN:
             self.weight = torch.empty(num_group, dtype=f32, device=dev)
             self.status = torch.zeros(1, dtype=i32, device=dev)
             f = self.final
-            self.shape_descriptor = torch.empty((num_shapes, f.h, f.w, f.c), dtype=f32, device=dev)
+            self.shape_descriptor = torch.empty((num_shapes, f.h, f.w, f.c), dtype=self.tdtype, device=dev)
             self.gap = torch.empty((num_shapes, f.c), dtype=f32, device=dev)
             self.logits = torch.empty((num_shapes, num_classes), dtype=f32, device=dev)
             self._all_ones_scheme = torch.ones((1, num_views), dtype=i32, device=dev)
@@ -253,7 +258,7 @@ class GVCNN:
         _lib.check(lib.gv_view_score_partial(raw_ptr, r.nb, r.h * r.w, r.c, r.ld,
                                              self.score_kernel.data_ptr(), self.score_bias.data_ptr(),
                                              self.V, _lib.GV_ORDER_SHAPE_MAJOR, self.r_img.data_ptr(),
-                                             _lib.GV_F32, _st()), "gv_view_score_partial")
+                                             self.dtype, _st()), "gv_view_score_partial")
         self.finalize_scores(self.r_img, self.N)
         return self.scores
 
@@ -300,19 +305,19 @@ class GVCNN:
             F_ptr, N = self.plan.view(f).data_ptr(), self.N
             S, gap, logits = self.shape_descriptor, self.gap, self.logits
         else:
-            F = F.contiguous()
+            F = F.to(self.tdtype).contiguous()
             N = F.shape[0]
             F_ptr = F.data_ptr()
-            S = torch.empty((N, f.h, f.w, f.c), dtype=torch.float32, device=self.device)
+            S = torch.empty((N, f.h, f.w, f.c), dtype=self.tdtype, device=self.device)
             gap = torch.empty((N, f.c), dtype=torch.float32, device=self.device)
             logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=self.device)
         G = scheme.shape[0]
         _lib.check(lib.gv_view_pool_fuse_fwd(F_ptr, self.V, N, E, E, self.V * E, scheme.data_ptr(), G,
                                              weight.data_ptr(), _POOL_MODES[self.pool], self.empty_fill,
-                                             None, S.data_ptr(), _lib.GV_F32, _st()),
+                                             None, S.data_ptr(), self.dtype, _st()),
                    "gv_view_pool_fuse_fwd")
         _lib.check(lib.gv_global_avg_pool(S.data_ptr(), N, f.h * f.w, f.c, f.c, gap.data_ptr(),
-                                          _lib.GV_F32, _st()), "gv_global_avg_pool")
+                                          self.dtype, _st()), "gv_global_avg_pool")
         _lib.check(lib.gv_dense_fwd(gap.data_ptr(), N, f.c, self.cls_kernel.data_ptr(),
                                     self.cls_bias.data_ptr(), self.num_classes, logits.data_ptr(),
                                     _st()), "gv_dense_fwd")
@@ -347,9 +352,9 @@ class GVCNN:
         _lib.check(lib.gv_view_pool_fuse_fwd(self.plan.view(f).data_ptr(), self.V, self.N, E, E,
                                              self.V * E, self._all_ones_scheme.data_ptr(), 1,
                                              self._one.data_ptr(), _lib.GV_VIEWPOOL_MAX, 1.0, None,
-                                             S.data_ptr(), _lib.GV_F32, _st()), "gv_view_pool_fuse_fwd")
+                                             S.data_ptr(), self.dtype, _st()), "gv_view_pool_fuse_fwd")
         _lib.check(lib.gv_global_avg_pool(S.data_ptr(), self.N, f.h * f.w, f.c, f.c,
-                                          self.gap.data_ptr(), _lib.GV_F32, _st()), "gv_global_avg_pool")
+                                          self.gap.data_ptr(), self.dtype, _st()), "gv_global_avg_pool")
         _lib.check(lib.gv_dense_fwd(self.gap.data_ptr(), self.N, f.c, self.cls_kernel.data_ptr(),
                                     self.cls_bias.data_ptr(), self.num_classes,
                                     self.logits.data_ptr(), _st()), "gv_dense_fwd")

@@ -39,12 +39,15 @@ extern "C" {
 /* element types (arithmetic type of the path; accumulation is always fp32) */
 #define GV_F32 0
 #define GV_BF16 1
+#define GV_F16 2
 
 /* gv_conv_desc.flags */
 #define GV_CONV_RELU 1        /* ReLU after scale/shift(/residual)   */
 #define GV_CONV_RELU2 2       /* ReLU on the second output           */
 #define GV_CONV_SPLIT 4       /* y2 is not a second activation but the destination of output
                                  columns >= split_col (sibling convs fused into one GEMM) */
+#define GV_CONV_X_F32 8       /* 16-bit dtype only: x is fp32 (the network input, nets/model.py:121) and is
+                                 rounded to `dtype` by the loader — no separate cast pass over the images */
 
 /* gv_conv_desc.math_mode: how an fp32 convolution is evaluated on the matrix cores */
 #define GV_MATH_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                         */
@@ -79,7 +82,8 @@ typedef struct gv_conv_desc {
     int32_t res_ld;            /* pixel stride of the residual input (ignored when residual == NULL) */
     int32_t y2_ld;             /* pixel stride of the optional second output */
     int32_t flags;             /* GV_CONV_* */
-    int32_t dtype;             /* GV_F32 | GV_BF16: type of x, w_packed, residual, y, y2 */
+    int32_t dtype;             /* GV_F32 | GV_BF16 | GV_F16: type of x, w_packed, residual, y, y2 (16-bit types:
+                                  fp32 accumulation and epilogue, one rounding on store; math_mode ignored) */
     int32_t split_col;         /* GV_CONV_SPLIT: columns [0,split_col) -> y, [split_col,cout) -> y2 at
                                   column (c - split_col), pixel stride y2_ld; same scale/shift/act */
     int32_t tile_cfg;          /* 0 = library heuristic; k >= 1 = tile configuration k-1 (a speed choice
@@ -108,7 +112,7 @@ const char* gv_error_string(int code);
 /* ---- filters ------------------------------------------------------------
  * Packed filter layout consumed by gv_conv2d_fwd, GV_MATH_F32: [cout][Kpad], k = (r*kw+s)*cin + c,
  * Kpad = K rounded up to 32, zero filled; GV_MATH_BF16X*: [cout][K/16][plane][16 bf16] (the filter is
- * split into its bf16 planes once, here).  Source is TensorFlow's HWIO
+ * split into its bf16 planes once, here); dtype GV_BF16 / GV_F16: [cout][Kpad] 16-bit.  Source is TensorFlow's HWIO
  * [kh,kw,cin,cout] fp32 variable (slim `.../weights`). */
 int64_t gv_packed_filter_bytes(int32_t kh, int32_t kw, int32_t cin, int32_t cout, int32_t dtype,
                                int32_t math_mode);

@@ -1,0 +1,335 @@
+"""Parity of the 16-bit storage path (GV_BF16 / GV_F16: configs c3-c5) against the CPU oracle, through the
+C ABI.  Inputs and filters are rounded to the storage type FIRST, so the oracle (fp32 arithmetic on those
+rounded values) and the kernel (exact 16-bit products, fp32 accumulate) differ only by fp32 summation
+order and by the one rounding of each output to the storage type:
+
+    tolerance = 1 ulp of the storage type (2^-8 relative for bf16, 2^-11 for fp16) of the value,
+                + 1e-4 of the tensor's scale for the summation order (north_star's fp32 1e-3 cannot apply
+                to values that are themselves stored with 8 or 11 significant bits).
+
+Max pooling and view max-pooling are rounding-free: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvcnn_tf_amd as gv                      # noqa: E402
+from gvcnn_tf_amd import _lib                   # noqa: E402
+from oracle import backbone as OB               # noqa: E402
+from oracle import grouping as OG               # noqa: E402
+from oracle import model as OM                  # noqa: E402
+
+DEV = "cuda:0"
+TYPES = {"bf16": (_lib.GV_BF16, torch.bfloat16, 2.0 ** -8), "f16": (_lib.GV_F16, torch.float16, 2.0 ** -11)}
+
+
+def lib():
+    return _lib.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rnd(t, td):
+    return t.to(td).to(torch.float32)
+
+
+def close(actual, desired, ulp, extra=1e-4):
+    actual, desired = np.asarray(actual, np.float32), np.asarray(desired, np.float32)
+    scale = max(float(np.abs(desired).max()), 1e-30)
+    np.testing.assert_allclose(actual, desired, rtol=1.01 * ulp, atol=extra * scale)
+
+
+def pack(w, code):
+    kh, kw, cin, cout = w.shape
+    n = lib().gv_packed_filter_bytes(kh, kw, cin, cout, code, 0)
+    assert n > 0 and n % 64 == 0 or n > 0
+    out = torch.empty((n + 3) // 4, dtype=torch.int32, device=DEV)
+    wd = w.to(DEV).contiguous()
+    _lib.check(lib().gv_pack_filter_hwio(wd.data_ptr(), kh, kw, cin, cout, out.data_ptr(), code, 0, st()), "pack")
+    torch.cuda.synchronize()
+    return out
+
+
+def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, second=None, split=0,
+             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0):
+    code, td, _ = TYPES[ty]
+    nb, ih, iw, cin = x.shape
+    kh, kw, _, cout = w.shape
+    oh, ow = out_hw
+    x_ld = x_ld or cin
+    n1 = split if split else cout
+    y_ld = y_ld or n1
+    xb = torch.full((nb, ih, iw, x_ld), 7.0)
+    xb[..., x_off:x_off + cin] = x
+    xd = xb.to(DEV) if x_f32 else xb.to(td).to(DEV)
+    xes = 4 if x_f32 else 2
+    yd = torch.full((nb, oh, ow, y_ld), -77.0, dtype=td, device=DEV)
+    n2 = cout - split if split else cout
+    y2d = torch.full((nb, oh, ow, n2), -55.0, dtype=td, device=DEV) if (second or split) else None
+    wp = pack(w, code)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    sc2 = second[0].to(DEV) if second else None
+    sh2 = second[1].to(DEV) if second else None
+    rd = residual.to(td).to(DEV).contiguous() if residual is not None else None
+    flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0) | \
+            (_lib.GV_CONV_SPLIT if split else 0) | (_lib.GV_CONV_X_F32 if x_f32 else 0)
+    d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
+                      cout if residual is not None else 0, n2 if y2d is not None else 0, flags, code, split, 0, 0, 0)
+    if tile is not None:
+        lib().gv_conv2d_set_tile_override(tile)
+    try:
+        rc = lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr() + xes * x_off, wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                 rd.data_ptr() if rd is not None else None, yd.data_ptr() + 2 * y_off,
+                                 y2d.data_ptr() if y2d is not None else None,
+                                 sc2.data_ptr() if second else None, sh2.data_ptr() if second else None, st())
+    finally:
+        lib().gv_conv2d_set_tile_override(-1)
+    _lib.check(rc, "gv_conv2d_fwd")
+    torch.cuda.synchronize()
+    y = yd.float().cpu().numpy()
+    if y_ld != n1:
+        mask = np.ones(y_ld, bool)
+        mask[y_off:y_off + n1] = False
+        assert (y[..., mask] == -77.0).all()
+    y = y[..., y_off:y_off + n1]
+    return (y, y2d.float().cpu().numpy()) if y2d is not None else y
+
+
+def oracle_conv(x, w, stride, padding, scale, shift, relu, residual=None):
+    y = OB.conv2d(x, w, stride, padding) * scale + shift
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
+
+
+def tf_pads(size, k, stride, padding):
+    return OB.same_pads(size, k, stride)[0] if padding == "SAME" else 0
+
+
+COMBOS = [
+    ((3, 3), 2, "VALID", 3, 32), ((3, 3), 1, "VALID", 32, 32), ((3, 3), 1, "SAME", 32, 64),
+    ((1, 1), 1, "SAME", 64, 80), ((3, 3), 1, "VALID", 80, 192), ((1, 1), 1, "SAME", 192, 48),
+    ((5, 5), 1, "SAME", 48, 64), ((3, 3), 2, "VALID", 96, 96), ((1, 7), 1, "SAME", 128, 128),
+    ((7, 1), 1, "SAME", 160, 192), ((1, 3), 1, "SAME", 384, 384), ((3, 1), 1, "SAME", 448, 384),
+    ((1, 1), 2, "VALID", 256, 512), ((7, 7), 2, (3, 3, 3, 3), 3, 64), ((3, 3), 2, (1, 1, 1, 1), 64, 64),
+    ((1, 1), 1, "SAME", 2048, 320), ((1, 1), 1, "SAME", 8, 24), ((3, 3), 1, "SAME", 40, 16),
+]
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("k,stride,padding,cin,cout", COMBOS)
+def test_lp_conv_combos_vs_oracle(k, stride, padding, cin, cout, ty):
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(hash((k, stride, cin, cout)) % 1000)
+    ih, iw = (23, 20) if cin <= 64 else (9, 10)
+    x = rnd(torch.randn(3, ih, iw, cin, generator=g), td)
+    w = rnd(torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5), td)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = oracle_conv(x, w, stride, padding, scale, shift, True)
+    if isinstance(padding, str):
+        pads = (tf_pads(ih, k[0], stride, padding), tf_pads(iw, k[1], stride, padding))
+    else:
+        pads = (padding[0], padding[2])
+    y = run_conv(x, w, stride, pads, ref.shape[1:3], scale, shift, True, ty)
+    close(y, ref.numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("tile", list(range(9)))
+@pytest.mark.parametrize("cout", [32, 48, 200])
+def test_lp_conv_every_tile_config(tile, cout, ty):
+    """All tile shapes, ragged M (286) and N not a multiple of 32; K = 360 is not a multiple of the k-tile."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(tile * 100 + cout)
+    x = rnd(torch.randn(2, 13, 11, 40, generator=g), td)
+    w = rnd(torch.randn(3, 3, 40, cout, generator=g) * 0.06, td)
+    scale, shift = torch.ones(cout), torch.zeros(cout)
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, False)
+    y = run_conv(x, w, 1, (1, 1), (13, 11), scale, shift, False, ty, tile=tile)
+    close(y, ref.numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_lp_conv_fp32_network_input(ty):
+    """GV_CONV_X_F32: the stem reads the fp32 images and rounds them in its loader (== casting first)."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 31, 29, 3, generator=g) - 0.5
+    w = rnd(torch.randn(3, 3, 3, 32, generator=g) * 0.2, td)
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    y = run_conv(x, w, 2, (0, 0), (15, 14), scale, shift, True, ty, x_f32=True)
+    y_cast = run_conv(rnd(x, td), w, 2, (0, 0), (15, 14), scale, shift, True, ty)
+    assert np.array_equal(y, y_cast)
+    close(y, oracle_conv(rnd(x, td), w, 2, "VALID", scale, shift, True).numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_lp_conv_residual_dual_and_slices(ty):
+    """ResNet unit tail (resnet_v2.py:87-91 + next preact :75) and concat-slice input/output."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(9)
+    x = rnd(torch.randn(2, 7, 9, 64, generator=g), td)
+    w = rnd(torch.randn(1, 1, 64, 256, generator=g) * 0.12, td)
+    res = rnd(torch.randn(2, 7, 9, 256, generator=g), td)
+    bias = torch.randn(256, generator=g) * 0.1
+    sc2, sh2 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    y, y2 = run_conv(x, w, 1, (0, 0), (7, 9), torch.ones(256), bias, False, ty, residual=res, second=(sc2, sh2))
+    ref = oracle_conv(x, w, 1, "SAME", torch.ones(256), bias, False, residual=res)
+    close(y, ref.numpy(), ulp)
+    close(y2, torch.relu(ref * sc2 + sh2).numpy(), ulp, extra=3e-3)    # y2 is computed from the unrounded y
+    # channel-slice in and out (16-byte aligned slice offsets)
+    y = run_conv(x, w[:, :, :, :96], 1, (0, 0), (7, 9), torch.ones(96), bias[:96], True, ty, x_ld=80, x_off=8,
+                 y_ld=128, y_off=24)
+    close(y, oracle_conv(x, w[:, :, :, :96], 1, "SAME", torch.ones(96), bias[:96], True).numpy(), ulp)
+    # misaligned slice: the gather path
+    y = run_conv(x, w[:, :, :, :96], 1, (0, 0), (7, 9), torch.ones(96), bias[:96], True, ty, x_ld=70, x_off=3,
+                 y_ld=101, y_off=5)
+    close(y, oracle_conv(x, w[:, :, :, :96], 1, "SAME", torch.ones(96), bias[:96], True).numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_lp_conv_split_output(ty):
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(11)
+    x = rnd(torch.randn(2, 12, 12, 192, generator=g), td)
+    w = rnd(torch.randn(1, 1, 192, 64 + 48 + 64, generator=g) * 0.07, td)
+    scale, shift = torch.rand(176, generator=g) + 0.5, torch.randn(176, generator=g) * 0.1
+    y, y2 = run_conv(x, w, 1, (0, 0), (12, 12), scale, shift, True, ty, split=64, y_ld=256, y_off=0)
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, True).numpy()
+    close(y, ref[..., :64], ulp)
+    close(y2, ref[..., 64:], ulp)
+
+
+def run_pool(x, k, stride, pads, out_hw, mode, ty, x_ld=None, y_ld=None, y_off=0):
+    code, td, _ = TYPES[ty]
+    nb, ih, iw, c = x.shape
+    x_ld = x_ld or c
+    y_ld = y_ld or c
+    xb = torch.full((nb, ih, iw, x_ld), 7.0)
+    xb[..., :c] = x
+    xd = xb.to(td).to(DEV)
+    yd = torch.full((nb, out_hw[0], out_hw[1], y_ld), -77.0, dtype=td, device=DEV)
+    d = _lib.PoolDesc(nb, ih, iw, c, x_ld, k, k, stride, pads[0], pads[1], out_hw[0], out_hw[1], y_ld, mode, code)
+    _lib.check(lib().gv_pool2d_fwd(C.byref(d), xd.data_ptr(), yd.data_ptr() + 2 * y_off, st()), "pool")
+    torch.cuda.synchronize()
+    return yd.float().cpu().numpy()[..., y_off:y_off + c]
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("c", [64, 20])
+def test_lp_pools(ty, c):
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(c)
+    x = rnd(torch.randn(2, 15, 14, c, generator=g), td)
+    # max 3x3/2 VALID (inception_v3.py:112) and SAME with TF's (0,1) pad (resnet_v2.py:181): exact
+    y = run_pool(x, 3, 2, (0, 0), (7, 6), _lib.GV_POOL_MAX, ty, y_ld=c + 16, y_off=8)
+    assert np.array_equal(y, OB.max_pool2d(x, 3, 2, "VALID").numpy())
+    ref = OB.max_pool2d(x, 3, 2, "SAME")
+    pt, pl = OB.same_pads(15, 3, 2)[0], OB.same_pads(14, 3, 2)[0]
+    y = run_pool(x, 3, 2, (pt, pl), ref.shape[1:3], _lib.GV_POOL_MAX, ty)
+    assert np.array_equal(y, ref.numpy())
+    # subsample (resnet_utils.py:64-67)
+    y = run_pool(x, 1, 2, (0, 0), (8, 7), _lib.GV_POOL_MAX, ty)
+    assert np.array_equal(y, x[:, ::2, ::2].numpy())
+    # avg 3x3/1 SAME, valid-tap divisor (inception_v3.py:152)
+    y = run_pool(x, 3, 1, (1, 1), (15, 14), _lib.GV_POOL_AVG, ty)
+    close(y, OB.avg_pool2d_same3(x).numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_lp_scale_shift_gap_and_scorer(ty):
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(3)
+    N, V, h, w, c = 2, 3, 4, 5, 72
+    x = rnd(torch.randn(N * V, h, w, c, generator=g), td)
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    xd = x.to(td).to(DEV)
+    yd = torch.empty_like(xd)
+    scd, shd = scale.to(DEV), shift.to(DEV)
+    _lib.check(lib().gv_scale_shift_act(xd.data_ptr(), N * V * h * w, c, c, scd.data_ptr(), shd.data_ptr(), 1,
+                                        yd.data_ptr(), c, code, st()), "ssa")
+    close(yd.float().cpu().numpy(), torch.relu(x * scale + shift).numpy(), ulp)
+    gap = torch.empty(N * V, c, device=DEV)
+    _lib.check(lib().gv_global_avg_pool(xd.data_ptr(), N * V, h * w, c, c, gap.data_ptr(), code, st()), "gap")
+    np.testing.assert_allclose(gap.cpu().numpy(), x.mean(dim=(1, 2)).numpy(), rtol=1e-5, atol=1e-6)
+    k = torch.randn(V, c, generator=g) * 0.3
+    b = torch.randn(V, generator=g)
+    kd, bd = k.to(DEV), b.to(DEV)
+    r = torch.empty(N * V, device=DEV)
+    _lib.check(lib().gv_view_score_partial(xd.data_ptr(), N * V, h * w, c, c, kd.data_ptr(), bd.data_ptr(), V,
+                                           _lib.GV_ORDER_SHAPE_MAJOR, r.data_ptr(), code, st()), "score")
+    want = [float(x[i].mean(dim=(0, 1)) @ k[i % V] + b[i % V]) for i in range(N * V)]
+    np.testing.assert_allclose(r.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [2 * 2 * 64, 3 * 5 * 7])
+def test_lp_view_pool_fuse(ty, E):
+    """model.py:44-102 on 16-bit descriptors: D (max) is exact, S within one rounding."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(E)
+    V, N, G = 6, 3, 5
+    F = rnd(torch.randn(N, V, E, generator=g), td)
+    scheme = OG.group_scheme([[0.05, 0.31, 0.32, 0.47, 0.07, 0.39]], G, V)
+    weight = OG.group_weight(scheme)
+    Fd = F.to(td).to(DEV)
+    D = torch.empty(G, N, E, dtype=td, device=DEV)
+    S = torch.empty(N, E, dtype=td, device=DEV)
+    sd = torch.from_numpy(scheme.astype(np.int32)).to(DEV)
+    wd = torch.from_numpy(weight).to(DEV)
+    _lib.check(lib().gv_view_pool_fuse_fwd(Fd.data_ptr(), V, N, E, E, V * E, sd.data_ptr(), G, wd.data_ptr(),
+                                           _lib.GV_VIEWPOOL_MAX, 1.0, D.data_ptr(), S.data_ptr(), code, st()), "fuse")
+    descs = [F[:, v].reshape(N, 1, 1, E).numpy() for v in range(V)]
+    oD = OG.view_pooling(descs, scheme)
+    oS = OG.group_fusion(oD, weight)
+    for gi in range(G):
+        assert np.array_equal(D[gi].float().cpu().numpy(), oD[gi].reshape(N, E))
+    close(S.float().cpu().numpy(), oS.reshape(N, E), ulp)
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end: the whole path on 16-bit storage against the fp32 oracle
+# ------------------------------------------------------------------------------------------------
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("backbone,size,ty", [("inception_v3", 75, "bf16"), ("resnet_v2_50", 64, "bf16"),
+                                              ("inception_v3", 75, "f16"), ("resnet_v2_50", 64, "f16")])
+def test_lp_gvcnn_vs_fp32_oracle(backbone, size, ty):
+    """Config c3/c4/c5 dtype path.  Against the fp32 oracle the descriptors carry the storage rounding of
+    every layer (~depth^0.5 * 2^-9 for bf16): bound = 3e-2 (bf16) / 4e-3 (fp16) in relative L2 and
+    8x that per element relative to the tensor's scale; the integer group assignment must be identical
+    (the synthetic scorer keeps scores away from bin edges)."""
+    code, td, ulp = TYPES[ty]
+    N, V, C_, G = 2, 6, 10, 10
+    eng = gv.GVCNN(backbone, N, V, size, size, C_, G, device=DEV, storage=ty)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    eng.plan.bind(P)
+    eng.set_head(Hd)
+    x = torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(1)) - 0.5
+    scores, S, logits = eng.forward(x.to(DEV))
+    o_scores, o_S, o_logits, o_scheme, o_weight = OM.gvcnn(x, C_, P, Hd, G, backbone)
+    bound = 3e-2 if ty == "bf16" else 4e-3
+    fin = eng.final_view_descriptors().float().cpu().numpy()
+    assert np.isfinite(fin).all()
+    assert S.dtype == td
+    np.testing.assert_allclose(scores.cpu().numpy(), np.array(o_scores), rtol=bound, atol=bound * 0.1)
+    assert eng.scheme.cpu().numpy().tolist() == o_scheme.tolist()
+    assert eng.weight.cpu().numpy().tolist() == o_weight.tolist()
+    Sn = S.float().cpu().numpy()
+    assert rel_l2(Sn, o_S) < bound, rel_l2(Sn, o_S)
+    assert np.abs(Sn - o_S).max() < 8 * bound * np.abs(o_S).max()
+    assert rel_l2(logits.cpu().numpy(), o_logits) < bound, rel_l2(logits.cpu().numpy(), o_logits)
+    # MVCNN baseline (model.py:169-206)
+    Sb, lb = eng.forward_basic(x.to(DEV))
+    _, ob_logits = OM.basic(x, C_, P, Hd, backbone)
+    assert rel_l2(lb.cpu().numpy(), ob_logits) < bound
