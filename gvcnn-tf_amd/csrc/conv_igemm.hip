@@ -469,6 +469,8 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         const bool xf32 = (d->flags & GV_CONV_X_F32) != 0;
         const bool generic = xf32 || (d->cin % 8 != 0) || (d->x_ld % 8 != 0) || !gv_aligned16(x);
         if (a.dil_shift && generic) return GV_E_UNSUPPORTED;
+        // the vector loader keeps 32-bit element offsets
+        if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1 : gvconv::lp_pick_tile(a.M, a.cout, a.K));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);

@@ -6,11 +6,12 @@
 // Structure (4 or 8 waves, wave tile TM x TN MFMA tiles of 32x32, k-tile = 32):
 //   * LDS row = 64 B (32 values) + 16 B pad = 5 sixteen-byte slots (odd): the ds_read_b128 fragment reads
 //     (lane (r = lane&31, h = lane>>5) reads k = 16s+8h .. +7 of row r) hit 16 distinct 4-bank groups in
-//     every 16-lane service group; the loader's ds_write_b128 (4 lanes per row) overlap by one chunk in
-//     8, inside the store's register-transfer time;
-//   * a loader lane owns one 16-byte chunk (8 channels of one filter tap) per slot; its tap position
-//     (r, s, c) advances incrementally, loads are unconditional from a clamped address and zeroed by a
-//     select, so the compiler counts vmcnt and keeps two k-tiles of global loads in flight;
+//     every 16-lane service group;
+//   * a loader lane owns one 16-byte chunk (8 channels of one filter tap) per slot; its element offset
+//     advances by 32 channels per k-tile and is re-derived from (r, s) only when the chunk moves to another
+//     tap, loads are unconditional (padding taps read offset 0 and are zeroed by a select before the LDS
+//     write), so the compiler counts vmcnt and keeps two k-tiles of global loads in flight; rows R and
+//     R+4 share an 8-lane ds_write_b128 group (conflict-free for 80-byte rows);
 //   * fragments are double buffered in registers; the k-tile barrier sits between the two halves of a
 //     tile's MFMAs;
 //   * GENERIC variant (cin % 8 != 0: the stems' cin = 3) gathers element-wise, optionally straight from the
@@ -48,43 +49,136 @@ __device__ __forceinline__ float from_bits(unsigned short b) {
     return (float)__builtin_bit_cast(T, b);
 }
 
-// y = act(acc*scale + shift (+ residual)) rounded once to T; y2 = second activation or split destination
+// Staged epilogue: each wave transposes its accumulators through a private LDS block (32 rows x CW fp32) so
+// that a lane ends up with 8 CONSECUTIVE channels of one pixel: scale/shift/residual/ReLU are applied to
+// the fp32 values, which are rounded once and leave as 16-byte stores (residual and second output: 16-byte
+// loads / stores as well).  Storing straight from the MFMA layout would issue 2-byte stores, one per lane
+// per row — 8x the store instructions, and the kernel then spends more time storing than multiplying.
+template <int TN> struct EpiGeom {
+    static constexpr int CW = (TN % 2 == 0) ? 64 : 32;     // columns per staging block
+    static constexpr int JB = CW / 32;                     // MFMA tiles per block
+    static constexpr int BYTES = 32 * CW * 4;              // per wave
+};
+
+template <typename T>
+__device__ __forceinline__ void store_chunk(unsigned short* dst, const float (&v)[8], int nvalid, bool vec) {
+    if (vec && nvalid == 8) {
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+        *reinterpret_cast<u32x4*>(dst) = o;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nvalid) dst[j] = to_bits<T>(v[j]);
+    }
+}
+
 template <typename T, int TM, int TN>
-__device__ __forceinline__ void lp_epilogue(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                            int wm, int wn, int lane) {
+__device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                   int wm, int wn, int lane, float* stage) {
+    if (a.dbg & 4) {            // timing ablation: keep the accumulators live without storing the tile
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 1.2345e-30f) a.y[0] = t;
+        return;
+    }
+    constexpr int CW = EpiGeom<TN>::CW, JB = EpiGeom<TN>::JB;
+    constexpr int CPR = CW / 8;                            // 8-column chunks per row
+    constexpr int RPP = 64 / CPR;                          // rows per read-back pass
     const int col_l = lane & 31;
     const int row_h = 4 * (lane >> 5);
+    const int rrow = lane / CPR, rchunk = lane % CPR;
     const unsigned short* res = reinterpret_cast<const unsigned short*>(a.res);
     unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
     unsigned short* y2 = reinterpret_cast<unsigned short*>(a.y2);
+    const bool dual = y2 != nullptr && a.split == 0;
+    // 16-byte accesses need 8-element aligned rows, slices and boundaries (true for every layer of both
+    // backbones); anything else takes the element-wise branch of store_chunk
+    const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
+                     (y2 == nullptr || ((a.y2_ld % 8 == 0) && ((((uintptr_t)y2) & 15) == 0))) &&
+                     (a.split % 8 == 0) && (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0)));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + col_l;
-        if (col >= a.cout) continue;
-        const float sc = a.scale[col], sh = a.shift[col];
+    for (int jb = 0; jb < TN / JB; ++jb) {
+        const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;     // this lane's 8 columns
+        const int nvalid = min(8, a.cout - col);                        // <= 0: nothing to store
+        float sc[8], sh[8], sc2[8], sh2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = min(col + e, a.cout - 1);
+            sc[e] = a.scale[c];
+            sh[e] = a.shift[c];
+            sc2[e] = dual ? a.scale2[c] : 0.f;
+            sh2[e] = dual ? a.shift2[c] : 0.f;
+        }
+        // split destination: a chunk lies on one side when split % 8 == 0; otherwise decide per element below
         const bool to_second = a.split > 0 && col >= a.split;
-        const bool dual = y2 != nullptr && a.split == 0;
-        float sc2 = 0.f, sh2 = 0.f;
-        if (dual) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
-        unsigned short* ybase = to_second ? y2 + (col - a.split) : y + col;
-        const int yld = to_second ? a.y2_ld : a.y_ld;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int rbase = m0 + (wm * TM + i) * 32 + row_h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = rbase + (r & 3) + 8 * (r >> 2);
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] * sc + sh;
-                if (res) v += from_bits<T>(res[(size_t)m * a.res_ld + col]);
-                if (dual) {
-                    float v2 = v * sc2 + sh2;
-                    if (a.relu2) v2 = fmaxf(v2, 0.f);
-                    y2[(size_t)m * a.y2_ld + col] = to_bits<T>(v2);
+            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[(row_h + (r & 3) + 8 * (r >> 2)) * CW + jj * 32 + col_l] = acc[i][jb * JB + jj][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 32 / RPP; ++pass) {
+                const int row = pass * RPP + rrow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8 + 4);
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                if (m >= a.M || nvalid <= 0) continue;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                if (res) {
+                    const unsigned short* rp = res + (size_t)m * a.res_ld + col;
+                    if (vec && nvalid == 8) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[2 * j] += from_bits<T>((unsigned short)(rv[j] & 0xffffu));
+                            v[2 * j + 1] += from_bits<T>((unsigned short)(rv[j] >> 16));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < nvalid) v[e] += from_bits<T>(rp[e]);
+                    }
                 }
-                if (a.relu) v = fmaxf(v, 0.f);
-                ybase[(size_t)m * yld] = to_bits<T>(v);
+                if (dual) {
+                    float v2[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v2[e] = v[e] * sc2[e] + sh2[e];
+                        if (a.relu2) v2[e] = fmaxf(v2[e], 0.f);
+                    }
+                    store_chunk<T>(y2 + (size_t)m * a.y2_ld + col, v2, nvalid, vec);
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.split > 0 && (a.split % 8) != 0) {          // boundary inside a chunk: element-wise
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e >= nvalid) continue;
+                        const int c = col + e;
+                        if (c >= a.split) y2[(size_t)m * a.y2_ld + (c - a.split)] = to_bits<T>(v[e]);
+                        else y[(size_t)m * a.y_ld + c] = to_bits<T>(v[e]);
+                    }
+                } else if (to_second) {
+                    store_chunk<T>(y2 + (size_t)m * a.y2_ld + (col - a.split), v, nvalid, vec);
+                } else {
+                    store_chunk<T>(y + (size_t)m * a.y_ld + col, v, nvalid, vec);
+                }
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -118,13 +212,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
     const int n0 = tile_n * BN;
 
     const int q = tid & 3;                           // this thread's 16-byte chunk of every row it loads
+    // slot -> row: an 8-lane ds_write_b128 group covers rows R and R+4 (80-byte rows: 16 banks apart mod 32)
+    auto slot_row = [](int idx) -> int {
+        const int g8 = idx >> 3;
+        return (g8 >> 2) * 8 + (g8 & 3) + 4 * ((idx >> 2) & 1);
+    };
     const unsigned short* xs = reinterpret_cast<const unsigned short*>(a.x);
 
     int a_img[A_SLOTS], a_iy0[A_SLOTS], a_ix0[A_SLOTS];
     const int ohow = a.oh * a.ow;
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
-        const int row = (tid + i * NT) >> 2;
+        const int row = slot_row(tid + i * NT);
         const int m = m0 + row;
         if (row < BM && m < a.M) {
             const int n = m / ohow;
@@ -144,7 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
     bool b_ok[B_SLOTS];
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
-        const int row = (tid + i * NT) >> 2;
+        const int row = slot_row(tid + i * NT);
         const int n = n0 + row;
         b_ok[i] = (row < BN);
         // rows past cout re-read the last filter: their accumulator columns are never stored
@@ -156,10 +255,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
     using I1 = std::integral_constant<int, 1>;
     u32x4 ra[2][A_SLOTS];                             // tile t is staged in register set t & 1
     u32x4 rb[2][B_SLOTS];
+    bool ra_ok[2][A_SLOTS];
     // filter tap / channel of this thread's chunk in the NEXT tile to load
     int fc = 8 * q, fs = 0, fr = 0;
+    unsigned a_off[A_SLOTS];                          // element offset of the chunk to load (0 when the tap is padding)
+    bool a_ok[A_SLOTS];
+    auto locate = [&]() {                             // (fr, fs, fc) -> per-slot offset / validity
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int iyn = a_iy0[i] + fr;
+            const int ixn = a_ix0[i] + fs;
+            const int dmask = (1 << a.dil_shift) - 1; // zero-dilated input: see conv_bf16s.hip
+            const int iy = iyn >> a.dil_shift;
+            const int ix = ixn >> a.dil_shift;
+            const bool ok = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw && fr < a.kh;
+            a_ok[i] = ok;
+            a_off[i] = ok ? ((unsigned)(a_img[i] + iy) * (unsigned)a.iw + (unsigned)ix) * (unsigned)a.x_ld + (unsigned)fc : 0u;
+        }
+    };
     if constexpr (!GENERIC) {
         while (fc >= a.cin) { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } }
+        locate();
     }
 
     auto load_tile = [&](auto rsc, int kt) {
@@ -168,20 +284,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
         for (int i = 0; i < A_SLOTS; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if constexpr (!GENERIC) {
-                const int iyn = a_iy0[i] + fr;
-                const int ixn = a_ix0[i] + fs;
-                const int dmask = (1 << a.dil_shift) - 1;     // zero-dilated input: see conv_bf16s.hip
-                const int iy = iyn >> a.dil_shift;
-                const int ix = ixn >> a.dil_shift;
-                const bool ok = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw &&
-                                fr < a.kh;
-                const int iyc = min(max(iy, 0), a.ih - 1);
-                const int ixc = min(max(ix, 0), a.iw - 1);
-                const unsigned short* p = xs + ((size_t)(a_img[i] + iyc) * a.iw + ixc) * a.x_ld + fc;
-                const u32x4 ld = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ok ? ld[j] : 0u;
+                // unconditional load (padding taps read offset 0.. of the tensor and are zeroed by the select)
+                v = *reinterpret_cast<const u32x4*>(xs + a_off[i]);
+                ra_ok[RS][i] = a_ok[i];
             } else {
+                ra_ok[RS][i] = true;
                 unsigned short e[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -215,7 +322,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
     auto advance_tap = [&]() {
         if constexpr (!GENERIC) {
             fc += KT;
-            while (fc >= a.cin) { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } }
+            if (fc >= a.cin) {                        // the chunk leaves this filter tap: new window position
+                do { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } } while (fc >= a.cin);
+                locate();
+            } else {                                  // same tap, next 32 channels
+#pragma unroll
+                for (int i = 0; i < A_SLOTS; ++i) a_off[i] += a_ok[i] ? (unsigned)KT : 0u;
+            }
         }
     };
     auto store_tile = [&](auto rsc, int buf) {
@@ -223,14 +336,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int idx = tid + i * NT;
-            if (A_SLOTS * NT == BM * 4 || idx < BM * 4)
-                *reinterpret_cast<u32x4*>(sA + buf * BM * RB + (idx >> 2) * RB + 16 * q) = ra[RS][i];
+            if (A_SLOTS * NT == BM * 4 || idx < BM * 4) {
+                u32x4 v = ra[RS][i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ra_ok[RS][i] ? v[j] : 0u;
+                *reinterpret_cast<u32x4*>(sA + buf * BM * RB + slot_row(idx) * RB + 16 * q) = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
             const int idx = tid + i * NT;
             if (B_SLOTS * NT == BN * 4 || b_ok[i])
-                *reinterpret_cast<u32x4*>(sB + buf * BN * RB + (idx >> 2) * RB + 16 * q) = rb[RS][i];
+                *reinterpret_cast<u32x4*>(sB + buf * BN * RB + slot_row(idx) * RB + 16 * q) = rb[RS][i];
         }
     };
 
@@ -307,7 +424,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
         mfma_range(I0{}, I0{}, IN{});
     }
 
-    lp_epilogue<T, TM, TN>(a, acc, m0, n0, wm, wn, lane);
+    __syncthreads();                                  // every wave is done with the main-loop buffers
+    lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane,
+                                  reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES));
 }
 
 // [kh][kw][cin][cout] fp32 -> [cout][Kpad] T, k = (r*kw+s)*cin + c, zero filled to a multiple of 32
@@ -346,7 +465,9 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     const int tiles_m = gv_ceil_div(a.M, BM);
     const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * BM + 2 * BN) * RB;
+    const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB;
+    const size_t lds_epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
+    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     if (xf32) return launch_one<T, WM, WN, TM, TN, true, true>(a, nwg, lds, st);
     if (generic) return launch_one<T, WM, WN, TM, TN, true, false>(a, nwg, lds, st);
     return launch_one<T, WM, WN, TM, TN, false, false>(a, nwg, lds, st);

@@ -26,11 +26,12 @@ ap.add_argument("--ablate", action="store_true", help="time ablated kernels (no 
 ap.add_argument("--autotune", action="store_true")
 ap.add_argument("--no-fuse", action="store_true")
 ap.add_argument("--math", default="f32")
+ap.add_argument("--storage", default="f32")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
 nb = a.shapes * a.views
-plan = backbones.make_plan(a.backbone, nb, a.size, a.size, dev, math=a.math)
+plan = backbones.make_plan(a.backbone, nb, a.size, a.size, dev, math=a.math, dtype=a.storage)
 P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
 plan.bind(P)
 x = (torch.rand(nb, a.size, a.size, 3) - 0.5).to(dev)
@@ -39,7 +40,7 @@ torch.cuda.synchronize()
 lib = _lib.load()
 if a.autotune:
     plan.autotune(x)
-ncfg = lib.gv_conv2d_num_tile_cfgs(plan.math_mode)
+ncfg = lib.gv_conv2d_num_tile_cfgs(plan.math_mode if a.storage == 'f32' else _lib.GV_MATH_BF16X1)
 rows = []
 tot = {"conv": 0.0, "pool": 0.0, "ssa": 0.0}
 for i, op in enumerate(plan.ops):

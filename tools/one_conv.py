@@ -18,10 +18,12 @@ ap.add_argument("--op", type=int, nargs="+", default=[5])
 ap.add_argument("--tile", type=int, default=-1)
 ap.add_argument("--dbg", type=int, nargs="+", default=[0])
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--storage", default="f32")
+ap.add_argument("--math", default="f32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 nb = a.shapes * 12
-plan = backbones.make_plan(a.backbone, nb, 224, 224, dev)
+plan = backbones.make_plan(a.backbone, nb, 224, 224, dev, dtype=a.storage, math=a.math)
 plan.bind(gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True))
 x = (torch.rand(nb, 224, 224, 3) - 0.5).to(dev)
 plan.run(x)
