@@ -117,6 +117,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
             a_ix0[i] = 0;
         }
     }
+    // gather path: k -> (offset of tap (r, s, c) from the window origin, r, s) looked up in LDS instead of two
+    // integer divisions per element; entries past K carry r = 0x7fff (never inside the image)
+    int2* ktab = reinterpret_cast<int2*>(smem_raw + (2 * BM + 2 * BN) * RB);
+    int a_base[A_SLOTS];
+    if constexpr (GENERIC) {
+        for (int k = tid; k < a.Kpad; k += NT) {
+            int2 t;
+            if (k < a.K) {
+                const int rs = k / a.cin, c = k - rs * a.cin;
+                const int r = rs / a.kw, s_ = rs - r * a.kw;
+                t.x = (r * a.iw + s_) * a.x_ld + c;
+                t.y = (r << 16) | s_;
+            } else {
+                t.x = 0;
+                t.y = 0x7fff << 16;
+            }
+            ktab[k] = t;
+        }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i)
+            a_base[i] = a_iy0[i] > -(1 << 27) ? ((a_img[i] + a_iy0[i]) * a.iw + a_ix0[i]) * a.x_ld : 0;
+        __syncthreads();
+    }
     const char* b_ptr[B_SLOTS];
     bool b_ok[B_SLOTS];
 #pragma unroll
@@ -137,6 +160,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
     u32x4 rb[2][B_SLOTS][NP];
     bool aok[2][A_SLOTS];
     int fr = 0, fs = 0, fc = 0;                       // filter tap / channel base of the NEXT tile to load
+    unsigned a_off[A_SLOTS];                          // element offset of the slot's 8 values (0 when the tap is padding)
+    bool a_ok[A_SLOTS];
+    auto locate = [&]() {                             // (fr, fs, fc) -> per-slot offset / validity
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int half = (tid + i * NT) & 1;
+            const int iyn = a_iy0[i] + fr;
+            const int ixn = a_ix0[i] + fs;
+            // zero-dilated input (data gradient of a strided conv): only positions that are multiples of
+            // the dilation exist, at index >> dil_shift
+            const int dmask = (1 << a.dil_shift) - 1;
+            const int iy = iyn >> a.dil_shift;
+            const int ix = ixn >> a.dil_shift;
+            const bool ok = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw && fr < a.kh;
+            a_ok[i] = ok;
+            a_off[i] = ok ? ((unsigned)(a_img[i] + iy) * (unsigned)a.iw + (unsigned)ix) * (unsigned)a.x_ld +
+                                (unsigned)(fc + 8 * half)
+                          : 0u;
+        }
+    };
+    if constexpr (!GENERIC) locate();
 
     auto load_tile = [&](auto rsc, int kt) {
         constexpr int RS = decltype(rsc)::value;
@@ -145,39 +189,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
             const int half = (tid + i * NT) & 1;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (!GENERIC) {
-                // unconditional loads from a clamped (always valid) address; padding taps and rows past
-                // M are zeroed / ignored later.  No divergent branch => the compiler can count vmcnt and
-                // leave the younger tile's loads in flight.
-                const int iyn = a_iy0[i] + fr;
-                const int ixn = a_ix0[i] + fs;
-                // zero-dilated input (data gradient of a strided conv): only positions that are multiples of
-                // the dilation exist, at index >> dil_shift
-                const int dmask = (1 << a.dil_shift) - 1;
-                const int iy = iyn >> a.dil_shift;
-                const int ix = ixn >> a.dil_shift;
-                aok[RS][i] = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw &&
-                             fr < a.kh;
-                const int iyc = min(max(iy, 0), a.ih - 1);
-                const int ixc = min(max(ix, 0), a.iw - 1);
-                const float* p = a.x + ((size_t)(a_img[i] + iyc) * a.iw + ixc) * a.x_ld + fc + 8 * half;
+                // unconditional loads (padding taps and rows past M read offset 0.. and are zeroed later).  No
+                // divergent branch => the compiler can count vmcnt and leave the younger tile's loads in flight.
+                aok[RS][i] = a_ok[i];
+                const float* p = a.x + a_off[i];
                 v0 = *reinterpret_cast<const f32x4*>(p);
                 v1 = *reinterpret_cast<const f32x4*>(p + 4);
             } else {
                 aok[RS][i] = true;
+                if (kt < a.ktiles)                            // (uniform) no gather work for prefetches past the end
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = kt * KT + 8 * half + j;
+                    const int2 t = ktab[k];                   // same k across the rows of a tile: LDS broadcast
+                    const int iy = a_iy0[i] + (t.y >> 16);
+                    const int ix = a_ix0[i] + (t.y & 0xffff);
                     float e = 0.f;
-                    if (k < a.K) {
-                        const int rs = k / a.cin;
-                        const int c = k - rs * a.cin;
-                        const int r = rs / a.kw;
-                        const int s = rs - r * a.kw;
-                        const int iy = a_iy0[i] + r;
-                        const int ix = a_ix0[i] + s;
-                        if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
-                            e = a.x[((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + c];
-                    }
+                    if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) e = a.x[a_base[i] + t.x];
                     if (j < 4) v0[j] = e; else v1[j - 4] = e;
                 }
             }
@@ -196,9 +224,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
     auto advance_tap = [&]() {
         if constexpr (!GENERIC) {
             fc += KT;
-            if (fc >= a.cin) {
+            if (fc >= a.cin) {                        // next filter tap: new window position
                 fc = 0;
                 if (++fs == a.kw) { fs = 0; ++fr; }
+                locate();
+            } else {                                  // same tap, next 16 channels
+#pragma unroll
+                for (int i = 0; i < A_SLOTS; ++i) a_off[i] += a_ok[i] ? (unsigned)KT : 0u;
             }
         }
     };
@@ -340,7 +372,7 @@ int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
     const int tiles_m = gv_ceil_div(a.M, BM);
     const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * BM + 2 * BN) * (NP * 32 + 16);
+    const size_t lds = (size_t)(2 * BM + 2 * BN) * (NP * 32 + 16) + (generic ? (size_t)a.Kpad * 8 : 0);
     if (generic) {
         if (lds > 64 * 1024) {
             static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, true>),

@@ -478,6 +478,8 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
     const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
     if (np > 0) {
+        // the vector loader keeps 32-bit element offsets
+        if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1 : gvconv::bf16s_pick_tile(np, a.M, a.cout, a.K));
         return gvconv::bf16s_launch(np, cfg, a, generic, (hipStream_t)stream);

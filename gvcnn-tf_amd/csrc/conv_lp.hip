@@ -239,6 +239,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
             a_ix0[i] = 0;
         }
     }
+    // gather path: k -> (offset of tap (r, s, c) from the window origin, r, s) looked up in LDS instead of two
+    // integer divisions per element; entries past K carry r = 0x7fff (never inside the image)
+    int2* ktab = reinterpret_cast<int2*>(smem_raw + (2 * BM + 2 * BN) * RB);
+    int a_base[A_SLOTS];
+    if constexpr (GENERIC) {
+        for (int k = tid; k < a.Kpad; k += NT) {
+            int2 t;
+            if (k < a.K) {
+                const int rs = k / a.cin, c = k - rs * a.cin;
+                const int r = rs / a.kw, s_ = rs - r * a.kw;
+                t.x = (r * a.iw + s_) * a.x_ld + c;
+                t.y = (r << 16) | s_;
+            } else {
+                t.x = 0;
+                t.y = 0x7fff << 16;
+            }
+            ktab[k] = t;
+        }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i)
+            a_base[i] = a_iy0[i] > -(1 << 27) ? ((a_img[i] + a_iy0[i]) * a.iw + a_ix0[i]) * a.x_ld : 0;
+        __syncthreads();
+    }
     const char* b_ptr[B_SLOTS];
     bool b_ok[B_SLOTS];
 #pragma unroll
@@ -289,23 +312,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
                 ra_ok[RS][i] = a_ok[i];
             } else {
                 ra_ok[RS][i] = true;
-                unsigned short e[8];
+                unsigned short e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kt < a.ktiles)                            // (uniform) no gather work for prefetches past the end
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = kt * KT + 8 * q + j;
+                    const int2 t = ktab[k];                   // same k across a row group: LDS broadcast
+                    const int iy = a_iy0[i] + (t.y >> 16);
+                    const int ix = a_ix0[i] + (t.y & 0xffff);
                     e[j] = 0;
-                    if (k < a.K) {
-                        const int rs = k / a.cin;
-                        const int c = k - rs * a.cin;
-                        const int r = rs / a.kw;
-                        const int s = rs - r * a.kw;
-                        const int iy = a_iy0[i] + r;
-                        const int ix = a_ix0[i] + s;
-                        if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) {
-                            const size_t off = ((size_t)(a_img[i] + iy) * a.iw + ix) * a.x_ld + c;
-                            if constexpr (XF32) e[j] = to_bits<T>(a.x[off]);
-                            else e[j] = xs[off];
-                        }
+                    if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) {
+                        const int off = a_base[i] + t.x;
+                        if constexpr (XF32) e[j] = to_bits<T>(a.x[off]);
+                        else e[j] = xs[off];
                     }
                 }
 #pragma unroll
@@ -465,7 +484,7 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     const int tiles_m = gv_ceil_div(a.M, BM);
     const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB;
+    const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB + ((generic || xf32) ? (size_t)a.Kpad * 8 : 0);
     const size_t lds_epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     if (xf32) return launch_one<T, WM, WN, TM, TN, true, true>(a, nwg, lds, st);
