@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
 GV_F32, GV_BF16, GV_F16 = 0, 1, 2
 GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT, GV_CONV_X_F32 = 1, 2, 4, 8
 GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
-GV_POOL_MAX, GV_POOL_AVG = 0, 1
+GV_POOL_MAX, GV_POOL_AVG, GV_POOL_AVG_RELU = 0, 1, 2
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
 GV_ABI_VERSION = 1
@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "cin", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
         "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype", "split_col", "tile_cfg",
-        "math_mode", "in_dilation")]
+        "math_mode", "in_dilation", "relu_cols")]
 
 
 class PoolDesc(C.Structure):

@@ -151,11 +151,21 @@ class BackbonePlan:
         self._ss_cache[key] = (so, ho)
         return so, ho
 
-    def conv_siblings(self, x, branches, first_out, norm, relu=True):
+    def conv_siblings(self, x, branches, first_out, norm, relu=True, pooled=None):
         """Several 1x1/stride-1 slim.conv2d that read the SAME input, as ONE implicit GEMM over their
         concatenated filters (GV_CONV_SPLIT): the first branch's columns land in `first_out` (a slice
         of the block's concat buffer), the others side by side in one scratch tensor whose channel
-        slices are returned.  branches = [(scope, cout), ...] in reference order."""
+        slices are returned.  branches = [(scope, cout), ...] in reference order.
+
+        pooled = (scope, cout, pool_name, out): the block's `avg_pool2d 3x3/1 SAME -> conv2d 1x1 -> BN -> ReLU`
+        branch (nets/inception_v3.py:152-154,...) joins the GEMM as trailing columns WITHOUT ReLU, followed by
+        one GV_POOL_AVG_RELU pass into `out`: relu(avgpool(BN(conv1x1(x)))) == relu(BN(conv1x1(avgpool(x))))
+        because the 1x1 conv and the BN affine commute with an average whose weights sum to 1.  The pool then
+        moves cout instead of cin channels (4-10x less HBM traffic) and one launch disappears."""
+        branches = list(branches)
+        n_relu = sum(c for _, c in branches)
+        if pooled is not None:
+            branches.append((pooled[0], pooled[1]))
         couts = [c for _, c in branches]
         total = sum(couts)
         rest = total - couts[0]
@@ -179,12 +189,20 @@ class BackbonePlan:
                              y2=scratch, res=None, w_off=w_off, scale_off=so, shift_off=ho,
                              scale2_off=0, shift2_off=0, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
                              relu=relu, split=couts[0], cout=total,
+                             relu_cols=n_relu if pooled is not None else 0,
                              flops=2.0 * x.npix * total * x.c,
-                             bytes=4.0 * (x.npix * x.c + x.c * total + x.npix * total)))
+                             bytes=float(self.esz) * (x.npix * x.c + x.c * total + x.npix * total)))
         outs, lo = [], 0
         for c in couts[1:]:
             outs.append(scratch.channels(lo, lo + c))
             lo += c
+        if pooled is not None:
+            z = outs.pop()
+            out = pooled[3]
+            assert (out.nb, out.h, out.w, out.c) == (x.nb, x.h, x.w, pooled[1])
+            self._record(dict(kind="pool", name=pooled[2], x=z, y=out, k=3, stride=1, pad_t=1, pad_l=1,
+                              mode=_lib.GV_POOL_AVG_RELU, flops=0.0,
+                              bytes=float(self.esz) * 2 * z.npix * z.c))
         return outs
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
@@ -320,7 +338,8 @@ class BackbonePlan:
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], y.h, y.w, op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
-                                  flags, self.dtype, split, op.get("tile", 0), self.math_mode)
+                                  flags, self.dtype, split, op.get("tile", 0), self.math_mode, 0,
+                                  op.get("relu_cols", 0))
                 rs, ro = ref(res)
                 y2s, y2o = ref(y2)
                 _lib.check(lib.gv_plan_add_conv(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"] * wmul,
@@ -546,16 +565,26 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     def conv(x, name, cout, k, stride=1, padding="SAME", out=None):
         return b.conv(x, scope + "/" + name, cout, k, stride, padding, out=out, norm=BN, relu=True)
 
-    def siblings(x, branches, first_out):
-        """The 1x1 convs of one block that read the block input (e.g. inception_v3.py:140,142,146)."""
+    def siblings(x, branches, first_out, pooled=None):
+        """The 1x1 convs of one block that read the block input (e.g. inception_v3.py:140,142,146), and the
+        block's pooled branch: pooled = (block scope, depth, destination slice)."""
         if not fuse_siblings:
             outs = []
             for i, (name, c) in enumerate(branches):
                 t = conv(x, name, c, 1, out=first_out if i == 0 else None)
                 if i:
                     outs.append(t)
+            if pooled is not None:
+                s, depth, dst = pooled
+                with b.lane(2):
+                    t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
+                    conv(t, s + "Branch_3/Conv2d_0b_1x1", depth, 1, out=dst)
             return outs
-        return b.conv_siblings(x, [(scope + "/" + n, c) for n, c in branches], first_out, BN)
+        pb = None
+        if pooled is not None:
+            s, depth, dst = pooled
+            pb = (scope + "/" + s + "Branch_3/Conv2d_0b_1x1", depth, s + "Branch_3/AvgPool_0a_3x3", dst)
+        return b.conv_siblings(x, [(scope + "/" + n, c) for n, c in branches], first_out, BN, pooled=pb)
 
     def done(name, t):
         b.end_points[name] = t
@@ -582,14 +611,12 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         s = name + "/"
         out = b.new_tensor(x.nb, x.h, x.w, 64 + 64 + 96 + pool_depth)
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 64), (s + "Branch_1/" + b1a, 48),
-                              (s + "Branch_2/Conv2d_0a_1x1", 64)], out.channels(0, 64))
+                              (s + "Branch_2/Conv2d_0a_1x1", 64)], out.channels(0, 64),
+                          pooled=(s, pool_depth, out.channels(224, 224 + pool_depth)))
         with b.lane(1):
             conv(t1, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
         t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 96, 3)
         conv(t, s + "Branch_2/Conv2d_0c_3x3", 96, 3, out=out.channels(128, 224))
-        with b.lane(2):
-            t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-            conv(t, s + "Branch_3/Conv2d_0b_1x1", pool_depth, 1, out=out.channels(224, 224 + pool_depth))
         return out
 
     net = mixed5(net, "Mixed_5b", "Conv2d_0a_1x1", "Conv2d_0b_5x5", 32)
@@ -618,7 +645,8 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         s = name + "/"
         out = b.new_tensor(x.nb, x.h, x.w, 768)
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 192), (s + "Branch_1/Conv2d_0a_1x1", d),
-                              (s + "Branch_2/Conv2d_0a_1x1", d)], out.channels(0, 192))
+                              (s + "Branch_2/Conv2d_0a_1x1", d)], out.channels(0, 192),
+                          pooled=(s, 192, out.channels(576, 768)))
         with b.lane(1):
             t = conv(t1, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
             conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), out=out.channels(192, 384))
@@ -626,9 +654,6 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         t = conv(t, s + "Branch_2/Conv2d_0c_1x7", d, (1, 7))
         t = conv(t, s + "Branch_2/Conv2d_0d_7x1", d, (7, 1))
         conv(t, s + "Branch_2/Conv2d_0e_1x7", 192, (1, 7), out=out.channels(384, 576))
-        with b.lane(2):
-            t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-            conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(576, 768))
         return out
 
     for name, d in (("Mixed_6b", 128), ("Mixed_6c", 160), ("Mixed_6d", 160), ("Mixed_6e", 192)):
@@ -656,16 +681,14 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         s = name + "/"
         out = b.new_tensor(x.nb, x.h, x.w, 2048)
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 320), (s + "Branch_1/Conv2d_0a_1x1", 384),
-                              (s + "Branch_2/Conv2d_0a_1x1", 448)], out.channels(0, 320))
+                              (s + "Branch_2/Conv2d_0a_1x1", 448)], out.channels(0, 320),
+                          pooled=(s, 192, out.channels(1856, 2048)))
         with b.lane(1):
             conv(t1, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
             conv(t1, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
         t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 384, 3)
         conv(t, s + "Branch_2/" + b2_names[0], 384, (1, 3), out=out.channels(1088, 1472))
         conv(t, s + "Branch_2/" + b2_names[1], 384, (3, 1), out=out.channels(1472, 1856))
-        with b.lane(2):
-            t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-            conv(t, s + "Branch_3/Conv2d_0b_1x1", 192, 1, out=out.channels(1856, 2048))
         return out
 
     net = mixed7(net, "Mixed_7b", "Conv2d_0b_3x1", ("Conv2d_0c_1x3", "Conv2d_0d_3x1"))

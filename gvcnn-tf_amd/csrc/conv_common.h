@@ -20,6 +20,7 @@ struct ConvArgs {
     int oh, ow, cout, y_ld, res_ld, y2_ld;
     int M, K, Kpad, ktiles;
     int relu, relu2, split;     // split > 0: columns >= split go to y2 (same scale/shift/relu)
+    int relu_limit;             // ReLU only for columns < relu_limit
     int tiles_n;
     int dil_shift;              // 0: plain; 1: input read as zero-dilated by 2 (stride-2 data gradient)
     int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
@@ -51,6 +52,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
         const float sc = a.scale[col], sh = a.shift[col];
         const bool to_second = a.split > 0 && col >= a.split;
         const bool dual = a.y2 != nullptr && a.split == 0;
+        const bool relu = a.relu && col < a.relu_limit;
         float sc2 = 0.f, sh2 = 0.f;
         if (dual) { sc2 = a.scale2[col]; sh2 = a.shift2[col]; }
         float* ybase = to_second ? a.y2 + (col - a.split) : a.y + col;
@@ -69,7 +71,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
                     if (a.relu2) v2 = fmaxf(v2, 0.f);
                     a.y2[(size_t)m * a.y2_ld + col] = v2;
                 }
-                if (a.relu) v = fmaxf(v, 0.f);
+                if (relu) v = fmaxf(v, 0.f);
                 ybase[(size_t)m * yld] = v;
             }
         }

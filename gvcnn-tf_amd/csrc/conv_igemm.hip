@@ -458,6 +458,8 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.relu = (d->flags & GV_CONV_RELU) ? 1 : 0;
     a.relu2 = (d->flags & GV_CONV_RELU2) ? 1 : 0;
     a.split = split ? d->split_col : 0;
+    if (d->relu_cols < 0) return GV_E_BADARG;
+    a.relu_limit = d->relu_cols > 0 ? d->relu_cols : 0x7fffffff;
     a.tiles_n = 0;
     a.dbg = g_debug;
     if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) return GV_E_BADARG;

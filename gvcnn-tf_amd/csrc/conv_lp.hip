@@ -162,7 +162,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 }
                 if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = (col + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
                 }
                 if (a.split > 0 && (a.split % 8) != 0) {          // boundary inside a chunk: element-wise
 #pragma unroll

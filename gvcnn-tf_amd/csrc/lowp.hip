@@ -78,10 +78,13 @@ __global__ __launch_bounds__(256) void pool2d_lp(const unsigned short* __restric
                 ++cnt;
             }
         }
-        if (mode == GV_POOL_AVG) {
+        if (mode != GV_POOL_MAX) {
             const float inv = (float)cnt;             // divisor = number of valid taps (TF SAME semantics)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] = acc[e] / inv;
+            for (int e = 0; e < VEC; ++e) {
+                acc[e] = acc[e] / inv;
+                if (mode == GV_POOL_AVG_RELU) acc[e] = fmaxf(acc[e], 0.f);
+            }
         }
         store_v<T, VEC>(y + (size_t)pix * y_ld + g * VEC, acc);
     }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void pool2d_lp(const unsigned short* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool3x3s1_row4_lp(const unsigned short* __restrict__ x,
                                                             unsigned short* __restrict__ y, int nb, int ih, int iw,
-                                                            int c, int x_ld, int y_ld) {
+                                                            int c, int x_ld, int y_ld, int relu) {
     const int cg = c >> 3;
     const int wg = (iw + 3) >> 2;
     const int64_t total = (int64_t)nb * ih * wg * cg;
@@ -136,7 +139,10 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_row4_lp(const unsigned short
             const float inv = (float)(rows * cols);
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (col[j][e] + col[j + 1][e] + col[j + 2][e]) / inv;
+            for (int e = 0; e < 8; ++e) {
+                v[e] = (col[j][e] + col[j + 1][e] + col[j + 2][e]) / inv;
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
             *reinterpret_cast<u32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 8) = pack8<T>(v);
         }
     }
@@ -301,11 +307,11 @@ inline unsigned grid_for(int64_t total) {
 template <typename T>
 int pool2d_t(const gv_pool_desc* d, const unsigned short* x, unsigned short* y, hipStream_t st) {
     const bool vec = (d->c % 8 == 0) && (d->x_ld % 8 == 0) && (d->y_ld % 8 == 0) && gv_aligned16(x) && gv_aligned16(y);
-    if (vec && d->mode == GV_POOL_AVG && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
+    if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
         const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
         hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
-                           d->iw, d->c, d->x_ld, d->y_ld);
+                           d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
     } else if (vec) {
         const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 8);
         hipLaunchKernelGGL((pool2d_lp<T, 8>), dim3(grid_for(total)), dim3(256), 0, st, x, y, d->nb, d->ih, d->iw,

@@ -61,13 +61,18 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
                 ++cnt;
             }
         }
-        if (mode == GV_POOL_AVG) {
+        if (mode != GV_POOL_MAX) {
             const float inv = (float)cnt;     // divisor = number of valid taps (TF SAME semantics)
+            const bool relu = mode == GV_POOL_AVG_RELU;
             if constexpr (VEC == 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = acc[e] / inv;
+                for (int e = 0; e < 4; ++e) {
+                    acc[e] = acc[e] / inv;
+                    if (relu) acc[e] = fmaxf(acc[e], 0.f);
+                }
             } else {
                 acc = acc / inv;
+                if (relu) acc = fmaxf(acc, 0.f);
             }
         }
         *reinterpret_cast<V*>(y + (size_t)pix * y_ld + g * VEC) = acc;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
 // instead of 36 — the generic kernel is L2-request bound on this op (2.4 TB/s).
 __global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __restrict__ x,
                                                              float* __restrict__ y, int nb, int ih,
-                                                             int iw, int c, int x_ld, int y_ld) {
+                                                             int iw, int c, int x_ld, int y_ld, int relu) {
     const int cg = c >> 2;
     const int wg = (iw + 3) >> 2;
     const int64_t total = (int64_t)nb * ih * wg * cg;
@@ -117,7 +122,10 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __rest
             const float inv = (float)(rows * cols);           // valid taps only (TF SAME semantics)
             f32x4 v = col[j] + col[j + 1] + col[j + 2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / inv;
+            for (int e = 0; e < 4; ++e) {
+                v[e] = v[e] / inv;
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
             *reinterpret_cast<f32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 4) = v;
         }
     }
@@ -180,7 +188,7 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
         d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
         return GV_E_BADARG;
     if (d->x_ld < d->c || d->y_ld < d->c) return GV_E_BADARG;
-    if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG) return GV_E_BADARG;
+    if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG && d->mode != GV_POOL_AVG_RELU) return GV_E_BADARG;
     if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
         return GV_E_BADARG;                   // an output whose window holds no valid tap
     if (d->pad_t >= d->kh || d->pad_l >= d->kw) return GV_E_BADARG;
@@ -189,11 +197,11 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
                      gv_aligned16(y);
     const int64_t total = (int64_t)d->nb * d->oh * d->ow * (vec ? d->c / 4 : d->c);
     hipStream_t st = (hipStream_t)stream;
-    if (vec && d->mode == GV_POOL_AVG && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
+    if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
         const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
         hipLaunchKernelGGL(avgpool3x3s1_row4_f32, dim3(grid_for(tot4)), dim3(256), 0, st, (const float*)x,
-                           (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld);
+                           (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
         GV_LAUNCH_CHECK();
         return GV_OK;
     }

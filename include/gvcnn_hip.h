@@ -59,6 +59,11 @@ extern "C" {
 /* pooling modes */
 #define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
 #define GV_POOL_AVG 1         /* divisor = number of VALID taps (slim.avg_pool2d, SAME) */
+#define GV_POOL_AVG_RELU 2    /* GV_POOL_AVG followed by ReLU.  avg_pool -> 1x1 conv -> BN -> ReLU
+                                 (nets/inception_v3.py:152-154,...) is evaluated as relu(avgpool(BN(conv1x1(x)))):
+                                 the 1x1 conv and the BN affine commute with the average (its weights sum to 1),
+                                 so the pool runs on cout instead of cin channels and the 1x1 joins the block's
+                                 other 1x1 convs in one GEMM */
 
 /* view-pooling modes */
 #define GV_VIEWPOOL_MAX 0     /* tf.reduce_max  — nets/model.py:72   */
@@ -92,6 +97,9 @@ typedef struct gv_conv_desc {
     int32_t in_dilation;       /* 0/1: plain convolution.  2: the input tensor is read as if zero-dilated by 2
                                   (only even tap positions exist, at index/2) — the data gradient of a stride-2
                                   convolution is a stride-1 convolution of the dilated dZ (GV_MATH_BF16X* only) */
+    int32_t relu_cols;         /* 0: GV_CONV_RELU applies to every output column.  n > 0: only to columns < n — the
+                                  trailing columns leave the GEMM as BN(conv) without ReLU (an Inception pooled branch
+                                  computed as relu(avgpool(BN(conv1x1(x)))), see GV_POOL_AVG_RELU) */
 } gv_conv_desc;
 
 typedef struct gv_pool_desc {

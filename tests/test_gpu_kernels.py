@@ -440,3 +440,37 @@ def test_conv_bf16x3_small_integers_exact_and_split_outputs():
                      x_ld=80, x_off=16, second=(s2, h2), math=1)
     np.testing.assert_allclose(y, pre.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(y2, torch.relu(pre * s2 + h2).numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("math", [0, 1])
+def test_pooled_branch_commutes_with_the_1x1_conv(math):
+    """inception_v3.py:152-154: relu(BN(conv1x1(avgpool(x)))) == relu(avgpool(BN(conv1x1(x)))) — the form the
+    plan runs (relu_cols: trailing GEMM columns without ReLU, then GV_POOL_AVG_RELU)."""
+    g = torch.Generator().manual_seed(21)
+    nb, h, wd, cin, couts = 2, 9, 11, 64, (32, 48, 40)             # last = the pooled branch
+    total = sum(couts)
+    x = torch.randn(nb, h, wd, cin, generator=g)
+    wcat = torch.randn(1, 1, cin, total, generator=g) * 0.1
+    scale = torch.rand(total, generator=g) + 0.5
+    shift = torch.randn(total, generator=g) * 0.1
+    n_relu = couts[0] + couts[1]
+    ref_plain = oracle_conv(x, wcat[..., :n_relu], 1, "SAME", scale[:n_relu], shift[:n_relu], True).numpy()
+    ref_pooled = oracle_conv(OB.avg_pool2d_same3(x), wcat[..., n_relu:], 1, "SAME", scale[n_relu:], shift[n_relu:],
+                             True).numpy()
+    xd, wp, sc, sh = x.to(DEV), pack_filter(wcat, math), scale.to(DEV), shift.to(DEV)
+    yd = torch.empty(nb, h, wd, couts[0], device=DEV)
+    y2d = torch.empty(nb, h, wd, total - couts[0], device=DEV)
+    d = _lib.ConvDesc(nb, h, wd, cin, cin, 1, 1, 1, 0, 0, h, wd, total, couts[0], 0, total - couts[0],
+                      _lib.GV_CONV_RELU | _lib.GV_CONV_SPLIT, _lib.GV_F32, couts[0], 0, math, 0, n_relu)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                   None, yd.data_ptr(), y2d.data_ptr(), None, None, st()), "conv")
+    out = torch.empty(nb, h, wd, couts[2], device=DEV)
+    pd = _lib.PoolDesc(nb, h, wd, couts[2], total - couts[0], 3, 3, 1, 1, 1, h, wd, couts[2], _lib.GV_POOL_AVG_RELU,
+                       _lib.GV_F32)
+    _lib.check(lib().gv_pool2d_fwd(C.byref(pd), y2d.data_ptr() + 4 * couts[1], out.data_ptr(), st()), "pool")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(yd.cpu().numpy(), ref_plain[..., :couts[0]], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(y2d.cpu().numpy()[..., :couts[1]], ref_plain[..., couts[0]:], rtol=2e-4, atol=2e-4)
+    z = y2d.cpu().numpy()[..., couts[1]:]
+    assert (z < 0).any()                                           # the pooled columns left the GEMM without ReLU
+    np.testing.assert_allclose(out.cpu().numpy(), ref_pooled, rtol=2e-4, atol=2e-4)

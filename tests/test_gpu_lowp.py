@@ -333,3 +333,34 @@ def test_lp_gvcnn_vs_fp32_oracle(backbone, size, ty):
     Sb, lb = eng.forward_basic(x.to(DEV))
     _, ob_logits = OM.basic(x, C_, P, Hd, backbone)
     assert rel_l2(lb.cpu().numpy(), ob_logits) < bound
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_lp_pooled_branch_commutes_with_the_1x1_conv(ty):
+    """relu_cols + GV_POOL_AVG_RELU on 16-bit storage (see the fp32 test of the same name): against the
+    reference order the only extra error is the rounding of the un-pooled 1x1 output: 2 ulp."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(21)
+    nb, h, wd, cin, couts = 2, 9, 11, 64, (32, 48, 40)
+    total = sum(couts)
+    x = rnd(torch.randn(nb, h, wd, cin, generator=g), td)
+    wcat = rnd(torch.randn(1, 1, cin, total, generator=g) * 0.1, td)
+    scale = torch.rand(total, generator=g) + 0.5
+    shift = torch.randn(total, generator=g) * 0.1
+    n_relu = couts[0] + couts[1]
+    ref_pooled = oracle_conv(OB.avg_pool2d_same3(x), wcat[..., n_relu:], 1, "SAME", scale[n_relu:], shift[n_relu:],
+                             True).numpy()
+    xd, wp, sc, sh = x.to(td).to(DEV), pack(wcat, code), scale.to(DEV), shift.to(DEV)
+    yd = torch.empty(nb, h, wd, couts[0], dtype=td, device=DEV)
+    y2d = torch.empty(nb, h, wd, total - couts[0], dtype=td, device=DEV)
+    d = _lib.ConvDesc(nb, h, wd, cin, cin, 1, 1, 1, 0, 0, h, wd, total, couts[0], 0, total - couts[0],
+                      _lib.GV_CONV_RELU | _lib.GV_CONV_SPLIT, code, couts[0], 0, 0, 0, n_relu)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                   None, yd.data_ptr(), y2d.data_ptr(), None, None, st()), "conv")
+    out = torch.empty(nb, h, wd, couts[2], dtype=td, device=DEV)
+    pd = _lib.PoolDesc(nb, h, wd, couts[2], total - couts[0], 3, 3, 1, 1, 1, h, wd, couts[2], _lib.GV_POOL_AVG_RELU, code)
+    _lib.check(lib().gv_pool2d_fwd(C.byref(pd), y2d.data_ptr() + 2 * couts[1], out.data_ptr(), st()), "pool")
+    torch.cuda.synchronize()
+    assert (y2d.float().cpu().numpy()[..., couts[1]:] < 0).any()
+    assert (y2d.float().cpu().numpy()[..., :couts[1]] >= 0).all()
+    close(out.float().cpu().numpy(), ref_pooled, 2 * ulp, extra=2 * ulp)

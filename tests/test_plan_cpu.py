@@ -26,7 +26,7 @@ def test_flops_per_view_match_survey(name, size, gflop):
     assert abs(p.total_flops / 1e9 - gflop) < 0.002 * gflop
     assert len(p.filters) == (94 if name == "inception_v3" else 53)          # slim.conv2d call sites
     n_launch = sum(1 for op in p.ops if op["kind"] == "conv")
-    assert n_launch == (94 - 2 * 9 if name == "inception_v3" else 53)       # 9 blocks fuse 3 sibling 1x1s
+    assert n_launch == (94 - 3 * 9 if name == "inception_v3" else 53)       # 9 blocks fuse 4 1x1s (3 siblings + the pooled branch)
 
 
 def test_end_point_shapes():
