@@ -86,3 +86,98 @@ class ShardedGVCNN:
         if check:
             eng.check_status()
         return eng.scores, S, logits
+
+
+# ------------------------------------------------------------------------------------------------
+# training: view-sharded data parallelism
+# ------------------------------------------------------------------------------------------------
+# In train mode BatchNorm normalises each view's graph copy over the N images of THAT view
+# (nets/model.py:129-141), so the batch is cut on VIEW boundaries: rank p runs the backbone for views
+# [p*V_l, (p+1)*V_l) of every shape and its BN statistics are exactly the reference's — no per-layer
+# statistics exchange.  Exchanges per step:
+#   forward   all-gather of the scorer responses [N, V_l] and of the final descriptors [N, V_l, h, w, C]
+#             (one large message each); every rank then runs the (tiny) grouping head on all V views;
+#   backward  each rank keeps the slice of dF that belongs to its views (no traffic), runs its backbone
+#             backward, and the variable gradients — shared by the V views, hence SUMMED over them
+#             (utils/train_utils.py:217-259) — are all-reduced in a few large buckets: xGMI is a
+#             point-to-point mesh, so few large messages beat one message per variable.
+def view_shard_range(num_views, world_size, rank):
+    """Views [lo, hi) owned by `rank`."""
+    if num_views % world_size != 0:
+        raise ValueError("%d views do not divide over %d ranks" % (num_views, world_size))
+    v_l = num_views // world_size
+    return rank * v_l, (rank + 1) * v_l
+
+
+def gather_views(t_local, group=None):
+    """All-gather along the VIEW axis: [N, V_l, ...] on every rank -> [N, P*V_l, ...] (global view order)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return t_local
+    t_local = t_local.contiguous()
+    n, v_l = t_local.shape[0], t_local.shape[1]
+    out = torch.empty((world * n,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
+    dist.all_gather_into_tensor(out, t_local, group=group)
+    out = out.view((world,) + tuple(t_local.shape))
+    return out.transpose(0, 1).reshape((n, world * v_l) + tuple(t_local.shape[2:])).contiguous()
+
+
+def allreduce_sum_bucketed(tensors, bucket_bytes=64 << 20, group=None):
+    """Sum `tensors` (same dtype, modified in place) over the ranks in buckets of about bucket_bytes: the
+    buckets are launched asynchronously back to back and waited for at the end."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 or not tensors:
+        return 0
+    buckets, cur, cur_bytes = [], [], 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if cur and cur_bytes + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(t)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        flat = torch.cat([t.reshape(-1) for t in b])
+        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
+    for work, flat, b in pending:
+        work.wait()
+        off = 0
+        for t in b:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    return len(buckets)
+
+
+class ShardedTrainGVCNN:
+    """Wraps a per-rank TrainGVCNN built with num_views = V/P, head_views = V, view_offset = rank*V/P."""
+
+    def __init__(self, engine, group=None, bucket_bytes=64 << 20):
+        self.eng = engine
+        self.group = group
+        self.bucket_bytes = bucket_bytes
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert engine.Vh == engine.V * self.world and engine.view_offset == self.rank * engine.V
+
+    def train_step(self, views_local, labels, lr=1e-3, mu=0.9, weight_decay=0.0, check=False):
+        """views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all ranks)."""
+        eng = self.eng
+        f = eng.final
+        eng.forward_backbone(views_local)
+        r_all = gather_views(eng.score_partial().view(eng.N, eng.V), self.group)
+        F_all = gather_views(eng.view(f).view(eng.N, eng.V, f.h, f.w, f.c), self.group)
+        eng.forward_head(labels, check=check, F=F_all, r_img=r_all.reshape(-1))
+        dF = torch.zeros_like(F_all)
+        eng.backward_head(dF=dF)
+        lo = eng.view_offset
+        eng.final_grad().copy_(dF[:, lo:lo + eng.V])
+        eng.backward_backbone()
+        # classifier gradients are identical on every rank (the head ran on the gathered data): not reduced
+        shared = [g for k, g in eng.grads.items() if k not in eng.cls_names]
+        allreduce_sum_bucketed(shared, self.bucket_bytes, self.group)
+        eng.apply_momentum(lr, mu, weight_decay)
+        return eng.loss

@@ -100,8 +100,16 @@ class TrainGVCNN:
 
     def __init__(self, backbone="resnet_v2_50", num_shapes=2, num_views=6, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
-                 raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2):
+                 raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2,
+                 head_views=None, view_offset=0):
+        """head_views / view_offset: view-sharded data parallelism (sharding.ShardedTrainGVCNN) — this engine
+        runs the backbone for views [view_offset, view_offset + num_views) of the head_views views of every shape
+        (so each view's BatchNorm statistics stay on one rank, exactly the reference's per-view statistics),
+        while the grouping head works on all head_views views."""
         self.lib = _lib.load()
+        self.Vh = head_views if head_views is not None else num_views
+        self.view_offset = view_offset
+        assert 0 <= view_offset and view_offset + num_views <= self.Vh
         self.device = dev = _dev(device)
         self.backbone = backbone
         self.N, self.V, self.H, self.W = num_shapes, num_views, height, width
@@ -133,15 +141,15 @@ class TrainGVCNN:
             self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()
                           if not k.endswith(("moving_mean", "moving_variance"))}
             if head_params is None:
-                head_params = _params.init_head_params(num_views, self.raw.c, self.final.c, num_classes, seed=seed + 1)
+                head_params = _params.init_head_params(self.Vh, self.raw.c, self.final.c, num_classes, seed=seed + 1)
             ks, bs = [], []
-            for v in range(num_views):
+            for v in range(view_offset, view_offset + num_views):
                 kn, bn = _params.scorer_names(v)
                 ks.append(torch.as_tensor(head_params[kn], dtype=f32).reshape(-1))
                 bs.append(torch.as_tensor(head_params[bn], dtype=f32).reshape(-1)[:1])
             self.score_kernel = torch.stack(ks).to(dev).contiguous()
             self.score_bias = torch.cat(bs).to(dev).contiguous()
-            kn, bn = _params.classifier_names(num_views)
+            kn, bn = _params.classifier_names(self.Vh)
             self.cls_names = (kn, bn)
             self.params[kn] = torch.as_tensor(head_params[kn], dtype=f32).to(dev).contiguous().clone()
             self.params[bn] = torch.as_tensor(head_params[bn], dtype=f32).to(dev).contiguous().clone()
@@ -169,9 +177,9 @@ class TrainGVCNN:
                     op["w_dgrad"] = torch.empty(nd, dtype=f32, device=dev) if op["x"].vbuf >= 0 else None
             nbv = nb
             self.r_img = torch.empty(nbv, dtype=f32, device=dev)
-            self.scores = torch.empty(num_views, dtype=f32, device=dev)
-            self.gidx = torch.empty(num_views, dtype=torch.int32, device=dev)
-            self.scheme = torch.empty((num_group, num_views), dtype=torch.int32, device=dev)
+            self.scores = torch.empty(self.Vh, dtype=f32, device=dev)
+            self.gidx = torch.empty(self.Vh, dtype=torch.int32, device=dev)
+            self.scheme = torch.empty((num_group, self.Vh), dtype=torch.int32, device=dev)
             self.weight = torch.empty(num_group, dtype=f32, device=dev)
             self.status = torch.zeros(1, dtype=torch.int32, device=dev)
             f = self.final
@@ -237,6 +245,13 @@ class TrainGVCNN:
     # -- forward (train mode) ----------------------------------------------------------------------------
     def forward(self, views, labels=None, g_scheme=None, g_weight=None, check=True):
         """Phase 1 + phase 2 of train.py:264-288.  Returns (scores [V], shape_descriptor, logits, loss)."""
+        assert self.Vh == self.V, "a view-sharded engine is driven by sharding.ShardedTrainGVCNN"
+        self.forward_backbone(views)
+        self.score_partial()
+        return self.forward_head(labels, g_scheme, g_weight, check)
+
+    def forward_backbone(self, views):
+        """Train-mode backbone over this engine's views (partial_run #1 without the scorer)."""
         lib = self.lib
         assert tuple(views.shape) == (self.N, self.V, self.H, self.W, 3) and views.is_cuda
         self._x = views.to(torch.float32).contiguous()
@@ -269,12 +284,26 @@ class TrainGVCNN:
                 d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                                   op["pad_l"], y.h, y.w, y.ld, op["mode"], _lib.GV_F32)
                 _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
-        # scorer (no gradient flows through it: scores leave the graph in partial_run #1)
+
+    def score_partial(self):
+        """Scorer responses r_img [N*V] of this engine's views (model.py:144-145); no gradient flows through the
+        scorer: the scores leave the graph in partial_run #1."""
         r = self.raw
-        _lib.check(lib.gv_view_score_partial(self._ptr(r), r.nb, r.h * r.w, r.c, r.ld, self.score_kernel.data_ptr(),
-                                             self.score_bias.data_ptr(), V, _lib.GV_ORDER_SHAPE_MAJOR,
-                                             self.r_img.data_ptr(), _lib.GV_F32, _st()), "score")
-        _lib.check(lib.gv_view_score_finalize(self.r_img.data_ptr(), self.N, V, _lib.GV_ORDER_SHAPE_MAJOR,
+        _lib.check(self.lib.gv_view_score_partial(self._ptr(r), r.nb, r.h * r.w, r.c, r.ld,
+                                                  self.score_kernel.data_ptr(), self.score_bias.data_ptr(), self.V,
+                                                  _lib.GV_ORDER_SHAPE_MAJOR, self.r_img.data_ptr(), _lib.GV_F32,
+                                                  _st()), "score")
+        return self.r_img
+
+    def forward_head(self, labels=None, g_scheme=None, g_weight=None, check=True, F=None, r_img=None):
+        """Scores -> scheme/weight -> view pooling + fusion -> classifier -> loss, over self.Vh views.
+        F [N, Vh, h, w, C] / r_img [N*Vh]: the gathered descriptors / scorer responses of a view-sharded job
+        (default: this engine's own taps)."""
+        lib, V = self.lib, self.Vh
+        r_img = self.r_img if r_img is None else r_img
+        assert r_img.numel() == self.N * V
+        self._F = F
+        _lib.check(lib.gv_view_score_finalize(r_img.data_ptr(), self.N, V, _lib.GV_ORDER_SHAPE_MAJOR,
                                               self.scores.data_ptr(), _st()), "score finalize")
         if g_scheme is None:
             _lib.check(lib.gv_group_assign(self.scores.data_ptr(), V, self.G, self.num_bins, self.gidx.data_ptr(),
@@ -287,7 +316,8 @@ class TrainGVCNN:
             self.weight.copy_(torch.as_tensor(np.asarray(g_weight), dtype=torch.float32))
         f = self.final
         E = f.h * f.w * f.c
-        _lib.check(lib.gv_view_pool_fuse_fwd(self._ptr(f), V, self.N, E, E, V * E, self.scheme.data_ptr(), self.G,
+        F_ptr = self._ptr(f) if F is None else F.data_ptr()
+        _lib.check(lib.gv_view_pool_fuse_fwd(F_ptr, V, self.N, E, E, V * E, self.scheme.data_ptr(), self.G,
                                              self.weight.data_ptr(), self.pool_mode, self.empty_fill, None,
                                              self.S.data_ptr(), _lib.GV_F32, _st()), "pool_fuse")
         _lib.check(lib.gv_global_avg_pool(self.S.data_ptr(), self.N, f.h * f.w, f.c, f.c, self.gap.data_ptr(),
@@ -305,7 +335,13 @@ class TrainGVCNN:
     # -- backward ----------------------------------------------------------------------------------------
     def backward(self):
         """Gradients of the mean CE loss (forward(labels=...) must have run).  Fills self.grads."""
-        lib, V = self.lib, self.V
+        self.backward_head()
+        return self.backward_backbone()
+
+    def backward_head(self, dF=None):
+        """Classifier, GAP, group fusion and view pooling backward.  The descriptor gradient is accumulated into
+        this engine's final tap, or (view-sharded job) into the zeroed tensor dF [N, Vh, h, w, C]."""
+        lib, V = self.lib, self.Vh
         for g in self.grads.values():
             g.zero_()
         for g in self.grad:
@@ -320,9 +356,21 @@ class TrainGVCNN:
         self.dS.zero_()
         _lib.check(lib.gv_global_avg_pool_bwd(self.dgap.data_ptr(), self.N, f.h * f.w, f.c, self.dS.data_ptr(), f.c,
                                               _st()), "gap_bwd")
-        _lib.check(lib.gv_view_pool_fuse_bwd(self._ptr(f), self.dS.data_ptr(), V, self.N, E, E, V * E,
+        F_ptr = self._ptr(f) if self._F is None else self._F.data_ptr()
+        dF_ptr = self._ptr(f, grad=True) if dF is None else dF.data_ptr()
+        _lib.check(lib.gv_view_pool_fuse_bwd(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E,
                                              self.scheme.data_ptr(), self.G, self.weight.data_ptr(), self.pool_mode,
-                                             self._ptr(f, grad=True), _st()), "pool_fuse_bwd")
+                                             dF_ptr, _st()), "pool_fuse_bwd")
+
+    def final_grad(self):
+        """[N, V, h, w, C] view of the gradient buffer of the final tap (allocated on first use)."""
+        f = self.final
+        self._ptr(f, grad=True)
+        return self.view(f, grad=True).view(self.N, self.V, f.h, f.w, f.c)
+
+    def backward_backbone(self):
+        """Backbone backward from the gradient held in the final tap's gradient buffer."""
+        lib, V = self.lib, self.V
         import os
         dbg = bool(os.environ.get("GV_SYNC_DEBUG"))
         for op in reversed(self.plan.ops):

@@ -15,6 +15,23 @@ from . import grouping as G
 from . import model as M
 
 
+def head(stacked, scheme, weight, Wc, bc, labels):
+    """nets/model.py:44-102,163-164 + train.py:145 on a stacked [V,N,h,w,C] tensor (autograd-traceable)."""
+    acc = None
+    for g in range(scheme.shape[0]):
+        idx = np.nonzero(scheme[g])[0]
+        if idx.size:
+            d = torch.amax(stacked[torch.as_tensor(idx)], dim=0)           # even split among ties
+        else:
+            d = torch.ones_like(stacked[0])
+        term = float(weight[g]) * d
+        acc = term if acc is None else acc + term
+    S = acc / float(weight.sum())
+    logits = S.mean(dim=(1, 2)) @ Wc + bc
+    loss = F.cross_entropy(logits, torch.as_tensor(labels, dtype=torch.long))
+    return loss, logits, S
+
+
 def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num_bins=10,
                    raw_tap=None, final_tap=None):
     """inputs [N,V,H,W,3] float32, labels [N] int64.  Returns dict(loss, grads{name: tensor}, scores, scheme,
@@ -39,18 +56,7 @@ def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num
     scheme = G.group_scheme([np.array(scores, dtype=np.float32)], num_group, n_views, num_bins)
     weight = G.group_weight(scheme)
     stacked = torch.stack(finals, dim=0)                                   # [V,N,h,w,C]
-    acc = None
-    for g in range(num_group):
-        idx = np.nonzero(scheme[g])[0]
-        if idx.size:
-            d = torch.amax(stacked[torch.as_tensor(idx)], dim=0)           # even split among ties
-        else:
-            d = torch.ones_like(stacked[0])
-        term = float(weight[g]) * d
-        acc = term if acc is None else acc + term
-    S = acc / float(weight.sum())
-    logits = S.mean(dim=(1, 2)) @ Wc + bc
-    loss = F.cross_entropy(logits, torch.as_tensor(labels, dtype=torch.long))
+    loss, logits, S = head(stacked, scheme, weight, Wc, bc, labels)
     loss.backward()
     grads = {k: v.grad for k, v in Pg.items() if v.requires_grad and v.grad is not None}
     grads[kn], grads[bn] = Wc.grad, bc.grad

@@ -281,3 +281,50 @@ def test_gradient_is_the_directional_derivative_of_the_loss(backbone, size):
     d1, d2 = central(1e-4), central(2e-4)
     deriv = (4 * d1 - d2) / 3
     assert abs(deriv - gnorm) <= 2e-2 * gnorm, (d1, d2, deriv, gnorm)
+
+
+def test_view_sharded_engines_reproduce_the_whole_step():
+    """sharding.ShardedTrainGVCNN's algorithm on ONE device: two engines own views {0,1} and {2,3} (per-view
+    BatchNorm statistics stay inside an engine), the gather along the view axis is a torch.cat, every
+    engine runs the head on the gathered data, takes its slice of dF, and the backbone gradients of the
+    two engines are added — equal to the unsharded engine's step."""
+    backbone, size, N, V, C_, G = "resnet_v2_50", 97, 3, 4, 5, 10
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    P = gv.params.init_backbone_params(full.plan.param_shapes(), seed=5, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, full.raw.c, full.final.c, C_, seed=6, spread_scores=True)
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(DEV)
+    labels = torch.tensor([0, 3, 1])
+    full.forward(x, labels)
+    ref = {k: v.clone() for k, v in full.backward().items()}
+    Vl = V // 2
+    engs = [TrainGVCNN(backbone, N, Vl, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV,
+                       head_views=V, view_offset=r * Vl) for r in range(2)]
+    f = engs[0].final
+    for r, e in enumerate(engs):
+        e.forward_backbone(x[:, r * Vl:(r + 1) * Vl].contiguous())
+    r_all = torch.cat([e.score_partial().view(N, Vl) for e in engs], dim=1).contiguous()
+    F_all = torch.cat([e.view(f).view(N, Vl, f.h, f.w, f.c) for e in engs], dim=1).contiguous()
+    total = None
+    for r, e in enumerate(engs):
+        _, S, logits, loss = e.forward_head(labels, F=F_all, r_img=r_all.reshape(-1))
+        close(loss.cpu(), full.loss.cpu(), 1e-5)
+        assert e.scheme.cpu().tolist() == full.scheme.cpu().tolist()
+        dF = torch.zeros_like(F_all)
+        e.backward_head(dF=dF)
+        e.final_grad().copy_(dF[:, r * Vl:(r + 1) * Vl])
+        g = e.backward_backbone()
+        if total is None:
+            total = {k: v.clone() for k, v in g.items()}
+        else:
+            for k, v in g.items():
+                if k not in e.cls_names:
+                    total[k] += v
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k, r_ in ref.items():
+        scale = float(r_.abs().max())
+        err = float((total[k] - r_).abs().max())
+        if scale < 1e-5 * gmax:
+            assert err < 1e-5 * gmax, k                  # bias in front of a train-mode BN: zero gradient
+        else:
+            assert err < 2e-4 * scale, (k, err, scale)   # same kernels; only atomic summation order differs
