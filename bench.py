@@ -41,9 +41,10 @@ MATH = {"f32": ("conv_igemm_f32", PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 
         "f16": ("conv_igemm_lp<f16>", PEAK_BF16_MFMA_TFLOPS, "fp16 activations/filters in HBM, v_mfma_f32_32x32x16_f16, fp32 accumulate + epilogue")}
 V, H, W, G, C = 12, 224, 224, 7, 10             # configs[1]; ModelNet10 -> 10 classes
 BACKBONE = "inception_v3"
-# other BASELINE.json configs, fp32 forward variants (parity-test cases; not the bench line)
-PRESETS = {"c2": ("inception_v3", 12, 224, 7, 10), "c4": ("resnet_v2_50", 12, 224, 10, 40),
-           "c5": ("inception_v3", 20, 299, 10, 40)}
+# other BASELINE.json configs, forward pass in the dtype the config names (parity-test cases; not the bench line)
+PRESETS = {"c2": ("inception_v3", 12, 224, 7, 10), "c3": ("inception_v3", 12, 224, 7, 40),
+           "c4": ("resnet_v2_50", 12, 224, 10, 40), "c5": ("inception_v3", 20, 299, 10, 40)}
+PRESET_STORAGE = {"c2": "f32", "c3": "bf16", "c4": "bf16", "c5": "f16"}      # the dtype each config names
 
 
 def parse():
@@ -64,10 +65,12 @@ def parse():
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
     ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
-    ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f16"],
-                    help="activation/filter storage type; f32 is BASELINE.json configs[1] (the bench line), bf16/f16 are "
-                         "the dtypes of configs[2..4]")
+    ap.add_argument("--storage", default=None, choices=["f32", "bf16", "f16"],
+                    help="activation/filter storage type (default: the preset's own: c2 f32 = the bench line, "
+                         "c3/c4 bf16, c5 f16; forward only)")
     a = ap.parse_args()
+    if a.storage is None:
+        a.storage = PRESET_STORAGE[a.preset]
     if a.storage != "f32":
         a.math = a.storage
     return a

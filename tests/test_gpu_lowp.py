@@ -364,3 +364,35 @@ def test_lp_pooled_branch_commutes_with_the_1x1_conv(ty):
     assert (y2d.float().cpu().numpy()[..., couts[1]:] < 0).any()
     assert (y2d.float().cpu().numpy()[..., :couts[1]] >= 0).all()
     close(out.float().cpu().numpy(), ref_pooled, 2 * ulp, extra=2 * ulp)
+
+
+@pytest.mark.parametrize("backbone,V,size,G,ty", [("resnet_v2_50", 12, 224, 10, "bf16"),      # configs[3]
+                                                  ("inception_v3", 20, 299, 10, "f16"),      # configs[4]
+                                                  ("inception_v3", 12, 224, 7, "bf16")])     # configs[2] (forward)
+def test_lp_baseline_configs_at_full_size(backbone, V, size, G, ty):
+    """BASELINE.json configs[2..4] at their real geometry and dtype: one image of the batch through the fp32 CPU
+    oracle backbone (bound as in test_lp_gvcnn_vs_fp32_oracle), the oracle grouping head on the device
+    descriptors (the head adds one rounding of S), and the size-independent weight identity."""
+    code, td, ulp = TYPES[ty]
+    N, C_ = 2, 40
+    # num_bins = G: with the reference's literal 10 bins a score >= G/10 is an IndexError (model.py:23)
+    eng = gv.GVCNN(backbone, N, V, size, size, C_, G, device=DEV, storage=ty, num_bins=G)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    eng.plan.bind(P)
+    eng.set_head(Hd)
+    x = torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(5)) - 0.5
+    scores, S, logits = eng.forward(x.to(DEV))
+    F = eng.final_view_descriptors().clone()
+    assert tuple(F.shape[2:]) == ((8, 8, 2048) if size == 299 else ((7, 7, 2048) if backbone == "resnet_v2_50" else (5, 5, 2048)))
+    assert float(eng.weight.sum()) == G + V and torch.isfinite(logits).all()
+    b = 7
+    ep = OM.run_backbone(backbone, x.reshape(N * V, size, size, 3)[b:b + 1], P)
+    bound = 3e-2 if ty == "bf16" else 4e-3
+    got = F.reshape(N * V, *F.shape[2:])[b].float().cpu().numpy()
+    assert rel_l2(got, ep[eng.plan.final_tap][0].numpy()) < bound
+    oS, oL = OG.grouping_head([F[:, v].float().cpu().numpy() for v in range(V)], eng.scheme.cpu().numpy(),
+                              eng.weight.cpu().numpy(), Hd["dense_%d/kernel" % V].numpy(),
+                              Hd["dense_%d/bias" % V].numpy())
+    close(S.float().cpu().numpy(), oS, ulp)
+    assert rel_l2(logits.cpu().numpy(), oL) < 2 * ulp
