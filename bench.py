@@ -95,9 +95,21 @@ def roofline(eng, x, math, iters=5):
             worst = (op["name"], ms, tf)
     achieved = flops / (t_ms * 1e-3) / 1e12
     kname, peak, how = MATH[math]
+    # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE /
+    # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh) — fp32 storage only
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_h_traffic_pmc.json")
+    if math in ("f32", "bf16x3", "bf16x2", "bf16x1") and os.path.exists(tpath):
+        try:
+            traffic = round(json.load(open(tpath))["conv_hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
+    alg_bytes = sum(op["bytes"] for op in plan.ops if op["kind"] == "conv") / n
     return {"bound": "mfma", "kernel": "%s<*> (%d launches/step)" % (kname, n), "math": how,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_note": "HBM bytes per conv launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/r1_h_traffic_pmc.json)",
+            "algorithmic_bytes_per_launch": round(alg_bytes),
             "flops_per_step": flops, "avg_launch_us": round(t_ms * 1e3 / n, 2),
             "conv_ms_per_step": round(t_ms, 3),
             "longest_launch": {"name": worst[0], "ms": round(worst[1], 4), "tflops": round(worst[2], 2)}}
