@@ -90,6 +90,7 @@ TUNING = {
     "gv_conv2d_set_tile_override": (None, [C.c_int]),
     "gv_conv2d_set_debug": (None, [C.c_int]),
     "gv_conv2d_num_tile_cfgs": (C.c_int, [C.c_int]),
+    "gv_conv2d_wgrad_set_v1": (None, [C.c_int]),
 }
 
 _lib = None

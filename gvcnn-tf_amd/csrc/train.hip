@@ -471,6 +471,234 @@ inline unsigned grid_for(int64_t total) {
     return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
+
+// Filter gradient, second generation: workgroup tile (64*TI) input channels x (64*TO) output channels for one
+// filter tap, 2x2 waves of TI x TO MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32; the k axis of this GEMM is
+// the PIXEL axis, and pixel-major LDS rows are exactly the k-major operand image this instruction wants:
+// lane (i, h) reads element [pixel k + h][channel i], 32 consecutive dwords per half-wave).  16 pixels per
+// step, LDS double buffered, the next step's global loads are issued before this step's MFMAs, one barrier
+// per step.  Pixel slices (blockIdx.y) are combined with fp32 atomics.
+template <int TI, int TO>
+__global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__ x, int x_ld,
+                                                       const float* __restrict__ dz, int dz_ld, int nb, int ih,
+                                                       int iw, int cin, int kh, int kw, int stride, int pad_t,
+                                                       int pad_l, int oh, int ow, int cout, int64_t M,
+                                                       int64_t m_per_block, float* __restrict__ dw) {
+    constexpr int PT = 16, BI = 64 * TI, BO = 64 * TO;
+    constexpr int XV = PT * BI / 4 / 256, ZV = PT * BO / 4 / 256;      // float4 loads per thread and step
+    __shared__ __attribute__((aligned(16))) float sX[2][PT][BI];
+    __shared__ __attribute__((aligned(16))) float sZ[2][PT][BO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int ntile_co = (cout + BO - 1) / BO, ntile_ci = (cin + BI - 1) / BI;
+    int b = blockIdx.x;
+    const int tco = b % ntile_co; b /= ntile_co;
+    const int tci = b % ntile_ci; b /= ntile_ci;
+    const int tap = b;
+    const int fr = tap / kw, fs = tap - fr * kw;
+    const int ci0 = tci * BI, co0 = tco * BO;
+    const int64_t m0 = (int64_t)blockIdx.y * m_per_block;
+    const int64_t m1 = m0 + m_per_block < M ? m0 + m_per_block : M;
+    f32x16 acc[TI][TO];
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+#pragma unroll
+        for (int u = 0; u < TO; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    const int ohow = oh * ow;
+    const bool xvec = (x_ld & 3) == 0 && (cin & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
+    const bool zvec = (dz_ld & 3) == 0 && (cout & 3) == 0 && ((((uintptr_t)dz) & 15u) == 0);
+    f32x4 xr[XV], zr[ZV];
+    auto load = [&](int64_t mt) {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            const int idx = tid + j * 256;
+            const int p = idx / (BI / 4), c = ci0 + (idx % (BI / 4)) * 4;
+            const int64_t m = mt + p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m1 && c < cin) {
+                const int n = (int)(m / ohow);
+                const int rem = (int)(m - (int64_t)n * ohow);
+                const int oy = rem / ow, ox = rem - oy * ow;
+                const int iy = oy * stride + fr - pad_t, ix = ox * stride + fs - pad_l;
+                if ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) {
+                    const float* xp = x + (((size_t)n * ih + iy) * iw + ix) * x_ld + c;
+                    if (xvec) {
+                        v = *reinterpret_cast<const f32x4*>(xp);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (c + e < cin) v[e] = xp[e];
+                    }
+                }
+            }
+            xr[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < ZV; ++j) {
+            const int idx = tid + j * 256;
+            const int p = idx / (BO / 4), c = co0 + (idx % (BO / 4)) * 4;
+            const int64_t m = mt + p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m1 && c < cout) {
+                const float* zp = dz + (size_t)m * dz_ld + c;
+                if (zvec) {
+                    v = *reinterpret_cast<const f32x4*>(zp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c + e < cout) v[e] = zp[e];
+                }
+            }
+            zr[j] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            const int idx = tid + j * 256;
+            *reinterpret_cast<f32x4*>(&sX[buf][idx / (BI / 4)][(idx % (BI / 4)) * 4]) = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ZV; ++j) {
+            const int idx = tid + j * 256;
+            *reinterpret_cast<f32x4*>(&sZ[buf][idx / (BO / 4)][(idx % (BO / 4)) * 4]) = zr[j];
+        }
+    };
+    load(m0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    const int li = lane & 31, lh = lane >> 5;
+    for (int64_t mt = m0; mt < m1; mt += PT) {
+        const bool more = mt + PT < m1;
+        if (more) load(mt + PT);
+#pragma unroll
+        for (int k = 0; k < PT; k += 2) {
+            float av[TI], bv[TO];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) av[t] = sX[buf][k + lh][(wi * TI + t) * 32 + li];
+#pragma unroll
+            for (int u = 0; u < TO; ++u) bv[u] = sZ[buf][k + lh][(wj * TO + u) * 32 + li];
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+#pragma unroll
+                for (int u = 0; u < TO; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int u = 0; u < TO; ++u) {
+        const int col = co0 + (wj * TO + u) * 32 + li;
+        if (col >= cout) continue;
+#pragma unroll
+        for (int t = 0; t < TI; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (wi * TI + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci < cin) atomicAdd(&dw[((size_t)tap * cin + ci) * cout + col], acc[t][u][r]);
+            }
+    }
+}
+
+
+// Filter gradient of the few-channel layers (the stems: kh*kw*cin <= 288 im2col rows).  The tap-per-workgroup
+// kernels above re-read x and dz once per filter tap and waste most of a 64-row tile on 3 or 32 input channels
+// (Conv2d_1a/2a/2b: 12 of the 41 ms of filter gradients per step).  Here one WAVE owns a contiguous pixel range and
+// ALL im2col rows rho = tap*cin + ci (NRT tiles of 32 rows) x one 32-column tile of cout; the MFMA operands are
+// fetched straight from global memory — the k axis of this GEMM is the pixel axis, so lane (i, h) needs
+// x[pixel k+h shifted by tap(i)][ci(i)] and dz[pixel k+h][co i]: 128-byte coalesced rows, no LDS, no barrier.
+// Loads run U pixel pairs ahead of the MFMAs that consume them.  Waves are combined with fp32 atomics.
+template <int NRT, int U>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const float* __restrict__ x, int x_ld,
+                                                             const float* __restrict__ dz, int dz_ld, int ih, int iw,
+                                                             int cin, int kh, int kw, int stride, int pad_t,
+                                                             int pad_l, int oh, int ow, int cout, int64_t M,
+                                                             int64_t m_per_wave, float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    // column tile fastest: the workgroups that share a pixel range (and re-read the same x) run side by side
+    const int nct = (cout + 31) / 32;
+    const int64_t w = (int64_t)(blockIdx.x / nct) * 4 + (threadIdx.x >> 6);
+    const int co = (blockIdx.x % nct) * 32 + li;
+    const int64_t m0 = w * m_per_wave;
+    const int64_t m1 = m0 + m_per_wave < M ? m0 + m_per_wave : M;
+    if (m0 >= M) return;
+    const int R = kh * kw * cin;
+    int fr[NRT], fs[NRT], delta[NRT];
+    bool rv[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+        const int rho = t * 32 + li;
+        rv[t] = rho < R;
+        const int tap = rv[t] ? rho / cin : 0;
+        const int ci = rv[t] ? rho - tap * cin : 0;
+        fr[t] = tap / kw;
+        fs[t] = tap - fr[t] * kw;
+        delta[t] = (fr[t] * iw + fs[t]) * x_ld + ci;
+    }
+    f32x16 acc[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // this lane's pixel of the current pair: m = m0 + 2*pair + lh
+    int64_t m = m0 + lh;
+    int n = (int)(m / ((int64_t)oh * ow));
+    int rem = (int)(m - (int64_t)n * oh * ow);
+    int oy = rem / ow, ox = rem - oy * ow;
+    float av[2][U][NRT], bv[2][U];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool pok = m < m1;
+            const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
+            const int base = ((n * ih + iy0) * iw + ix0) * x_ld;          // < 2^31 elements (checked by the launcher)
+            // (no branch around the loads: a join would force vmcnt(0) and serialise the prefetch)
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                const bool ok = pok && rv[t] && (unsigned)(iy0 + fr[t]) < (unsigned)ih &&
+                                (unsigned)(ix0 + fs[t]) < (unsigned)iw;
+                av[s][u][t] = ok ? x[base + delta[t]] : 0.f;
+            }
+            bv[s][u] = (pok && co < cout) ? dz[m * dz_ld + co] : 0.f;
+            m += 2;
+            ox += 2;
+            while (ox >= ow) {
+                ox -= ow;
+                if (++oy == oh) { oy = 0; ++n; }
+            }
+        }
+    };
+    auto consume = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NRT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][u][t], bv[s][u], acc[t], 0, 0, 0);
+    };
+    const int64_t pairs = (m1 - m0 + 1) / 2;
+    const int64_t stages = (pairs + U - 1) / U;
+    fetch(0);
+    for (int64_t st = 0; st + 1 < stages; st += 2) {     // two stages per trip: static register sets
+        fetch(1);
+        consume(0);
+        if (st + 2 < stages) fetch(0);
+        consume(1);
+    }
+    if (stages & 1) consume(0);
+    if (co < cout) {
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (rho < R) atomicAdd(&dw[(size_t)rho * cout + co], acc[t][r]);
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
@@ -617,12 +845,64 @@ extern "C" int gv_sgd_momentum(float* w, const float* g, float* m, int64_t n, fl
     return GV_OK;
 }
 
+static int g_wgrad_v1 = 0;
+extern "C" void gv_conv2d_wgrad_set_v1(int on) { g_wgrad_v1 = on; }
+
 extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const float* dz, int32_t dz_ld,
                                float* dw_hwio, void* stream) {
     if (!d || !x || !dz || !dw_hwio) return GV_E_BADARG;
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
     if (d->nb <= 0 || d->cin <= 0 || d->cout <= 0 || dz_ld < d->cout || d->x_ld < d->cin) return GV_E_BADARG;
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
+    const int R = d->kh * d->kw * d->cin;
+    if (!g_wgrad_v1 && R <= 288 && d->cin <= 32 && M >= 200000 &&
+        (int64_t)d->nb * d->ih * d->iw * d->x_ld < 0x7fffffffll) {
+        // few-channel stem layers: all taps in one wave, operands straight from global memory
+        const int nrt = (R + 31) / 32;
+        const int64_t waves = 256 * 4 * (nrt == 1 ? 6 : (nrt <= 5 ? 2 : 1));
+        int64_t per = (M + waves - 1) / waves;
+        per = (per + 1) / 2 * 2;
+        const int64_t nw = (M + per - 1) / per;
+        const dim3 grid((unsigned)(((nw + 3) / 4) * ((d->cout + 31) / 32)));
+        hipStream_t st = (hipStream_t)stream;
+#define GV_WGRAD_D(NRT, U)                                                                                          \
+        hipLaunchKernelGGL((conv_wgrad_direct_f32<NRT, U>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->ih,     \
+                           d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per,  \
+                           dw_hwio)
+        if (nrt == 1) GV_WGRAD_D(1, 8);
+        else if (nrt <= 5) GV_WGRAD_D(5, 4);
+        else GV_WGRAD_D(9, 8);
+#undef GV_WGRAD_D
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
+    if (!g_wgrad_v1) {
+        // 128 channels on a side only where that wastes no more rows than 64-wide tiles would
+        const int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
+        const int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
+        const int tiles = d->kh * d->kw * ((d->cin + 64 * ti - 1) / (64 * ti)) * ((d->cout + 64 * to - 1) / (64 * to));
+        int64_t splits = (2048 + tiles - 1) / tiles;            // ~2k workgroups: 256 CUs x 2-4 resident, 2+ rounds
+        const int64_t max_splits = (M + 511) / 512;             // at least 512 pixels per workgroup
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > 65535) splits = 65535;
+        int64_t per = (M + splits - 1) / splits;
+        per = (per + 15) / 16 * 16;
+        splits = (M + per - 1) / per;
+        const dim3 grid((unsigned)tiles, (unsigned)splits);
+        hipStream_t st = (hipStream_t)stream;
+#define GV_WGRAD2(TI, TO)                                                                                          \
+        hipLaunchKernelGGL((conv_wgrad2_f32<TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih,   \
+                           d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, \
+                           dw_hwio)
+        if (ti == 2 && to == 2) GV_WGRAD2(2, 2);
+        else if (ti == 2) GV_WGRAD2(2, 1);
+        else if (to == 2) GV_WGRAD2(1, 2);
+        else GV_WGRAD2(1, 1);
+#undef GV_WGRAD2
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     const int tiles = d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
     int64_t splits = (4096 + tiles - 1) / tiles;                // ~4k workgroups in flight
     const int64_t max_splits = (M + 255) / 256;                 // at least 256 pixels per workgroup
