@@ -247,6 +247,11 @@ class BackbonePlan:
                              bytes=float(self.esz) * (x.npix * x.c + out.npix * out.c)))
         return out
 
+    def pooled_branch(self, x, conv_scope, pool_name, depth, dst, norm):
+        """avg_pool2d 3x3/1 SAME -> conv2d 1x1 -> BN -> ReLU in the reference order (un-fused plans)."""
+        t = self.pool(x, 3, 1, "SAME", _lib.GV_POOL_AVG, name=pool_name)
+        return self.conv(t, conv_scope, depth, 1, out=dst, norm=norm, relu=True)
+
     def bn_relu(self, x, bn_scope, eps, name):
         """Stand-alone slim.batch_norm(activation_fn=relu) (resnet_v2.py:75, first unit only)."""
         out = self.new_tensor(x.nb, x.h, x.w, x.c)
@@ -577,8 +582,8 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
             if pooled is not None:
                 s, depth, dst = pooled
                 with b.lane(2):
-                    t = b.pool(x, 3, 1, "SAME", AVG, name=s + "Branch_3/AvgPool_0a_3x3")
-                    conv(t, s + "Branch_3/Conv2d_0b_1x1", depth, 1, out=dst)
+                    b.pooled_branch(x, scope + "/" + s + "Branch_3/Conv2d_0b_1x1", s + "Branch_3/AvgPool_0a_3x3",
+                                    depth, dst, BN)
             return outs
         pb = None
         if pooled is not None:

@@ -67,6 +67,18 @@ class TrainPlan(backbones.BackbonePlan):
                 outs.append(t)
         return outs
 
+    def pooled_branch(self, x, conv_scope, pool_name, depth, dst, norm):
+        """The pooled Inception branch as BN(avgpool(conv1x1(x))): a 1x1 convolution commutes with the average,
+        so the pool (forward AND backward) moves `depth` instead of x.c channels; the train-mode BatchNorm stays
+        after the pool, i.e. its batch statistics are those of the reference's tensor."""
+        z = self.new_tensor(x.nb, x.h, x.w, depth)
+        self.ops.append(dict(kind="conv", name=conv_scope, x=x, y=z, res=None, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+                             bias=None, flops=2.0 * x.npix * depth * x.c))
+        p = self.pool(z, 3, 1, "SAME", _lib.GV_POOL_AVG, name=pool_name)
+        self.ops.append(dict(kind="bn", name=conv_scope + "/BatchNorm", x=p, y=dst, eps=norm[1], has_gamma=norm[2],
+                             relu=True))
+        return dst
+
     def pool(self, x, k, stride, padding, mode, out=None, name="pool"):
         oh, pad_t = _out_size(x.h, k, stride, padding)
         ow, pad_l = _out_size(x.w, k, stride, padding)
