@@ -229,11 +229,40 @@ class TrainGVCNN:
         if not dgrad:
             return _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"], op["pad_t"],
                                  op["pad_l"], y.h, y.w, y.c, y.ld, op["res"].ld if op["res"] is not None else 0,
-                                 0, 0, _lib.GV_F32, 0, 0, self.math_mode, 0)
+                                 0, 0, _lib.GV_F32, 0, op.get("tile_f", 0), self.math_mode, 0)
         # data gradient: dX = conv(dilate(dZ, stride), flip(W)^T), pad' = k-1-pad, accumulate into dX
         return _lib.ConvDesc(y.nb, y.h, y.w, y.c, y.ld, op["kh"], op["kw"], 1, op["kh"] - 1 - op["pad_t"],
-                             op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, _lib.GV_F32, 0, 0,
-                             self.math_mode, op["stride"] if op["stride"] > 1 else 0)
+                             op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, _lib.GV_F32, 0,
+                             op.get("tile_d", 0), self.math_mode, op["stride"] if op["stride"] > 1 else 0)
+
+    def autotune(self, iters=2):
+        """Measure, per convolution, the fastest tile configuration of the forward launch and of the data-gradient
+        launch (hipEvents on the launch stream, this engine's own buffers; gradients buffers are scratch here).
+        A speed choice only.  forward() must have run once (buffers and packed filters exist)."""
+        lib = self.lib
+        if self._packed_dirty:
+            self.repack()
+        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode)
+        ms = C.c_float(0)
+        for op in self.plan.ops:
+            if op["kind"] != "conv":
+                continue
+            x, y = op["x"], op["y"]
+            jobs = [("tile_f", False, self._ptr(x), op["w_fwd"], self._ptr(y))]
+            if x.vbuf >= 0:
+                jobs.append(("tile_d", True, self._ptr(y, True), op["w_dgrad"], self._ptr(x, True)))
+            for key, dgrad, src, w, dst in jobs:
+                op[key] = 0
+                best, best_ms = 0, float("inf")
+                for t in range(ncfg):
+                    op[key] = t + 1
+                    d = self._conv_desc(op, dgrad=dgrad)
+                    d.res_ld = 0
+                    rc = lib.gv_conv2d_time(C.byref(d), src, w.data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(),
+                                            dst, iters, C.byref(ms), _st())
+                    if rc == 0 and ms.value < best_ms:
+                        best, best_ms = t + 1, ms.value
+                op[key] = best
 
     def repack(self):
         """Refresh the packed filters from the trainable HWIO variables (after an optimizer step)."""

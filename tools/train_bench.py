@@ -17,7 +17,11 @@ eng = TrainGVCNN(a.backbone, a.shapes, a.views, a.size, a.size, 40, 10, device="
 x = (torch.rand(a.shapes, a.views, a.size, a.size, 3) - 0.5).cuda()
 labels = torch.randint(0, 40, (a.shapes,))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+ap_tune = os.environ.get("GV_NO_TUNE") is None
 eng.train_step(x, labels, lr=1e-6)
+if ap_tune:
+    eng.autotune()              # untimed: per-launch tile choice (speed only)
+    eng.train_step(x, labels, lr=1e-6)
 torch.cuda.synchronize()
 tf = tb = to = 0.0
 for _ in range(a.steps):
