@@ -59,6 +59,7 @@ SIGNATURES = {
     "gv_view_pool_fuse_fwd": (C.c_int, [_P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _F, _P, _P, _I, _P]),
     "gv_dense_fwd": (C.c_int, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "gv_bn_stats_grouped": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_bn_update_moving": (C.c_int, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "gv_scale_shift_act_grouped": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P]),
     "gv_bn_relu_bwd_grouped": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P,
                                          _P, _P]),

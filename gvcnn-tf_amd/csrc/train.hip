@@ -699,6 +699,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const float* __rest
     }
 }
 
+
+__global__ void bn_update_moving(const float* __restrict__ mean, const float* __restrict__ var,
+                                 const int* __restrict__ counts, int G, int c, float decay,
+                                 float* __restrict__ mm, float* __restrict__ mv) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float m = mm[ch], v = mv[ch];
+    for (int g = 0; g < G; ++g) {                         // one update per view graph copy, in view order
+        const float n = (float)counts[g];
+        const float unb = n > 1.f ? n / (n - 1.f) : 1.f;
+        m = __fadd_rn(__fmul_rn(m, decay), __fmul_rn(mean[(size_t)g * c + ch], 1.f - decay));
+        v = __fadd_rn(__fmul_rn(v, decay), __fmul_rn(__fmul_rn(var[(size_t)g * c + ch], unb), 1.f - decay));
+    }
+    mm[ch] = m;
+    mv[ch] = v;
+}
+
 }  // namespace
 
 extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
@@ -841,6 +858,15 @@ extern "C" int gv_sgd_momentum(float* w, const float* g, float* m, int64_t n, fl
     if (!w || !g || !m || n <= 0) return GV_E_BADARG;
     hipLaunchKernelGGL(sgd_momentum_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, g,
                        m, n, lr, mu, wd);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_bn_update_moving(const float* mean, const float* var, const int32_t* counts, int32_t num_groups,
+                                   int32_t c, float decay, float* moving_mean, float* moving_var, void* stream) {
+    if (!mean || !var || !counts || !moving_mean || !moving_var || num_groups <= 0 || c <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(bn_update_moving, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, var,
+                       counts, num_groups, c, decay, moving_mean, moving_var);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }

@@ -465,8 +465,25 @@ class TrainGVCNN:
                                                 g.numel(), float(lr), float(mu), float(wd), _st()), "sgd")
         self._packed_dirty = True
 
-    def train_step(self, views, labels, lr=1e-3, mu=0.9, weight_decay=0.0):
+    def update_moving_averages(self, decay=None):
+        """The batch-norm UPDATE_OPS of train.py:178-186: V sequential moving-average updates per BN layer from the
+        batch statistics of the last forward.  decay defaults to the backbone's arg-scope value."""
+        if decay is None:
+            decay = 0.9997 if self.backbone == "inception_v3" else 0.997
+        for op in self.plan.ops:
+            if op["kind"] != "bn":
+                continue
+            st, x = op["stat"], op["x"]
+            _lib.check(self.lib.gv_bn_update_moving(st["mean"].data_ptr(), st["var"].data_ptr(),
+                                                    self._count(x.h * x.w).data_ptr(), self.V, x.c, float(decay),
+                                                    self.params[op["name"] + "/moving_mean"].data_ptr(),
+                                                    self.params[op["name"] + "/moving_variance"].data_ptr(), _st()),
+                       "bn_update_moving")
+
+    def train_step(self, views, labels, lr=1e-3, mu=0.9, weight_decay=0.0, update_moving=True):
         self.forward(views, labels, check=False)
         self.backward()
+        if update_moving:
+            self.update_moving_averages()
         self.apply_momentum(lr, mu, weight_decay)
         return self.loss

@@ -219,6 +219,13 @@ int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32
                         const int32_t* counts, const float* gamma, const float* beta, float eps,
                         double* accum, float* mean, float* var, float* inv, float* scale, float* shift,
                         void* stream);
+/* Moving-average update of slim.batch_norm in training (the UPDATE_OPS train.py:178-186 groups with the
+ * optimizer step), one update per view graph copy, applied in view order:
+ *   moving_mean = moving_mean*decay + mean[g]*(1-decay)
+ *   moving_var  = moving_var *decay + var[g]*n/(n-1)*(1-decay)      (fused batch norm: unbiased estimate)
+ * for g = 0..num_groups-1, n = counts[g].  decay: inception_utils.py:32 (0.9997), resnet_utils.py:199 (0.997). */
+int gv_bn_update_moving(const float* mean, const float* var, const int32_t* counts, int32_t num_groups,
+                        int32_t c, float decay, float* moving_mean, float* moving_var, void* stream);
 /* y = act(x*scale[g][c] + shift[g][c]), g = image % num_groups. */
 int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
                                const float* scale, const float* shift, int32_t num_groups, int32_t relu,

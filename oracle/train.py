@@ -63,3 +63,18 @@ def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num
     return dict(finals=[f.detach() for f in finals], final_grads=[f.grad for f in finals],
                 loss=float(loss.detach()), grads=grads, scores=scores, scheme=scheme, weight=weight,
                 logits=logits.detach().numpy(), shape_descriptor=S.detach().numpy())
+
+
+def moving_average_update(moving_mean, moving_var, means, variances, counts, decay):
+    """slim.batch_norm UPDATE_OPS (train.py:178-186), one per view graph copy in view order; fused batch norm
+    feeds the UNBIASED batch variance into the moving variance (SURVEY a-note 4).  numpy fp32."""
+    mm = np.asarray(moving_mean, np.float32).copy()
+    mv = np.asarray(moving_var, np.float32).copy()
+    d = np.float32(decay)
+    one = np.float32(1.0)
+    for g in range(len(means)):
+        n = np.float32(counts[g])
+        unb = n / (n - one) if n > 1 else one
+        mm = (mm * d + np.asarray(means[g], np.float32) * (one - d)).astype(np.float32)
+        mv = (mv * d + (np.asarray(variances[g], np.float32) * unb).astype(np.float32) * (one - d)).astype(np.float32)
+    return mm, mv

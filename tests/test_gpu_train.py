@@ -328,3 +328,34 @@ def test_view_sharded_engines_reproduce_the_whole_step():
             assert err < 1e-5 * gmax, k                  # bias in front of a train-mode BN: zero gradient
         else:
             assert err < 2e-4 * scale, (k, err, scale)   # same kernels; only atomic summation order differs
+
+
+def test_bn_moving_average_update():
+    """UPDATE_OPS of train.py:178-186: V sequential updates with the unbiased variance; and end to end through
+    TrainGVCNN (moving statistics after one step == oracle formula on the engine's own batch statistics)."""
+    from oracle import train as OT
+    g = torch.Generator().manual_seed(4)
+    V, c = 5, 70
+    mean, var = torch.randn(V, c, generator=g), torch.rand(V, c, generator=g) + 0.1
+    mm, mv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    counts = torch.tensor([12, 12, 7, 1, 30], dtype=torch.int32)
+    md, vd, cd, mmd, mvd = mean.to(DEV), var.to(DEV), counts.to(DEV), mm.to(DEV), mv.to(DEV)
+    _lib.check(lib().gv_bn_update_moving(md.data_ptr(), vd.data_ptr(), cd.data_ptr(), V, c, 0.997, mmd.data_ptr(),
+                                         mvd.data_ptr(), st()), "bn_update_moving")
+    omm, omv = OT.moving_average_update(mm.numpy(), mv.numpy(), mean.numpy(), var.numpy(), counts.numpy(), 0.997)
+    np.testing.assert_allclose(mmd.cpu().numpy(), omm, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mvd.cpu().numpy(), omv, rtol=1e-6, atol=1e-7)
+    # through the engine
+    eng = TrainGVCNN("resnet_v2_50", 2, 2, 64, 64, 5, 10, device=DEV)
+    x = (torch.rand(2, 2, 64, 64, 3, generator=g) - 0.5).to(DEV)
+    name = "resnet_v2_50/block1/unit_1/bottleneck_v2/preact"
+    mm0 = eng.params[name + "/moving_mean"].clone()
+    mv0 = eng.params[name + "/moving_variance"].clone()
+    eng.train_step(x, torch.tensor([1, 2]), lr=0.0)
+    op = [o for o in eng.plan.ops if o["kind"] == "bn" and o["name"] == name][0]
+    n = 2 * op["x"].h * op["x"].w
+    omm, omv = OT.moving_average_update(mm0.cpu().numpy(), mv0.cpu().numpy(), op["stat"]["mean"].cpu().numpy(),
+                                        op["stat"]["var"].cpu().numpy(), [n, n], 0.997)
+    np.testing.assert_allclose(eng.params[name + "/moving_mean"].cpu().numpy(), omm, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(eng.params[name + "/moving_variance"].cpu().numpy(), omv, rtol=1e-6, atol=1e-7)
+    assert not torch.equal(eng.params[name + "/moving_mean"], mm0)
