@@ -15,6 +15,7 @@ GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
 GV_POOL_MAX, GV_POOL_AVG, GV_POOL_AVG_RELU = 0, 1, 2
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
+GV_WEIGHT_COUNT, GV_WEIGHT_MEAN_SCORE = 0, 1
 GV_ABI_VERSION = 1
 
 
@@ -57,6 +58,9 @@ SIGNATURES = {
     "gv_group_assign": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "gv_group_weight": (C.c_int, [_P, _I, _I, _P, _P]),
     "gv_view_pool_fuse_fwd": (C.c_int, [_P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _F, _P, _P, _I, _P]),
+    "gv_view_score_per_shape": (C.c_int, [_P, _I, _P, _P]),
+    "gv_group_assign_per_shape": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gv_view_pool_fuse_fwd_per_shape": (C.c_int, [_P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _F, _P, _P, _I, _P]),
     "gv_dense_fwd": (C.c_int, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "gv_bn_stats_grouped": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gv_bn_update_moving": (C.c_int, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),

@@ -361,7 +361,8 @@ __global__ void pack_filter_bf16s(const float* __restrict__ w, int K, int ktiles
 
 struct TileCfg { int bm, bn; };
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32},
-                              {256, 128}, {128, 256}, {256, 64}};   // the last three: 8 waves
+                              {256, 128}, {128, 256}, {256, 64},    // these three: 8 waves
+                              {128, 192}, {64, 192}};               // one n-tile for the many 192-channel layers
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int WM, int WN, int TM, int TN, int NP>
@@ -404,6 +405,8 @@ int launch_np(int cfg, const ConvArgs& a, bool generic, hipStream_t st) {
         case 6: return launch_cfg<4, 2, 2, 2, NP>(a, generic, st);
         case 7: return launch_cfg<2, 4, 2, 2, NP>(a, generic, st);
         case 8: return launch_cfg<4, 2, 2, 1, NP>(a, generic, st);
+        case 9: return launch_cfg<2, 2, 2, 3, NP>(a, generic, st);
+        case 10: return launch_cfg<2, 2, 1, 3, NP>(a, generic, st);
     }
     return GV_E_UNSUPPORTED;
 }

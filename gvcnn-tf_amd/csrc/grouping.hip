@@ -124,11 +124,14 @@ template <int VEC>
 __global__ __launch_bounds__(256) void view_pool_fuse_f32(
     const float* __restrict__ F, int V, int N, int64_t E, int64_t view_stride, int64_t shape_stride,
     const int* __restrict__ scheme, int G, const float* __restrict__ weight, int mode, float fill,
-    float* __restrict__ D, float* __restrict__ S) {
+    float* __restrict__ D, float* __restrict__ S, int64_t scheme_stride, int64_t weight_stride) {
     using Vt = typename std::conditional<VEC == 4, f32x4, float>::type;
     __shared__ unsigned long long s_mask[64];
     __shared__ float s_w[64];
     __shared__ float s_wsum;
+    const int n = blockIdx.y;                       // one shape per grid row: its own scheme when strides != 0
+    scheme += (size_t)n * scheme_stride;
+    weight += (size_t)n * weight_stride;
     for (int g = threadIdx.x; g < G; g += 256) {
         unsigned long long m = 0;
         for (int v = 0; v < V; ++v)
@@ -145,11 +148,9 @@ __global__ __launch_bounds__(256) void view_pool_fuse_f32(
     __syncthreads();
     const float wsum = s_wsum;
     const int64_t eg = E / VEC;
-    const int64_t total = (int64_t)N * eg;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < eg;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx / eg);
-        const int64_t e = (idx - (int64_t)n * eg) * VEC;
+        const int64_t e = idx * VEC;
         const float* base = F + (size_t)n * shape_stride + e;
         Vt acc;
         if constexpr (VEC == 4) acc = Vt{0.f, 0.f, 0.f, 0.f}; else acc = 0.f;
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(256) void view_pool_fuse_f32(
         if (S) {
             if constexpr (VEC == 4) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = __fdiv_rn(acc[k], wsum);                  // tf.div
+                for (int k = 0; k < 4; ++k) acc[k] = wsum != 0.f ? __fdiv_rn(acc[k], wsum) : 0.f;   // tf.div
             } else {
-                acc = __fdiv_rn(acc, wsum);
+                acc = wsum != 0.f ? __fdiv_rn(acc, wsum) : 0.f;
             }
             *reinterpret_cast<Vt*>(S + (size_t)n * E + e) = acc;
         }
@@ -277,34 +278,120 @@ extern "C" int gv_group_weight(const int32_t* scheme, int32_t num_groups, int32_
     return GV_OK;
 }
 
-extern "C" int gv_view_pool_fuse_fwd(const void* F, int32_t num_views, int32_t num_shapes, int64_t E,
-                                     int64_t view_stride, int64_t shape_stride,
-                                     const int32_t* scheme, int32_t num_groups, const float* weight,
-                                     int32_t mode, float empty_fill, void* D, void* S, int32_t dtype,
-                                     void* stream) {
+static int pool_fuse_launch(const void* F, int32_t num_views, int32_t num_shapes, int64_t E, int64_t view_stride,
+                            int64_t shape_stride, const int32_t* scheme, int32_t num_groups, const float* weight,
+                            int32_t mode, float empty_fill, void* D, void* S, int32_t dtype, void* stream,
+                            int64_t scheme_stride, int64_t weight_stride) {
     if (!F || !scheme || !weight || (!D && !S)) return GV_E_BADARG;
     if (num_views <= 0 || num_shapes <= 0 || E <= 0 || num_groups <= 0 || view_stride < 0 ||
         shape_stride < 0)
         return GV_E_BADARG;
     if (mode != GV_VIEWPOOL_MAX && mode != GV_VIEWPOOL_MEAN) return GV_E_BADARG;
-    if (num_views > 64 || num_groups > 64) return GV_E_UNSUPPORTED;
+    if (num_views > 64 || num_groups > 64 || num_shapes > 65535) return GV_E_UNSUPPORTED;
     if (dtype != GV_F32)
         return gvlp::view_pool_fuse(dtype, F, num_views, num_shapes, E, view_stride, shape_stride, scheme, num_groups,
-                                    weight, mode, empty_fill, D, S, (hipStream_t)stream);
+                                    weight, mode, empty_fill, D, S, (hipStream_t)stream, scheme_stride, weight_stride);
     const bool vec = (E % 4 == 0) && (view_stride % 4 == 0) && (shape_stride % 4 == 0) &&
                      gv_aligned16(F) && (!D || gv_aligned16(D)) && (!S || gv_aligned16(S));
-    const int64_t total = (int64_t)num_shapes * (vec ? E / 4 : E);
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int64_t per_shape = vec ? E / 4 : E;
+    int64_t bx = (per_shape + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const dim3 grid((unsigned)bx, (unsigned)num_shapes);
     hipStream_t st = (hipStream_t)stream;
     if (vec)
-        hipLaunchKernelGGL(view_pool_fuse_f32<4>, dim3((unsigned)blocks), dim3(256), 0, st,
+        hipLaunchKernelGGL(view_pool_fuse_f32<4>, grid, dim3(256), 0, st,
                            (const float*)F, num_views, num_shapes, E, view_stride, shape_stride,
-                           scheme, num_groups, weight, mode, empty_fill, (float*)D, (float*)S);
+                           scheme, num_groups, weight, mode, empty_fill, (float*)D, (float*)S, scheme_stride,
+                           weight_stride);
     else
-        hipLaunchKernelGGL(view_pool_fuse_f32<1>, dim3((unsigned)blocks), dim3(256), 0, st,
+        hipLaunchKernelGGL(view_pool_fuse_f32<1>, grid, dim3(256), 0, st,
                            (const float*)F, num_views, num_shapes, E, view_stride, shape_stride,
-                           scheme, num_groups, weight, mode, empty_fill, (float*)D, (float*)S);
+                           scheme, num_groups, weight, mode, empty_fill, (float*)D, (float*)S, scheme_stride,
+                           weight_stride);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_view_pool_fuse_fwd(const void* F, int32_t num_views, int32_t num_shapes, int64_t E,
+                                     int64_t view_stride, int64_t shape_stride,
+                                     const int32_t* scheme, int32_t num_groups, const float* weight,
+                                     int32_t mode, float empty_fill, void* D, void* S, int32_t dtype,
+                                     void* stream) {
+    return pool_fuse_launch(F, num_views, num_shapes, E, view_stride, shape_stride, scheme, num_groups, weight, mode,
+                            empty_fill, D, S, dtype, stream, 0, 0);
+}
+
+extern "C" int gv_view_pool_fuse_fwd_per_shape(const void* F, int32_t num_views, int32_t num_shapes, int64_t E,
+                                               int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
+                                               int32_t num_groups, const float* weight, int32_t mode,
+                                               float empty_fill, void* D, void* S, int32_t dtype, void* stream) {
+    return pool_fuse_launch(F, num_views, num_shapes, E, view_stride, shape_stride, scheme, num_groups, weight, mode,
+                            empty_fill, D, S, dtype, stream, (int64_t)num_groups * num_views, num_groups);
+}
+
+// sigmoid(log|r|) per image (the paper's per-shape scorer; model.py:147 without the batch mean of :146)
+__global__ void view_score_per_shape_f32(const float* __restrict__ r_img, int nb, float* __restrict__ scores) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const float lg = logf(fabsf(r_img[b]));
+    scores[b] = 1.0f / (1.0f + expf(-lg));
+}
+
+extern "C" int gv_view_score_per_shape(const float* r_img, int32_t nb, float* scores, void* stream) {
+    if (!r_img || !scores || nb <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(view_score_per_shape_f32, dim3((nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, r_img, nb,
+                       scores);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+// one workgroup per shape: binning exactly as group_assign_kernel
+__global__ __launch_bounds__(64) void group_assign_per_shape_kernel(const float* __restrict__ scores, int V, int G,
+                                                                    int num_bins, int weight_mode,
+                                                                    int* __restrict__ gidx, int* __restrict__ scheme,
+                                                                    float* __restrict__ weight,
+                                                                    int* __restrict__ status) {
+    __shared__ int s_gidx[64];
+    __shared__ float s_score[64];
+    const int n = blockIdx.x, t = threadIdx.x;
+    scores += (size_t)n * V;
+    gidx += (size_t)n * V;
+    scheme += (size_t)n * G * V;
+    weight += (size_t)n * G;
+    if (t < V) {
+        const float sc = scores[t];
+        const float prod = __fmul_rn(sc, (float)num_bins);
+        int b = (int)prod;
+        if (sc != sc) { atomicOr(status, 2); b = -1; }
+        else if (b >= G || b < 0 || prod >= 2147483648.0f) { atomicOr(status, 1); if (prod >= 2147483648.0f) b = 0x7fffffff; }
+        s_gidx[t] = b;
+        s_score[t] = sc;
+        gidx[t] = b;
+    }
+    __syncthreads();
+    for (int i = t; i < G * V; i += 64) {
+        const int g = i / V, v = i - g * V;
+        scheme[i] = (s_gidx[v] == g) ? 1 : 0;
+    }
+    for (int g = t; g < G; g += 64) {
+        int cnt = 0;
+        float sum = 0.f;
+        for (int v = 0; v < V; ++v)
+            if (s_gidx[v] == g) { ++cnt; sum = __fadd_rn(sum, s_score[v]); }      // view order: reproducible
+        weight[g] = weight_mode == GV_WEIGHT_COUNT ? (float)(1 + cnt) : (cnt ? __fdiv_rn(sum, (float)cnt) : 0.f);
+    }
+}
+
+extern "C" int gv_group_assign_per_shape(const float* scores, int32_t num_shapes, int32_t num_views,
+                                         int32_t num_groups, int32_t num_bins, int32_t weight_mode, int32_t* gidx,
+                                         int32_t* scheme, float* weight, int32_t* status, void* stream) {
+    if (!scores || !gidx || !scheme || !weight || !status) return GV_E_BADARG;
+    if (num_shapes <= 0 || num_views <= 0 || num_groups <= 0 || num_bins <= 0) return GV_E_BADARG;
+    if (weight_mode != GV_WEIGHT_COUNT && weight_mode != GV_WEIGHT_MEAN_SCORE) return GV_E_BADARG;
+    if (num_views > 64 || num_groups > 64) return GV_E_UNSUPPORTED;
+    GV_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(group_assign_per_shape_kernel, dim3(num_shapes), dim3(64), 0, (hipStream_t)stream, scores,
+                       num_views, num_groups, num_bins, weight_mode, gidx, scheme, weight, status);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }

@@ -231,10 +231,14 @@ __global__ __launch_bounds__(256) void view_pool_fuse_lp(const unsigned short* _
                                                          int64_t view_stride, int64_t shape_stride,
                                                          const int* __restrict__ scheme, int G,
                                                          const float* __restrict__ weight, int mode, float fill,
-                                                         unsigned short* __restrict__ D, unsigned short* __restrict__ S) {
+                                                         unsigned short* __restrict__ D, unsigned short* __restrict__ S,
+                                                         int64_t scheme_stride, int64_t weight_stride) {
     __shared__ unsigned long long s_mask[64];
     __shared__ float s_w[64];
     __shared__ float s_wsum;
+    const int n = blockIdx.y;                       // one shape per grid row: its own scheme when strides != 0
+    scheme += (size_t)n * scheme_stride;
+    weight += (size_t)n * weight_stride;
     for (int g = threadIdx.x; g < G; g += 256) {
         unsigned long long m = 0;
         for (int v = 0; v < V; ++v)
@@ -251,11 +255,9 @@ __global__ __launch_bounds__(256) void view_pool_fuse_lp(const unsigned short* _
     __syncthreads();
     const float wsum = s_wsum;
     const int64_t eg = E / VEC;
-    const int64_t total = (int64_t)N * eg;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < eg;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx / eg);
-        const int64_t e = (idx - (int64_t)n * eg) * VEC;
+        const int64_t e = idx * VEC;
         const unsigned short* base = F + (size_t)n * shape_stride + e;
         float acc[8];
 #pragma unroll
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void view_pool_fuse_lp(const unsigned short* _
         }
         if (S) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = __fdiv_rn(acc[k], wsum);
+            for (int k = 0; k < VEC; ++k) acc[k] = wsum != 0.f ? __fdiv_rn(acc[k], wsum) : 0.f;
             store_v<T, VEC>(S + (size_t)n * E + e, acc);
         }
     }
@@ -341,16 +343,20 @@ int ssa_t(const unsigned short* x, int64_t npix, int c, int x_ld, const float* s
 
 template <typename T>
 int fuse_t(const unsigned short* F, int V, int N, int64_t E, int64_t vs, int64_t ss, const int* scheme, int G,
-           const float* weight, int mode, float fill, unsigned short* D, unsigned short* S, hipStream_t st) {
+           const float* weight, int mode, float fill, unsigned short* D, unsigned short* S, hipStream_t st,
+           int64_t scheme_stride, int64_t weight_stride) {
     const bool vec = (E % 8 == 0) && (vs % 8 == 0) && (ss % 8 == 0) && gv_aligned16(F) && (!D || gv_aligned16(D)) &&
                      (!S || gv_aligned16(S));
-    const int64_t total = (int64_t)N * (vec ? E / 8 : E);
+    const int64_t per_shape = vec ? E / 8 : E;
+    int64_t bx = (per_shape + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const dim3 grid((unsigned)bx, (unsigned)N);
     if (vec)
-        hipLaunchKernelGGL((view_pool_fuse_lp<T, 8>), dim3(grid_for(total)), dim3(256), 0, st, F, V, N, E, vs, ss,
-                           scheme, G, weight, mode, fill, D, S);
+        hipLaunchKernelGGL((view_pool_fuse_lp<T, 8>), grid, dim3(256), 0, st, F, V, N, E, vs, ss,
+                           scheme, G, weight, mode, fill, D, S, scheme_stride, weight_stride);
     else
-        hipLaunchKernelGGL((view_pool_fuse_lp<T, 1>), dim3(grid_for(total)), dim3(256), 0, st, F, V, N, E, vs, ss,
-                           scheme, G, weight, mode, fill, D, S);
+        hipLaunchKernelGGL((view_pool_fuse_lp<T, 1>), grid, dim3(256), 0, st, F, V, N, E, vs, ss,
+                           scheme, G, weight, mode, fill, D, S, scheme_stride, weight_stride);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
@@ -400,13 +406,14 @@ int view_score_partial(int dtype, const void* raw, int nb, int hw, int cr, int r
 }
 
 int view_pool_fuse(int dtype, const void* F, int V, int N, int64_t E, int64_t vs, int64_t ss, const int* scheme,
-                   int G, const float* weight, int mode, float fill, void* D, void* S, hipStream_t st) {
+                   int G, const float* weight, int mode, float fill, void* D, void* S, hipStream_t st,
+                   int64_t scheme_stride, int64_t weight_stride) {
     if (dtype == GV_BF16)
         return fuse_t<__bf16>((const unsigned short*)F, V, N, E, vs, ss, scheme, G, weight, mode, fill,
-                              (unsigned short*)D, (unsigned short*)S, st);
+                              (unsigned short*)D, (unsigned short*)S, st, scheme_stride, weight_stride);
     if (dtype == GV_F16)
         return fuse_t<_Float16>((const unsigned short*)F, V, N, E, vs, ss, scheme, G, weight, mode, fill,
-                                (unsigned short*)D, (unsigned short*)S, st);
+                                (unsigned short*)D, (unsigned short*)S, st, scheme_stride, weight_stride);
     return GV_E_UNSUPPORTED;
 }
 

@@ -180,10 +180,17 @@ class GVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=1, num_views=12, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, seed=2,
-                 math="f32", lanes=True, storage="f32"):
+                 math="f32", lanes=True, storage="f32", per_shape=False, weight_mode="count"):
         """storage: 'f32' (configs c1/c2), 'bf16' (c3/c4) or 'f16' (c5): the type activations, filters and
         descriptors are kept in; accumulation and every epilogue are fp32 (`math` applies to 'f32' only)."""
         self.lib = _lib.load()
+        # per_shape: the paper's grouping (SURVEY §8 f1) — every shape scores / bins / fuses its own views; the
+        # reference's batch-mean score (model.py:146) is the default.  weight_mode: 'count' (model.py:28-41) or
+        # 'mean_score' (score-derived group weights)
+        self.per_shape = bool(per_shape)
+        self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
+        if self.weight_mode != _lib.GV_WEIGHT_COUNT and not self.per_shape:
+            raise ValueError("weight_mode='mean_score' needs per_shape=True")
         self.dtype = backbones.DTYPES[storage]
         self.tdtype = backbones.TORCH_DTYPES[self.dtype]
         self.device = _dev(device)
@@ -218,6 +225,11 @@ class GVCNN:
             self.shape_descriptor = torch.empty((num_shapes, f.h, f.w, f.c), dtype=self.tdtype, device=dev)
             self.gap = torch.empty((num_shapes, f.c), dtype=f32, device=dev)
             self.logits = torch.empty((num_shapes, num_classes), dtype=f32, device=dev)
+            if self.per_shape:
+                self.scores_ps = torch.empty((num_shapes, num_views), dtype=f32, device=dev)
+                self.gidx_ps = torch.empty((num_shapes, num_views), dtype=i32, device=dev)
+                self.scheme_ps = torch.empty((num_shapes, num_group, num_views), dtype=i32, device=dev)
+                self.weight_ps = torch.empty((num_shapes, num_group), dtype=f32, device=dev)
             self._all_ones_scheme = torch.ones((1, num_views), dtype=i32, device=dev)
             self._one = torch.ones(1, dtype=f32, device=dev)
 
@@ -333,9 +345,39 @@ class GVCNN:
             weight = _as_dev_weight(g_weight, self.device)
         return self.pool_fuse_classify(scheme, weight)
 
+    def forward_per_shape(self, views, check=True):
+        """Per-shape grouping: (scores [N,V], shape_descriptor, logits).  Nothing couples the shapes
+        of the batch, so a shape-sharded job needs no exchange."""
+        lib, f = self.lib, self.final
+        self.forward_phase1(views)                     # fills r_img (the batch-mean scores are not used)
+        _lib.check(lib.gv_view_score_per_shape(self.r_img.data_ptr(), self.N * self.V, self.scores_ps.data_ptr(),
+                                               _st()), "gv_view_score_per_shape")
+        _lib.check(lib.gv_group_assign_per_shape(self.scores_ps.data_ptr(), self.N, self.V, self.G, self.num_bins,
+                                                 self.weight_mode, self.gidx_ps.data_ptr(), self.scheme_ps.data_ptr(),
+                                                 self.weight_ps.data_ptr(), self.status.data_ptr(), _st()),
+                   "gv_group_assign_per_shape")
+        E = f.h * f.w * f.c
+        S = self.shape_descriptor
+        _lib.check(lib.gv_view_pool_fuse_fwd_per_shape(self.plan.view(f).data_ptr(), self.V, self.N, E, E, self.V * E,
+                                                       self.scheme_ps.data_ptr(), self.G, self.weight_ps.data_ptr(),
+                                                       _POOL_MODES[self.pool], self.empty_fill, None, S.data_ptr(),
+                                                       self.dtype, _st()), "gv_view_pool_fuse_fwd_per_shape")
+        _lib.check(lib.gv_global_avg_pool(S.data_ptr(), self.N, f.h * f.w, f.c, f.c, self.gap.data_ptr(),
+                                          self.dtype, _st()), "gv_global_avg_pool")
+        _lib.check(lib.gv_dense_fwd(self.gap.data_ptr(), self.N, f.c, self.cls_kernel.data_ptr(),
+                                    self.cls_bias.data_ptr(), self.num_classes, self.logits.data_ptr(), _st()),
+                   "gv_dense_fwd")
+        if check:
+            st = int(self.status.item())
+            if st:
+                _raise_for_status(st, self.gidx_ps.reshape(-1), self.G)
+        return self.scores_ps, S, self.logits
+
     def forward(self, views, check=True):
         """Fused forward: (scores [V], shape_descriptor [N,h,w,C], logits [N,num_classes]), all on
         device; the only host interaction is the optional status read (check=True)."""
+        if self.per_shape:
+            return self.forward_per_shape(views, check)
         self.forward_phase1(views)
         self.assign_groups(check=False)
         S, logits = self.pool_fuse_classify(self.scheme, self.weight)

@@ -72,6 +72,8 @@ class ShardedGVCNN:
         exchange='allgather' over all N_g = P*N_l shapes (identical on every rank), for
         exchange='scores' over the local N_l shapes."""
         eng = self.eng
+        if getattr(eng, "per_shape", False):                   # per-shape grouping couples nothing: no exchange
+            return eng.forward_per_shape(views_local, check)
         eng.run_backbone(views_local)
         eng.compute_scores()                                   # fills eng.r_img (local) + local scores
         if self.world > 1:

@@ -199,6 +199,27 @@ int gv_view_pool_fuse_fwd(const void* F, int32_t num_views, int32_t num_shapes, 
                           int32_t num_groups, const float* weight, int32_t mode, float empty_fill,
                           void* D, void* S, int32_t dtype, void* stream);
 
+/* ---- per-shape grouping (the paper's grouping module; NOT what nets/model.py computes) -------
+ * nets/model.py:146 averages the scorer response over the batch, so one scheme serves all N shapes.  The
+ * per-shape form scores, bins and fuses every shape on its own: nothing couples the shapes of a batch, hence a
+ * shape-sharded multi-GPU job needs no exchange at all. */
+#define GV_WEIGHT_COUNT 0       /* weight[g] = 1 + #members                      (nets/model.py:28-41)          */
+#define GV_WEIGHT_MEAN_SCORE 1  /* weight[g] = mean score of the members, 0 for an empty group (score-derived,
+                                   as in the paper's figure assets/grouping module.png)                          */
+/* scores[b] = sigmoid(log(|r_img[b]|)) for every image b (no batch mean). */
+int gv_view_score_per_shape(const float* r_img, int32_t nb, float* scores, void* stream);
+/* scores [N,V] (image b = n*V + v) -> gidx [N,V], scheme [N,G,V] one-hot int32, weight [N,G]; binning exactly as
+ * gv_group_assign; status is OR-ed over the shapes. */
+int gv_group_assign_per_shape(const float* scores, int32_t num_shapes, int32_t num_views, int32_t num_groups,
+                              int32_t num_bins, int32_t weight_mode, int32_t* gidx, int32_t* scheme,
+                              float* weight, int32_t* status, void* stream);
+/* gv_view_pool_fuse_fwd with one scheme [G,V] and one weight [G] PER SHAPE (scheme [N,G,V], weight [N,G]).
+ * A shape whose weights sum to 0 gets S = 0. */
+int gv_view_pool_fuse_fwd_per_shape(const void* F, int32_t num_views, int32_t num_shapes, int64_t E,
+                                    int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
+                                    int32_t num_groups, const float* weight, int32_t mode, float empty_fill,
+                                    void* D, void* S, int32_t dtype, void* stream);
+
 /* tf.keras.layers.Dense at nets/model.py:164: y[n,:] = x[n,:] @ kernel[F,C] + bias (fp32). */
 int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel, const float* bias,
                  int32_t c, float* y, void* stream);

@@ -146,3 +146,40 @@ def basic_head(final_descs, cls_kernel, cls_bias):
     shape_desc = stacked.max(axis=0)
     logits = dense(global_average_pool(shape_desc), cls_kernel, cls_bias)
     return shape_desc, logits
+
+
+# --------------------------------------------------------------------------
+# per-shape grouping: the paper's module — every shape scores, bins and fuses its own views.
+# NOT computed by the reference (nets/model.py:146 averages the response over the batch); restated here from
+# the same building blocks so the HIP kernels have a checker.  No reference fixture exists: parity unpinned.
+# --------------------------------------------------------------------------
+def group_weight_mean_score(scheme, scores):
+    """weight[g] = mean score of the views in group g (fp32, view order), 0 for an empty group."""
+    scheme = np.asarray(scheme)
+    w = np.zeros(scheme.shape[0], dtype=F32)
+    for g in range(scheme.shape[0]):
+        acc, cnt = F32(0), 0
+        for v in range(scheme.shape[1]):
+            if scheme[g, v]:
+                acc = F32(acc + F32(scores[v]))
+                cnt += 1
+        w[g] = F32(acc / F32(cnt)) if cnt else F32(0)
+    return w
+
+
+def per_shape_grouping(final_descs, r, num_group, num_bins=10, weight_mode="count", pool="max", empty_fill=1.0):
+    """final_descs [N,V,h,w,C]; r [N,V] scorer responses.  Returns (scores [N,V], schemes [N,G,V],
+    weights [N,G], shape_descriptor [N,h,w,C])."""
+    Fd = np.asarray(final_descs, dtype=F32)
+    r = np.asarray(r, dtype=F32)
+    N, V = r.shape
+    scores = score_from_r(r)
+    schemes = np.zeros((N, num_group, V), dtype=np.int64)
+    weights = np.zeros((N, num_group), dtype=F32)
+    S = np.zeros((N,) + Fd.shape[2:], dtype=F32)
+    for n in range(N):
+        schemes[n] = group_scheme([scores[n]], num_group, V, num_bins)
+        weights[n] = group_weight(schemes[n]) if weight_mode == "count" else group_weight_mean_score(schemes[n], scores[n])
+        gd = view_pooling([Fd[n:n + 1, v] for v in range(V)], schemes[n], pool=pool, empty_fill=empty_fill)
+        S[n] = group_fusion(gd, weights[n])[0] if float(weights[n].sum()) != 0.0 else 0.0
+    return scores, schemes, weights, S

@@ -409,7 +409,7 @@ def test_conv_bf16_split_vs_oracle(math, k, stride, padding, cin, cout):
     np.testing.assert_allclose(y, ref.numpy(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("tile", list(range(9)))
+@pytest.mark.parametrize("tile", list(range(11)))
 @pytest.mark.parametrize("cout", [32, 80, 200])
 def test_conv_bf16x3_every_tile_config(tile, cout):
     g = torch.Generator().manual_seed(tile * 100 + cout)
@@ -474,3 +474,49 @@ def test_pooled_branch_commutes_with_the_1x1_conv(math):
     z = y2d.cpu().numpy()[..., couts[1]:]
     assert (z < 0).any()                                           # the pooled columns left the GEMM without ReLU
     np.testing.assert_allclose(out.cpu().numpy(), ref_pooled, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("weight_mode", [0, 1])
+@pytest.mark.parametrize("pool", ["max", "mean"])
+def test_per_shape_assign_and_fuse_vs_oracle(weight_mode, pool):
+    """SURVEY §8 f1 kernels on random per-shape scores (every shape gets its own scheme, some groups empty,
+    one shape with all-zero scores => zero weights under mean_score)."""
+    rng = np.random.RandomState(11 + weight_mode)
+    N, V, G, E = 5, 7, 10, 2 * 3 * 8
+    scores = rng.uniform(0.0, 0.99, size=(N, V)).astype(np.float32)
+    scores[3] = 0.0                                            # r == 0 -> score 0 for every view of shape 3
+    F = rng.randn(N, V, E).astype(np.float32)
+    sd = torch.from_numpy(scores).to(DEV)
+    gidx = torch.empty(N, V, dtype=torch.int32, device=DEV)
+    scheme = torch.empty(N, G, V, dtype=torch.int32, device=DEV)
+    weight = torch.empty(N, G, device=DEV)
+    status = torch.ones(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib().gv_group_assign_per_shape(sd.data_ptr(), N, V, G, 10, weight_mode, gidx.data_ptr(),
+                                               scheme.data_ptr(), weight.data_ptr(), status.data_ptr(), st()), "assign")
+    assert int(status.item()) == 0
+    Fd = torch.from_numpy(F).to(DEV)
+    S = torch.empty(N, E, device=DEV)
+    D = torch.empty(G, N, E, device=DEV)
+    mode = _lib.GV_VIEWPOOL_MAX if pool == "max" else _lib.GV_VIEWPOOL_MEAN
+    _lib.check(lib().gv_view_pool_fuse_fwd_per_shape(Fd.data_ptr(), V, N, E, E, V * E, scheme.data_ptr(), G,
+                                                     weight.data_ptr(), mode, 1.0, D.data_ptr(), S.data_ptr(),
+                                                     _lib.GV_F32, st()), "fuse")
+    assert len({tuple(r) for r in gidx.cpu().tolist()}) > 1
+    for n in range(N):
+        sch = OG.group_scheme([scores[n]], G, V)
+        assert scheme[n].cpu().numpy().tolist() == sch.tolist()                    # integer path: exact
+        w = OG.group_weight(sch) if weight_mode == 0 else OG.group_weight_mean_score(sch, scores[n])
+        np.testing.assert_allclose(weight[n].cpu().numpy(), w, rtol=1e-6, atol=0)
+        gd = OG.view_pooling([F[n:n + 1, v].reshape(1, 1, 1, E) for v in range(V)], sch, pool=pool)
+        for g in range(G):
+            np.testing.assert_allclose(D[g, n].cpu().numpy(), gd[g].reshape(E), rtol=1e-6, atol=1e-6)
+        want = OG.group_fusion(gd, w).reshape(E) if float(w.sum()) != 0 else np.zeros(E, np.float32)
+        np.testing.assert_allclose(S[n].cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    if weight_mode == 1:
+        assert float(weight[3].sum()) == 0.0 and float(S[3].abs().max()) == 0.0
+    # an out-of-range bin in ONE shape is reported (the reference's IndexError, model.py:23)
+    sd2 = sd.clone()
+    sd2[2, 4] = 0.995
+    _lib.check(lib().gv_group_assign_per_shape(sd2.data_ptr(), N, V, 9, 10, weight_mode, gidx.data_ptr(),
+                                               scheme.data_ptr(), weight.data_ptr(), status.data_ptr(), st()), "assign")
+    assert int(status.item()) & 1

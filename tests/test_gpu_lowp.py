@@ -141,7 +141,7 @@ def test_lp_conv_combos_vs_oracle(k, stride, padding, cin, cout, ty):
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
-@pytest.mark.parametrize("tile", list(range(9)))
+@pytest.mark.parametrize("tile", list(range(11)))
 @pytest.mark.parametrize("cout", [32, 48, 200])
 def test_lp_conv_every_tile_config(tile, cout, ty):
     """All tile shapes, ragged M (286) and N not a multiple of 32; K = 360 is not a multiple of the k-tile."""

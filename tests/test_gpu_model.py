@@ -206,3 +206,33 @@ def test_other_baseline_configs_properties(backbone, V, size, G, math):
                               Hd["dense_%d/bias" % V].numpy())
     np.testing.assert_allclose(S.cpu().numpy(), oS, rtol=1e-6, atol=1e-6 * float(np.abs(oS).max()))
     assert_close(logits.cpu().numpy(), oL)
+
+
+@pytest.mark.parametrize("weight_mode", ["count", "mean_score"])
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_per_shape_grouping_vs_oracle(weight_mode, storage):
+    """SURVEY §8 f1: per-shape scores / schemes / weights / fusion.  Integer results bit-exact given the scores;
+    the kernels are checked on the DEVICE's descriptors and responses (the backbone has its own tests)."""
+    import ctypes as C_
+    from gvcnn_tf_amd import _lib
+    N, V, G, C = 3, 6, 10, 10
+    eng, P, Hd = make_engine("resnet_v2_50", N, V, 64, 64, C, G, storage=storage, per_shape=True, weight_mode=weight_mode)
+    x = views(N, V, 64, 64, seed=3)
+    scores, S, logits = eng.forward(x.to(DEV))
+    assert tuple(scores.shape) == (N, V)
+    F = eng.final_view_descriptors().float().cpu().numpy()
+    r = eng.r_img.cpu().numpy().reshape(N, V)
+    o_scores, o_schemes, o_weights, o_S = OG.per_shape_grouping(F, r, G, weight_mode=weight_mode)
+    np.testing.assert_allclose(scores.cpu().numpy(), o_scores, rtol=1e-5, atol=1e-6)
+    # bins from the DEVICE scores (identical fp32 inputs => identical integers)
+    dev_scores = scores.cpu().numpy()
+    for n in range(N):
+        sch = OG.group_scheme([dev_scores[n]], G, V)
+        assert eng.scheme_ps[n].cpu().numpy().tolist() == sch.tolist()
+        w = OG.group_weight(sch) if weight_mode == "count" else OG.group_weight_mean_score(sch, dev_scores[n])
+        np.testing.assert_allclose(eng.weight_ps[n].cpu().numpy(), w, rtol=1e-6)
+    tol = 1e-5 if storage == "f32" else 2.0 ** -7
+    np.testing.assert_allclose(S.float().cpu().numpy(), o_S, rtol=tol, atol=tol * float(np.abs(o_S).max()))
+    oL = OG.dense(OG.global_average_pool(S.float().cpu().numpy()), Hd["dense_%d/kernel" % V].numpy(),
+                  Hd["dense_%d/bias" % V].numpy())
+    np.testing.assert_allclose(logits.cpu().numpy(), oL, rtol=1e-4, atol=1e-4 * float(np.abs(oL).max()))

@@ -31,7 +31,7 @@ def probe(nb, hw, cin, cout, k, iters=5, tiles=None, dbg=0):
     fl = 2.0 * M * cout * K
     res = []
     lib.gv_conv2d_set_debug(dbg)
-    for t in (tiles if tiles is not None else range(9)):
+    for t in (tiles if tiles is not None else range(11)):
         lib.gv_conv2d_set_tile_override(t)
         ms = C.c_float(0)
         rc = lib.gv_conv2d_time(C.byref(d), x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(),
@@ -43,7 +43,7 @@ def probe(nb, hw, cin, cout, k, iters=5, tiles=None, dbg=0):
 
 
 if __name__ == "__main__":
-    print("tiles: 128x128 128x64 64x64 128x96 64x128 128x32 256x128 128x256 256x64")
+    print("tiles: 128x128 128x64 64x64 128x96 64x128 128x32 256x128 128x256 256x64 128x192 64x192")
     for dbg in (0, 4):
         for (nb, hw, cin, k) in [(256, 32, 128, 3), (256, 32, 512, 1), (256, 32, 2048, 1), (54, 32, 192, 3)]:
             for cout in (256, 192, 128):
