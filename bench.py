@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
     ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the real multi-GPU path); gloo + --same-device: control-flow check of the N>1 path "
+                         "on a single-GPU box (every rank on cuda:0, collectives through host memory)")
+    ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--storage", default=None, choices=["f32", "bf16", "f16"],
                     help="activation/filter storage type (default: the preset's own: c2 f32 = the bench line, "
                          "c3/c4 bf16, c5 f16; forward only)")
@@ -159,10 +163,15 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (a.gpus, a.gpus))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import gvcnn_tf_amd as gv
     from gvcnn_tf_amd.sharding import ShardedGVCNN
@@ -200,7 +209,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.check_status()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

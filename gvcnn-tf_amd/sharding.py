@@ -34,14 +34,24 @@ def shard_range(num_shapes_global, world_size, rank):
     return rank * n_l, (rank + 1) * n_l
 
 
+def _all_gather_flat(t_local, group=None):
+    """all_gather_into_tensor along dim 0.  RCCL takes device tensors directly; a gloo group (CPU tests, and the
+    single-device control-flow check `bench.py --backend gloo`) is fed through host memory."""
+    world = dist.get_world_size(group)
+    t_local = t_local.contiguous()
+    via_host = t_local.is_cuda and dist.get_backend(group) == "gloo"
+    src = t_local.cpu() if via_host else t_local
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(t_local.device) if via_host else out
+
+
 def gather_scores(r_img_local, group=None):
     """All-gather the local scorer responses [N_l*V] -> [P*N_l*V] (global shape-major order)."""
     world = dist.get_world_size(group)
     if world == 1:
         return r_img_local
-    out = torch.empty(world * r_img_local.numel(), dtype=r_img_local.dtype, device=r_img_local.device)
-    dist.all_gather_into_tensor(out, r_img_local.contiguous(), group=group)
-    return out
+    return _all_gather_flat(r_img_local.reshape(-1), group)
 
 
 def gather_descriptors(F_local, group=None):
@@ -49,10 +59,7 @@ def gather_descriptors(F_local, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return F_local
-    out = torch.empty((world * F_local.shape[0],) + tuple(F_local.shape[1:]), dtype=F_local.dtype,
-                      device=F_local.device)
-    dist.all_gather_into_tensor(out, F_local.contiguous(), group=group)
-    return out
+    return _all_gather_flat(F_local, group)
 
 
 class ShardedGVCNN:
@@ -118,9 +125,7 @@ def gather_views(t_local, group=None):
         return t_local
     t_local = t_local.contiguous()
     n, v_l = t_local.shape[0], t_local.shape[1]
-    out = torch.empty((world * n,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
-    dist.all_gather_into_tensor(out, t_local, group=group)
-    out = out.view((world,) + tuple(t_local.shape))
+    out = _all_gather_flat(t_local, group).view((world,) + tuple(t_local.shape))
     return out.transpose(0, 1).reshape((n, world * v_l) + tuple(t_local.shape[2:])).contiguous()
 
 
@@ -141,8 +146,11 @@ def allreduce_sum_bucketed(tensors, bucket_bytes=64 << 20, group=None):
     if cur:
         buckets.append(cur)
     pending = []
+    via_host = tensors[0].is_cuda and dist.get_backend(group) == "gloo"
     for b in buckets:
         flat = torch.cat([t.reshape(-1) for t in b])
+        if via_host:
+            flat = flat.cpu()
         pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True), flat, b))
     for work, flat, b in pending:
         work.wait()

@@ -236,3 +236,28 @@ def test_per_shape_grouping_vs_oracle(weight_mode, storage):
     oL = OG.dense(OG.global_average_pool(S.float().cpu().numpy()), Hd["dense_%d/kernel" % V].numpy(),
                   Hd["dense_%d/bias" % V].numpy())
     np.testing.assert_allclose(logits.cpu().numpy(), oL, rtol=1e-4, atol=1e-4 * float(np.abs(oL).max()))
+
+
+def test_bench_two_rank_control_flow_on_one_device():
+    """The N>1 path of bench.py (rank/world from the environment, shape sharding, score exchange, max-over-ranks
+    timing, one JSON line from rank 0) with two ranks that share cuda:0 and a gloo group — RCCL itself needs two
+    devices and is exercised by the driver's multi-GPU run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--same-device", "--steps", "2", "--warmup", "1", "--shapes", "2", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                      # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_views"] == 2 * 2 * 12 and j["scaling"] == "weak"
+    assert j["value"] > 0 and j["config"]["exchange"] == "scores"
