@@ -412,15 +412,10 @@ class TrainGVCNN:
     def backward_backbone(self):
         """Backbone backward from the gradient held in the final tap's gradient buffer."""
         lib, V = self.lib, self.V
-        import os
-        dbg = bool(os.environ.get("GV_SYNC_DEBUG"))
         for op in reversed(self.plan.ops):
             x, y = op["x"], op["y"]
             if y.vbuf < 0 or self.grad[y.vbuf] is None:
                 continue                                  # nothing downstream of the final tap reaches it
-            if dbg:
-                torch.cuda.synchronize()
-                print("bwd", op["kind"], op["name"], flush=True)
             if op["kind"] == "bn":
                 st = op["stat"]
                 hw = x.h * x.w
