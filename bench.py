@@ -69,6 +69,10 @@ def parse():
                     help="nccl = RCCL (the real multi-GPU path); gloo + --same-device: control-flow check of the N>1 path "
                          "on a single-GPU box (every rank on cuda:0, collectives through host memory)")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="time the TRAINING step instead (SURVEY a12 / configs[2]: train-mode forward + loss + backward + "
+                         "BN moving averages + Momentum; fp32 storage, bf16x3 math).  N > 1: view-sharded data "
+                         "parallelism (the world size must divide the number of views)")
     ap.add_argument("--storage", default=None, choices=["f32", "bf16", "f16"],
                     help="activation/filter storage type (default: the preset's own: c2 f32 = the bench line, "
                          "c3/c4 bf16, c5 f16; forward only)")
@@ -147,6 +151,50 @@ def cpu_baseline(P, Hd, seconds):
                       % (passes, V, H, W, BACKBONE, dt)}
 
 
+def train_main(a, world, rank, dev):
+    """One JSON line for the training step (not the driver's bench line)."""
+    from gvcnn_tf_amd.training import TrainGVCNN
+    from gvcnn_tf_amd.sharding import ShardedTrainGVCNN, view_shard_range
+    N = a.shapes
+    lo, hi = view_shard_range(V, world, rank)
+    eng = TrainGVCNN(BACKBONE, N, hi - lo, H, W, C, G, device=dev, num_bins=G, head_views=V, view_offset=lo)
+    sh = ShardedTrainGVCNN(eng)
+    x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5)[:, lo:hi].contiguous().to(dev)
+    labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1))
+    sh.train_step(x, labels, lr=1e-6)
+    eng.autotune()                                   # untimed: per-launch tile choice
+    for _ in range(max(a.warmup, 1)):
+        sh.train_step(x, labels, lr=1e-6)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sh.train_step(x, labels, lr=1e-6)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        flops = 3.0 * sum(op.get("flops", 0) for op in eng.plan.ops) * world
+        print(json.dumps({
+            "metric": "views/sec (training step)", "value": round(N * V / (ms * 1e-3), 1), "unit": "views/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "training step (SURVEY a12): %s, %d shapes x %d views x %dx%d, train-mode BN per view, "
+                                   "CE loss, backward, BN moving averages, Momentum; fp32 storage, bf16x3 math; views sharded "
+                                   "over the ranks" % (BACKBONE, N, V, H, W), "views_per_gpu": N * (hi - lo)},
+            "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}), flush=True)
+
+
 def main():
     global BACKBONE, V, H, W, G, C
     a = parse()
@@ -175,6 +223,8 @@ def main():
 
     import gvcnn_tf_amd as gv
     from gvcnn_tf_amd.sharding import ShardedGVCNN
+    if a.train:
+        return train_main(a, world, rank, dev)
 
     N = a.shapes
     eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math if a.storage == "f32" else "f32",
