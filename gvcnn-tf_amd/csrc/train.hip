@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__
                                                        int iw, int cin, int kh, int kw, int stride, int pad_t,
                                                        int pad_l, int oh, int ow, int cout, int64_t M,
                                                        int64_t m_per_block, float* __restrict__ dw) {
-    constexpr int PT = 16, BI = 64 * TI, BO = 64 * TO;
+    constexpr int PT = (TI * TO == 1) ? 32 : 16, BI = 64 * TI, BO = 64 * TO;   // pixels per step
     constexpr int XV = PT * BI / 4 / 256, ZV = PT * BO / 4 / 256;      // float4 loads per thread and step
     __shared__ __attribute__((aligned(16))) float sX[2][PT][BI];
     __shared__ __attribute__((aligned(16))) float sZ[2][PT][BO];
@@ -913,7 +913,7 @@ extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const floa
         if (splits < 1) splits = 1;
         if (splits > 65535) splits = 65535;
         int64_t per = (M + splits - 1) / splits;
-        per = (per + 15) / 16 * 16;
+        per = (per + 31) / 32 * 32;
         splits = (M + per - 1) / per;
         const dim3 grid((unsigned)tiles, (unsigned)splits);
         hipStream_t st = (hipStream_t)stream;
