@@ -501,8 +501,7 @@ class BackbonePlan:
         the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
         chain sums k in the same order under every configuration, so results are bitwise unchanged."""
         lib = self.lib
-        # the 16-bit storage kernel has the tile table of the split-bf16 kernel
-        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dtype == _lib.GV_F32 else _lib.GV_MATH_BF16X1)
+        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dtype == _lib.GV_F32 else -1)   # -1: 16-bit storage
         self.run(x)
         chosen = {}
         try:

@@ -373,6 +373,7 @@ static int planes_of(int math_mode) {
 }
 
 extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
+    if (math_mode == -1) return gvconv::lp_num_cfgs();     // the 16-bit storage kernels
     const int np = planes_of(math_mode);
     return np < 0 ? GV_E_BADARG : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs());
 }
@@ -474,7 +475,9 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         // the vector loader keeps 32-bit element offsets
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
-                        : (d->tile_cfg > 0 ? d->tile_cfg - 1 : gvconv::lp_pick_tile(a.M, a.cout, a.K));
+                        : (d->tile_cfg > 0 ? d->tile_cfg - 1
+                           : (gvconv::lp_halo_ok(a, generic) && a.M >= 100000 ? gvconv::lp_num_cfgs() - 1
+                                                                              : gvconv::lp_pick_tile(a.M, a.cout, a.K)));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
     }
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels

@@ -76,7 +76,7 @@ __device__ __forceinline__ void store_chunk(unsigned short* dst, const float (&v
 
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                                   int wm, int wn, int lane, float* stage) {
+                                                   int wm, int wn, int lane, float* stage, int rows_valid = 32) {
     if (a.dbg & 4) {            // timing ablation: keep the accumulators live without storing the tile
         float t = 0.f;
 #pragma unroll
@@ -132,7 +132,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8 + 4);
                 const int m = m0 + (wm * TM + i) * 32 + row;
-                if (m >= a.M || nvalid <= 0) continue;
+                if (m >= a.M || nvalid <= 0 || row >= rows_valid) continue;
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
@@ -448,6 +448,162 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) 
                                   reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Halo-tiled 3x3 / stride-1 convolution for the few-channel stem layers (cin = 32, cout = 32 or 64:
+// Conv2d_2a_3x3 / Conv2d_2b_3x3).  The implicit-GEMM kernel above fetches every input element once per filter tap
+// (9x) from L2, which — not HBM, not the matrix pipe — bounds these layers.  Here a workgroup owns a 32-pixel-wide
+// column strip of one image and walks down it 4 output rows at a time: the (4+2) x (32+2) pixel halo is staged ONCE
+// in LDS (80-byte pixels: the 32 consecutive pixels a wave's MFMA rows map to are conflict-free), every tap's A
+// fragment is a ds_read_b128 at a shifted pixel, and the whole filter (9 taps x 2 k-steps x TN fragments) lives in
+// REGISTERS for the life of the workgroup.  The next tile's halo is loaded into registers under this tile's
+// MFMAs.  Epilogue: the staged 16-byte path above.
+template <typename T, int TN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
+    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, PB = 80;       // halo pixel = 64 B + 16 B pad
+    constexpr int NCH = HH * HW * 4;                                          // 16-byte chunks of one halo
+    constexpr int SL = (NCH + 255) / 256;
+    constexpr bool BREG = TN == 1;                                            // filter fragments in registers
+    constexpr int WB = 288 * 2 + 16;                                          // LDS filter row: K = 288 values + pad
+    constexpr int SW = 32 + 4;                                                // staging row: one 32-column tile (+ pad)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sH = smem_raw;                                                      // [HH*HW][PB]
+    float* stage = reinterpret_cast<float*>(smem_raw + HH * HW * PB) + (threadIdx.x >> 6) * (32 * SW);
+    char* sW = smem_raw + HH * HW * PB + 4 * 32 * SW * 4;                     // [32*TN][WB]   (!BREG)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.ow + TW - 1) / TW;
+    const int n = blockIdx.x / tiles_x;
+    const int ox0 = (blockIdx.x % tiles_x) * TW;
+    const unsigned short* xs = reinterpret_cast<const unsigned short*>(a.x);
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.w);
+    const unsigned short* res = reinterpret_cast<const unsigned short*>(a.res);
+    unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
+
+    // the filter: B fragment of tap t, k-step c, column tile j = 8 values k = t*32 + c*16 + 8*lh .. of row n = j*32 + li
+    u32x4 fb[BREG ? 9 : 1][2][TN];
+    if constexpr (BREG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = min(li, a.cout - 1);
+                fb[t][c][0] = *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + t * 32 + c * 16 + 8 * lh);
+            }
+    } else {
+        for (int idx = tid; idx < 32 * TN * 36; idx += 256) {                 // 36 chunks of 16 B per filter row
+            const int row = idx / 36, ch = idx - row * 36;
+            const int col = min(row, a.cout - 1);
+            *reinterpret_cast<u32x4*>(sW + row * WB + ch * 16) =
+                *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + ch * 8);
+        }
+    }
+
+    // epilogue constants of this lane's 8 output channels of column tile j (read-back layout: 4 lanes per 32 columns)
+    constexpr int RPP = 16;
+    const int rrow = lane >> 2, col8 = (lane & 3) * 8;
+    float sc[TN][8], sh[TN][8];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = min(j * 32 + col8 + e, a.cout - 1);
+            sc[j][e] = a.scale[c];
+            sh[j][e] = a.shift[c];
+        }
+    const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
+                     (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0)));
+
+    u32x4 hr[SL];
+    auto fetch = [&](int oy0) {
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (idx < NCH) {
+                const int pix = idx >> 2, ch = idx & 3;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int iy = oy0 + hy - a.pad_t, ix = ox0 + hx - a.pad_l;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
+                    v = *reinterpret_cast<const u32x4*>(xs + ((size_t)(n * a.ih + iy) * a.iw + ix) * a.x_ld + ch * 8);
+            }
+            hr[k] = v;
+        }
+    };
+    fetch(0);
+    for (int oy0 = 0; oy0 < a.oh; oy0 += TH) {
+        __syncthreads();                                   // previous tile: fragment reads and staging done
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < NCH) *reinterpret_cast<u32x4*>(sH + (idx >> 2) * PB + (idx & 3) * 16) = hr[k];
+        }
+        __syncthreads();
+        if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under the MFMAs below
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, s_ = t - r * 3;
+            const char* ap = sH + ((wave + r) * HW + li + s_) * PB + 16 * lh;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u32x4 fa = *reinterpret_cast<const u32x4*>(ap + c * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    u32x4 b;
+                    if constexpr (BREG) b = fb[t][c][j];
+                    else b = *reinterpret_cast<const u32x4*>(sW + (j * 32 + li) * WB + (t * 32 + c * 16 + 8 * lh) * 2);
+                    acc[j] = mfma16<T>(fa, b, acc[j]);
+                }
+            }
+        }
+        const int oy = oy0 + wave;
+        // transposing epilogue (see lp_epilogue_staged): accumulators -> private LDS block -> 8 channels per lane
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int colj = j * 32 + col8;
+            const int nvalid = min(8, a.cout - colj);
+#pragma unroll
+            for (int pass = 0; pass < 32 / RPP; ++pass) {
+                const int row = pass * RPP + rrow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+                if (oy >= a.oh || nvalid <= 0 || ox0 + row >= a.ow) continue;
+                const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[j][e] + sh[j][e];
+                if (res) {
+                    const unsigned short* rp = res + m * a.res_ld + colj;
+                    if (vec && nvalid == 8) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] += from_bits<T>((unsigned short)(rv[q] & 0xffffu));
+                            v[2 * q + 1] += from_bits<T>((unsigned short)(rv[q] >> 16));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < nvalid) v[e] += from_bits<T>(rp[e]);
+                    }
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (colj + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
+                }
+                store_chunk<T>(y + m * a.y_ld + colj, v, nvalid, vec);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // [kh][kw][cin][cout] fp32 -> [cout][Kpad] T, k = (r*kw+s)*cin + c, zero filled to a multiple of 32
 template <typename T>
 __global__ void pack_filter_lp(const float* __restrict__ w, int K, int Kpad, int cout,
@@ -511,11 +667,38 @@ int launch_t(int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st
     return GV_E_UNSUPPORTED;
 }
 
+template <typename T>
+int launch_halo(const ConvArgs& a, hipStream_t st) {
+    const int tiles_x = (a.ow + 31) / 32;
+    const dim3 grid((unsigned)(a.nb * tiles_x));
+    const size_t halo = (size_t)6 * 34 * 80;
+    if (a.cout <= 32) {
+        const size_t lds = halo + 4 * 32 * (32 + 4) * 4;
+        hipLaunchKernelGGL((conv3x3_halo_lp<T, 1>), grid, dim3(256), lds, st, a);
+    } else {
+        const size_t lds = halo + 4 * 32 * (32 + 4) * 4 + 64 * (288 * 2 + 16);
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 2>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!ok) return GV_E_UNSUPPORTED;
+        hipLaunchKernelGGL((conv3x3_halo_lp<T, 2>), grid, dim3(256), lds, st, a);
+    }
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 }  // namespace
 
 namespace gvconv {
 
-int lp_num_cfgs() { return kNumTiles; }
+int lp_num_cfgs() { return kNumTiles + 1; }               // + the halo-tiled stem kernel
+
+// the halo kernel's layer class: 3x3 / stride 1, 32 input channels in 16-byte aligned pixels, <= 64 output channels,
+// plain epilogue (Conv2d_2a_3x3, Conv2d_2b_3x3)
+bool lp_halo_ok(const ConvArgs& a, bool generic) {
+    return !generic && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cin == 32 && a.cout <= 64 && a.cout % 8 == 0 &&
+           a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.oh == a.ih + 2 * a.pad_t - 2 &&
+           a.ow == a.iw + 2 * a.pad_l - 2;
+}
 
 int lp_pick_tile(int M, int N, int /*K*/) {
     int best = 0;
@@ -539,6 +722,12 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
     ConvArgs a = a0;
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
+    if (cfg == kNumTiles) {
+        if (!lp_halo_ok(a, generic)) return GV_E_UNSUPPORTED;
+        if (dtype == GV_BF16) return launch_halo<__bf16>(a, st);
+        if (dtype == GV_F16) return launch_halo<_Float16>(a, st);
+        return GV_E_UNSUPPORTED;
+    }
     if (dtype == GV_BF16) return launch_t<__bf16>(cfg, a, generic, xf32, st);
     if (dtype == GV_F16) return launch_t<_Float16>(cfg, a, generic, xf32, st);
     return GV_E_UNSUPPORTED;

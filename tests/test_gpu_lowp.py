@@ -156,6 +156,27 @@ def test_lp_conv_every_tile_config(tile, cout, ty):
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70))])
+def test_lp_halo_stem_kernel(ty, cout, pad, hw):
+    """The halo-tiled 3x3 kernel of Conv2d_2a/2b (tile configuration 11): ragged strips (width not a multiple of
+    32, height not a multiple of 4), VALID and SAME, with a residual, into a channel slice — equal to the
+    implicit-GEMM kernel's result up to fp32 summation order."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(cout + pad)
+    ih, iw = hw
+    x = rnd(torch.randn(3, ih, iw, 32, generator=g), td)
+    w = rnd(torch.randn(3, 3, 32, cout, generator=g) * 0.06, td)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
+    res = rnd(torch.randn(3, oh, ow, cout, generator=g), td)
+    ref = oracle_conv(x, w, 1, "SAME" if pad else "VALID", scale, shift, True, residual=res)
+    y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=11, y_ld=cout + 16, y_off=8)
+    close(y, ref.numpy(), ulp)
+    y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=0, y_ld=cout + 16, y_off=8)
+    close(y, y0, ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
 def test_lp_conv_fp32_network_input(ty):
     """GV_CONV_X_F32: the stem reads the fp32 images and rounds them in its loader (== casting first)."""
     code, td, ulp = TYPES[ty]

@@ -40,7 +40,7 @@ torch.cuda.synchronize()
 lib = _lib.load()
 if a.autotune:
     plan.autotune(x)
-ncfg = lib.gv_conv2d_num_tile_cfgs(plan.math_mode if a.storage == 'f32' else _lib.GV_MATH_BF16X1)
+ncfg = lib.gv_conv2d_num_tile_cfgs(plan.math_mode if a.storage == 'f32' else -1)
 rows = []
 tot = {"conv": 0.0, "pool": 0.0, "ssa": 0.0}
 for i, op in enumerate(plan.ops):
