@@ -340,6 +340,160 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
     gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Halo-tiled 3x3 / stride-1 convolution for the few-channel stem layers on fp32 storage (cin = 32, cout <= 64:
+// Conv2d_2a_3x3 / Conv2d_2b_3x3), GV_MATH_BF16X3.  The implicit-GEMM kernel above fetches AND SPLITS every input
+// element once per filter tap (9x); with 32 or 64 output channels that split costs as many VALU cycles as the
+// MFMAs it feeds.  Here a workgroup owns a 32-pixel-wide column strip of one image and 32 output channels and walks
+// down the strip 4 output rows at a time: the (4+2) x (32+2) pixel halo is split ONCE into its three bf16 planes
+// while it is written to LDS (208-byte pixels), every tap's A fragments are ds_read_b128 at a shifted pixel, the
+// packed filter ([n][k-tile][plane][16], 55 KB for 32 columns) is LDS resident for the life of the workgroup, and
+// the next tile's halo is loaded into registers under this tile's 108 MFMAs per wave.
+__global__ __launch_bounds__(256) void conv3x3_halo_x3(const ConvArgs a) {
+    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, PB = 3 * 64 + 16;   // halo pixel: 3 planes x 32 ch + pad
+    constexpr int NCH = HH * HW * 4;                                              // 8-channel chunks of one halo
+    constexpr int SL = (NCH + 255) / 256;
+    constexpr int WB = 18 * 96 + 16;                                              // LDS filter row: 18 k-tiles x 3 planes
+    constexpr int SW = 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sH = smem_raw;                                                          // [HH*HW][PB]
+    float* stage = reinterpret_cast<float*>(smem_raw + HH * HW * PB) + (threadIdx.x >> 6) * (32 * SW);
+    char* sW = smem_raw + HH * HW * PB + 4 * 32 * SW * 4;                         // [32][WB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.ow + TW - 1) / TW;
+    const int nct = (a.cout + 31) / 32;
+    const int ct = blockIdx.x % nct;                       // column tile fastest: the workgroups sharing a halo run together
+    const int strip = blockIdx.x / nct;
+    const int n = strip / tiles_x;
+    const int ox0 = (strip % tiles_x) * TW;
+    const int co0 = ct * 32;
+
+    for (int idx = tid; idx < 32 * 108; idx += 256) {      // 108 chunks of 16 B per packed filter row
+        const int row = idx / 108, ch = idx - row * 108;
+        const int col = min(co0 + row, a.cout - 1);
+        *reinterpret_cast<u32x4*>(sW + row * WB + ch * 16) =
+            *reinterpret_cast<const u32x4*>((const char*)a.w + (size_t)col * a.ktiles * 96 + ch * 16);
+    }
+
+    const int rrow = lane >> 2, col8 = (lane & 3) * 8;      // read-back layout of the epilogue: 4 lanes per 32 columns
+    const int colg = co0 + col8;
+    const int nvalid = min(8, a.cout - colg);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = min(colg + e, a.cout - 1);
+        sc[e] = a.scale[c];
+        sh[e] = a.shift[c];
+    }
+    const bool vec = (a.y_ld % 4 == 0) && ((((uintptr_t)a.y) & 15) == 0) &&
+                     (a.res == nullptr || ((a.res_ld % 4 == 0) && ((((uintptr_t)a.res) & 15) == 0)));
+
+    f32x4 hr[SL][2];
+    auto fetch = [&](int oy0) {
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (idx < NCH) {
+                const int pix = idx >> 2, ch = idx & 3;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int iy = oy0 + hy - a.pad_t, ix = ox0 + hx - a.pad_l;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw) {
+                    const float* p = a.x + ((size_t)(n * a.ih + iy) * a.iw + ix) * a.x_ld + ch * 8;
+                    v0 = *reinterpret_cast<const f32x4*>(p);
+                    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+            }
+            hr[k][0] = v0;
+            hr[k][1] = v1;
+        }
+    };
+    fetch(0);
+    for (int oy0 = 0; oy0 < a.oh; oy0 += TH) {
+        __syncthreads();                                   // previous tile: fragment reads and staging done
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < NCH) {
+                u32x4 pl[3];
+                split8<3>(hr[k][0], hr[k][1], true, pl);
+                char* dst = sH + (idx >> 2) * PB + (idx & 3) * 16;   // plane p of a pixel at +64*p
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 64) = pl[p];
+            }
+        }
+        __syncthreads();
+        if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under the MFMAs below
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, s_ = t - r * 3;
+            const char* ap = sH + ((wave + r) * HW + li + s_) * PB + 16 * lh;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u32x4 fa[3], fb[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    fa[p] = *reinterpret_cast<const u32x4*>(ap + p * 64 + c * 32);
+                    fb[p] = *reinterpret_cast<const u32x4*>(sW + li * WB + (t * 2 + c) * 96 + p * 32 + 16 * lh);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[prod_pa(3, q)]),
+                                                                  __builtin_bit_cast(bf16x8, fb[prod_pb(3, q)]), acc, 0, 0, 0);
+            }
+        }
+        const int oy = oy0 + wave;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 16 + rrow;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+            if (oy >= a.oh || nvalid <= 0 || ox0 + row >= a.ow) continue;
+            const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (a.res) {
+                const float* rp = a.res + m * a.res_ld + colg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < nvalid) v[e] += rp[e];
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (colg + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
+            }
+            float* yp = a.y + m * a.y_ld + colg;
+            if (vec && nvalid == 8) {
+                *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(yp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < nvalid) yp[e] = v[e];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
+    const int tiles_x = (a.ow + 31) / 32, nct = (a.cout + 31) / 32;
+    const size_t lds = (size_t)6 * 34 * 208 + 4 * 32 * 36 * 4 + 32 * (18 * 96 + 16);
+    static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!ok) return GV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(conv3x3_halo_x3, dim3((unsigned)(a.nb * tiles_x * nct)), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 // [kh][kw][cin][cout] fp32 -> [cout][k-tile][plane][16 bf16]
 template <int NP>
 __global__ void pack_filter_bf16s(const float* __restrict__ w, int K, int ktiles, int cout,
@@ -415,7 +569,14 @@ int launch_np(int cfg, const ConvArgs& a, bool generic, hipStream_t st) {
 
 namespace gvconv {
 
-int bf16s_num_cfgs() { return kNumTiles; }
+int bf16s_num_cfgs() { return kNumTiles + 1; }          // + the halo-tiled stem kernel (3 planes only)
+
+// the halo kernel's layer class: 3x3 / stride 1, 32 input channels, <= 64 output channels, plain epilogue
+bool bf16s_halo_ok(int planes, const ConvArgs& a, bool generic) {
+    return planes == 3 && !generic && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cin == 32 && a.cout <= 64 &&
+           a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.oh == a.ih + 2 * a.pad_t - 2 &&
+           a.ow == a.iw + 2 * a.pad_l - 2;
+}
 
 int bf16s_pick_tile(int /*planes*/, int M, int N, int /*K*/) {
     int best = 0;
@@ -439,6 +600,7 @@ int bf16s_launch(int planes, int cfg, const ConvArgs& a0, bool generic, hipStrea
     ConvArgs a = a0;
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
+    if (cfg == kNumTiles) return bf16s_halo_ok(planes, a, generic) ? launch_halo_x3(a, st) : GV_E_UNSUPPORTED;
     switch (planes) {
         case 3: return launch_np<3>(cfg, a, generic, st);
         case 2: return launch_np<2>(cfg, a, generic, st);

@@ -520,3 +520,22 @@ def test_per_shape_assign_and_fuse_vs_oracle(weight_mode, pool):
     _lib.check(lib().gv_group_assign_per_shape(sd2.data_ptr(), N, V, 9, 10, weight_mode, gidx.data_ptr(),
                                                scheme.data_ptr(), weight.data_ptr(), status.data_ptr(), st()), "assign")
     assert int(status.item()) & 1
+
+
+@pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70))])
+def test_halo_stem_kernel_fp32_storage(cout, pad, hw):
+    """The halo-tiled 3x3 kernel of Conv2d_2a/2b on fp32 storage (GV_MATH_BF16X3, tile configuration 11): ragged
+    strips, VALID and SAME, residual, channel-slice output — fp32-level agreement with the oracle and with the
+    implicit-GEMM kernel."""
+    g = torch.Generator().manual_seed(cout + pad)
+    ih, iw = hw
+    x = torch.randn(3, ih, iw, 32, generator=g)
+    w = torch.randn(3, 3, 32, cout, generator=g) * 0.06
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
+    res = torch.randn(3, oh, ow, cout, generator=g)
+    ref = oracle_conv(x, w, 1, "SAME" if pad else "VALID", scale, shift, True, residual=res).numpy()
+    y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, residual=res, tile=11, math=1, y_ld=cout + 8, y_off=4)
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+    y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, residual=res, tile=0, math=1, y_ld=cout + 8, y_off=4)
+    np.testing.assert_allclose(y, y0, rtol=2e-5, atol=2e-5)
