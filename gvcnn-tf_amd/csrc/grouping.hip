@@ -396,6 +396,34 @@ extern "C" int gv_group_assign_per_shape(const float* scores, int32_t num_shapes
     return GV_OK;
 }
 
+// eval.py:94-99: argmax, correct count, confusion matrix; one thread per shape
+__global__ void eval_metrics_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, int n,
+                                    int c, long long* __restrict__ prediction, int* __restrict__ confusion,
+                                    int* __restrict__ correct) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* row = logits + (size_t)i * c;
+    int best = 0;
+    float bv = row[0];
+    for (int k = 1; k < c; ++k)
+        if (row[k] > bv) { bv = row[k]; best = k; }               // strict >: the first maximum wins
+    prediction[i] = best;
+    const long long l = labels[i];
+    if (l >= 0 && l < c) {
+        atomicAdd(&confusion[(size_t)l * c + best], 1);
+        if (l == best) atomicAdd(correct, 1);
+    }
+}
+
+extern "C" int gv_eval_metrics(const float* logits, const int64_t* labels, int32_t n, int32_t c,
+                               int64_t* prediction, int32_t* confusion, int32_t* correct, void* stream) {
+    if (!logits || !labels || !prediction || !confusion || !correct || n <= 0 || c <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits,
+                       (const long long*)labels, n, c, (long long*)prediction, confusion, correct);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 extern "C" int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel,
                             const float* bias, int32_t c, float* y, void* stream) {
     if (!x || !kernel || !bias || !y || n <= 0 || f <= 0 || c <= 0) return GV_E_BADARG;

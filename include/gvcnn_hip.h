@@ -224,6 +224,13 @@ int gv_view_pool_fuse_fwd_per_shape(const void* F, int32_t num_views, int32_t nu
 int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel, const float* bias,
                  int32_t c, float* y, void* stream);
 
+/* ---- evaluation metrics (eval.py:94-99) ---------------------------------------------------------
+ * prediction[n] = argmax_c logits[n,c] (first maximum, like tf.argmax); confusion[label, prediction] += 1
+ * (tf.math.confusion_matrix, int32 [C,C], ACCUMULATED so a whole evaluation run needs one buffer);
+ * *correct += #{n : prediction[n] == labels[n]}.  labels int64 [N]; a label outside [0,C) is counted in neither. */
+int gv_eval_metrics(const float* logits, const int64_t* labels, int32_t n, int32_t c, int64_t* prediction,
+                    int32_t* confusion, int32_t* correct, void* stream);
+
 /* ---- training step (train.py:145,166-187, utils/train_utils.py:217-259) -----------
  * fp32.  Gradient outputs ACCUMULATE (+=) into caller-zeroed buffers, because a tensor that feeds several
  * consumers (an Inception block input, a ResNet shortcut) sums their gradients.

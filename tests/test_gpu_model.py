@@ -261,3 +261,43 @@ def test_bench_two_rank_control_flow_on_one_device():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_views"] == 2 * 2 * 12 and j["scaling"] == "weak"
     assert j["value"] > 0 and j["config"]["exchange"] == "scores"
+
+
+def test_eval_harness_metrics_and_protocols():
+    """SURVEY §8 f4 (eval.py:94-99,146-215): argmax / confusion matrix / correct count against numpy (ties -> first
+    maximum, out-of-range label ignored), mean-of-batch accuracy, and both calling protocols give the same result."""
+    import ctypes as C_
+    from gvcnn_tf_amd import _lib
+    from gvcnn_tf_amd.evaluate import Evaluator
+    rng = np.random.RandomState(3)
+    n, c = 37, 10
+    logits = rng.randn(n, c).astype(np.float32)
+    logits[5, 2] = logits[5, 7] = logits[5].max() + 1.0           # tie: first maximum (index 2)
+    labels = rng.randint(0, c, size=n).astype(np.int64)
+    labels[9] = 12                                                  # out of range: counted nowhere
+    ld, lab = torch.from_numpy(logits).to(DEV), torch.from_numpy(labels).to(DEV)
+    pred = torch.empty(n, dtype=torch.int64, device=DEV)
+    conf = torch.zeros(c, c, dtype=torch.int32, device=DEV)
+    corr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.load().gv_eval_metrics(ld.data_ptr(), lab.data_ptr(), n, c, pred.data_ptr(), conf.data_ptr(),
+                                           corr.data_ptr(), torch.cuda.current_stream().cuda_stream), "eval")
+    want_pred = logits.argmax(axis=1)
+    assert pred.cpu().numpy().tolist() == want_pred.tolist() and want_pred[5] == 2
+    want_conf = np.zeros((c, c), np.int32)
+    for l, p in zip(labels, want_pred):
+        if 0 <= l < c:
+            want_conf[l, p] += 1
+    assert conf.cpu().numpy().tolist() == want_conf.tolist()
+    assert int(corr.item()) == int(((labels == want_pred) & (labels < c)).sum())
+    # the harness: two batches through both protocols
+    N, V, G = 2, 6, 10
+    eng, P, Hd = make_engine("resnet_v2_50", N, V, 64, 64, c, G)
+    accs = []
+    for fused in (True, False):
+        ev = Evaluator(eng)
+        for seed in (1, 2):
+            ev.add_batch(views(N, V, 64, 64, seed=seed).to(DEV), torch.tensor([seed, 3]), fused=fused)
+        acc, cm, count = ev.result()
+        assert count == 4 and cm.sum() == 4 and abs(acc - sum(ev.batch_accuracies) / 2) < 1e-12
+        accs.append((acc, cm.tolist()))
+    assert accs[0] == accs[1]
