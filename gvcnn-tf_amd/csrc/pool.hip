@@ -182,6 +182,52 @@ inline unsigned grid_for(int64_t total) {
 
 }  // namespace
 
+// train_data.py:63,81-84,101: legacy bilinear resize + flips + brightness + x/255 - 0.5; thread per output pixel
+__global__ __launch_bounds__(256) void preprocess_views_kernel(const unsigned char* __restrict__ src, int nimg, int h0,
+                                                               int w0, int H, int W, const int* __restrict__ flip,
+                                                               const float* __restrict__ delta,
+                                                               float* __restrict__ dst) {
+    const int64_t total = (int64_t)nimg * H * W;
+    const float sy = (float)h0 / (float)H, sx = (float)w0 / (float)W;        // resize_images: scale = in / out
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int64_t t = idx / W;
+        const int y = (int)(t % H);
+        const int img = (int)(t / H);
+        const int f = flip ? flip[img] : 0;
+        const int xr = (f & 1) ? W - 1 - x : x;                               // a flip of the resized image
+        const int yr = (f & 2) ? H - 1 - y : y;
+        const float fy = __fmul_rn((float)yr, sy), fx = __fmul_rn((float)xr, sx);
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = min(y0 + 1, h0 - 1), x1 = min(x0 + 1, w0 - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const unsigned char* p = src + (size_t)img * h0 * w0 * 3;
+        const float d = delta ? delta[img] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float tl = p[((size_t)y0 * w0 + x0) * 3 + c], tr = p[((size_t)y0 * w0 + x1) * 3 + c];
+            const float bl = p[((size_t)y1 * w0 + x0) * 3 + c], br = p[((size_t)y1 * w0 + x1) * 3 + c];
+            const float top = __fadd_rn(tl, __fmul_rn(tr - tl, lx));
+            const float bot = __fadd_rn(bl, __fmul_rn(br - bl, lx));
+            float v = __fadd_rn(top, __fmul_rn(bot - top, ly));
+            v = __fadd_rn(v, d);
+            dst[idx * 3 + c] = __fadd_rn(__fmul_rn(v, 1.0f / 255.0f), -0.5f);
+        }
+    }
+}
+
+extern "C" int gv_preprocess_views(const uint8_t* src, int32_t nimg, int32_t h0, int32_t w0, int32_t height,
+                                   int32_t width, const int32_t* flip, const float* delta, float* dst,
+                                   void* stream) {
+    if (!src || !dst || nimg <= 0 || h0 <= 0 || w0 <= 0 || height <= 0 || width <= 0) return GV_E_BADARG;
+    const int64_t total = (int64_t)nimg * height * width;
+    hipLaunchKernelGGL(preprocess_views_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, nimg, h0,
+                       w0, height, width, flip, delta, dst);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void* stream) {
     if (!d || !x || !y) return GV_E_BADARG;
     if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->c <= 0 || d->kh <= 0 || d->kw <= 0 ||

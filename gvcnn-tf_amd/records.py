@@ -1,0 +1,289 @@
+"""Input pipeline of the reference, host side: the container formats, nothing more.
+
+    read_tfrecords(path)          GZIP TFRecord framing (train_data.py:22-24, create_modelnet_tf_record.py:141-142)
+    parse_example(record)         tf.Example with `image/encoded` (V PNG strings) and `image/label` (int64)
+                                  (train_data.py:47-54, create_modelnet_tf_record.py:119-129)
+    decode_png(data)              tf.image.decode_png(channels=3) (train_data.py:63): 8-bit gray / gray+alpha / RGB /
+                                  RGBA / palette, non-interlaced -> uint8 [h, w, 3]
+    ViewBatcher                   batches shapes, draws the augmentation decisions on the host RNG
+                                  (train_data.py:81-84) and hands the decoded bytes to ONE device launch
+                                  (gv_preprocess_views: resize + flips + brightness + x/255 - 0.5)
+
+The writer halves (write_tfrecords / make_example / encode_png) exist for tests and for building fixtures; they
+produce files the reference's own readers accept (masked CRC32C framing).  Pure Python + zlib: decoding stays on
+host cores, the arithmetic on the pixels happens on the device.
+"""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+
+# ------------------------------------------------------------------------------------------------
+# TFRecord framing: [length u64][masked crc32c(length) u32][data][masked crc32c(data) u32]
+# ------------------------------------------------------------------------------------------------
+_CRC_TABLE = None
+
+
+def _crc32c(data):
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        tab = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            tab.append(c)
+        _CRC_TABLE = tab
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _CRC_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _masked_crc(data):
+    c = _crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def read_tfrecords(path, check_crc=False):
+    """Yields the payload of every record of a (GZIP or plain) TFRecord file."""
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    opener = gzip.open if magic == b"\x1f\x8b" else open
+    with opener(path, "rb") as f:
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) < 12:
+                raise ValueError("truncated TFRecord header")
+            (length,), (lcrc,) = struct.unpack("<Q", head[:8]), struct.unpack("<I", head[8:])
+            if check_crc and _masked_crc(head[:8]) != lcrc:
+                raise ValueError("TFRecord length CRC mismatch")
+            data = f.read(length)
+            tail = f.read(4)
+            if len(data) < length or len(tail) < 4:
+                raise ValueError("truncated TFRecord")
+            if check_crc and _masked_crc(data) != struct.unpack("<I", tail)[0]:
+                raise ValueError("TFRecord data CRC mismatch")
+            yield data
+
+
+def write_tfrecords(path, records, compress=True):
+    opener = gzip.open if compress else open
+    with opener(path, "wb") as f:
+        for data in records:
+            head = struct.pack("<Q", len(data))
+            f.write(head + struct.pack("<I", _masked_crc(head)) + data + struct.pack("<I", _masked_crc(data)))
+
+
+# ------------------------------------------------------------------------------------------------
+# tf.Example (protobuf wire format, only what the features of this dataset need)
+# ------------------------------------------------------------------------------------------------
+def _varint(buf, pos):
+    out, shift = 0, 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+
+
+def _fields(buf):
+    """(field number, wire type, value) of one message; length-delimited values as memoryview slices."""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            val, pos = _varint(buf, pos)
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            val = buf[pos:pos + ln]
+            pos += ln
+        elif wt == 1:
+            val = buf[pos:pos + 8]
+            pos += 8
+        elif wt == 5:
+            val = buf[pos:pos + 4]
+            pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield num, wt, val
+
+
+def parse_example(record):
+    """tf.Example -> {feature name: list of bytes | list of int | list of float}."""
+    out = {}
+    buf = memoryview(record)
+    for num, _, features in _fields(buf):                           # Example.features = 1
+        if num != 1:
+            continue
+        for fnum, _, entry in _fields(features):                    # Features.feature (map entry) = 1
+            if fnum != 1:
+                continue
+            name, feat = None, None
+            for knum, _, val in _fields(entry):                     # key = 1, value = 2
+                if knum == 1:
+                    name = bytes(val).decode("utf8")
+                elif knum == 2:
+                    feat = val
+            values = []
+            for tnum, _, lst in _fields(feat):                      # bytes_list = 1, float_list = 2, int64_list = 3
+                for vnum, wt, val in _fields(lst):
+                    if tnum == 1:
+                        values.append(bytes(val))
+                    elif tnum == 3:
+                        if wt == 2:                                 # packed
+                            p = 0
+                            while p < len(val):
+                                v, p = _varint(val, p)
+                                values.append(v - (1 << 64) if v >> 63 else v)
+                        else:
+                            values.append(val - (1 << 64) if val >> 63 else val)
+                    elif tnum == 2:
+                        raw = bytes(val)
+                        values.extend(struct.unpack("<%df" % (len(raw) // 4), raw))
+            out[name] = values
+    return out
+
+
+def _enc_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(num, payload):
+    return _enc_varint((num << 3) | 2) + _enc_varint(len(payload)) + payload
+
+
+def make_example(encoded_views, label):
+    """tf.Example with `image/encoded` (list of PNG byte strings) and `image/label`."""
+    bl = b"".join(_ld(1, v) for v in encoded_views)
+    f_enc = _ld(1, b"image/encoded") + _ld(2, _ld(1, bl))
+    il = _ld(1, _enc_varint(int(label)))                              # packed int64
+    f_lab = _ld(1, b"image/label") + _ld(2, _ld(3, il))
+    return _ld(1, _ld(1, f_enc) + _ld(1, f_lab))
+
+
+# ------------------------------------------------------------------------------------------------
+# PNG (tf.image.decode_png(channels=3)): 8-bit, non-interlaced
+# ------------------------------------------------------------------------------------------------
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+def decode_png(data):
+    if data[:8] != _PNG_SIG:
+        raise ValueError("not a PNG")
+    pos, idat, plte, trns = 8, [], None, None
+    w = h = depth = ctype = None
+    while pos < len(data):
+        ln, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+        if kind == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            if depth != 8 or interlace:
+                raise ValueError("only 8-bit non-interlaced PNGs are supported")
+        elif kind == b"PLTE":
+            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, 1 + w * ch)
+    img = np.zeros((h, w * ch), np.uint8)
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:                                   # Sub / Average / Paeth depend on the pixel to the left
+            cur = np.zeros(w * ch, np.int32)
+            for x in range(w * ch):
+                a = cur[x - ch] if x >= ch else 0
+                b = prev[x]
+                c = prev[x - ch] if x >= ch else 0
+                if ft == 1:
+                    p = a
+                elif ft == 3:
+                    p = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[x] = (line[x] + p) & 255
+        img[y] = cur
+        prev = cur
+    img = img.reshape(h, w, ch)
+    if ctype == 3:
+        return plte[img[..., 0]]
+    if ctype in (0, 4):
+        return np.repeat(img[..., :1], 3, axis=2)
+    return np.ascontiguousarray(img[..., :3])
+
+
+def encode_png(img):
+    """uint8 [h, w, 3] -> PNG bytes (filter 0 on every line)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, _ = img.shape
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    return (_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+# ------------------------------------------------------------------------------------------------
+# batches for the engine
+# ------------------------------------------------------------------------------------------------
+class ViewBatcher:
+    """TFRecord shapes -> (views [N, V, H, W, 3] fp32 on the device, labels [N]).  All views of a file must share one
+    decoded size (the ModelNet renders do).  augment=True draws the flips and the brightness delta of
+    train_data.py:81-84 per view from `rng`."""
+
+    def __init__(self, path, num_views, height, width, batch_size, device, augment=False, seed=0):
+        self.path, self.V, self.H, self.W, self.N = path, num_views, height, width, batch_size
+        self.device, self.augment = device, augment
+        self.rng = np.random.RandomState(seed)
+
+    def __iter__(self):
+        import torch
+        from . import _lib
+        from .model import _st
+        lib = _lib.load()
+        imgs, labels = [], []
+        for rec in read_tfrecords(self.path):
+            ex = parse_example(rec)
+            enc = ex["image/encoded"]
+            if len(enc) != self.V:
+                raise ValueError("record holds %d views, expected %d" % (len(enc), self.V))
+            imgs.append(np.stack([decode_png(e) for e in enc]))
+            labels.append(int(ex["image/label"][0]))
+            if len(imgs) == self.N:
+                raw = np.stack(imgs)                                    # [N, V, h0, w0, 3] uint8
+                nimg, h0, w0 = self.N * self.V, raw.shape[2], raw.shape[3]
+                src = torch.from_numpy(raw).to(self.device)
+                dst = torch.empty((self.N, self.V, self.H, self.W, 3), dtype=torch.float32, device=self.device)
+                flip = delta = None
+                if self.augment:
+                    flip = torch.from_numpy(self.rng.randint(0, 4, size=nimg).astype(np.int32)).to(self.device)
+                    delta = torch.from_numpy(self.rng.uniform(-1.1, 1.1, size=nimg).astype(np.float32)).to(self.device)
+                _lib.check(lib.gv_preprocess_views(src.data_ptr(), nimg, h0, w0, self.H, self.W,
+                                                   flip.data_ptr() if flip is not None else None,
+                                                   delta.data_ptr() if delta is not None else None, dst.data_ptr(),
+                                                   _st()), "gv_preprocess_views")
+                yield dst, torch.tensor(labels, dtype=torch.int64)
+                imgs, labels = [], []

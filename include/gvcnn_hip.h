@@ -224,6 +224,16 @@ int gv_view_pool_fuse_fwd_per_shape(const void* F, int32_t num_views, int32_t nu
 int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel, const float* bias,
                  int32_t c, float* y, void* stream);
 
+/* ---- input preprocessing (train_data.py:63,81-84,101; eval_data.py:72,109) -----------------------
+ * One launch turns a batch of decoded 8-bit RGB views [nimg, h0, w0, 3] into the network input [nimg, H, W, 3] fp32:
+ *   tf.image.resize (TF1 resize_images: bilinear, align_corners=False, src = dst * in/out — no half-pixel shift),
+ *   random_flip_left_right / random_flip_up_down (bit 0 / bit 1 of flip[img]; NULL = none),
+ *   random_brightness (delta[img] added on the 0..255 scale; NULL = none),
+ *   x * (1/255) - 0.5.
+ * The random decisions are made by the caller (host RNG), the arithmetic happens here. */
+int gv_preprocess_views(const uint8_t* src, int32_t nimg, int32_t h0, int32_t w0, int32_t height, int32_t width,
+                        const int32_t* flip, const float* delta, float* dst, void* stream);
+
 /* ---- evaluation metrics (eval.py:94-99) ---------------------------------------------------------
  * prediction[n] = argmax_c logits[n,c] (first maximum, like tf.argmax); confusion[label, prediction] += 1
  * (tf.math.confusion_matrix, int32 [C,C], ACCUMULATED so a whole evaluation run needs one buffer);

@@ -301,3 +301,36 @@ def test_eval_harness_metrics_and_protocols():
         assert count == 4 and cm.sum() == 4 and abs(acc - sum(ev.batch_accuracies) / 2) < 1e-12
         accs.append((acc, cm.tolist()))
     assert accs[0] == accs[1]
+
+
+def test_input_pipeline_preprocess_and_batcher(tmp_path):
+    """gv_preprocess_views (legacy bilinear resize, flips, brightness, x/255 - 0.5) against the numpy
+    oracle, and a GZIP TFRecord of PNG views through ViewBatcher into the engine's input layout."""
+    import os
+    from gvcnn_tf_amd import _lib, records as R
+    from oracle import preprocess as OP
+    rng = np.random.RandomState(2)
+    nimg, h0, w0, H, W = 5, 37, 53, 64, 48
+    src = rng.randint(0, 256, size=(nimg, h0, w0, 3)).astype(np.uint8)
+    flip = np.array([0, 1, 2, 3, 0], np.int32)
+    delta = rng.uniform(-1.1, 1.1, size=nimg).astype(np.float32)
+    sd, fd, dd = torch.from_numpy(src).to(DEV), torch.from_numpy(flip).to(DEV), torch.from_numpy(delta).to(DEV)
+    out = torch.empty(nimg, H, W, 3, device=DEV)
+    st_ = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.load().gv_preprocess_views(sd.data_ptr(), nimg, h0, w0, H, W, fd.data_ptr(), dd.data_ptr(),
+                                               out.data_ptr(), st_), "preprocess")
+    np.testing.assert_allclose(out.cpu().numpy(), OP.preprocess_views(src, H, W, flip, delta), rtol=0, atol=2e-6)
+    _lib.check(_lib.load().gv_preprocess_views(sd.data_ptr(), nimg, h0, w0, h0, w0, None, None,
+                                               torch.empty(nimg, h0, w0, 3, device=DEV).data_ptr(), st_), "preprocess")
+    # records -> batches
+    N, V = 2, 3
+    shapes = [([rng.randint(0, 256, size=(20, 24, 3)).astype(np.uint8) for _ in range(V)], 7 - i) for i in range(4)]
+    path = os.path.join(tmp_path, "train.record")
+    R.write_tfrecords(path, [R.make_example([R.encode_png(v) for v in vs], lab) for vs, lab in shapes])
+    batches = list(R.ViewBatcher(path, V, 32, 32, N, DEV))
+    assert len(batches) == 2
+    for b, (x, labels) in enumerate(batches):
+        assert tuple(x.shape) == (N, V, 32, 32, 3) and labels.tolist() == [shapes[2 * b][1], shapes[2 * b + 1][1]]
+        want = OP.preprocess_views(np.stack([v for k in (2 * b, 2 * b + 1) for v in shapes[k][0]]), 32, 32)
+        np.testing.assert_allclose(x.cpu().numpy().reshape(N * V, 32, 32, 3), want, rtol=0, atol=2e-6)
+        assert float(x.min()) >= -0.5 and float(x.max()) <= 0.5 + 1e-6     # 255 * fp32(1/255) - 0.5 = 0.50000006
