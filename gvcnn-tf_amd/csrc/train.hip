@@ -257,10 +257,13 @@ __global__ __launch_bounds__(256) void pool2d_bwd_f32(const float* __restrict__ 
 __global__ __launch_bounds__(256) void view_pool_fuse_bwd_f32(
     const float* __restrict__ F, const float* __restrict__ dS, int V, int N, int64_t E, int64_t view_stride,
     int64_t shape_stride, const int* __restrict__ scheme, int G, const float* __restrict__ weight, int mode,
-    float* __restrict__ dF) {
+    float* __restrict__ dF, int64_t scheme_stride, int64_t weight_stride) {
     __shared__ unsigned long long s_mask[64];
     __shared__ float s_w[64];
     __shared__ float s_wsum;
+    const int n = blockIdx.y;                       // one shape per grid row: its own scheme when strides != 0
+    scheme += (size_t)n * scheme_stride;
+    weight += (size_t)n * weight_stride;
     for (int g = threadIdx.x; g < G; g += 256) {
         unsigned long long m = 0;
         for (int v = 0; v < V; ++v)
@@ -275,13 +278,10 @@ __global__ __launch_bounds__(256) void view_pool_fuse_bwd_f32(
         s_wsum = ws;
     }
     __syncthreads();
-    const int64_t total = (int64_t)N * E;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(idx / E);
-        const int64_t e = idx - (int64_t)n * E;
+    if (s_wsum == 0.f) return;                      // (per-shape, mean-score weights) S = 0 for this shape: no gradient
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         const size_t base = (size_t)n * shape_stride + e;
-        const float ds = dS[idx];
+        const float ds = dS[(size_t)n * E + e];
         for (int g = 0; g < G; ++g) {
             const unsigned long long m0 = s_mask[g];
             if (m0 == 0) continue;
@@ -810,18 +810,36 @@ extern "C" int gv_pool2d_bwd(const gv_pool_desc* d, const float* x, const float*
     return GV_OK;
 }
 
+static int pool_fuse_bwd_launch(const float* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
+                                int64_t view_stride, int64_t shape_stride, const int32_t* scheme, int32_t num_groups,
+                                const float* weight, int32_t mode, float* dF, void* stream, int64_t scheme_stride,
+                                int64_t weight_stride) {
+    if (!F || !dS || !scheme || !weight || !dF) return GV_E_BADARG;
+    if (num_views <= 0 || num_shapes <= 0 || E <= 0 || num_groups <= 0) return GV_E_BADARG;
+    if (num_views > 64 || num_groups > 64 || num_shapes > 65535) return GV_E_UNSUPPORTED;
+    int64_t bx = (E + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(view_pool_fuse_bwd_f32, dim3((unsigned)bx, (unsigned)num_shapes), dim3(256), 0,
+                       (hipStream_t)stream, F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme,
+                       num_groups, weight, mode, dF, scheme_stride, weight_stride);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 extern "C" int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes,
                                      int64_t E, int64_t view_stride, int64_t shape_stride,
                                      const int32_t* scheme, int32_t num_groups, const float* weight,
                                      int32_t mode, float* dF, void* stream) {
-    if (!F || !dS || !scheme || !weight || !dF) return GV_E_BADARG;
-    if (num_views <= 0 || num_shapes <= 0 || E <= 0 || num_groups <= 0) return GV_E_BADARG;
-    if (num_views > 64 || num_groups > 64) return GV_E_UNSUPPORTED;
-    hipLaunchKernelGGL(view_pool_fuse_bwd_f32, dim3(grid_for((int64_t)num_shapes * E)), dim3(256), 0,
-                       (hipStream_t)stream, F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme,
-                       num_groups, weight, mode, dF);
-    GV_LAUNCH_CHECK();
-    return GV_OK;
+    return pool_fuse_bwd_launch(F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme, num_groups, weight,
+                                mode, dF, stream, 0, 0);
+}
+
+extern "C" int gv_view_pool_fuse_bwd_per_shape(const float* F, const float* dS, int32_t num_views,
+                                               int32_t num_shapes, int64_t E, int64_t view_stride,
+                                               int64_t shape_stride, const int32_t* scheme, int32_t num_groups,
+                                               const float* weight, int32_t mode, float* dF, void* stream) {
+    return pool_fuse_bwd_launch(F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme, num_groups, weight,
+                                mode, dF, stream, (int64_t)num_groups * num_views, num_groups);
 }
 
 extern "C" int gv_global_avg_pool_bwd(const float* dgap, int32_t nb, int32_t hw, int32_t c, float* dx,

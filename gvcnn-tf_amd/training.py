@@ -113,12 +113,15 @@ class TrainGVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=2, num_views=6, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2,
-                 head_views=None, view_offset=0):
+                 head_views=None, view_offset=0, per_shape=False, weight_mode="count"):
         """head_views / view_offset: view-sharded data parallelism (sharding.ShardedTrainGVCNN) — this engine
         runs the backbone for views [view_offset, view_offset + num_views) of the head_views views of every shape
         (so each view's BatchNorm statistics stay on one rank, exactly the reference's per-view statistics),
         while the grouping head works on all head_views views."""
         self.lib = _lib.load()
+        # per_shape: the paper's grouping (model.GVCNN(per_shape=True), DESIGN §3c) in the training step
+        self.per_shape = bool(per_shape)
+        self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
         self.Vh = head_views if head_views is not None else num_views
         self.view_offset = view_offset
         assert 0 <= view_offset and view_offset + num_views <= self.Vh
@@ -194,6 +197,11 @@ class TrainGVCNN:
             self.scheme = torch.empty((num_group, self.Vh), dtype=torch.int32, device=dev)
             self.weight = torch.empty(num_group, dtype=f32, device=dev)
             self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+            if self.per_shape:
+                self.scores_ps = torch.empty((num_shapes, self.Vh), dtype=f32, device=dev)
+                self.gidx_ps = torch.empty((num_shapes, self.Vh), dtype=torch.int32, device=dev)
+                self.scheme_ps = torch.empty((num_shapes, num_group, self.Vh), dtype=torch.int32, device=dev)
+                self.weight_ps = torch.empty((num_shapes, num_group), dtype=f32, device=dev)
             f = self.final
             self.S = torch.empty((num_shapes, f.h, f.w, f.c), dtype=f32, device=dev)
             self.dS = torch.empty_like(self.S)
@@ -344,6 +352,26 @@ class TrainGVCNN:
         r_img = self.r_img if r_img is None else r_img
         assert r_img.numel() == self.N * V
         self._F = F
+        f = self.final
+        E = f.h * f.w * f.c
+        F_ptr = self._ptr(f) if F is None else F.data_ptr()
+        if self.per_shape:
+            assert g_scheme is None, "per-shape grouping derives its schemes on the device"
+            _lib.check(lib.gv_view_score_per_shape(r_img.data_ptr(), self.N * V, self.scores_ps.data_ptr(), _st()),
+                       "score per shape")
+            _lib.check(lib.gv_group_assign_per_shape(self.scores_ps.data_ptr(), self.N, V, self.G, self.num_bins,
+                                                     self.weight_mode, self.gidx_ps.data_ptr(),
+                                                     self.scheme_ps.data_ptr(), self.weight_ps.data_ptr(),
+                                                     self.status.data_ptr(), _st()), "assign per shape")
+            if check:
+                st_ = int(self.status.item())
+                if st_:
+                    _raise_for_status(st_, self.gidx_ps.reshape(-1), self.G)
+            _lib.check(lib.gv_view_pool_fuse_fwd_per_shape(F_ptr, V, self.N, E, E, V * E, self.scheme_ps.data_ptr(),
+                                                           self.G, self.weight_ps.data_ptr(), self.pool_mode,
+                                                           self.empty_fill, None, self.S.data_ptr(), _lib.GV_F32,
+                                                           _st()), "pool_fuse per shape")
+            return self._classify_and_loss(labels, self.scores_ps)
         _lib.check(lib.gv_view_score_finalize(r_img.data_ptr(), self.N, V, _lib.GV_ORDER_SHAPE_MAJOR,
                                               self.scores.data_ptr(), _st()), "score finalize")
         if g_scheme is None:
@@ -355,12 +383,13 @@ class TrainGVCNN:
         else:
             self.scheme.copy_(torch.as_tensor(np.asarray(g_scheme), dtype=torch.int32))
             self.weight.copy_(torch.as_tensor(np.asarray(g_weight), dtype=torch.float32))
-        f = self.final
-        E = f.h * f.w * f.c
-        F_ptr = self._ptr(f) if F is None else F.data_ptr()
         _lib.check(lib.gv_view_pool_fuse_fwd(F_ptr, V, self.N, E, E, V * E, self.scheme.data_ptr(), self.G,
                                              self.weight.data_ptr(), self.pool_mode, self.empty_fill, None,
                                              self.S.data_ptr(), _lib.GV_F32, _st()), "pool_fuse")
+        return self._classify_and_loss(labels, self.scores)
+
+    def _classify_and_loss(self, labels, scores):
+        lib, f = self.lib, self.final
         _lib.check(lib.gv_global_avg_pool(self.S.data_ptr(), self.N, f.h * f.w, f.c, f.c, self.gap.data_ptr(),
                                           _lib.GV_F32, _st()), "gap")
         kn, bn = self.cls_names
@@ -371,7 +400,7 @@ class TrainGVCNN:
             self._labels = labels.to(device=self.device, dtype=torch.int64).contiguous()
             _lib.check(lib.gv_softmax_ce(self.logits.data_ptr(), self._labels.data_ptr(), self.N, self.num_classes,
                                          self.loss.data_ptr(), self.dlogits.data_ptr(), _st()), "softmax_ce")
-        return self.scores, self.S, self.logits, self.loss
+        return scores, self.S, self.logits, self.loss
 
     # -- backward ----------------------------------------------------------------------------------------
     def backward(self):
@@ -399,9 +428,14 @@ class TrainGVCNN:
                                               _st()), "gap_bwd")
         F_ptr = self._ptr(f) if self._F is None else self._F.data_ptr()
         dF_ptr = self._ptr(f, grad=True) if dF is None else dF.data_ptr()
-        _lib.check(lib.gv_view_pool_fuse_bwd(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E,
-                                             self.scheme.data_ptr(), self.G, self.weight.data_ptr(), self.pool_mode,
-                                             dF_ptr, _st()), "pool_fuse_bwd")
+        if self.per_shape:
+            _lib.check(lib.gv_view_pool_fuse_bwd_per_shape(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E,
+                                                           self.scheme_ps.data_ptr(), self.G, self.weight_ps.data_ptr(),
+                                                           self.pool_mode, dF_ptr, _st()), "pool_fuse_bwd per shape")
+        else:
+            _lib.check(lib.gv_view_pool_fuse_bwd(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E,
+                                                 self.scheme.data_ptr(), self.G, self.weight.data_ptr(), self.pool_mode,
+                                                 dF_ptr, _st()), "pool_fuse_bwd")
 
     def final_grad(self):
         """[N, V, h, w, C] view of the gradient buffer of the final tap (allocated on first use)."""

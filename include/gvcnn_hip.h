@@ -291,6 +291,11 @@ int gv_pool2d_bwd(const gv_pool_desc* d, const float* x, const float* dy, int32_
 int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
                           int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
                           int32_t num_groups, const float* weight, int32_t mode, float* dF, void* stream);
+/* The same with one scheme [G,V] / weight [G] per shape (gv_view_pool_fuse_fwd_per_shape); the scores that produced
+ * scheme and weight receive no gradient (they are constants of the backward pass, as in the batch form). */
+int gv_view_pool_fuse_bwd_per_shape(const float* F, const float* dS, int32_t num_views, int32_t num_shapes,
+                                    int64_t E, int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
+                                    int32_t num_groups, const float* weight, int32_t mode, float* dF, void* stream);
 int gv_global_avg_pool_bwd(const float* dgap, int32_t nb, int32_t hw, int32_t c, float* dx, int32_t dx_ld,
                            void* stream);
 /* Mean sparse-softmax cross-entropy (train.py:145): loss (device scalar) and dlogits = (softmax-onehot)/n. */

@@ -359,3 +359,68 @@ def test_bn_moving_average_update():
     np.testing.assert_allclose(eng.params[name + "/moving_mean"].cpu().numpy(), omm, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(eng.params[name + "/moving_variance"].cpu().numpy(), omv, rtol=1e-6, atol=1e-7)
     assert not torch.equal(eng.params[name + "/moving_mean"], mm0)
+
+
+@pytest.mark.parametrize("weight_mode,pool", [(0, "max"), (1, "max"), (1, "mean")])
+def test_per_shape_fuse_backward_vs_autograd(weight_mode, pool):
+    """gv_view_pool_fuse_bwd_per_shape: every shape has its own scheme/weights (constants of the backward pass); ties
+    split equally; a shape whose weights sum to 0 (mean_score, all scores 0) gets no gradient."""
+    rng = np.random.RandomState(5 + weight_mode)
+    N, V, G, E = 4, 6, 10, 40
+    scores = rng.uniform(0, 0.99, size=(N, V)).astype(np.float32)
+    scores[2] = 0.0
+    Fh = rng.randn(N, V, E).astype(np.float32)
+    Fh[1, 3] = Fh[1, 0]                                         # a full tie between two views of shape 1
+    scores[1, 3] = scores[1, 0]                                 # ... in the same group
+    dS = rng.randn(N, E).astype(np.float32)
+    sd, Fd, dSd = torch.from_numpy(scores).to(DEV), torch.from_numpy(Fh).to(DEV), torch.from_numpy(dS).to(DEV)
+    gidx = torch.empty(N, V, dtype=torch.int32, device=DEV)
+    scheme = torch.empty(N, G, V, dtype=torch.int32, device=DEV)
+    weight = torch.empty(N, G, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib().gv_group_assign_per_shape(sd.data_ptr(), N, V, G, 10, weight_mode, gidx.data_ptr(),
+                                               scheme.data_ptr(), weight.data_ptr(), status.data_ptr(), st()), "assign")
+    mode = _lib.GV_VIEWPOOL_MAX if pool == "max" else _lib.GV_VIEWPOOL_MEAN
+    dF = torch.zeros(N, V, E, device=DEV)
+    _lib.check(lib().gv_view_pool_fuse_bwd_per_shape(Fd.data_ptr(), dSd.data_ptr(), V, N, E, E, V * E, scheme.data_ptr(),
+                                                     G, weight.data_ptr(), mode, dF.data_ptr(), st()), "bwd")
+    # autograd through the oracle-shaped forward, shape by shape
+    Ft = torch.from_numpy(Fh).requires_grad_(True)
+    sch, w = scheme.cpu().numpy(), weight.cpu().numpy()
+    total = 0.0
+    for n in range(N):
+        if float(w[n].sum()) == 0.0:
+            continue
+        acc = 0.0
+        for g in range(G):
+            idx = np.nonzero(sch[n, g])[0]
+            if idx.size == 0:
+                d = torch.ones(E)
+            elif pool == "max":
+                d = torch.amax(Ft[n, torch.as_tensor(idx)], dim=0)
+            else:
+                d = Ft[n, torch.as_tensor(idx)].mean(dim=0)
+            acc = acc + float(w[n, g]) * d
+        total = total + ((acc / float(w[n].sum())) * torch.from_numpy(dS[n])).sum()
+    total.backward()
+    close(dF.cpu(), Ft.grad, 1e-5)
+    if weight_mode == 1:
+        assert float(dF[2].abs().max()) == 0.0
+
+
+def test_training_engine_with_per_shape_grouping():
+    """TrainGVCNN(per_shape=True): the head is the per-shape module (checked against the oracle on the engine's own
+    descriptors / responses) and the backward pass runs through it."""
+    from oracle import grouping as OG
+    N, V, C_, G = 3, 4, 5, 10
+    eng = TrainGVCNN("resnet_v2_50", N, V, 64, 64, C_, G, device=DEV, per_shape=True, weight_mode="mean_score")
+    x = (torch.rand(N, V, 64, 64, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    scores, S, logits, loss = eng.forward(x, torch.tensor([0, 1, 2]))
+    f = eng.final
+    Fh = eng.view(f).view(N, V, f.h, f.w, f.c).cpu().numpy()
+    o_scores, o_sch, o_w, o_S = OG.per_shape_grouping(Fh, eng.r_img.cpu().numpy().reshape(N, V), G, weight_mode="mean_score")
+    np.testing.assert_allclose(scores.cpu().numpy(), o_scores, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(S.cpu().numpy(), o_S, rtol=1e-5, atol=1e-5 * float(np.abs(o_S).max()))
+    grads = eng.backward()
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert np.isfinite(float(loss)) and np.isfinite(gn) and gn > 0
