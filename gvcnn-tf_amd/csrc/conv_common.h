@@ -92,6 +92,7 @@ int64_t bf16s_packed_bytes(int kh, int kw, int cin, int cout, int planes);
 int lp_num_cfgs();
 int lp_pick_tile(int M, int N, int K);
 bool lp_halo_ok(const ConvArgs& a, bool generic);
+bool lp_stem_ok(const ConvArgs& a, bool xf32);
 int lp_launch(int dtype, int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st);
 int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int dtype, void* out, hipStream_t st);
 int64_t lp_packed_bytes(int kh, int kw, int cin, int cout);

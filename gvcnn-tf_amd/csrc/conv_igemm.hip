@@ -476,7 +476,8 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1
-                           : (gvconv::lp_halo_ok(a, generic) && a.M >= 100000 ? gvconv::lp_num_cfgs() - 1
+                           : ((gvconv::lp_halo_ok(a, generic) || gvconv::lp_stem_ok(a, xf32)) && a.M >= 100000
+                                  ? gvconv::lp_num_cfgs() - 1
                                                                               : gvconv::lp_pick_tile(a.M, a.cout, a.K)));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
     }

@@ -604,6 +604,136 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 3-channel stems (Inception Conv2d_1a 3x3/2, ResNet conv1 7x7/2 with explicit pad) straight from the fp32
+// images (GV_CONV_X_F32).  The gather path of conv_igemm_lp issues one 4-byte global load, one table lookup and a
+// bounds test per (pixel, k) element.  Here a workgroup owns a 32-pixel-wide column strip of one image and walks down
+// it 4 output rows at a time: the input patch ((3*2 + KW) rows x (31*2 + KW) pixels x 3 channels) is loaded with
+// coalesced row reads, rounded to the storage type once and kept in LDS; k is re-ordered row-wise — filter row r
+// owns KR = 16 (3x3) or 24 (7x7) slots of which KW*3 are real — so the 8 values of an MFMA fragment are 8
+// CONSECUTIVE patch elements: four ds_read_b32 (lane stride 12 B: conflict-free), no per-element addressing at all.
+// The filter is re-ordered the same way into LDS once per workgroup.
+template <typename T, int TN, int KW>
+__global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
+    constexpr int KR = KW == 3 ? 16 : 24;                   // k slots per filter row (multiple of 8)
+    constexpr int NG = (KW * KR / 8 + 1) / 2 * 2;           // 8-value groups, padded to whole 16-deep k-steps
+    constexpr int PR = 3 * 2 + KW + 1;                      // patch rows (+1 zero row for the padding group)
+    constexpr int PC = 31 * 2 + KW;                         // patch pixels per row
+    constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;    // patch row bytes (+ slack for the last fragment)
+    constexpr int NEL = (PR - 1) * PC * 3;                  // patch elements loaded per tile
+    constexpr int SL = (NEL + 255) / 256;
+    constexpr int WB = NG * 16 + 16;                        // LDS filter row bytes
+    constexpr int SW = 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sP = smem_raw;                                                      // [PR][PITCH]
+    float* stage = reinterpret_cast<float*>(smem_raw + PR * PITCH) + (threadIdx.x >> 6) * (32 * SW);
+    char* sW = smem_raw + PR * PITCH + 4 * 32 * SW * 4;                       // [32*TN][WB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.ow + 31) / 32;
+    const int n = blockIdx.x / tiles_x;
+    const int ox0 = (blockIdx.x % tiles_x) * 32;
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.w);
+    unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
+
+    for (int idx = tid; idx < 32 * TN * NG * 8; idx += 256) {               // filter in the row-wise k order
+        const int row = idx / (NG * 8), kk = idx - row * (NG * 8);
+        const int r = kk / KR, j = kk - r * KR;
+        unsigned short v = 0;
+        if (row < a.cout && r < KW && j < KW * 3) v = wp[(size_t)row * a.Kpad + r * KW * 3 + j];
+        *reinterpret_cast<unsigned short*>(sW + row * WB + kk * 2) = v;
+    }
+    for (int idx = tid; idx < PR * PITCH / 4; idx += 256)                    // zero row + the slack at every row end
+        reinterpret_cast<unsigned*>(sP)[idx] = 0u;                           // (read against zero filter slots)
+
+    const int rrow = lane >> 2, col8 = (lane & 3) * 8;
+    float sc[TN][8], sh[TN][8];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = min(j * 32 + col8 + e, a.cout - 1);
+            sc[j][e] = a.scale[c];
+            sh[j][e] = a.shift[c];
+        }
+    const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0);
+
+    float pr_[SL];
+    auto fetch = [&](int oy0) {
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            float v = 0.f;
+            if (idx < NEL) {
+                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
+                const int px = e / 3, ch = e - px * 3;
+                const int iy = oy0 * 2 - a.pad_t + prow, ix = ox0 * 2 - a.pad_l + px;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
+                    v = a.x[((size_t)(n * a.ih + iy) * a.iw + ix) * a.x_ld + ch];
+            }
+            pr_[k] = v;
+        }
+    };
+    fetch(0);
+    for (int oy0 = 0; oy0 < a.oh; oy0 += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < NEL) {
+                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
+                *reinterpret_cast<unsigned short*>(sP + prow * PITCH + e * 2) = to_bits<T>(pr_[k]);
+            }
+        }
+        __syncthreads();
+        if (oy0 + 4 < a.oh) fetch(oy0 + 4);
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NG / 2; ++c) {
+            const int g = 2 * c + lh;                      // this half-wave's 8-value group
+            const int r = g / (KR / 8), q = g - r * (KR / 8);   // filter row, 8-slot group inside it
+            const int prow = r < KW ? 2 * wave + r : PR - 1;    // the padding group reads the zero row
+            const char* ap = sP + prow * PITCH + li * 12 + q * 16;
+            u32x4 fa;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) fa[d] = *reinterpret_cast<const unsigned*>(ap + 4 * d);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const u32x4 b = *reinterpret_cast<const u32x4*>(sW + (j * 32 + li) * WB + g * 16);
+                acc[j] = mfma16<T>(fa, b, acc[j]);
+            }
+        }
+        const int oy = oy0 + wave;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int colj = j * 32 + col8;
+            const int nvalid = min(8, a.cout - colj);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = pass * 16 + rrow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+                if (oy >= a.oh || nvalid <= 0 || ox0 + row >= a.ow) continue;
+                const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = v[e] * sc[j][e] + sh[j][e];
+                    if (a.relu && colj + e < a.relu_limit) v[e] = fmaxf(v[e], 0.f);
+                }
+                store_chunk<T>(y + m * a.y_ld + colj, v, nvalid, vec);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // [kh][kw][cin][cout] fp32 -> [cout][Kpad] T, k = (r*kw+s)*cin + c, zero filled to a multiple of 32
 template <typename T>
 __global__ void pack_filter_lp(const float* __restrict__ w, int K, int Kpad, int cout,
@@ -686,11 +816,34 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
     return GV_OK;
 }
 
+template <typename T, int TN, int KW>
+int launch_stem_one(const ConvArgs& a, hipStream_t st) {
+    constexpr int KR = KW == 3 ? 16 : 24, NG = (KW * KR / 8 + 1) / 2 * 2, PR = 3 * 2 + KW + 1, PC = 31 * 2 + KW;
+    constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;
+    const size_t lds = (size_t)PR * PITCH + 4 * 32 * 36 * 4 + (size_t)32 * TN * (NG * 16 + 16);
+    hipLaunchKernelGGL((conv_stem_patch_lp<T, TN, KW>), dim3((unsigned)(a.nb * ((a.ow + 31) / 32))), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
+int launch_stem(const ConvArgs& a, hipStream_t st) {
+    if (a.kw == 3) return a.cout <= 32 ? launch_stem_one<T, 1, 3>(a, st) : launch_stem_one<T, 2, 3>(a, st);
+    return a.cout <= 32 ? launch_stem_one<T, 1, 7>(a, st) : launch_stem_one<T, 2, 7>(a, st);
+}
+
 }  // namespace
 
 namespace gvconv {
 
-int lp_num_cfgs() { return kNumTiles + 1; }               // + the halo-tiled stem kernel
+int lp_num_cfgs() { return kNumTiles + 1; }               // + the strip kernels of the stem layers
+
+// the 3-channel stems read from the fp32 images: square 3x3 or 7x7 window, stride 2, <= 64 output channels
+bool lp_stem_ok(const ConvArgs& a, bool xf32) {
+    return xf32 && a.cin == 3 && a.kh == a.kw && (a.kw == 3 || a.kw == 7) && a.stride == 2 && a.cout <= 64 &&
+           a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.res == nullptr &&
+           (int64_t)a.nb * a.ih * a.iw * a.x_ld < 0x7fffffffll;
+}
 
 // the halo kernel's layer class: 3x3 / stride 1, 32 input channels in 16-byte aligned pixels, <= 64 output channels,
 // plain epilogue (Conv2d_2a_3x3, Conv2d_2b_3x3)
@@ -723,6 +876,11 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
     if (cfg == kNumTiles) {
+        if (lp_stem_ok(a, xf32)) {
+            if (dtype == GV_BF16) return launch_stem<__bf16>(a, st);
+            if (dtype == GV_F16) return launch_stem<_Float16>(a, st);
+            return GV_E_UNSUPPORTED;
+        }
         if (!lp_halo_ok(a, generic)) return GV_E_UNSUPPORTED;
         if (dtype == GV_BF16) return launch_halo<__bf16>(a, st);
         if (dtype == GV_F16) return launch_halo<_Float16>(a, st);

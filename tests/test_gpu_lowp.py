@@ -177,6 +177,26 @@ def test_lp_halo_stem_kernel(ty, cout, pad, hw):
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("k,pad,cout,hw", [(3, 0, 32, (47, 75)), (7, 3, 64, (47, 75)), (7, 3, 64, (224, 64)), (3, 0, 24, (9, 131))])
+def test_lp_stem_strip_kernel(ty, k, pad, cout, hw):
+    """The strip kernel of the 3-channel stems (Conv2d_1a 3x3/2 VALID, ResNet conv1 7x7/2 with explicit pad 3) reading
+    the fp32 images: ragged strips and heights, equal to the gather kernel (same rounding of the inputs)."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(k + cout)
+    ih, iw = hw
+    x = torch.rand(2, ih, iw, 3, generator=g) - 0.5
+    w = rnd(torch.randn(k, k, 3, cout, generator=g) * 0.2, td)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    oh, ow = (ih + 2 * pad - k) // 2 + 1, (iw + 2 * pad - k) // 2 + 1
+    y = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, ty, x_f32=True, tile=11)
+    y0 = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, ty, x_f32=True, tile=2)
+    close(y, y0, 2 * ulp)            # two roundings of sums in different order: 1 ulp, 2 across a binade boundary
+    xr = rnd(x, td)
+    ref = OB.conv2d(torch.nn.functional.pad(xr, (0, 0, pad, pad, pad, pad)) if pad else xr, w, 2, "VALID") * scale + shift
+    close(y, torch.relu(ref).numpy(), 2 * ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
 def test_lp_conv_fp32_network_input(ty):
     """GV_CONV_X_F32: the stem reads the fp32 images and rounds them in its loader (== casting first)."""
     code, td, ulp = TYPES[ty]
