@@ -494,6 +494,177 @@ int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
     return GV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The 3-channel stems on fp32 storage (Inception Conv2d_1a 3x3/2, ResNet conv1 7x7/2), GV_MATH_BF16X3: the strip
+// kernel of conv_lp.hip (conv_stem_patch_lp) with the input patch split ONCE into its three bf16 planes while it is
+// written to LDS and the six plane products per k-step.  k is re-ordered row-wise (filter row r owns KR slots of
+// which KW*3 are real) so the 8 values of a fragment are consecutive patch elements: four ds_read_b32 per plane.
+template <int TN, int KW>
+__global__ __launch_bounds__(256, 2) void conv_stem_patch_x3(const ConvArgs a) {
+    constexpr int KR = KW == 3 ? 16 : 24;
+    constexpr int NG = (KW * KR / 8 + 1) / 2 * 2;
+    constexpr int PR = 3 * 2 + KW + 1, PC = 31 * 2 + KW;
+    constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;    // one plane of one patch row
+    constexpr int NEL = (PR - 1) * PC * 3;
+    constexpr int SL = (NEL + 255) / 256;
+    constexpr int WB = NG * 16 + 16;                        // one plane of one filter row
+    constexpr int SW = 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sP = smem_raw;                                                      // [3][PR][PITCH]
+    float* stage = reinterpret_cast<float*>(smem_raw + 3 * PR * PITCH) + (threadIdx.x >> 6) * (32 * SW);
+    char* sW = smem_raw + 3 * PR * PITCH + 4 * 32 * SW * 4;                   // [3][32*TN][WB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (a.ow + 31) / 32;
+    const int n = blockIdx.x / tiles_x;
+    const int ox0 = (blockIdx.x % tiles_x) * 32;
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.w);   // [cout][k-tile][plane][16]
+
+    for (int idx = tid; idx < 32 * TN * NG * 8; idx += 256) {               // filter planes in the row-wise k order
+        const int row = idx / (NG * 8), kk = idx - row * (NG * 8);
+        const int r = kk / KR, j = kk - r * KR;
+        const bool ok = row < a.cout && r < KW && j < KW * 3;
+        const int k = r * KW * 3 + j;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<unsigned short*>(sW + (p * 32 * TN + row) * WB + kk * 2) =
+                ok ? wp[((size_t)row * a.ktiles + k / 16) * 48 + p * 16 + (k & 15)] : (unsigned short)0;
+    }
+    for (int idx = tid; idx < 3 * PR * PITCH / 4; idx += 256) reinterpret_cast<unsigned*>(sP)[idx] = 0u;
+
+    const int rrow = lane >> 2, col8 = (lane & 3) * 8;
+    float sc[TN][8], sh[TN][8];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = min(j * 32 + col8 + e, a.cout - 1);
+            sc[j][e] = a.scale[c];
+            sh[j][e] = a.shift[c];
+        }
+    const bool vec = (a.y_ld % 4 == 0) && ((((uintptr_t)a.y) & 15) == 0);
+
+    float pr_[SL];
+    auto fetch = [&](int oy0) {
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            float v = 0.f;
+            if (idx < NEL) {
+                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
+                const int px = e / 3, ch = e - px * 3;
+                const int iy = oy0 * 2 - a.pad_t + prow, ix = ox0 * 2 - a.pad_l + px;
+                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
+                    v = a.x[((size_t)(n * a.ih + iy) * a.iw + ix) * a.x_ld + ch];
+            }
+            pr_[k] = v;
+        }
+    };
+    fetch(0);
+    for (int oy0 = 0; oy0 < a.oh; oy0 += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < NEL) {
+                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
+                float x = pr_[k];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {                 // a = a0 + a1 + a2, exact (see the file header)
+                    const __bf16 h = (__bf16)x;
+                    *reinterpret_cast<unsigned short*>(sP + (p * PR + prow) * PITCH + e * 2) =
+                        __builtin_bit_cast(unsigned short, h);
+                    x -= (float)h;
+                }
+            }
+        }
+        __syncthreads();
+        if (oy0 + 4 < a.oh) fetch(oy0 + 4);
+        f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NG / 2; ++c) {
+            const int g = 2 * c + lh;
+            const int r = g / (KR / 8), q = g - r * (KR / 8);
+            const int prow = r < KW ? 2 * wave + r : PR - 1;
+            u32x4 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const char* ap = sP + (p * PR + prow) * PITCH + li * 12 + q * 16;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) fa[p][d] = *reinterpret_cast<const unsigned*>(ap + 4 * d);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                u32x4 fb[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fb[p] = *reinterpret_cast<const u32x4*>(sW + (p * 32 * TN + j * 32 + li) * WB + g * 16);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[prod_pa(3, t)]),
+                                                                     __builtin_bit_cast(bf16x8, fb[prod_pb(3, t)]),
+                                                                     acc[j], 0, 0, 0);
+            }
+        }
+        const int oy = oy0 + wave;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int colj = j * 32 + col8;
+            const int nvalid = min(8, a.cout - colj);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row = pass * 16 + rrow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+                if (oy >= a.oh || nvalid <= 0 || ox0 + row >= a.ow) continue;
+                const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = v[e] * sc[j][e] + sh[j][e];
+                    if (a.relu && colj + e < a.relu_limit) v[e] = fmaxf(v[e], 0.f);
+                }
+                float* yp = a.y + m * a.y_ld + colj;
+                if (vec && nvalid == 8) {
+                    *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(yp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < nvalid) yp[e] = v[e];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int TN, int KW>
+int launch_stem_x3_one(const ConvArgs& a, hipStream_t st) {
+    constexpr int KR = KW == 3 ? 16 : 24, NG = (KW * KR / 8 + 1) / 2 * 2, PR = 3 * 2 + KW + 1, PC = 31 * 2 + KW;
+    constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;
+    const size_t lds = (size_t)3 * PR * PITCH + 4 * 32 * 36 * 4 + (size_t)3 * 32 * TN * (NG * 16 + 16);
+    if (lds > 64 * 1024) {
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_patch_x3<TN, KW>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!ok) return GV_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((conv_stem_patch_x3<TN, KW>), dim3((unsigned)(a.nb * ((a.ow + 31) / 32))), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+int launch_stem_x3(const ConvArgs& a, hipStream_t st) {
+    if (a.kw == 3) return a.cout <= 32 ? launch_stem_x3_one<1, 3>(a, st) : launch_stem_x3_one<2, 3>(a, st);
+    return a.cout <= 32 ? launch_stem_x3_one<1, 7>(a, st) : launch_stem_x3_one<2, 7>(a, st);
+}
+
 // [kh][kw][cin][cout] fp32 -> [cout][k-tile][plane][16 bf16]
 template <int NP>
 __global__ void pack_filter_bf16s(const float* __restrict__ w, int K, int ktiles, int cout,
@@ -571,6 +742,13 @@ namespace gvconv {
 
 int bf16s_num_cfgs() { return kNumTiles + 1; }          // + the halo-tiled stem kernel (3 planes only)
 
+// the 3-channel stems: square 3x3 or 7x7 window, stride 2, <= 64 output channels, plain epilogue
+bool bf16s_stem_ok(int planes, const ConvArgs& a) {
+    return planes == 3 && a.cin == 3 && a.kh == a.kw && (a.kw == 3 || a.kw == 7) && a.stride == 2 && a.cout <= 64 &&
+           a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.res == nullptr &&
+           (int64_t)a.nb * a.ih * a.iw * a.x_ld < 0x7fffffffll;
+}
+
 // the halo kernel's layer class: 3x3 / stride 1, 32 input channels, <= 64 output channels, plain epilogue
 bool bf16s_halo_ok(int planes, const ConvArgs& a, bool generic) {
     return planes == 3 && !generic && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cin == 32 && a.cout <= 64 &&
@@ -600,7 +778,10 @@ int bf16s_launch(int planes, int cfg, const ConvArgs& a0, bool generic, hipStrea
     ConvArgs a = a0;
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
-    if (cfg == kNumTiles) return bf16s_halo_ok(planes, a, generic) ? launch_halo_x3(a, st) : GV_E_UNSUPPORTED;
+    if (cfg == kNumTiles) {
+        if (bf16s_stem_ok(planes, a)) return launch_stem_x3(a, st);
+        return bf16s_halo_ok(planes, a, generic) ? launch_halo_x3(a, st) : GV_E_UNSUPPORTED;
+    }
     switch (planes) {
         case 3: return launch_np<3>(cfg, a, generic, st);
         case 2: return launch_np<2>(cfg, a, generic, st);

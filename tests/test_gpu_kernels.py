@@ -539,3 +539,19 @@ def test_halo_stem_kernel_fp32_storage(cout, pad, hw):
     np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
     y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, residual=res, tile=0, math=1, y_ld=cout + 8, y_off=4)
     np.testing.assert_allclose(y, y0, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("k,pad,cout,hw", [(3, 0, 32, (47, 75)), (7, 3, 64, (47, 75)), (7, 3, 64, (224, 64)), (3, 0, 24, (9, 131))])
+def test_stem_strip_kernel_fp32_storage(k, pad, cout, hw):
+    """The strip kernel of the 3-channel stems on fp32 storage (GV_MATH_BF16X3, tile configuration 11): Conv2d_1a
+    (3x3/2 VALID) and ResNet conv1 (7x7/2, explicit pad 3), ragged strips — fp32-level agreement with the oracle."""
+    g = torch.Generator().manual_seed(k + cout)
+    ih, iw = hw
+    x = torch.rand(2, ih, iw, 3, generator=g) - 0.5
+    w = torch.randn(k, k, 3, cout, generator=g) * 0.2
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    oh, ow = (ih + 2 * pad - k) // 2 + 1, (iw + 2 * pad - k) // 2 + 1
+    xp = torch.nn.functional.pad(x, (0, 0, pad, pad, pad, pad)) if pad else x
+    ref = torch.relu(OB.conv2d(xp, w, 2, "VALID") * scale + shift).numpy()
+    y = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, tile=11, math=1)
+    np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
