@@ -19,8 +19,6 @@ plus the fused, device-resident forms BASELINE.json:north_star asks for:
 Every array that crosses this API is a torch tensor on the HIP device (PyTorch is plumbing:
 device memory + streams).  All arithmetic happens in libgvcnn_hip.so; there is no CPU path.
 """
-import ctypes as C
-
 import numpy as np
 import torch
 

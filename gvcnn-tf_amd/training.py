@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from . import backbones
 from . import params as _params
-from .backbones import TRef, _out_size
+from .backbones import _out_size
 from .model import _st, _dev, _raise_for_status
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training-step throughput (fp32 storage, bf16x3 math): forward(train BN) + loss + backward + Momentum.
     python tools/train_bench.py [--backbone inception_v3] [--shapes 8] [--views 12] [--size 224]"""
-import argparse, os, sys, time
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gvcnn_tf_amd.training import TrainGVCNN

@@ -9,7 +9,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-import gvcnn_tf_amd as gv  # noqa: E402
 from gvcnn_tf_amd import _lib  # noqa: E402
 from gvcnn_tf_amd.training import TrainGVCNN  # noqa: E402
 
