@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (SURVEY a12 / configs[2]: train-mode forward + loss + backward + "
                          "BN moving averages + Momentum; fp32 storage, bf16x3 math).  N > 1: view-sharded data "
-                         "parallelism (the world size must divide the number of views)")
+                         "parallelism (any world size up to the number of views)")
     ap.add_argument("--storage", default=None, choices=["f32", "bf16", "f16"],
                     help="activation/filter storage type (default: the preset's own: c2 f32 = the bench line, "
                          "c3/c4 bf16, c5 f16; forward only)")

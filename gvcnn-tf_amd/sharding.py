@@ -111,22 +111,35 @@ class ShardedGVCNN:
 #             (utils/train_utils.py:217-259) — are all-reduced in a few large buckets: xGMI is a
 #             point-to-point mesh, so few large messages beat one message per variable.
 def view_shard_range(num_views, world_size, rank):
-    """Views [lo, hi) owned by `rank`."""
-    if num_views % world_size != 0:
-        raise ValueError("%d views do not divide over %d ranks" % (num_views, world_size))
-    v_l = num_views // world_size
-    return rank * v_l, (rank + 1) * v_l
+    """Views [lo, hi) owned by `rank`: as even as possible (the first num_views % world_size ranks own one more), so
+    any world size up to num_views works — 12 views on 8 GPUs run as 2,2,2,2,1,1,1,1."""
+    if world_size > num_views:
+        raise ValueError("%d ranks for %d views: a rank would own no view" % (world_size, num_views))
+    base, extra = divmod(num_views, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_views(t_local, group=None):
-    """All-gather along the VIEW axis: [N, V_l, ...] on every rank -> [N, P*V_l, ...] (global view order)."""
+def gather_views(t_local, group=None, num_views=None):
+    """All-gather along the VIEW axis: [N, V_l, ...] on every rank -> [N, V, ...] (global view order).  Ranks may own
+    different numbers of views (view_shard_range): pass the global `num_views`; shards are padded to the largest one
+    for the collective and trimmed afterwards."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return t_local
     t_local = t_local.contiguous()
     n, v_l = t_local.shape[0], t_local.shape[1]
-    out = _all_gather_flat(t_local, group).view((world,) + tuple(t_local.shape))
-    return out.transpose(0, 1).reshape((n, world * v_l) + tuple(t_local.shape[2:])).contiguous()
+    if num_views is None:
+        num_views = v_l * world
+    counts = [view_shard_range(num_views, world, r) for r in range(world)]
+    v_max = max(hi - lo for lo, hi in counts)
+    if v_l < v_max:
+        pad = torch.zeros((n, v_max - v_l) + tuple(t_local.shape[2:]), dtype=t_local.dtype, device=t_local.device)
+        t_local = torch.cat([t_local, pad], dim=1).contiguous()
+    out = _all_gather_flat(t_local, group).view((world, n, v_max) + tuple(t_local.shape[2:]))
+    if v_max * world == num_views:
+        return out.transpose(0, 1).reshape((n, num_views) + tuple(t_local.shape[2:])).contiguous()
+    return torch.cat([out[r, :, :hi - lo] for r, (lo, hi) in enumerate(counts)], dim=1).contiguous()
 
 
 def allreduce_sum_bucketed(tensors, bucket_bytes=64 << 20, group=None):
@@ -171,15 +184,15 @@ class ShardedTrainGVCNN:
         self.bucket_bytes = bucket_bytes
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        assert engine.Vh == engine.V * self.world and engine.view_offset == self.rank * engine.V
+        assert (engine.view_offset, engine.view_offset + engine.V) == view_shard_range(engine.Vh, self.world, self.rank)
 
     def train_step(self, views_local, labels, lr=1e-3, mu=0.9, weight_decay=0.0, check=False):
         """views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all ranks)."""
         eng = self.eng
         f = eng.final
         eng.forward_backbone(views_local)
-        r_all = gather_views(eng.score_partial().view(eng.N, eng.V), self.group)
-        F_all = gather_views(eng.view(f).view(eng.N, eng.V, f.h, f.w, f.c), self.group)
+        r_all = gather_views(eng.score_partial().view(eng.N, eng.V), self.group, eng.Vh)
+        F_all = gather_views(eng.view(f).view(eng.N, eng.V, f.h, f.w, f.c), self.group, eng.Vh)
         eng.forward_head(labels, check=check, F=F_all, r_img=r_all.reshape(-1))
         dF = torch.zeros_like(F_all)
         eng.backward_head(dF=dF)

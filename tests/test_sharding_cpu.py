@@ -84,3 +84,32 @@ def test_shard_range():
     import pytest
     with pytest.raises(ValueError):
         sh.shard_range(30, 8, 0)
+
+
+def _uneven_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=3)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    full = torch.arange(2 * 7 * 3, dtype=torch.float32).reshape(2, 7, 3)          # [N, V = 7, E]
+    lo, hi = sh.view_shard_range(7, 3, rank)
+    ret[rank] = ((lo, hi), sh.gather_views(full[:, lo:hi].contiguous(), num_views=7).numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_view_shards_gather_in_view_order():
+    """7 views over 3 ranks (3, 2, 2): padded all-gather, trimmed, global view order on every rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_uneven_worker, args=(port, ret), nprocs=3, join=True)
+    full = np.arange(2 * 7 * 3, dtype=np.float32).reshape(2, 7, 3)
+    assert [ret[r][0] for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
+    for r in range(3):
+        assert np.array_equal(ret[r][1], full)
