@@ -184,7 +184,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
 }
 
 template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_lp(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 3 ? 3 : 2) : 1)) void conv_igemm_lp(const ConvArgs a) {
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     static_assert(GENERIC || !XF32, "fp32 input only on the gather path");
     constexpr int NT = WM * WN * 64;                 // threads
