@@ -69,6 +69,8 @@ def parse():
                     help="nccl = RCCL (the real multi-GPU path); gloo + --same-device: control-flow check of the N>1 path "
                          "on a single-GPU box (every rank on cuda:0, collectives through host memory)")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one hipGraph (GVCNN.capture): for small, launch-bound view batches; N = 1 only")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (SURVEY a12 / configs[2]: train-mode forward + loss + backward + "
                          "BN moving averages + Momentum; fp32 storage, bf16x3 math).  N > 1: view-sharded data "
@@ -249,12 +251,16 @@ def main():
         chosen = eng.plan.autotune(x.view(N * V, H, W, 3))
         if a.tile_cache and rank == 0:
             json.dump({k: v[0] for k, v in chosen.items()}, open(a.tile_cache, "w"))
+    step = (lambda: sh.forward(x, check=False))
+    if a.graph:
+        assert world == 1, "--graph is a single-GPU option"
+        step = eng.capture(x)
     for _ in range(a.warmup):
-        sh.forward(x, check=False)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        sh.forward(x, check=False)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     eng.check_status()
@@ -289,6 +295,8 @@ def main():
             out["roofline"] = roofline(eng, x.view(N * V, H, W, 3), a.math)
         out["config"]["math"] = a.math + ": " + MATH[a.math][2]
         out["config"]["branch_lanes"] = eng.plan.lanes_used if not a.no_lanes else 1
+        out["config"]["launch"] = "hipGraph replay" if a.graph else "eager"
+
         if world == 1 and a.math != "f32" and not a.no_exact:
             # the same step on the exact fp32 MFMA path, for reference (short run, same inputs)
             e32 = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math="f32", lanes=not a.no_lanes)

@@ -90,6 +90,10 @@ SIGNATURES = {
     "gv_plan_add_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _L, _I, _L, _L, _I, _L]),
     "gv_plan_run": (C.c_int, [_P, C.POINTER(_P), _I, _P]),
     "gv_plan_run_range": (C.c_int, [_P, _I, _I, C.POINTER(_P), _I, _P]),
+    "gv_capture_begin": (C.c_int, [_P]),
+    "gv_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
+    "gv_graph_launch": (C.c_int, [_P, _P]),
+    "gv_graph_destroy": (None, [_P]),
     "gv_conv2d_time": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, C.POINTER(_F), _P]),
     "gv_plan_time": (C.c_int, [_P, _I, _I, C.POINTER(_P), _I, _I, C.POINTER(_F), _P]),
 }

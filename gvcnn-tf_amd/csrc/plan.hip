@@ -289,3 +289,43 @@ extern "C" int gv_plan_time(const gv_plan* p, int32_t first, int32_t count, void
     (void)hipEventDestroy(e1);
     return rc;
 }
+
+// ---- hipGraph capture of whatever the caller enqueues on a stream (gvcnn_hip.h) --------------------------------
+struct gv_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int gv_capture_begin(void* stream) {
+    if (!stream) return GV_E_BADARG;                       // the legacy default stream cannot be captured
+    GV_HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+    return GV_OK;
+}
+
+extern "C" int gv_capture_end(void* stream, gv_graph** out) {
+    if (!stream || !out) return GV_E_BADARG;
+    gv_graph* g = new (std::nothrow) gv_graph();
+    if (!g) return GV_E_PLAN;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        return (int)e;
+    }
+    *out = g;
+    return GV_OK;
+}
+
+extern "C" int gv_graph_launch(const gv_graph* g, void* stream) {
+    if (!g || !g->exec) return GV_E_BADARG;
+    GV_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return GV_OK;
+}
+
+extern "C" void gv_graph_destroy(gv_graph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}

@@ -383,6 +383,33 @@ class GVCNN:
             self.check_status()
         return self.scores, S, logits
 
+    # -- hipGraph replay (small batches are launch-bound) ---------------------------------------------------
+    def capture(self, views):
+        """Record one fused forward on `views` (a device tensor that stays alive: the graph keeps its address) into a
+        hipGraph and return replay(): one launch per step instead of ~90.  Replays re-read `views` in place — copy the
+        next batch INTO it.  The status word is not checked inside the graph; call check_status() when needed."""
+        import ctypes as C
+        views = self._check_input(views)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        handle = C.c_void_p()
+        with torch.cuda.stream(side):
+            self.forward(views, check=False)                 # warm: lazily created streams / attributes exist
+            side.synchronize()
+            _lib.check(self.lib.gv_capture_begin(side.cuda_stream), "gv_capture_begin")
+            try:
+                self.forward(views, check=False)
+            finally:
+                rc = self.lib.gv_capture_end(side.cuda_stream, C.byref(handle))
+            _lib.check(rc, "gv_capture_end")
+        self._graphs = getattr(self, "_graphs", [])
+        self._graphs.append((handle, views, side))
+
+        def replay():
+            _lib.check(self.lib.gv_graph_launch(handle, _st()), "gv_graph_launch")
+            return (self.scores_ps if self.per_shape else self.scores), self.shape_descriptor, self.logits
+        return replay
+
     def forward_basic(self, views):
         """nets/model.py:169-206 (MVCNN baseline): max over all views -> GAP -> Dense."""
         self.run_backbone(views)

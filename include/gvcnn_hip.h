@@ -345,6 +345,17 @@ int gv_plan_run(const gv_plan* p, void* const* buffers_host, int32_t num_slots, 
 int gv_plan_run_range(const gv_plan* p, int32_t first, int32_t count, void* const* buffers_host,
                       int32_t num_slots, void* stream);
 
+/* ---- hipGraph capture ------------------------------------------------------
+ * Small view batches are launch-bound (~90 launches for ~2 ms of work at 12 views): record everything enqueued on
+ * `stream` between begin and end — gv_plan_run with its lane fork/join included, the grouping kernels, anything else
+ * the caller launches there — into one executable graph and replay it with one call.  `stream` must not be the
+ * legacy default stream.  The recorded launches keep the POINTERS they were issued with: replay on the same buffers. */
+typedef struct gv_graph gv_graph;
+int gv_capture_begin(void* stream);
+int gv_capture_end(void* stream, gv_graph** out);
+int gv_graph_launch(const gv_graph* g, void* stream);
+void gv_graph_destroy(gv_graph* g);
+
 /* ---- timing helper ---------------------------------------------------------
  * Average duration (ms) of `iters` back-to-back gv_conv2d_fwd launches measured with
  * hipEvents on `stream` (the stream the kernel is launched on); used by bench.py for the

@@ -334,3 +334,20 @@ def test_input_pipeline_preprocess_and_batcher(tmp_path):
         want = OP.preprocess_views(np.stack([v for k in (2 * b, 2 * b + 1) for v in shapes[k][0]]), 32, 32)
         np.testing.assert_allclose(x.cpu().numpy().reshape(N * V, 32, 32, 3), want, rtol=0, atol=2e-6)
         assert float(x.min()) >= -0.5 and float(x.max()) <= 0.5 + 1e-6     # 255 * fp32(1/255) - 0.5 = 0.50000006
+
+
+@pytest.mark.parametrize("lanes", [False, True])
+def test_hipgraph_replay_matches_eager(lanes):
+    """GVCNN.capture: the whole fused forward (plan with or without branch lanes, scorer, grouping, classifier) as one
+    hipGraph; a replay on new input data written INTO the captured buffer equals the eager forward bit for bit."""
+    N, V, C, G = 1, 6, 10, 10
+    eng, P, Hd = make_engine("inception_v3", N, V, 75, 75, C, G, lanes=lanes)
+    x = views(N, V, 75, 75, seed=4).to(DEV)
+    replay = eng.capture(x)
+    x2 = views(N, V, 75, 75, seed=9).to(DEV)
+    s_e, S_e, l_e = [t.clone() for t in eng.forward(x2)]
+    x.copy_(x2)
+    s_g, S_g, l_g = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(s_g, s_e) and torch.equal(S_g, S_e) and torch.equal(l_g, l_e)
+    eng.check_status()
