@@ -69,6 +69,9 @@ def parse():
                     help="nccl = RCCL (the real multi-GPU path); gloo + --same-device: control-flow check of the N>1 path "
                          "on a single-GPU box (every rank on cuda:0, collectives through host memory)")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--dp", default="views", choices=["views", "shapes"],
+                    help="--train with N > 1: shard the views of every shape (BN statistics stay local) or the shapes "
+                         "(every BN layer all-reduces its per-view sums)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph (GVCNN.capture): for small, launch-bound view batches; N = 1 only")
     ap.add_argument("--train", action="store_true",
@@ -158,11 +161,20 @@ def train_main(a, world, rank, dev):
     from gvcnn_tf_amd.training import TrainGVCNN
     from gvcnn_tf_amd.sharding import ShardedTrainGVCNN, view_shard_range
     N = a.shapes
-    lo, hi = view_shard_range(V, world, rank)
-    eng = TrainGVCNN(BACKBONE, N, hi - lo, H, W, C, G, device=dev, num_bins=G, head_views=V, view_offset=lo)
-    sh = ShardedTrainGVCNN(eng)
-    x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5)[:, lo:hi].contiguous().to(dev)
-    labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1))
+    if a.dp == "views":
+        lo, hi = view_shard_range(V, world, rank)
+        eng = TrainGVCNN(BACKBONE, N, hi - lo, H, W, C, G, device=dev, num_bins=G, head_views=V, view_offset=lo)
+        sh = ShardedTrainGVCNN(eng)
+        x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5)[:, lo:hi].contiguous().to(dev)
+        labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1))
+        views_per_step, views_local = N * V, N * (hi - lo)
+    else:                                            # N shapes PER RANK (weak scaling), all their views
+        lo, hi = 0, V
+        eng = TrainGVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G)
+        sh = ShardedTrainGVCNN(eng, mode="shapes")
+        x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(rank)) - 0.5).to(dev)
+        labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(100 + rank))
+        views_per_step, views_local = N * V * world, N * V
     sh.train_step(x, labels, lr=1e-6)
     eng.autotune()                                   # untimed: per-launch tile choice
     for _ in range(max(a.warmup, 1)):
@@ -188,12 +200,13 @@ def train_main(a, world, rank, dev):
         ms = dt / a.steps * 1e3
         flops = 3.0 * sum(op.get("flops", 0) for op in eng.plan.ops) * world
         print(json.dumps({
-            "metric": "views/sec (training step)", "value": round(N * V / (ms * 1e-3), 1), "unit": "views/s",
+            "metric": "views/sec (training step)", "value": round(views_per_step / (ms * 1e-3), 1), "unit": "views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if a.dp == "views" else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "training step (SURVEY a12): %s, %d shapes x %d views x %dx%d, train-mode BN per view, "
-                                   "CE loss, backward, BN moving averages, Momentum; fp32 storage, bf16x3 math; views sharded "
-                                   "over the ranks" % (BACKBONE, N, V, H, W), "views_per_gpu": N * (hi - lo)},
+                                   "CE loss, backward, BN moving averages, Momentum; fp32 storage, bf16x3 math; %s sharded "
+                                   "over the ranks" % (BACKBONE, N, V, H, W, a.dp), "views_per_gpu": views_local},
             "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}), flush=True)
 
 

@@ -65,6 +65,12 @@ SIGNATURES = {
     "gv_eval_metrics": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "gv_dense_fwd": (C.c_int, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "gv_bn_stats_grouped": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_bn_sums_grouped": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "gv_bn_finalize_grouped": (C.c_int, [_P, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P]),
+    "gv_bn_relu_bwd_sums_grouped": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "gv_bn_relu_bwd_apply_grouped": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P,
+                                               _P, _P]),
+    "gv_scale": (C.c_int, [_P, _L, _F, _P]),
     "gv_bn_update_moving": (C.c_int, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
     "gv_scale_shift_act_grouped": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P]),
     "gv_bn_relu_bwd_grouped": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P,

@@ -718,11 +718,9 @@ __global__ void bn_update_moving(const float* __restrict__ mean, const float* __
 
 }  // namespace
 
-extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
-                                   int32_t num_groups, const int32_t* counts, const float* gamma,
-                                   const float* beta, float eps, double* accum, float* mean, float* var,
-                                   float* inv, float* scale, float* shift, void* stream) {
-    if (!z || !counts || !beta || !accum || !mean || !var || !inv || !scale || !shift) return GV_E_BADARG;
+extern "C" int gv_bn_sums_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
+                                  int32_t num_groups, double* accum, void* stream) {
+    if (!z || !accum) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || z_ld < c || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
@@ -731,10 +729,28 @@ extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32
     if (splits > 256) splits = 256;
     launch_grouped_sums<0>(dim3((c + 63) / 64, splits, num_groups), st, (c & 3) == 0 && vec_ok(z, z_ld), z, z_ld,
                            nullptr, 0, nullptr, 0, nullptr, nullptr, nb, hw, c, num_groups, accum);
-    hipLaunchKernelGGL(bn_finalize_grouped, dim3((num_groups * c + 255) / 256), dim3(256), 0, st, accum,
-                       num_groups, c, counts, gamma, beta, eps, mean, var, inv, scale, shift);
     GV_LAUNCH_CHECK();
     return GV_OK;
+}
+
+extern "C" int gv_bn_finalize_grouped(const double* accum, int32_t c, int32_t num_groups, const int32_t* counts,
+                                      const float* gamma, const float* beta, float eps, float* mean, float* var,
+                                      float* inv, float* scale, float* shift, void* stream) {
+    if (!accum || !counts || !beta || !mean || !var || !inv || !scale || !shift || c <= 0 || num_groups <= 0)
+        return GV_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_grouped, dim3((num_groups * c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       accum, num_groups, c, counts, gamma, beta, eps, mean, var, inv, scale, shift);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
+                                   int32_t num_groups, const int32_t* counts, const float* gamma,
+                                   const float* beta, float eps, double* accum, float* mean, float* var,
+                                   float* inv, float* scale, float* shift, void* stream) {
+    const int rc = gv_bn_sums_grouped(z, nb, hw, c, z_ld, num_groups, accum, stream);
+    if (rc != GV_OK) return rc;
+    return gv_bn_finalize_grouped(accum, c, num_groups, counts, gamma, beta, eps, mean, var, inv, scale, shift, stream);
 }
 
 extern "C" int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
@@ -751,12 +767,11 @@ extern "C" int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw
     return GV_OK;
 }
 
-extern "C" int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
-                                      const float* z, int32_t z_ld, const float* mean, const float* inv,
-                                      const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
-                                      int32_t c, int32_t num_groups, double* accum, float* dz, int32_t dz_ld,
-                                      float* dbeta, float* dgamma, void* stream) {
-    if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
+extern "C" int gv_bn_relu_bwd_sums_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
+                                           const float* z, int32_t z_ld, const float* mean, const float* inv,
+                                           int32_t nb, int32_t hw, int32_t c, int32_t num_groups, double* accum,
+                                           void* stream) {
+    if (!dy || !z || !mean || !inv || !accum) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
@@ -766,11 +781,47 @@ extern "C" int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const floa
     launch_grouped_sums<1>(dim3((c + 63) / 64, splits, num_groups), st,
                            (c & 3) == 0 && vec_ok(z, z_ld) && vec_ok(dy, dy_ld) && vec_ok(y, y_ld), z, z_ld, dy, dy_ld, y,
                            y_ld, mean, inv, nb, hw, c, num_groups, accum);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_bn_relu_bwd_apply_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
+                                            const float* z, int32_t z_ld, const float* mean, const float* inv,
+                                            const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
+                                            int32_t c, int32_t num_groups, const double* accum, float* dz,
+                                            int32_t dz_ld, float* dbeta, float* dgamma, void* stream) {
+    if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_apply_grouped_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, dy, dy_ld,
                        y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw, c, num_groups, dz, dz_ld);
     if (dbeta || dgamma)
         hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
                            dgamma);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
+                                      const float* z, int32_t z_ld, const float* mean, const float* inv,
+                                      const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
+                                      int32_t c, int32_t num_groups, double* accum, float* dz, int32_t dz_ld,
+                                      float* dbeta, float* dgamma, void* stream) {
+    const int rc = gv_bn_relu_bwd_sums_grouped(dy, dy_ld, y, y_ld, z, z_ld, mean, inv, nb, hw, c, num_groups, accum,
+                                               stream);
+    if (rc != GV_OK) return rc;
+    return gv_bn_relu_bwd_apply_grouped(dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, counts, nb, hw, c, num_groups,
+                                        accum, dz, dz_ld, dbeta, dgamma, stream);
+}
+
+__global__ void scale_inplace_f32(float* __restrict__ x, int64_t n, float s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
+extern "C" int gv_scale(float* x, int64_t n, float s, void* stream) {
+    if (!x || n <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(scale_inplace_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }

@@ -175,19 +175,73 @@ def allreduce_sum_bucketed(tensors, bucket_bytes=64 << 20, group=None):
     return len(buckets)
 
 
-class ShardedTrainGVCNN:
-    """Wraps a per-rank TrainGVCNN built with num_views = V/P, head_views = V, view_offset = rank*V/P."""
+def allreduce_sum_(t, group=None):
+    """In-place sum over the ranks (a gloo group is fed through host memory)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
 
-    def __init__(self, engine, group=None, bucket_bytes=64 << 20):
+
+class ShardedTrainGVCNN:
+    """Data-parallel training step around a per-rank TrainGVCNN.
+
+    mode='views'  (default): the engine owns views [view_offset, view_offset + V_l) of every shape (built with
+                  num_views = V_l, head_views = V): BatchNorm statistics stay local, descriptors are gathered.
+    mode='shapes': the engine owns N_l shapes with all their views (the usual data parallelism, any world size,
+                  even work).  A view's images now live on every rank, so each train-mode BatchNorm all-reduces its
+                  per-(view, channel) sums — forward (sum, sum of squares) and backward (sum g, sum g*zhat): two small
+                  collectives per layer — and normalises with the GLOBAL counts: exactly the reference's statistics
+                  over the whole batch.  The scorer responses are gathered like in inference (batch-mean scores);
+                  pooling, classifier and loss run on the local shapes with the 1/world factor of the global mean."""
+
+    def __init__(self, engine, group=None, bucket_bytes=64 << 20, mode="views"):
+        if mode not in ("views", "shapes"):
+            raise ValueError(mode)
         self.eng = engine
         self.group = group
+        self.mode = mode
         self.bucket_bytes = bucket_bytes
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        assert (engine.view_offset, engine.view_offset + engine.V) == view_shard_range(engine.Vh, self.world, self.rank)
+        if mode == "views":
+            assert (engine.view_offset, engine.view_offset + engine.V) == view_shard_range(engine.Vh, self.world, self.rank)
+        else:
+            assert engine.Vh == engine.V and engine.view_offset == 0
+            if self.world > 1:
+                engine.shape_world = self.world
+                engine.bn_sync = lambda accum: allreduce_sum_(accum, self.group)
+
+    def _train_step_shapes(self, views_local, labels_local, lr, mu, weight_decay, check):
+        eng = self.eng
+        eng.forward_backbone(views_local)
+        r_all = gather_scores(eng.score_partial(), self.group)              # [P*N_l*V], global shape-major order
+        # batch-mean scores over the GLOBAL batch (identical on every rank), then the local head
+        _lib_scores = eng.lib.gv_view_score_finalize
+        from . import _lib
+        from .model import _st
+        _lib.check(_lib_scores(r_all.data_ptr(), eng.N * self.world, eng.V, _lib.GV_ORDER_SHAPE_MAJOR,
+                               eng.scores.data_ptr(), _st()), "score finalize (global)")
+        eng.forward_head(labels_local, check=check, r_img=None, scores_ready=True)
+        eng.backward_head()
+        eng.backward_backbone()
+        # BN beta/gamma gradients come out of the all-reduced sums: already global.  Everything else is a local sum.
+        local = [g for k, g in eng.grads.items() if not k.endswith(("/beta", "/gamma"))]
+        allreduce_sum_bucketed(local, self.bucket_bytes, self.group)
+        eng.update_moving_averages()
+        eng.apply_momentum(lr, mu, weight_decay)
+        return eng.loss
 
     def train_step(self, views_local, labels, lr=1e-3, mu=0.9, weight_decay=0.0, check=False):
-        """views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all ranks)."""
+        """mode='views': views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all
+        ranks).  mode='shapes': views_local [N_l, V, H, W, 3], labels [N_l] (this rank's shapes)."""
+        if self.mode == "shapes":
+            return self._train_step_shapes(views_local, labels, lr, mu, weight_decay, check)
         eng = self.eng
         f = eng.final
         eng.forward_backbone(views_local)
@@ -202,5 +256,31 @@ class ShardedTrainGVCNN:
         # classifier gradients are identical on every rank (the head ran on the gathered data): not reduced
         shared = [g for k, g in eng.grads.items() if k not in eng.cls_names]
         allreduce_sum_bucketed(shared, self.bucket_bytes, self.group)
+        self.update_moving_averages_views()
         eng.apply_momentum(lr, mu, weight_decay)
         return eng.loss
+
+    def update_moving_averages_views(self, decay=None):
+        """BN moving averages in view-sharded mode: the reference applies one update per view graph copy, so every
+        rank needs the batch statistics of ALL views — one all-gather of every layer's [V_l, c] means and variances
+        (packed into a single message), then the V sequential updates run identically on every rank."""
+        from . import _lib
+        from .model import _st
+        eng = self.eng
+        if decay is None:
+            decay = 0.9997 if eng.backbone == "inception_v3" else 0.997
+        bns = [op for op in eng.plan.ops if op["kind"] == "bn"]
+        packed = torch.cat([torch.cat([op["stat"]["mean"], op["stat"]["var"]], dim=1) for op in bns], dim=1)  # [V_l, sum 2c]
+        full = gather_views(packed.unsqueeze(0), self.group, eng.Vh)[0]                                        # [V, sum 2c]
+        off = 0
+        for op in bns:
+            c, hw = op["x"].c, op["x"].h * op["x"].w
+            mean = full[:, off:off + c].contiguous()
+            var = full[:, off + c:off + 2 * c].contiguous()
+            off += 2 * c
+            counts = torch.full((eng.Vh,), eng.N * hw, dtype=torch.int32, device=full.device)
+            _lib.check(eng.lib.gv_bn_update_moving(mean.data_ptr(), var.data_ptr(), counts.data_ptr(), eng.Vh, c,
+                                                   float(decay), eng.params[op["name"] + "/moving_mean"].data_ptr(),
+                                                   eng.params[op["name"] + "/moving_variance"].data_ptr(), _st()),
+                       "bn_update_moving")
+            op["_keep"] = (mean, var, counts)            # alive until the launches above have run

@@ -122,6 +122,10 @@ class TrainGVCNN:
         # per_shape: the paper's grouping (model.GVCNN(per_shape=True)) in the training step
         self.per_shape = bool(per_shape)
         self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
+        # shape-sharded data parallelism (sharding.ShardedTrainGVCNN(mode='shapes')): bn_sync(accum) all-reduces the
+        # per-(view, channel) BatchNorm sums over the ranks, shape_world = number of ranks sharing every view
+        self.bn_sync = None
+        self.shape_world = 1
         self.Vh = head_views if head_views is not None else num_views
         self.view_offset = view_offset
         assert 0 <= view_offset and view_offset + num_views <= self.Vh
@@ -228,9 +232,11 @@ class TrainGVCNN:
         return torch.as_strided(base, (t.nb, t.h, t.w, t.c), (t.h * t.w * t.ld, t.w * t.ld, t.ld, 1), t.off)
 
     def _count(self, hw):
-        if hw not in self._counts:
-            self._counts[hw] = torch.full((self.V,), self.N * hw, dtype=torch.int32, device=self.device)
-        return self._counts[hw]
+        key = (hw, self.shape_world)
+        if key not in self._counts:                       # pixels of one view over the GLOBAL batch
+            self._counts[key] = torch.full((self.V,), self.N * hw * self.shape_world, dtype=torch.int32,
+                                           device=self.device)
+        return self._counts[key]
 
     def _conv_desc(self, op, dgrad=False):
         x, y = op["x"], op["y"]
@@ -321,11 +327,23 @@ class TrainGVCNN:
                 gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
                 beta = self.params[op["name"] + "/beta"]
                 hw = x.h * x.w
-                _lib.check(lib.gv_bn_stats_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, V, self._count(hw).data_ptr(),
-                                                   gamma.data_ptr() if gamma is not None else None, beta.data_ptr(),
-                                                   float(op["eps"]), self.accum.data_ptr(), st["mean"].data_ptr(),
-                                                   st["var"].data_ptr(), st["inv"].data_ptr(), st["scale"].data_ptr(),
-                                                   st["shift"].data_ptr(), _st()), "bn stats " + op["name"])
+                if self.bn_sync is None:
+                    _lib.check(lib.gv_bn_stats_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, V, self._count(hw).data_ptr(),
+                                                       gamma.data_ptr() if gamma is not None else None, beta.data_ptr(),
+                                                       float(op["eps"]), self.accum.data_ptr(), st["mean"].data_ptr(),
+                                                       st["var"].data_ptr(), st["inv"].data_ptr(),
+                                                       st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
+                               "bn stats " + op["name"])
+                else:                                         # shape-sharded: reduce the sums over the ranks first
+                    _lib.check(lib.gv_bn_sums_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, V, self.accum.data_ptr(),
+                                                      _st()), "bn sums " + op["name"])
+                    self.bn_sync(self.accum[:2 * V * x.c])
+                    _lib.check(lib.gv_bn_finalize_grouped(self.accum.data_ptr(), x.c, V, self._count(hw).data_ptr(),
+                                                          gamma.data_ptr() if gamma is not None else None,
+                                                          beta.data_ptr(), float(op["eps"]), st["mean"].data_ptr(),
+                                                          st["var"].data_ptr(), st["inv"].data_ptr(),
+                                                          st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
+                               "bn finalize " + op["name"])
                 _lib.check(lib.gv_scale_shift_act_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
                                                           st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
                                                           y.ld, _st()), "bn apply " + op["name"])
@@ -344,7 +362,8 @@ class TrainGVCNN:
                                                   _st()), "score")
         return self.r_img
 
-    def forward_head(self, labels=None, g_scheme=None, g_weight=None, check=True, F=None, r_img=None):
+    def forward_head(self, labels=None, g_scheme=None, g_weight=None, check=True, F=None, r_img=None,
+                     scores_ready=False):
         """Scores -> scheme/weight -> view pooling + fusion -> classifier -> loss, over self.Vh views.
         F [N, Vh, h, w, C] / r_img [N*Vh]: the gathered descriptors / scorer responses of a view-sharded job
         (default: this engine's own taps)."""
@@ -372,8 +391,9 @@ class TrainGVCNN:
                                                            self.empty_fill, None, self.S.data_ptr(), _lib.GV_F32,
                                                            _st()), "pool_fuse per shape")
             return self._classify_and_loss(labels, self.scores_ps)
-        _lib.check(lib.gv_view_score_finalize(r_img.data_ptr(), self.N, V, _lib.GV_ORDER_SHAPE_MAJOR,
-                                              self.scores.data_ptr(), _st()), "score finalize")
+        if not scores_ready:                              # (shape-sharded jobs finalise the scores over the global batch)
+            _lib.check(lib.gv_view_score_finalize(r_img.data_ptr(), self.N, V, _lib.GV_ORDER_SHAPE_MAJOR,
+                                                  self.scores.data_ptr(), _st()), "score finalize")
         if g_scheme is None:
             _lib.check(lib.gv_group_assign(self.scores.data_ptr(), V, self.G, self.num_bins, self.gidx.data_ptr(),
                                            self.scheme.data_ptr(), self.weight.data_ptr(), self.status.data_ptr(),
@@ -400,6 +420,9 @@ class TrainGVCNN:
             self._labels = labels.to(device=self.device, dtype=torch.int64).contiguous()
             _lib.check(lib.gv_softmax_ce(self.logits.data_ptr(), self._labels.data_ptr(), self.N, self.num_classes,
                                          self.loss.data_ptr(), self.dlogits.data_ptr(), _st()), "softmax_ce")
+            if self.shape_world > 1:                      # the loss is the mean over the GLOBAL batch
+                _lib.check(lib.gv_scale(self.dlogits.data_ptr(), self.dlogits.numel(), 1.0 / self.shape_world, _st()),
+                           "gv_scale")
         return scores, self.S, self.logits, self.loss
 
     # -- backward ----------------------------------------------------------------------------------------
@@ -454,13 +477,25 @@ class TrainGVCNN:
                 st = op["stat"]
                 hw = x.h * x.w
                 gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
-                _lib.check(lib.gv_bn_relu_bwd_grouped(
-                    self._ptr(y, True), y.ld, self._ptr(y) if op["relu"] else None, y.ld, self._ptr(x), x.ld,
-                    st["mean"].data_ptr(), st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
-                    self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
-                    self.grads[op["name"] + "/beta"].data_ptr(),
-                    self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None, _st()),
-                    "bn_bwd " + op["name"])
+                dbeta = self.grads[op["name"] + "/beta"].data_ptr()
+                dgamma = self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None
+                yptr = self._ptr(y) if op["relu"] else None
+                if self.bn_sync is None:
+                    _lib.check(lib.gv_bn_relu_bwd_grouped(
+                        self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                        st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                        self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
+                        dbeta, dgamma, _st()), "bn_bwd " + op["name"])
+                else:
+                    _lib.check(lib.gv_bn_relu_bwd_sums_grouped(
+                        self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                        st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), _st()), "bn_bwd sums " + op["name"])
+                    self.bn_sync(self.accum[:2 * V * x.c])
+                    _lib.check(lib.gv_bn_relu_bwd_apply_grouped(
+                        self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                        st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                        self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
+                        dbeta, dgamma, _st()), "bn_bwd apply " + op["name"])
             elif op["kind"] == "conv":
                 dz = self._ptr(y, True)
                 if op["bias"]:

@@ -257,6 +257,14 @@ int gv_bn_stats_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32
                         const int32_t* counts, const float* gamma, const float* beta, float eps,
                         double* accum, float* mean, float* var, float* inv, float* scale, float* shift,
                         void* stream);
+/* The two halves of gv_bn_stats_grouped, for data-parallel jobs that cut the batch on SHAPE boundaries: a view's
+ * images then live on several ranks, so the per-(view, channel) sums (accum: double [num_groups, c, 2] = sum, sum of
+ * squares) are all-reduced between the halves and `counts` holds the GLOBAL pixel counts. */
+int gv_bn_sums_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld, int32_t num_groups,
+                       double* accum, void* stream);
+int gv_bn_finalize_grouped(const double* accum, int32_t c, int32_t num_groups, const int32_t* counts,
+                           const float* gamma, const float* beta, float eps, float* mean, float* var, float* inv,
+                           float* scale, float* shift, void* stream);
 /* Moving-average update of slim.batch_norm in training (the UPDATE_OPS train.py:178-186 groups with the
  * optimizer step), one update per view graph copy, applied in view order:
  *   moving_mean = moving_mean*decay + mean[g]*(1-decay)
@@ -274,6 +282,18 @@ int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const float* y, int32
                            int32_t z_ld, const float* mean, const float* inv, const float* gamma,
                            const int32_t* counts, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
                            double* accum, float* dz, int32_t dz_ld, float* dbeta, float* dgamma, void* stream);
+/* The two halves of gv_bn_relu_bwd_grouped (sums of g and g*zhat -> all-reduce over the ranks -> apply with the
+ * global counts).  After the all-reduce dbeta / dgamma are already the GLOBAL gradients on every rank. */
+int gv_bn_relu_bwd_sums_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld, const float* z,
+                                int32_t z_ld, const float* mean, const float* inv, int32_t nb, int32_t hw, int32_t c,
+                                int32_t num_groups, double* accum, void* stream);
+int gv_bn_relu_bwd_apply_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld, const float* z,
+                                 int32_t z_ld, const float* mean, const float* inv, const float* gamma,
+                                 const int32_t* counts, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
+                                 const double* accum, float* dz, int32_t dz_ld, float* dbeta, float* dgamma,
+                                 void* stream);
+/* x *= s (the 1/world factor of a loss averaged over a sharded batch). */
+int gv_scale(float* x, int64_t n, float s, void* stream);
 /* dst[p][c] += src[p][c]: gradient fan-in of `shortcut + residual` (nets/resnet_v2.py:91). */
 int gv_accumulate(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix, int32_t c,
                   void* stream);

@@ -424,3 +424,82 @@ def test_training_engine_with_per_shape_grouping():
     grads = eng.backward()
     gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
     assert np.isfinite(float(loss)) and np.isfinite(gn) and gn > 0
+
+
+def test_shape_sharded_engines_reproduce_the_whole_step():
+    """sharding.ShardedTrainGVCNN(mode='shapes') on ONE device: two engines own shapes {0,1} and {2,3} with all their
+    views; every BatchNorm's sums are added across the two engines between the two halves of the split entry points
+    (the all-reduce), scores are finalised over the global batch, dlogits carry the 1/world factor — gradients, loss
+    and BN batch statistics equal the unsharded engine's."""
+    import threading
+    backbone, size, N, V, C_, G, W_ = "resnet_v2_50", 64, 4, 2, 5, 10, 2
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    P = gv.params.init_backbone_params(full.plan.param_shapes(), seed=5, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, full.raw.c, full.final.c, C_, seed=6, spread_scores=True)
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(DEV)
+    labels = torch.tensor([0, 3, 1, 2])
+    full.forward(x, labels)
+    ref = {k: v.clone() for k, v in full.backward().items()}
+    Nl = N // W_
+    engs = [TrainGVCNN(backbone, Nl, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV) for _ in range(W_)]
+    # a two-party "all-reduce" between the engines: each bn_sync call parks its accumulator until the peer arrives
+    barrier = threading.Barrier(W_)
+    slots = [None] * W_
+
+    def make_sync(r):
+        def sync(acc):
+            torch.cuda.synchronize()
+            slots[r] = acc.clone()
+            barrier.wait()
+            total = slots[0] + slots[1]
+            barrier.wait()
+            acc.copy_(total)
+        return sync
+    for r, e in enumerate(engs):
+        e.shape_world = W_
+        e.bn_sync = make_sync(r)
+    out = [None] * W_
+    r_parts = [None] * W_
+
+    def run(r):
+        with torch.cuda.device(0):
+            e = engs[r]
+            e.forward_backbone(x[r * Nl:(r + 1) * Nl].contiguous())
+            torch.cuda.synchronize()
+            r_parts[r] = e.score_partial().clone()
+            torch.cuda.synchronize()
+            barrier.wait()
+            r_all = torch.cat(r_parts)
+            _lib.check(lib().gv_view_score_finalize(r_all.data_ptr(), N, V, _lib.GV_ORDER_SHAPE_MAJOR,
+                                                    e.scores.data_ptr(), st()), "finalize")
+            e.forward_head(labels[r * Nl:(r + 1) * Nl], scores_ready=True)
+            e.backward_head()
+            out[r] = {k: v.clone() for k, v in e.backward_backbone().items()}
+            torch.cuda.synchronize()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W_)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(o is not None for o in out)
+    assert engs[0].scheme.cpu().tolist() == full.scheme.cpu().tolist()
+    close((engs[0].loss + engs[1].loss).cpu() / W_, full.loss.cpu(), 1e-5)
+    # batch statistics of a deep layer are the global ones on both engines
+    name = "resnet_v2_50/block3/unit_2/bottleneck_v2/conv1/BatchNorm"
+    fs = [o for o in full.plan.ops if o["kind"] == "bn" and o["name"] == name][0]["stat"]
+    for e in engs:
+        es = [o for o in e.plan.ops if o["kind"] == "bn" and o["name"] == name][0]["stat"]
+        close(es["mean"].cpu(), fs["mean"].cpu(), 1e-4)
+        close(es["var"].cpu(), fs["var"].cpu(), 1e-4)
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k, r_ in ref.items():
+        if k.endswith(("/beta", "/gamma")):
+            got = out[0][k]                              # already global on every engine
+            close(out[1][k].cpu(), out[0][k].cpu(), 1e-5)
+        else:
+            got = out[0][k] + out[1][k]
+        scale = float(r_.abs().max())
+        err = float((got - r_).abs().max())
+        if scale < 1e-5 * gmax:
+            assert err < 1e-5 * gmax, k
+        else:
+            assert err < 1e-3 * scale, (k, err, scale)

@@ -113,3 +113,29 @@ def test_uneven_view_shards_gather_in_view_order():
     assert [ret[r][0] for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
     for r in range(3):
         assert np.array_equal(ret[r][1], full)
+
+
+def _allreduce_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    t = torch.arange(10, dtype=torch.float64) * (rank + 1)          # the BatchNorm sums are fp64
+    sh.allreduce_sum_(t)
+    ret[rank] = t.numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bn_sum_allreduce_helper():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_allreduce_worker, args=(port, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert np.array_equal(ret[r], np.arange(10, dtype=np.float64) * 3)
