@@ -748,7 +748,8 @@ __global__ void pack_filter_lp(const float* __restrict__ w, int K, int Kpad, int
 struct TileCfg { int bm, bn; };
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32},
                               {256, 128}, {128, 256}, {256, 64},    // these three: 8 waves
-                              {128, 192}, {64, 192}};               // one n-tile for the many 192-channel layers
+                              {128, 192}, {64, 192},                // one n-tile for the many 192-channel layers
+                              {256, 192}};                          // 8 waves: least operand traffic per flop (Conv2d_4a)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
@@ -793,6 +794,7 @@ int launch_t(int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st
         case 8: return launch_cfg<T, 4, 2, 2, 1>(a, generic, xf32, st);
         case 9: return launch_cfg<T, 2, 2, 2, 3>(a, generic, xf32, st);
         case 10: return launch_cfg<T, 2, 2, 1, 3>(a, generic, xf32, st);
+        case 11: return launch_cfg<T, 4, 2, 2, 3>(a, generic, xf32, st);
     }
     return GV_E_UNSUPPORTED;
 }

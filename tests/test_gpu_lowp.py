@@ -34,6 +34,11 @@ def st():
     return torch.cuda.current_stream().cuda_stream
 
 
+def special_tile():
+    """Index of the strip kernels (halo-tiled 3x3, 3-channel stems): the last tile configuration."""
+    return lib().gv_conv2d_num_tile_cfgs(-1) - 1
+
+
 def rnd(t, td):
     return t.to(td).to(torch.float32)
 
@@ -141,7 +146,7 @@ def test_lp_conv_combos_vs_oracle(k, stride, padding, cin, cout, ty):
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
-@pytest.mark.parametrize("tile", list(range(11)))
+@pytest.mark.parametrize("tile", list(range(12)))
 @pytest.mark.parametrize("cout", [32, 48, 200])
 def test_lp_conv_every_tile_config(tile, cout, ty):
     """All tile shapes, ragged M (286) and N not a multiple of 32; K = 360 is not a multiple of the k-tile."""
@@ -158,7 +163,7 @@ def test_lp_conv_every_tile_config(tile, cout, ty):
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
 @pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70))])
 def test_lp_halo_stem_kernel(ty, cout, pad, hw):
-    """The halo-tiled 3x3 kernel of Conv2d_2a/2b (tile configuration 11): ragged strips (width not a multiple of
+    """The halo-tiled 3x3 kernel of Conv2d_2a/2b (the last tile configuration): ragged strips (width not a multiple of
     32, height not a multiple of 4), VALID and SAME, with a residual, into a channel slice — equal to the
     implicit-GEMM kernel's result up to fp32 summation order."""
     code, td, ulp = TYPES[ty]
@@ -170,7 +175,7 @@ def test_lp_halo_stem_kernel(ty, cout, pad, hw):
     oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
     res = rnd(torch.randn(3, oh, ow, cout, generator=g), td)
     ref = oracle_conv(x, w, 1, "SAME" if pad else "VALID", scale, shift, True, residual=res)
-    y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=11, y_ld=cout + 16, y_off=8)
+    y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=special_tile(), y_ld=cout + 16, y_off=8)
     close(y, ref.numpy(), ulp)
     y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=0, y_ld=cout + 16, y_off=8)
     close(y, y0, ulp)
@@ -188,7 +193,7 @@ def test_lp_stem_strip_kernel(ty, k, pad, cout, hw):
     w = rnd(torch.randn(k, k, 3, cout, generator=g) * 0.2, td)
     scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     oh, ow = (ih + 2 * pad - k) // 2 + 1, (iw + 2 * pad - k) // 2 + 1
-    y = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, ty, x_f32=True, tile=11)
+    y = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, ty, x_f32=True, tile=special_tile())
     y0 = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, ty, x_f32=True, tile=2)
     close(y, y0, 2 * ulp)            # two roundings of sums in different order: 1 ulp, 2 across a binade boundary
     xr = rnd(x, td)
