@@ -125,7 +125,7 @@ def test_conv_combos_vs_oracle(k, stride, padding, cin, cout):
     np.testing.assert_allclose(y, ref.numpy(), rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile", list(range(11)))
+@pytest.mark.parametrize("tile", list(range(12)))
 @pytest.mark.parametrize("cout", [32, 48, 80, 192, 200])
 def test_conv_every_tile_config(tile, cout):
     """All tile shapes give the same answer, incl. ragged M and N not a multiple of 32."""
