@@ -351,3 +351,32 @@ def test_hipgraph_replay_matches_eager(lanes):
     torch.cuda.synchronize()
     assert torch.equal(s_g, s_e) and torch.equal(S_g, S_e) and torch.equal(l_g, l_e)
     eng.check_status()
+
+
+def test_bench_line_contract():
+    """bench.py prints exactly ONE JSON line with every key the driver and the judge read (metric/value/unit/n_gpus/
+    steps/warmup/ms_per_step/higher_is_better/scaling/vs_baseline/dtype/data/config + roofline + cpu_baseline)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--shapes", "2",
+                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(j[k], t), (k, j[k])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["vs_baseline"] is None
+    assert j["metric"] == "views/sec" and j["unit"] == "views/s" and j["scaling"] == "weak" and j["dtype"] == "f32"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 2 * 12 / (j["ms_per_step"] * 1e-3)) < 0.01 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
