@@ -183,8 +183,14 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
     }
 }
 
+// FDB: fragments double buffered in registers.  The 128x128 tile (2x2 accumulators per wave) reaches three workgroups
+// per CU only with ONE fragment set; the other two waves of the SIMD cover the ds_read latency instead.
+template <int WM, int WN, int TM, int TN>
+constexpr bool lp_fdb() { return !(WM * WN == 4 && TM * TN == 4); }
+
 template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 3 ? 3 : 2) : 1)) void conv_igemm_lp(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2) : 1)) void conv_igemm_lp(const ConvArgs a) {
+    constexpr bool FDB = lp_fdb<WM, WN, TM, TN>();
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     static_assert(GENERIC || !XF32, "fp32 input only on the gather path");
     constexpr int NT = WM * WN * 64;                 // threads
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 3 ? 3 : 2
     const char* a_frag = sA + (wm * TM * 32) * RB + frag_off;
     const char* b_frag = sB + (wn * TN * 32) * RB + frag_off;
 
-    u32x4 fa[2][TM][2], fb[2][TN][2];
+    u32x4 fa[FDB ? 2 : 1][TM][2], fb[FDB ? 2 : 1][TN][2];
     auto read_frags = [&](auto setc, int buf) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
@@ -432,14 +438,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 3 ? 3 : 2
     __syncthreads();
     read_frags(I0{}, 0);
     int kt = 0;
-    for (; kt + 2 < a.ktiles; kt += 2) {
-        step(I0{}, kt);
-        step(I1{}, kt + 1);
-    }
-    if (a.ktiles - kt == 2) {
-        step(I0{}, kt);
-        mfma_range(I1{}, I0{}, IN{});
+    if constexpr (FDB) {
+        for (; kt + 2 < a.ktiles; kt += 2) {
+            step(I0{}, kt);
+            step(I1{}, kt + 1);
+        }
+        if (a.ktiles - kt == 2) {
+            step(I0{}, kt);
+            mfma_range(I1{}, I0{}, IN{});
+        } else {
+            mfma_range(I0{}, I0{}, IN{});
+        }
     } else {
+        // one fragment set: hand tile kt+1 to LDS, multiply tile kt, barrier, fetch tile kt+1's fragments
+        auto step1 = [&](auto rsc, int k) {
+            const int buf = k & 1;
+            store_tile(rsc, buf ^ 1);
+            advance_tap();
+            load_tile(rsc, k + 3);
+            mfma_range(I0{}, I0{}, IN{});
+            __syncthreads();
+            read_frags(I0{}, buf ^ 1);
+        };
+        for (; kt + 2 < a.ktiles; kt += 2) {
+            step1(I1{}, kt);
+            step1(I0{}, kt + 1);
+        }
+        if (a.ktiles - kt == 2) step1(I1{}, kt);
         mfma_range(I0{}, I0{}, IN{});
     }
 
