@@ -163,14 +163,15 @@ def train_main(a, world, rank, dev):
     N = a.shapes
     if a.dp == "views":
         lo, hi = view_shard_range(V, world, rank)
-        eng = TrainGVCNN(BACKBONE, N, hi - lo, H, W, C, G, device=dev, num_bins=G, head_views=V, view_offset=lo)
+        eng = TrainGVCNN(BACKBONE, N, hi - lo, H, W, C, G, device=dev, num_bins=G, head_views=V, view_offset=lo,
+                         storage=a.storage)
         sh = ShardedTrainGVCNN(eng)
         x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5)[:, lo:hi].contiguous().to(dev)
         labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1))
         views_per_step, views_local = N * V, N * (hi - lo)
     else:                                            # N shapes PER RANK (weak scaling), all their views
         lo, hi = 0, V
-        eng = TrainGVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G)
+        eng = TrainGVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, storage=a.storage)
         sh = ShardedTrainGVCNN(eng, mode="shapes")
         x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(rank)) - 0.5).to(dev)
         labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(100 + rank))
@@ -203,10 +204,13 @@ def train_main(a, world, rank, dev):
             "metric": "views/sec (training step)", "value": round(views_per_step / (ms * 1e-3), 1), "unit": "views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong" if a.dp == "views" else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": a.storage, "data": "synthetic",
             "config": {"workload": "training step (SURVEY a12): %s, %d shapes x %d views x %dx%d, train-mode BN per view, "
-                                   "CE loss, backward, BN moving averages, Momentum; fp32 storage, bf16x3 math; %s sharded "
-                                   "over the ranks" % (BACKBONE, N, V, H, W, a.dp), "views_per_gpu": views_local},
+                                   "CE loss, backward, BN moving averages, Momentum; %s; %s sharded "
+                                   "over the ranks" % (BACKBONE, N, V, H, W,
+                                                       "fp32 storage, bf16x3 math" if a.storage == "f32" else
+                                                       a.storage + " activations and gradients on the 16-bit MFMA, fp32 "
+                                                       "master weights", a.dp), "views_per_gpu": views_local},
             "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}), flush=True)
 
 

@@ -85,6 +85,14 @@ SIGNATURES = {
     "gv_softmax_ce": (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     "gv_dense_bwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "gv_sgd_momentum": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _P]),
+    "gv_bn_sums_grouped_t": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "gv_scale_shift_act_grouped_t": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
+    "gv_bn_relu_bwd_sums_grouped_t": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "gv_bn_relu_bwd_apply_grouped_t": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P,
+                                                 _P, _I, _P]),
+    "gv_accumulate_t": (C.c_int, [_P, _I, _P, _I, _L, _I, _I, _P]),
+    "gv_bias_grad_t": (C.c_int, [_P, _I, _L, _I, _P, _P, _I, _P]),
+    "gv_view_pool_fuse_bwd_t": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _I, _I, _P]),
     "gv_plan_create": (C.c_int, [C.POINTER(_P)]),
     "gv_plan_destroy": (None, [_P]),
     "gv_plan_num_ops": (C.c_int, [_P]),
@@ -109,6 +117,7 @@ TUNING = {
     "gv_conv2d_set_debug": (None, [C.c_int]),
     "gv_conv2d_num_tile_cfgs": (C.c_int, [C.c_int]),
     "gv_conv2d_wgrad_set_v1": (None, [C.c_int]),
+    "gv_conv2d_wgrad_set_lp_f32": (None, [C.c_int]),
 }
 
 _lib = None

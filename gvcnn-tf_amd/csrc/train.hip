@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include "gv_common.h"
+#include "lowp.h"
 
 namespace {
 
@@ -472,15 +473,35 @@ inline unsigned grid_for(int64_t total) {
 }
 
 
+// Storage-typed loads of the filter-gradient kernels: S = float, __bf16 or _Float16 in HBM, fp32 in registers.
+template <typename S>
+__device__ __forceinline__ f32x4 ld4(const S* p) {
+    if constexpr (sizeof(S) == 4) {
+        return *reinterpret_cast<const f32x4*>(p);
+    } else {
+        const uint2 raw = *reinterpret_cast<const uint2*>(p);
+        f32x4 v;
+        v[0] = (float)__builtin_bit_cast(S, (unsigned short)(raw.x & 0xffffu));
+        v[1] = (float)__builtin_bit_cast(S, (unsigned short)(raw.x >> 16));
+        v[2] = (float)__builtin_bit_cast(S, (unsigned short)(raw.y & 0xffffu));
+        v[3] = (float)__builtin_bit_cast(S, (unsigned short)(raw.y >> 16));
+        return v;
+    }
+}
+template <typename S>
+__device__ __forceinline__ bool ld4_ok(const S* p, int ld) {
+    return (ld & 3) == 0 && ((((uintptr_t)p) & (4 * sizeof(S) - 1)) == 0);
+}
+
 // Filter gradient, second generation: workgroup tile (64*TI) input channels x (64*TO) output channels for one
 // filter tap, 2x2 waves of TI x TO MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32; the k axis of this GEMM is
 // the PIXEL axis, and pixel-major LDS rows are exactly the k-major operand image this instruction wants:
 // lane (i, h) reads element [pixel k + h][channel i], 32 consecutive dwords per half-wave).  16 pixels per
 // step, LDS double buffered, the next step's global loads are issued before this step's MFMAs, one barrier
 // per step.  Pixel slices (blockIdx.y) are combined with fp32 atomics.
-template <int TI, int TO>
-__global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__ x, int x_ld,
-                                                       const float* __restrict__ dz, int dz_ld, int nb, int ih,
+template <typename S, int TI, int TO>
+__global__ __launch_bounds__(256) void conv_wgrad2_f32(const S* __restrict__ x, int x_ld,
+                                                       const S* __restrict__ dz, int dz_ld, int nb, int ih,
                                                        int iw, int cin, int kh, int kw, int stride, int pad_t,
                                                        int pad_l, int oh, int ow, int cout, int64_t M,
                                                        int64_t m_per_block, float* __restrict__ dw) {
@@ -507,8 +528,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
     const int ohow = oh * ow;
-    const bool xvec = (x_ld & 3) == 0 && (cin & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
-    const bool zvec = (dz_ld & 3) == 0 && (cout & 3) == 0 && ((((uintptr_t)dz) & 15u) == 0);
+    const bool xvec = (cin & 3) == 0 && ld4_ok(x, x_ld);
+    const bool zvec = (cout & 3) == 0 && ld4_ok(dz, dz_ld);
     f32x4 xr[XV], zr[ZV];
     auto load = [&](int64_t mt) {
 #pragma unroll
@@ -523,12 +544,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__
                 const int oy = rem / ow, ox = rem - oy * ow;
                 const int iy = oy * stride + fr - pad_t, ix = ox * stride + fs - pad_l;
                 if ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) {
-                    const float* xp = x + (((size_t)n * ih + iy) * iw + ix) * x_ld + c;
+                    const S* xp = x + (((size_t)n * ih + iy) * iw + ix) * x_ld + c;
                     if (xvec) {
-                        v = *reinterpret_cast<const f32x4*>(xp);
+                        v = ld4(xp);
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (c + e < cin) v[e] = xp[e];
+                        for (int e = 0; e < 4; ++e) if (c + e < cin) v[e] = (float)xp[e];
                     }
                 }
             }
@@ -541,12 +562,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__
             const int64_t m = mt + p;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (m < m1 && c < cout) {
-                const float* zp = dz + (size_t)m * dz_ld + c;
+                const S* zp = dz + (size_t)m * dz_ld + c;
                 if (zvec) {
-                    v = *reinterpret_cast<const f32x4*>(zp);
+                    v = ld4(zp);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (c + e < cout) v[e] = zp[e];
+                    for (int e = 0; e < 4; ++e) if (c + e < cout) v[e] = (float)zp[e];
                 }
             }
             zr[j] = v;
@@ -611,9 +632,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const float* __restrict__
 // fetched straight from global memory — the k axis of this GEMM is the pixel axis, so lane (i, h) needs
 // x[pixel k+h shifted by tap(i)][ci(i)] and dz[pixel k+h][co i]: 128-byte coalesced rows, no LDS, no barrier.
 // Loads run U pixel pairs ahead of the MFMAs that consume them.  Waves are combined with fp32 atomics.
-template <int NRT, int U>
-__global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const float* __restrict__ x, int x_ld,
-                                                             const float* __restrict__ dz, int dz_ld, int ih, int iw,
+template <typename S, int NRT, int U>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const S* __restrict__ x, int x_ld,
+                                                             const S* __restrict__ dz, int dz_ld, int ih, int iw,
                                                              int cin, int kh, int kw, int stride, int pad_t,
                                                              int pad_l, int oh, int ow, int cout, int64_t M,
                                                              int64_t m_per_wave, float* __restrict__ dw) {
@@ -660,9 +681,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const float* __rest
             for (int t = 0; t < NRT; ++t) {
                 const bool ok = pok && rv[t] && (unsigned)(iy0 + fr[t]) < (unsigned)ih &&
                                 (unsigned)(ix0 + fs[t]) < (unsigned)iw;
-                av[s][u][t] = ok ? x[base + delta[t]] : 0.f;
+                av[s][u][t] = ok ? (float)x[base + delta[t]] : 0.f;
             }
-            bv[s][u] = (pok && co < cout) ? dz[m * dz_ld + co] : 0.f;
+            bv[s][u] = (pok && co < cout) ? (float)dz[m * dz_ld + co] : 0.f;
             m += 2;
             ox += 2;
             while (ox >= ow) {
@@ -849,14 +870,16 @@ extern "C" int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
     return GV_OK;
 }
 
-extern "C" int gv_pool2d_bwd(const gv_pool_desc* d, const float* x, const float* dy, int32_t dy_ld, float* dx,
+extern "C" int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t dy_ld, void* dx,
                              int32_t dx_ld, void* stream) {
     if (!d || !dy || !dx || (d->mode == GV_POOL_MAX && !x)) return GV_E_BADARG;
     if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG) return GV_E_BADARG;
+    if (d->dtype == GV_BF16 || d->dtype == GV_F16)
+        return gvlp::pool2d_bwd(d, x, dy, dy_ld, dx, dx_ld, (hipStream_t)stream);
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
     hipLaunchKernelGGL(pool2d_bwd_f32, dim3(grid_for((int64_t)d->nb * d->oh * d->ow * d->c)), dim3(256), 0,
-                       (hipStream_t)stream, x, d->x_ld, dy, dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw,
-                       d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->mode, dx, dx_ld);
+                       (hipStream_t)stream, (const float*)x, d->x_ld, (const float*)dy, dy_ld, d->nb, d->ih, d->iw, d->c,
+                       d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->mode, (float*)dx, dx_ld);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
@@ -943,25 +966,28 @@ extern "C" int gv_bn_update_moving(const float* mean, const float* var, const in
 static int g_wgrad_v1 = 0;
 extern "C" void gv_conv2d_wgrad_set_v1(int on) { g_wgrad_v1 = on; }
 
-extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const float* dz, int32_t dz_ld,
-                               float* dw_hwio, void* stream) {
-    if (!d || !x || !dz || !dw_hwio) return GV_E_BADARG;
-    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
-    if (d->nb <= 0 || d->cin <= 0 || d->cout <= 0 || dz_ld < d->cout || d->x_ld < d->cin) return GV_E_BADARG;
+// few-channel stem layers: all taps in one wave, operands straight from global memory
+static bool wgrad_direct_ok(const gv_conv_desc* d) {
+    const int64_t M = (int64_t)d->nb * d->oh * d->ow;
+    return d->kh * d->kw * d->cin <= 288 && d->cin <= 32 && M >= 200000 &&
+           (int64_t)d->nb * d->ih * d->iw * d->x_ld < 0x7fffffffll;
+}
+
+// the fp32-MFMA filter gradient for storage type S (float; 16-bit: stems and shapes the 16-bit MFMA kernel
+// does not take)
+template <typename S>
+static int wgrad_f32mfma(const gv_conv_desc* d, const S* x, const S* dz, int32_t dz_ld, float* dw_hwio, hipStream_t st) {
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
     const int R = d->kh * d->kw * d->cin;
-    if (!g_wgrad_v1 && R <= 288 && d->cin <= 32 && M >= 200000 &&
-        (int64_t)d->nb * d->ih * d->iw * d->x_ld < 0x7fffffffll) {
-        // few-channel stem layers: all taps in one wave, operands straight from global memory
+    if (wgrad_direct_ok(d)) {
         const int nrt = (R + 31) / 32;
         const int64_t waves = 256 * 4 * (nrt == 1 ? 6 : (nrt <= 5 ? 2 : 1));
         int64_t per = (M + waves - 1) / waves;
         per = (per + 1) / 2 * 2;
         const int64_t nw = (M + per - 1) / per;
         const dim3 grid((unsigned)(((nw + 3) / 4) * ((d->cout + 31) / 32)));
-        hipStream_t st = (hipStream_t)stream;
 #define GV_WGRAD_D(NRT, U)                                                                                          \
-        hipLaunchKernelGGL((conv_wgrad_direct_f32<NRT, U>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->ih,     \
+        hipLaunchKernelGGL((conv_wgrad_direct_f32<S, NRT, U>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->ih,  \
                            d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per,  \
                            dw_hwio)
         if (nrt == 1) GV_WGRAD_D(1, 8);
@@ -971,33 +997,50 @@ extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const floa
         GV_LAUNCH_CHECK();
         return GV_OK;
     }
-    if (!g_wgrad_v1) {
-        // 128 channels on a side only where that wastes no more rows than 64-wide tiles would
-        const int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
-        const int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
-        const int tiles = d->kh * d->kw * ((d->cin + 64 * ti - 1) / (64 * ti)) * ((d->cout + 64 * to - 1) / (64 * to));
-        int64_t splits = (2048 + tiles - 1) / tiles;            // ~2k workgroups: 256 CUs x 2-4 resident, 2+ rounds
-        const int64_t max_splits = (M + 511) / 512;             // at least 512 pixels per workgroup
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        if (splits > 65535) splits = 65535;
-        int64_t per = (M + splits - 1) / splits;
-        per = (per + 31) / 32 * 32;
-        splits = (M + per - 1) / per;
-        const dim3 grid((unsigned)tiles, (unsigned)splits);
-        hipStream_t st = (hipStream_t)stream;
+    // 128 channels on a side only where that wastes no more rows than 64-wide tiles would
+    const int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
+    const int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
+    const int tiles = d->kh * d->kw * ((d->cin + 64 * ti - 1) / (64 * ti)) * ((d->cout + 64 * to - 1) / (64 * to));
+    int64_t splits = (2048 + tiles - 1) / tiles;            // ~2k workgroups: 256 CUs x 2-4 resident, 2+ rounds
+    const int64_t max_splits = (M + 511) / 512;             // at least 512 pixels per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    int64_t per = (M + splits - 1) / splits;
+    per = (per + 31) / 32 * 32;
+    splits = (M + per - 1) / per;
+    const dim3 grid((unsigned)tiles, (unsigned)splits);
 #define GV_WGRAD2(TI, TO)                                                                                          \
-        hipLaunchKernelGGL((conv_wgrad2_f32<TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih,   \
-                           d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, \
-                           dw_hwio)
-        if (ti == 2 && to == 2) GV_WGRAD2(2, 2);
-        else if (ti == 2) GV_WGRAD2(2, 1);
-        else if (to == 2) GV_WGRAD2(1, 2);
-        else GV_WGRAD2(1, 1);
+    hipLaunchKernelGGL((conv_wgrad2_f32<S, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih,    \
+                       d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per,     \
+                       dw_hwio)
+    if (ti == 2 && to == 2) GV_WGRAD2(2, 2);
+    else if (ti == 2) GV_WGRAD2(2, 1);
+    else if (to == 2) GV_WGRAD2(1, 2);
+    else GV_WGRAD2(1, 1);
 #undef GV_WGRAD2
-        GV_LAUNCH_CHECK();
-        return GV_OK;
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+static int g_wgrad_lp_f32 = 0;
+/* tuning hook: 16-bit storage filter gradients on the fp32 MFMA (typed loads) instead of the 16-bit MFMA kernel */
+extern "C" void gv_conv2d_wgrad_set_lp_f32(int on) { g_wgrad_lp_f32 = on; }
+
+extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld,
+                               float* dw_hwio, void* stream) {
+    if (!d || !x || !dz || !dw_hwio) return GV_E_BADARG;
+    if (d->nb <= 0 || d->cin <= 0 || d->cout <= 0 || dz_ld < d->cout || d->x_ld < d->cin) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == GV_BF16 || d->dtype == GV_F16) {
+        if (!g_wgrad_lp_f32 && !wgrad_direct_ok(d) && gvlp::wgrad_mfma_ok(d, x, dz, dz_ld))
+            return gvlp::conv_wgrad(d, x, dz, dz_ld, dw_hwio, st);
+        if (d->dtype == GV_BF16) return wgrad_f32mfma<__bf16>(d, (const __bf16*)x, (const __bf16*)dz, dz_ld, dw_hwio, st);
+        return wgrad_f32mfma<_Float16>(d, (const _Float16*)x, (const _Float16*)dz, dz_ld, dw_hwio, st);
     }
+    if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (!g_wgrad_v1) return wgrad_f32mfma<float>(d, (const float*)x, (const float*)dz, dz_ld, dw_hwio, st);
+    const int64_t M = (int64_t)d->nb * d->oh * d->ow;
     const int tiles = d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
     int64_t splits = (4096 + tiles - 1) / tiles;                // ~4k workgroups in flight
     const int64_t max_splits = (M + 255) / 256;                 // at least 256 pixels per workgroup
@@ -1007,9 +1050,121 @@ extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const floa
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
-    hipLaunchKernelGGL(conv_wgrad_f32, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, (hipStream_t)stream, x,
-                       d->x_ld, dz, dz_ld, d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t,
+    hipLaunchKernelGGL(conv_wgrad_f32, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, (const float*)x,
+                       d->x_ld, (const float*)dz, dz_ld, d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t,
                        d->pad_l, d->oh, d->ow, d->cout, M, per, dw_hwio);
     GV_LAUNCH_CHECK();
     return GV_OK;
+}
+
+// ---- storage-typed forms (16-bit training step; GV_F32 forwards to the fp32 entry points) ---------------------------
+static inline bool lp_type(int dtype) { return dtype == GV_BF16 || dtype == GV_F16; }
+
+static inline int sums_splits(int64_t npix, int cap) {
+    int splits = (int)((npix + 2047) / 2048);
+    return splits > cap ? cap : (splits < 1 ? 1 : splits);
+}
+
+extern "C" int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
+                                    int32_t num_groups, double* accum, int32_t dtype, void* stream) {
+    if (dtype == GV_F32) return gv_bn_sums_grouped((const float*)z, nb, hw, c, z_ld, num_groups, accum, stream);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!z || !accum) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || z_ld < c || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
+    return gvlp::grouped_sums(dtype, 0, z, z_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, nb, hw, c, num_groups,
+                              sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
+}
+
+extern "C" int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
+                                            const float* scale, const float* shift, int32_t num_groups,
+                                            int32_t relu, void* y, int32_t y_ld, int32_t dtype, void* stream) {
+    if (dtype == GV_F32)
+        return gv_scale_shift_act_grouped((const float*)x, nb, hw, c, x_ld, scale, shift, num_groups, relu, (float*)y,
+                                          y_ld, stream);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!x || !y || !scale || !shift || nb <= 0 || hw <= 0 || c <= 0 || x_ld < c || y_ld < c || num_groups <= 0)
+        return GV_E_BADARG;
+    return gvlp::scale_shift_act_grouped(dtype, x, nb, hw, c, x_ld, scale, shift, num_groups, relu, y, y_ld,
+                                         (hipStream_t)stream);
+}
+
+extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld,
+                                             const void* z, int32_t z_ld, const float* mean, const float* inv,
+                                             int32_t nb, int32_t hw, int32_t c, int32_t num_groups, double* accum,
+                                             int32_t dtype, void* stream) {
+    if (dtype == GV_F32)
+        return gv_bn_relu_bwd_sums_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
+                                           inv, nb, hw, c, num_groups, accum, stream);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!dy || !z || !mean || !inv || !accum) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
+    return gvlp::grouped_sums(dtype, 1, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, nb, hw, c, num_groups,
+                              sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
+}
+
+extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld,
+                                              const void* z, int32_t z_ld, const float* mean, const float* inv,
+                                              const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
+                                              int32_t c, int32_t num_groups, const double* accum, void* dz,
+                                              int32_t dz_ld, float* dbeta, float* dgamma, int32_t dtype,
+                                              void* stream) {
+    if (dtype == GV_F32)
+        return gv_bn_relu_bwd_apply_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
+                                            inv, gamma, counts, nb, hw, c, num_groups, accum, (float*)dz, dz_ld, dbeta,
+                                            dgamma, stream);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = gvlp::bn_bwd_apply_grouped(dtype, dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw,
+                                              c, num_groups, dz, dz_ld, st);
+    if (rc != GV_OK) return rc;
+    if (dbeta || dgamma)
+        hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
+                           dgamma);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_accumulate_t(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                               int32_t dtype, void* stream) {
+    if (dtype == GV_F32) return gv_accumulate((const float*)src, src_ld, (float*)dst, dst_ld, npix, c, stream);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!src || !dst || npix <= 0 || c <= 0 || src_ld < c || dst_ld < c) return GV_E_BADARG;
+    return gvlp::accumulate(dtype, src, src_ld, dst, dst_ld, npix, c, (hipStream_t)stream);
+}
+
+extern "C" int gv_bias_grad_t(const void* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum, float* dbias,
+                              int32_t dtype, void* stream) {
+    if (dtype == GV_F32) return gv_bias_grad((const float*)dz, dz_ld, npix, c, accum, dbias, stream);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!dz || !accum || !dbias || npix <= 0 || c <= 0 || dz_ld < c || npix > 0x7fffffff) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)c, st));
+    const int rc = gvlp::grouped_sums(dtype, 2, nullptr, 0, dz, dz_ld, nullptr, 0, nullptr, nullptr, (int)npix, 1, c, 1,
+                                      sums_splits(npix, 1024), accum, st);
+    if (rc != GV_OK) return rc;
+    hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, 1, c, dbias, (float*)nullptr);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+extern "C" int gv_view_pool_fuse_bwd_t(const void* F, const float* dS, int32_t num_views, int32_t num_shapes,
+                                       int64_t E, int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
+                                       int32_t num_groups, const float* weight, int32_t mode, void* dF,
+                                       int32_t per_shape, int32_t dtype, void* stream) {
+    const int64_t ss = per_shape ? (int64_t)num_groups * num_views : 0, ws = per_shape ? num_groups : 0;
+    if (dtype == GV_F32)
+        return pool_fuse_bwd_launch((const float*)F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme,
+                                    num_groups, weight, mode, (float*)dF, stream, ss, ws);
+    if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
+    if (!F || !dS || !scheme || !weight || !dF) return GV_E_BADARG;
+    if (num_views <= 0 || num_shapes <= 0 || E <= 0 || num_groups <= 0) return GV_E_BADARG;
+    if (num_views > 64 || num_groups > 64 || num_shapes > 65535) return GV_E_UNSUPPORTED;
+    return gvlp::view_pool_fuse_bwd(dtype, F, dS, num_views, num_shapes, E, view_stride, shape_stride, scheme,
+                                    num_groups, weight, mode, dF, (hipStream_t)stream, ss, ws);
 }

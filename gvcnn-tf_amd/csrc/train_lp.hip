@@ -1,0 +1,640 @@
+// train_lp.hip — the training step on 16-bit storage (configs[2]: bf16 forward + backward).
+// Activations and activation gradients live in HBM as GV_BF16 / GV_F16; batch statistics accumulate in fp64,
+// parameter gradients (dW, dbeta, dgamma, dbias) and the optimizer state stay fp32, every elementwise result is
+// computed in fp32 and rounded to the storage type once.  Same algorithms as train.hip (the fp32 step); a thread
+// owns 8 consecutive channels (one 16-byte load) wherever the channel count allows.
+//
+// The filter gradient runs on v_mfma_f32_32x32x16_{bf16,f16}.  Its reduction axis is the PIXEL axis while both
+// operands (the shifted input and dZ) are channel-contiguous in HBM, i.e. k-strided for the MFMA: the tiles are
+// written to LDS as they arrive ([pixel][channel], ds_write_b128) and read back with gfx950's transposing
+// ds_read_b64_tr_b16, which hands lane (channel i) four consecutive pixels of its column.
+#include <math.h>
+
+#include "lowp.h"
+#include "lp_elem.h"
+
+namespace {
+
+using namespace gvlp_elem;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = 256 * 16;
+    return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+// dst[p][c] += src[p][c]
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void accumulate_lp(const unsigned short* __restrict__ src, int src_ld,
+                                                     unsigned short* __restrict__ dst, int dst_ld, int64_t npix,
+                                                     int c) {
+    const int cg = c / VEC;
+    const int64_t total = npix * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        float a[8], b[8];
+        load_v<T, VEC>(src + pix * src_ld + q * VEC, a);
+        load_v<T, VEC>(dst + pix * dst_ld + q * VEC, b);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) b[e] += a[e];
+        store_v<T, VEC>(dst + pix * dst_ld + q * VEC, b);
+    }
+}
+
+// Per-(group, channel) sums, see grouped_sums_f32 in train.hip.  MODE 0: sum z, sum z^2; MODE 1: sum g, sum g*zhat with
+// g = dy*[y>0]; MODE 2: sum dz.  A thread owns VEC channels; 64 channels per block; grid (channel blocks, splits, G).
+template <typename T, int MODE, int VEC>
+__global__ __launch_bounds__(256) void grouped_sums_lp(const unsigned short* __restrict__ z, int z_ld,
+                                                       const unsigned short* __restrict__ dy, int dy_ld,
+                                                       const unsigned short* __restrict__ y, int y_ld,
+                                                       const float* __restrict__ mean, const float* __restrict__ inv,
+                                                       int nb, int hw, int c, int G, double* __restrict__ acc) {
+    constexpr int TPC = 64 / VEC;
+    constexpr int PL = 256 / TPC;
+    const int cl = threadIdx.x % TPC;
+    const int pl = threadIdx.x / TPC;
+    const int ch = blockIdx.x * 64 + cl * VEC;
+    const int g = blockIdx.z;
+    const int nimg = (nb - g + G - 1) / G;
+    const int64_t npix = (int64_t)nimg * hw;
+    const int64_t per = (npix + gridDim.y - 1) / gridDim.y;
+    const int64_t p0 = (int64_t)blockIdx.y * per;
+    const int64_t p1 = p0 + per < npix ? p0 + per : npix;
+    double s0[VEC], s1[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.0;
+    if (ch < c) {
+        float mu[VEC], iv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
+            iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
+        }
+        // fp32 partial sums over short runs (exact enough for 16-bit inputs), folded into fp64 every 16 pixels
+        for (int64_t pb = p0 + pl; pb < p1; pb += (int64_t)PL * 16) {
+            float f0[VEC], f1[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f0[e] = f1[e] = 0.f;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int64_t p = pb + (int64_t)it * PL;
+                if (p >= p1) break;
+                const int k = (int)(p / hw);
+                const int64_t pix = (int64_t)(k * G + g) * hw + (p - (int64_t)k * hw);
+                float zv[8], gv[8], yv[8];
+                if (MODE != 2) load_v<T, VEC>(z + pix * z_ld + ch, zv);
+                if (MODE != 0) load_v<T, VEC>(dy + pix * dy_ld + ch, gv);
+                if (MODE == 1 && y) load_v<T, VEC>(y + pix * y_ld + ch, yv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (MODE == 0) {
+                        f0[e] += zv[e];
+                        f1[e] = fmaf(zv[e], zv[e], f1[e]);
+                    } else if (MODE == 1) {
+                        float gr = gv[e];
+                        if (y && !(yv[e] > 0.f)) gr = 0.f;
+                        f0[e] += gr;
+                        f1[e] = fmaf(gr, (zv[e] - mu[e]) * iv[e], f1[e]);
+                    } else {
+                        f0[e] += gv[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s0[e] += f0[e]; s1[e] += f1[e]; }
+        }
+    }
+    __shared__ double red[2][PL][64];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        red[0][pl][cl * VEC + e] = s0[e];
+        red[1][pl][cl * VEC + e] = s1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < c) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
+        const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
+        atomicAdd(&acc[o], a);
+        if (MODE != 2) atomicAdd(&acc[o + 1], b);
+    }
+}
+
+// y = act(x*scale[g][c] + shift[g][c]),  g = image % G
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void scale_shift_act_grouped_lp(const unsigned short* __restrict__ x, int nb, int hw,
+                                                                  int c, int x_ld, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int G, int relu,
+                                                                  unsigned short* __restrict__ y, int y_ld) {
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * hw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int g = (int)((pix / hw) % G);
+        float v[8];
+        load_v<T, VEC>(x + pix * x_ld + q * VEC, v);
+        const float* sc = scale + (size_t)g * c + q * VEC;
+        const float* sh = shift + (size_t)g * c + q * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[e] = v[e] * sc[e] + sh[e];
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        store_v<T, VEC>(y + pix * y_ld + q * VEC, v);
+    }
+}
+
+// dz += gamma*inv * (g - s1/m - zhat*s2/m),  g = dy*[y>0]
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_grouped_lp(
+    const unsigned short* __restrict__ dy, int dy_ld, const unsigned short* __restrict__ y, int y_ld,
+    const unsigned short* __restrict__ z, int z_ld, const float* __restrict__ mean, const float* __restrict__ inv,
+    const float* __restrict__ gamma, const double* __restrict__ acc, const int* __restrict__ counts, int nb, int hw,
+    int c, int G, unsigned short* __restrict__ dz, int dz_ld) {
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * hw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int g = (int)((pix / hw) % G);
+        const int gi = g * c + q * VEC;
+        float gr[8], yv[8], zv[8], dv[8];
+        load_v<T, VEC>(dy + pix * dy_ld + q * VEC, gr);
+        if (y) load_v<T, VEC>(y + pix * y_ld + q * VEC, yv);
+        load_v<T, VEC>(z + pix * z_ld + q * VEC, zv);
+        load_v<T, VEC>(dz + pix * dz_ld + q * VEC, dv);
+        const float rm = 1.f / (float)counts[g];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float gg = gr[e];
+            if (y && !(yv[e] > 0.f)) gg = 0.f;
+            const float iv = inv[gi + e];
+            const float zh = (zv[e] - mean[gi + e]) * iv;
+            const float s1 = (float)acc[(size_t)(gi + e) * 2], s2 = (float)acc[(size_t)(gi + e) * 2 + 1];
+            const float coef = (gamma ? gamma[q * VEC + e] : 1.f) * iv;
+            dv[e] += coef * (gg - s1 * rm - zh * s2 * rm);
+        }
+        store_v<T, VEC>(dz + pix * dz_ld + q * VEC, dv);
+    }
+}
+
+// Pool backward as a GATHER over the input pixels (no atomics: 16-bit storage has none worth using, and the result
+// is deterministic): an input pixel visits the windows that contain it.  max: it receives a window's gradient when
+// it is that window's first maximum in scan order (tf MaxPoolGrad / torch); avg: dy / #valid taps of every window.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __restrict__ x, int x_ld,
+                                                     const unsigned short* __restrict__ dy, int dy_ld, int nb, int ih,
+                                                     int iw, int c, int kh, int kw, int stride, int pad_t, int pad_l,
+                                                     int oh, int ow, int mode, unsigned short* __restrict__ dx,
+                                                     int dx_ld) {
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * ih * iw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int ix = (int)(pix % iw);
+        const int64_t t = pix / iw;
+        const int iy = (int)(t % ih);
+        const int n = (int)(t / ih);
+        // windows (oy, ox) with oy*stride - pad_t <= iy <= oy*stride - pad_t + kh - 1
+        int oy0 = iy + pad_t - kh + 1;
+        oy0 = oy0 <= 0 ? 0 : (oy0 + stride - 1) / stride;
+        int oy1 = (iy + pad_t) / stride;
+        if (oy1 > oh - 1) oy1 = oh - 1;
+        int ox0 = ix + pad_l - kw + 1;
+        ox0 = ox0 <= 0 ? 0 : (ox0 + stride - 1) / stride;
+        int ox1 = (ix + pad_l) / stride;
+        if (ox1 > ow - 1) ox1 = ow - 1;
+        if (oy0 > oy1 || ox0 > ox1) continue;
+        float sum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+        float mine[8];
+        if (mode == GV_POOL_MAX) load_v<T, VEC>(x + pix * x_ld + q * VEC, mine);
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                float g[8];
+                load_v<T, VEC>(dy + ((int64_t)(n * oh + oy) * ow + ox) * dy_ld + q * VEC, g);
+                if (mode == GV_POOL_MAX) {
+                    // this pixel wins when no earlier tap is >= it and no later tap is > it
+                    bool win[8];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) win[e] = true;
+                    bool before = true;
+                    for (int r = 0; r < kh; ++r) {
+                        const int yy = oy * stride + r - pad_t;
+                        if ((unsigned)yy >= (unsigned)ih) continue;
+                        for (int s = 0; s < kw; ++s) {
+                            const int xx = ox * stride + s - pad_l;
+                            if ((unsigned)xx >= (unsigned)iw) continue;
+                            if (yy == iy && xx == ix) { before = false; continue; }
+                            float v[8];
+                            load_v<T, VEC>(x + ((int64_t)(n * ih + yy) * iw + xx) * x_ld + q * VEC, v);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                win[e] = win[e] && (before ? !(v[e] >= mine[e]) : !(v[e] > mine[e]));
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sum[e] += win[e] ? g[e] : 0.f;
+                } else {
+                    int cnt = 0;
+                    for (int r = 0; r < kh; ++r) {
+                        if ((unsigned)(oy * stride + r - pad_t) >= (unsigned)ih) continue;
+                        for (int s = 0; s < kw; ++s) cnt += (unsigned)(ox * stride + s - pad_l) < (unsigned)iw;
+                    }
+                    const float rc = 1.f / (float)cnt;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) sum[e] += g[e] * rc;
+                }
+            }
+        }
+        float d[8];
+        load_v<T, VEC>(dx + pix * dx_ld + q * VEC, d);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[e] += sum[e];
+        store_v<T, VEC>(dx + pix * dx_ld + q * VEC, d);
+    }
+}
+
+// Backward of the fused view pooling + group fusion (view_pool_fuse_bwd_f32 in train.hip) with F and dF in the
+// storage type and dS in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void view_pool_fuse_bwd_lp(
+    const unsigned short* __restrict__ F, const float* __restrict__ dS, int V, int N, int64_t E, int64_t view_stride,
+    int64_t shape_stride, const int* __restrict__ scheme, int G, const float* __restrict__ weight, int mode,
+    unsigned short* __restrict__ dF, int64_t scheme_stride, int64_t weight_stride) {
+    __shared__ unsigned long long s_mask[64];
+    __shared__ float s_w[64];
+    __shared__ float s_wsum;
+    const int n = blockIdx.y;
+    scheme += (size_t)n * scheme_stride;
+    weight += (size_t)n * weight_stride;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        unsigned long long m = 0;
+        for (int v = 0; v < V; ++v)
+            if (scheme[g * V + v] != 0) m |= 1ull << v;
+        s_mask[g] = m;
+        s_w[g] = weight[g];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ws = 0.f;
+        for (int g = 0; g < G; ++g) ws += s_w[g];
+        s_wsum = ws;
+    }
+    __syncthreads();
+    if (s_wsum == 0.f) return;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
+        const size_t base = (size_t)n * shape_stride + e;
+        const float ds = dS[(size_t)n * E + e];
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long m0 = s_mask[g];
+            if (m0 == 0) continue;
+            const float coef = s_w[g] / s_wsum * ds;
+            if (mode == GV_VIEWPOOL_MEAN) {
+                const float each = coef / (float)__popcll(m0);
+                for (unsigned long long m = m0; m; m &= m - 1) {
+                    const size_t a = base + (size_t)(__ffsll((long long)m) - 1) * view_stride;
+                    dF[a] = down<T>(up<T>(dF[a]) + each);
+                }
+            } else {
+                float best = -INFINITY;
+                for (unsigned long long m = m0; m; m &= m - 1)
+                    best = fmaxf(best, up<T>(F[base + (size_t)(__ffsll((long long)m) - 1) * view_stride]));
+                int ties = 0;
+                for (unsigned long long m = m0; m; m &= m - 1)
+                    ties += up<T>(F[base + (size_t)(__ffsll((long long)m) - 1) * view_stride]) == best;
+                const float each = coef / (float)ties;
+                for (unsigned long long m = m0; m; m &= m - 1) {
+                    const size_t a = base + (size_t)(__ffsll((long long)m) - 1) * view_stride;
+                    if (up<T>(F[a]) == best) dF[a] = down<T>(up<T>(dF[a]) + each);
+                }
+            }
+        }
+    }
+}
+
+// ---- filter gradient on the 16-bit MFMA ----------------------------------------------------------------------------
+// dW[tap][ci][co] += sum_m X[shift_tap(m)][ci] * dZ[m][co].  One TN GEMM per filter tap; a workgroup owns a
+// (64*TI) x (64*TO) tile of one tap and a slice of the pixels (slices are combined with fp32 atomics), 2x2 waves of
+// TI x TO accumulators.  32 pixels per stage, LDS double buffered, the next stage's global loads are issued before
+// this stage's MFMAs, one barrier per stage.
+//   LDS rows = pixels, 2*B + 64 bytes apart: the four rows a transposed read touches per 16-lane group then start 16
+//   dwords apart (conflict-free), and the 16-byte writes of 8 consecutive lanes fill one row's 128 bytes.
+//   Operand of a 32-channel tile and 16 pixels k0..k0+15: lane l (channel c0 + l%32) needs pixels k0 + 8*(l/32) + 0..7 =
+//   two ds_read_b64_tr_b16; in each, lane 4q+p of a 16-lane group supplies row q, channels 4p..4p+3 of the group's
+//   16 channels.  Both operands use the same pixel order, so any consistent order is a valid k order.
+template <typename T>
+__device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
+    if constexpr (__is_same(T, __bf16))
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+template <typename T, int TI, int TO>
+__global__ __launch_bounds__(256) void conv_wgrad_lp(const unsigned short* __restrict__ x, int x_ld,
+                                                     const unsigned short* __restrict__ dz, int dz_ld, int nb, int ih,
+                                                     int iw, int cin, int kh, int kw, int stride, int pad_t,
+                                                     int pad_l, int oh, int ow, int cout, int64_t M,
+                                                     int64_t m_per_block, float* __restrict__ dw) {
+    constexpr int PT = 32, BI = 64 * TI, BO = 64 * TO;
+    constexpr int SX = 2 * BI + 64, SZ = 2 * BO + 64;                  // row strides in bytes
+    constexpr int XV = PT * BI / 8 / 256, ZV = PT * BO / 8 / 256;      // 16-byte loads per thread and stage
+    __shared__ __attribute__((aligned(16))) unsigned char sX[2][PT * SX];
+    __shared__ __attribute__((aligned(16))) unsigned char sZ[2][PT * SZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int ntile_co = (cout + BO - 1) / BO, ntile_ci = (cin + BI - 1) / BI;
+    int b = blockIdx.x;
+    const int tco = b % ntile_co; b /= ntile_co;
+    const int tci = b % ntile_ci; b /= ntile_ci;
+    const int tap = b;
+    const int fr = tap / kw, fs = tap - fr * kw;
+    const int ci0 = tci * BI, co0 = tco * BO;
+    const int64_t m0 = (int64_t)blockIdx.y * m_per_block;
+    const int64_t m1 = m0 + m_per_block < M ? m0 + m_per_block : M;
+    f32x16 acc[TI][TO];
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+#pragma unroll
+        for (int u = 0; u < TO; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    const int ohow = oh * ow;
+    u32x4 xr[XV], zr[ZV];
+    auto load = [&](int64_t mt) {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            const int idx = tid + j * 256;
+            const int p = idx / (BI / 8), c = ci0 + (idx % (BI / 8)) * 8;
+            const int64_t m = mt + p;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < m1 && c < cin) {
+                const int n = (int)(m / ohow);
+                const int rem = (int)(m - (int64_t)n * ohow);
+                const int oy = rem / ow, ox = rem - oy * ow;
+                const int iy = oy * stride + fr - pad_t, ix = ox * stride + fs - pad_l;
+                if ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw)
+                    v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * ih + iy) * iw + ix) * x_ld + c);
+            }
+            xr[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < ZV; ++j) {
+            const int idx = tid + j * 256;
+            const int p = idx / (BO / 8), c = co0 + (idx % (BO / 8)) * 8;
+            const int64_t m = mt + p;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < m1 && c < cout) v = *reinterpret_cast<const u32x4*>(dz + (size_t)m * dz_ld + c);
+            zr[j] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            const int idx = tid + j * 256;
+            *reinterpret_cast<u32x4*>(&sX[buf][(idx / (BI / 8)) * SX + (idx % (BI / 8)) * 16]) = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ZV; ++j) {
+            const int idx = tid + j * 256;
+            *reinterpret_cast<u32x4*>(&sZ[buf][(idx / (BO / 8)) * SZ + (idx % (BO / 8)) * 16]) = zr[j];
+        }
+    };
+    // transposed-read address of this lane inside a (16-pixel, 32-channel) operand block
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int row_l = 8 * (g16 >> 1) + q;                              // + 4*j for the second read
+    const int col_l = 16 * (g16 & 1) + 4 * p4;                         // channel within the 32-channel tile
+    const int xo = row_l * SX + 2 * ((wi * TI) * 32 + col_l);
+    const int zo = row_l * SZ + 2 * ((wj * TO) * 32 + col_l);
+    load(m0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t mt = m0; mt < m1; mt += PT) {
+        const bool more = mt + PT < m1;
+        if (more) load(mt + PT);
+#pragma unroll
+        for (int k = 0; k < PT; k += 16) {
+            s16x8 av[TI], bv[TO];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const unsigned char* pa = &sX[buf][xo + k * SX + t * 64];
+                const s16x4 lo = lds_read_tr(pa), hi = lds_read_tr(pa + 4 * SX);
+                av[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int u = 0; u < TO; ++u) {
+                const unsigned char* pb = &sZ[buf][zo + k * SZ + u * 64];
+                const s16x4 lo = lds_read_tr(pb), hi = lds_read_tr(pb + 4 * SZ);
+                bv[u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < TI; ++t)
+#pragma unroll
+                for (int u = 0; u < TO; ++u) acc[t][u] = mfma16<T>(av[t], bv[u], acc[t][u]);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < TO; ++u) {
+        const int col = co0 + (wj * TO + u) * 32 + li;
+        if (col >= cout) continue;
+#pragma unroll
+        for (int t = 0; t < TI; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (wi * TI + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci < cin) atomicAdd(&dw[((size_t)tap * cin + ci) * cout + col], acc[t][u][r]);
+            }
+    }
+}
+
+inline bool vec8(const void* p, int ld) { return p == nullptr || (gv_aligned16(p) && (ld % 8) == 0); }
+
+template <typename T>
+int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy, int dy_ld, const unsigned short* y,
+           int y_ld, const float* mean, const float* inv, int nb, int hw, int c, int G, int splits, double* acc,
+           hipStream_t st) {
+    const bool v = (c % 8 == 0) && vec8(z, z_ld) && vec8(dy, dy_ld) && vec8(y, y_ld);
+    const dim3 grid((c + 63) / 64, splits, G);
+#define GV_SUMS(MODE)                                                                                                \
+    do {                                                                                                             \
+        if (v)                                                                                                       \
+            hipLaunchKernelGGL((grouped_sums_lp<T, MODE, 8>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, \
+                               inv, nb, hw, c, G, acc);                                                              \
+        else                                                                                                         \
+            hipLaunchKernelGGL((grouped_sums_lp<T, MODE, 1>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, \
+                               inv, nb, hw, c, G, acc);                                                              \
+    } while (0)
+    if (mode == 0) GV_SUMS(0);
+    else if (mode == 1) GV_SUMS(1);
+    else GV_SUMS(2);
+#undef GV_SUMS
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
+int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+            hipStream_t st) {
+    const int64_t M = (int64_t)d->nb * d->oh * d->ow;
+    const int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
+    const int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
+    const int tiles = d->kh * d->kw * ((d->cin + 64 * ti - 1) / (64 * ti)) * ((d->cout + 64 * to - 1) / (64 * to));
+    int64_t splits = (2048 + tiles - 1) / tiles;
+    const int64_t max_splits = (M + 1023) / 1024;                // at least 1024 pixels per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    int64_t per = (M + splits - 1) / splits;
+    per = (per + 31) / 32 * 32;
+    splits = (M + per - 1) / per;
+    const dim3 grid((unsigned)tiles, (unsigned)splits);
+#define GV_WGRAD_LP(TI, TO)                                                                                          \
+    hipLaunchKernelGGL((conv_wgrad_lp<T, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih, d->iw, \
+                       d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, dw)
+    if (ti == 2 && to == 2) GV_WGRAD_LP(2, 2);
+    else if (ti == 2) GV_WGRAD_LP(2, 1);
+    else if (to == 2) GV_WGRAD_LP(1, 2);
+    else GV_WGRAD_LP(1, 1);
+#undef GV_WGRAD_LP
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+}  // namespace
+
+namespace gvlp {
+
+#define GV_LP_DISPATCH(dtype, CALL)                       \
+    do {                                                  \
+        if ((dtype) == GV_BF16) { using T = __bf16; CALL; }   \
+        if ((dtype) == GV_F16) { using T = _Float16; CALL; }  \
+        return GV_E_UNSUPPORTED;                          \
+    } while (0)
+
+int accumulate(int dtype, const void* src, int src_ld, void* dst, int dst_ld, int64_t npix, int c, hipStream_t st) {
+    const unsigned short* s = (const unsigned short*)src;
+    unsigned short* d = (unsigned short*)dst;
+    const bool v = (c % 8 == 0) && vec8(s, src_ld) && vec8(d, dst_ld);
+    GV_LP_DISPATCH(dtype, {
+        if (v)
+            hipLaunchKernelGGL((accumulate_lp<T, 8>), dim3(grid_for(npix * (c / 8))), dim3(256), 0, st, s, src_ld, d,
+                               dst_ld, npix, c);
+        else
+            hipLaunchKernelGGL((accumulate_lp<T, 1>), dim3(grid_for(npix * c)), dim3(256), 0, st, s, src_ld, d, dst_ld,
+                               npix, c);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    });
+}
+
+int grouped_sums(int dtype, int mode, const void* z, int z_ld, const void* dy, int dy_ld, const void* y, int y_ld,
+                 const float* mean, const float* inv, int nb, int hw, int c, int G, int splits, double* acc,
+                 hipStream_t st) {
+    GV_LP_DISPATCH(dtype, return sums_t<T>(mode, (const unsigned short*)z, z_ld, (const unsigned short*)dy, dy_ld,
+                                           (const unsigned short*)y, y_ld, mean, inv, nb, hw, c, G, splits, acc, st));
+}
+
+int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int x_ld, const float* scale,
+                            const float* shift, int G, int relu, void* y, int y_ld, hipStream_t st) {
+    const unsigned short* xs = (const unsigned short*)x;
+    unsigned short* ys = (unsigned short*)y;
+    const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld);
+    GV_LP_DISPATCH(dtype, {
+        if (v)
+            hipLaunchKernelGGL((scale_shift_act_grouped_lp<T, 8>), dim3(grid_for((int64_t)nb * hw * (c / 8))), dim3(256),
+                               0, st, xs, nb, hw, c, x_ld, scale, shift, G, relu, ys, y_ld);
+        else
+            hipLaunchKernelGGL((scale_shift_act_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st,
+                               xs, nb, hw, c, x_ld, scale, shift, G, relu, ys, y_ld);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    });
+}
+
+int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, const void* z, int z_ld,
+                         const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
+                         int nb, int hw, int c, int G, void* dz, int dz_ld, hipStream_t st) {
+    const unsigned short* a = (const unsigned short*)dy;
+    const unsigned short* b = (const unsigned short*)y;
+    const unsigned short* zz = (const unsigned short*)z;
+    unsigned short* o = (unsigned short*)dz;
+    const bool v = (c % 8 == 0) && vec8(a, dy_ld) && vec8(b, y_ld) && vec8(zz, z_ld) && vec8(o, dz_ld);
+    GV_LP_DISPATCH(dtype, {
+        if (v)
+            hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 8>), dim3(grid_for((int64_t)nb * hw * (c / 8))), dim3(256), 0,
+                               st, a, dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, o, dz_ld);
+        else
+            hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, a,
+                               dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, o, dz_ld);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    });
+}
+
+int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, void* dx, int dx_ld, hipStream_t st) {
+    const unsigned short* xs = (const unsigned short*)x;
+    const unsigned short* g = (const unsigned short*)dy;
+    unsigned short* o = (unsigned short*)dx;
+    const bool v = (d->c % 8 == 0) && vec8(xs, d->x_ld) && vec8(g, dy_ld) && vec8(o, dx_ld);
+    const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
+    GV_LP_DISPATCH(d->dtype, {
+        if (v)
+            hipLaunchKernelGGL((pool2d_bwd_lp<T, 8>), dim3(grid_for(npix * (d->c / 8))), dim3(256), 0, st, xs, d->x_ld, g,
+                               dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh,
+                               d->ow, d->mode, o, dx_ld);
+        else
+            hipLaunchKernelGGL((pool2d_bwd_lp<T, 1>), dim3(grid_for(npix * d->c)), dim3(256), 0, st, xs, d->x_ld, g, dy_ld,
+                               d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow,
+                               d->mode, o, dx_ld);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    });
+}
+
+int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,
+                       const int* scheme, int G, const float* weight, int mode, void* dF, hipStream_t st,
+                       int64_t scheme_stride, int64_t weight_stride) {
+    int64_t bx = (E + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const dim3 grid((unsigned)bx, (unsigned)N);
+    GV_LP_DISPATCH(dtype, {
+        hipLaunchKernelGGL(view_pool_fuse_bwd_lp<T>, grid, dim3(256), 0, st, (const unsigned short*)F, dS, V, N, E, vs, ss,
+                           scheme, G, weight, mode, (unsigned short*)dF, scheme_stride, weight_stride);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    });
+}
+
+bool wgrad_mfma_ok(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld) {
+    return d->cin % 8 == 0 && d->cout % 8 == 0 && d->x_ld % 8 == 0 && dz_ld % 8 == 0 && gv_aligned16(x) &&
+           gv_aligned16(dz);
+}
+
+int conv_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st) {
+    GV_LP_DISPATCH(d->dtype, return wgrad_t<T>(d, (const unsigned short*)x, (const unsigned short*)dz, dz_ld, dw, st));
+}
+
+}  // namespace gvlp

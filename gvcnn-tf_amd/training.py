@@ -30,8 +30,8 @@ from .model import _st, _dev, _raise_for_status
 class TrainPlan(backbones.BackbonePlan):
     """Symbolic op list for training: un-fused, nothing recycled."""
 
-    def __init__(self, nb, height, width, math_mode):
-        super().__init__(nb, height, width, _lib.GV_F32, math_mode)
+    def __init__(self, nb, height, width, math_mode, dtype=_lib.GV_F32):
+        super().__init__(nb, height, width, dtype, math_mode)
         self.use_lanes = False
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
@@ -113,12 +113,18 @@ class TrainGVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=2, num_views=6, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2,
-                 head_views=None, view_offset=0, per_shape=False, weight_mode="count"):
+                 head_views=None, view_offset=0, per_shape=False, weight_mode="count", storage="f32"):
         """head_views / view_offset: view-sharded data parallelism (sharding.ShardedTrainGVCNN) — this engine
         runs the backbone for views [view_offset, view_offset + num_views) of the head_views views of every shape
         (so each view's BatchNorm statistics stay on one rank, exactly the reference's per-view statistics),
         while the grouping head works on all head_views views."""
         self.lib = _lib.load()
+        # storage: element type of activations and activation gradients in HBM.  "bf16" is BASELINE configs[2]
+        # (bf16 forward + backward): 16-bit MFMA convolutions (forward, data and filter gradient), fp32 master
+        # weights / parameter gradients / optimizer state, fp64 batch statistics.
+        self.dt = backbones.DTYPES[storage]
+        self.tdt = backbones.TORCH_DTYPES[self.dt]
+        self.es = 4 if self.dt == _lib.GV_F32 else 2
         # per_shape: the paper's grouping (model.GVCNN(per_shape=True), DESIGN §3c) in the training step
         self.per_shape = bool(per_shape)
         self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
@@ -139,7 +145,7 @@ class TrainGVCNN:
         if self.math_mode == _lib.GV_MATH_F32:
             raise ValueError("training uses the bf16-plane convolution kernels (math='bf16x3')")
         nb = num_shapes * num_views
-        p = TrainPlan(nb, height, width, self.math_mode)
+        p = TrainPlan(nb, height, width, self.math_mode, self.dt)
         raw_tap = raw_tap or backbones.TAPS[backbone][0]
         final_tap = final_tap or backbones.TAPS[backbone][1]
         if backbone == "inception_v3":
@@ -150,7 +156,7 @@ class TrainGVCNN:
         self.raw, self.final = p.end_points[raw_tap], p.end_points[final_tap]
         f32 = torch.float32
         with torch.cuda.device(dev):
-            self.act = [torch.empty(n, dtype=f32, device=dev) for n, _ in p.vbufs]
+            self.act = [torch.empty((n + 7) // 8 * 8, dtype=self.tdt, device=dev) for n, _ in p.vbufs]
             self.grad = [None] * len(p.vbufs)
             shapes = p.param_shapes()
             if backbone_params is None:
@@ -190,10 +196,10 @@ class TrainGVCNN:
                 elif op["kind"] == "conv":
                     w = self.params[op["name"] + "/weights"]
                     kh, kw, cin, cout = w.shape
-                    nf = self.lib.gv_packed_filter_bytes(kh, kw, cin, cout, _lib.GV_F32, self.math_mode) // 4
-                    nd = self.lib.gv_packed_filter_bytes(kh, kw, cout, cin, _lib.GV_F32, self.math_mode) // 4
-                    op["w_fwd"] = torch.empty(nf, dtype=f32, device=dev)
-                    op["w_dgrad"] = torch.empty(nd, dtype=f32, device=dev) if op["x"].vbuf >= 0 else None
+                    nf = self.lib.gv_packed_filter_bytes(kh, kw, cin, cout, self.dt, self.math_mode)
+                    nd = self.lib.gv_packed_filter_bytes(kh, kw, cout, cin, self.dt, self.math_mode)
+                    op["w_fwd"] = torch.empty(nf, dtype=torch.uint8, device=dev)
+                    op["w_dgrad"] = torch.empty(nd, dtype=torch.uint8, device=dev) if op["x"].vbuf >= 0 else None
             nbv = nb
             self.r_img = torch.empty(nbv, dtype=f32, device=dev)
             self.scores = torch.empty(self.Vh, dtype=f32, device=dev)
@@ -207,8 +213,8 @@ class TrainGVCNN:
                 self.scheme_ps = torch.empty((num_shapes, num_group, self.Vh), dtype=torch.int32, device=dev)
                 self.weight_ps = torch.empty((num_shapes, num_group), dtype=f32, device=dev)
             f = self.final
-            self.S = torch.empty((num_shapes, f.h, f.w, f.c), dtype=f32, device=dev)
-            self.dS = torch.empty_like(self.S)
+            self.S = torch.empty((num_shapes, f.h, f.w, f.c), dtype=self.tdt, device=dev)
+            self.dS = torch.empty((num_shapes, f.h, f.w, f.c), dtype=f32, device=dev)
             self.gap = torch.empty((num_shapes, f.c), dtype=f32, device=dev)
             self.dgap = torch.empty_like(self.gap)
             self.logits = torch.empty((num_shapes, num_classes), dtype=f32, device=dev)
@@ -220,12 +226,12 @@ class TrainGVCNN:
     def _ptr(self, t, grad=False):
         if t.vbuf < 0:
             assert not grad
-            return self._x.data_ptr() + 4 * t.off
+            return self._x.data_ptr() + self.es * t.off
         if grad:
             if self.grad[t.vbuf] is None:
                 self.grad[t.vbuf] = torch.zeros_like(self.act[t.vbuf])
-            return self.grad[t.vbuf].data_ptr() + 4 * t.off
-        return self.act[t.vbuf].data_ptr() + 4 * t.off
+            return self.grad[t.vbuf].data_ptr() + self.es * t.off
+        return self.act[t.vbuf].data_ptr() + self.es * t.off
 
     def view(self, t, grad=False):
         base = self.grad[t.vbuf] if grad else self.act[t.vbuf]
@@ -243,10 +249,10 @@ class TrainGVCNN:
         if not dgrad:
             return _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"], op["pad_t"],
                                  op["pad_l"], y.h, y.w, y.c, y.ld, op["res"].ld if op["res"] is not None else 0,
-                                 0, 0, _lib.GV_F32, 0, op.get("tile_f", 0), self.math_mode, 0)
+                                 0, 0, self.dt, 0, op.get("tile_f", 0), self.math_mode, 0)
         # data gradient: dX = conv(dilate(dZ, stride), flip(W)^T), pad' = k-1-pad, accumulate into dX
         return _lib.ConvDesc(y.nb, y.h, y.w, y.c, y.ld, op["kh"], op["kw"], 1, op["kh"] - 1 - op["pad_t"],
-                             op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, _lib.GV_F32, 0,
+                             op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, self.dt, 0,
                              op.get("tile_d", 0), self.math_mode, op["stride"] if op["stride"] > 1 else 0)
 
     def autotune(self, iters=2):
@@ -256,7 +262,7 @@ class TrainGVCNN:
         lib = self.lib
         if self._packed_dirty:
             self.repack()
-        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode)
+        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dt == _lib.GV_F32 else -1)
         ms = C.c_float(0)
         for op in self.plan.ops:
             if op["kind"] != "conv":
@@ -288,12 +294,12 @@ class TrainGVCNN:
             w = self.params[op["name"] + "/weights"]
             kh, kw, cin, cout = w.shape
             _lib.check(lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout, op["w_fwd"].data_ptr(),
-                                               _lib.GV_F32, self.math_mode, _st()), "gv_pack_filter_hwio")
+                                               self.dt, self.math_mode, _st()), "gv_pack_filter_hwio")
             if op["w_dgrad"] is not None:
                 wt = torch.flip(w, (0, 1)).permute(0, 1, 3, 2).contiguous()      # [kh,kw,cout,cin]
                 keep.append(wt)
                 _lib.check(lib.gv_pack_filter_hwio(wt.data_ptr(), kh, kw, cout, cin, op["w_dgrad"].data_ptr(),
-                                                   _lib.GV_F32, self.math_mode, _st()), "gv_pack_filter_hwio")
+                                                   self.dt, self.math_mode, _st()), "gv_pack_filter_hwio")
         torch.cuda.synchronize(self.device)
         self._packed_dirty = False
 
@@ -309,7 +315,7 @@ class TrainGVCNN:
         """Train-mode backbone over this engine's views (partial_run #1 without the scorer)."""
         lib = self.lib
         assert tuple(views.shape) == (self.N, self.V, self.H, self.W, 3) and views.is_cuda
-        self._x = views.to(torch.float32).contiguous()
+        self._x = views.to(self.tdt).contiguous()
         if self._packed_dirty:
             self.repack()
         V = self.V
@@ -327,29 +333,22 @@ class TrainGVCNN:
                 gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
                 beta = self.params[op["name"] + "/beta"]
                 hw = x.h * x.w
-                if self.bn_sync is None:
-                    _lib.check(lib.gv_bn_stats_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, V, self._count(hw).data_ptr(),
-                                                       gamma.data_ptr() if gamma is not None else None, beta.data_ptr(),
-                                                       float(op["eps"]), self.accum.data_ptr(), st["mean"].data_ptr(),
-                                                       st["var"].data_ptr(), st["inv"].data_ptr(),
-                                                       st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
-                               "bn stats " + op["name"])
-                else:                                         # shape-sharded: reduce the sums over the ranks first
-                    _lib.check(lib.gv_bn_sums_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, V, self.accum.data_ptr(),
-                                                      _st()), "bn sums " + op["name"])
+                _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, self.accum.data_ptr(), self.dt,
+                                                    _st()), "bn sums " + op["name"])
+                if self.bn_sync is not None:                  # shape-sharded: reduce the sums over the ranks first
                     self.bn_sync(self.accum[:2 * V * x.c])
-                    _lib.check(lib.gv_bn_finalize_grouped(self.accum.data_ptr(), x.c, V, self._count(hw).data_ptr(),
-                                                          gamma.data_ptr() if gamma is not None else None,
-                                                          beta.data_ptr(), float(op["eps"]), st["mean"].data_ptr(),
-                                                          st["var"].data_ptr(), st["inv"].data_ptr(),
-                                                          st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
-                               "bn finalize " + op["name"])
-                _lib.check(lib.gv_scale_shift_act_grouped(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
-                                                          st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
-                                                          y.ld, _st()), "bn apply " + op["name"])
+                _lib.check(lib.gv_bn_finalize_grouped(self.accum.data_ptr(), x.c, V, self._count(hw).data_ptr(),
+                                                      gamma.data_ptr() if gamma is not None else None,
+                                                      beta.data_ptr(), float(op["eps"]), st["mean"].data_ptr(),
+                                                      st["var"].data_ptr(), st["inv"].data_ptr(),
+                                                      st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
+                           "bn finalize " + op["name"])
+                _lib.check(lib.gv_scale_shift_act_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
+                                                            st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
+                                                            y.ld, self.dt, _st()), "bn apply " + op["name"])
             else:
                 d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
-                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], _lib.GV_F32)
+                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
                 _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
 
     def score_partial(self):
@@ -358,7 +357,7 @@ class TrainGVCNN:
         r = self.raw
         _lib.check(self.lib.gv_view_score_partial(self._ptr(r), r.nb, r.h * r.w, r.c, r.ld,
                                                   self.score_kernel.data_ptr(), self.score_bias.data_ptr(), self.V,
-                                                  _lib.GV_ORDER_SHAPE_MAJOR, self.r_img.data_ptr(), _lib.GV_F32,
+                                                  _lib.GV_ORDER_SHAPE_MAJOR, self.r_img.data_ptr(), self.dt,
                                                   _st()), "score")
         return self.r_img
 
@@ -388,7 +387,7 @@ class TrainGVCNN:
                     _raise_for_status(st_, self.gidx_ps.reshape(-1), self.G)
             _lib.check(lib.gv_view_pool_fuse_fwd_per_shape(F_ptr, V, self.N, E, E, V * E, self.scheme_ps.data_ptr(),
                                                            self.G, self.weight_ps.data_ptr(), self.pool_mode,
-                                                           self.empty_fill, None, self.S.data_ptr(), _lib.GV_F32,
+                                                           self.empty_fill, None, self.S.data_ptr(), self.dt,
                                                            _st()), "pool_fuse per shape")
             return self._classify_and_loss(labels, self.scores_ps)
         if not scores_ready:                              # (shape-sharded jobs finalise the scores over the global batch)
@@ -405,13 +404,13 @@ class TrainGVCNN:
             self.weight.copy_(torch.as_tensor(np.asarray(g_weight), dtype=torch.float32))
         _lib.check(lib.gv_view_pool_fuse_fwd(F_ptr, V, self.N, E, E, V * E, self.scheme.data_ptr(), self.G,
                                              self.weight.data_ptr(), self.pool_mode, self.empty_fill, None,
-                                             self.S.data_ptr(), _lib.GV_F32, _st()), "pool_fuse")
+                                             self.S.data_ptr(), self.dt, _st()), "pool_fuse")
         return self._classify_and_loss(labels, self.scores)
 
     def _classify_and_loss(self, labels, scores):
         lib, f = self.lib, self.final
         _lib.check(lib.gv_global_avg_pool(self.S.data_ptr(), self.N, f.h * f.w, f.c, f.c, self.gap.data_ptr(),
-                                          _lib.GV_F32, _st()), "gap")
+                                          self.dt, _st()), "gap")
         kn, bn = self.cls_names
         _lib.check(lib.gv_dense_fwd(self.gap.data_ptr(), self.N, f.c, self.params[kn].data_ptr(),
                                     self.params[bn].data_ptr(), self.num_classes, self.logits.data_ptr(), _st()),
@@ -451,14 +450,10 @@ class TrainGVCNN:
                                               _st()), "gap_bwd")
         F_ptr = self._ptr(f) if self._F is None else self._F.data_ptr()
         dF_ptr = self._ptr(f, grad=True) if dF is None else dF.data_ptr()
-        if self.per_shape:
-            _lib.check(lib.gv_view_pool_fuse_bwd_per_shape(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E,
-                                                           self.scheme_ps.data_ptr(), self.G, self.weight_ps.data_ptr(),
-                                                           self.pool_mode, dF_ptr, _st()), "pool_fuse_bwd per shape")
-        else:
-            _lib.check(lib.gv_view_pool_fuse_bwd(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E,
-                                                 self.scheme.data_ptr(), self.G, self.weight.data_ptr(), self.pool_mode,
-                                                 dF_ptr, _st()), "pool_fuse_bwd")
+        scheme, weight = (self.scheme_ps, self.weight_ps) if self.per_shape else (self.scheme, self.weight)
+        _lib.check(lib.gv_view_pool_fuse_bwd_t(F_ptr, self.dS.data_ptr(), V, self.N, E, E, V * E, scheme.data_ptr(),
+                                               self.G, weight.data_ptr(), self.pool_mode, dF_ptr, int(self.per_shape),
+                                               self.dt, _st()), "pool_fuse_bwd")
 
     def final_grad(self):
         """[N, V, h, w, C] view of the gradient buffer of the final tap (allocated on first use)."""
@@ -480,30 +475,26 @@ class TrainGVCNN:
                 dbeta = self.grads[op["name"] + "/beta"].data_ptr()
                 dgamma = self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None
                 yptr = self._ptr(y) if op["relu"] else None
-                if self.bn_sync is None:
-                    _lib.check(lib.gv_bn_relu_bwd_grouped(
-                        self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                        st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
-                        self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
-                        dbeta, dgamma, _st()), "bn_bwd " + op["name"])
-                else:
-                    _lib.check(lib.gv_bn_relu_bwd_sums_grouped(
-                        self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                        st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), _st()), "bn_bwd sums " + op["name"])
+                _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
+                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                    st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self.dt, _st()),
+                    "bn_bwd sums " + op["name"])
+                if self.bn_sync is not None:
                     self.bn_sync(self.accum[:2 * V * x.c])
-                    _lib.check(lib.gv_bn_relu_bwd_apply_grouped(
-                        self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                        st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
-                        self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
-                        dbeta, dgamma, _st()), "bn_bwd apply " + op["name"])
+                _lib.check(lib.gv_bn_relu_bwd_apply_grouped_t(
+                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                    st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                    self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
+                    dbeta, dgamma, self.dt, _st()), "bn_bwd apply " + op["name"])
             elif op["kind"] == "conv":
                 dz = self._ptr(y, True)
                 if op["bias"]:
-                    _lib.check(lib.gv_bias_grad(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
-                                                self.grads[op["bias"]].data_ptr(), _st()), "bias_grad")
+                    _lib.check(lib.gv_bias_grad_t(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
+                                                  self.grads[op["bias"]].data_ptr(), self.dt, _st()), "bias_grad")
                 if op["res"] is not None:
                     r = op["res"]
-                    _lib.check(lib.gv_accumulate(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, _st()), "res grad")
+                    _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
+                               "res grad")
                 d = self._conv_desc(op)
                 _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld,
                                                self.grads[op["name"] + "/weights"].data_ptr(), _st()),
@@ -516,7 +507,7 @@ class TrainGVCNN:
                                "dgrad " + op["name"])
             else:
                 d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
-                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], _lib.GV_F32)
+                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
                 _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
                                              x.ld, _st()), "pool_bwd " + op["name"])
         return self.grads

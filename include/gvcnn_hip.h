@@ -300,12 +300,13 @@ int gv_accumulate(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, 
 /* dbias[c] += sum over pixels of dz (bias-only convolutions, nets/resnet_v2.py:79-89,178-180). */
 int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum, float* dbias,
                  void* stream);
-/* dW_hwio[r,s,ci,co] += sum_pixels x[shifted pixel, ci] * dz[pixel, co]  (descriptor of the FORWARD conv). */
-int gv_conv2d_wgrad(const gv_conv_desc* d, const float* x, const float* dz, int32_t dz_ld, float* dw_hwio,
+/* dW_hwio[r,s,ci,co] += sum_pixels x[shifted pixel, ci] * dz[pixel, co]  (descriptor of the FORWARD conv).
+ * x and dz in d->dtype (GV_F32: exact fp32 MFMA; GV_BF16 / GV_F16: 16-bit MFMA, fp32 accumulation); dW is fp32. */
+int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld, float* dw_hwio,
                     void* stream);
 /* Pool backward (descriptor of the forward pool): max -> first maximum of each window (tf MaxPoolGrad),
- * avg -> dy / #valid taps.  x is the forward input (max only). */
-int gv_pool2d_bwd(const gv_pool_desc* d, const float* x, const float* dy, int32_t dy_ld, float* dx,
+ * avg -> dy / #valid taps.  x is the forward input (max only).  x, dy, dx in d->dtype. */
+int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t dy_ld, void* dx,
                   int32_t dx_ld, void* stream);
 /* Backward of gv_view_pool_fuse_fwd: dF += ... (tf.reduce_max splits equally among ties). */
 int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
@@ -327,6 +328,36 @@ int gv_dense_bwd(const float* x, const float* dy, const float* kernel, int32_t n
 /* tf.train.MomentumOptimizer(lr, mu) with the slim L2 term: m = mu*m + (g + wd*w); w -= lr*m. */
 int gv_sgd_momentum(float* w, const float* g, float* m, int64_t n, float lr, float mu, float wd,
                     void* stream);
+
+/* ---- the training step on 16-bit storage (configs[2]: bf16 forward + backward) --------------------------
+ * Storage-typed forms of the functions above: activations and activation gradients (z, y, dy, dz, F, dF, src, dst)
+ * are `dtype` elements (GV_BF16 / GV_F16; GV_F32 forwards to the fp32 function), arithmetic is fp32 with one
+ * rounding per stored element, batch statistics accumulate in fp64, parameter gradients (dbeta, dgamma, dbias, dW),
+ * dS and the optimizer state stay fp32.  gv_conv2d_fwd (forward and data gradient), gv_conv2d_wgrad,
+ * gv_pool2d_fwd/_bwd, gv_global_avg_pool, gv_view_score_partial and gv_view_pool_fuse_fwd take the storage type
+ * from their descriptor / dtype argument. */
+int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld, int32_t num_groups,
+                         double* accum, int32_t dtype, void* stream);
+int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld, const float* scale,
+                                 const float* shift, int32_t num_groups, int32_t relu, void* y, int32_t y_ld,
+                                 int32_t dtype, void* stream);
+int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld, const void* z,
+                                  int32_t z_ld, const float* mean, const float* inv, int32_t nb, int32_t hw,
+                                  int32_t c, int32_t num_groups, double* accum, int32_t dtype, void* stream);
+int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld, const void* z,
+                                   int32_t z_ld, const float* mean, const float* inv, const float* gamma,
+                                   const int32_t* counts, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
+                                   const double* accum, void* dz, int32_t dz_ld, float* dbeta, float* dgamma,
+                                   int32_t dtype, void* stream);
+int gv_accumulate_t(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                    int32_t dtype, void* stream);
+int gv_bias_grad_t(const void* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum, float* dbias,
+                   int32_t dtype, void* stream);
+/* gv_view_pool_fuse_bwd (per_shape = 0) / gv_view_pool_fuse_bwd_per_shape (per_shape = 1) with F, dF in `dtype`. */
+int gv_view_pool_fuse_bwd_t(const void* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
+                            int64_t view_stride, int64_t shape_stride, const int32_t* scheme, int32_t num_groups,
+                            const float* weight, int32_t mode, void* dF, int32_t per_shape, int32_t dtype,
+                            void* stream);
 
 /* ---- plan: the per-view backbone as one native launch sequence -------------
  * A plan is an ordered list of the ops above whose operands are (slot, element offset)

@@ -1,0 +1,304 @@
+"""Training step on 16-bit storage (BASELINE configs[2]: bf16 forward + backward; csrc/train_lp.hip).
+
+Every storage-typed kernel is checked against torch autograd through the CPU oracle's ops ON THE SAME 16-bit
+representable inputs, so the only differences are the summation order (filter gradient, statistics) and the single
+rounding of each stored output (tolerance 2^-8 relative for bf16 outputs, 2^-11 for fp16).  The whole step is then
+held against the fp32 engine (itself pinned to the oracle in test_gpu_train.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvcnn_tf_amd as gv                          # noqa: E402
+from gvcnn_tf_amd import _lib                       # noqa: E402
+from gvcnn_tf_amd.training import TrainGVCNN        # noqa: E402
+from oracle import backbone as OB                   # noqa: E402
+
+DEV = "cuda:0"
+TYPES = [(_lib.GV_BF16, torch.bfloat16, 2.0 ** -8), (_lib.GV_F16, torch.float16, 2.0 ** -11)]
+
+
+def lib():
+    return _lib.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def close(a, d, tol):
+    a, d = np.asarray(a, dtype=np.float64), np.asarray(d, dtype=np.float64)
+    scale = max(float(np.abs(d).max()), 1e-30)
+    err = float(np.abs(a - d).max())
+    assert err <= tol * scale, "max|diff| %.3e vs scale %.3e (%.2e rel)" % (err, scale, err / scale)
+
+
+def q(t, tdt):
+    """fp32 tensor with values representable in the storage type."""
+    return t.to(tdt).to(torch.float32)
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("c,ld", [(32, 32), (40, 48), (12, 12)])
+def test_bn_train_forward_and_backward_typed(dt, tdt, eps, c, ld):
+    g = torch.Generator().manual_seed(0)
+    N, V, h, w = 3, 4, 5, 6
+    z = q(torch.randn(N * V, h, w, c, generator=g) * 2 + 0.5, tdt)
+    beta, gamma = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    dy = q(torch.randn(N * V, h, w, c, generator=g), tdt)
+    groups = [b % V for b in range(N * V)]
+
+    def dev(t):                                         # [.., c] -> device tensor with pixel stride ld
+        buf = torch.zeros(*t.shape[:-1], ld, dtype=tdt, device=DEV)
+        buf[..., :c] = t.to(tdt).to(DEV)
+        return buf
+
+    for gm in (None, gamma):
+        zz = z.clone().requires_grad_(True)
+        be = beta.clone().requires_grad_(True)
+        ga = gm.clone().requires_grad_(True) if gm is not None else None
+        y_ref, mean_ref, var_ref = OB.batch_norm_train_grouped(zz, be, ga, 1e-3, groups)
+        y_ref = torch.relu(y_ref)
+        zd = dev(z)
+        counts = torch.full((V,), N * h * w, dtype=torch.int32, device=DEV)
+        accum = torch.zeros(2 * V * c, dtype=torch.float64, device=DEV)
+        stt = {k: torch.empty(V, c, device=DEV) for k in ("mean", "var", "inv", "scale", "shift")}
+        bd, gd = beta.to(DEV), (gm.to(DEV) if gm is not None else None)
+        _lib.check(lib().gv_bn_sums_grouped_t(zd.data_ptr(), N * V, h * w, c, ld, V, accum.data_ptr(), dt, st()), "sums")
+        _lib.check(lib().gv_bn_finalize_grouped(accum.data_ptr(), c, V, counts.data_ptr(),
+                                                gd.data_ptr() if gd is not None else None, bd.data_ptr(), 1e-3,
+                                                stt["mean"].data_ptr(), stt["var"].data_ptr(), stt["inv"].data_ptr(),
+                                                stt["scale"].data_ptr(), stt["shift"].data_ptr(), st()), "finalize")
+        yd = torch.zeros_like(zd)
+        _lib.check(lib().gv_scale_shift_act_grouped_t(zd.data_ptr(), N * V, h * w, c, ld, stt["scale"].data_ptr(),
+                                                      stt["shift"].data_ptr(), V, 1, yd.data_ptr(), ld, dt, st()),
+                   "apply")
+        close(stt["mean"].cpu(), mean_ref.detach(), 1e-5)
+        close(stt["var"].cpu(), var_ref.detach(), 1e-5)
+        close(yd[..., :c].float().cpu(), y_ref.detach(), eps)
+        assert float(yd[..., c:].float().abs().max()) == 0.0 if ld > c else True
+        # backward from the ROUNDED y (its ReLU mask is what the kernel sees): take the reference mask from it too
+        mask = (yd[..., :c].float().cpu() > 0).float()
+        y_lin, _, _ = OB.batch_norm_train_grouped(zz, be, ga, 1e-3, groups)
+        (y_lin * mask).backward(dy)
+        dyd = dev(dy)
+        dz = dev(q(torch.full_like(z, 0.125), tdt))     # pre-existing gradient: accumulated into
+        dbeta = torch.zeros(c, device=DEV)
+        dgamma = torch.zeros(c, device=DEV)
+        _lib.check(lib().gv_bn_relu_bwd_sums_grouped_t(dyd.data_ptr(), ld, yd.data_ptr(), ld, zd.data_ptr(), ld,
+                                                       stt["mean"].data_ptr(), stt["inv"].data_ptr(), N * V, h * w, c,
+                                                       V, accum.data_ptr(), dt, st()), "bwd sums")
+        _lib.check(lib().gv_bn_relu_bwd_apply_grouped_t(dyd.data_ptr(), ld, yd.data_ptr(), ld, zd.data_ptr(), ld,
+                                                        stt["mean"].data_ptr(), stt["inv"].data_ptr(),
+                                                        gd.data_ptr() if gd is not None else None, counts.data_ptr(),
+                                                        N * V, h * w, c, V, accum.data_ptr(), dz.data_ptr(), ld,
+                                                        dbeta.data_ptr(),
+                                                        dgamma.data_ptr() if gd is not None else None, dt, st()),
+                   "bwd apply")
+        close(dz[..., :c].float().cpu() - 0.125, zz.grad, 2 * eps)
+        close(dbeta.cpu(), be.grad, 1e-5)
+        if gm is not None:
+            close(dgamma.cpu(), ga.grad, 1e-4)
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("k,stride,padding,mode", [(3, 2, "VALID", "max"), (3, 2, "SAME", "max"),
+                                                    (3, 1, "SAME", "avg"), (1, 2, "VALID", "max"),
+                                                    (3, 1, "SAME", "max")])
+@pytest.mark.parametrize("c", [16, 12])
+def test_pool_backward_typed(dt, tdt, eps, k, stride, padding, mode, c):
+    g = torch.Generator().manual_seed(1)
+    x = q(torch.randn(2, 9, 8, c, generator=g), tdt)
+    x[0, 2:5, 2:5, :] = 0.5                              # ties: the first maximum in scan order takes the gradient
+    x = x.requires_grad_(True)
+    y = OB.max_pool2d(x, k, stride, padding) if mode == "max" else OB.avg_pool2d_same3(x)
+    dy = q(torch.randn(*y.shape, generator=g), tdt)
+    y.backward(dy)
+    pt = OB.same_pads(9, k, stride)[0] if padding == "SAME" else 0
+    pl = OB.same_pads(8, k, stride)[0] if padding == "SAME" else 0
+    d = _lib.PoolDesc(2, 9, 8, c, c, k, k, stride, pt, pl, y.shape[1], y.shape[2], c,
+                      _lib.GV_POOL_MAX if mode == "max" else _lib.GV_POOL_AVG, dt)
+    xd, dyd = x.detach().to(tdt).to(DEV), dy.to(tdt).to(DEV)
+    dx = torch.full_like(xd, 0.25)
+    _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dyd.data_ptr(), c, dx.data_ptr(), c, st()), "pool_bwd")
+    # the fp32 kernel on the same inputs picks the same winners (ties included)
+    d32 = _lib.PoolDesc(2, 9, 8, c, c, k, k, stride, pt, pl, y.shape[1], y.shape[2], c,
+                        _lib.GV_POOL_MAX if mode == "max" else _lib.GV_POOL_AVG, _lib.GV_F32)
+    x32, dy32 = x.detach().to(DEV), dy.to(DEV)
+    dx32 = torch.zeros_like(x32)
+    _lib.check(lib().gv_pool2d_bwd(C.byref(d32), x32.data_ptr(), dy32.data_ptr(), c, dx32.data_ptr(), c, st()), "pool_bwd")
+    close(dx.float().cpu() - 0.25, dx32.cpu(), 2 * eps)
+    if mode == "avg" or (k, stride) != (3, 1):
+        close(dx32.cpu(), x.grad, 1e-5)                  # (torch splits differently only where windows tie)
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+def test_accumulate_and_bias_grad_typed(dt, tdt, eps):
+    g = torch.Generator().manual_seed(5)
+    for c, ld in ((64, 64), (24, 40), (5, 7)):
+        src = q(torch.randn(37, c, generator=g), tdt)
+        dst = q(torch.randn(37, c, generator=g), tdt)
+        sd = torch.zeros(37, ld, dtype=tdt, device=DEV)
+        dd = torch.zeros(37, ld, dtype=tdt, device=DEV)
+        sd[:, :c], dd[:, :c] = src.to(tdt).to(DEV), dst.to(tdt).to(DEV)
+        _lib.check(lib().gv_accumulate_t(sd.data_ptr(), ld, dd.data_ptr(), ld, 37, c, dt, st()), "acc")
+        close(dd[:, :c].float().cpu(), src + dst, eps)
+        accum = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+        db = torch.full((c,), 0.5, device=DEV)
+        _lib.check(lib().gv_bias_grad_t(sd.data_ptr(), ld, 37, c, accum.data_ptr(), db.data_ptr(), dt, st()), "bias")
+        close(db.cpu() - 0.5, src.sum(0), 1e-5)
+
+
+CONVS = [((3, 3), 1, "SAME", 32, 48, 3, 12, 11), ((3, 3), 2, "VALID", 32, 64, 3, 12, 11),
+         ((1, 7), 1, "SAME", 48, 32, 3, 12, 11), ((5, 5), 1, "SAME", 48, 64, 3, 12, 11),
+         ((3, 3), 1, "VALID", 80, 96, 3, 12, 11), ((1, 1), 1, "SAME", 96, 32, 3, 12, 11),
+         ((3, 3), 2, (1, 1, 1, 1), 64, 64, 3, 12, 11), ((1, 1), 2, "VALID", 64, 128, 3, 12, 11),
+         ((3, 3), 2, "VALID", 3, 32, 3, 12, 11),                 # stem: fp32-MFMA kernel with typed loads
+         ((3, 3), 1, "SAME", 288, 384, 2, 9, 9), ((1, 1), 1, "SAME", 768, 192, 4, 12, 12),
+         ((7, 1), 1, "SAME", 128, 192, 5, 12, 12), ((3, 3), 1, "SAME", 200, 136, 2, 7, 7),
+         ((3, 3), 1, "VALID", 32, 64, 18, 111, 111)]             # few-channel layer at full size: the direct kernel
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("k,stride,padding,cin,cout,nb,ih,iw", CONVS)
+def test_conv_wgrad_and_dgrad_typed(dt, tdt, eps, k, stride, padding, cin, cout, nb, ih, iw):
+    g = torch.Generator().manual_seed(hash((k, stride, cin)) % 997)
+    x = q(torch.randn(nb, ih, iw, cin, generator=g), tdt).requires_grad_(True)
+    w = q(torch.randn(k[0], k[1], cin, cout, generator=g) * 0.1, tdt).requires_grad_(True)
+    big = nb * ih * iw > 100000
+    dev = DEV if big else "cpu"
+    z = OB.conv2d(x.to(dev), w.to(dev), stride, padding) if big else OB.conv2d(x, w, stride, padding)
+    dz = q(torch.randn(*z.shape, generator=g), tdt)
+    z.backward(dz.to(z.device))
+    oh, ow = z.shape[1:3]
+    if isinstance(padding, str):
+        pt = OB.same_pads(ih, k[0], stride)[0] if padding == "SAME" else 0
+        pl = OB.same_pads(iw, k[1], stride)[0] if padding == "SAME" else 0
+    else:
+        pt, pl = padding[0], padding[2]
+    # operands inside wider buffers (a concat slice): pixel strides larger than the channel counts
+    xld, zld = (cin + 8 if cin % 8 == 0 else cin), cout + 16
+    xd = torch.zeros(nb, ih, iw, xld, dtype=tdt, device=DEV)
+    xd[..., :cin] = x.detach().to(tdt).to(DEV)
+    dzd = torch.zeros(nb, oh, ow, zld, dtype=tdt, device=DEV)
+    dzd[..., :cout] = dz.to(tdt).to(DEV)
+    dw = torch.full((k[0], k[1], cin, cout), 0.5, device=DEV)
+    d = _lib.ConvDesc(nb, ih, iw, cin, xld, k[0], k[1], stride, pt, pl, oh, ow, cout, cout, 0, 0, 0, dt, 0, 0, 0, 0)
+    _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad")
+    # products of 16-bit values are exact in fp32: only the summation order differs from autograd
+    close(dw.cpu() - 0.5, w.grad, 3e-5 if not big else 2e-4)
+    if cin % 16 or big:
+        return
+    wt = torch.flip(w.detach(), (0, 1)).permute(0, 1, 3, 2).contiguous().to(DEV)
+    n = lib().gv_packed_filter_bytes(k[0], k[1], cout, cin, dt, 0)
+    wp = torch.empty(n, dtype=torch.uint8, device=DEV)
+    _lib.check(lib().gv_pack_filter_hwio(wt.data_ptr(), k[0], k[1], cout, cin, wp.data_ptr(), dt, 0, st()), "pack")
+    dx = torch.full((nb, ih, iw, xld), 0.25, dtype=tdt, device=DEV)
+    ones, zeros = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+    dd = _lib.ConvDesc(nb, oh, ow, cout, zld, k[0], k[1], 1, k[0] - 1 - pt, k[1] - 1 - pl, ih, iw, cin, xld, xld, 0,
+                       0, dt, 0, 0, 0, stride if stride > 1 else 0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(dd), dzd.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(),
+                                   dx.data_ptr(), dx.data_ptr(), None, None, None, st()), "dgrad")
+    close(dx[..., :cin].float().cpu() - 0.25, x.grad, 2 * eps)
+    assert float((dx[..., cin:].float() - 0.25).abs().max()) == 0.0     # neighbours in the wider buffer untouched
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+def test_wgrad_mfma_kernel_equals_the_fp32_mfma_kernel_on_typed_loads(dt, tdt, eps):
+    """Two independent implementations of the 16-bit filter gradient (transposed-LDS-read 16-bit MFMA vs fp32 MFMA
+    with typed loads) agree to summation order."""
+    g = torch.Generator().manual_seed(11)
+    nb, ih, iw, cin, cout = 6, 17, 17, 160, 192
+    x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
+    dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
+    outs = []
+    for f32 in (0, 1):
+        lib().gv_conv2d_wgrad_set_lp_f32(f32)
+        dw = torch.zeros(1, 7, cin, cout, device=DEV)
+        d = _lib.ConvDesc(nb, ih, iw, cin, cin, 1, 7, 1, 0, 3, ih, iw, cout, cout, 0, 0, 0, dt, 0, 0, 0, 0)
+        _lib.check(lib().gv_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), cout, dw.data_ptr(), st()), "wgrad")
+        outs.append(dw.cpu())
+    lib().gv_conv2d_wgrad_set_lp_f32(0)
+    close(outs[0], outs[1], 2e-5)
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("per_shape", [0, 1])
+def test_view_pool_fuse_backward_typed(dt, tdt, eps, per_shape):
+    g = torch.Generator().manual_seed(3)
+    V, N, E, G = 6, 3, 40, 5
+    F = q(torch.randn(N, V, E, generator=g), tdt)
+    F[:, 1] = F[:, 0]                                    # ties inside a group
+    dS = torch.randn(N, E, generator=g)
+    sch = torch.zeros(N if per_shape else 1, G, V, dtype=torch.int32)
+    for n in range(sch.shape[0]):
+        for v in range(V):
+            sch[n, (v + n) % 3, v] = 1                   # groups 3, 4 stay empty
+    wt = 1.0 + sch.sum(-1).float()
+    Fd = F.to(tdt).to(DEV)
+    dF = torch.full_like(Fd, 0.5)
+    _lib.check(lib().gv_view_pool_fuse_bwd_t(Fd.data_ptr(), dS.to(DEV).data_ptr(), V, N, E, E, V * E,
+                                             sch.to(DEV).data_ptr(), G, wt.to(DEV).data_ptr(), _lib.GV_VIEWPOOL_MAX,
+                                             dF.data_ptr(), per_shape, dt, st()), "fuse bwd")
+    F32 = F.to(DEV)
+    dF32 = torch.zeros_like(F32)
+    fn = lib().gv_view_pool_fuse_bwd_per_shape if per_shape else lib().gv_view_pool_fuse_bwd
+    _lib.check(fn(F32.data_ptr(), dS.to(DEV).data_ptr(), V, N, E, E, V * E, sch.to(DEV).data_ptr(), G,
+                  wt.to(DEV).data_ptr(), _lib.GV_VIEWPOOL_MAX, dF32.data_ptr(), st()), "fuse bwd f32")
+    close(dF.float().cpu() - 0.5, dF32.cpu(), 4 * eps)
+
+
+def _flat(grads, names):
+    return torch.cat([grads[k].reshape(-1).double().cpu() for k in names])
+
+
+@pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 171, 4, 2), ("resnet_v2_50", 97, 3, 2)])
+def test_bf16_training_step_tracks_the_fp32_step(backbone, size, N, V):
+    """The whole step on bf16 storage against the fp32 engine (same variables, same batch, same scheme).  bf16
+    activations carry 2^-9 relative rounding per stored tensor and train-mode BN over a handful of samples amplifies
+    it, so the comparison is norm-wise: loss within 3 %, the whole gradient within 25 % in norm with cosine > 0.97."""
+    C_, G = 5, 10
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    shapes = eng.plan.param_shapes()
+    P = gv.params.init_backbone_params(shapes, seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
+    labels = torch.tensor([1, 4, 2, 0][:N])
+    e32 = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
+    _, S32, logits32, loss32 = e32.forward(x, labels)
+    g32 = {k: v.clone() for k, v in e32.backward().items()}
+    scheme, weight = e32.scheme.cpu().numpy(), e32.weight.cpu().numpy()
+    e16 = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage="bf16")
+    assert e16.act[0].dtype == torch.bfloat16
+    _, S16, logits16, loss16 = e16.forward(x, labels, g_scheme=scheme, g_weight=weight)
+    g16 = e16.backward()
+    torch.cuda.synchronize()
+    close(S16.float().cpu(), S32.cpu(), 0.05)
+    close(logits16.cpu(), logits32.cpu(), 0.05)
+    assert abs(float(loss16) - float(loss32)) <= 0.03 * max(1.0, abs(float(loss32)))
+    names = sorted(g32)
+    a, d = _flat(g16, names), _flat(g32, names)
+    cos = float((a @ d) / (a.norm() * d.norm()))
+    rel = float((a - d).norm() / d.norm())
+    print("bf16 vs fp32 step: cosine %.4f, relative error %.3f" % (cos, rel))
+    assert cos > 0.97 and rel < 0.25
+    # one Momentum step moves the loss down on the same batch
+    e16.apply_momentum(lr=1e-5, mu=0.9, weight_decay=1e-4)
+    _, _, _, loss1 = e16.forward(x, labels, g_scheme=scheme, g_weight=weight)
+    assert float(loss1) < float(loss16)
+
+
+def test_bf16_training_autotune_and_per_shape_step_runs():
+    eng = TrainGVCNN("inception_v3", 2, 3, 139, 139, 10, 10, device=DEV, storage="bf16", per_shape=True)
+    x = (torch.rand(2, 3, 139, 139, 3, generator=torch.Generator().manual_seed(4)) - 0.5).to(DEV)
+    labels = torch.tensor([3, 7])
+    eng.forward(x, labels, check=False)
+    eng.autotune(iters=1)
+    l0 = float(eng.train_step(x, labels, lr=1e-4))
+    assert np.isfinite(l0)
+    for _ in range(3):
+        l1 = float(eng.train_step(x, labels, lr=1e-4))
+    assert np.isfinite(l1) and l1 < l0

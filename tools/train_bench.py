@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Training-step throughput (fp32 storage, bf16x3 math): forward(train BN) + loss + backward + Momentum.
+"""Training-step throughput (--storage f32: fp32 storage, bf16x3 math; bf16: 16-bit storage and MFMA): forward(train BN) + loss + backward + Momentum.
     python tools/train_bench.py [--backbone inception_v3] [--shapes 8] [--views 12] [--size 224]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,9 @@ ap.add_argument("--shapes", type=int, default=8)
 ap.add_argument("--views", type=int, default=12)
 ap.add_argument("--size", type=int, default=224)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f16"])
 a = ap.parse_args()
-eng = TrainGVCNN(a.backbone, a.shapes, a.views, a.size, a.size, 40, 10, device="cuda:0")
+eng = TrainGVCNN(a.backbone, a.shapes, a.views, a.size, a.size, 40, 10, device="cuda:0", storage=a.storage)
 x = (torch.rand(a.shapes, a.views, a.size, a.size, 3) - 0.5).cuda()
 labels = torch.randint(0, 40, (a.shapes,))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -30,6 +31,6 @@ for _ in range(a.steps):
     tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2]); to += ev[2].elapsed_time(ev[3])
 n = a.steps
 flops = sum(op.get("flops", 0) for op in eng.plan.ops)
-print("%s %dx%d views %d^2: forward %.2f ms, backward %.2f ms, update+repack %.2f ms => %.1f views/s; fwd %.1f TF/s, bwd(2x flops) %.1f TF/s"
+print("[%s] " % a.storage + "%s %dx%d views %d^2: forward %.2f ms, backward %.2f ms, update+repack %.2f ms => %.1f views/s; fwd %.1f TF/s, bwd(2x flops) %.1f TF/s"
       % (a.backbone, a.shapes, a.views, a.size, tf / n, tb / n, to / n, a.shapes * a.views / ((tf + tb + to) / n * 1e-3),
          flops / (tf / n) / 1e9, 2 * flops / (tb / n) / 1e9))
