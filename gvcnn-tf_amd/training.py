@@ -318,38 +318,42 @@ class TrainGVCNN:
         self._x = views.to(self.tdt).contiguous()
         if self._packed_dirty:
             self.repack()
-        V = self.V
         for op in self.plan.ops:
-            x, y = op["x"], op["y"]
-            if op["kind"] == "conv":
-                d = self._conv_desc(op)
-                shift = self.params[op["bias"]] if op["bias"] else self.zeros
-                res = op["res"]
-                _lib.check(lib.gv_conv2d_fwd(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
-                                             shift.data_ptr(), self._ptr(res) if res is not None else None,
-                                             self._ptr(y), None, None, None, _st()), "conv " + op["name"])
-            elif op["kind"] == "bn":
-                st = op["stat"]
-                gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
-                beta = self.params[op["name"] + "/beta"]
-                hw = x.h * x.w
-                _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, self.accum.data_ptr(), self.dt,
-                                                    _st()), "bn sums " + op["name"])
-                if self.bn_sync is not None:                  # shape-sharded: reduce the sums over the ranks first
-                    self.bn_sync(self.accum[:2 * V * x.c])
-                _lib.check(lib.gv_bn_finalize_grouped(self.accum.data_ptr(), x.c, V, self._count(hw).data_ptr(),
-                                                      gamma.data_ptr() if gamma is not None else None,
-                                                      beta.data_ptr(), float(op["eps"]), st["mean"].data_ptr(),
-                                                      st["var"].data_ptr(), st["inv"].data_ptr(),
-                                                      st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
-                           "bn finalize " + op["name"])
-                _lib.check(lib.gv_scale_shift_act_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
-                                                            st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
-                                                            y.ld, self.dt, _st()), "bn apply " + op["name"])
-            else:
-                d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
-                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
-                _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
+            self._forward_op(op)
+
+    def _forward_op(self, op):
+        """One op of the train-mode forward pass (conv -> z, BatchNorm on batch statistics (+ReLU), pool)."""
+        lib, V = self.lib, self.V
+        x, y = op["x"], op["y"]
+        if op["kind"] == "conv":
+            d = self._conv_desc(op)
+            shift = self.params[op["bias"]] if op["bias"] else self.zeros
+            res = op["res"]
+            _lib.check(lib.gv_conv2d_fwd(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
+                                         shift.data_ptr(), self._ptr(res) if res is not None else None,
+                                         self._ptr(y), None, None, None, _st()), "conv " + op["name"])
+        elif op["kind"] == "bn":
+            st = op["stat"]
+            gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
+            beta = self.params[op["name"] + "/beta"]
+            hw = x.h * x.w
+            _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, self.accum.data_ptr(), self.dt,
+                                                _st()), "bn sums " + op["name"])
+            if self.bn_sync is not None:                  # shape-sharded: reduce the sums over the ranks first
+                self.bn_sync(self.accum[:2 * V * x.c])
+            _lib.check(lib.gv_bn_finalize_grouped(self.accum.data_ptr(), x.c, V, self._count(hw).data_ptr(),
+                                                  gamma.data_ptr() if gamma is not None else None,
+                                                  beta.data_ptr(), float(op["eps"]), st["mean"].data_ptr(),
+                                                  st["var"].data_ptr(), st["inv"].data_ptr(),
+                                                  st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
+                       "bn finalize " + op["name"])
+            _lib.check(lib.gv_scale_shift_act_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
+                                                        st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
+                                                        y.ld, self.dt, _st()), "bn apply " + op["name"])
+        else:
+            d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
+                              op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
+            _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
 
     def score_partial(self):
         """Scorer responses r_img [N*V] of this engine's views (model.py:144-145); no gradient flows through the
@@ -463,54 +467,60 @@ class TrainGVCNN:
 
     def backward_backbone(self):
         """Backbone backward from the gradient held in the final tap's gradient buffer."""
-        lib, V = self.lib, self.V
         for op in reversed(self.plan.ops):
-            x, y = op["x"], op["y"]
+            y = op["y"]
             if y.vbuf < 0 or self.grad[y.vbuf] is None:
                 continue                                  # nothing downstream of the final tap reaches it
-            if op["kind"] == "bn":
-                st = op["stat"]
-                hw = x.h * x.w
-                gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
-                dbeta = self.grads[op["name"] + "/beta"].data_ptr()
-                dgamma = self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None
-                yptr = self._ptr(y) if op["relu"] else None
-                _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
-                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                    st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self.dt, _st()),
-                    "bn_bwd sums " + op["name"])
-                if self.bn_sync is not None:
-                    self.bn_sync(self.accum[:2 * V * x.c])
-                _lib.check(lib.gv_bn_relu_bwd_apply_grouped_t(
-                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                    st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
-                    self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
-                    dbeta, dgamma, self.dt, _st()), "bn_bwd apply " + op["name"])
-            elif op["kind"] == "conv":
-                dz = self._ptr(y, True)
-                if op["bias"]:
-                    _lib.check(lib.gv_bias_grad_t(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
-                                                  self.grads[op["bias"]].data_ptr(), self.dt, _st()), "bias_grad")
-                if op["res"] is not None:
-                    r = op["res"]
-                    _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
-                               "res grad")
-                d = self._conv_desc(op)
-                _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld,
-                                               self.grads[op["name"] + "/weights"].data_ptr(), _st()),
-                           "wgrad " + op["name"])
-                if x.vbuf >= 0:
-                    dd = self._conv_desc(op, dgrad=True)
-                    dx = self._ptr(x, True)
-                    _lib.check(lib.gv_conv2d_fwd(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
-                                                 self.zeros.data_ptr(), dx, dx, None, None, None, _st()),
-                               "dgrad " + op["name"])
-            else:
-                d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
-                                  op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
-                _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
-                                             x.ld, _st()), "pool_bwd " + op["name"])
+            self._backward_op(op)
         return self.grads
+
+    def _backward_op(self, op):
+        """Backward of one op: reads the gradient of its output, ACCUMULATES into the gradient of its input(s) and
+        of its variables."""
+        lib, V = self.lib, self.V
+        x, y = op["x"], op["y"]
+        if op["kind"] == "bn":
+            st = op["stat"]
+            hw = x.h * x.w
+            gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
+            dbeta = self.grads[op["name"] + "/beta"].data_ptr()
+            dgamma = self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None
+            yptr = self._ptr(y) if op["relu"] else None
+            _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
+                self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self.dt, _st()),
+                "bn_bwd sums " + op["name"])
+            if self.bn_sync is not None:
+                self.bn_sync(self.accum[:2 * V * x.c])
+            _lib.check(lib.gv_bn_relu_bwd_apply_grouped_t(
+                self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
+                dbeta, dgamma, self.dt, _st()), "bn_bwd apply " + op["name"])
+        elif op["kind"] == "conv":
+            dz = self._ptr(y, True)
+            if op["bias"]:
+                _lib.check(lib.gv_bias_grad_t(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
+                                              self.grads[op["bias"]].data_ptr(), self.dt, _st()), "bias_grad")
+            if op["res"] is not None:
+                r = op["res"]
+                _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
+                           "res grad")
+            d = self._conv_desc(op)
+            _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld,
+                                           self.grads[op["name"] + "/weights"].data_ptr(), _st()),
+                       "wgrad " + op["name"])
+            if x.vbuf >= 0:
+                dd = self._conv_desc(op, dgrad=True)
+                dx = self._ptr(x, True)
+                _lib.check(lib.gv_conv2d_fwd(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
+                                             self.zeros.data_ptr(), dx, dx, None, None, None, _st()),
+                           "dgrad " + op["name"])
+        else:
+            d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
+                              op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
+            _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
+                                         x.ld, _st()), "pool_bwd " + op["name"])
 
     def apply_momentum(self, lr, mu=0.9, weight_decay=0.0):
         """tf.train.MomentumOptimizer(lr, 0.9); the slim L2 term (wd * w) applies to conv weights only."""
