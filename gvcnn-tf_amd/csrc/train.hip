@@ -1033,7 +1033,9 @@ extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void*
     if (d->nb <= 0 || d->cin <= 0 || d->cout <= 0 || dz_ld < d->cout || d->x_ld < d->cin) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == GV_BF16 || d->dtype == GV_F16) {
-        if (!g_wgrad_lp_f32 && !wgrad_direct_ok(d) && gvlp::wgrad_mfma_ok(d, x, dz, dz_ld))
+        // (the 16-bit MFMA kernel also takes the 32-channel stem layers: the direct kernel's scalar 16-bit loads
+        // lose the prefetch, 7-13 ms against ~1 ms)
+        if (!g_wgrad_lp_f32 && gvlp::wgrad_mfma_ok(d, x, dz, dz_ld))
             return gvlp::conv_wgrad(d, x, dz, dz_ld, dw_hwio, st);
         if (d->dtype == GV_BF16) return wgrad_f32mfma<__bf16>(d, (const __bf16*)x, (const __bf16*)dz, dz_ld, dw_hwio, st);
         return wgrad_f32mfma<_Float16>(d, (const _Float16*)x, (const _Float16*)dz, dz_ld, dw_hwio, st);

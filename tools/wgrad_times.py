@@ -15,9 +15,10 @@ from gvcnn_tf_amd.training import TrainGVCNN  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", type=int, default=32)
 ap.add_argument("--backbone", default="inception_v3")
+ap.add_argument("--storage", default="f32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-eng = TrainGVCNN(a.backbone, a.shapes, 12, 224, 224, 40, 7, device=dev, num_bins=7)
+eng = TrainGVCNN(a.backbone, a.shapes, 12, 224, 224, 40, 7, device=dev, num_bins=7, storage=a.storage)
 lib = _lib.load()
 x = (torch.rand(a.shapes, 12, 224, 224, 3, device=dev) - 0.5)
 eng.forward(x, torch.zeros(a.shapes, dtype=torch.int64), check=False)
@@ -33,7 +34,10 @@ for op in eng.plan.ops:
     dw = eng.grads[op["name"] + "/weights"]
     res = []
     for v1 in (1, 0):
-        lib.gv_conv2d_wgrad_set_v1(v1)
+        if a.storage == "f32":
+            lib.gv_conv2d_wgrad_set_v1(v1)
+        else:                                    # 16-bit storage: column 1 = fp32 MFMA with typed loads, column 2 = 16-bit MFMA
+            lib.gv_conv2d_wgrad_set_lp_f32(v1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         lib.gv_conv2d_wgrad(C.byref(d), eng._ptr(xx), eng._ptr(y, True), y.ld, dw.data_ptr(), st)
         e0.record()
@@ -43,6 +47,7 @@ for op in eng.plan.ops:
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 3)
     lib.gv_conv2d_wgrad_set_v1(0)
+    lib.gv_conv2d_wgrad_set_lp_f32(0)
     tot[0] += res[0]
     tot[1] += res[1]
     fl = op["flops"]
