@@ -188,6 +188,222 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_lp(
     }
 }
 
+// ---- the three BatchNorm passes, 8 channels per thread, streaming form ------------------------------------------
+// Block = 8 channel threads (64 channels, 128 contiguous bytes per pixel) x 32 pixel lanes; grid (channel blocks,
+// pixel splits, G).  A thread keeps its channels for the whole pixel range, so everything per (group, channel) —
+// mean, inv, the folded backward coefficients — is computed once, and the walk over the group's pixels (images
+// g, g+G, g+2G, ... of the batch) is incremental: no division in the loop, four 16-byte loads in flight per stream.
+struct GroupWalk {
+    int r, hw, step_img;
+    int64_t pix;
+    __device__ __forceinline__ void init(int p, int hw_, int G, int g) {
+        hw = hw_;
+        const int k = p / hw_;
+        r = p - k * hw_;
+        pix = (int64_t)(k * G + g) * hw_ + r;
+        step_img = (G - 1) * hw_;
+    }
+    __device__ __forceinline__ void advance(int n) {
+        r += n;
+        pix += n;
+        while (r >= hw) { r -= hw; pix += step_img; }
+    }
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __restrict__ z, int z_ld,
+                                                       const unsigned short* __restrict__ dy, int dy_ld,
+                                                       const unsigned short* __restrict__ y, int y_ld,
+                                                       const float* __restrict__ mean, const float* __restrict__ inv,
+                                                       int nb, int hw, int c, int G, double* __restrict__ acc) {
+    constexpr int PL = 32, U = 4;
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int ch = blockIdx.x * 64 + cl * 8;
+    const int g = blockIdx.z;
+    const int nimg = (nb - g + G - 1) / G;
+    const int npix = nimg * hw;                                  // < 2^31 (checked by the launcher)
+    const int per = (npix + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per;
+    const int p1 = p0 + per < npix ? p0 + per : npix;
+    double s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.0;
+    if (ch < c && p0 + pl < p1) {
+        float mu[8], iv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
+            iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
+        }
+        GroupWalk w;
+        w.init(p0 + pl, hw, G, g);
+        const int n_it = (p1 - p0 - pl + PL - 1) / PL;
+        float f0[8], f1[8];
+        auto fold = [&]() {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s0[e] += f0[e]; s1[e] += f1[e]; f0[e] = f1[e] = 0.f; }
+        };
+        auto add = [&](const u32x4 zq, const u32x4 gq, const u32x4 yq) {
+            float zv[8], gv[8], yv[8];
+            if (MODE != 2) unpack8<T>(zq, zv);
+            if (MODE != 0) unpack8<T>(gq, gv);
+            if (MODE == 1 && y) unpack8<T>(yq, yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (MODE == 0) {
+                    f0[e] += zv[e];
+                    f1[e] = fmaf(zv[e], zv[e], f1[e]);
+                } else if (MODE == 1) {
+                    float gr = gv[e];
+                    if (y && !(yv[e] > 0.f)) gr = 0.f;
+                    f0[e] += gr;
+                    f1[e] = fmaf(gr, (zv[e] - mu[e]) * iv[e], f1[e]);
+                } else {
+                    f0[e] += gv[e];
+                }
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f0[e] = f1[e] = 0.f;
+        int it = 0;
+        for (; it + U <= n_it; it += U) {
+            u32x4 zq[U], gq[U], yq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (MODE != 2) zq[u] = *reinterpret_cast<const u32x4*>(z + w.pix * z_ld + ch);
+                if (MODE != 0) gq[u] = *reinterpret_cast<const u32x4*>(dy + w.pix * dy_ld + ch);
+                if (MODE == 1 && y) yq[u] = *reinterpret_cast<const u32x4*>(y + w.pix * y_ld + ch);
+                w.advance(PL);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) add(zq[u], gq[u], yq[u]);
+            if ((it & 12) == 12) fold();                         // fp32 runs of 16 values, then fp64
+        }
+        for (; it < n_it; ++it) {
+            u32x4 zq = {0u, 0u, 0u, 0u}, gq = zq, yq = zq;
+            if (MODE != 2) zq = *reinterpret_cast<const u32x4*>(z + w.pix * z_ld + ch);
+            if (MODE != 0) gq = *reinterpret_cast<const u32x4*>(dy + w.pix * dy_ld + ch);
+            if (MODE == 1 && y) yq = *reinterpret_cast<const u32x4*>(y + w.pix * y_ld + ch);
+            w.advance(PL);
+            add(zq, gq, yq);
+        }
+        fold();
+    }
+    __shared__ double red[2][32][64];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[0][pl][cl * 8 + e] = s0[e];
+        red[1][pl][cl * 8 + e] = s1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < c) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < 32; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
+        const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
+        atomicAdd(&acc[o], a);
+        if (MODE != 2) atomicAdd(&acc[o + 1], b);
+    }
+}
+
+// FWD: y = act(x*scale + shift).  BWD: dz += A*g + B*z + C with g = dy*[y>0] and, per (group, channel),
+// A = gamma*inv, B = -A*inv*s2/m, C = A*(mean*inv*s2 - s1)/m   (= gamma*inv*(g - s1/m - zhat*s2/m)).
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __restrict__ x, int x_ld,
+                                                    const unsigned short* __restrict__ dy, int dy_ld,
+                                                    const unsigned short* __restrict__ yact, int y_ld,
+                                                    const float* __restrict__ p0f, const float* __restrict__ p1f,
+                                                    const float* __restrict__ gamma, const double* __restrict__ acc,
+                                                    const int* __restrict__ counts, int nb, int hw, int c, int G,
+                                                    int relu, unsigned short* __restrict__ out, int out_ld) {
+    constexpr int PL = 32, U = 4;
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int ch = blockIdx.x * 64 + cl * 8;
+    const int g = blockIdx.z;
+    const int nimg = (nb - g + G - 1) / G;
+    const int npix = nimg * hw;
+    const int per = (npix + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per;
+    const int p1 = p0 + per < npix ? p0 + per : npix;
+    if (ch >= c || p0 + pl >= p1) return;
+    float A[8], B[8], Cc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int gi = g * c + ch + e;
+        if constexpr (BWD) {                                     // p0f = mean, p1f = inv
+            const float iv = p1f[gi], mu = p0f[gi];
+            const float rm = 1.f / (float)counts[g];
+            const float s1 = (float)acc[(size_t)gi * 2], s2 = (float)acc[(size_t)gi * 2 + 1];
+            A[e] = (gamma ? gamma[ch + e] : 1.f) * iv;
+            B[e] = -A[e] * iv * s2 * rm;
+            Cc[e] = A[e] * (mu * iv * s2 - s1) * rm;
+        } else {                                                 // p0f = scale, p1f = shift
+            A[e] = p0f[gi];
+            B[e] = p1f[gi];
+        }
+    }
+    GroupWalk w;
+    w.init(p0 + pl, hw, G, g);
+    const int n_it = (p1 - p0 - pl + PL - 1) / PL;
+    auto one = [&](int64_t pix, const u32x4 xq, const u32x4 gq, const u32x4 yq, const u32x4 oq) {
+        float xv[8], o[8];
+        unpack8<T>(xq, xv);
+        if constexpr (BWD) {
+            float gv[8], yv[8];
+            unpack8<T>(gq, gv);
+            unpack8<T>(oq, o);
+            if (yact) unpack8<T>(yq, yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gg = gv[e];
+                if (yact && !(yv[e] > 0.f)) gg = 0.f;
+                o[e] += fmaf(A[e], gg, fmaf(B[e], xv[e], Cc[e]));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = fmaf(xv[e], A[e], B[e]);
+                if (relu) o[e] = fmaxf(o[e], 0.f);
+            }
+        }
+        *reinterpret_cast<u32x4*>(out + pix * out_ld + ch) = pack8<T>(o);
+    };
+    int it = 0;
+    for (; it + U <= n_it; it += U) {
+        u32x4 xq[U], gq[U], yq[U], oq[U];
+        int64_t px[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            px[u] = w.pix;
+            xq[u] = *reinterpret_cast<const u32x4*>(x + w.pix * x_ld + ch);
+            if constexpr (BWD) {
+                gq[u] = *reinterpret_cast<const u32x4*>(dy + w.pix * dy_ld + ch);
+                if (yact) yq[u] = *reinterpret_cast<const u32x4*>(yact + w.pix * y_ld + ch);
+                oq[u] = *reinterpret_cast<const u32x4*>(out + w.pix * out_ld + ch);
+            }
+            w.advance(PL);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(px[u], xq[u], gq[u], yq[u], oq[u]);
+    }
+    for (; it < n_it; ++it) {
+        u32x4 xq, gq = {0u, 0u, 0u, 0u}, yq = gq, oq = gq;
+        xq = *reinterpret_cast<const u32x4*>(x + w.pix * x_ld + ch);
+        if constexpr (BWD) {
+            gq = *reinterpret_cast<const u32x4*>(dy + w.pix * dy_ld + ch);
+            if (yact) yq = *reinterpret_cast<const u32x4*>(yact + w.pix * y_ld + ch);
+            oq = *reinterpret_cast<const u32x4*>(out + w.pix * out_ld + ch);
+        }
+        one(w.pix, xq, gq, yq, oq);
+        w.advance(PL);
+    }
+}
+
+inline int stream_splits(int nb, int hw, int G) {
+    const int64_t npix = (int64_t)((nb + G - 1) / G) * hw;
+    int64_t s = (npix + 1023) / 1024;                            // ~32 pixels per thread
+    return (int)(s < 1 ? 1 : (s > 65535 ? 65535 : s));
+}
+
 // Pool backward as a GATHER over the input pixels (no atomics: 16-bit storage has none worth using, and the result
 // is deterministic): an input pixel visits the windows that contain it.  max: it receives a window's gradient when
 // it is that window's first maximum in scan order (tf MaxPoolGrad / torch); avg: dy / #valid taps of every window.
@@ -265,6 +481,80 @@ __global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __res
 #pragma unroll
         for (int e = 0; e < VEC; ++e) d[e] += sum[e];
         store_v<T, VEC>(dx + pix * dx_ld + q * VEC, d);
+    }
+}
+
+// 3x3 / stride 2 / VALID max pool (every max pool of Inception-v3): a thread owns the 2x2 input pixels (2a..2a+1,
+// 2b..2b+1) x 8 channels and visits the four windows (a-1..a, b-1..b) that touch them ONCE each — argmax per window
+// from its nine taps, then the gradient goes to whichever of the thread's pixels is that tap: 11 loads per input pixel
+// instead of the 23 of the per-pixel gather above.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* __restrict__ x, int x_ld,
+                                                         const unsigned short* __restrict__ dy, int dy_ld, int nb,
+                                                         int ih, int iw, int c, int oh, int ow,
+                                                         unsigned short* __restrict__ dx, int dx_ld) {
+    const int cg = c / 8, ah = (ih + 1) / 2, aw = (iw + 1) / 2;
+    const int64_t total = (int64_t)nb * ah * aw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int b = (int)(t % aw);
+        t /= aw;
+        const int a = (int)(t % ah);
+        const int n = (int)(t / ah);
+        float sum[4][8];                                         // [2*dy + dx of the 2x2 block]
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[k][e] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = a - 1 + wy, ox = b - 1 + wx;
+                if ((unsigned)oy >= (unsigned)oh || (unsigned)ox >= (unsigned)ow) continue;
+                float best[8];
+                int arg[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int yy = 2 * oy + tap / 3, xx = 2 * ox + tap % 3;      // in bounds: VALID padding
+                    float v[8];
+                    load_v<T, 8>(x + ((int64_t)(n * ih + yy) * iw + xx) * x_ld + q * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = tap; }
+                }
+                float g[8];
+                load_v<T, 8>(dy + ((int64_t)(n * oh + oy) * ow + ox) * dy_ld + q * 8, g);
+                // the thread's pixel (2a+py, 2b+px) is tap (2a+py-2oy, 2b+px-2ox) = (py + 2*(1-wy), px + 2*(1-wx))
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const int tr = py + 2 * (1 - wy), tc = px + 2 * (1 - wx);
+                        if (tr > 2 || tc > 2) continue;
+                        const int tap = tr * 3 + tc;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum[2 * py + px][e] += arg[e] == tap ? g[e] : 0.f;
+                    }
+            }
+        }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int iy = 2 * a + py, ix = 2 * b + px;
+                if (iy >= ih || ix >= iw) continue;
+                unsigned short* dp = dx + ((int64_t)(n * ih + iy) * iw + ix) * dx_ld + q * 8;
+                float d[8];
+                load_v<T, 8>(dp, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] += sum[2 * py + px][e];
+                store_v<T, 8>(dp, d);
+            }
     }
 }
 
@@ -478,6 +768,17 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
            hipStream_t st) {
     const bool v = (c % 8 == 0) && vec8(z, z_ld) && vec8(dy, dy_ld) && vec8(y, y_ld);
     const dim3 grid((c + 63) / 64, splits, G);
+    if (v && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll) {
+#define GV_SUMS8(MODE)                                                                                               \
+        hipLaunchKernelGGL((grouped_sums_v8<T, MODE>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, nb, \
+                           hw, c, G, acc)
+        if (mode == 0) GV_SUMS8(0);
+        else if (mode == 1) GV_SUMS8(1);
+        else GV_SUMS8(2);
+#undef GV_SUMS8
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
 #define GV_SUMS(MODE)                                                                                                \
     do {                                                                                                             \
         if (v)                                                                                                       \
@@ -561,11 +862,13 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
                             const float* shift, int G, int relu, void* y, int y_ld, hipStream_t st) {
     const unsigned short* xs = (const unsigned short*)x;
     unsigned short* ys = (unsigned short*)y;
-    const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld);
+    const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
     GV_LP_DISPATCH(dtype, {
         if (v)
-            hipLaunchKernelGGL((scale_shift_act_grouped_lp<T, 8>), dim3(grid_for((int64_t)nb * hw * (c / 8))), dim3(256),
-                               0, st, xs, nb, hw, c, x_ld, scale, shift, G, relu, ys, y_ld);
+            hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
+                               xs, x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, scale, shift,
+                               (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, nb, hw, c, G, relu, ys,
+                               y_ld);
         else
             hipLaunchKernelGGL((scale_shift_act_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st,
                                xs, nb, hw, c, x_ld, scale, shift, G, relu, ys, y_ld);
@@ -581,11 +884,12 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
     const unsigned short* b = (const unsigned short*)y;
     const unsigned short* zz = (const unsigned short*)z;
     unsigned short* o = (unsigned short*)dz;
-    const bool v = (c % 8 == 0) && vec8(a, dy_ld) && vec8(b, y_ld) && vec8(zz, z_ld) && vec8(o, dz_ld);
+    const bool v = (c % 8 == 0) && vec8(a, dy_ld) && vec8(b, y_ld) && vec8(zz, z_ld) && vec8(o, dz_ld) &&
+                   (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
     GV_LP_DISPATCH(dtype, {
         if (v)
-            hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 8>), dim3(grid_for((int64_t)nb * hw * (c / 8))), dim3(256), 0,
-                               st, a, dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, o, dz_ld);
+            hipLaunchKernelGGL((bn_stream_v8<T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
+                               zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, 0, o, dz_ld);
         else
             hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, a,
                                dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, o, dz_ld);
@@ -600,8 +904,14 @@ int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, 
     unsigned short* o = (unsigned short*)dx;
     const bool v = (d->c % 8 == 0) && vec8(xs, d->x_ld) && vec8(g, dy_ld) && vec8(o, dx_ld);
     const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
+    const bool m3s2 = v && d->mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
+                      d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
     GV_LP_DISPATCH(d->dtype, {
-        if (v)
+        if (m3s2)
+            hipLaunchKernelGGL((maxpool3s2_bwd_lp<T>),
+                               dim3(grid_for((int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2) * (d->c / 8))), dim3(256),
+                               0, st, xs, d->x_ld, g, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, o, dx_ld);
+        else if (v)
             hipLaunchKernelGGL((pool2d_bwd_lp<T, 8>), dim3(grid_for(npix * (d->c / 8))), dim3(256), 0, st, xs, d->x_ld, g,
                                dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh,
                                d->ow, d->mode, o, dx_ld);
