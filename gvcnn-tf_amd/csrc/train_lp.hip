@@ -796,15 +796,26 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
     return GV_OK;
 }
 
+// Launch geometry: d->tile_cfg = 0 picks by divisibility (128 channels on a side only where that wastes no more rows
+// than 64-wide tiles would) and ~2048 workgroups; tile_cfg = 1 + tile + 4*split selects tile (TI,TO) in {(1,1),(2,1),
+// (1,2),(2,2)} and a target of 1024 / 2048 / 4096 workgroups (TrainGVCNN.autotune measures them per layer).
 template <typename T>
 int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
             hipStream_t st) {
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
-    const int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
-    const int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
+    int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
+    int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
+    int64_t target = 2048;
+    if (d->tile_cfg > 0) {
+        const int k = d->tile_cfg - 1;
+        if (k >= 12) return GV_E_BADARG;
+        ti = 1 + ((k & 3) & 1);
+        to = 1 + ((k & 3) >> 1);
+        target = 1024 << (k >> 2);
+    }
     const int tiles = d->kh * d->kw * ((d->cin + 64 * ti - 1) / (64 * ti)) * ((d->cout + 64 * to - 1) / (64 * to));
-    int64_t splits = (2048 + tiles - 1) / tiles;
-    const int64_t max_splits = (M + 1023) / 1024;                // at least 1024 pixels per workgroup
+    int64_t splits = (target + tiles - 1) / tiles;
+    const int64_t max_splits = (M + 511) / 512;                  // at least 512 pixels per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;

@@ -244,8 +244,12 @@ class TrainGVCNN:
                                            device=self.device)
         return self._counts[key]
 
-    def _conv_desc(self, op, dgrad=False):
+    def _conv_desc(self, op, dgrad=False, wgrad=False):
         x, y = op["x"], op["y"]
+        if wgrad:                                         # descriptor of the forward conv, filter-gradient launch choice
+            return _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"], op["pad_t"],
+                                 op["pad_l"], y.h, y.w, y.c, y.ld, 0, 0, 0, self.dt, 0, op.get("tile_w", 0),
+                                 self.math_mode, 0)
         if not dgrad:
             return _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"], op["pad_t"],
                                  op["pad_l"], y.h, y.w, y.c, y.ld, op["res"].ld if op["res"] is not None else 0,
@@ -283,6 +287,26 @@ class TrainGVCNN:
                     if rc == 0 and ms.value < best_ms:
                         best, best_ms = t + 1, ms.value
                 op[key] = best
+            # filter gradient (16-bit storage): tile and pixel-split choice, timed with events on the launch stream
+            nw = lib.gv_conv2d_wgrad_num_cfgs(self.dt)
+            if nw:
+                dw = torch.empty_like(self.grads[op["name"] + "/weights"])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                best, best_ms = 0, float("inf")
+                for t in range(nw + 1):
+                    op["tile_w"] = t
+                    d = self._conv_desc(op, wgrad=True)
+                    args = (C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, dw.data_ptr(), _st())
+                    if lib.gv_conv2d_wgrad(*args) != 0:
+                        continue
+                    e0.record()
+                    for _ in range(iters):
+                        lib.gv_conv2d_wgrad(*args)
+                    e1.record()
+                    e1.synchronize()
+                    if e0.elapsed_time(e1) < best_ms:
+                        best, best_ms = t, e0.elapsed_time(e1)
+                op["tile_w"] = best
 
     def repack(self):
         """Refresh the packed filters from the trainable HWIO variables (after an optimizer step)."""
@@ -506,7 +530,7 @@ class TrainGVCNN:
                 r = op["res"]
                 _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
                            "res grad")
-            d = self._conv_desc(op)
+            d = self._conv_desc(op, wgrad=True)
             _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld,
                                            self.grads[op["name"] + "/weights"].data_ptr(), _st()),
                        "wgrad " + op["name"])

@@ -226,6 +226,27 @@ def test_wgrad_mfma_kernel_equals_the_fp32_mfma_kernel_on_typed_loads(dt, tdt, e
 
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
+def test_wgrad_every_launch_configuration(dt, tdt, eps):
+    """gv_conv_desc.tile_cfg of the 16-bit filter gradient (tile shape x pixel split, a speed choice): same result."""
+    g = torch.Generator().manual_seed(12)
+    nb, ih, iw, cin, cout = 5, 13, 12, 96, 160
+    x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
+    dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
+    n = lib().gv_conv2d_wgrad_num_cfgs(dt)
+    assert n == 12 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0
+    outs = []
+    for cfg in range(n + 1):
+        dw = torch.zeros(3, 3, cin, cout, device=DEV)
+        d = _lib.ConvDesc(nb, ih, iw, cin, cin, 3, 3, 1, 1, 1, ih, iw, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
+        _lib.check(lib().gv_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), cout, dw.data_ptr(), st()), "wgrad")
+        outs.append(dw.cpu())
+    for o in outs[1:]:
+        close(o, outs[0], 2e-5)
+    d = _lib.ConvDesc(nb, ih, iw, cin, cin, 3, 3, 1, 1, 1, ih, iw, cout, cout, 0, 0, 0, dt, 0, n + 1, 0, 0)
+    assert lib().gv_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), cout, outs[0].to(DEV).data_ptr(), st()) != 0
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
 @pytest.mark.parametrize("per_shape", [0, 1])
 def test_view_pool_fuse_backward_typed(dt, tdt, eps, per_shape):
     g = torch.Generator().manual_seed(3)
