@@ -87,9 +87,9 @@ SIGNATURES = {
     "gv_sgd_momentum": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _P]),
     "gv_bn_sums_grouped_t": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "gv_scale_shift_act_grouped_t": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P]),
-    "gv_bn_relu_bwd_sums_grouped_t": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "gv_bn_relu_bwd_sums_grouped_t": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "gv_bn_relu_bwd_apply_grouped_t": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P,
-                                                 _P, _I, _P]),
+                                                 _P, _P, _P, _I, _I, _P]),
     "gv_accumulate_t": (C.c_int, [_P, _I, _P, _I, _L, _I, _I, _P]),
     "gv_bias_grad_t": (C.c_int, [_P, _I, _L, _I, _P, _P, _I, _P]),
     "gv_view_pool_fuse_bwd_t": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _I, _I, _P]),

@@ -19,13 +19,14 @@ int view_pool_fuse(int dtype, const void* F, int V, int N, int64_t E, int64_t vs
 // train_lp.hip: the training step on 16-bit storage
 int accumulate(int dtype, const void* src, int src_ld, void* dst, int dst_ld, int64_t npix, int c, hipStream_t st);
 int grouped_sums(int dtype, int mode, const void* z, int z_ld, const void* dy, int dy_ld, const void* y, int y_ld,
-                 const float* mean, const float* inv, int nb, int hw, int c, int G, int splits, double* acc,
-                 hipStream_t st);
+                 const float* mean, const float* inv, const float* scale, const float* shift, int nb, int hw, int c,
+                 int G, int splits, double* acc, hipStream_t st);
 int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int x_ld, const float* scale,
                             const float* shift, int G, int relu, void* y, int y_ld, hipStream_t st);
 int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, const void* z, int z_ld,
                          const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
-                         int nb, int hw, int c, int G, void* dz, int dz_ld, hipStream_t st);
+                         const float* scale, const float* shift, int accumulate, int nb, int hw, int c, int G, void* dz,
+                         int dz_ld, hipStream_t st);
 int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, void* dx, int dx_ld, hipStream_t st);
 int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,
                        const int* scheme, int G, const float* weight, int mode, void* dF, hipStream_t st,

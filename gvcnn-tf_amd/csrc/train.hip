@@ -1078,8 +1078,8 @@ extern "C" int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32
     if (nb <= 0 || hw <= 0 || c <= 0 || z_ld < c || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
-    return gvlp::grouped_sums(dtype, 0, z, z_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, nb, hw, c, num_groups,
-                              sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
+    return gvlp::grouped_sums(dtype, 0, z, z_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nb, hw, c,
+                              num_groups, sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
 }
 
 extern "C" int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
@@ -1098,16 +1098,19 @@ extern "C" int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t h
 extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld,
                                              const void* z, int32_t z_ld, const float* mean, const float* inv,
                                              int32_t nb, int32_t hw, int32_t c, int32_t num_groups, double* accum,
-                                             int32_t dtype, void* stream) {
-    if (dtype == GV_F32)
+                                             const float* scale, const float* shift, int32_t dtype, void* stream) {
+    if (dtype == GV_F32) {
+        if (scale && !y) return GV_E_UNSUPPORTED;                // the fp32 step reads its ReLU mask from y
         return gv_bn_relu_bwd_sums_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
                                            inv, nb, hw, c, num_groups, accum, stream);
+    }
+    if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
     if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
     if (!dy || !z || !mean || !inv || !accum) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
-    return gvlp::grouped_sums(dtype, 1, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, nb, hw, c, num_groups,
+    return gvlp::grouped_sums(dtype, 1, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, shift, nb, hw, c, num_groups,
                               sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
 }
 
@@ -1115,18 +1118,21 @@ extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, con
                                               const void* z, int32_t z_ld, const float* mean, const float* inv,
                                               const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
                                               int32_t c, int32_t num_groups, const double* accum, void* dz,
-                                              int32_t dz_ld, float* dbeta, float* dgamma, int32_t dtype,
-                                              void* stream) {
-    if (dtype == GV_F32)
+                                              int32_t dz_ld, float* dbeta, float* dgamma, const float* scale,
+                                              const float* shift, int32_t accumulate, int32_t dtype, void* stream) {
+    if (dtype == GV_F32) {
+        if ((scale && !y) || !accumulate) return GV_E_UNSUPPORTED;   // the fp32 step: mask from y, dz += only
         return gv_bn_relu_bwd_apply_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
                                             inv, gamma, counts, nb, hw, c, num_groups, accum, (float*)dz, dz_ld, dbeta,
                                             dgamma, stream);
+    }
+    if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
     if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
     if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    const int rc = gvlp::bn_bwd_apply_grouped(dtype, dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw,
-                                              c, num_groups, dz, dz_ld, st);
+    const int rc = gvlp::bn_bwd_apply_grouped(dtype, dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, scale,
+                                              shift, accumulate, nb, hw, c, num_groups, dz, dz_ld, st);
     if (rc != GV_OK) return rc;
     if (dbeta || dgamma)
         hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
@@ -1150,8 +1156,8 @@ extern "C" int gv_bias_grad_t(const void* dz, int32_t dz_ld, int64_t npix, int32
     if (!dz || !accum || !dbias || npix <= 0 || c <= 0 || dz_ld < c || npix > 0x7fffffff) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)c, st));
-    const int rc = gvlp::grouped_sums(dtype, 2, nullptr, 0, dz, dz_ld, nullptr, 0, nullptr, nullptr, (int)npix, 1, c, 1,
-                                      sums_splits(npix, 1024), accum, st);
+    const int rc = gvlp::grouped_sums(dtype, 2, nullptr, 0, dz, dz_ld, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                                      (int)npix, 1, c, 1, sums_splits(npix, 1024), accum, st);
     if (rc != GV_OK) return rc;
     hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, 1, c, dbias, (float*)nullptr);
     GV_LAUNCH_CHECK();

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void grouped_sums_lp(const unsigned short* __r
                                                        const unsigned short* __restrict__ dy, int dy_ld,
                                                        const unsigned short* __restrict__ y, int y_ld,
                                                        const float* __restrict__ mean, const float* __restrict__ inv,
-                                                       int nb, int hw, int c, int G, double* __restrict__ acc) {
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int nb, int hw, int c, int G,
+                                                       double* __restrict__ acc) {
     constexpr int TPC = 64 / VEC;
     constexpr int PL = 256 / TPC;
     const int cl = threadIdx.x % TPC;
@@ -71,11 +73,14 @@ __global__ __launch_bounds__(256) void grouped_sums_lp(const unsigned short* __r
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.0;
     if (ch < c) {
-        float mu[VEC], iv[VEC];
+        float mu[VEC], iv[VEC], sc[VEC], sh[VEC];
+        const bool rmask = MODE == 1 && !y && scale;          // ReLU mask recomputed from z: y = z*scale + shift > 0
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
             iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
+            sc[e] = rmask ? scale[g * c + ch + e] : 0.f;
+            sh[e] = rmask ? shift[g * c + ch + e] : 0.f;
         }
         // fp32 partial sums over short runs (exact enough for 16-bit inputs), folded into fp64 every 16 pixels
         for (int64_t pb = p0 + pl; pb < p1; pb += (int64_t)PL * 16) {
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(256) void grouped_sums_lp(const unsigned short* __r
                     } else if (MODE == 1) {
                         float gr = gv[e];
                         if (y && !(yv[e] > 0.f)) gr = 0.f;
+                        if (rmask && !(fmaf(zv[e], sc[e], sh[e]) > 0.f)) gr = 0.f;
                         f0[e] += gr;
                         f1[e] = fmaf(gr, (zv[e] - mu[e]) * iv[e], f1[e]);
                     } else {
@@ -158,8 +164,9 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_lp(
     const unsigned short* __restrict__ dy, int dy_ld, const unsigned short* __restrict__ y, int y_ld,
     const unsigned short* __restrict__ z, int z_ld, const float* __restrict__ mean, const float* __restrict__ inv,
-    const float* __restrict__ gamma, const double* __restrict__ acc, const int* __restrict__ counts, int nb, int hw,
-    int c, int G, unsigned short* __restrict__ dz, int dz_ld) {
+    const float* __restrict__ gamma, const double* __restrict__ acc, const int* __restrict__ counts,
+    const float* __restrict__ scale, const float* __restrict__ shift, int accumulate, int nb, int hw, int c, int G,
+    unsigned short* __restrict__ dz, int dz_ld) {
     const int cg = c / VEC;
     const int64_t total = (int64_t)nb * hw * cg;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -172,12 +179,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_lp(
         load_v<T, VEC>(dy + pix * dy_ld + q * VEC, gr);
         if (y) load_v<T, VEC>(y + pix * y_ld + q * VEC, yv);
         load_v<T, VEC>(z + pix * z_ld + q * VEC, zv);
-        load_v<T, VEC>(dz + pix * dz_ld + q * VEC, dv);
+        if (accumulate) load_v<T, VEC>(dz + pix * dz_ld + q * VEC, dv);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dv[e] = 0.f;
         const float rm = 1.f / (float)counts[g];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float gg = gr[e];
             if (y && !(yv[e] > 0.f)) gg = 0.f;
+            if (!y && scale && !(fmaf(zv[e], scale[gi + e], shift[gi + e]) > 0.f)) gg = 0.f;
             const float iv = inv[gi + e];
             const float zh = (zv[e] - mean[gi + e]) * iv;
             const float s1 = (float)acc[(size_t)(gi + e) * 2], s2 = (float)acc[(size_t)(gi + e) * 2 + 1];
@@ -215,7 +226,9 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
                                                        const unsigned short* __restrict__ dy, int dy_ld,
                                                        const unsigned short* __restrict__ y, int y_ld,
                                                        const float* __restrict__ mean, const float* __restrict__ inv,
-                                                       int nb, int hw, int c, int G, double* __restrict__ acc) {
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int nb, int hw, int c, int G,
+                                                       double* __restrict__ acc) {
     constexpr int PL = 32, U = 4;
     const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int ch = blockIdx.x * 64 + cl * 8;
@@ -229,11 +242,14 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.0;
     if (ch < c && p0 + pl < p1) {
-        float mu[8], iv[8];
+        float mu[8], iv[8], sc[8], sh[8];
+        const bool rmask = MODE == 1 && !y && scale;          // ReLU mask recomputed from z: y = z*scale + shift > 0
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
             iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
+            sc[e] = rmask ? scale[g * c + ch + e] : 0.f;
+            sh[e] = rmask ? shift[g * c + ch + e] : 0.f;
         }
         GroupWalk w;
         w.init(p0 + pl, hw, G, g);
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
                 } else if (MODE == 1) {
                     float gr = gv[e];
                     if (y && !(yv[e] > 0.f)) gr = 0.f;
+                    if (rmask && !(fmaf(zv[e], sc[e], sh[e]) > 0.f)) gr = 0.f;
                     f0[e] += gr;
                     f1[e] = fmaf(gr, (zv[e] - mu[e]) * iv[e], f1[e]);
                 } else {
@@ -313,8 +330,10 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
                                                     const unsigned short* __restrict__ yact, int y_ld,
                                                     const float* __restrict__ p0f, const float* __restrict__ p1f,
                                                     const float* __restrict__ gamma, const double* __restrict__ acc,
-                                                    const int* __restrict__ counts, int nb, int hw, int c, int G,
-                                                    int relu, unsigned short* __restrict__ out, int out_ld) {
+                                                    const int* __restrict__ counts, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int accumulate, int nb, int hw,
+                                                    int c, int G, int relu, unsigned short* __restrict__ out,
+                                                    int out_ld) {
     constexpr int PL = 32, U = 4;
     const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int ch = blockIdx.x * 64 + cl * 8;
@@ -325,10 +344,13 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
     const int p0 = blockIdx.y * per;
     const int p1 = p0 + per < npix ? p0 + per : npix;
     if (ch >= c || p0 + pl >= p1) return;
-    float A[8], B[8], Cc[8];
+    float A[8], B[8], Cc[8], sc[8], sh[8];
+    const bool rmask = BWD && !yact && scale;                    // ReLU mask recomputed from z (x here)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int gi = g * c + ch + e;
+        sc[e] = rmask ? scale[gi] : 0.f;
+        sh[e] = rmask ? shift[gi] : 0.f;
         if constexpr (BWD) {                                     // p0f = mean, p1f = inv
             const float iv = p1f[gi], mu = p0f[gi];
             const float rm = 1.f / (float)counts[g];
@@ -350,12 +372,16 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
         if constexpr (BWD) {
             float gv[8], yv[8];
             unpack8<T>(gq, gv);
-            unpack8<T>(oq, o);
+            if (accumulate) unpack8<T>(oq, o);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
             if (yact) unpack8<T>(yq, yv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float gg = gv[e];
                 if (yact && !(yv[e] > 0.f)) gg = 0.f;
+                if (rmask && !(fmaf(xv[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
                 o[e] += fmaf(A[e], gg, fmaf(B[e], xv[e], Cc[e]));
             }
         } else {
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
             if constexpr (BWD) {
                 gq[u] = *reinterpret_cast<const u32x4*>(dy + w.pix * dy_ld + ch);
                 if (yact) yq[u] = *reinterpret_cast<const u32x4*>(yact + w.pix * y_ld + ch);
-                oq[u] = *reinterpret_cast<const u32x4*>(out + w.pix * out_ld + ch);
+                if (accumulate) oq[u] = *reinterpret_cast<const u32x4*>(out + w.pix * out_ld + ch);
             }
             w.advance(PL);
         }
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
         if constexpr (BWD) {
             gq = *reinterpret_cast<const u32x4*>(dy + w.pix * dy_ld + ch);
             if (yact) yq = *reinterpret_cast<const u32x4*>(yact + w.pix * y_ld + ch);
-            oq = *reinterpret_cast<const u32x4*>(out + w.pix * out_ld + ch);
+            if (accumulate) oq = *reinterpret_cast<const u32x4*>(out + w.pix * out_ld + ch);
         }
         one(w.pix, xq, gq, yq, oq);
         w.advance(PL);
@@ -764,14 +790,14 @@ inline bool vec8(const void* p, int ld) { return p == nullptr || (gv_aligned16(p
 
 template <typename T>
 int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy, int dy_ld, const unsigned short* y,
-           int y_ld, const float* mean, const float* inv, int nb, int hw, int c, int G, int splits, double* acc,
-           hipStream_t st) {
+           int y_ld, const float* mean, const float* inv, const float* scale, const float* shift, int nb, int hw, int c,
+           int G, int splits, double* acc, hipStream_t st) {
     const bool v = (c % 8 == 0) && vec8(z, z_ld) && vec8(dy, dy_ld) && vec8(y, y_ld);
     const dim3 grid((c + 63) / 64, splits, G);
     if (v && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll) {
 #define GV_SUMS8(MODE)                                                                                               \
-        hipLaunchKernelGGL((grouped_sums_v8<T, MODE>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, nb, \
-                           hw, c, G, acc)
+        hipLaunchKernelGGL((grouped_sums_v8<T, MODE>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, \
+                           shift, nb, hw, c, G, acc)
         if (mode == 0) GV_SUMS8(0);
         else if (mode == 1) GV_SUMS8(1);
         else GV_SUMS8(2);
@@ -783,10 +809,10 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
     do {                                                                                                             \
         if (v)                                                                                                       \
             hipLaunchKernelGGL((grouped_sums_lp<T, MODE, 8>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, \
-                               inv, nb, hw, c, G, acc);                                                              \
+                               inv, scale, shift, nb, hw, c, G, acc);                                                              \
         else                                                                                                         \
             hipLaunchKernelGGL((grouped_sums_lp<T, MODE, 1>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, \
-                               inv, nb, hw, c, G, acc);                                                              \
+                               inv, scale, shift, nb, hw, c, G, acc);                                                              \
     } while (0)
     if (mode == 0) GV_SUMS(0);
     else if (mode == 1) GV_SUMS(1);
@@ -863,10 +889,11 @@ int accumulate(int dtype, const void* src, int src_ld, void* dst, int dst_ld, in
 }
 
 int grouped_sums(int dtype, int mode, const void* z, int z_ld, const void* dy, int dy_ld, const void* y, int y_ld,
-                 const float* mean, const float* inv, int nb, int hw, int c, int G, int splits, double* acc,
-                 hipStream_t st) {
+                 const float* mean, const float* inv, const float* scale, const float* shift, int nb, int hw, int c,
+                 int G, int splits, double* acc, hipStream_t st) {
     GV_LP_DISPATCH(dtype, return sums_t<T>(mode, (const unsigned short*)z, z_ld, (const unsigned short*)dy, dy_ld,
-                                           (const unsigned short*)y, y_ld, mean, inv, nb, hw, c, G, splits, acc, st));
+                                           (const unsigned short*)y, y_ld, mean, inv, scale, shift, nb, hw, c, G, splits,
+                                           acc, st));
 }
 
 int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int x_ld, const float* scale,
@@ -878,8 +905,8 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
         if (v)
             hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
                                xs, x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, scale, shift,
-                               (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, nb, hw, c, G, relu, ys,
-                               y_ld);
+                               (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld);
         else
             hipLaunchKernelGGL((scale_shift_act_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st,
                                xs, nb, hw, c, x_ld, scale, shift, G, relu, ys, y_ld);
@@ -890,7 +917,8 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
 
 int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, const void* z, int z_ld,
                          const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
-                         int nb, int hw, int c, int G, void* dz, int dz_ld, hipStream_t st) {
+                         const float* scale, const float* shift, int accumulate, int nb, int hw, int c, int G, void* dz,
+                         int dz_ld, hipStream_t st) {
     const unsigned short* a = (const unsigned short*)dy;
     const unsigned short* b = (const unsigned short*)y;
     const unsigned short* zz = (const unsigned short*)z;
@@ -900,10 +928,12 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
     GV_LP_DISPATCH(dtype, {
         if (v)
             hipLaunchKernelGGL((bn_stream_v8<T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
-                               zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, 0, o, dz_ld);
+                               zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c,
+                               G, 0, o, dz_ld);
         else
             hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, a,
-                               dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, nb, hw, c, G, o, dz_ld);
+                               dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c, G,
+                               o, dz_ld);
         GV_LAUNCH_CHECK();
         return GV_OK;
     });

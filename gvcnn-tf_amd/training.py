@@ -125,6 +125,12 @@ class TrainGVCNN:
         self.dt = backbones.DTYPES[storage]
         self.tdt = backbones.TORCH_DTYPES[self.dt]
         self.es = 4 if self.dt == _lib.GV_F32 else 2
+        # 16-bit step: no up-front zero fill of the activation gradients.  The first contribution to a tensor's
+        # gradient in a backward pass STORES (data gradient without residual, BatchNorm backward with accumulate=0;
+        # ops that can only add get that one tensor zeroed first), later ones add; and the ReLU mask of a BatchNorm
+        # backward is recomputed from z instead of read from y.  Saves ~2 B/element of fills and 4 B/element of reads.
+        self._lazy = self.es == 2
+        self._written = set()
         # per_shape: the paper's grouping (model.GVCNN(per_shape=True)) in the training step
         self.per_shape = bool(per_shape)
         self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
@@ -233,6 +239,26 @@ class TrainGVCNN:
             return self.grad[t.vbuf].data_ptr() + self.es * t.off
         return self.act[t.vbuf].data_ptr() + self.es * t.off
 
+    def _claim(self, t):
+        """True for the FIRST gradient contribution to tensor t in this backward pass (lazy mode: it must store, or
+        zero t first); always False in the fp32 step, whose gradient buffers are zero-filled up front."""
+        if not self._lazy:
+            return False
+        key = (t.vbuf, t.off, t.c)
+        first = key not in self._written
+        self._written.add(key)
+        return first
+
+    def _has_grad(self, t):
+        """Has the gradient of t (or of a concat tensor that contains it) been produced in this backward pass?"""
+        if not self._lazy:
+            return self.grad[t.vbuf] is not None
+        return any(v == t.vbuf and o <= t.off and t.off + t.c <= o + c for v, o, c in self._written)
+
+    def _zero_grad_of(self, t):
+        self._ptr(t, grad=True)
+        self.view(t, grad=True).zero_()
+
     def view(self, t, grad=False):
         base = self.grad[t.vbuf] if grad else self.act[t.vbuf]
         return torch.as_strided(base, (t.nb, t.h, t.w, t.c), (t.h * t.w * t.ld, t.w * t.ld, t.ld, 1), t.off)
@@ -308,7 +334,7 @@ class TrainGVCNN:
                         best, best_ms = t, e0.elapsed_time(e1)
                 op["tile_w"] = best
 
-    def repack(self):
+    def repack(self, sync=True):
         """Refresh the packed filters from the trainable HWIO variables (after an optimizer step)."""
         lib = self.lib
         keep = []
@@ -324,7 +350,8 @@ class TrainGVCNN:
                 keep.append(wt)
                 _lib.check(lib.gv_pack_filter_hwio(wt.data_ptr(), kh, kw, cout, cin, op["w_dgrad"].data_ptr(),
                                                    self.dt, self.math_mode, _st()), "gv_pack_filter_hwio")
-        torch.cuda.synchronize(self.device)
+        if sync:                                          # (the flipped copies in `keep` die with this frame)
+            torch.cuda.synchronize(self.device)
         self._packed_dirty = False
 
     # -- forward (train mode) ----------------------------------------------------------------------------
@@ -464,9 +491,13 @@ class TrainGVCNN:
         lib, V = self.lib, self.Vh
         for g in self.grads.values():
             g.zero_()
-        for g in self.grad:
-            if g is not None:
-                g.zero_()
+        self._written = set()
+        if not self._lazy:
+            for g in self.grad:
+                if g is not None:
+                    g.zero_()
+        elif dF is None and self._claim(self.final):
+            self._zero_grad_of(self.final)                    # the head adds into the final tap's gradient
         f = self.final
         E = f.h * f.w * f.c
         kn, bn = self.cls_names
@@ -487,13 +518,14 @@ class TrainGVCNN:
         """[N, V, h, w, C] view of the gradient buffer of the final tap (allocated on first use)."""
         f = self.final
         self._ptr(f, grad=True)
+        self._claim(f)                                        # (the caller writes all of it)
         return self.view(f, grad=True).view(self.N, self.V, f.h, f.w, f.c)
 
     def backward_backbone(self):
         """Backbone backward from the gradient held in the final tap's gradient buffer."""
         for op in reversed(self.plan.ops):
             y = op["y"]
-            if y.vbuf < 0 or self.grad[y.vbuf] is None:
+            if y.vbuf < 0 or not self._has_grad(y):
                 continue                                  # nothing downstream of the final tap reaches it
             self._backward_op(op)
         return self.grads
@@ -509,10 +541,13 @@ class TrainGVCNN:
             gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
             dbeta = self.grads[op["name"] + "/beta"].data_ptr()
             dgamma = self.grads[op["name"] + "/gamma"].data_ptr() if gamma is not None else None
-            yptr = self._ptr(y) if op["relu"] else None
+            yptr = self._ptr(y) if op["relu"] and not self._lazy else None
+            sc = st["scale"].data_ptr() if op["relu"] and self._lazy else None      # mask from z*scale + shift > 0
+            sh = st["shift"].data_ptr() if op["relu"] and self._lazy else None
+            acc = 0 if self._claim(x) else 1
             _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self.dt, _st()),
+                st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), sc, sh, self.dt, _st()),
                 "bn_bwd sums " + op["name"])
             if self.bn_sync is not None:
                 self.bn_sync(self.accum[:2 * V * x.c])
@@ -520,7 +555,7 @@ class TrainGVCNN:
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
                 st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
                 self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
-                dbeta, dgamma, self.dt, _st()), "bn_bwd apply " + op["name"])
+                dbeta, dgamma, sc, sh, acc if self._lazy else 1, self.dt, _st()), "bn_bwd apply " + op["name"])
         elif op["kind"] == "conv":
             dz = self._ptr(y, True)
             if op["bias"]:
@@ -528,6 +563,8 @@ class TrainGVCNN:
                                               self.grads[op["bias"]].data_ptr(), self.dt, _st()), "bias_grad")
             if op["res"] is not None:
                 r = op["res"]
+                if self._claim(r):
+                    self._zero_grad_of(r)
                 _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
                            "res grad")
             d = self._conv_desc(op, wgrad=True)
@@ -537,12 +574,17 @@ class TrainGVCNN:
             if x.vbuf >= 0:
                 dd = self._conv_desc(op, dgrad=True)
                 dx = self._ptr(x, True)
+                store = self._claim(x)                        # first contribution: no residual read, plain store
+                if store:
+                    dd.res_ld = 0
                 _lib.check(lib.gv_conv2d_fwd(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
-                                             self.zeros.data_ptr(), dx, dx, None, None, None, _st()),
-                           "dgrad " + op["name"])
+                                             self.zeros.data_ptr(), None if store else dx, dx, None, None, None,
+                                             _st()), "dgrad " + op["name"])
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
+            if self._claim(x):
+                self._zero_grad_of(x)
             _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
                                          x.ld, _st()), "pool_bwd " + op["name"])
 

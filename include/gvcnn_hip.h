@@ -341,14 +341,20 @@ int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32
 int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld, const float* scale,
                                  const float* shift, int32_t num_groups, int32_t relu, void* y, int32_t y_ld,
                                  int32_t dtype, void* stream);
+/* Backward of y = relu(BN_train(z)).  The ReLU mask [y > 0] is read from y, or — y == NULL with scale/shift given (the
+ * folded forward coefficients of gv_bn_finalize_grouped) — recomputed as [z*scale + shift > 0], which is the same
+ * mask (the forward pass rounded that very value) without reading y at all; y == NULL and scale == NULL: no ReLU.
+ * accumulate = 0 stores dz instead of adding to it (z has one consumer: no zero-fill, no read of dz). */
 int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld, const void* z,
                                   int32_t z_ld, const float* mean, const float* inv, int32_t nb, int32_t hw,
-                                  int32_t c, int32_t num_groups, double* accum, int32_t dtype, void* stream);
+                                  int32_t c, int32_t num_groups, double* accum, const float* scale,
+                                  const float* shift, int32_t dtype, void* stream);
 int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld, const void* z,
                                    int32_t z_ld, const float* mean, const float* inv, const float* gamma,
                                    const int32_t* counts, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
                                    const double* accum, void* dz, int32_t dz_ld, float* dbeta, float* dgamma,
-                                   int32_t dtype, void* stream);
+                                   const float* scale, const float* shift, int32_t accumulate, int32_t dtype,
+                                   void* stream);
 int gv_accumulate_t(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int64_t npix, int32_t c,
                     int32_t dtype, void* stream);
 int gv_bias_grad_t(const void* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum, float* dbias,

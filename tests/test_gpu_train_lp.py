@@ -90,18 +90,34 @@ def test_bn_train_forward_and_backward_typed(dt, tdt, eps, c, ld):
         dgamma = torch.zeros(c, device=DEV)
         _lib.check(lib().gv_bn_relu_bwd_sums_grouped_t(dyd.data_ptr(), ld, yd.data_ptr(), ld, zd.data_ptr(), ld,
                                                        stt["mean"].data_ptr(), stt["inv"].data_ptr(), N * V, h * w, c,
-                                                       V, accum.data_ptr(), dt, st()), "bwd sums")
+                                                       V, accum.data_ptr(), None, None, dt, st()), "bwd sums")
         _lib.check(lib().gv_bn_relu_bwd_apply_grouped_t(dyd.data_ptr(), ld, yd.data_ptr(), ld, zd.data_ptr(), ld,
                                                         stt["mean"].data_ptr(), stt["inv"].data_ptr(),
                                                         gd.data_ptr() if gd is not None else None, counts.data_ptr(),
                                                         N * V, h * w, c, V, accum.data_ptr(), dz.data_ptr(), ld,
                                                         dbeta.data_ptr(),
-                                                        dgamma.data_ptr() if gd is not None else None, dt, st()),
+                                                        dgamma.data_ptr() if gd is not None else None, None, None, 1,
+                                                        dt, st()),
                    "bwd apply")
         close(dz[..., :c].float().cpu() - 0.125, zz.grad, 2 * eps)
         close(dbeta.cpu(), be.grad, 1e-5)
         if gm is not None:
             close(dgamma.cpu(), ga.grad, 1e-4)
+        # the engine's form: ReLU mask recomputed from z*scale + shift (y is not read), dz STORED over garbage
+        dz2 = dev(q(torch.full_like(z, 77.0), tdt))
+        accum2 = torch.zeros_like(accum)
+        _lib.check(lib().gv_bn_relu_bwd_sums_grouped_t(dyd.data_ptr(), ld, None, 0, zd.data_ptr(), ld,
+                                                       stt["mean"].data_ptr(), stt["inv"].data_ptr(), N * V, h * w, c,
+                                                       V, accum2.data_ptr(), stt["scale"].data_ptr(),
+                                                       stt["shift"].data_ptr(), dt, st()), "bwd sums")
+        assert torch.equal(accum2, accum)
+        _lib.check(lib().gv_bn_relu_bwd_apply_grouped_t(dyd.data_ptr(), ld, None, 0, zd.data_ptr(), ld,
+                                                        stt["mean"].data_ptr(), stt["inv"].data_ptr(),
+                                                        gd.data_ptr() if gd is not None else None, counts.data_ptr(),
+                                                        N * V, h * w, c, V, accum2.data_ptr(), dz2.data_ptr(), ld, None,
+                                                        None, stt["scale"].data_ptr(), stt["shift"].data_ptr(), 0, dt,
+                                                        st()), "bwd apply")
+        close(dz2[..., :c].float().cpu(), zz.grad, 2 * eps)
 
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
@@ -307,7 +323,7 @@ def test_bf16_engine_op_by_op_against_the_fp32_engine(backbone, size, N, V):
     ref_grad = [g.to(torch.bfloat16).float() if g is not None else None for g in e32.grad]
     x32 = e32._x.to(torch.bfloat16).float()
     e32._x = x32                                         # the network input too
-    worst = {}
+    worst, y_forced = {}, {}
 
     def note(kind, what, err, name):
         key = (kind, what)
@@ -324,6 +340,7 @@ def test_bf16_engine_op_by_op_against_the_fp32_engine(backbone, size, N, V):
         e32._forward_op(o32)
         e16._forward_op(o16)
         note(o16["kind"], "y", _rel(e16.view(o16["y"]).float(), e32.view(o32["y"])), o16["name"])
+        y_forced[id(o32)] = e32.view(o32["y"]).to(torch.bfloat16)    # (the output that belongs to the forced input)
     for o32, o16 in zip(reversed(e32.plan.ops), reversed(e16.plan.ops)):
         xt, yt, rt = o32["x"], o32["y"], o32.get("res")
         if yt.vbuf < 0 or ref_grad[yt.vbuf] is None:
@@ -338,6 +355,9 @@ def test_bf16_engine_op_by_op_against_the_fp32_engine(backbone, size, N, V):
                 e.grads[k].zero_()
         for t in (xt, yt, rt):
             force_act(t)
+        if o32["kind"] == "bn":                              # its ReLU mask: the forced forward's own output
+            e32.view(yt).copy_(y_forced[id(o32)])
+            e16.view(yt).copy_(y_forced[id(o32)])
         assert xt.vbuf != yt.vbuf
         e32._backward_op(o32)
         e16._backward_op(o16)
@@ -404,6 +424,46 @@ def test_bf16_training_step_tracks_the_fp32_step(backbone, size, N, V):
     e16.apply_momentum(lr=1e-4, mu=0.9, weight_decay=1e-4)
     _, _, _, loss1 = e16.forward(x, labels, g_scheme=scheme, g_weight=weight)
     assert float(loss1) < l0
+
+
+@pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 171, 4, 2), ("resnet_v2_50", 97, 3, 2)])
+def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V):
+    """The 16-bit backward pass keeps no zero-filled gradient buffers: the first contribution to a tensor's gradient
+    stores, later ones add, and the ReLU mask is recomputed from z.  Against the plain form (zero-fill everything,
+    always accumulate, mask read from y) on the same forward pass the gradients must be IDENTICAL: same addends,
+    same order, same masks."""
+    eng = TrainGVCNN(backbone, N, V, size, size, 5, 10, device=DEV, storage="bf16")
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
+    labels = torch.tensor([1, 4, 2, 0][:N])
+    eng.forward(x, labels, check=False)
+    assert eng._lazy
+
+    def run():
+        grads = {k: v.clone() for k, v in eng.backward().items()}
+        acts = {}
+        for op in eng.plan.ops:
+            t = op["x"]
+            if t.vbuf >= 0 and (t.vbuf, t.off, t.c) in written:
+                acts[(t.vbuf, t.off, t.c)] = eng.view(t, grad=True).clone()
+        return grads, acts
+    eng.backward()
+    written = set(eng._written)
+    assert len(written) > 50
+    lazy = run()
+    for g in eng.grad:                                   # poison: nothing may depend on what the buffers held
+        if g is not None:
+            g.fill_(float("nan"))
+    lazy2 = run()
+    eng._lazy = False
+    plain = run()
+    torch.cuda.synchronize()
+    for k in plain[1]:                                   # activation gradients: bit for bit
+        assert bool(torch.isfinite(lazy2[1][k].float()).all()), k
+        assert torch.equal(lazy[1][k], lazy2[1][k]), k
+        assert torch.equal(lazy[1][k], plain[1][k]), k
+    big = max(float(v.abs().max()) for v in plain[0].values())
+    for k in plain[0]:                                   # variables: fp32 atomics in the filter gradient, order varies
+        assert float((lazy2[0][k] - plain[0][k]).abs().max()) <= 1e-4 * max(float(plain[0][k].abs().max()), 1e-6 * big), k
 
 
 def test_bf16_training_autotune_and_per_shape_step_runs():

@@ -15,9 +15,10 @@ from gvcnn_tf_amd.training import TrainGVCNN  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", type=int, default=32)
 ap.add_argument("--backbone", default="inception_v3")
+ap.add_argument("--storage", default="f32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-eng = TrainGVCNN(a.backbone, a.shapes, 12, 224, 224, 40, 7, device=dev, num_bins=7)
+eng = TrainGVCNN(a.backbone, a.shapes, 12, 224, 224, 40, 7, device=dev, num_bins=7, storage=a.storage)
 lib = _lib.load()
 x = (torch.rand(a.shapes, 12, 224, 224, 3, device=dev) - 0.5)
 eng.forward(x, torch.zeros(a.shapes, dtype=torch.int64), check=False)

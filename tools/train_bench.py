@@ -13,10 +13,11 @@ ap.add_argument("--views", type=int, default=12)
 ap.add_argument("--size", type=int, default=224)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f16"])
+ap.add_argument("--graph", action="store_true", help="replay the whole step from one captured graph")
 a = ap.parse_args()
 eng = TrainGVCNN(a.backbone, a.shapes, a.views, a.size, a.size, 40, 10, device="cuda:0", storage=a.storage)
 x = (torch.rand(a.shapes, a.views, a.size, a.size, 3) - 0.5).cuda()
-labels = torch.randint(0, 40, (a.shapes,))
+labels = torch.randint(0, 40, (a.shapes,)).cuda()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 ap_tune = os.environ.get("GV_NO_TUNE") is None
 eng.train_step(x, labels, lr=1e-6)
@@ -29,6 +30,23 @@ for _ in range(a.steps):
     ev[0].record(); eng.forward(x, labels, check=False); ev[1].record(); eng.backward(); ev[2].record()
     eng.apply_momentum(1e-6); eng.repack(); ev[3].record(); torch.cuda.synchronize()
     tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2]); to += ev[2].elapsed_time(ev[3])
+if a.graph:
+    # the whole step (forward, loss, backward, moving averages, Momentum, filter re-pack) as ONE graph launch
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        eng.train_step(x, labels, lr=1e-6); eng.repack()
+    torch.cuda.current_stream().wait_stream(s_)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        eng.forward(x, labels, check=False); eng.backward(); eng.update_moving_averages(); eng.apply_momentum(1e-6); eng.repack(sync=False)
+    gr.replay(); torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(a.steps):
+        gr.replay()
+    ev[1].record(); torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / a.steps
+    print("[%s] graph replay: %.2f ms/step => %.1f views/s (loss %.4f)" % (a.storage, ms, a.shapes * a.views / (ms * 1e-3), float(eng.loss)))
 n = a.steps
 flops = sum(op.get("flops", 0) for op in eng.plan.ops)
 print("[%s] " % a.storage + "%s %dx%d views %d^2: forward %.2f ms, backward %.2f ms, update+repack %.2f ms => %.1f views/s; fwd %.1f TF/s, bwd(2x flops) %.1f TF/s"
