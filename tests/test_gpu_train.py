@@ -283,23 +283,36 @@ def test_gradient_is_the_directional_derivative_of_the_loss(backbone, size):
     assert abs(deriv - gnorm) <= 2e-2 * gnorm, (d1, d2, deriv, gnorm)
 
 
-def test_view_sharded_engines_reproduce_the_whole_step():
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_view_sharded_engines_reproduce_the_whole_step(storage):
     """sharding.ShardedTrainGVCNN's algorithm on ONE device: two engines own views {0,1} and {2,3} (per-view
     BatchNorm statistics stay inside an engine), the gather along the view axis is a torch.cat, every
     engine runs the head on the gathered data, takes its slice of dF, and the backbone gradients of the
-    two engines are added — equal to the unsharded engine's step."""
+    two engines are added — equal to the unsharded engine's step.  bf16 storage: with one fixed tile configuration
+    (the heuristic's choice depends on the number of images, and a different summation order inside a tile moves
+    bf16 roundings, which the train-mode network then amplifies) every per-view tensor is bit-identical in the
+    sharded and the unsharded run, so the same tolerance holds."""
+    if storage != "f32":
+        lib().gv_conv2d_set_tile_override(0)
+    try:
+        _view_sharded_step(storage)
+    finally:
+        lib().gv_conv2d_set_tile_override(-1)
+
+
+def _view_sharded_step(storage):
     backbone, size, N, V, C_, G = "resnet_v2_50", 97, 3, 4, 5, 10
     full = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
     P = gv.params.init_backbone_params(full.plan.param_shapes(), seed=5, perturb_bn=True)
     Hd = gv.params.init_head_params(V, full.raw.c, full.final.c, C_, seed=6, spread_scores=True)
-    full = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage=storage)
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(DEV)
     labels = torch.tensor([0, 3, 1])
     full.forward(x, labels)
     ref = {k: v.clone() for k, v in full.backward().items()}
     Vl = V // 2
     engs = [TrainGVCNN(backbone, N, Vl, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV,
-                       head_views=V, view_offset=r * Vl) for r in range(2)]
+                       head_views=V, view_offset=r * Vl, storage=storage) for r in range(2)]
     f = engs[0].final
     for r, e in enumerate(engs):
         e.forward_backbone(x[:, r * Vl:(r + 1) * Vl].contiguous())
