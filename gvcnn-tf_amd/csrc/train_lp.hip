@@ -786,6 +786,173 @@ __global__ __launch_bounds__(256) void conv_wgrad_lp(const unsigned short* __res
     }
 }
 
+// ---- filter gradient, strip form (stride-1 filters with more than one tap) ----------------------------------------
+// The tap-per-workgroup kernel above re-reads dZ and X once per filter tap and is bound by L2->LDS traffic at
+// 32-64 flop/byte.  Here a workgroup owns a tile (ci x co) for a GROUP OF TAPS (up to 9) and walks over "strips":
+// up to 32 output pixels = R consecutive rows x L columns of one image.  Per strip it loads dZ ONCE ([32 slots][co])
+// and the input patch with its halo ONCE ([(R+kh-1) x (L+kw-1) pixels][ci]); tap (r,s) of output slot (rho, ox) is
+// LDS row (rho+r)*(L+kw-1) + ox+s, and because every lane of ds_read_b64_tr_b16 supplies its own row address the
+// k-slot -> LDS-row map is free: the same patch serves every tap at a wave-uniform byte offset.  Accumulators: one
+// 32x32 tile per (wave, tap).  Waves = WI x WJ x WT: WI x WJ sub-tiles of 32 channels, WT-way split of the taps
+// (few-channel stem layers have only one 32x32 tile per tap).  One LDS buffer; the next strip's global loads are in
+// flight (registers) while this strip's MFMAs run.
+struct StripGeom {
+    int nb, ih, iw, cin, kh, kw, pad_t, pad_l, oh, ow, cout;
+    int R, L, Wx, Hx;             // strip rows/cols, patch width/height
+    int nrs, ncs;                 // strips per image along y / x
+    int tap0, ntaps;              // tap group of this launch slice: taps tap0 .. tap0+ntaps-1 (set per blockIdx.z)
+    int stages, stages_per_block;
+    int xrows;                    // Hx*Wx
+    int x_ld, dz_ld;
+};
+
+template <typename T, int WI, int WJ, int WT, int NTW>
+__global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ dz, StripGeom gm,
+                                                           int taps_per_group, float* __restrict__ dw) {
+    static_assert(WI * WJ * WT == 4, "four waves");
+    constexpr int BI = 32 * WI, BO = 32 * WJ;
+    constexpr int SX = 2 * BI + 64, SZ = 2 * BO + 64;
+    constexpr int XC = BI / 8, ZC = BO / 8;                      // 16-byte chunks per LDS row
+    constexpr int XVMAX = 6, ZV = (32 * ZC + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* sZ = lds;
+    unsigned char* sX = lds + 32 * SZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave % WT, wj = (wave / WT) % WJ, wi = wave / (WT * WJ);
+    const int ntile_co = (gm.cout + BO - 1) / BO, ntile_ci = (gm.cin + BI - 1) / BI;
+    int b = blockIdx.x;
+    const int tco = b % ntile_co; b /= ntile_co;
+    const int tci = b % ntile_ci; b /= ntile_ci;
+    const int tap0 = b * taps_per_group;
+    const int ntaps = min(taps_per_group, gm.kh * gm.kw - tap0);
+    const int ci0 = tci * BI, co0 = tco * BO;
+    const int s0 = blockIdx.y * gm.stages_per_block;
+    const int s1 = min(s0 + gm.stages_per_block, gm.stages);
+    if (s0 >= s1) return;
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // loader roles (strip-invariant): X chunk j of this thread -> patch pixel (py, px) and channel chunk
+    const int xchunks = gm.xrows * XC;
+    int xpy[XVMAX], xpx[XVMAX], xoff[XVMAX], xch[XVMAX];
+#pragma unroll
+    for (int j = 0; j < XVMAX; ++j) {
+        const int idx = tid + j * 256;
+        const int row = idx / XC;
+        xch[j] = ci0 + (idx % XC) * 8;
+        xpy[j] = row / gm.Wx;
+        xpx[j] = row - xpy[j] * gm.Wx;
+        xoff[j] = idx < xchunks ? row * SX + (idx % XC) * 16 : -1;
+    }
+    int zr[ZV], zc[ZV], zch[ZV], zoff[ZV];
+#pragma unroll
+    for (int j = 0; j < ZV; ++j) {
+        const int idx = tid + j * 256;
+        const int p = idx / ZC;                                  // k slot
+        zr[j] = p / gm.L;
+        zc[j] = p - zr[j] * gm.L;
+        zch[j] = co0 + (idx % ZC) * 8;
+        zoff[j] = idx < 32 * ZC ? p * SZ + (idx % ZC) * 16 : -1;
+        if (zr[j] >= gm.R) zr[j] = -1;                           // padding slot: always zero
+    }
+    u32x4 xq[XVMAX], zq[ZV];
+    auto load = [&](int stage) {
+        const int cs = stage % gm.ncs;
+        const int t = stage / gm.ncs;
+        const int rs = t % gm.nrs;
+        const int n = t / gm.nrs;
+        const int oy0 = rs * gm.R, ox0 = cs * gm.L;
+        const int lv = min(gm.L, gm.ow - ox0);                   // valid columns of this strip
+#pragma unroll
+        for (int j = 0; j < XVMAX; ++j) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (xoff[j] >= 0) {
+                const int iy = oy0 - gm.pad_t + xpy[j], ix = ox0 - gm.pad_l + xpx[j];
+                if ((unsigned)iy < (unsigned)gm.ih && (unsigned)ix < (unsigned)gm.iw && xch[j] < gm.cin)
+                    v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * gm.ih + iy) * gm.iw + ix) * gm.x_ld + xch[j]);
+            }
+            xq[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < ZV; ++j) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (zoff[j] >= 0 && zr[j] >= 0) {
+                const int oy = oy0 + zr[j];
+                if (oy < gm.oh && zc[j] < lv && zch[j] < gm.cout)
+                    v = *reinterpret_cast<const u32x4*>(dz + (((size_t)n * gm.oh + oy) * gm.ow + ox0 + zc[j]) * gm.dz_ld + zch[j]);
+            }
+            zq[j] = v;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < XVMAX; ++j)
+            if (xoff[j] >= 0) *reinterpret_cast<u32x4*>(sX + xoff[j]) = xq[j];
+#pragma unroll
+        for (int j = 0; j < ZV; ++j)
+            if (zoff[j] >= 0) *reinterpret_cast<u32x4*>(sZ + zoff[j]) = zq[j];
+    };
+    // transposed-read addresses: k slot p = 16*ks + 8*(lane/32) + 4*j + q  ->  dZ row p, X row (p/L)*Wx + p%L (+ tap)
+    const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int col_l = 16 * (g16 & 1) + 4 * p4;
+    int xb[2][2], zb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = 16 * ks + 8 * (g16 >> 1) + 4 * j + q;
+            int rr = p / gm.L, cc = p - rr * gm.L;
+            if (rr >= gm.R) { rr = 0; cc = 0; }                  // padding slot: dZ is zero there, any row will do
+            xb[ks][j] = (rr * gm.Wx + cc) * SX + 2 * (wi * 32 + col_l);
+            zb[ks][j] = p * SZ + 2 * (wj * 32 + col_l);
+        }
+    int tapoff[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int tap = tap0 + wt + WT * i;
+        const int fr = tap / gm.kw, fs = tap - fr * gm.kw;
+        tapoff[i] = (fr * gm.Wx + fs) * SX;
+    }
+    load(s0);
+    for (int stage = s0; stage < s1; ++stage) {
+        store();
+        __syncthreads();
+        if (stage + 1 < s1) load(stage + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const s16x4 blo = lds_read_tr(sZ + zb[ks][0]), bhi = lds_read_tr(sZ + zb[ks][1]);
+            const s16x8 bv = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                if (wt + WT * i < ntaps) {                       // wave-uniform
+                    const s16x4 alo = lds_read_tr(sX + xb[ks][0] + tapoff[i]);
+                    const s16x4 ahi = lds_read_tr(sX + xb[ks][1] + tapoff[i]);
+                    const s16x8 av = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[i] = mfma16<T>(av, bv, acc[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int li = lane & 31, lh = lane >> 5;
+    const int col = co0 + wj * 32 + li;
+    if (col < gm.cout) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            if (wt + WT * i >= ntaps) continue;
+            const int tap = tap0 + wt + WT * i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ci < gm.cin) atomicAdd(&dw[((size_t)tap * gm.cin + ci) * gm.cout + col], acc[i][r]);
+            }
+        }
+    }
+}
+
 inline bool vec8(const void* p, int ld) { return p == nullptr || (gv_aligned16(p) && (ld % 8) == 0); }
 
 template <typename T>
@@ -825,6 +992,72 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
 // Launch geometry: d->tile_cfg = 0 picks by divisibility (128 channels on a side only where that wastes no more rows
 // than 64-wide tiles would) and ~2048 workgroups; tile_cfg = 1 + tile + 4*split selects tile (TI,TO) in {(1,1),(2,1),
 // (1,2),(2,2)} and a target of 1024 / 2048 / 4096 workgroups (TrainGVCNN.autotune measures them per layer).
+// strip form: geometry and eligibility
+inline bool strip_geom(const gv_conv_desc* d, int dz_ld, int bi, StripGeom* gm) {
+    if (d->stride != 1 || d->kh * d->kw < 2) return false;
+    StripGeom& g = *gm;
+    g.nb = d->nb; g.ih = d->ih; g.iw = d->iw; g.cin = d->cin; g.kh = d->kh; g.kw = d->kw;
+    g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.oh = d->oh; g.ow = d->ow; g.cout = d->cout;
+    g.x_ld = d->x_ld; g.dz_ld = dz_ld;
+    if (d->ow >= 32) {
+        g.ncs = (d->ow + 31) / 32;
+        g.L = (d->ow + g.ncs - 1) / g.ncs;
+        g.R = 1;
+    } else {
+        g.ncs = 1;
+        g.L = d->ow;
+        g.R = 32 / d->ow;
+        if (g.R > d->oh) g.R = d->oh;
+    }
+    g.nrs = (d->oh + g.R - 1) / g.R;
+    g.Wx = g.L + d->kw - 1;
+    g.Hx = g.R + d->kh - 1;
+    g.xrows = g.Hx * g.Wx;
+    const int64_t stages = (int64_t)d->nb * g.nrs * g.ncs;
+    if (stages > 0x7fffffff) return false;
+    g.stages = (int)stages;
+    if (g.xrows * (bi / 8) > 6 * 256) return false;              // XVMAX chunks per thread
+    if ((int64_t)g.xrows * (2 * bi + 64) + 32 * (2 * 128 + 64) > 64 * 1024) return false;
+    return true;
+}
+
+template <typename T, int WI, int WJ, int WT, int NTW>
+int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+                 int target_wgs, hipStream_t st) {
+    constexpr int BI = 32 * WI, BO = 32 * WJ;
+    StripGeom gm;
+    if (!strip_geom(d, dz_ld, BI, &gm)) return GV_E_UNSUPPORTED;
+    const int taps = d->kh * d->kw, tpg = NTW * WT;              // taps per workgroup
+    const int groups = (taps + tpg - 1) / tpg;
+    const int tiles = ((d->cin + BI - 1) / BI) * ((d->cout + BO - 1) / BO) * groups;
+    int64_t splits = (target_wgs + tiles - 1) / tiles;
+    const int64_t max_splits = (gm.stages + 7) / 8;              // at least 8 strips per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    gm.stages_per_block = (int)((gm.stages + splits - 1) / splits);
+    splits = (gm.stages + gm.stages_per_block - 1) / gm.stages_per_block;
+    const size_t lds = (size_t)32 * (2 * BO + 64) + (size_t)gm.xrows * (2 * BI + 64);
+    auto kern = conv_wgrad_strip_lp<T, WI, WJ, WT, NTW>;
+    static bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           64 * 1024) == hipSuccess;
+    (void)attr;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, x, dz, gm, tpg, dw);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
+int strip_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+            int target_wgs, hipStream_t st) {
+    if (d->cin <= 32 && d->cout <= 32) return strip_launch<T, 1, 1, 4, 3>(d, x, dz, dz_ld, dw, target_wgs, st);
+    if (d->cin <= 32) return strip_launch<T, 1, 2, 2, 5>(d, x, dz, dz_ld, dw, target_wgs, st);
+    if (d->cout <= 32) return strip_launch<T, 2, 1, 2, 5>(d, x, dz, dz_ld, dw, target_wgs, st);
+    return strip_launch<T, 2, 2, 1, 9>(d, x, dz, dz_ld, dw, target_wgs, st);
+}
+
+int g_strip_default = 1;
+
 template <typename T>
 int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
             hipStream_t st) {
@@ -832,6 +1065,16 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
     int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
     int64_t target = 2048;
+    if (d->tile_cfg > 12) {                                      // 13..15: strip form, 1024 / 2048 / 4096 workgroups
+        if (d->tile_cfg > 15) return GV_E_BADARG;
+        return strip_t<T>(d, x, dz, dz_ld, dw, 1024 << (d->tile_cfg - 13), st);
+    }
+    // heuristic: the strip form for the few-channel stem layers (2.5-3.5x there); its general 64x64x9-tap variant
+    // runs at one wave per SIMD and loses to the tap-per-workgroup tiles — autotune may still pick it (cfg 13-15)
+    if (d->tile_cfg == 0 && g_strip_default && d->cin <= 32) {
+        const int rc = strip_t<T>(d, x, dz, dz_ld, dw, 2048, st);
+        if (rc != GV_E_UNSUPPORTED) return rc;
+    }
     if (d->tile_cfg > 0) {
         const int k = d->tile_cfg - 1;
         if (k >= 12) return GV_E_BADARG;

@@ -175,7 +175,9 @@ CONVS = [((3, 3), 1, "SAME", 32, 48, 3, 12, 11), ((3, 3), 2, "VALID", 32, 64, 3,
          ((3, 3), 2, "VALID", 3, 32, 3, 12, 11),                 # stem: fp32-MFMA kernel with typed loads
          ((3, 3), 1, "SAME", 288, 384, 2, 9, 9), ((1, 1), 1, "SAME", 768, 192, 4, 12, 12),
          ((7, 1), 1, "SAME", 128, 192, 5, 12, 12), ((3, 3), 1, "SAME", 200, 136, 2, 7, 7),
-         ((3, 3), 1, "VALID", 32, 64, 18, 111, 111)]             # few-channel layer at full size: the direct kernel
+         ((3, 3), 1, "VALID", 32, 64, 18, 111, 111),             # few-channel stem layers at full width (strips of 28)
+         ((3, 3), 1, "VALID", 32, 32, 3, 40, 37), ((1, 3), 1, "SAME", 384, 384, 7, 5, 5),
+         ((3, 1), 1, "SAME", 96, 32, 4, 17, 17), ((3, 3), 1, "SAME", 64, 96, 3, 35, 35)]
 
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
@@ -243,13 +245,14 @@ def test_wgrad_mfma_kernel_equals_the_fp32_mfma_kernel_on_typed_loads(dt, tdt, e
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
 def test_wgrad_every_launch_configuration(dt, tdt, eps):
-    """gv_conv_desc.tile_cfg of the 16-bit filter gradient (tile shape x pixel split, a speed choice): same result."""
+    """gv_conv_desc.tile_cfg of the 16-bit filter gradient (tap-per-workgroup tiles x pixel split, strip form x
+    workgroup count; a speed choice): same result."""
     g = torch.Generator().manual_seed(12)
     nb, ih, iw, cin, cout = 5, 13, 12, 96, 160
     x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
     dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
     n = lib().gv_conv2d_wgrad_num_cfgs(dt)
-    assert n == 12 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0
+    assert n == 15 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0
     outs = []
     for cfg in range(n + 1):
         dw = torch.zeros(3, 3, cin, cout, device=DEV)
