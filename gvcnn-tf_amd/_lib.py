@@ -32,6 +32,11 @@ class ConvDesc(C.Structure):
         "math_mode", "in_dilation", "relu_cols")]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32)]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "c", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
@@ -93,6 +98,7 @@ SIGNATURES = {
     "gv_accumulate_t": (C.c_int, [_P, _I, _P, _I, _L, _I, _I, _P]),
     "gv_bias_grad_t": (C.c_int, [_P, _I, _L, _I, _P, _P, _I, _P]),
     "gv_view_pool_fuse_bwd_t": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _I, _I, _P]),
+    "gv_pack_filters_batched": (C.c_int, [_P, _I, _P, _I, _I, _P]),
     "gv_plan_create": (C.c_int, [C.POINTER(_P)]),
     "gv_plan_destroy": (None, [_P]),
     "gv_plan_num_ops": (C.c_int, [_P]),

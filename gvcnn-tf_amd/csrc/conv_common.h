@@ -97,5 +97,6 @@ bool lp_stem_ok(const ConvArgs& a, bool xf32);
 int lp_launch(int dtype, int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st);
 int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int dtype, void* out, hipStream_t st);
 int64_t lp_packed_bytes(int kh, int kw, int cin, int cout);
+int lp_pack_filters_batched(const gv_pack_job* jobs_dev, const int* block_job_dev, int nblocks, int dtype, hipStream_t st);
 
 }  // namespace gvconv

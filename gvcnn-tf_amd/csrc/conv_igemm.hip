@@ -409,6 +409,13 @@ extern "C" int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, 
     return GV_OK;
 }
 
+extern "C" int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
+                                       int32_t num_blocks, int32_t dtype, void* stream) {
+    if (!jobs_dev || !block_job_dev || num_jobs <= 0 || num_blocks <= 0) return GV_E_BADARG;
+    if (dtype != GV_BF16 && dtype != GV_F16) return GV_E_UNSUPPORTED;
+    return gvconv::lp_pack_filters_batched(jobs_dev, block_job_dev, num_blocks, dtype, (hipStream_t)stream);
+}
+
 extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
                              const float* scale, const float* shift, const void* residual,
                              void* y, void* y2, const float* scale2, const float* shift2,

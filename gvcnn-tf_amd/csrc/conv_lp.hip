@@ -770,6 +770,34 @@ __global__ void pack_filter_lp(const float* __restrict__ w, int K, int Kpad, int
     out[i] = to_bits<T>(k < K ? w[(size_t)k * cout + n] : 0.f);
 }
 
+// The same packing for MANY filters in one launch (the training step re-packs every filter, forward and data-gradient
+// form, after each update): block -> job through a table; `flipped` packs the data-gradient filter
+// W'[r',s',co,ci] = W[kh-1-r', kw-1-s', ci, co] straight from the forward HWIO variable.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job* __restrict__ jobs,
+                                                               const int* __restrict__ block_job) {
+    const gv_pack_job j = jobs[block_job[blockIdx.x]];
+    const int co_p = j.flipped ? j.cin : j.cout;                 // rows of the packed image
+    const int ci_p = j.flipped ? j.cout : j.cin;                 // channels per tap on its k axis
+    const int K = j.kh * j.kw * ci_p;
+    const int Kpad = (K + KT - 1) / KT * KT;
+    const int64_t i = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (i >= (int64_t)co_p * Kpad) return;
+    const int n = (int)(i / Kpad);
+    const int k = (int)(i - (int64_t)n * Kpad);
+    float v = 0.f;
+    if (k < K) {
+        if (!j.flipped) {
+            v = j.w[(size_t)k * j.cout + n];
+        } else {
+            const int tap = k / ci_p, co = k - tap * ci_p;
+            const int r = tap / j.kw, sx = tap - r * j.kw;
+            v = j.w[((size_t)((j.kh - 1 - r) * j.kw + (j.kw - 1 - sx)) * j.cin + n) * j.cout + co];
+        }
+    }
+    reinterpret_cast<unsigned short*>(j.out)[i] = to_bits<T>(v);
+}
+
 struct TileCfg { int bm, bn; };
 constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 128}, {128, 32},
                               {256, 128}, {128, 256}, {256, 64},    // these three: 8 waves
@@ -931,6 +959,18 @@ int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int d
         hipLaunchKernelGGL(pack_filter_lp<__bf16>, grid, dim3(256), 0, st, w_hwio, K, Kpad, cout, (unsigned short*)out);
     else if (dtype == GV_F16)
         hipLaunchKernelGGL(pack_filter_lp<_Float16>, grid, dim3(256), 0, st, w_hwio, K, Kpad, cout, (unsigned short*)out);
+    else
+        return GV_E_UNSUPPORTED;
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+int lp_pack_filters_batched(const gv_pack_job* jobs_dev, const int* block_job_dev, int nblocks, int dtype,
+                            hipStream_t st) {
+    if (dtype == GV_BF16)
+        hipLaunchKernelGGL(pack_filters_batched_lp<__bf16>, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, block_job_dev);
+    else if (dtype == GV_F16)
+        hipLaunchKernelGGL(pack_filters_batched_lp<_Float16>, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, block_job_dev);
     else
         return GV_E_UNSUPPORTED;
     GV_LAUNCH_CHECK();

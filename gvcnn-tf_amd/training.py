@@ -167,10 +167,6 @@ class TrainGVCNN:
             shapes = p.param_shapes()
             if backbone_params is None:
                 backbone_params = _params.init_backbone_params(shapes, seed=seed)
-            self.params = {k: torch.as_tensor(backbone_params[k], dtype=f32).to(dev).contiguous().clone()
-                           for k in shapes}
-            self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()
-                          if not k.endswith(("moving_mean", "moving_variance"))}
             if head_params is None:
                 head_params = _params.init_head_params(self.Vh, self.raw.c, self.final.c, num_classes, seed=seed + 1)
             ks, bs = [], []
@@ -182,11 +178,32 @@ class TrainGVCNN:
             self.score_bias = torch.cat(bs).to(dev).contiguous()
             kn, bn = _params.classifier_names(self.Vh)
             self.cls_names = (kn, bn)
-            self.params[kn] = torch.as_tensor(head_params[kn], dtype=f32).to(dev).contiguous().clone()
-            self.params[bn] = torch.as_tensor(head_params[bn], dtype=f32).to(dev).contiguous().clone()
-            self.grads[kn] = torch.zeros_like(self.params[kn])
-            self.grads[bn] = torch.zeros_like(self.params[bn])
-            self.momentum = {k: torch.zeros_like(v) for k, v in self.grads.items()}
+            # Trainable variables, their gradients and the Momentum slots live in three FLAT fp32 buffers (the dicts
+            # hold views): zeroing the gradients is one fill and the optimizer two launches (slim's L2 term applies to
+            # the conv filters, which come first) instead of one per variable.
+            init = {k: torch.as_tensor(backbone_params[k], dtype=f32) for k in shapes}
+            init[kn] = torch.as_tensor(head_params[kn], dtype=f32)
+            init[bn] = torch.as_tensor(head_params[bn], dtype=f32)
+            moving = [k for k in init if k.endswith(("moving_mean", "moving_variance"))]
+            train = [k for k in init if k not in moving]
+            train = [k for k in train if k.endswith("/weights")] + [k for k in train if not k.endswith("/weights")]
+            offs, total = {}, 0
+            for k in train:
+                if total and not k.endswith("/weights") and "n_wd" not in offs:
+                    offs["n_wd"] = total
+                offs[k] = total
+                total += (init[k].numel() + 15) // 16 * 16
+            self._n_wd = offs.pop("n_wd", total)
+            self._flat_p, self._flat_g, self._flat_m = (torch.zeros(total, dtype=f32, device=dev) for _ in range(3))
+            self.params, self.grads, self.momentum = {}, {}, {}
+            for k in train:
+                o, n, shp = offs[k], init[k].numel(), tuple(init[k].shape)
+                self.params[k] = self._flat_p[o:o + n].view(shp)
+                self.params[k].copy_(init[k])
+                self.grads[k] = self._flat_g[o:o + n].view(shp)
+                self.momentum[k] = self._flat_m[o:o + n].view(shp)
+            for k in moving:
+                self.params[k] = init[k].to(dev).contiguous().clone()
             # per-op device state
             cmax = max(op["x"].c for op in p.ops if op["kind"] == "bn") if any(o["kind"] == "bn" for o in p.ops) else 4
             cmax = max(cmax, max(max(op["y"].c, op["x"].c) for op in p.ops if op["kind"] == "conv"))
@@ -227,6 +244,7 @@ class TrainGVCNN:
             self.dlogits = torch.empty_like(self.logits)
             self.loss = torch.zeros(1, dtype=f32, device=dev)
         self._packed_dirty = True
+        self._pack_jobs = None
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _ptr(self, t, grad=False):
@@ -337,6 +355,32 @@ class TrainGVCNN:
     def repack(self, sync=True):
         """Refresh the packed filters from the trainable HWIO variables (after an optimizer step)."""
         lib = self.lib
+        if self.es == 2:                                  # 16-bit storage: every filter, both forms, ONE launch
+            if self._pack_jobs is None:
+                jobs, blocks = [], []
+                for op in self.plan.ops:
+                    if op["kind"] != "conv":
+                        continue
+                    w = self.params[op["name"] + "/weights"]
+                    kh, kw, cin, cout = w.shape
+                    for flipped, dst in ((0, op["w_fwd"]), (1, op["w_dgrad"])):
+                        if dst is None:
+                            continue
+                        rows, k = (cin, kh * kw * cout) if flipped else (cout, kh * kw * cin)
+                        nblk = (rows * ((k + 31) // 32 * 32) + 255) // 256
+                        assert dst.numel() >= rows * ((k + 31) // 32 * 32) * 2
+                        jobs.append(_lib.PackJob(w.data_ptr(), dst.data_ptr(), kh, kw, cin, cout, flipped, len(blocks)))
+                        blocks.extend([len(jobs) - 1] * nblk)
+                raw = b"".join(bytes(j) for j in jobs)
+                self._pack_jobs = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(jobs),
+                                   torch.tensor(blocks, dtype=torch.int32, device=self.device))
+            jd, nj, bj = self._pack_jobs
+            _lib.check(lib.gv_pack_filters_batched(jd.data_ptr(), nj, bj.data_ptr(), bj.numel(), self.dt, _st()),
+                       "gv_pack_filters_batched")
+            if sync:
+                torch.cuda.synchronize(self.device)
+            self._packed_dirty = False
+            return
         keep = []
         for op in self.plan.ops:
             if op["kind"] != "conv":
@@ -489,8 +533,7 @@ class TrainGVCNN:
         """Classifier, GAP, group fusion and view pooling backward.  The descriptor gradient is accumulated into
         this engine's final tap, or (view-sharded job) into the zeroed tensor dF [N, Vh, h, w, C]."""
         lib, V = self.lib, self.Vh
-        for g in self.grads.values():
-            g.zero_()
+        self._flat_g.zero_()
         self._written = set()
         if not self._lazy:
             for g in self.grad:
@@ -590,10 +633,11 @@ class TrainGVCNN:
 
     def apply_momentum(self, lr, mu=0.9, weight_decay=0.0):
         """tf.train.MomentumOptimizer(lr, 0.9); the slim L2 term (wd * w) applies to conv weights only."""
-        for k, g in self.grads.items():
-            wd = weight_decay if k.endswith("/weights") else 0.0
-            _lib.check(self.lib.gv_sgd_momentum(self.params[k].data_ptr(), g.data_ptr(), self.momentum[k].data_ptr(),
-                                                g.numel(), float(lr), float(mu), float(wd), _st()), "sgd")
+        for lo, hi, wd in ((0, self._n_wd, weight_decay), (self._n_wd, self._flat_p.numel(), 0.0)):
+            if hi > lo:
+                _lib.check(self.lib.gv_sgd_momentum(self._flat_p.data_ptr() + 4 * lo, self._flat_g.data_ptr() + 4 * lo,
+                                                    self._flat_m.data_ptr() + 4 * lo, hi - lo, float(lr), float(mu),
+                                                    float(wd), _st()), "sgd")
         self._packed_dirty = True
 
     def update_moving_averages(self, decay=None):

@@ -126,6 +126,20 @@ int64_t gv_packed_filter_bytes(int32_t kh, int32_t kw, int32_t cin, int32_t cout
                                int32_t math_mode);
 int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin, int32_t cout,
                         void* w_packed, int32_t dtype, int32_t math_mode, void* stream);
+/* Many filters in ONE launch (16-bit dtypes; the training step re-packs every filter after each update).
+ * jobs (device array): source HWIO variable, destination, geometry; flipped = 1 packs the DATA-GRADIENT filter
+ * W'[r',s',co,ci] = W[kh-1-r', kw-1-s', ci, co] (gv_packed_filter_bytes(kh,kw,cout,cin) bytes) straight from the
+ * forward variable.  Job j owns blocks [first_block, first_block + ceil(rows*Kpad/256)); block_job (device int32
+ * [num_blocks]) maps a block to its job. */
+typedef struct gv_pack_job {
+    const float* w;
+    void* out;
+    int32_t kh, kw, cin, cout;
+    int32_t flipped;
+    int32_t first_block;
+} gv_pack_job;
+int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
+                            int32_t num_blocks, int32_t dtype, void* stream);
 
 /* ---- convolution ---------------------------------------------------------
  * y  = act( conv(x, w) * scale[c] + shift[c] (+ residual) )

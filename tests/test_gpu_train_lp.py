@@ -266,6 +266,40 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
 
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
+def test_batched_filter_packing_equals_the_per_filter_call(dt, tdt, eps):
+    """gv_pack_filters_batched: forward and data-gradient (flipped + transposed) images of many filters in one launch,
+    bit for bit what gv_pack_filter_hwio makes of W and of flip(W)^T."""
+    g = torch.Generator().manual_seed(21)
+    shapes = [(3, 3, 32, 48), (1, 7, 48, 32), (5, 5, 48, 64), (1, 1, 96, 40), (7, 1, 128, 192), (3, 3, 3, 32)]
+    ws = [torch.randn(*sh, generator=g).to(DEV) for sh in shapes]
+    jobs, blocks, outs, refs = [], [], [], []
+    for w in ws:
+        kh, kw, cin, cout = w.shape
+        for flipped in (0, 1):
+            if flipped and cin % 8:
+                continue
+            src = torch.flip(w, (0, 1)).permute(0, 1, 3, 2).contiguous() if flipped else w
+            a, b = (cout, cin) if flipped else (cin, cout)
+            n = lib().gv_packed_filter_bytes(kh, kw, a, b, dt, 0)
+            ref = torch.zeros(n, dtype=torch.uint8, device=DEV)
+            _lib.check(lib().gv_pack_filter_hwio(src.data_ptr(), kh, kw, a, b, ref.data_ptr(), dt, 0, st()), "pack")
+            out = torch.full((n,), 0xAB, dtype=torch.uint8, device=DEV)
+            rows, k = (cin, kh * kw * cout) if flipped else (cout, kh * kw * cin)
+            nblk = (rows * ((k + 31) // 32 * 32) + 255) // 256
+            jobs.append(_lib.PackJob(w.data_ptr(), out.data_ptr(), kh, kw, cin, cout, flipped, len(blocks)))
+            blocks.extend([len(jobs) - 1] * nblk)
+            outs.append(out)
+            refs.append(ref)
+    jd = torch.frombuffer(bytearray(b"".join(bytes(j) for j in jobs)), dtype=torch.uint8).to(DEV)
+    bj = torch.tensor(blocks, dtype=torch.int32, device=DEV)
+    _lib.check(lib().gv_pack_filters_batched(jd.data_ptr(), len(jobs), bj.data_ptr(), bj.numel(), dt, st()), "batched")
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+    assert lib().gv_pack_filters_batched(jd.data_ptr(), len(jobs), bj.data_ptr(), bj.numel(), _lib.GV_F32, st()) != 0
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
 @pytest.mark.parametrize("per_shape", [0, 1])
 def test_view_pool_fuse_backward_typed(dt, tdt, eps, per_shape):
     g = torch.Generator().manual_seed(3)
