@@ -99,6 +99,8 @@ SIGNATURES = {
     "gv_bias_grad_t": (C.c_int, [_P, _I, _L, _I, _P, _P, _I, _P]),
     "gv_view_pool_fuse_bwd_t": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _I, _I, _P]),
     "gv_pack_filters_batched": (C.c_int, [_P, _I, _P, _I, _I, _P]),
+    "gv_bn_finalize_apply_grouped_t": (C.c_int, [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P,
+                                                 _I, _P]),
     "gv_plan_create": (C.c_int, [C.POINTER(_P)]),
     "gv_plan_destroy": (None, [_P]),
     "gv_plan_num_ops": (C.c_int, [_P]),

@@ -1095,6 +1095,25 @@ extern "C" int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t h
                                          (hipStream_t)stream);
 }
 
+extern "C" int gv_bn_finalize_apply_grouped_t(const double* accum, const int32_t* counts, const float* gamma,
+                                              const float* beta, float eps, const void* x, int32_t nb, int32_t hw,
+                                              int32_t c, int32_t x_ld, int32_t num_groups, int32_t relu, void* y,
+                                              int32_t y_ld, float* mean, float* var, float* inv, float* scale,
+                                              float* shift, int32_t dtype, void* stream) {
+    if (!accum || !counts || !beta || !x || !y || !mean || !var || !inv || !scale || !shift) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || x_ld < c || y_ld < c || num_groups <= 0) return GV_E_BADARG;
+    if (lp_type(dtype)) {
+        const int rc = gvlp::bn_finalize_apply_grouped(dtype, accum, counts, gamma, beta, eps, x, nb, hw, c, x_ld,
+                                                       num_groups, relu, y, y_ld, mean, var, inv, scale, shift,
+                                                       (hipStream_t)stream);
+        if (rc != GV_E_UNSUPPORTED) return rc;
+    }
+    const int rc = gv_bn_finalize_grouped(accum, c, num_groups, counts, gamma, beta, eps, mean, var, inv, scale, shift,
+                                          stream);
+    if (rc != GV_OK) return rc;
+    return gv_scale_shift_act_grouped_t(x, nb, hw, c, x_ld, scale, shift, num_groups, relu, y, y_ld, dtype, stream);
+}
+
 extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld,
                                              const void* z, int32_t z_ld, const float* mean, const float* inv,
                                              int32_t nb, int32_t hw, int32_t c, int32_t num_groups, double* accum,
@@ -1131,10 +1150,12 @@ extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, con
     if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    bool done = false;                                           // (the streaming kernel also sums dbeta / dgamma)
     const int rc = gvlp::bn_bwd_apply_grouped(dtype, dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, scale,
-                                              shift, accumulate, nb, hw, c, num_groups, dz, dz_ld, st);
+                                              shift, accumulate, nb, hw, c, num_groups, dz, dz_ld, dbeta, dgamma, &done,
+                                              st);
     if (rc != GV_OK) return rc;
-    if (dbeta || dgamma)
+    if ((dbeta || dgamma) && !done)
         hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
                            dgamma);
     GV_LAUNCH_CHECK();

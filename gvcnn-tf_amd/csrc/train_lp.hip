@@ -324,6 +324,18 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
 
 // FWD: y = act(x*scale + shift).  BWD: dz += A*g + B*z + C with g = dy*[y>0] and, per (group, channel),
 // A = gamma*inv, B = -A*inv*s2/m, C = A*(mean*inv*s2 - s1)/m   (= gamma*inv*(g - s1/m - zhat*s2/m)).
+// Optional work folded into the streaming kernels (saves two tiny launches per BatchNorm):
+//   forward : the finalize step — mean/var/inv and the folded scale/shift from the fp64 sums (exactly the arithmetic of
+//             bn_finalize_grouped), computed by every thread for its channels, stored by one thread per (group, channel);
+//   backward: dbeta / dgamma = the sums over the groups (bn_param_grads), by one thread per channel.
+struct BnExtra {
+    const double* fin_acc;
+    const float* beta;
+    float eps;
+    float *mean, *var, *inv, *scale_out, *shift_out;
+    float *dbeta, *dgamma;
+};
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __restrict__ x, int x_ld,
                                                     const unsigned short* __restrict__ dy, int dy_ld,
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
                                                     const int* __restrict__ counts, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int accumulate, int nb, int hw,
                                                     int c, int G, int relu, unsigned short* __restrict__ out,
-                                                    int out_ld) {
+                                                    int out_ld, BnExtra ex) {
     constexpr int PL = 32, U = 4;
     const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int ch = blockIdx.x * 64 + cl * 8;
@@ -358,9 +370,39 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
             A[e] = (gamma ? gamma[ch + e] : 1.f) * iv;
             B[e] = -A[e] * iv * s2 * rm;
             Cc[e] = A[e] * (mu * iv * s2 - s1) * rm;
+        } else if (ex.fin_acc) {                                 // finalize here (bn_finalize_grouped's arithmetic)
+            const double m = (double)counts[g];
+            const double mu = ex.fin_acc[(size_t)gi * 2] / m;
+            double v = ex.fin_acc[(size_t)gi * 2 + 1] / m - mu * mu;
+            if (v < 0.0) v = 0.0;
+            const float iv = (float)(1.0 / sqrt(v + (double)ex.eps));
+            const float ga = gamma ? gamma[ch + e] : 1.f;
+            A[e] = iv * ga;
+            B[e] = ex.beta[ch + e] - (float)mu * iv * ga;
+            if (blockIdx.y == 0 && pl == 0) {
+                ex.mean[gi] = (float)mu;
+                ex.var[gi] = (float)v;
+                ex.inv[gi] = iv;
+                ex.scale_out[gi] = A[e];
+                ex.shift_out[gi] = B[e];
+            }
         } else {                                                 // p0f = scale, p1f = shift
             A[e] = p0f[gi];
             B[e] = p1f[gi];
+        }
+    }
+    if constexpr (BWD) {
+        if ((ex.dbeta || ex.dgamma) && blockIdx.y == 0 && g == 0 && pl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                double a = 0.0, b2 = 0.0;
+                for (int gg = 0; gg < G; ++gg) {
+                    a += acc[((size_t)gg * c + ch + e) * 2];
+                    b2 += acc[((size_t)gg * c + ch + e) * 2 + 1];
+                }
+                if (ex.dbeta) ex.dbeta[ch + e] += (float)a;
+                if (ex.dgamma) ex.dgamma[ch + e] += (float)b2;
+            }
         }
     }
     GroupWalk w;
@@ -1149,7 +1191,7 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
             hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
                                xs, x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, scale, shift,
                                (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, (const float*)nullptr,
-                               (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld);
+                               (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld, BnExtra{});
         else
             hipLaunchKernelGGL((scale_shift_act_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st,
                                xs, nb, hw, c, x_ld, scale, shift, G, relu, ys, y_ld);
@@ -1158,21 +1200,45 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
     });
 }
 
+// Fused finalize + apply (forward).  Returns GV_E_UNSUPPORTED when the shape needs the separate kernels.
+int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, const float* gamma, const float* beta,
+                              float eps, const void* x, int nb, int hw, int c, int x_ld, int G, int relu, void* y,
+                              int y_ld, float* mean, float* var, float* inv, float* scale, float* shift, hipStream_t st) {
+    const unsigned short* xs = (const unsigned short*)x;
+    unsigned short* ys = (unsigned short*)y;
+    const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
+    if (!v) return GV_E_UNSUPPORTED;
+    BnExtra ex{};
+    ex.fin_acc = acc; ex.beta = beta; ex.eps = eps;
+    ex.mean = mean; ex.var = var; ex.inv = inv; ex.scale_out = scale; ex.shift_out = shift;
+    GV_LP_DISPATCH(dtype, {
+        hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st, xs,
+                           x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, (const float*)nullptr,
+                           (const float*)nullptr, gamma, (const double*)nullptr, counts, (const float*)nullptr,
+                           (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld, ex);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    });
+}
+
 int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, const void* z, int z_ld,
                          const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
                          const float* scale, const float* shift, int accumulate, int nb, int hw, int c, int G, void* dz,
-                         int dz_ld, hipStream_t st) {
+                         int dz_ld, float* dbeta, float* dgamma, bool* param_grads_done, hipStream_t st) {
     const unsigned short* a = (const unsigned short*)dy;
     const unsigned short* b = (const unsigned short*)y;
     const unsigned short* zz = (const unsigned short*)z;
     unsigned short* o = (unsigned short*)dz;
     const bool v = (c % 8 == 0) && vec8(a, dy_ld) && vec8(b, y_ld) && vec8(zz, z_ld) && vec8(o, dz_ld) &&
                    (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
+    BnExtra ex{};
+    ex.dbeta = dbeta; ex.dgamma = dgamma;
+    *param_grads_done = v;
     GV_LP_DISPATCH(dtype, {
         if (v)
             hipLaunchKernelGGL((bn_stream_v8<T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
                                zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c,
-                               G, 0, o, dz_ld);
+                               G, 0, o, dz_ld, ex);
         else
             hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, a,
                                dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c, G,

@@ -436,15 +436,11 @@ class TrainGVCNN:
                                                 _st()), "bn sums " + op["name"])
             if self.bn_sync is not None:                  # shape-sharded: reduce the sums over the ranks first
                 self.bn_sync(self.accum[:2 * V * x.c])
-            _lib.check(lib.gv_bn_finalize_grouped(self.accum.data_ptr(), x.c, V, self._count(hw).data_ptr(),
-                                                  gamma.data_ptr() if gamma is not None else None,
-                                                  beta.data_ptr(), float(op["eps"]), st["mean"].data_ptr(),
-                                                  st["var"].data_ptr(), st["inv"].data_ptr(),
-                                                  st["scale"].data_ptr(), st["shift"].data_ptr(), _st()),
-                       "bn finalize " + op["name"])
-            _lib.check(lib.gv_scale_shift_act_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, st["scale"].data_ptr(),
-                                                        st["shift"].data_ptr(), V, int(op["relu"]), self._ptr(y),
-                                                        y.ld, self.dt, _st()), "bn apply " + op["name"])
+            _lib.check(lib.gv_bn_finalize_apply_grouped_t(
+                self.accum.data_ptr(), self._count(hw).data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                beta.data_ptr(), float(op["eps"]), self._ptr(x), x.nb, hw, x.c, x.ld, V, int(op["relu"]), self._ptr(y),
+                y.ld, st["mean"].data_ptr(), st["var"].data_ptr(), st["inv"].data_ptr(), st["scale"].data_ptr(),
+                st["shift"].data_ptr(), self.dt, _st()), "bn finalize + apply " + op["name"])
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)

@@ -355,6 +355,13 @@ int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32
 int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld, const float* scale,
                                  const float* shift, int32_t num_groups, int32_t relu, void* y, int32_t y_ld,
                                  int32_t dtype, void* stream);
+/* gv_bn_finalize_grouped + gv_scale_shift_act_grouped_t as one call (one launch on 16-bit storage: every thread
+ * derives its channels' scale/shift from the fp64 sums with gv_bn_finalize_grouped's arithmetic, one thread per
+ * (group, channel) stores mean/var/inv/scale/shift for the backward pass and the moving averages). */
+int gv_bn_finalize_apply_grouped_t(const double* accum, const int32_t* counts, const float* gamma, const float* beta,
+                                   float eps, const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
+                                   int32_t num_groups, int32_t relu, void* y, int32_t y_ld, float* mean, float* var,
+                                   float* inv, float* scale, float* shift, int32_t dtype, void* stream);
 /* Backward of y = relu(BN_train(z)).  The ReLU mask [y > 0] is read from y, or — y == NULL with scale/shift given (the
  * folded forward coefficients of gv_bn_finalize_grouped) — recomputed as [z*scale + shift > 0], which is the same
  * mask (the forward pass rounded that very value) without reading y at all; y == NULL and scale == NULL: no ReLU.

@@ -79,6 +79,18 @@ def test_bn_train_forward_and_backward_typed(dt, tdt, eps, c, ld):
         close(stt["mean"].cpu(), mean_ref.detach(), 1e-5)
         close(stt["var"].cpu(), var_ref.detach(), 1e-5)
         close(yd[..., :c].float().cpu(), y_ref.detach(), eps)
+        # finalize + apply as ONE call (one launch when c % 8 == 0): identical statistics, identical y
+        st2 = {k: torch.full((V, c), 7.0, device=DEV) for k in stt}
+        yd2 = torch.zeros_like(zd)
+        _lib.check(lib().gv_bn_finalize_apply_grouped_t(accum.data_ptr(), counts.data_ptr(),
+                                                        gd.data_ptr() if gd is not None else None, bd.data_ptr(), 1e-3,
+                                                        zd.data_ptr(), N * V, h * w, c, ld, V, 1, yd2.data_ptr(), ld,
+                                                        st2["mean"].data_ptr(), st2["var"].data_ptr(),
+                                                        st2["inv"].data_ptr(), st2["scale"].data_ptr(),
+                                                        st2["shift"].data_ptr(), dt, st()), "finalize+apply")
+        for k in stt:
+            assert torch.equal(st2[k], stt[k]), k
+        assert torch.equal(yd2, yd)
         assert float(yd[..., c:].float().abs().max()) == 0.0 if ld > c else True
         # backward from the ROUNDED y (its ReLU mask is what the kernel sees): take the reference mask from it too
         mask = (yd[..., :c].float().cpu() > 0).float()
