@@ -355,6 +355,47 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
     const int per = (npix + gridDim.y - 1) / gridDim.y;
     const int p0 = blockIdx.y * per;
     const int p1 = p0 + per < npix ? p0 + per : npix;
+    // forward with finalize: ONE thread per channel of the block does the fp64 arithmetic (64 instead of 2048 fp64
+    // rsqrt per block), the others pick the result up from LDS
+    __shared__ float sA[64], sB[64];
+    if constexpr (!BWD) {
+        if (ex.fin_acc) {
+            const int cht = blockIdx.x * 64 + threadIdx.x;
+            if (threadIdx.x < 64 && cht < c) {
+                const int gi = g * c + cht;
+                const double m = (double)counts[g];
+                const double mu = ex.fin_acc[(size_t)gi * 2] / m;
+                double v = ex.fin_acc[(size_t)gi * 2 + 1] / m - mu * mu;
+                if (v < 0.0) v = 0.0;
+                const float iv = (float)(1.0 / sqrt(v + (double)ex.eps));
+                const float ga = gamma ? gamma[cht] : 1.f;
+                const float a_ = iv * ga, b_ = ex.beta[cht] - (float)mu * iv * ga;
+                sA[threadIdx.x] = a_;
+                sB[threadIdx.x] = b_;
+                if (blockIdx.y == 0) {
+                    ex.mean[gi] = (float)mu;
+                    ex.var[gi] = (float)v;
+                    ex.inv[gi] = iv;
+                    ex.scale_out[gi] = a_;
+                    ex.shift_out[gi] = b_;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if constexpr (BWD) {                                         // dbeta / dgamma: one thread per channel, once per launch
+        const int cht = blockIdx.x * 64 + threadIdx.x;
+        if ((ex.dbeta || ex.dgamma) && blockIdx.y == 0 && g == 0 && threadIdx.x < 64 && cht < c) {
+            double a = 0.0, b2 = 0.0;
+#pragma unroll 4
+            for (int gg = 0; gg < G; ++gg) {
+                a += acc[((size_t)gg * c + cht) * 2];
+                b2 += acc[((size_t)gg * c + cht) * 2 + 1];
+            }
+            if (ex.dbeta) ex.dbeta[cht] += (float)a;
+            if (ex.dgamma) ex.dgamma[cht] += (float)b2;
+        }
+    }
     if (ch >= c || p0 + pl >= p1) return;
     float A[8], B[8], Cc[8], sc[8], sh[8];
     const bool rmask = BWD && !yact && scale;                    // ReLU mask recomputed from z (x here)
@@ -370,39 +411,12 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
             A[e] = (gamma ? gamma[ch + e] : 1.f) * iv;
             B[e] = -A[e] * iv * s2 * rm;
             Cc[e] = A[e] * (mu * iv * s2 - s1) * rm;
-        } else if (ex.fin_acc) {                                 // finalize here (bn_finalize_grouped's arithmetic)
-            const double m = (double)counts[g];
-            const double mu = ex.fin_acc[(size_t)gi * 2] / m;
-            double v = ex.fin_acc[(size_t)gi * 2 + 1] / m - mu * mu;
-            if (v < 0.0) v = 0.0;
-            const float iv = (float)(1.0 / sqrt(v + (double)ex.eps));
-            const float ga = gamma ? gamma[ch + e] : 1.f;
-            A[e] = iv * ga;
-            B[e] = ex.beta[ch + e] - (float)mu * iv * ga;
-            if (blockIdx.y == 0 && pl == 0) {
-                ex.mean[gi] = (float)mu;
-                ex.var[gi] = (float)v;
-                ex.inv[gi] = iv;
-                ex.scale_out[gi] = A[e];
-                ex.shift_out[gi] = B[e];
-            }
+        } else if (ex.fin_acc) {                                 // finalized above
+            A[e] = sA[cl * 8 + e];
+            B[e] = sB[cl * 8 + e];
         } else {                                                 // p0f = scale, p1f = shift
             A[e] = p0f[gi];
             B[e] = p1f[gi];
-        }
-    }
-    if constexpr (BWD) {
-        if ((ex.dbeta || ex.dgamma) && blockIdx.y == 0 && g == 0 && pl == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                double a = 0.0, b2 = 0.0;
-                for (int gg = 0; gg < G; ++gg) {
-                    a += acc[((size_t)gg * c + ch + e) * 2];
-                    b2 += acc[((size_t)gg * c + ch + e) * 2 + 1];
-                }
-                if (ex.dbeta) ex.dbeta[ch + e] += (float)a;
-                if (ex.dgamma) ex.dgamma[ch + e] += (float)b2;
-            }
         }
     }
     GroupWalk w;
