@@ -872,8 +872,10 @@ extern "C" int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
 
 extern "C" int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t dy_ld, void* dx,
                              int32_t dx_ld, void* stream) {
-    if (!d || !dy || !dx || (d->mode == GV_POOL_MAX && !x)) return GV_E_BADARG;
-    if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG) return GV_E_BADARG;
+    if (!d || !dy || !dx) return GV_E_BADARG;
+    const int mode = d->mode & ~GV_POOL_BWD_STORE;
+    if ((mode == GV_POOL_MAX && !x) || (mode != GV_POOL_MAX && mode != GV_POOL_AVG)) return GV_E_BADARG;
+    if ((d->mode & GV_POOL_BWD_STORE) && d->dtype == GV_F32) return GV_E_UNSUPPORTED;   // the fp32 kernel scatters (+=)
     if (d->dtype == GV_BF16 || d->dtype == GV_F16)
         return gvlp::pool2d_bwd(d, x, dy, dy_ld, dx, dx_ld, (hipStream_t)stream);
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;

@@ -493,7 +493,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __restrict__ x, int x_ld,
                                                      const unsigned short* __restrict__ dy, int dy_ld, int nb, int ih,
                                                      int iw, int c, int kh, int kw, int stride, int pad_t, int pad_l,
-                                                     int oh, int ow, int mode, unsigned short* __restrict__ dx,
+                                                     int oh, int ow, int mode, int store, unsigned short* __restrict__ dx,
                                                      int dx_ld) {
     const int cg = c / VEC;
     const int64_t total = (int64_t)nb * ih * iw * cg;
@@ -514,7 +514,13 @@ __global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __res
         ox0 = ox0 <= 0 ? 0 : (ox0 + stride - 1) / stride;
         int ox1 = (ix + pad_l) / stride;
         if (ox1 > ow - 1) ox1 = ow - 1;
-        if (oy0 > oy1 || ox0 > ox1) continue;
+        if (oy0 > oy1 || ox0 > ox1) {                            // no window covers this pixel
+            if (store) {
+                float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store_v<T, VEC>(dx + pix * dx_ld + q * VEC, zero);
+            }
+            continue;
+        }
         float sum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum[e] = 0.f;
@@ -559,7 +565,12 @@ __global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __res
             }
         }
         float d[8];
-        load_v<T, VEC>(dx + pix * dx_ld + q * VEC, d);
+        if (store) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = 0.f;
+        } else {
+            load_v<T, VEC>(dx + pix * dx_ld + q * VEC, d);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) d[e] += sum[e];
         store_v<T, VEC>(dx + pix * dx_ld + q * VEC, d);
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __res
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* __restrict__ x, int x_ld,
                                                          const unsigned short* __restrict__ dy, int dy_ld, int nb,
-                                                         int ih, int iw, int c, int oh, int ow,
+                                                         int ih, int iw, int c, int oh, int ow, int store,
                                                          unsigned short* __restrict__ dx, int dx_ld) {
     const int cg = c / 8, ah = (ih + 1) / 2, aw = (iw + 1) / 2;
     const int64_t total = (int64_t)nb * ah * aw * cg;
@@ -632,7 +643,12 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* _
                 if (iy >= ih || ix >= iw) continue;
                 unsigned short* dp = dx + ((int64_t)(n * ih + iy) * iw + ix) * dx_ld + q * 8;
                 float d[8];
-                load_v<T, 8>(dp, d);
+                if (store) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] = 0.f;
+                } else {
+                    load_v<T, 8>(dp, d);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d[e] += sum[2 * py + px][e];
                 store_v<T, 8>(dp, d);
@@ -1268,21 +1284,23 @@ int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, 
     unsigned short* o = (unsigned short*)dx;
     const bool v = (d->c % 8 == 0) && vec8(xs, d->x_ld) && vec8(g, dy_ld) && vec8(o, dx_ld);
     const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
-    const bool m3s2 = v && d->mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
+    const int store = (d->mode & GV_POOL_BWD_STORE) ? 1 : 0;
+    const int mode = d->mode & ~GV_POOL_BWD_STORE;
+    const bool m3s2 = v && mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
                       d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
     GV_LP_DISPATCH(d->dtype, {
         if (m3s2)
             hipLaunchKernelGGL((maxpool3s2_bwd_lp<T>),
                                dim3(grid_for((int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2) * (d->c / 8))), dim3(256),
-                               0, st, xs, d->x_ld, g, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, o, dx_ld);
+                               0, st, xs, d->x_ld, g, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, store, o, dx_ld);
         else if (v)
             hipLaunchKernelGGL((pool2d_bwd_lp<T, 8>), dim3(grid_for(npix * (d->c / 8))), dim3(256), 0, st, xs, d->x_ld, g,
                                dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh,
-                               d->ow, d->mode, o, dx_ld);
+                               d->ow, mode, store, o, dx_ld);
         else
             hipLaunchKernelGGL((pool2d_bwd_lp<T, 1>), dim3(grid_for(npix * d->c)), dim3(256), 0, st, xs, d->x_ld, g, dy_ld,
                                d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow,
-                               d->mode, o, dx_ld);
+                               mode, store, o, dx_ld);
         GV_LAUNCH_CHECK();
         return GV_OK;
     });

@@ -622,8 +622,8 @@ class TrainGVCNN:
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
-            if self._claim(x):
-                self._zero_grad_of(x)
+            if self._claim(x):                                # first contribution: the gather kernels store
+                d.mode |= _lib.GV_POOL_BWD_STORE
             _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
                                          x.ld, _st()), "pool_bwd " + op["name"])
 

@@ -59,6 +59,7 @@ extern "C" {
 /* pooling modes */
 #define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
 #define GV_POOL_AVG 1         /* divisor = number of VALID taps (slim.avg_pool2d, SAME) */
+#define GV_POOL_BWD_STORE 0x100 /* gv_pool2d_bwd only, OR-ed into mode, 16-bit dtypes: dx = ... instead of dx += ... */
 #define GV_POOL_AVG_RELU 2    /* GV_POOL_AVG followed by ReLU.  avg_pool -> 1x1 conv -> BN -> ReLU
                                  (nets/inception_v3.py:152-154,...) is evaluated as relu(avgpool(BN(conv1x1(x)))):
                                  the 1x1 conv and the BN affine commute with the average (its weights sum to 1),

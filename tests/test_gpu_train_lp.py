@@ -159,6 +159,11 @@ def test_pool_backward_typed(dt, tdt, eps, k, stride, padding, mode, c):
     dx32 = torch.zeros_like(x32)
     _lib.check(lib().gv_pool2d_bwd(C.byref(d32), x32.data_ptr(), dy32.data_ptr(), c, dx32.data_ptr(), c, st()), "pool_bwd")
     close(dx.float().cpu() - 0.25, dx32.cpu(), 2 * eps)
+    # store form (the first contribution to a gradient): dx = ..., whatever dx held
+    d.mode |= _lib.GV_POOL_BWD_STORE
+    dxs = torch.full_like(xd, float("nan"))
+    _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dyd.data_ptr(), c, dxs.data_ptr(), c, st()), "pool_bwd")
+    close(dxs.float().cpu(), dx32.cpu(), eps)
     if mode == "avg" or (k, stride) != (3, 1):
         close(dx32.cpu(), x.grad, 1e-5)                  # (torch splits differently only where windows tie)
 
