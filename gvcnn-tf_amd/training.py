@@ -43,18 +43,18 @@ class TrainPlan(backbones.BackbonePlan):
             z = out
         else:
             z = self.new_tensor(x.nb, oh, ow, cout)
-        self.ops.append(dict(kind="conv", name=scope, x=x, y=z, res=residual, kh=kh, kw=kw, stride=stride,
+        self.ops.append(dict(lane=self.cur_lane, kind="conv", name=scope, x=x, y=z, res=residual, kh=kh, kw=kw, stride=stride,
                              pad_t=pad_t, pad_l=pad_l, bias=None if norm is not None else scope + "/biases",
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c))
         result = z
         if norm is not None:
             a = out if out is not None else self.new_tensor(x.nb, oh, ow, cout)
-            self.ops.append(dict(kind="bn", name=scope + "/BatchNorm", x=z, y=a, eps=norm[1], has_gamma=norm[2],
+            self.ops.append(dict(lane=self.cur_lane, kind="bn", name=scope + "/BatchNorm", x=z, y=a, eps=norm[1], has_gamma=norm[2],
                                  relu=relu))
             result = a
         if next_preact is not None:
             pre = self.new_tensor(x.nb, oh, ow, cout)
-            self.ops.append(dict(kind="bn", name=next_preact[0], x=result, y=pre, eps=next_preact[1],
+            self.ops.append(dict(lane=self.cur_lane, kind="bn", name=next_preact[0], x=result, y=pre, eps=next_preact[1],
                                  has_gamma=True, relu=True))
             return result, pre
         return result
@@ -72,10 +72,10 @@ class TrainPlan(backbones.BackbonePlan):
         so the pool (forward AND backward) moves `depth` instead of x.c channels; the train-mode BatchNorm stays
         after the pool, i.e. its batch statistics are those of the reference's tensor."""
         z = self.new_tensor(x.nb, x.h, x.w, depth)
-        self.ops.append(dict(kind="conv", name=conv_scope, x=x, y=z, res=None, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+        self.ops.append(dict(lane=self.cur_lane, kind="conv", name=conv_scope, x=x, y=z, res=None, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
                              bias=None, flops=2.0 * x.npix * depth * x.c))
         p = self.pool(z, 3, 1, "SAME", _lib.GV_POOL_AVG, name=pool_name)
-        self.ops.append(dict(kind="bn", name=conv_scope + "/BatchNorm", x=p, y=dst, eps=norm[1], has_gamma=norm[2],
+        self.ops.append(dict(lane=self.cur_lane, kind="bn", name=conv_scope + "/BatchNorm", x=p, y=dst, eps=norm[1], has_gamma=norm[2],
                              relu=True))
         return dst
 
@@ -84,13 +84,13 @@ class TrainPlan(backbones.BackbonePlan):
         ow, pad_l = _out_size(x.w, k, stride, padding)
         if out is None:
             out = self.new_tensor(x.nb, oh, ow, x.c)
-        self.ops.append(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t, pad_l=pad_l,
+        self.ops.append(dict(lane=self.cur_lane, kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t, pad_l=pad_l,
                              mode=mode))
         return out
 
     def bn_relu(self, x, bn_scope, eps, name):
         out = self.new_tensor(x.nb, x.h, x.w, x.c)
-        self.ops.append(dict(kind="bn", name=bn_scope, x=x, y=out, eps=eps, has_gamma=True, relu=True))
+        self.ops.append(dict(lane=self.cur_lane, kind="bn", name=bn_scope, x=x, y=out, eps=eps, has_gamma=True, relu=True))
         return out
 
     def param_shapes(self):
@@ -131,6 +131,7 @@ class TrainGVCNN:
         # backward is recomputed from z instead of read from y.  Saves ~2 B/element of fills and 4 B/element of reads.
         self._lazy = self.es == 2
         self._written = set()
+        self._lane_streams = None
         # per_shape: the paper's grouping (model.GVCNN(per_shape=True)) in the training step
         self.per_shape = bool(per_shape)
         self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
@@ -256,6 +257,87 @@ class TrainGVCNN:
                 self.grad[t.vbuf] = torch.zeros_like(self.act[t.vbuf])
             return self.grad[t.vbuf].data_ptr() + self.es * t.off
         return self.act[t.vbuf].data_ptr() + self.es * t.off
+
+    # -- launch lanes: the independent branches of an Inception block on separate HIP streams -------------------------
+    def enable_lanes(self, n=3):
+        """Run the ops of lane k > 0 (backbones.build_inception_v3 puts the branches of a block on lanes 0..2) on
+        their own streams.  Ordering comes from the tensors: an op waits for the last writer of everything it reads
+        or updates (events, at most one wait per source lane), so the fan-in of a block input's gradient stays a
+        chain; every phase forks from and joins back into the caller's stream.  A speed choice only, and measured
+        NEUTRAL at 32 shapes x 12 views (31.9 vs 32.0 ms: every kernel of the step already fills the chip); it is kept
+        for small batches.  Capturing the multi-stream step into one graph crashes hipStreamEndCapture in this runtime
+        (tools/lanes_capture_probe.py) — the single-stream step captures fine."""
+        self._lane_streams = [None] + [torch.cuda.Stream(self.device) for _ in range(n - 1)]
+        self._lane_accum = [self.accum] + [torch.zeros_like(self.accum) for _ in range(n - 1)]
+        self._ready = {}
+        # events come from a fixed pool (one per op and phase boundary): none is created or destroyed while a
+        # stream capture is in progress
+        self._ev_pool = [torch.cuda.Event() for _ in range(2 * len(self.plan.ops) + 4 * n + 8)]
+        self._ev_next = 0
+
+    def _event(self):
+        ev = self._ev_pool[self._ev_next % len(self._ev_pool)]
+        self._ev_next += 1
+        return ev
+
+    def _phase_begin(self):
+        if self._lane_streams is None:
+            return
+        self._ready = {}
+        self._lane_seen = [dict() for _ in self._lane_streams]
+        self._ev_next = 0 if self._ev_next >= len(self._ev_pool) // 2 else len(self._ev_pool) // 2   # two halves
+        ev = self._event()
+        ev.record(torch.cuda.current_stream(self.device))
+        for s_ in self._lane_streams[1:]:
+            s_.wait_event(ev)
+
+    def _phase_end(self):
+        if self._lane_streams is None:
+            return
+        main = torch.cuda.current_stream(self.device)
+        for s_ in self._lane_streams[1:]:
+            ev = self._event()
+            ev.record(s_)
+            main.wait_event(ev)
+        self._ready = {}
+
+    def _on_lane(self, op, kind, touched, written, fn):
+        """Run fn() on the op's lane after the last writers of `touched` (tensors read or updated); record this op
+        as the last writer of `written`."""
+        if self._lane_streams is None:
+            return fn()
+        lane = min(op.get("lane", 0), len(self._lane_streams) - 1)
+        main = torch.cuda.current_stream(self.device)
+        stream = main if lane == 0 else self._lane_streams[lane]
+        latest = {}                                       # per source lane only its most recent event: a stream is ordered
+        for t in touched:
+            if t is None or t.vbuf < 0:
+                continue
+            for off, c, ev, ln, seq in self._ready.get((kind, t.vbuf), ()):
+                if ln != lane and off < t.off + t.c and t.off < off + c and seq > latest.get(ln, (-1, None))[0]:
+                    latest[ln] = (seq, ev)
+        for ln, (seq, ev) in latest.items():
+            if seq > self._lane_seen[lane].get(ln, -1):   # (not already ordered after it by an earlier wait)
+                stream.wait_event(ev)
+                self._lane_seen[lane][ln] = seq
+        saved = self.accum
+        self.accum = self._lane_accum[lane]
+        try:
+            if lane == 0:
+                fn()
+            else:
+                with torch.cuda.stream(stream):
+                    fn()
+        finally:
+            self.accum = saved
+        ev = self._event()
+        ev.record(stream)
+        for t in written:
+            if t is None or t.vbuf < 0:
+                continue
+            lst = [e for e in self._ready.get((kind, t.vbuf), []) if not (t.off <= e[0] and e[0] + e[1] <= t.off + t.c)]
+            lst.append((t.off, t.c, ev, lane, self._ev_next))
+            self._ready[(kind, t.vbuf)] = lst
 
     def _claim(self, t):
         """True for the FIRST gradient contribution to tensor t in this backward pass (lazy mode: it must store, or
@@ -413,8 +495,10 @@ class TrainGVCNN:
         self._x = views.to(self.tdt).contiguous()
         if self._packed_dirty:
             self.repack()
+        self._phase_begin()
         for op in self.plan.ops:
-            self._forward_op(op)
+            self._on_lane(op, "a", (op["x"], op.get("res")), (op["y"],), lambda: self._forward_op(op))
+        self._phase_end()
 
     def _forward_op(self, op):
         """One op of the train-mode forward pass (conv -> z, BatchNorm on batch statistics (+ReLU), pool)."""
@@ -562,11 +646,14 @@ class TrainGVCNN:
 
     def backward_backbone(self):
         """Backbone backward from the gradient held in the final tap's gradient buffer."""
+        self._phase_begin()
         for op in reversed(self.plan.ops):
             y = op["y"]
             if y.vbuf < 0 or not self._has_grad(y):
                 continue                                  # nothing downstream of the final tap reaches it
-            self._backward_op(op)
+            outs = (op["x"], op.get("res"))
+            self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op))
+        self._phase_end()
         return self.grads
 
     def _backward_op(self, op):

@@ -14,6 +14,7 @@ ap.add_argument("--size", type=int, default=224)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--storage", default="f32", choices=["f32", "bf16", "f16"])
 ap.add_argument("--graph", action="store_true", help="replay the whole step from one captured graph")
+ap.add_argument("--lanes", action="store_true", help="branches of a block on separate streams (meant for --graph)")
 a = ap.parse_args()
 eng = TrainGVCNN(a.backbone, a.shapes, a.views, a.size, a.size, 40, 10, device="cuda:0", storage=a.storage)
 x = (torch.rand(a.shapes, a.views, a.size, a.size, 3) - 0.5).cuda()
@@ -30,6 +31,10 @@ for _ in range(a.steps):
     ev[0].record(); eng.forward(x, labels, check=False); ev[1].record(); eng.backward(); ev[2].record()
     eng.apply_momentum(1e-6); eng.repack(); ev[3].record(); torch.cuda.synchronize()
     tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2]); to += ev[2].elapsed_time(ev[3])
+if a.lanes:
+    eng.enable_lanes()
+    eng.train_step(x, labels, lr=1e-6)
+    torch.cuda.synchronize()
 if a.graph:
     # the whole step (forward, loss, backward, moving averages, Momentum, filter re-pack) as ONE graph launch
     s_ = torch.cuda.Stream()
