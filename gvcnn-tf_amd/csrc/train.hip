@@ -669,7 +669,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const S* __restrict
     int n = (int)(m / ((int64_t)oh * ow));
     int rem = (int)(m - (int64_t)n * oh * ow);
     int oy = rem / ow, ox = rem - oy * ow;
-    float av[2][U][NRT], bv[2][U];
+    S av[2][U][NRT], bv[2][U];             // RAW storage values: converting at the load site would wait for each load
+                                          // (16-bit loads) and serialise the prefetch; the conversion happens at the MFMA
     auto fetch = [&](int s) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -681,9 +682,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const S* __restrict
             for (int t = 0; t < NRT; ++t) {
                 const bool ok = pok && rv[t] && (unsigned)(iy0 + fr[t]) < (unsigned)ih &&
                                 (unsigned)(ix0 + fs[t]) < (unsigned)iw;
-                av[s][u][t] = ok ? (float)x[base + delta[t]] : 0.f;
+                av[s][u][t] = ok ? x[base + delta[t]] : (S)0.f;
             }
-            bv[s][u] = (pok && co < cout) ? (float)dz[m * dz_ld + co] : 0.f;
+            bv[s][u] = (pok && co < cout) ? dz[m * dz_ld + co] : (S)0.f;
             m += 2;
             ox += 2;
             while (ox >= ow) {
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const S* __restrict
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < NRT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][u][t], bv[s][u], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)av[s][u][t], (float)bv[s][u], acc[t], 0, 0, 0);
     };
     const int64_t pairs = (m1 - m0 + 1) / 2;
     const int64_t stages = (pairs + U - 1) / U;
