@@ -1119,12 +1119,16 @@ int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned 
     return GV_OK;
 }
 
+int g_strip_ntw = 5;     // taps per workgroup of the general strip variant: 5 keeps two waves per SIMD (9: one)
+
 template <typename T>
 int strip_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
             int target_wgs, hipStream_t st) {
     if (d->cin <= 32 && d->cout <= 32) return strip_launch<T, 1, 1, 4, 3>(d, x, dz, dz_ld, dw, target_wgs, st);
     if (d->cin <= 32) return strip_launch<T, 1, 2, 2, 5>(d, x, dz, dz_ld, dw, target_wgs, st);
     if (d->cout <= 32) return strip_launch<T, 2, 1, 2, 5>(d, x, dz, dz_ld, dw, target_wgs, st);
+    if (g_strip_ntw == 5) return strip_launch<T, 2, 2, 1, 5>(d, x, dz, dz_ld, dw, target_wgs, st);
+    if (g_strip_ntw == 4) return strip_launch<T, 2, 2, 1, 4>(d, x, dz, dz_ld, dw, target_wgs, st);
     return strip_launch<T, 2, 2, 1, 9>(d, x, dz, dz_ld, dw, target_wgs, st);
 }
 
@@ -1177,6 +1181,8 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
 }
 
 }  // namespace
+
+extern "C" void gv_conv2d_wgrad_set_strip_taps(int n) { g_strip_ntw = n; }
 
 namespace gvlp {
 
