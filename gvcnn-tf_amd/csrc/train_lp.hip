@@ -750,13 +750,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_lp(const unsigned short* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int ntile_co = (cout + BO - 1) / BO, ntile_ci = (cin + BI - 1) / BI;
-    int b = blockIdx.x;
+    // 1-D grid, XCD-aware: all tiles (taps x ci x co) of one PIXEL SLICE re-read the same X and dZ rows, so they get
+    // consecutive logical ids = one XCD's L2 (round-robin dispatch would spread them over all eight)
+    const int tiles = ntile_co * ntile_ci * kh * kw;
+    const int logical = gv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int b = logical % tiles;
+    const int slice = logical / tiles;
     const int tco = b % ntile_co; b /= ntile_co;
     const int tci = b % ntile_ci; b /= ntile_ci;
     const int tap = b;
     const int fr = tap / kw, fs = tap - fr * kw;
     const int ci0 = tci * BI, co0 = tco * BO;
-    const int64_t m0 = (int64_t)blockIdx.y * m_per_block;
+    const int64_t m0 = (int64_t)slice * m_per_block;
     const int64_t m1 = m0 + m_per_block < M ? m0 + m_per_block : M;
     f32x16 acc[TI][TO];
 #pragma unroll
@@ -893,13 +898,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave % WT, wj = (wave / WT) % WJ, wi = wave / (WT * WJ);
     const int ntile_co = (gm.cout + BO - 1) / BO, ntile_ci = (gm.cin + BI - 1) / BI;
-    int b = blockIdx.x;
+    const int groups = (gm.kh * gm.kw + taps_per_group - 1) / taps_per_group;
+    const int tiles = ntile_co * ntile_ci * groups;
+    const int logical = gv_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // tiles of one strip range share an XCD's L2
+    int b = logical % tiles;
     const int tco = b % ntile_co; b /= ntile_co;
     const int tci = b % ntile_ci; b /= ntile_ci;
     const int tap0 = b * taps_per_group;
     const int ntaps = min(taps_per_group, gm.kh * gm.kw - tap0);
     const int ci0 = tci * BI, co0 = tco * BO;
-    const int s0 = blockIdx.y * gm.stages_per_block;
+    const int s0 = (logical / tiles) * gm.stages_per_block;
     const int s1 = min(s0 + gm.stages_per_block, gm.stages);
     if (s0 >= s1) return;
     f32x16 acc[NTW];
@@ -1114,7 +1122,7 @@ int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned 
     static bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            64 * 1024) == hipSuccess;
     (void)attr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), lds, st, x, dz, gm, tpg, dw);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, x, dz, gm, tpg, dw);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
@@ -1167,7 +1175,7 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
-    const dim3 grid((unsigned)tiles, (unsigned)splits);
+    const dim3 grid((unsigned)(tiles * splits));
 #define GV_WGRAD_LP(TI, TO)                                                                                          \
     hipLaunchKernelGGL((conv_wgrad_lp<T, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih, d->iw, \
                        d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, dw)
