@@ -512,13 +512,16 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const S* __restrict__ x, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int ntile_co = (cout + BO - 1) / BO, ntile_ci = (cin + BI - 1) / BI;
-    int b = blockIdx.x;
+    // 1-D grid, XCD-aware: the tiles of one pixel slice re-read the same rows, so they share an XCD's L2
+    const int tiles = ntile_co * ntile_ci * kh * kw;
+    const int logical = gv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int b = logical % tiles;
     const int tco = b % ntile_co; b /= ntile_co;
     const int tci = b % ntile_ci; b /= ntile_ci;
     const int tap = b;
     const int fr = tap / kw, fs = tap - fr * kw;
     const int ci0 = tci * BI, co0 = tco * BO;
-    const int64_t m0 = (int64_t)blockIdx.y * m_per_block;
+    const int64_t m0 = (int64_t)(logical / tiles) * m_per_block;
     const int64_t m1 = m0 + m_per_block < M ? m0 + m_per_block : M;
     f32x16 acc[TI][TO];
 #pragma unroll
@@ -1012,7 +1015,7 @@ static int wgrad_f32mfma(const gv_conv_desc* d, const S* x, const S* dz, int32_t
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
-    const dim3 grid((unsigned)tiles, (unsigned)splits);
+    const dim3 grid((unsigned)(tiles * splits));
 #define GV_WGRAD2(TI, TO)                                                                                          \
     hipLaunchKernelGGL((conv_wgrad2_f32<S, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih,    \
                        d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per,     \
