@@ -35,7 +35,8 @@ class ConvDesc(C.Structure):
 
 class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
-                ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32)]
+                ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32), ("k_off", C.c_int32),
+                ("k_total", C.c_int32)]
 
 
 class PoolDesc(C.Structure):

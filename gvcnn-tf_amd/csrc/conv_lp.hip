@@ -777,8 +777,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job* __restrict__ jobs,
                                                                const int* __restrict__ block_job) {
     const gv_pack_job j = jobs[block_job[blockIdx.x]];
-    const int co_p = j.flipped ? j.cin : j.cout;                 // rows of the packed image
-    const int ci_p = j.flipped ? j.cout : j.cin;                 // channels per tap on its k axis
+    const int co_p = j.flipped ? j.cin : j.cout;                 // rows of this job in the packed image
+    const int ci_p = j.flipped ? j.cout : j.cin;                 // this job's channels per tap on the k axis
     const int K = j.kh * j.kw * ci_p;
     const int Kpad = (K + KT - 1) / KT * KT;
     const int64_t i = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job
     const int n = (int)(i / Kpad);
     const int k = (int)(i - (int64_t)n * Kpad);
     float v = 0.f;
+    int64_t dst = i;
     if (k < K) {
         if (!j.flipped) {
             v = j.w[(size_t)k * j.cout + n];
@@ -793,9 +794,15 @@ __global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job
             const int tap = k / ci_p, co = k - tap * ci_p;
             const int r = tap / j.kw, sx = tap - r * j.kw;
             v = j.w[((size_t)((j.kh - 1 - r) * j.kw + (j.kw - 1 - sx)) * j.cin + n) * j.cout + co];
+            if (j.k_total > 0) {                                 // one member of a wider fused filter: its column range
+                const int kt = j.kh * j.kw * j.k_total;
+                dst = (int64_t)n * ((kt + KT - 1) / KT * KT) + (int64_t)tap * j.k_total + j.k_off + co;
+            }
         }
+    } else if (j.flipped && j.k_total > 0) {
+        return;                                                  // (the fused image's own padding was zeroed once)
     }
-    reinterpret_cast<unsigned short*>(j.out)[i] = to_bits<T>(v);
+    reinterpret_cast<unsigned short*>(j.out)[dst] = to_bits<T>(v);
 }
 
 struct TileCfg { int bm, bn; };

@@ -59,12 +59,37 @@ class TrainPlan(backbones.BackbonePlan):
             return result, pre
         return result
 
-    def conv_siblings(self, x, branches, first_out, norm, relu=True):
+    def conv_siblings(self, x, branches, first_out, norm, relu=True, pooled=None):
+        """The 1x1 convolutions of one block that read the SAME input (and the pooled branch's 1x1, which commutes
+        with its average pool) as ONE GEMM over their concatenated filters: z_all [pixels, sum of couts], each
+        member's train-mode BatchNorm reads its channel slice.  Forward reads x once instead of 4 times; backward
+        is ONE data-gradient launch (no read-modify-write fan-in on dX) and ONE filter gradient whose columns are
+        copied to the members' variables.  The variables keep the reference's names and shapes."""
+        members = list(branches) + ([(pooled[0], pooled[1])] if pooled is not None else [])
+        total = sum(c for _, c in members)
+        zall = self.new_tensor(x.nb, x.h, x.w, total)
+        cols, off = [], 0
+        for scope, c in members:
+            cols.append((scope + "/weights", off, c))
+            off += c
+        self.ops.append(dict(lane=self.cur_lane, kind="conv", name="+".join(sc for sc, _ in members), x=x, y=zall,
+                             res=None, kh=1, kw=1, stride=1, pad_t=0, pad_l=0, bias=None, members=cols,
+                             flops=2.0 * x.npix * total * x.c))
         outs = []
         for i, (scope, c) in enumerate(branches):
-            t = self.conv(x, scope, c, 1, out=first_out if i == 0 else None, norm=norm, relu=relu)
+            z = zall.channels(cols[i][1], cols[i][1] + c)
+            a = first_out if i == 0 else self.new_tensor(x.nb, x.h, x.w, c)
+            self.ops.append(dict(lane=self.cur_lane, kind="bn", name=scope + "/BatchNorm", x=z, y=a, eps=norm[1],
+                                 has_gamma=norm[2], relu=relu))
             if i:
-                outs.append(t)
+                outs.append(a)
+        if pooled is not None:
+            scope, depth, pool_name, dst = pooled
+            z = zall.channels(cols[-1][1], cols[-1][1] + depth)
+            with self.lane(2):
+                pz = self.pool(z, 3, 1, "SAME", _lib.GV_POOL_AVG, name=pool_name)
+                self.ops.append(dict(lane=self.cur_lane, kind="bn", name=scope + "/BatchNorm", x=pz, y=dst, eps=norm[1],
+                                     has_gamma=norm[2], relu=True))
         return outs
 
     def pooled_branch(self, x, conv_scope, pool_name, depth, dst, norm):
@@ -97,6 +122,10 @@ class TrainPlan(backbones.BackbonePlan):
         shapes = {}
         for op in self.ops:
             if op["kind"] == "conv":
+                if op.get("members"):
+                    for wname, _, c in op["members"]:
+                        shapes[wname] = (1, 1, op["x"].c, c)
+                    continue
                 shapes[op["name"] + "/weights"] = (op["kh"], op["kw"], op["x"].c, op["y"].c)
                 if op["bias"]:
                     shapes[op["bias"]] = (op["y"].c,)
@@ -113,7 +142,8 @@ class TrainGVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=2, num_views=6, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2,
-                 head_views=None, view_offset=0, per_shape=False, weight_mode="count", storage="f32"):
+                 head_views=None, view_offset=0, per_shape=False, weight_mode="count", storage="f32",
+                 fuse_siblings=True):
         """head_views / view_offset: view-sharded data parallelism (sharding.ShardedTrainGVCNN) — this engine
         runs the backbone for views [view_offset, view_offset + num_views) of the head_views views of every shape
         (so each view's BatchNorm statistics stay on one rank, exactly the reference's per-view statistics),
@@ -156,7 +186,7 @@ class TrainGVCNN:
         raw_tap = raw_tap or backbones.TAPS[backbone][0]
         final_tap = final_tap or backbones.TAPS[backbone][1]
         if backbone == "inception_v3":
-            backbones.build_inception_v3(p, keep=(raw_tap, final_tap), fuse_siblings=False)
+            backbones.build_inception_v3(p, keep=(raw_tap, final_tap), fuse_siblings=fuse_siblings)
         else:
             backbones.build_resnet_v2_50(p, keep=(raw_tap, final_tap))
         self.plan = p
@@ -218,12 +248,20 @@ class TrainGVCNN:
                     op["stat"] = {k: torch.empty((num_views, c), dtype=f32, device=dev)
                                   for k in ("mean", "var", "inv", "scale", "shift")}
                 elif op["kind"] == "conv":
-                    w = self.params[op["name"] + "/weights"]
-                    kh, kw, cin, cout = w.shape
+                    kh, kw, cin, cout = op["kh"], op["kw"], op["x"].c, op["y"].c
                     nf = self.lib.gv_packed_filter_bytes(kh, kw, cin, cout, self.dt, self.math_mode)
                     nd = self.lib.gv_packed_filter_bytes(kh, kw, cout, cin, self.dt, self.math_mode)
-                    op["w_fwd"] = torch.empty(nf, dtype=torch.uint8, device=dev)
-                    op["w_dgrad"] = torch.empty(nd, dtype=torch.uint8, device=dev) if op["x"].vbuf >= 0 else None
+                    op["w_fwd"] = torch.zeros(nf, dtype=torch.uint8, device=dev)
+                    op["w_dgrad"] = torch.zeros(nd, dtype=torch.uint8, device=dev) if op["x"].vbuf >= 0 else None
+            # the filter gradient of a fused sibling GEMM lands in a scratch [cin, sum of couts] (one flat buffer for
+            # all of them, zeroed with the variables' gradients) and is copied column-wise to the members' variables
+            fused = [op for op in p.ops if op["kind"] == "conv" and op.get("members")]
+            self._flat_fused = torch.zeros(max(sum(op["x"].c * op["y"].c for op in fused), 4), dtype=f32, device=dev)
+            o = 0
+            for op in fused:
+                n = op["x"].c * op["y"].c
+                op["dw_fused"] = self._flat_fused[o:o + n].view(1, 1, op["x"].c, op["y"].c)
+                o += n
             nbv = nb
             self.r_img = torch.empty(nbv, dtype=f32, device=dev)
             self.scores = torch.empty(self.Vh, dtype=f32, device=dev)
@@ -339,6 +377,14 @@ class TrainGVCNN:
             lst.append((t.off, t.c, ev, lane, self._ev_next))
             self._ready[(kind, t.vbuf)] = lst
 
+    def _members(self, op):
+        """[(variable name, first column, columns)] of a convolution: one entry, or the members of a fused sibling GEMM."""
+        return op.get("members") or [(op["name"] + "/weights", 0, op["y"].c)]
+
+    def _dw(self, op):
+        """Where the filter gradient of `op` is accumulated: the variable's gradient, or the fused scratch."""
+        return op["dw_fused"] if op.get("members") else self.grads[op["name"] + "/weights"]
+
     def _claim(self, t):
         """True for the FIRST gradient contribution to tensor t in this backward pass (lazy mode: it must store, or
         zero t first); always False in the fp32 step, whose gradient buffers are zero-filled up front."""
@@ -353,7 +399,11 @@ class TrainGVCNN:
         """Has the gradient of t (or of a concat tensor that contains it) been produced in this backward pass?"""
         if not self._lazy:
             return self.grad[t.vbuf] is not None
-        return any(v == t.vbuf and o <= t.off and t.off + t.c <= o + c for v, o, c in self._written)
+        pos = t.off                                           # union of the written channel ranges covers [off, off + c)
+        for o, c in sorted((o, c) for v, o, c in self._written if v == t.vbuf):
+            if o <= pos < o + c:
+                pos = o + c
+        return pos >= t.off + t.c
 
     def _zero_grad_of(self, t):
         self._ptr(t, grad=True)
@@ -416,7 +466,7 @@ class TrainGVCNN:
             # filter gradient (16-bit storage): tile and pixel-split choice, timed with events on the launch stream
             nw = lib.gv_conv2d_wgrad_num_cfgs(self.dt)
             if nw:
-                dw = torch.empty_like(self.grads[op["name"] + "/weights"])
+                dw = torch.empty_like(self._dw(op))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 best, best_ms = 0, float("inf")
                 for t in range(nw + 1):
@@ -443,16 +493,23 @@ class TrainGVCNN:
                 for op in self.plan.ops:
                     if op["kind"] != "conv":
                         continue
-                    w = self.params[op["name"] + "/weights"]
-                    kh, kw, cin, cout = w.shape
-                    for flipped, dst in ((0, op["w_fwd"]), (1, op["w_dgrad"])):
-                        if dst is None:
-                            continue
-                        rows, k = (cin, kh * kw * cout) if flipped else (cout, kh * kw * cin)
-                        nblk = (rows * ((k + 31) // 32 * 32) + 255) // 256
-                        assert dst.numel() >= rows * ((k + 31) // 32 * 32) * 2
-                        jobs.append(_lib.PackJob(w.data_ptr(), dst.data_ptr(), kh, kw, cin, cout, flipped, len(blocks)))
-                        blocks.extend([len(jobs) - 1] * nblk)
+                    kh, kw, cin, total = op["kh"], op["kw"], op["x"].c, op["y"].c
+                    kpad_f = (kh * kw * cin + 31) // 32 * 32          # row length of the forward image
+                    fused = bool(op.get("members"))
+                    for wname, col, cout in self._members(op):
+                        w = self.params[wname]
+                        assert tuple(w.shape) == (kh, kw, cin, cout) and w.is_contiguous()
+                        for flipped, dst in ((0, op["w_fwd"]), (1, op["w_dgrad"])):
+                            if dst is None:
+                                continue
+                            rows, k = (cin, kh * kw * cout) if flipped else (cout, kh * kw * cin)
+                            nblk = (rows * ((k + 31) // 32 * 32) + 255) // 256
+                            # forward image: member rows [col, col + cout) are contiguous; data-gradient image of a
+                            # fused filter: member columns inside rows of kh*kw*total (k_off / k_total)
+                            out = dst.data_ptr() + (0 if flipped else col * kpad_f * 2)
+                            jobs.append(_lib.PackJob(w.data_ptr(), out, kh, kw, cin, cout, flipped, len(blocks),
+                                                     col if flipped and fused else 0, total if flipped and fused else 0))
+                            blocks.extend([len(jobs) - 1] * nblk)
                 raw = b"".join(bytes(j) for j in jobs)
                 self._pack_jobs = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(jobs),
                                    torch.tensor(blocks, dtype=torch.int32, device=self.device))
@@ -467,7 +524,9 @@ class TrainGVCNN:
         for op in self.plan.ops:
             if op["kind"] != "conv":
                 continue
-            w = self.params[op["name"] + "/weights"]
+            mem = self._members(op)
+            w = self.params[mem[0][0]] if len(mem) == 1 else torch.cat([self.params[m[0]] for m in mem], dim=3)
+            keep.append(w)
             kh, kw, cin, cout = w.shape
             _lib.check(lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout, op["w_fwd"].data_ptr(),
                                                self.dt, self.math_mode, _st()), "gv_pack_filter_hwio")
@@ -614,6 +673,7 @@ class TrainGVCNN:
         this engine's final tap, or (view-sharded job) into the zeroed tensor dF [N, Vh, h, w, C]."""
         lib, V = self.lib, self.Vh
         self._flat_g.zero_()
+        self._flat_fused.zero_()
         self._written = set()
         if not self._lazy:
             for g in self.grad:
@@ -694,9 +754,11 @@ class TrainGVCNN:
                 _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
                            "res grad")
             d = self._conv_desc(op, wgrad=True)
-            _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld,
-                                           self.grads[op["name"] + "/weights"].data_ptr(), _st()),
+            _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld, self._dw(op).data_ptr(), _st()),
                        "wgrad " + op["name"])
+            if op.get("members"):                             # columns of the fused gradient -> the members' variables
+                for wname, col, c in op["members"]:
+                    self.grads[wname].copy_(op["dw_fused"][..., col:col + c])
             if x.vbuf >= 0:
                 dd = self._conv_desc(op, dgrad=True)
                 dx = self._ptr(x, True)

@@ -130,7 +130,8 @@ int gv_pack_filter_hwio(const float* w_hwio, int32_t kh, int32_t kw, int32_t cin
 /* Many filters in ONE launch (16-bit dtypes; the training step re-packs every filter after each update).
  * jobs (device array): source HWIO variable, destination, geometry; flipped = 1 packs the DATA-GRADIENT filter
  * W'[r',s',co,ci] = W[kh-1-r', kw-1-s', ci, co] (gv_packed_filter_bytes(kh,kw,cout,cin) bytes) straight from the
- * forward variable.  Job j owns blocks [first_block, first_block + ceil(rows*Kpad/256)); block_job (device int32
+ * forward variable (the forward image of a fused filter needs no extra field: member rows are contiguous, `out`
+ * points at the member's first row).  Job j owns blocks [first_block, first_block + ceil(rows*Kpad/256)); block_job (device int32
  * [num_blocks]) maps a block to its job. */
 typedef struct gv_pack_job {
     const float* w;
@@ -138,6 +139,9 @@ typedef struct gv_pack_job {
     int32_t kh, kw, cin, cout;
     int32_t flipped;
     int32_t first_block;
+    int32_t k_off, k_total;     /* flipped only, k_total > 0: this filter is columns [k_off, k_off + cout) of a FUSED
+                                   filter of k_total output channels (several 1x1 convolutions of one input run as one
+                                   GEMM; its data-gradient image has rows of kh*kw*k_total, padding zeroed by the caller) */
 } gv_pack_job;
 int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
                             int32_t num_blocks, int32_t dtype, void* stream);

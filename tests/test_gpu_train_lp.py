@@ -400,6 +400,11 @@ def test_bf16_engine_op_by_op_against_the_fp32_engine(backbone, size, N, V):
         if yt.vbuf < 0 or ref_grad[yt.vbuf] is None:
             continue
         pnames = [k for k in e32.grads if k.startswith(o32["name"] + "/") or k == o32.get("bias")]
+        if o32["kind"] == "conv":
+            pnames = [m[0] for m in e32._members(o32)] + ([o32["bias"]] if o32.get("bias") else [])
+        for e in (e32, e16):
+            if o32.get("members"):
+                e._dw(o32 if e is e32 else o16).zero_()
         for e, o in ((e32, o32), (e16, o16)):
             for t in (xt, rt):
                 if t is not None and t.vbuf >= 0 and e.grad[t.vbuf] is not None:

@@ -16,7 +16,7 @@ def t(op, cfg):
     op["tile_w"] = cfg
     d = eng._conv_desc(op, wgrad=True)
     xx, y = op["x"], op["y"]
-    dw = eng.grads[op["name"] + "/weights"]
+    dw = eng._dw(op)
     args = (C.byref(d), eng._ptr(xx), eng._ptr(y, True), y.ld, dw.data_ptr(), st)
     if lib.gv_conv2d_wgrad(*args) != 0: return float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -31,7 +31,7 @@ for op in eng.plan.ops:
         continue
     xx, y = op["x"], op["y"]
     d = eng._conv_desc(op)
-    dw = eng.grads[op["name"] + "/weights"]
+    dw = eng._dw(op)
     res = []
     for v1 in (1, 0):
         if a.storage == "f32":
