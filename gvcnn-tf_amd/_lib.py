@@ -39,6 +39,11 @@ class PackJob(C.Structure):
                 ("k_total", C.c_int32)]
 
 
+class BnMovingJob(C.Structure):
+    _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("counts", C.c_void_p), ("moving_mean", C.c_void_p),
+                ("moving_var", C.c_void_p), ("c", C.c_int32), ("first_block", C.c_int32)]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "c", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
@@ -101,6 +106,7 @@ SIGNATURES = {
     "gv_bias_grad_t": (C.c_int, [_P, _I, _L, _I, _P, _P, _I, _P]),
     "gv_view_pool_fuse_bwd_t": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _I, _I, _P]),
     "gv_pack_filters_batched": (C.c_int, [_P, _I, _P, _I, _I, _P]),
+    "gv_bn_update_moving_batched": (C.c_int, [_P, _I, _P, _I, _I, _F, _P]),
     "gv_bn_finalize_apply_grouped_t": (C.c_int, [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P,
                                                  _I, _P]),
     "gv_plan_create": (C.c_int, [C.POINTER(_P)]),

@@ -741,7 +741,34 @@ __global__ void bn_update_moving(const float* __restrict__ mean, const float* __
     mv[ch] = v;
 }
 
+// every BatchNorm layer's moving-average update in ONE launch (block -> job through a table)
+__global__ void bn_update_moving_batched(const gv_bn_moving_job* __restrict__ jobs, const int* __restrict__ block_job,
+                                         int G, float decay) {
+    const gv_bn_moving_job j = jobs[block_job[blockIdx.x]];
+    const int ch = (blockIdx.x - j.first_block) * blockDim.x + threadIdx.x;
+    if (ch >= j.c) return;
+    float m = j.moving_mean[ch], v = j.moving_var[ch];
+    for (int g = 0; g < G; ++g) {
+        const float n = (float)j.counts[g];
+        const float unb = n > 1.f ? n / (n - 1.f) : 1.f;
+        m = __fadd_rn(__fmul_rn(m, decay), __fmul_rn(j.mean[(size_t)g * j.c + ch], 1.f - decay));
+        v = __fadd_rn(__fmul_rn(v, decay), __fmul_rn(__fmul_rn(j.var[(size_t)g * j.c + ch], unb), 1.f - decay));
+    }
+    j.moving_mean[ch] = m;
+    j.moving_var[ch] = v;
+}
+
 }  // namespace
+
+extern "C" int gv_bn_update_moving_batched(const gv_bn_moving_job* jobs_dev, int32_t num_jobs,
+                                           const int32_t* block_job_dev, int32_t num_blocks, int32_t num_groups,
+                                           float decay, void* stream) {
+    if (!jobs_dev || !block_job_dev || num_jobs <= 0 || num_blocks <= 0 || num_groups <= 0) return GV_E_BADARG;
+    hipLaunchKernelGGL(bn_update_moving_batched, dim3((unsigned)num_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev,
+                       block_job_dev, num_groups, decay);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
 
 extern "C" int gv_bn_sums_grouped(const float* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
                                   int32_t num_groups, double* accum, void* stream) {

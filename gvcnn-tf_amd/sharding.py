@@ -240,6 +240,13 @@ class ShardedTrainGVCNN:
     def train_step(self, views_local, labels, lr=1e-3, mu=0.9, weight_decay=0.0, check=False):
         """mode='views': views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all
         ranks).  mode='shapes': views_local [N_l, V, H, W, 3], labels [N_l] (this rank's shapes)."""
+        if self.world == 1:                               # nothing to exchange: the engine's own step
+            eng = self.eng
+            eng.forward(views_local, labels, check=check)
+            eng.backward()
+            eng.update_moving_averages()
+            eng.apply_momentum(lr, mu, weight_decay)
+            return eng.loss
         if self.mode == "shapes":
             return self._train_step_shapes(views_local, labels, lr, mu, weight_decay, check)
         eng = self.eng
@@ -267,6 +274,8 @@ class ShardedTrainGVCNN:
         from . import _lib
         from .model import _st
         eng = self.eng
+        if self.world == 1:                               # all views are local: the engine's own (one-launch) update
+            return eng.update_moving_averages(decay)
         if decay is None:
             decay = 0.9997 if eng.backbone == "inception_v3" else 0.997
         bns = [op for op in eng.plan.ops if op["kind"] == "bn"]

@@ -284,6 +284,7 @@ class TrainGVCNN:
             self.loss = torch.zeros(1, dtype=f32, device=dev)
         self._packed_dirty = True
         self._pack_jobs = None
+        self._moving_jobs = None
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _ptr(self, t, grad=False):
@@ -790,15 +791,24 @@ class TrainGVCNN:
         batch statistics of the last forward.  decay defaults to the backbone's arg-scope value."""
         if decay is None:
             decay = 0.9997 if self.backbone == "inception_v3" else 0.997
-        for op in self.plan.ops:
-            if op["kind"] != "bn":
-                continue
-            st, x = op["stat"], op["x"]
-            _lib.check(self.lib.gv_bn_update_moving(st["mean"].data_ptr(), st["var"].data_ptr(),
-                                                    self._count(x.h * x.w).data_ptr(), self.V, x.c, float(decay),
-                                                    self.params[op["name"] + "/moving_mean"].data_ptr(),
-                                                    self.params[op["name"] + "/moving_variance"].data_ptr(), _st()),
-                       "bn_update_moving")
+        if self._moving_jobs is None:                     # every layer in ONE launch: a table of device pointers
+            jobs, blocks = [], []
+            for op in self.plan.ops:
+                if op["kind"] != "bn":
+                    continue
+                st, x = op["stat"], op["x"]
+                jobs.append(_lib.BnMovingJob(st["mean"].data_ptr(), st["var"].data_ptr(),
+                                             self._count(x.h * x.w).data_ptr(),
+                                             self.params[op["name"] + "/moving_mean"].data_ptr(),
+                                             self.params[op["name"] + "/moving_variance"].data_ptr(), x.c, len(blocks)))
+                blocks.extend([len(jobs) - 1] * ((x.c + 255) // 256))
+            self._moving_jobs = (torch.frombuffer(bytearray(b"".join(bytes(j) for j in jobs)), dtype=torch.uint8)
+                                 .to(self.device), len(jobs), torch.tensor(blocks, dtype=torch.int32, device=self.device),
+                                 self.shape_world)
+        assert self._moving_jobs[3] == self.shape_world   # (the pixel counts are part of the table)
+        jd, nj, bj, _ = self._moving_jobs
+        _lib.check(self.lib.gv_bn_update_moving_batched(jd.data_ptr(), nj, bj.data_ptr(), bj.numel(), self.V,
+                                                        float(decay), _st()), "bn_update_moving_batched")
 
     def train_step(self, views, labels, lr=1e-3, mu=0.9, weight_decay=0.0, update_moving=True):
         self.forward(views, labels, check=False)

@@ -291,6 +291,20 @@ int gv_bn_finalize_grouped(const double* accum, int32_t c, int32_t num_groups, c
  * for g = 0..num_groups-1, n = counts[g].  decay: inception_utils.py:32 (0.9997), resnet_utils.py:199 (0.997). */
 int gv_bn_update_moving(const float* mean, const float* var, const int32_t* counts, int32_t num_groups,
                         int32_t c, float decay, float* moving_mean, float* moving_var, void* stream);
+/* gv_bn_update_moving for every BatchNorm layer of a plan in ONE launch: job j = one layer (device pointers as in
+ * gv_bn_update_moving), owning blocks [first_block, first_block + ceil(c / 256)); block_job (device int32) maps a
+ * block to its job. */
+typedef struct gv_bn_moving_job {
+    const float* mean;
+    const float* var;
+    const int32_t* counts;
+    float* moving_mean;
+    float* moving_var;
+    int32_t c;
+    int32_t first_block;
+} gv_bn_moving_job;
+int gv_bn_update_moving_batched(const gv_bn_moving_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
+                                int32_t num_blocks, int32_t num_groups, float decay, void* stream);
 /* y = act(x*scale[g][c] + shift[g][c]), g = image % num_groups. */
 int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
                                const float* scale, const float* shift, int32_t num_groups, int32_t relu,
