@@ -41,7 +41,8 @@ class PackJob(C.Structure):
 
 class BnMovingJob(C.Structure):
     _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("counts", C.c_void_p), ("moving_mean", C.c_void_p),
-                ("moving_var", C.c_void_p), ("c", C.c_int32), ("first_block", C.c_int32)]
+                ("moving_var", C.c_void_p), ("c", C.c_int32), ("first_block", C.c_int32), ("ld", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class PoolDesc(C.Structure):

@@ -748,11 +748,12 @@ __global__ void bn_update_moving_batched(const gv_bn_moving_job* __restrict__ jo
     const int ch = (blockIdx.x - j.first_block) * blockDim.x + threadIdx.x;
     if (ch >= j.c) return;
     float m = j.moving_mean[ch], v = j.moving_var[ch];
+    const size_t ld = j.ld > 0 ? (size_t)j.ld : (size_t)j.c;
     for (int g = 0; g < G; ++g) {
         const float n = (float)j.counts[g];
         const float unb = n > 1.f ? n / (n - 1.f) : 1.f;
-        m = __fadd_rn(__fmul_rn(m, decay), __fmul_rn(j.mean[(size_t)g * j.c + ch], 1.f - decay));
-        v = __fadd_rn(__fmul_rn(v, decay), __fmul_rn(__fmul_rn(j.var[(size_t)g * j.c + ch], unb), 1.f - decay));
+        m = __fadd_rn(__fmul_rn(m, decay), __fmul_rn(j.mean[g * ld + ch], 1.f - decay));
+        v = __fadd_rn(__fmul_rn(v, decay), __fmul_rn(__fmul_rn(j.var[g * ld + ch], unb), 1.f - decay));
     }
     j.moving_mean[ch] = m;
     j.moving_var[ch] = v;

@@ -281,15 +281,24 @@ class ShardedTrainGVCNN:
         bns = [op for op in eng.plan.ops if op["kind"] == "bn"]
         packed = torch.cat([torch.cat([op["stat"]["mean"], op["stat"]["var"]], dim=1) for op in bns], dim=1)  # [V_l, sum 2c]
         full = gather_views(packed.unsqueeze(0), self.group, eng.Vh)[0]                                        # [V, sum 2c]
-        off = 0
+        # ONE launch over all layers: the jobs point straight into the gathered message (row stride = its width)
+        full = full.contiguous()
+        ld = full.shape[1]
+        if getattr(self, "_mv_counts", None) is None:
+            self._mv_counts = {}
+        jobs, blocks, off = [], [], 0
         for op in bns:
             c, hw = op["x"].c, op["x"].h * op["x"].w
-            mean = full[:, off:off + c].contiguous()
-            var = full[:, off + c:off + 2 * c].contiguous()
+            if hw not in self._mv_counts:
+                self._mv_counts[hw] = torch.full((eng.Vh,), eng.N * hw, dtype=torch.int32, device=full.device)
+            jobs.append(_lib.BnMovingJob(full.data_ptr() + 4 * off, full.data_ptr() + 4 * (off + c),
+                                         self._mv_counts[hw].data_ptr(),
+                                         eng.params[op["name"] + "/moving_mean"].data_ptr(),
+                                         eng.params[op["name"] + "/moving_variance"].data_ptr(), c, len(blocks), ld, 0))
+            blocks.extend([len(jobs) - 1] * ((c + 255) // 256))
             off += 2 * c
-            counts = torch.full((eng.Vh,), eng.N * hw, dtype=torch.int32, device=full.device)
-            _lib.check(eng.lib.gv_bn_update_moving(mean.data_ptr(), var.data_ptr(), counts.data_ptr(), eng.Vh, c,
-                                                   float(decay), eng.params[op["name"] + "/moving_mean"].data_ptr(),
-                                                   eng.params[op["name"] + "/moving_variance"].data_ptr(), _st()),
-                       "bn_update_moving")
-            op["_keep"] = (mean, var, counts)            # alive until the launches above have run
+        jd = torch.frombuffer(bytearray(b"".join(bytes(j) for j in jobs)), dtype=torch.uint8).to(full.device)
+        bj = torch.tensor(blocks, dtype=torch.int32, device=full.device)
+        _lib.check(eng.lib.gv_bn_update_moving_batched(jd.data_ptr(), len(jobs), bj.data_ptr(), bj.numel(), eng.Vh,
+                                                       float(decay), _st()), "bn_update_moving_batched")
+        self._mv_keep = (full, jd, bj)                    # alive until the launch above has run

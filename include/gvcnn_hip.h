@@ -302,6 +302,9 @@ typedef struct gv_bn_moving_job {
     float* moving_var;
     int32_t c;
     int32_t first_block;
+    int32_t ld;                 /* row stride of mean / var in elements (0 = c): statistics gathered from all ranks sit
+                                   side by side in one [views, sum of 2c] message */
+    int32_t reserved;
 } gv_bn_moving_job;
 int gv_bn_update_moving_batched(const gv_bn_moving_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
                                 int32_t num_blocks, int32_t num_groups, float decay, void* stream);

@@ -263,6 +263,31 @@ def test_bench_two_rank_control_flow_on_one_device():
     assert j["value"] > 0 and j["config"]["exchange"] == "scores"
 
 
+@pytest.mark.parametrize("dp", ["views", "shapes"])
+def test_two_rank_training_bench_on_bf16_storage(dp):
+    """bench.py --train --preset c3 as two ranks on one device (gloo): the sharded training step on bf16 storage —
+    gathers, gradient all-reduce, per-layer BN sum all-reduce (shapes) / the gathered moving-average update (views)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--same-device", "--train", "--preset", "c3", "--dp", dp, "--steps", "2", "--warmup", "1", "--shapes", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dtype"] == "bf16" and j["value"] > 0
+    assert j["scaling"] == ("strong" if dp == "views" else "weak")
+
+
 def test_eval_harness_metrics_and_protocols():
     """SURVEY §8 f4 (eval.py:94-99,146-215): argmax / confusion matrix / correct count against numpy (ties -> first
     maximum, out-of-range label ignored), mean-of-batch accuracy, and both calling protocols give the same result."""
