@@ -1106,12 +1106,14 @@ static inline int sums_splits(int64_t npix, int cap) {
 
 extern "C" int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
                                     int32_t num_groups, double* accum, int32_t dtype, void* stream) {
+    const bool zeroed = (dtype & GV_ACCUM_ZEROED) != 0;          // the caller keeps a pre-zeroed accumulator per layer
+    dtype &= ~GV_ACCUM_ZEROED;
     if (dtype == GV_F32) return gv_bn_sums_grouped((const float*)z, nb, hw, c, z_ld, num_groups, accum, stream);
     if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
     if (!z || !accum) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || z_ld < c || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
+    if (!zeroed) GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
     return gvlp::grouped_sums(dtype, 0, z, z_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nb, hw, c,
                               num_groups, sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
 }
@@ -1152,6 +1154,8 @@ extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, cons
                                              const void* z, int32_t z_ld, const float* mean, const float* inv,
                                              int32_t nb, int32_t hw, int32_t c, int32_t num_groups, double* accum,
                                              const float* scale, const float* shift, int32_t dtype, void* stream) {
+    const bool zeroed = (dtype & GV_ACCUM_ZEROED) != 0;
+    dtype &= ~GV_ACCUM_ZEROED;
     if (dtype == GV_F32) {
         if (scale && !y) return GV_E_UNSUPPORTED;                // the fp32 step reads its ReLU mask from y
         return gv_bn_relu_bwd_sums_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
@@ -1162,7 +1166,7 @@ extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, cons
     if (!dy || !z || !mean || !inv || !accum) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
+    if (!zeroed) GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
     return gvlp::grouped_sums(dtype, 1, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, shift, nb, hw, c, num_groups,
                               sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
 }

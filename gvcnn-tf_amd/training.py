@@ -239,6 +239,17 @@ class TrainGVCNN:
             cmax = max(op["x"].c for op in p.ops if op["kind"] == "bn") if any(o["kind"] == "bn" for o in p.ops) else 4
             cmax = max(cmax, max(max(op["y"].c, op["x"].c) for op in p.ops if op["kind"] == "conv"))
             self.accum = torch.zeros(2 * num_views * cmax, dtype=torch.float64, device=dev)
+            # 16-bit step: one fp64 accumulator per BatchNorm layer and pass (forward sums, backward sums), all zeroed
+            # by ONE fill per step instead of one memset per call
+            bns = [op for op in p.ops if op["kind"] == "bn"]
+            tot = max(sum(2 * num_views * op["x"].c for op in bns), 4)
+            self._accum_f = torch.zeros(tot, dtype=torch.float64, device=dev)
+            self._accum_b = torch.zeros(tot, dtype=torch.float64, device=dev)
+            o = 0
+            for op in bns:
+                n = 2 * num_views * op["x"].c
+                op["acc_f"], op["acc_b"] = self._accum_f[o:o + n], self._accum_b[o:o + n]
+                o += n
             self.ones = torch.ones(cmax, dtype=f32, device=dev)
             self.zeros = torch.zeros(cmax, dtype=f32, device=dev)
             self._counts = {}
@@ -555,13 +566,17 @@ class TrainGVCNN:
         self._x = views.to(self.tdt).contiguous()
         if self._packed_dirty:
             self.repack()
+        if self._lazy:
+            self._accum_f.zero_()                         # every layer's forward sums: one fill
         self._phase_begin()
         for op in self.plan.ops:
-            self._on_lane(op, "a", (op["x"], op.get("res")), (op["y"],), lambda: self._forward_op(op))
+            self._on_lane(op, "a", (op["x"], op.get("res")), (op["y"],), lambda: self._forward_op(op, self._lazy))
         self._phase_end()
 
-    def _forward_op(self, op):
-        """One op of the train-mode forward pass (conv -> z, BatchNorm on batch statistics (+ReLU), pool)."""
+    def _forward_op(self, op, zeroed=False):
+        """One op of the train-mode forward pass (conv -> z, BatchNorm on batch statistics (+ReLU), pool).
+        zeroed: the op's own fp64 accumulator was zero-filled by the caller (the pass loops do that for all layers at
+        once); otherwise the sums call clears it itself, so calling an op on its own is always safe."""
         lib, V = self.lib, self.V
         x, y = op["x"], op["y"]
         if op["kind"] == "conv":
@@ -576,12 +591,14 @@ class TrainGVCNN:
             gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
             beta = self.params[op["name"] + "/beta"]
             hw = x.h * x.w
-            _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, self.accum.data_ptr(), self.dt,
+            acc = op["acc_f"] if self._lazy else self.accum
+            zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
+            _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, acc.data_ptr(), self.dt | zf,
                                                 _st()), "bn sums " + op["name"])
             if self.bn_sync is not None:                  # shape-sharded: reduce the sums over the ranks first
-                self.bn_sync(self.accum[:2 * V * x.c])
+                self.bn_sync(acc[:2 * V * x.c])
             _lib.check(lib.gv_bn_finalize_apply_grouped_t(
-                self.accum.data_ptr(), self._count(hw).data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                acc.data_ptr(), self._count(hw).data_ptr(), gamma.data_ptr() if gamma is not None else None,
                 beta.data_ptr(), float(op["eps"]), self._ptr(x), x.nb, hw, x.c, x.ld, V, int(op["relu"]), self._ptr(y),
                 y.ld, st["mean"].data_ptr(), st["var"].data_ptr(), st["inv"].data_ptr(), st["scale"].data_ptr(),
                 st["shift"].data_ptr(), self.dt, _st()), "bn finalize + apply " + op["name"])
@@ -707,17 +724,19 @@ class TrainGVCNN:
 
     def backward_backbone(self):
         """Backbone backward from the gradient held in the final tap's gradient buffer."""
+        if self._lazy:
+            self._accum_b.zero_()                         # every layer's backward sums: one fill
         self._phase_begin()
         for op in reversed(self.plan.ops):
             y = op["y"]
             if y.vbuf < 0 or not self._has_grad(y):
                 continue                                  # nothing downstream of the final tap reaches it
             outs = (op["x"], op.get("res"))
-            self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op))
+            self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op, self._lazy))
         self._phase_end()
         return self.grads
 
-    def _backward_op(self, op):
+    def _backward_op(self, op, zeroed=False):
         """Backward of one op: reads the gradient of its output, ACCUMULATES into the gradient of its input(s) and
         of its variables."""
         lib, V = self.lib, self.V
@@ -732,16 +751,18 @@ class TrainGVCNN:
             sc = st["scale"].data_ptr() if op["relu"] and self._lazy else None      # mask from z*scale + shift > 0
             sh = st["shift"].data_ptr() if op["relu"] and self._lazy else None
             acc = 0 if self._claim(x) else 1
+            accb = op["acc_b"] if self._lazy else self.accum
+            zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
             _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                st["inv"].data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), sc, sh, self.dt, _st()),
+                st["inv"].data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), sc, sh, self.dt | zf, _st()),
                 "bn_bwd sums " + op["name"])
             if self.bn_sync is not None:
-                self.bn_sync(self.accum[:2 * V * x.c])
+                self.bn_sync(accb[:2 * V * x.c])
             _lib.check(lib.gv_bn_relu_bwd_apply_grouped_t(
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
                 st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
-                self._count(hw).data_ptr(), x.nb, hw, x.c, V, self.accum.data_ptr(), self._ptr(x, True), x.ld,
+                self._count(hw).data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), self._ptr(x, True), x.ld,
                 dbeta, dgamma, sc, sh, acc if self._lazy else 1, self.dt, _st()), "bn_bwd apply " + op["name"])
         elif op["kind"] == "conv":
             dz = self._ptr(y, True)

@@ -372,6 +372,9 @@ int gv_sgd_momentum(float* w, const float* g, float* m, int64_t n, float lr, flo
  * dS and the optimizer state stay fp32.  gv_conv2d_fwd (forward and data gradient), gv_conv2d_wgrad,
  * gv_pool2d_fwd/_bwd, gv_global_avg_pool, gv_view_score_partial and gv_view_pool_fuse_fwd take the storage type
  * from their descriptor / dtype argument. */
+/* OR-ed into the `dtype` of the two *_sums_grouped_t calls (16-bit dtypes): `accum` is already zero (a training engine
+ * keeps one accumulator per layer and zeroes them all with one fill per step instead of one memset per call). */
+#define GV_ACCUM_ZEROED 0x100
 int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld, int32_t num_groups,
                          double* accum, int32_t dtype, void* stream);
 int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld, const float* scale,
