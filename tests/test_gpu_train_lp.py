@@ -575,3 +575,18 @@ def test_bf16_training_autotune_and_per_shape_step_runs():
     for _ in range(3):
         l1 = float(eng.train_step(x, labels, lr=1e-4))
     assert np.isfinite(l1) and l1 < l0
+
+
+@pytest.mark.parametrize("backbone,storage,N,V,size,kw", [("inception_v3", "bf16", 2, 20, 299, {}),
+                                                         ("inception_v3", "f16", 2, 3, 171, {}),
+                                                         ("resnet_v2_50", "bf16", 3, 4, 129, {"per_shape": True})])
+def test_16bit_training_runs_at_other_geometries(backbone, storage, N, V, size, kw):
+    """configs[4]'s geometry (20 views, 299x299) on the bf16 step, the fp16 instantiation of the engine, ResNet with
+    per-shape grouping: a few steps on one batch lower the loss, every gradient stays finite."""
+    eng = TrainGVCNN(backbone, N, V, size, size, 10, 10, device=DEV, storage=storage, **kw)
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
+    y = torch.randint(0, 10, (N,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    losses = [float(eng.train_step(x, y, lr=3e-4)) for _ in range(4)]
+    grads = eng.backward()
+    assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], losses
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values())
