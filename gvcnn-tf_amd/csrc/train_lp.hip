@@ -889,7 +889,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
                                                            int taps_per_group, float* __restrict__ dw) {
     static_assert(WI * WJ * WT == 4, "four waves");
     constexpr int BI = 32 * WI, BO = 32 * WJ;
-    constexpr int SX = 2 * BI + 64, SZ = 2 * BO + 64;
+    // row strides: the four rows a transposed read touches per 16-lane group must start 16 dwords apart; a 32-channel
+    // row IS 16 dwords (no padding: 2*B + 64 = 128 bytes would put rows q and q+2 on the same banks — measured 43 %
+    // bank conflicts on the stem layers before this)
+    constexpr int SX = BI == 32 ? 64 : 2 * BI + 64, SZ = BO == 32 ? 64 : 2 * BO + 64;
     constexpr int XC = BI / 8, ZC = BO / 8;                      // 16-byte chunks per LDS row
     constexpr int XVMAX = 6, ZV = (32 * ZC + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1117,7 +1120,7 @@ int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned 
     if (splits > 65535) splits = 65535;
     gm.stages_per_block = (int)((gm.stages + splits - 1) / splits);
     splits = (gm.stages + gm.stages_per_block - 1) / gm.stages_per_block;
-    const size_t lds = (size_t)32 * (2 * BO + 64) + (size_t)gm.xrows * (2 * BI + 64);
+    const size_t lds = (size_t)32 * (BO == 32 ? 64 : 2 * BO + 64) + (size_t)gm.xrows * (BI == 32 ? 64 : 2 * BI + 64);
     auto kern = conv_wgrad_strip_lp<T, WI, WJ, WT, NTW>;
     static bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            64 * 1024) == hipSuccess;
