@@ -1072,9 +1072,9 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
     return GV_OK;
 }
 
-// Launch geometry: d->tile_cfg = 0 picks by divisibility (128 channels on a side only where that wastes no more rows
-// than 64-wide tiles would) and ~2048 workgroups; tile_cfg = 1 + tile + 4*split selects tile (TI,TO) in {(1,1),(2,1),
-// (1,2),(2,2)} and a target of 1024 / 2048 / 4096 workgroups (TrainGVCNN.autotune measures them per layer).
+// Launch geometry: d->tile_cfg = 0 picks the side widths by divisibility and ~2048 workgroups; tile_cfg = 1 + tile +
+// 9*split selects tile (TI,TO) in {1,2,3}^2 (64/128/192 channels per side) and a target of 1024 / 2048 / 4096
+// workgroups; 28..30 the strip form (TrainGVCNN.autotune measures them per layer).
 // strip form: geometry and eligibility
 inline bool strip_geom(const gv_conv_desc* d, int dz_ld, int bi, StripGeom* gm) {
     if (d->stride != 1 || d->kh * d->kw < 2) return false;
@@ -1149,12 +1149,19 @@ template <typename T>
 int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
             hipStream_t st) {
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
-    int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
-    int to = (d->cout + 127) / 128 * 128 == (d->cout + 63) / 64 * 64 ? 2 : 1;
+    // side width 64 / 128 / 192 channels (TI, TO = 1..3): the widest that pads no more channels than 64-wide tiles
+    // would (a 192-wide side triples the flop/byte of this L2->LDS bound kernel on the many 192-channel layers)
+    auto side = [](int c) {
+        const int base = (c + 63) / 64 * 64;
+        if ((c + 191) / 192 * 192 == base) return 3;
+        if ((c + 127) / 128 * 128 == base) return 2;
+        return 1;
+    };
+    int ti = side(d->cin), to = side(d->cout);
     int64_t target = 2048;
-    if (d->tile_cfg > 12) {                                      // 13..15: strip form, 1024 / 2048 / 4096 workgroups
-        if (d->tile_cfg > 15) return GV_E_BADARG;
-        return strip_t<T>(d, x, dz, dz_ld, dw, 1024 << (d->tile_cfg - 13), st);
+    if (d->tile_cfg > 27) {                                      // 28..30: strip form, 1024 / 2048 / 4096 workgroups
+        if (d->tile_cfg > 30) return GV_E_BADARG;
+        return strip_t<T>(d, x, dz, dz_ld, dw, 1024 << (d->tile_cfg - 28), st);
     }
     // heuristic: the strip form for the few-channel stem layers (2.5-3.5x there); its general 64x64x9-tap variant
     // runs at one wave per SIMD and loses to the tap-per-workgroup tiles — autotune may still pick it (cfg 13-15)
@@ -1162,12 +1169,11 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
         const int rc = strip_t<T>(d, x, dz, dz_ld, dw, 2048, st);
         if (rc != GV_E_UNSUPPORTED) return rc;
     }
-    if (d->tile_cfg > 0) {
+    if (d->tile_cfg > 0) {                                       // 1..27: tile (TI, TO) in {1,2,3}^2 x workgroup target
         const int k = d->tile_cfg - 1;
-        if (k >= 12) return GV_E_BADARG;
-        ti = 1 + ((k & 3) & 1);
-        to = 1 + ((k & 3) >> 1);
-        target = 1024 << (k >> 2);
+        ti = 1 + (k % 9) % 3;
+        to = 1 + (k % 9) / 3;
+        target = 1024 << (k / 9);
     }
     const int tiles = d->kh * d->kw * ((d->cin + 64 * ti - 1) / (64 * ti)) * ((d->cout + 64 * to - 1) / (64 * to));
     int64_t splits = (target + tiles - 1) / tiles;
@@ -1182,10 +1188,17 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
 #define GV_WGRAD_LP(TI, TO)                                                                                          \
     hipLaunchKernelGGL((conv_wgrad_lp<T, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih, d->iw, \
                        d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, dw)
-    if (ti == 2 && to == 2) GV_WGRAD_LP(2, 2);
-    else if (ti == 2) GV_WGRAD_LP(2, 1);
-    else if (to == 2) GV_WGRAD_LP(1, 2);
-    else GV_WGRAD_LP(1, 1);
+    switch (ti * 10 + to) {
+        case 11: GV_WGRAD_LP(1, 1); break;
+        case 12: GV_WGRAD_LP(1, 2); break;
+        case 13: GV_WGRAD_LP(1, 3); break;
+        case 21: GV_WGRAD_LP(2, 1); break;
+        case 22: GV_WGRAD_LP(2, 2); break;
+        case 23: GV_WGRAD_LP(2, 3); break;
+        case 31: GV_WGRAD_LP(3, 1); break;
+        case 32: GV_WGRAD_LP(3, 2); break;
+        default: GV_WGRAD_LP(3, 3); break;
+    }
 #undef GV_WGRAD_LP
     GV_LAUNCH_CHECK();
     return GV_OK;

@@ -269,7 +269,7 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
     dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
     n = lib().gv_conv2d_wgrad_num_cfgs(dt)
-    assert n == 15 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0
+    assert n == 30 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0
     outs = []
     for cfg in range(n + 1):
         dw = torch.zeros(3, 3, cin, cout, device=DEV)

@@ -29,11 +29,11 @@ seen = set()
 for op in eng.plan.ops:
     if op["kind"] != "conv" or op["kh"] * op["kw"] < 2 or op["stride"] != 1 or op["x"].c <= 32: continue
     key = (op["kh"], op["kw"], op["x"].c, op["y"].c, op["y"].h)
-    best = min(t(op, c) for c in range(1, 13))
+    best = min(t(op, c) for c in range(1, 28))
     res = [best]
     for ntw in (9, 5, 4):
         lib.gv_conv2d_wgrad_set_strip_taps(ntw)
-        res.append(min(t(op, c) for c in (13, 14, 15)))
+        res.append(min(t(op, c) for c in (28, 29, 30)))
     lib.gv_conv2d_wgrad_set_strip_taps(5)
     for i, r in enumerate(res): tot[i] += r
     if key not in seen:
