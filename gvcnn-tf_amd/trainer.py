@@ -5,10 +5,16 @@
     Trainer                        train.py:166-187,259-302: learning rate -> forward/backward/update (BN moving
                                    averages + Momentum) -> global step; `check_numerics` on the loss (train.py:175)
 
-Pure host logic on top of gvcnn-tf_amd/training.py (no arithmetic on tensors here).  Not built: summaries,
-checkpoints (tf.train.Saver) and the TF-checkpoint importer.
+    Trainer.save / restore         tf.train.Saver's role (train.py:225-234,297-302): every variable of the engine (slim /
+                                   Keras names), the Momentum slots (`<variable>/Momentum`, the slot name
+                                   tf.train.MomentumOptimizer uses) and `global_step` as a TF checkpoint-v2 bundle
+                                   (gvcnn-tf_amd/tf_checkpoint.py)
+
+Pure host logic on top of gvcnn-tf_amd/training.py (no arithmetic on tensors here).  Not built: summaries.
 """
 import math
+
+import numpy as np
 
 
 def get_model_learning_rate(learning_policy, base_learning_rate, learning_rate_decay_step,
@@ -59,3 +65,64 @@ class Trainer:
             if math.isnan(v) or math.isinf(v):
                 raise FloatingPointError("Loss is inf or nan.")
         return loss
+
+    # -- checkpoints (tf.train.Saver: train.py:225-234 restores, train.py:297-302 saves) -------------------------------
+    def _engine(self):
+        return getattr(self.engine, "eng", self.engine)
+
+    def state_dict(self):
+        """{checkpoint key: ndarray}: the engine's variables under their slim / Keras names (trainable, BN moving
+        statistics, the V scorer layers), the Momentum slots as `<variable>/Momentum`, and `global_step` (int64)."""
+        eng = self._engine()
+        out = {k: v.detach().cpu().numpy() for k, v in eng.params.items()}
+        for k, v in eng.momentum.items():
+            out[k + "/Momentum"] = v.detach().cpu().numpy()
+        if hasattr(eng, "score_kernel"):
+            from . import params as _params
+            for i in range(eng.score_kernel.shape[0]):
+                kn, bn = _params.scorer_names(eng.view_offset + i)
+                out[kn] = eng.score_kernel[i].detach().cpu().numpy().reshape(-1, 1)
+                out[bn] = eng.score_bias[i:i + 1].detach().cpu().numpy()
+        out["global_step"] = np.asarray(self.global_step, dtype=np.int64)
+        return out
+
+    def save(self, prefix):
+        """Writes `prefix.index` + `prefix.data-00000-of-00001` (checkpoint-v2)."""
+        from . import tf_checkpoint
+        tf_checkpoint.write_checkpoint(prefix, {k: np.ascontiguousarray(v) for k, v in self.state_dict().items()})
+
+    def restore(self, prefix, strict=True):
+        """Loads a checkpoint written by save() (or a TF-slim backbone checkpoint with strict=False: whatever names
+        match are bound, e.g. ImageNet `InceptionV3/...` weights; the rest keeps its values).  Returns the names that
+        were NOT found."""
+        import torch
+        from . import tf_checkpoint
+        eng = self._engine()
+        ck = tf_checkpoint.load_checkpoint(prefix)
+        missing = []
+
+        def bind(name, dst):
+            if name not in ck:
+                missing.append(name)
+                return
+            src = torch.as_tensor(np.asarray(ck[name])).reshape(dst.shape)
+            dst.copy_(src.to(dst.dtype))
+        for k, v in eng.params.items():
+            bind(k, v)
+        for k, v in eng.momentum.items():
+            bind(k + "/Momentum", v)
+        if hasattr(eng, "score_kernel"):
+            from . import params as _params
+            for i in range(eng.score_kernel.shape[0]):
+                kn, bn = _params.scorer_names(eng.view_offset + i)
+                bind(kn, eng.score_kernel[i])
+                bind(bn, eng.score_bias[i:i + 1])
+        if "global_step" in ck:
+            self.global_step = int(np.asarray(ck["global_step"]).reshape(-1)[0])
+        elif strict:
+            missing.append("global_step")
+        if strict and missing:
+            raise KeyError("checkpoint %s lacks %d variables, e.g. %s" % (prefix, len(missing), missing[:3]))
+        if hasattr(eng, "_packed_dirty"):
+            eng._packed_dirty = True                      # the packed filter images are stale now
+        return missing

@@ -516,3 +516,29 @@ def test_shape_sharded_engines_reproduce_the_whole_step():
             assert err < 1e-5 * gmax, k
         else:
             assert err < 1e-3 * scale, (k, err, scale)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_trainer_checkpoint_resumes_the_run(tmp_path, storage):
+    """Trainer.save / restore (tf.train.Saver's role): a run restored from its checkpoint-v2 bundle — variables, BN
+    moving statistics, Momentum slots, scorer layers, global step — takes the same next step as the run that wrote it."""
+    from gvcnn_tf_amd.trainer import Trainer
+    N, V, size, C_, G = 2, 2, 64, 5, 10
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    labels = torch.tensor([1, 3]).to(DEV)
+    eng = TrainGVCNN("resnet_v2_50", N, V, size, size, C_, G, device=DEV, seed=7, storage=storage)
+    tr = Trainer(eng, base_learning_rate=1e-3, training_number_of_steps=50, check_every=0)
+    tr.step(x, labels)
+    tr.step(x, labels)
+    prefix = str(tmp_path / "model.ckpt-2")
+    tr.save(prefix)
+    want = float(tr.step(x, labels))
+    eng2 = TrainGVCNN("resnet_v2_50", N, V, size, size, C_, G, device=DEV, seed=99, storage=storage)   # other values
+    tr2 = Trainer(eng2, base_learning_rate=1e-3, training_number_of_steps=50, check_every=0)
+    assert tr2.restore(prefix) == [] and tr2.global_step == 2
+    got = float(tr2.step(x, labels))
+    assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (got, want)
+    tol = 1e-4 if storage == "f32" else 2e-2             # (fp32 atomics in the filter gradient; bf16 roundings on top)
+    for k in eng.params:                                 # and lands on the same variables
+        a, b = eng2.params[k].float().cpu(), eng.params[k].float().cpu()
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-3), k
