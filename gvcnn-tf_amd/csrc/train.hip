@@ -1099,9 +1099,13 @@ extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void*
 // ---- storage-typed forms (16-bit training step; GV_F32 forwards to the fp32 entry points) ---------------------------
 static inline bool lp_type(int dtype) { return dtype == GV_BF16 || dtype == GV_F16; }
 
-static inline int sums_splits(int64_t npix, int cap) {
-    int splits = (int)((npix + 2047) / 2048);
-    return splits > cap ? cap : (splits < 1 ? 1 : splits);
+// pixel splits of a sums launch: 2048 pixels per workgroup on the big layers, but at least ~1024 workgroups in total
+// (down to 128 pixels per workgroup) on the small, latency-bound ones
+static inline int sums_splits(int64_t npix, int cap, int c = 64, int G = 1) {
+    int64_t splits = (npix + 2047) / 2048;
+    const int64_t want = 1024 / ((int64_t)((c + 63) / 64) * G) + 1, most = (npix + 127) / 128;
+    if (splits < want) splits = want < most ? want : most;
+    return (int)(splits > cap ? cap : (splits < 1 ? 1 : splits));
 }
 
 extern "C" int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32_t c, int32_t z_ld,
@@ -1115,7 +1119,7 @@ extern "C" int gv_bn_sums_grouped_t(const void* z, int32_t nb, int32_t hw, int32
     hipStream_t st = (hipStream_t)stream;
     if (!zeroed) GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
     return gvlp::grouped_sums(dtype, 0, z, z_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nb, hw, c,
-                              num_groups, sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
+                              num_groups, sums_splits((int64_t)(nb / num_groups) * hw, 256, c, num_groups), accum, st);
 }
 
 extern "C" int gv_scale_shift_act_grouped_t(const void* x, int32_t nb, int32_t hw, int32_t c, int32_t x_ld,
@@ -1168,7 +1172,7 @@ extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, cons
     hipStream_t st = (hipStream_t)stream;
     if (!zeroed) GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
     return gvlp::grouped_sums(dtype, 1, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, shift, nb, hw, c, num_groups,
-                              sums_splits((int64_t)(nb / num_groups) * hw, 256), accum, st);
+                              sums_splits((int64_t)(nb / num_groups) * hw, 256, c, num_groups), accum, st);
 }
 
 extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, const void* y, int32_t y_ld,

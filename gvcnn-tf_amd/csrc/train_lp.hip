@@ -480,9 +480,14 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
     }
 }
 
-inline int stream_splits(int nb, int hw, int G) {
+// Pixel splits of a streaming BN launch: ~32 pixels per thread on the big layers, but at least ~1024 workgroups in
+// total while a thread still gets 4 pixels — the small late layers are latency-bound, a longer per-thread loop only
+// adds to their time.
+inline int stream_splits(int nb, int hw, int G, int c) {
     const int64_t npix = (int64_t)((nb + G - 1) / G) * hw;
-    int64_t s = (npix + 1023) / 1024;                            // ~32 pixels per thread
+    int64_t s = (npix + 1023) / 1024;
+    const int64_t want = 1024 / ((int64_t)((c + 63) / 64) * G) + 1, most = (npix + 127) / 128;
+    if (s < want) s = want < most ? want : most;
     return (int)(s < 1 ? 1 : (s > 65535 ? 65535 : s));
 }
 
@@ -1248,7 +1253,7 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
     const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
     GV_LP_DISPATCH(dtype, {
         if (v)
-            hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
                                xs, x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, scale, shift,
                                (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, (const float*)nullptr,
                                (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld, BnExtra{});
@@ -1272,7 +1277,7 @@ int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, c
     ex.fin_acc = acc; ex.beta = beta; ex.eps = eps;
     ex.mean = mean; ex.var = var; ex.inv = inv; ex.scale_out = scale; ex.shift_out = shift;
     GV_LP_DISPATCH(dtype, {
-        hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st, xs,
+        hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st, xs,
                            x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, (const float*)nullptr,
                            (const float*)nullptr, gamma, (const double*)nullptr, counts, (const float*)nullptr,
                            (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld, ex);
@@ -1296,7 +1301,7 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
     *param_grads_done = v;
     GV_LP_DISPATCH(dtype, {
         if (v)
-            hipLaunchKernelGGL((bn_stream_v8<T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G), G), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_stream_v8<T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
                                zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c,
                                G, 0, o, dz_ld, ex);
         else
