@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
 class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32), ("k_off", C.c_int32),
-                ("k_total", C.c_int32)]
+                ("k_total", C.c_int32), ("w_ld", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BnMovingJob(C.Structure):

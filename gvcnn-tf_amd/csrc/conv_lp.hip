@@ -787,13 +787,14 @@ __global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job
     const int k = (int)(i - (int64_t)n * Kpad);
     float v = 0.f;
     int64_t dst = i;
+    const size_t wld = j.w_ld > 0 ? (size_t)j.w_ld : (size_t)j.cout;       // row stride of the HWIO source
     if (k < K) {
         if (!j.flipped) {
-            v = j.w[(size_t)k * j.cout + n];
+            v = j.w[(size_t)k * wld + n];
         } else {
             const int tap = k / ci_p, co = k - tap * ci_p;
             const int r = tap / j.kw, sx = tap - r * j.kw;
-            v = j.w[((size_t)((j.kh - 1 - r) * j.kw + (j.kw - 1 - sx)) * j.cin + n) * j.cout + co];
+            v = j.w[((size_t)((j.kh - 1 - r) * j.kw + (j.kw - 1 - sx)) * j.cin + n) * wld + co];
             if (j.k_total > 0) {                                 // one member of a wider fused filter: its column range
                 const int kt = j.kh * j.kw * j.k_total;
                 dst = (int64_t)n * ((kt + KT - 1) / KT * KT) + (int64_t)tap * j.k_total + j.k_off + co;

@@ -218,21 +218,45 @@ class TrainGVCNN:
             moving = [k for k in init if k.endswith(("moving_mean", "moving_variance"))]
             train = [k for k in init if k not in moving]
             train = [k for k in train if k.endswith("/weights")] + [k for k in train if not k.endswith("/weights")]
+            # The members of a fused sibling GEMM are COLUMN SLICES of one [1,1,cin,sum of couts] block (same place in
+            # all three buffers): the fused filter gradient lands directly in the members' gradients, the forward and
+            # data-gradient images are packed from the block (row stride = its width).  Their dict entries are strided
+            # views with the reference's shapes.
+            fused_of = {}
+            for op in p.ops:
+                if op["kind"] == "conv" and op.get("members"):
+                    for wname, col, c in op["members"]:
+                        fused_of[wname] = (op, col, c)
             offs, total = {}, 0
             for k in train:
                 if total and not k.endswith("/weights") and "n_wd" not in offs:
                     offs["n_wd"] = total
+                if k in fused_of:
+                    op = fused_of[k][0]
+                    if "flat_off" not in op:
+                        op["flat_off"] = total
+                        total += (op["x"].c * op["y"].c + 15) // 16 * 16
+                    continue
                 offs[k] = total
                 total += (init[k].numel() + 15) // 16 * 16
             self._n_wd = offs.pop("n_wd", total)
             self._flat_p, self._flat_g, self._flat_m = (torch.zeros(total, dtype=f32, device=dev) for _ in range(3))
             self.params, self.grads, self.momentum = {}, {}, {}
             for k in train:
-                o, n, shp = offs[k], init[k].numel(), tuple(init[k].shape)
-                self.params[k] = self._flat_p[o:o + n].view(shp)
+                if k in fused_of:
+                    op, col, c = fused_of[k]
+                    o, cin, tot_c = op["flat_off"], op["x"].c, op["y"].c
+                    blk = lambda buf: buf[o:o + cin * tot_c].view(1, 1, cin, tot_c)
+                    self.params[k] = blk(self._flat_p)[..., col:col + c]
+                    self.grads[k] = blk(self._flat_g)[..., col:col + c]
+                    self.momentum[k] = blk(self._flat_m)[..., col:col + c]
+                    op["w_fused"], op["dw_fused"] = blk(self._flat_p), blk(self._flat_g)
+                else:
+                    o, n, shp = offs[k], init[k].numel(), tuple(init[k].shape)
+                    self.params[k] = self._flat_p[o:o + n].view(shp)
+                    self.grads[k] = self._flat_g[o:o + n].view(shp)
+                    self.momentum[k] = self._flat_m[o:o + n].view(shp)
                 self.params[k].copy_(init[k])
-                self.grads[k] = self._flat_g[o:o + n].view(shp)
-                self.momentum[k] = self._flat_m[o:o + n].view(shp)
             for k in moving:
                 self.params[k] = init[k].to(dev).contiguous().clone()
             # per-op device state
@@ -264,15 +288,6 @@ class TrainGVCNN:
                     nd = self.lib.gv_packed_filter_bytes(kh, kw, cout, cin, self.dt, self.math_mode)
                     op["w_fwd"] = torch.zeros(nf, dtype=torch.uint8, device=dev)
                     op["w_dgrad"] = torch.zeros(nd, dtype=torch.uint8, device=dev) if op["x"].vbuf >= 0 else None
-            # the filter gradient of a fused sibling GEMM lands in a scratch [cin, sum of couts] (one flat buffer for
-            # all of them, zeroed with the variables' gradients) and is copied column-wise to the members' variables
-            fused = [op for op in p.ops if op["kind"] == "conv" and op.get("members")]
-            self._flat_fused = torch.zeros(max(sum(op["x"].c * op["y"].c for op in fused), 4), dtype=f32, device=dev)
-            o = 0
-            for op in fused:
-                n = op["x"].c * op["y"].c
-                op["dw_fused"] = self._flat_fused[o:o + n].view(1, 1, op["x"].c, op["y"].c)
-                o += n
             nbv = nb
             self.r_img = torch.empty(nbv, dtype=f32, device=dev)
             self.scores = torch.empty(self.Vh, dtype=f32, device=dev)
@@ -510,7 +525,8 @@ class TrainGVCNN:
                     fused = bool(op.get("members"))
                     for wname, col, cout in self._members(op):
                         w = self.params[wname]
-                        assert tuple(w.shape) == (kh, kw, cin, cout) and w.is_contiguous()
+                        assert tuple(w.shape) == (kh, kw, cin, cout) and w.stride(3) == 1
+                        w_ld = w.stride(2) if fused else 0            # members of a fused block: row stride = its width
                         for flipped, dst in ((0, op["w_fwd"]), (1, op["w_dgrad"])):
                             if dst is None:
                                 continue
@@ -520,7 +536,8 @@ class TrainGVCNN:
                             # fused filter: member columns inside rows of kh*kw*total (k_off / k_total)
                             out = dst.data_ptr() + (0 if flipped else col * kpad_f * 2)
                             jobs.append(_lib.PackJob(w.data_ptr(), out, kh, kw, cin, cout, flipped, len(blocks),
-                                                     col if flipped and fused else 0, total if flipped and fused else 0))
+                                                     col if flipped and fused else 0, total if flipped and fused else 0,
+                                                     w_ld))
                             blocks.extend([len(jobs) - 1] * nblk)
                 raw = b"".join(bytes(j) for j in jobs)
                 self._pack_jobs = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(jobs),
@@ -536,9 +553,7 @@ class TrainGVCNN:
         for op in self.plan.ops:
             if op["kind"] != "conv":
                 continue
-            mem = self._members(op)
-            w = self.params[mem[0][0]] if len(mem) == 1 else torch.cat([self.params[m[0]] for m in mem], dim=3)
-            keep.append(w)
+            w = op["w_fused"] if op.get("members") else self.params[op["name"] + "/weights"]
             kh, kw, cin, cout = w.shape
             _lib.check(lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout, op["w_fwd"].data_ptr(),
                                                self.dt, self.math_mode, _st()), "gv_pack_filter_hwio")
@@ -691,7 +706,6 @@ class TrainGVCNN:
         this engine's final tap, or (view-sharded job) into the zeroed tensor dF [N, Vh, h, w, C]."""
         lib, V = self.lib, self.Vh
         self._flat_g.zero_()
-        self._flat_fused.zero_()
         self._written = set()
         if not self._lazy:
             for g in self.grad:
@@ -778,9 +792,7 @@ class TrainGVCNN:
             d = self._conv_desc(op, wgrad=True)
             _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld, self._dw(op).data_ptr(), _st()),
                        "wgrad " + op["name"])
-            if op.get("members"):                             # columns of the fused gradient -> the members' variables
-                for wname, col, c in op["members"]:
-                    self.grads[wname].copy_(op["dw_fused"][..., col:col + c])
+            # (a fused sibling GEMM: its gradient block IS the members' gradients, column by column)
             if x.vbuf >= 0:
                 dd = self._conv_desc(op, dgrad=True)
                 dx = self._ptr(x, True)

@@ -142,6 +142,9 @@ typedef struct gv_pack_job {
     int32_t k_off, k_total;     /* flipped only, k_total > 0: this filter is columns [k_off, k_off + cout) of a FUSED
                                    filter of k_total output channels (several 1x1 convolutions of one input run as one
                                    GEMM; its data-gradient image has rows of kh*kw*k_total, padding zeroed by the caller) */
+    int32_t w_ld;               /* row stride of `w` in elements (0 = cout): a member filter stored as a column slice of
+                                   the fused [kh,kw,cin,k_total] variable block */
+    int32_t reserved;
 } gv_pack_job;
 int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
                             int32_t num_blocks, int32_t dtype, void* stream);
