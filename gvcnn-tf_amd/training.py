@@ -63,8 +63,9 @@ class TrainPlan(backbones.BackbonePlan):
         """The 1x1 convolutions of one block that read the SAME input (and the pooled branch's 1x1, which commutes
         with its average pool) as ONE GEMM over their concatenated filters: z_all [pixels, sum of couts], each
         member's train-mode BatchNorm reads its channel slice.  Forward reads x once instead of 4 times; backward
-        is ONE data-gradient launch (no read-modify-write fan-in on dX) and ONE filter gradient whose columns are
-        copied to the members' variables.  The variables keep the reference's names and shapes."""
+        is ONE data-gradient launch (no read-modify-write fan-in on dX) and ONE filter gradient that lands directly
+        in the members' gradients (column slices of one block, see TrainGVCNN.__init__).  The variables keep the
+        reference's names and shapes."""
         members = list(branches) + ([(pooled[0], pooled[1])] if pooled is not None else [])
         total = sum(c for _, c in members)
         zall = self.new_tensor(x.nb, x.h, x.w, total)
