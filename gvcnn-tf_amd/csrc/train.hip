@@ -779,6 +779,10 @@ extern "C" int gv_bn_sums_grouped(const float* z, int32_t nb, int32_t hw, int32_
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
     const int64_t npix = (int64_t)(nb / num_groups) * hw;
     int splits = (int)((npix + 2047) / 2048);
+    {   // at least ~1024 workgroups on the small late layers (latency-bound), down to 128 pixels per workgroup
+        const int64_t want = 1024 / ((int64_t)((c + 63) / 64) * num_groups) + 1, most = (npix + 127) / 128;
+        if (splits < want) splits = (int)(want < most ? want : most);
+    }
     if (splits > 256) splits = 256;
     launch_grouped_sums<0>(dim3((c + 63) / 64, splits, num_groups), st, (c & 3) == 0 && vec_ok(z, z_ld), z, z_ld,
                            nullptr, 0, nullptr, 0, nullptr, nullptr, nb, hw, c, num_groups, accum);
@@ -830,6 +834,10 @@ extern "C" int gv_bn_relu_bwd_sums_grouped(const float* dy, int32_t dy_ld, const
     GV_HIP_CHECK(hipMemsetAsync(accum, 0, sizeof(double) * 2 * (size_t)num_groups * c, st));
     const int64_t npix = (int64_t)(nb / num_groups) * hw;
     int splits = (int)((npix + 2047) / 2048);
+    {   // at least ~1024 workgroups on the small late layers (latency-bound), down to 128 pixels per workgroup
+        const int64_t want = 1024 / ((int64_t)((c + 63) / 64) * num_groups) + 1, most = (npix + 127) / 128;
+        if (splits < want) splits = (int)(want < most ? want : most);
+    }
     if (splits > 256) splits = 256;
     launch_grouped_sums<1>(dim3((c + 63) / 64, splits, num_groups), st,
                            (c & 3) == 0 && vec_ok(z, z_ld) && vec_ok(dy, dy_ld) && vec_ok(y, y_ld), z, z_ld, dy, dy_ld, y,
