@@ -58,9 +58,13 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
             mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
             iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
         }
-        for (int64_t p = p0 + pl; p < p1; p += PL) {
-            const int k = (int)(p / hw);
-            const int64_t pix = (int64_t)(k * G + g) * hw + (p - (int64_t)k * hw);
+        // division-free walk over the group's pixels (images g, g+G, ... of the batch): one division to start
+        int64_t pw = p0 + pl;
+        int kw_ = (int)(pw / hw);
+        int rw = (int)(pw - (int64_t)kw_ * hw);
+        int64_t pix = (int64_t)(kw_ * G + g) * hw + rw;
+        const int64_t step_img = (int64_t)(G - 1) * hw;
+        for (int64_t p = pw; p < p1; p += PL) {
             float zv[VEC], gv[VEC], yv[VEC];
             if constexpr (VEC == 4) {
                 if (MODE != 2) *reinterpret_cast<f32x4*>(zv) = *reinterpret_cast<const f32x4*>(z + pix * z_ld + ch);
@@ -84,6 +88,11 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
                 } else {
                     s0[e] += gv[e];
                 }
+            }
+            pix += PL;
+            if (step_img) {                                   // (one group: the pixels are contiguous, nothing to skip)
+                rw += PL;
+                while (rw >= hw) { rw -= hw; pix += step_img; }
             }
         }
     }

@@ -215,9 +215,11 @@ struct GroupWalk {
         step_img = (G - 1) * hw_;
     }
     __device__ __forceinline__ void advance(int n) {
-        r += n;
         pix += n;
-        while (r >= hw) { r -= hw; pix += step_img; }
+        if (step_img) {                                          // (one group: the pixels are contiguous)
+            r += n;
+            while (r >= hw) { r -= hw; pix += step_img; }
+        }
     }
 };
 
