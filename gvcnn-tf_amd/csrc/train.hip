@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
                                                         const float* __restrict__ y, int y_ld,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ inv, int nb, int hw, int c,
-                                                        int G, double* __restrict__ acc) {
+                                                        int G, double* __restrict__ acc,
+                                                        const float* __restrict__ scale = nullptr,
+                                                        const float* __restrict__ shift = nullptr) {
     constexpr int TPC = 64 / VEC;                          // threads across the 64-channel block
     constexpr int PL = 256 / TPC;                          // pixel lanes
     const int cl = threadIdx.x % TPC;
@@ -52,11 +54,14 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.0;
     if (ch < c) {                                          // c % VEC == 0 (checked by the launcher)
-        float mu[VEC], iv[VEC];
+        float mu[VEC], iv[VEC], sc[VEC], sh[VEC];
+        const bool rmask = MODE == 1 && !y && scale;          // ReLU mask recomputed from z: [z*scale + shift > 0]
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
             iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
+            sc[e] = rmask ? scale[g * c + ch + e] : 0.f;
+            sh[e] = rmask ? shift[g * c + ch + e] : 0.f;
         }
         // division-free walk over the group's pixels (images g, g+G, ... of the batch): one division to start
         int64_t pw = p0 + pl;
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
                 } else if (MODE == 1) {
                     float gr = gv[e];
                     if (y && !(yv[e] > 0.f)) gr = 0.f;
+                    if (rmask && !(zv[e] * sc[e] + sh[e] > 0.f)) gr = 0.f;
                     s0[e] += gr;
                     s1[e] += (double)gr * ((zv[e] - mu[e]) * iv[e]);
                 } else {
@@ -115,13 +121,13 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
 template <int MODE>
 void launch_grouped_sums(dim3 grid, hipStream_t st, bool vec, const float* z, int z_ld, const float* dy, int dy_ld,
                          const float* y, int y_ld, const float* mean, const float* inv, int nb, int hw, int c, int G,
-                         double* acc) {
+                         double* acc, const float* scale = nullptr, const float* shift = nullptr) {
     if (vec)
         hipLaunchKernelGGL((grouped_sums_f32<MODE, 4>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv,
-                           nb, hw, c, G, acc);
+                           nb, hw, c, G, acc, scale, shift);
     else
         hipLaunchKernelGGL((grouped_sums_f32<MODE, 1>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv,
-                           nb, hw, c, G, acc);
+                           nb, hw, c, G, acc, scale, shift);
 }
 
 inline bool vec_ok(const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15u) == 0 && (ld & 3) == 0); }
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_f32(
     const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld, const float* __restrict__ z,
     int z_ld, const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ gamma,
     const double* __restrict__ acc, const int* __restrict__ counts, int nb, int hw, int c, int G,
-    float* __restrict__ dz, int dz_ld) {
+    float* __restrict__ dz, int dz_ld, const float* __restrict__ scale = nullptr,
+    const float* __restrict__ shift = nullptr, int accumulate = 1) {
     const int64_t total = (int64_t)nb * hw * c;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -187,12 +194,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_f32(
         const int gi = g * c + ch;
         float gr = dy[pix * dy_ld + ch];
         if (y && !(y[pix * y_ld + ch] > 0.f)) gr = 0.f;
+        const float zval = z[pix * z_ld + ch];
+        if (!y && scale && !(zval * scale[gi] + shift[gi] > 0.f)) gr = 0.f;
         const float iv = inv[gi];
-        const float zh = (z[pix * z_ld + ch] - mean[gi]) * iv;
+        const float zh = (zval - mean[gi]) * iv;
         const float m = (float)counts[g];
         const float s1 = (float)acc[(size_t)gi * 2], s2 = (float)acc[(size_t)gi * 2 + 1];
         const float coef = (gamma ? gamma[ch] : 1.f) * iv;
-        dz[pix * dz_ld + ch] += coef * (gr - s1 / m - zh * s2 / m);
+        const float upd = coef * (gr - s1 / m - zh * s2 / m);
+        dz[pix * dz_ld + ch] = accumulate ? dz[pix * dz_ld + ch] + upd : upd;
     }
 }
 
@@ -833,10 +843,20 @@ extern "C" int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw
     return GV_OK;
 }
 
+static int bn_bwd_sums_f32(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld, const float* z, int32_t z_ld,
+                           const float* mean, const float* inv, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
+                           double* accum, const float* scale, const float* shift, void* stream);
+
 extern "C" int gv_bn_relu_bwd_sums_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
                                            const float* z, int32_t z_ld, const float* mean, const float* inv,
                                            int32_t nb, int32_t hw, int32_t c, int32_t num_groups, double* accum,
                                            void* stream) {
+    return bn_bwd_sums_f32(dy, dy_ld, y, y_ld, z, z_ld, mean, inv, nb, hw, c, num_groups, accum, nullptr, nullptr, stream);
+}
+
+static int bn_bwd_sums_f32(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld, const float* z, int32_t z_ld,
+                           const float* mean, const float* inv, int32_t nb, int32_t hw, int32_t c, int32_t num_groups,
+                           double* accum, const float* scale, const float* shift, void* stream) {
     if (!dy || !z || !mean || !inv || !accum) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -850,7 +870,24 @@ extern "C" int gv_bn_relu_bwd_sums_grouped(const float* dy, int32_t dy_ld, const
     if (splits > 256) splits = 256;
     launch_grouped_sums<1>(dim3((c + 63) / 64, splits, num_groups), st,
                            (c & 3) == 0 && vec_ok(z, z_ld) && vec_ok(dy, dy_ld) && vec_ok(y, y_ld), z, z_ld, dy, dy_ld, y,
-                           y_ld, mean, inv, nb, hw, c, num_groups, accum);
+                           y_ld, mean, inv, nb, hw, c, num_groups, accum, scale, shift);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+static int bn_bwd_apply_f32(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld, const float* z, int32_t z_ld,
+                            const float* mean, const float* inv, const float* gamma, const int32_t* counts, int32_t nb,
+                            int32_t hw, int32_t c, int32_t num_groups, const double* accum, float* dz, int32_t dz_ld,
+                            float* dbeta, float* dgamma, const float* scale, const float* shift, int accumulate,
+                            void* stream) {
+    if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
+    if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_apply_grouped_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, dy, dy_ld,
+                       y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw, c, num_groups, dz, dz_ld, scale, shift, accumulate);
+    if (dbeta || dgamma)
+        hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
+                           dgamma);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
@@ -860,16 +897,8 @@ extern "C" int gv_bn_relu_bwd_apply_grouped(const float* dy, int32_t dy_ld, cons
                                             const float* gamma, const int32_t* counts, int32_t nb, int32_t hw,
                                             int32_t c, int32_t num_groups, const double* accum, float* dz,
                                             int32_t dz_ld, float* dbeta, float* dgamma, void* stream) {
-    if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
-    if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_apply_grouped_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, dy, dy_ld,
-                       y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw, c, num_groups, dz, dz_ld);
-    if (dbeta || dgamma)
-        hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,
-                           dgamma);
-    GV_LAUNCH_CHECK();
-    return GV_OK;
+    return bn_bwd_apply_f32(dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, counts, nb, hw, c, num_groups, accum, dz, dz_ld,
+                            dbeta, dgamma, nullptr, nullptr, 1, stream);
 }
 
 extern "C" int gv_bn_relu_bwd_grouped(const float* dy, int32_t dy_ld, const float* y, int32_t y_ld,
@@ -1178,9 +1207,9 @@ extern "C" int gv_bn_relu_bwd_sums_grouped_t(const void* dy, int32_t dy_ld, cons
     const bool zeroed = (dtype & GV_ACCUM_ZEROED) != 0;
     dtype &= ~GV_ACCUM_ZEROED;
     if (dtype == GV_F32) {
-        if (scale && !y) return GV_E_UNSUPPORTED;                // the fp32 step reads its ReLU mask from y
-        return gv_bn_relu_bwd_sums_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
-                                           inv, nb, hw, c, num_groups, accum, stream);
+        if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
+        return bn_bwd_sums_f32((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean, inv, nb, hw, c,
+                               num_groups, accum, scale, shift, stream);
     }
     if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
     if (!lp_type(dtype)) return GV_E_UNSUPPORTED;
@@ -1199,10 +1228,10 @@ extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, con
                                               int32_t dz_ld, float* dbeta, float* dgamma, const float* scale,
                                               const float* shift, int32_t accumulate, int32_t dtype, void* stream) {
     if (dtype == GV_F32) {
-        if ((scale && !y) || !accumulate) return GV_E_UNSUPPORTED;   // the fp32 step: mask from y, dz += only
-        return gv_bn_relu_bwd_apply_grouped((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean,
-                                            inv, gamma, counts, nb, hw, c, num_groups, accum, (float*)dz, dz_ld, dbeta,
-                                            dgamma, stream);
+        if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
+        return bn_bwd_apply_f32((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean, inv, gamma,
+                                counts, nb, hw, c, num_groups, accum, (float*)dz, dz_ld, dbeta, dgamma, scale, shift,
+                                accumulate, stream);
     }
     if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
     if (!lp_type(dtype)) return GV_E_UNSUPPORTED;

