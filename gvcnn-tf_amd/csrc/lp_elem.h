@@ -40,4 +40,25 @@ __device__ __forceinline__ void store_v(unsigned short* p, const float (&f)[8]) 
     else *p = down<T>(f[0]);
 }
 
+// the same access pattern on fp32 storage (VEC = 4: one 16-byte load), so kernels templated on the pointer type serve
+// both storages
+template <typename T, int VEC>
+__device__ __forceinline__ void load_v(const float* p, float (&f)[8]) {
+    if constexpr (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    } else {
+        f[0] = *p;
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_v(float* p, const float (&f)[8]) {
+    if constexpr (VEC == 4) {
+        f32x4 v = {f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+        *p = f[0];
+    }
+}
+
 }  // namespace gvlp_elem

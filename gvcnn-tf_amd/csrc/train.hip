@@ -948,18 +948,23 @@ extern "C" int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
     return GV_OK;
 }
 
+static int g_pool_scatter = 0;
+extern "C" void gv_pool2d_bwd_set_scatter(int on) { g_pool_scatter = on; }
+
 extern "C" int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t dy_ld, void* dx,
                              int32_t dx_ld, void* stream) {
     if (!d || !dy || !dx) return GV_E_BADARG;
     const int mode = d->mode & ~GV_POOL_BWD_STORE;
     if ((mode == GV_POOL_MAX && !x) || (mode != GV_POOL_MAX && mode != GV_POOL_AVG)) return GV_E_BADARG;
-    if ((d->mode & GV_POOL_BWD_STORE) && d->dtype == GV_F32) return GV_E_UNSUPPORTED;   // the fp32 kernel scatters (+=)
-    if (d->dtype == GV_BF16 || d->dtype == GV_F16)
+    // one deterministic gather kernel family for all storage types (train_lp.hip); the atomic-scatter fp32 kernel
+    // (pool2d_bwd_f32) is kept behind the tuning hook gv_pool2d_bwd_set_scatter for comparison
+    if (d->dtype == GV_BF16 || d->dtype == GV_F16 || (d->dtype == GV_F32 && !g_pool_scatter))
         return gvlp::pool2d_bwd(d, x, dy, dy_ld, dx, dx_ld, (hipStream_t)stream);
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
+    if (d->mode & GV_POOL_BWD_STORE) return GV_E_UNSUPPORTED;    // the scatter kernel only adds
     hipLaunchKernelGGL(pool2d_bwd_f32, dim3(grid_for((int64_t)d->nb * d->oh * d->ow * d->c)), dim3(256), 0,
                        (hipStream_t)stream, (const float*)x, d->x_ld, (const float*)dy, dy_ld, d->nb, d->ih, d->iw, d->c,
-                       d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->mode, (float*)dx, dx_ld);
+                       d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, mode, (float*)dx, dx_ld);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }

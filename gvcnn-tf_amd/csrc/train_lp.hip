@@ -496,11 +496,11 @@ inline int stream_splits(int nb, int hw, int G, int c) {
 // Pool backward as a GATHER over the input pixels (no atomics: 16-bit storage has none worth using, and the result
 // is deterministic): an input pixel visits the windows that contain it.  max: it receives a window's gradient when
 // it is that window's first maximum in scan order (tf MaxPoolGrad / torch); avg: dy / #valid taps of every window.
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __restrict__ x, int x_ld,
-                                                     const unsigned short* __restrict__ dy, int dy_ld, int nb, int ih,
+template <typename E, typename T, int VEC>
+__global__ __launch_bounds__(256) void pool2d_bwd_lp(const E* __restrict__ x, int x_ld,
+                                                     const E* __restrict__ dy, int dy_ld, int nb, int ih,
                                                      int iw, int c, int kh, int kw, int stride, int pad_t, int pad_l,
-                                                     int oh, int ow, int mode, int store, unsigned short* __restrict__ dx,
+                                                     int oh, int ow, int mode, int store, E* __restrict__ dx,
                                                      int dx_ld) {
     const int cg = c / VEC;
     const int64_t total = (int64_t)nb * ih * iw * cg;
@@ -588,12 +588,12 @@ __global__ __launch_bounds__(256) void pool2d_bwd_lp(const unsigned short* __res
 // 2b..2b+1) x 8 channels and visits the four windows (a-1..a, b-1..b) that touch them ONCE each — argmax per window
 // from its nine taps, then the gradient goes to whichever of the thread's pixels is that tap: 11 loads per input pixel
 // instead of the 23 of the per-pixel gather above.
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* __restrict__ x, int x_ld,
-                                                         const unsigned short* __restrict__ dy, int dy_ld, int nb,
+template <typename E, typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const E* __restrict__ x, int x_ld,
+                                                         const E* __restrict__ dy, int dy_ld, int nb,
                                                          int ih, int iw, int c, int oh, int ow, int store,
-                                                         unsigned short* __restrict__ dx, int dx_ld) {
-    const int cg = c / 8, ah = (ih + 1) / 2, aw = (iw + 1) / 2;
+                                                         E* __restrict__ dx, int dx_ld) {
+    const int cg = c / VEC, ah = (ih + 1) / 2, aw = (iw + 1) / 2;
     const int64_t total = (int64_t)nb * ah * aw * cg;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* _
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum[k][e] = 0.f;
+            for (int e = 0; e < VEC; ++e) sum[k][e] = 0.f;
 #pragma unroll
         for (int wy = 0; wy < 2; ++wy) {
 #pragma unroll
@@ -617,18 +617,18 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* _
                 float best[8];
                 int arg[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+                for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; arg[e] = -1; }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int yy = 2 * oy + tap / 3, xx = 2 * ox + tap % 3;      // in bounds: VALID padding
                     float v[8];
-                    load_v<T, 8>(x + ((int64_t)(n * ih + yy) * iw + xx) * x_ld + q * 8, v);
+                    load_v<T, VEC>(x + ((int64_t)(n * ih + yy) * iw + xx) * x_ld + q * VEC, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
+                    for (int e = 0; e < VEC; ++e)
                         if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = tap; }
                 }
                 float g[8];
-                load_v<T, 8>(dy + ((int64_t)(n * oh + oy) * ow + ox) * dy_ld + q * 8, g);
+                load_v<T, VEC>(dy + ((int64_t)(n * oh + oy) * ow + ox) * dy_ld + q * VEC, g);
                 // the thread's pixel (2a+py, 2b+px) is tap (2a+py-2oy, 2b+px-2ox) = (py + 2*(1-wy), px + 2*(1-wx))
 #pragma unroll
                 for (int py = 0; py < 2; ++py)
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* _
                         if (tr > 2 || tc > 2) continue;
                         const int tap = tr * 3 + tc;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) sum[2 * py + px][e] += arg[e] == tap ? g[e] : 0.f;
+                        for (int e = 0; e < VEC; ++e) sum[2 * py + px][e] += arg[e] == tap ? g[e] : 0.f;
                     }
             }
         }
@@ -648,17 +648,17 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_lp(const unsigned short* _
             for (int px = 0; px < 2; ++px) {
                 const int iy = 2 * a + py, ix = 2 * b + px;
                 if (iy >= ih || ix >= iw) continue;
-                unsigned short* dp = dx + ((int64_t)(n * ih + iy) * iw + ix) * dx_ld + q * 8;
+                E* dp = dx + ((int64_t)(n * ih + iy) * iw + ix) * dx_ld + q * VEC;
                 float d[8];
                 if (store) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) d[e] = 0.f;
+                    for (int e = 0; e < VEC; ++e) d[e] = 0.f;
                 } else {
-                    load_v<T, 8>(dp, d);
+                    load_v<T, VEC>(dp, d);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d[e] += sum[2 * py + px][e];
-                store_v<T, 8>(dp, d);
+                for (int e = 0; e < VEC; ++e) d[e] += sum[2 * py + px][e];
+                store_v<T, VEC>(dp, d);
             }
     }
 }
@@ -1316,31 +1316,42 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
 }
 
 int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, void* dx, int dx_ld, hipStream_t st) {
+    const int store = (d->mode & GV_POOL_BWD_STORE) ? 1 : 0;
+    const int mode = d->mode & ~GV_POOL_BWD_STORE;
+    const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
+    const bool m3s2g = mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
+                       d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
+    const int64_t nblk2 = (int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2);
+#define GV_POOL_BWD(E, T, VEC, XS, G_, O_)                                                                              \
+    do {                                                                                                                \
+        if (m3s2g && VEC > 1)                                                                                           \
+            hipLaunchKernelGGL((maxpool3s2_bwd_lp<E, T, VEC>), dim3(grid_for(nblk2 * (d->c / VEC))), dim3(256), 0, st, XS, \
+                               d->x_ld, G_, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, store, O_, dx_ld);          \
+        else                                                                                                            \
+            hipLaunchKernelGGL((pool2d_bwd_lp<E, T, VEC>), dim3(grid_for(npix * (d->c / VEC))), dim3(256), 0, st, XS,      \
+                               d->x_ld, G_, dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t,        \
+                               d->pad_l, d->oh, d->ow, mode, store, O_, dx_ld);                                         \
+        GV_LAUNCH_CHECK();                                                                                              \
+        return GV_OK;                                                                                                   \
+    } while (0)
+    if (d->dtype == GV_F32) {                                    // the same gather on fp32 storage (4 channels per thread)
+        const float* xs = (const float*)x;
+        const float* g = (const float*)dy;
+        float* o = (float*)dx;
+        const bool v4 = (d->c % 4 == 0) && (xs == nullptr || (gv_aligned16(xs) && d->x_ld % 4 == 0)) && gv_aligned16(g) &&
+                        dy_ld % 4 == 0 && gv_aligned16(o) && dx_ld % 4 == 0;
+        if (v4) GV_POOL_BWD(float, float, 4, xs, g, o);
+        GV_POOL_BWD(float, float, 1, xs, g, o);
+    }
     const unsigned short* xs = (const unsigned short*)x;
     const unsigned short* g = (const unsigned short*)dy;
     unsigned short* o = (unsigned short*)dx;
     const bool v = (d->c % 8 == 0) && vec8(xs, d->x_ld) && vec8(g, dy_ld) && vec8(o, dx_ld);
-    const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
-    const int store = (d->mode & GV_POOL_BWD_STORE) ? 1 : 0;
-    const int mode = d->mode & ~GV_POOL_BWD_STORE;
-    const bool m3s2 = v && mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
-                      d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
     GV_LP_DISPATCH(d->dtype, {
-        if (m3s2)
-            hipLaunchKernelGGL((maxpool3s2_bwd_lp<T>),
-                               dim3(grid_for((int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2) * (d->c / 8))), dim3(256),
-                               0, st, xs, d->x_ld, g, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, store, o, dx_ld);
-        else if (v)
-            hipLaunchKernelGGL((pool2d_bwd_lp<T, 8>), dim3(grid_for(npix * (d->c / 8))), dim3(256), 0, st, xs, d->x_ld, g,
-                               dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh,
-                               d->ow, mode, store, o, dx_ld);
-        else
-            hipLaunchKernelGGL((pool2d_bwd_lp<T, 1>), dim3(grid_for(npix * d->c)), dim3(256), 0, st, xs, d->x_ld, g, dy_ld,
-                               d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow,
-                               mode, store, o, dx_ld);
-        GV_LAUNCH_CHECK();
-        return GV_OK;
+        if (v) GV_POOL_BWD(unsigned short, T, 8, xs, g, o);
+        GV_POOL_BWD(unsigned short, T, 1, xs, g, o);
     });
+#undef GV_POOL_BWD
 }
 
 int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,

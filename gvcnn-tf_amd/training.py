@@ -807,11 +807,8 @@ class TrainGVCNN:
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
-            if self._claim(x):                                # first contribution: the 16-bit gather kernels store,
-                if self.es == 2:                              # the fp32 kernel scatters with atomics into zeros
-                    d.mode |= _lib.GV_POOL_BWD_STORE
-                else:
-                    self._zero_grad_of(x)
+            if self._claim(x):                                # first contribution: the gather kernels store
+                d.mode |= _lib.GV_POOL_BWD_STORE
             _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
                                          x.ld, _st()), "pool_bwd " + op["name"])
 

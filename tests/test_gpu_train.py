@@ -95,6 +95,19 @@ def test_pool_backward(k, stride, padding, mode):
     dx = torch.zeros_like(xd)
     _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dyd.data_ptr(), 16, dx.data_ptr(), 16, st()), "pool_bwd")
     close(dx.cpu(), x.grad, 1e-5)
+    # store form over garbage, and the first-generation atomic-scatter kernel behind its hook: same gradient
+    d.mode |= _lib.GV_POOL_BWD_STORE
+    dxs = torch.full_like(xd, float("nan"))
+    _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dyd.data_ptr(), 16, dxs.data_ptr(), 16, st()), "pool_bwd")
+    assert torch.equal(dxs, dx)
+    d.mode &= ~_lib.GV_POOL_BWD_STORE
+    lib().gv_pool2d_bwd_set_scatter(1)
+    try:
+        dxa = torch.zeros_like(xd)
+        _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dyd.data_ptr(), 16, dxa.data_ptr(), 16, st()), "pool_bwd")
+    finally:
+        lib().gv_pool2d_bwd_set_scatter(0)
+    close(dxa.cpu(), x.grad, 1e-5)
 
 
 @pytest.mark.parametrize("k,stride,padding,cin,cout", [((3, 3), 1, "SAME", 32, 48), ((3, 3), 2, "VALID", 32, 64),
