@@ -26,8 +26,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(ROOT, "include", "gvcnn_hip.h"), os.path.join(CSRC, "gv_common.h"),
-               os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "lowp.h")]
+    # every header is a dependency of every object (a header-only edit must rebuild: lp_elem.h was once missing here)
+    headers = [os.path.join(ROOT, "include", "gvcnn_hip.h")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
