@@ -40,6 +40,26 @@ __device__ __forceinline__ void store_v(unsigned short* p, const float (&f)[8]) 
     else *p = down<T>(f[0]);
 }
 
+// one 16-byte quad of storage elements <-> fp32 registers: 8 elements of a 16-bit type T, or 4 floats (E = float)
+template <typename E, typename T>
+__device__ __forceinline__ void unpackq(u32x4 v, float (&f)[8]) {
+    if constexpr (sizeof(E) == 2) {
+        unpack8<T>(v, f);
+    } else {
+        const f32x4 w = __builtin_bit_cast(f32x4, v);
+        f[0] = w[0]; f[1] = w[1]; f[2] = w[2]; f[3] = w[3];
+    }
+}
+template <typename E, typename T>
+__device__ __forceinline__ u32x4 packq(const float (&f)[8]) {
+    if constexpr (sizeof(E) == 2) {
+        return pack8<T>(f);
+    } else {
+        const f32x4 w = {f[0], f[1], f[2], f[3]};
+        return __builtin_bit_cast(u32x4, w);
+    }
+}
+
 // the same access pattern on fp32 storage (VEC = 4: one 16-byte load), so kernels templated on the pointer type serve
 // both storages
 template <typename T, int VEC>

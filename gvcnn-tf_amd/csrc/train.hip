@@ -803,6 +803,10 @@ extern "C" int gv_bn_sums_grouped(const float* z, int32_t nb, int32_t hw, int32_
         if (splits < want) splits = (int)(want < most ? want : most);
     }
     if (splits > 256) splits = 256;
+    // (the streaming kernels of train_lp.hip, instantiated for fp32, when the shape is 16-byte vectorisable)
+    if (gvlp::grouped_sums(GV_F32, 0, z, z_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nb, hw, c,
+                           num_groups, splits, accum, st) == GV_OK)
+        return GV_OK;
     launch_grouped_sums<0>(dim3((c + 63) / 64, splits, num_groups), st, (c & 3) == 0 && vec_ok(z, z_ld), z, z_ld,
                            nullptr, 0, nullptr, 0, nullptr, nullptr, nb, hw, c, num_groups, accum);
     GV_LAUNCH_CHECK();
@@ -837,6 +841,9 @@ extern "C" int gv_scale_shift_act_grouped(const float* x, int32_t nb, int32_t hw
     if ((c & 3) || (x_ld & 3) || (y_ld & 3) || !gv_aligned16(x) || !gv_aligned16(y) || !gv_aligned16(scale) ||
         !gv_aligned16(shift))
         return GV_E_ALIGN;
+    if (gvlp::scale_shift_act_grouped(GV_F32, x, nb, hw, c, x_ld, scale, shift, num_groups, relu, y, y_ld,
+                                      (hipStream_t)stream) == GV_OK)
+        return GV_OK;
     hipLaunchKernelGGL(scale_shift_act_grouped_f32, dim3(grid_for((int64_t)nb * hw * (c / 4))), dim3(256), 0,
                        (hipStream_t)stream, x, nb, hw, c, x_ld, scale, shift, num_groups, relu, y, y_ld);
     GV_LAUNCH_CHECK();
@@ -868,6 +875,9 @@ static int bn_bwd_sums_f32(const float* dy, int32_t dy_ld, const float* y, int32
         if (splits < want) splits = (int)(want < most ? want : most);
     }
     if (splits > 256) splits = 256;
+    if (gvlp::grouped_sums(GV_F32, 1, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, shift, nb, hw, c, num_groups, splits,
+                           accum, st) == GV_OK)
+        return GV_OK;
     launch_grouped_sums<1>(dim3((c + 63) / 64, splits, num_groups), st,
                            (c & 3) == 0 && vec_ok(z, z_ld) && vec_ok(dy, dy_ld) && vec_ok(y, y_ld), z, z_ld, dy, dy_ld, y,
                            y_ld, mean, inv, nb, hw, c, num_groups, accum, scale, shift);
@@ -883,6 +893,12 @@ static int bn_bwd_apply_f32(const float* dy, int32_t dy_ld, const float* y, int3
     if (!dy || !z || !mean || !inv || !counts || !accum || !dz) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || num_groups <= 0 || nb % num_groups != 0) return GV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    {
+        bool done = false;
+        if (gvlp::bn_bwd_apply_grouped(GV_F32, dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, scale, shift,
+                                       accumulate, nb, hw, c, num_groups, dz, dz_ld, dbeta, dgamma, &done, st) == GV_OK)
+            return GV_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_apply_grouped_f32, dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, dy, dy_ld,
                        y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, nb, hw, c, num_groups, dz, dz_ld, scale, shift, accumulate);
     if (dbeta || dgamma)
@@ -1193,7 +1209,7 @@ extern "C" int gv_bn_finalize_apply_grouped_t(const double* accum, const int32_t
                                               float* shift, int32_t dtype, void* stream) {
     if (!accum || !counts || !beta || !x || !y || !mean || !var || !inv || !scale || !shift) return GV_E_BADARG;
     if (nb <= 0 || hw <= 0 || c <= 0 || x_ld < c || y_ld < c || num_groups <= 0) return GV_E_BADARG;
-    if (lp_type(dtype)) {
+    if (lp_type(dtype) || dtype == GV_F32) {
         const int rc = gvlp::bn_finalize_apply_grouped(dtype, accum, counts, gamma, beta, eps, x, nb, hw, c, x_ld,
                                                        num_groups, relu, y, y_ld, mean, var, inv, scale, shift,
                                                        (hipStream_t)stream);

@@ -223,17 +223,17 @@ struct GroupWalk {
     }
 };
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __restrict__ z, int z_ld,
-                                                       const unsigned short* __restrict__ dy, int dy_ld,
-                                                       const unsigned short* __restrict__ y, int y_ld,
+template <typename E, typename T, int MODE>
+__global__ __launch_bounds__(256) void grouped_sums_v8(const E* __restrict__ z, int z_ld,
+                                                       const E* __restrict__ dy, int dy_ld,
+                                                       const E* __restrict__ y, int y_ld,
                                                        const float* __restrict__ mean, const float* __restrict__ inv,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int nb, int hw, int c, int G,
                                                        double* __restrict__ acc) {
-    constexpr int PL = 32, U = 4;
-    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int ch = blockIdx.x * 64 + cl * 8;
+    constexpr int NE = 16 / sizeof(E), TPC = 64 / NE, PL = 256 / TPC, U = 4;   // elements per quad, channel threads, pixel lanes
+    const int cl = threadIdx.x % TPC, pl = threadIdx.x / TPC;
+    const int ch = blockIdx.x * 64 + cl * NE;
     const int g = blockIdx.z;
     const int nimg = (nb - g + G - 1) / G;
     const int npix = nimg * hw;                                  // < 2^31 (checked by the launcher)
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
     const int p1 = p0 + per < npix ? p0 + per : npix;
     double s0[8], s1[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.0;
+    for (int e = 0; e < NE; ++e) s0[e] = s1[e] = 0.0;
     if (ch < c && p0 + pl < p1) {
         float mu[8], iv[8], sc[8], sh[8];
         const bool rmask = MODE == 1 && !y && scale;          // ReLU mask recomputed from z: y = z*scale + shift > 0
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < NE; ++e) {
             mu[e] = MODE == 1 ? mean[g * c + ch + e] : 0.f;
             iv[e] = MODE == 1 ? inv[g * c + ch + e] : 0.f;
             sc[e] = rmask ? scale[g * c + ch + e] : 0.f;
@@ -259,15 +259,33 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
         float f0[8], f1[8];
         auto fold = [&]() {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s0[e] += f0[e]; s1[e] += f1[e]; f0[e] = f1[e] = 0.f; }
+            for (int e = 0; e < NE; ++e) { s0[e] += f0[e]; s1[e] += f1[e]; f0[e] = f1[e] = 0.f; }
         };
         auto add = [&](const u32x4 zq, const u32x4 gq, const u32x4 yq) {
             float zv[8], gv[8], yv[8];
-            if (MODE != 2) unpack8<T>(zq, zv);
-            if (MODE != 0) unpack8<T>(gq, gv);
-            if (MODE == 1 && y) unpack8<T>(yq, yv);
+            if (MODE != 2) unpackq<E, T>(zq, zv);
+            if (MODE != 0) unpackq<E, T>(gq, gv);
+            if (MODE == 1 && y) unpackq<E, T>(yq, yv);
+            if constexpr (sizeof(E) == 4) {                      // fp32 storage: straight into fp64 (fp32 runs would cost
+#pragma unroll                                                   // 1e-7 of the statistics; 16-bit inputs lose nothing)
+                for (int e = 0; e < NE; ++e) {
+                    if (MODE == 0) {
+                        s0[e] += zv[e];
+                        s1[e] += (double)zv[e] * zv[e];
+                    } else if (MODE == 1) {
+                        float gr = gv[e];
+                        if (y && !(yv[e] > 0.f)) gr = 0.f;
+                        if (rmask && !(fmaf(zv[e], sc[e], sh[e]) > 0.f)) gr = 0.f;
+                        s0[e] += gr;
+                        s1[e] += (double)gr * ((zv[e] - mu[e]) * iv[e]);
+                    } else {
+                        s0[e] += gv[e];
+                    }
+                }
+                return;
+            }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 if (MODE == 0) {
                     f0[e] += zv[e];
                     f1[e] = fmaf(zv[e], zv[e], f1[e]);
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
             }
         };
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f0[e] = f1[e] = 0.f;
+        for (int e = 0; e < NE; ++e) f0[e] = f1[e] = 0.f;
         int it = 0;
         for (; it + U <= n_it; it += U) {
             u32x4 zq[U], gq[U], yq[U];
@@ -308,16 +326,16 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const unsigned short* __r
         }
         fold();
     }
-    __shared__ double red[2][32][64];
+    __shared__ double red[2][PL][64];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        red[0][pl][cl * 8 + e] = s0[e];
-        red[1][pl][cl * 8 + e] = s1[e];
+    for (int e = 0; e < NE; ++e) {
+        red[0][pl][cl * NE + e] = s0[e];
+        red[1][pl][cl * NE + e] = s1[e];
     }
     __syncthreads();
     if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < c) {
         double a = 0.0, b = 0.0;
-        for (int q = 0; q < 32; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
+        for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
         atomicAdd(&acc[o], a);
         if (MODE != 2) atomicAdd(&acc[o + 1], b);
@@ -338,19 +356,19 @@ struct BnExtra {
     float *dbeta, *dgamma;
 };
 
-template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __restrict__ x, int x_ld,
-                                                    const unsigned short* __restrict__ dy, int dy_ld,
-                                                    const unsigned short* __restrict__ yact, int y_ld,
+template <typename E, typename T, bool BWD>
+__global__ __launch_bounds__(256) void bn_stream_v8(const E* __restrict__ x, int x_ld,
+                                                    const E* __restrict__ dy, int dy_ld,
+                                                    const E* __restrict__ yact, int y_ld,
                                                     const float* __restrict__ p0f, const float* __restrict__ p1f,
                                                     const float* __restrict__ gamma, const double* __restrict__ acc,
                                                     const int* __restrict__ counts, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int accumulate, int nb, int hw,
-                                                    int c, int G, int relu, unsigned short* __restrict__ out,
+                                                    int c, int G, int relu, E* __restrict__ out,
                                                     int out_ld, BnExtra ex) {
-    constexpr int PL = 32, U = 4;
-    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int ch = blockIdx.x * 64 + cl * 8;
+    constexpr int NE = 16 / sizeof(E), TPC = 64 / NE, PL = 256 / TPC, U = 4;   // elements per quad, channel threads, pixel lanes
+    const int cl = threadIdx.x % TPC, pl = threadIdx.x / TPC;
+    const int ch = blockIdx.x * 64 + cl * NE;
     const int g = blockIdx.z;
     const int nimg = (nb - g + G - 1) / G;
     const int npix = nimg * hw;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
     float A[8], B[8], Cc[8], sc[8], sh[8];
     const bool rmask = BWD && !yact && scale;                    // ReLU mask recomputed from z (x here)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int gi = g * c + ch + e;
         sc[e] = rmask ? scale[gi] : 0.f;
         sh[e] = rmask ? shift[gi] : 0.f;
@@ -414,8 +432,8 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
             B[e] = -A[e] * iv * s2 * rm;
             Cc[e] = A[e] * (mu * iv * s2 - s1) * rm;
         } else if (ex.fin_acc) {                                 // finalized above
-            A[e] = sA[cl * 8 + e];
-            B[e] = sB[cl * 8 + e];
+            A[e] = sA[cl * NE + e];
+            B[e] = sB[cl * NE + e];
         } else {                                                 // p0f = scale, p1f = shift
             A[e] = p0f[gi];
             B[e] = p1f[gi];
@@ -426,17 +444,17 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
     const int n_it = (p1 - p0 - pl + PL - 1) / PL;
     auto one = [&](int64_t pix, const u32x4 xq, const u32x4 gq, const u32x4 yq, const u32x4 oq) {
         float xv[8], o[8];
-        unpack8<T>(xq, xv);
+        unpackq<E, T>(xq, xv);
         if constexpr (BWD) {
             float gv[8], yv[8];
-            unpack8<T>(gq, gv);
-            if (accumulate) unpack8<T>(oq, o);
+            unpackq<E, T>(gq, gv);
+            if (accumulate) unpackq<E, T>(oq, o);
             else
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = 0.f;
-            if (yact) unpack8<T>(yq, yv);
+                for (int e = 0; e < NE; ++e) o[e] = 0.f;
+            if (yact) unpackq<E, T>(yq, yv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 float gg = gv[e];
                 if (yact && !(yv[e] > 0.f)) gg = 0.f;
                 if (rmask && !(fmaf(xv[e], sc[e], sh[e]) > 0.f)) gg = 0.f;
@@ -444,12 +462,12 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const unsigned short* __rest
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 o[e] = fmaf(xv[e], A[e], B[e]);
                 if (relu) o[e] = fmaxf(o[e], 0.f);
             }
         }
-        *reinterpret_cast<u32x4*>(out + pix * out_ld + ch) = pack8<T>(o);
+        *reinterpret_cast<u32x4*>(out + pix * out_ld + ch) = packq<E, T>(o);
     };
     int it = 0;
     for (; it + U <= n_it; it += U) {
@@ -1044,6 +1062,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
 }
 
 inline bool vec8(const void* p, int ld) { return p == nullptr || (gv_aligned16(p) && (ld % 8) == 0); }
+inline bool vec4(const void* p, int ld) { return p == nullptr || (gv_aligned16(p) && (ld % 4) == 0); }
 
 template <typename T>
 int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy, int dy_ld, const unsigned short* y,
@@ -1053,7 +1072,7 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
     const dim3 grid((c + 63) / 64, splits, G);
     if (v && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll) {
 #define GV_SUMS8(MODE)                                                                                               \
-        hipLaunchKernelGGL((grouped_sums_v8<T, MODE>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, \
+        hipLaunchKernelGGL((grouped_sums_v8<unsigned short, T, MODE>), grid, dim3(256), 0, st, z, z_ld, dy, dy_ld, y, y_ld, mean, inv, scale, \
                            shift, nb, hw, c, G, acc)
         if (mode == 0) GV_SUMS8(0);
         else if (mode == 1) GV_SUMS8(1);
@@ -1243,6 +1262,22 @@ int accumulate(int dtype, const void* src, int src_ld, void* dst, int dst_ld, in
 int grouped_sums(int dtype, int mode, const void* z, int z_ld, const void* dy, int dy_ld, const void* y, int y_ld,
                  const float* mean, const float* inv, const float* scale, const float* shift, int nb, int hw, int c,
                  int G, int splits, double* acc, hipStream_t st) {
+    if (dtype == GV_F32) {                                       // the same streaming kernels on fp32 storage (4 per quad)
+        if (!((c % 4 == 0) && vec4(z, z_ld) && vec4(dy, dy_ld) && vec4(y, y_ld) &&
+              (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll))
+            return GV_E_UNSUPPORTED;
+        const dim3 grid((c + 63) / 64, splits, G);
+        const float *zf = (const float*)z, *df = (const float*)dy, *yf = (const float*)y;
+#define GV_SUMS32(MODE)                                                                                              \
+        hipLaunchKernelGGL((grouped_sums_v8<float, float, MODE>), grid, dim3(256), 0, st, zf, z_ld, df, dy_ld, yf, y_ld,   \
+                           mean, inv, scale, shift, nb, hw, c, G, acc)
+        if (mode == 0) GV_SUMS32(0);
+        else if (mode == 1) GV_SUMS32(1);
+        else GV_SUMS32(2);
+#undef GV_SUMS32
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     GV_LP_DISPATCH(dtype, return sums_t<T>(mode, (const unsigned short*)z, z_ld, (const unsigned short*)dy, dy_ld,
                                            (const unsigned short*)y, y_ld, mean, inv, scale, shift, nb, hw, c, G, splits,
                                            acc, st));
@@ -1250,12 +1285,22 @@ int grouped_sums(int dtype, int mode, const void* z, int z_ld, const void* dy, i
 
 int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int x_ld, const float* scale,
                             const float* shift, int G, int relu, void* y, int y_ld, hipStream_t st) {
+    if (dtype == GV_F32) {
+        if (!((c % 4 == 0) && vec4(x, x_ld) && vec4(y, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll))
+            return GV_E_UNSUPPORTED;
+        hipLaunchKernelGGL((bn_stream_v8<float, float, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0,
+                           st, (const float*)x, x_ld, (const float*)nullptr, 0, (const float*)nullptr, 0, scale, shift,
+                           (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, 0, nb, hw, c, G, relu, (float*)y, y_ld, BnExtra{});
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     const unsigned short* xs = (const unsigned short*)x;
     unsigned short* ys = (unsigned short*)y;
     const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
     GV_LP_DISPATCH(dtype, {
         if (v)
-            hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_stream_v8<unsigned short, T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
                                xs, x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, scale, shift,
                                (const float*)nullptr, (const double*)nullptr, (const int*)nullptr, (const float*)nullptr,
                                (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld, BnExtra{});
@@ -1271,15 +1316,25 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
 int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, const float* gamma, const float* beta,
                               float eps, const void* x, int nb, int hw, int c, int x_ld, int G, int relu, void* y,
                               int y_ld, float* mean, float* var, float* inv, float* scale, float* shift, hipStream_t st) {
+    BnExtra ex{};
+    ex.fin_acc = acc; ex.beta = beta; ex.eps = eps;
+    ex.mean = mean; ex.var = var; ex.inv = inv; ex.scale_out = scale; ex.shift_out = shift;
+    if (dtype == GV_F32) {
+        if (!((c % 4 == 0) && vec4(x, x_ld) && vec4(y, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll))
+            return GV_E_UNSUPPORTED;
+        hipLaunchKernelGGL((bn_stream_v8<float, float, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0,
+                           st, (const float*)x, x_ld, (const float*)nullptr, 0, (const float*)nullptr, 0,
+                           (const float*)nullptr, (const float*)nullptr, gamma, (const double*)nullptr, counts,
+                           (const float*)nullptr, (const float*)nullptr, 0, nb, hw, c, G, relu, (float*)y, y_ld, ex);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     const unsigned short* xs = (const unsigned short*)x;
     unsigned short* ys = (unsigned short*)y;
     const bool v = (c % 8 == 0) && vec8(xs, x_ld) && vec8(ys, y_ld) && (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll;
     if (!v) return GV_E_UNSUPPORTED;
-    BnExtra ex{};
-    ex.fin_acc = acc; ex.beta = beta; ex.eps = eps;
-    ex.mean = mean; ex.var = var; ex.inv = inv; ex.scale_out = scale; ex.shift_out = shift;
     GV_LP_DISPATCH(dtype, {
-        hipLaunchKernelGGL((bn_stream_v8<T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st, xs,
+        hipLaunchKernelGGL((bn_stream_v8<unsigned short, T, false>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st, xs,
                            x_ld, (const unsigned short*)nullptr, 0, (const unsigned short*)nullptr, 0, (const float*)nullptr,
                            (const float*)nullptr, gamma, (const double*)nullptr, counts, (const float*)nullptr,
                            (const float*)nullptr, 0, nb, hw, c, G, relu, ys, y_ld, ex);
@@ -1292,6 +1347,20 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
                          const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
                          const float* scale, const float* shift, int accumulate, int nb, int hw, int c, int G, void* dz,
                          int dz_ld, float* dbeta, float* dgamma, bool* param_grads_done, hipStream_t st) {
+    if (dtype == GV_F32) {
+        *param_grads_done = false;
+        if (!((c % 4 == 0) && vec4(dy, dy_ld) && vec4(y, y_ld) && vec4(z, z_ld) && vec4(dz, dz_ld) &&
+              (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll))
+            return GV_E_UNSUPPORTED;
+        BnExtra ex32{};
+        ex32.dbeta = dbeta; ex32.dgamma = dgamma;
+        *param_grads_done = true;
+        hipLaunchKernelGGL((bn_stream_v8<float, float, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0,
+                           st, (const float*)z, z_ld, (const float*)dy, dy_ld, (const float*)y, y_ld, mean, inv, gamma, acc,
+                           counts, scale, shift, accumulate, nb, hw, c, G, 0, (float*)dz, dz_ld, ex32);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     const unsigned short* a = (const unsigned short*)dy;
     const unsigned short* b = (const unsigned short*)y;
     const unsigned short* zz = (const unsigned short*)z;
@@ -1303,7 +1372,7 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
     *param_grads_done = v;
     GV_LP_DISPATCH(dtype, {
         if (v)
-            hipLaunchKernelGGL((bn_stream_v8<T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
+            hipLaunchKernelGGL((bn_stream_v8<unsigned short, T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
                                zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c,
                                G, 0, o, dz_ld, ex);
         else
