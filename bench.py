@@ -7,16 +7,24 @@ Workload (BASELINE.json configs[1]): ModelNet-shaped synthetic views, 12 views x
 shape, Inception-v3 backbone, num_groups = 7, fp32, forward only (inference BatchNorm).  One "step"
 is one pass of the whole hot path — folded backbone over all views, scorer, device-side group
 assignment, view pooling + group fusion, classifier — over one batch that is already resident in
-HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed.run); per-GPU work is fixed
-(weak scaling): the batch is cut on shape boundaries, the ranks all-gather the scorer responses over
-RCCL (the batch-mean score of nets/model.py:146 is the only coupling), and each rank pools the shapes
-it owns; --exchange allgather additionally all-gathers the final view descriptors.
+HBM.  N > 1: one rank per GPU.  Launched by torch.distributed.run the process IS a rank (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment); typed as plain `python bench.py --gpus N` the process is
+only a launcher — it makes no GPU call, starts `python -m torch.distributed.run --nproc-per-node N
+bench.py <same flags>` as a child, relays rank 0's JSON line and exits with the child's code.
+Per-GPU work is fixed (weak scaling): the batch is cut on shape boundaries and the ranks all-gather
+the scorer responses over RCCL (the batch-mean score of nets/model.py:146 couples the shapes of a
+batch).  --exchange allgather (default; the form BASELINE.json north_star names) also all-gathers the
+final view descriptors so every rank pools all shapes; --exchange scores stops at the scorer
+responses and every rank pools the shapes it owns.  An N > 1 line times BOTH and reports the other
+one under "other_exchange".
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -53,9 +61,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shapes", type=int, default=32, help="shapes per GPU per step (x12 views)")
-    ap.add_argument("--exchange", default="scores", choices=["allgather", "scores"],
-                    help="multi-GPU: 'scores' exchanges only the scorer responses (each rank pools the shapes it "
-                         "owns); 'allgather' also all-gathers the final view descriptors (north_star form)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "scores"],
+                    help="multi-GPU: 'allgather' (north_star form) all-gathers the scorer responses AND the final view "
+                         "descriptors, every rank pools all shapes; 'scores' exchanges only the scorer responses (each "
+                         "rank pools the shapes it owns).  The N > 1 line reports the other one too (other_exchange)")
+    ap.add_argument("--no-other-exchange", action="store_true", help="N > 1: time only --exchange")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the in-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE children (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tile-cache", default=None, help="JSON file with measured per-launch tile choices")
@@ -89,7 +102,7 @@ def parse():
     return a
 
 
-def roofline(eng, x, math, iters=5):
+def roofline(eng, x, math, iters=5, traffic=None):
     """Per-launch hipEvent timing (on the launch stream) of every implicit-GEMM conv launch of one
     step; achieved = algorithmic conv FLOPs of the step / summed conv kernel time."""
     plan = eng.plan
@@ -108,52 +121,165 @@ def roofline(eng, x, math, iters=5):
             worst = (op["name"], ms, tf)
     achieved = flops / (t_ms * 1e-3) / 1e12
     kname, peak, how = MATH[math]
-    # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE /
-    # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh) — fp32 storage only
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_h_traffic_pmc.json")
-    if math in ("f32", "bf16x3", "bf16x2", "bf16x1") and os.path.exists(tpath):
-        try:
-            traffic = round(json.load(open(tpath))["conv_hbm_bytes_per_launch"])
-        except Exception:
-            traffic = None
     alg_bytes = sum(op["bytes"] for op in plan.ops if op["kind"] == "conv") / n
     return {"bound": "mfma", "kernel": "%s<*> (%d launches/step)" % (kname, n), "math": how,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": "HBM bytes per conv launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (profiles/r1_h_traffic_pmc.json)",
+            "frac": round(achieved / peak, 4),
+            "traffic": round(traffic["conv_hbm_bytes_per_launch"]) if traffic and "conv_hbm_bytes_per_launch" in traffic else None,
+            "traffic_note": (traffic or {}).get("note", "not measured (--no-traffic)"),
             "algorithmic_bytes_per_launch": round(alg_bytes),
             "flops_per_step": flops, "avg_launch_us": round(t_ms * 1e3 / n, 2),
             "conv_ms_per_step": round(t_ms, 3),
             "longest_launch": {"name": worst[0], "ms": round(worst[1], 4), "tflops": round(worst[2], 2)}}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(P, Hd, seconds):
-    """The CPU oracle (a port of the reference graph; TensorFlow itself cannot run here) timed on
-    this box's host cores on a bounded sample of the same workload: 1 shape x 12 views per pass,
-    reference-shaped (V sequential backbone calls, nets/model.py:129-141)."""
+    """The CPU oracle (a port of the reference graph; TensorFlow itself cannot run here) timed on this
+    box's host cores on a bounded sample of the same workload: configs[0] as written
+    (2 shapes x 6 views) and configs[1] reduced to 2 shapes, each REFERENCE-SHAPED (V sequential
+    backbone calls at batch N, nets/model.py:129-141) and FOLDED (one call at batch N*V).  `value` is the
+    reference-shaped rate on the bench line's own config; `cores` = the torch threads that gave it."""
     from oracle import model as OM
-    # 16 threads: on a 256-thread host the oneDNN convs of a batch-1 view stop scaling (and
-    # collapse from oversubscription) well before that; `cores` reports what was actually used.
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    x = torch.rand(1, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5
-    t0 = time.time()
-    OM.gvcnn_scores(x[:, :2].contiguous(), P, Hd, BACKBONE)               # page in, size the sample
-    per_pass = (time.time() - t0) * V / 2
-    max_passes = 1 if per_pass > seconds else 50     # a cold estimate; the loop below is time-bound
-    t0 = time.time()
-    passes = 0
-    while passes < max_passes:
-        OM.gvcnn(x, C, P, Hd, G, BACKBONE, num_bins=G)
-        passes += 1
-        if time.time() - t0 >= seconds:
-            break
-    dt = time.time() - t0
-    return {"value": round(passes * V / dt, 2), "unit": "views/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d passes of 1 shape x %d views %dx%d %s, torch-CPU fp32 oracle, %.1f s"
-                      % (passes, V, H, W, BACKBONE, dt)}
+    host = os.cpu_count() or 1
+    budget = max(seconds, 4.0)
+    t_all = time.time()
+
+    def rate(fn, views, max_s):
+        fn()                                            # page in
+        t0 = time.time()
+        n = 0
+        while True:
+            fn()
+            n += 1
+            if time.time() - t0 >= max_s or n >= 20:
+                break
+        return n * views / (time.time() - t0)
+
+    # thread count: oneDNN convolutions at these batch sizes stop scaling well below a 2-socket host's thread
+    # count; pick the best of a few on the folded c2 pass (short), report what was used
+    x2 = torch.rand(2, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5
+    cands = sorted({min(host, t) for t in (16, 32, 64, host)})
+    best_t, best_r, tried = cands[0], 0.0, {}
+    for t in cands:
+        torch.set_num_threads(t)
+        r = rate(lambda: OM.folded_backbone(x2, P, BACKBONE), 2 * V, budget * 0.08)
+        tried[str(t)] = round(r, 1)
+        if r > best_r:
+            best_t, best_r = t, r
+    torch.set_num_threads(best_t)
+    share = budget * 0.17
+    res = {}
+    res["c2_reduced_reference_shaped"] = rate(lambda: OM.gvcnn(x2, C, P, Hd, G, BACKBONE, num_bins=G), 2 * V, share)
+    res["c2_reduced_folded"] = rate(lambda: OM.folded_backbone(x2, P, BACKBONE), 2 * V, share)
+    if BACKBONE == "inception_v3" and H == 224:         # configs[0]: 2 shapes x 6 views, G = 5 (same weights)
+        x1 = x2[:, :6].contiguous()
+        Hd1 = OM.init_head_params(6, Hd["dense/kernel"].shape[0], Hd["dense_%d/kernel" % V].shape[0], C, seed=3)
+        res["c1_reference_shaped"] = rate(lambda: OM.gvcnn(x1, C, P, Hd1, 5, BACKBONE, num_bins=5), 12, share)
+        res["c1_folded"] = rate(lambda: OM.folded_backbone(x1, P, BACKBONE), 12, share)
+    return {"value": round(res["c2_reduced_reference_shaped"], 2), "unit": "views/s", "cores": best_t,
+            "host_cores": host, "cpu_model": cpu_model(), "kind": "port",
+            "views_per_sec": {k: round(v, 2) for k, v in res.items()},
+            "threads_tried_folded_views_per_sec": tried,
+            "sample": "torch-CPU fp32 oracle (oracle/model.py), %s %dx%d: configs[1] reduced to 2 shapes x %d views and "
+                      "configs[0] as written (2 shapes x 6 views), each reference-shaped (V sequential backbone calls at "
+                      "batch 2 + grouping head) and folded (one backbone call); %.1f s of CPU time in all"
+                      % (BACKBONE, H, W, V, time.time() - t_all)}
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher / profiler children (the parent makes no GPU call before they have exited)
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        return sck.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` typed without a launcher: start one rank per GPU as children
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1), relay rank 0's JSON line, exit with
+    the children's code.  This process never initialises the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["GVBENCH_SELF"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    for line in p.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
+def _is_conv_kernel(n):
+    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n
+
+
+def _pmc_rows(path, counter, steps):
+    import csv
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ends = [i for i, r in enumerate(rows) if "dense_f32" in r["Kernel_Name"]]   # one step ends with the classifier
+    start = ends[-steps - 1] + 1 if len(ends) > steps else 0
+    return rows[start:]
+
+
+def measure_traffic(a, tiles_path):
+    """HBM bytes per conv launch of THIS run's configuration, from two rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE need separate passes: 3 + 2 of the 4 TCC slots) over a short child run of this same file with the
+    same per-launch tiles; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), KiB units
+    (MI355X_MICROARCH.md, HBM).  The program sits directly behind `--`; the children run before this process
+    touches the GPU.  Returns a dict (or a dict with only a note when the profiler is unavailable)."""
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {"note": "rocprofv3 not found: traffic not measured"}
+    steps = 2
+    tmp = tempfile.mkdtemp(prefix="gvbench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    base = [sys.executable, os.path.abspath(__file__), "--pmc-child", "1", "--preset", a.preset, "--storage", a.storage,
+            "--math", a.math if a.storage == "f32" else "bf16x3", "--shapes", str(a.shapes), "--steps", str(steps),
+            "--warmup", "1", "--no-lanes", "--tile-cache", tiles_path]
+    out = {}
+    try:
+        for tag, counter in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, tag), "-o", tag,
+                   "--output-format", "csv", "--"] + base
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                               timeout=420)
+            files = glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"note": "rocprofv3 --pmc %s pass failed (rc %d): traffic not measured: %s"
+                                % (counter, r.returncode, r.stderr[-200:].replace("\n", " "))}
+            out[counter] = _pmc_rows(files[0], counter, steps)
+        fetch, write = out["FETCH_SIZE"], out["WRITE_SIZE"]
+        n_conv = sum(1 for r in fetch if _is_conv_kernel(r["Kernel_Name"]))
+        f_conv = sum(float(r["Counter_Value"]) for r in fetch if _is_conv_kernel(r["Kernel_Name"])) * 1024 * 2
+        w_conv = sum(float(r["Counter_Value"]) for r in write if _is_conv_kernel(r["Kernel_Name"])) * 1024
+        if n_conv == 0:
+            return {"note": "no conv dispatches in the PMC passes: traffic not measured"}
+        return {"conv_hbm_bytes_per_launch": (f_conv + w_conv) / n_conv, "conv_launches": n_conv, "steps": steps,
+                "conv_fetch_bytes_per_step": f_conv / steps, "conv_write_bytes_per_step": w_conv / steps,
+                "note": "measured in this run: HBM bytes per conv launch from two rocprofv3 --kernel-trace --pmc child "
+                        "passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE; KiB units) over %d steps of this same "
+                        "command with the same per-launch tiles, single launch lane" % steps}
+    except Exception as e:                                  # the profiler must never take the bench line down
+        return {"note": "traffic not measured: %s" % (str(e)[:200],)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def train_main(a, world, rank, dev):
@@ -219,16 +345,43 @@ def main():
     a = parse()
     BACKBONE, V, H, G, C = PRESETS[a.preset]
     W = H
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    if not under_launcher and a.gpus > 1:
+        sys.exit(launch_ranks(a))                       # no GPU call was made in this process
+    if world != a.gpus:
+        sys.exit("bench.py --gpus %d but the launcher started %d ranks" % (a.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+
+    # N = 1: tile tuning and the HBM-traffic PMC passes run as CHILDREN before this process touches the GPU
+    traffic = None
+    tmp_tiles = None
+    want_traffic = (world == 1 and not a.pmc_child and not a.train and not a.no_roofline and not a.no_traffic
+                    and not a.graph)
+    if want_traffic:
+        if not (a.tile_cache and os.path.exists(a.tile_cache)):
+            if not a.tile_cache:
+                import tempfile
+                fd, tmp_tiles = tempfile.mkstemp(prefix="gvbench_tiles_", suffix=".json", dir="/tmp")
+                os.close(fd)
+                os.unlink(tmp_tiles)
+                a.tile_cache = tmp_tiles
+            tune = [sys.executable, os.path.abspath(__file__), "--pmc-child", "tune", "--preset", a.preset, "--storage",
+                    a.storage, "--math", a.math if a.storage == "f32" else "bf16x3", "--shapes", str(a.shapes),
+                    "--tile-cache", a.tile_cache] + (["--no-lanes"] if a.no_lanes else [])
+            r = subprocess.run(tune, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600)
+            if r.returncode != 0 or not os.path.exists(a.tile_cache):
+                sys.stderr.write("bench.py: tuning child failed (rc %d), tuning in-process instead\n%s\n"
+                                 % (r.returncode, r.stderr[-500:]))
+        if os.path.exists(a.tile_cache):
+            traffic = measure_traffic(a, a.tile_cache)
+        else:
+            traffic = {"note": "traffic not measured: no tile table from the tuning child"}
+
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if a.same_device:
         local_rank = 0
@@ -268,28 +421,52 @@ def main():
         chosen = eng.plan.autotune(x.view(N * V, H, W, 3))
         if a.tile_cache and rank == 0:
             json.dump({k: v[0] for k, v in chosen.items()}, open(a.tile_cache, "w"))
+    if tmp_tiles and os.path.exists(tmp_tiles):
+        os.unlink(tmp_tiles)
+    if a.pmc_child == "tune":
+        return
+
+    def timed(step):
+        """W untimed steps, then exactly K steps between two barrier + synchronize pairs; MAX over the ranks."""
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     step = (lambda: sh.forward(x, check=False))
     if a.graph:
         assert world == 1, "--graph is a single-GPU option"
         step = eng.capture(x)
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(step)
     eng.check_status()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if a.pmc_child:
+        return
+    other = None
+    if world > 1 and not a.no_other_exchange:
+        name = "scores" if a.exchange == "allgather" else "allgather"
+        sh2 = ShardedGVCNN(eng, exchange=name)
+        dt2 = timed(lambda: sh2.forward(x, check=False))
+        other = (name, dt2)
 
     out = None
     if rank == 0:
         views_per_step = N * V * world
         ms = dt / a.steps * 1e3
+        f = eng.final
+        esz = 4 if a.storage == "f32" else 2
+        desc_bytes = N * V * f.h * f.w * f.c * esz
+        xbytes = {"scores": {"sent_per_rank": N * V * 4, "received_per_rank": N * V * 4 * (world - 1)},
+                  "allgather": {"sent_per_rank": N * V * 4 + desc_bytes,
+                                "received_per_rank": (N * V * 4 + desc_bytes) * (world - 1)}}
         out = {
             "metric": "views/sec", "value": round(views_per_step / (ms * 1e-3), 1), "unit": "views/s",
             "shapes_per_sec": round(N * world / (ms * 1e-3), 2),
@@ -306,10 +483,20 @@ def main():
                        "exchange": a.exchange if world > 1 else "none",
                        "gflop_per_view": round(eng.plan.total_flops / (N * V) / 1e9, 3)},
         }
+        if world > 1:
+            out["config"]["world_size"] = dist.get_world_size()          # what the ranks saw, not the flag
+            out["config"]["backend"] = "rccl (torch.distributed nccl)" if a.backend == "nccl" else "gloo (control-flow check)"
+            out["config"]["exchange_bytes_per_step"] = xbytes[a.exchange]
+            out["config"]["launched_by"] = "bench.py (self-launched ranks)" if os.environ.get("GVBENCH_SELF") else "external torch.distributed.run"
+            if other is not None:
+                ms2 = other[1] / a.steps * 1e3
+                out["other_exchange"] = {"exchange": other[0], "value": round(views_per_step / (ms2 * 1e-3), 1),
+                                         "unit": "views/s", "ms_per_step": round(ms2, 3),
+                                         "exchange_bytes_per_step": xbytes[other[0]]}
         step_tflops = eng.plan.total_flops / (ms * 1e-3) / 1e12
         out["step_tflops_per_gpu"] = round(step_tflops, 2)
         if not a.no_roofline:
-            out["roofline"] = roofline(eng, x.view(N * V, H, W, 3), a.math)
+            out["roofline"] = roofline(eng, x.view(N * V, H, W, 3), a.math, traffic=traffic)
         out["config"]["math"] = a.math + ": " + MATH[a.math][2]
         out["config"]["branch_lanes"] = eng.plan.lanes_used if not a.no_lanes else 1
         out["config"]["launch"] = "hipGraph replay" if a.graph else "eager"

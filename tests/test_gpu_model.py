@@ -239,9 +239,33 @@ def test_per_shape_grouping_vs_oracle(weight_mode, storage):
 
 
 def test_bench_two_rank_control_flow_on_one_device():
-    """The N>1 path of bench.py (rank/world from the environment, shape sharding, score exchange, max-over-ranks
-    timing, one JSON line from rank 0) with two ranks that share cuda:0 and a gloo group — RCCL itself needs two
-    devices and is exercised by the driver's multi-GPU run."""
+    """`python bench.py --gpus 2` exactly as the driver types it (NO torch.distributed.run in front): the process
+    launches its own two ranks, relays rank 0's single JSON line and returns their exit code.  The ranks share
+    cuda:0 over a gloo group (control flow of the N>1 path: shape sharding, score + descriptor exchange,
+    max-over-ranks timing) — RCCL itself needs two devices and is exercised by the driver's multi-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--same-device", "--steps", "2", "--warmup", "1", "--shapes", "2", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                      # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_views"] == 2 * 2 * 12 and j["scaling"] == "weak"
+    assert j["config"]["world_size"] == 2                       # what the ranks saw
+    assert j["value"] > 0 and j["config"]["exchange"] == "allgather"          # the north_star form is the default
+    desc = 2 * 12 * 5 * 5 * 2048 * 4 + 2 * 12 * 4
+    assert j["config"]["exchange_bytes_per_step"] == {"sent_per_rank": desc, "received_per_rank": desc}
+    assert j["other_exchange"]["exchange"] == "scores" and j["other_exchange"]["value"] > 0
+
+
+def test_bench_external_launcher_form_still_works():
+    """The other form the contract names: the driver's own `python -m torch.distributed.run ... bench.py --gpus N`."""
     import json
     import os
     import socket
@@ -253,14 +277,14 @@ def test_bench_two_rank_control_flow_on_one_device():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--same-device", "--steps", "2", "--warmup", "1", "--shapes", "2", "--no-roofline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+           "--same-device", "--steps", "2", "--warmup", "1", "--shapes", "2", "--no-roofline", "--exchange", "scores",
+           "--no-other-exchange"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                      # rank 0 only
+    assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["config"]["global_views"] == 2 * 2 * 12 and j["scaling"] == "weak"
-    assert j["value"] > 0 and j["config"]["exchange"] == "scores"
+    assert j["n_gpus"] == 2 and j["config"]["exchange"] == "scores" and "other_exchange" not in j
 
 
 @pytest.mark.parametrize("dp", ["views", "shapes"])
