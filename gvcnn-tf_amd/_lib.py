@@ -134,6 +134,7 @@ TUNING = {
     "gv_conv2d_set_tile_override": (None, [C.c_int]),
     "gv_conv2d_set_debug": (None, [C.c_int]),
     "gv_conv2d_num_tile_cfgs": (C.c_int, [C.c_int]),
+    "gv_conv2d_special_tile_cfg": (C.c_int, [C.c_int]),
     "gv_conv2d_wgrad_set_v1": (None, [C.c_int]),
     "gv_conv2d_wgrad_set_lp_f32": (None, [C.c_int]),
     "gv_conv2d_wgrad_num_cfgs": (C.c_int, [C.c_int]),

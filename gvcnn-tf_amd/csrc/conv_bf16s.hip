@@ -193,8 +193,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
                 // divergent branch => the compiler can count vmcnt and leave the younger tile's loads in flight.
                 aok[RS][i] = a_ok[i];
                 const float* p = a.x + a_off[i];
-                v0 = *reinterpret_cast<const f32x4*>(p);
-                v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                if (!(a.dbg & 16)) {                          // (timing ablation 16: no A loads)
+                    v0 = *reinterpret_cast<const f32x4*>(p);
+                    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                }
             } else {
                 aok[RS][i] = true;
                 if (kt < a.ktiles)                            // (uniform) no gather work for prefetches past the end
@@ -236,12 +238,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
     };
     auto store_tile = [&](auto rsc, int buf) {
         constexpr int RS = decltype(rsc)::value;
+        if (a.dbg & 32) {                                      // timing ablation 32: no LDS writes (operands stay live)
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i) asm volatile("" ::"v"(ra[RS][i][0]), "v"(ra[RS][i][1]));
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(rb[RS][i][p]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int idx = tid + i * NT;
             if (A_SLOTS * NT == BM * 2 || idx < BM * 2) {
                 u32x4 pl[NP];
-                split8<NP>(ra[RS][i][0], ra[RS][i][1], aok[RS][i], pl);
+                if (a.dbg & 8) {                              // timing ablation: no plane split (wrong values)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) pl[p] = __builtin_bit_cast(u32x4, ra[RS][i][p & 1]);
+                } else {
+                    split8<NP>(ra[RS][i][0], ra[RS][i][1], aok[RS][i], pl);
+                }
                 char* dst = sA + buf * BM * RB + slot_row(idx) * RB + 16 * (idx & 1);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 32) = pl[p];

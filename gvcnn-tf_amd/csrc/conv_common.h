@@ -24,6 +24,7 @@ struct ConvArgs {
     int tiles_n;
     int dil_shift;              // 0: plain; 1: input read as zero-dilated by 2 (stride-2 data gradient)
     int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
+    const void* zeros;          // conv_dma.hip: a zero page for the padding taps of the gather
 };
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:
@@ -98,5 +99,11 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a, bool generic, bool xf32, hi
 int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int dtype, void* out, hipStream_t st);
 int64_t lp_packed_bytes(int kh, int kw, int cin, int cout);
 int lp_pack_filters_batched(const gv_pack_job* jobs_dev, const int* block_job_dev, int nblocks, int dtype, hipStream_t st);
+int lp_special_cfg();           // the strip / halo kernels of the stem layers
+
+// conv_dma.hip (LDS-DMA loader; extra tile configurations of the 16-bit storage path)
+int dma_lp_num_cfgs();
+bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32);
+int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);
 
 }  // namespace gvconv

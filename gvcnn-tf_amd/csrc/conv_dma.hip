@@ -1,0 +1,379 @@
+// conv_dma.hip — implicit-GEMM convolution whose operands travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write, no VALU between the load and the LDS image), through a
+// ring of ST LDS stages with counted vmcnt waits and one raw s_barrier per k-tile.
+//
+// Both operands are "rows of 16-value groups", each group NP planes x 32 bytes:
+//   NP = 1   16-bit storage (GV_BF16 / GV_F16): plain NHWC activations [pixel][channel] and filters [cout][Kpad];
+//   NP = 3   fp32 values kept as three bf16 planes a = a0 + a1 + a2 (GV_MATH_BF16X3 on "P3" storage):
+//            activations [pixel][channel/16][plane][16], filters [cout][k/16][plane][16]; six plane products per
+//            MFMA block give fp32-level accuracy (conv_bf16s.hip explains the arithmetic), and because the PRODUCER's
+//            epilogue split the activation once, the loader here moves bytes only.
+//
+// LDS image of one stage: per operand and plane a [rows][KT values] sub-image (KT = 32 for NP = 1: 64-byte rows, 16 rows
+// per DMA instruction; KT = 16 for NP = 3: 32-byte rows, 32 rows per instruction).  One global_load_lds_dwordx4 writes
+// 1 KiB = wave-uniform base + lane * 16, i.e. one whole row block; the lane -> (row, 16-byte chunk) map is therefore
+// fixed and the bank-conflict swizzle is applied to the SOURCE address: lane (row r, physical chunk c) fetches logical
+// chunk c ^ swz(r), and the MFMA fragment read of logical chunk q of row r reads physical chunk q ^ swz(r)
+// (swz(r) = (r >> 2) & 3 for 64-byte rows, (r >> 3) & 1 for 32-byte rows: every 16-lane ds_read_b128 service group
+// then touches 16 distinct 4-bank groups).  Padding taps of the im2col gather read a zero page.
+//
+// Pipeline per k-tile kt:  wait until this wave's loads of tile kt have landed (vmcnt counted: the ST-2 younger tiles
+// stay in flight) -> s_barrier (every wave's part of tile kt is in LDS, and every wave is done reading tile kt-1) ->
+// issue the loads of tile kt+ST-1 into the stage tile kt-1 occupied -> read the fragments of tile kt -> MFMAs.
+#include <mutex>
+#include <type_traits>
+
+#include "conv_common.h"
+#include "conv_lp_epi.h"
+
+namespace {
+
+template <int NP> struct DmaGeom {
+    static constexpr int KT = NP == 1 ? 32 : 16;       // k-tile depth
+    static constexpr int RBYTES = KT * 2;               // one plane of one LDS row
+    static constexpr int RPI = 1024 / RBYTES;           // rows per DMA instruction
+    static constexpr int CPR = RBYTES / 16;             // 16-byte chunks per row
+    static constexpr int G16 = NP * 32;                 // bytes of one 16-value group in global memory (all planes)
+    static constexpr int KSTEPS = KT / 16;              // MFMA k-steps per k-tile
+};
+
+__device__ __forceinline__ void dma16(const char* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// plane products of the 3-plane form, small terms first (as conv_bf16s.hip)
+__host__ __device__ constexpr int dprod_count(int np) { return np == 3 ? 6 : 1; }
+__host__ __device__ constexpr int dprod_pa(int np, int t) { return np == 3 ? (t == 0 ? 2 : (t == 2 || t == 3 ? 1 : 0)) : 0; }
+__host__ __device__ constexpr int dprod_pb(int np, int t) { return np == 3 ? (t == 1 ? 2 : (t == 2 || t == 4 ? 1 : 0)) : 0; }
+
+// EPI: 0 = 16-bit output through the LDS-staged epilogue (conv_lp_epi.h)
+template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
+    using G = DmaGeom<NP>;
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int KT = G::KT, RBYTES = G::RBYTES, RPI = G::RPI, CPR = G::CPR, G16 = G::G16, KS = G::KSTEPS;
+    constexpr int UA = BM / RPI, UB = BN / RPI;                    // row blocks (one DMA instruction per plane each)
+    constexpr int UAW = (UA + NW - 1) / NW, UBW = (UB + NW - 1) / NW;
+    constexpr int A_PLANE = BM * RBYTES, B_PLANE = BN * RBYTES;
+    constexpr int STAGE = NP * (A_PLANE + B_PLANE);
+    constexpr int LPT = NP * (UAW + UBW);                          // DMA instructions per wave per k-tile
+    static_assert(ST >= 2 && ST <= 4, "2..4 LDS stages");
+    static_assert((ST - 1) * LPT < 64, "vmcnt range");
+    constexpr int NPR = dprod_count(NP);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % a.tiles_n;
+    const int tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- loader state -------------------------------------------------------------------------------------------
+    const int lrow = lane / CPR;                                   // row inside a row block
+    const int pc = lane % CPR;                                     // physical chunk this lane's 16 bytes land in
+    const int lc = pc ^ (CPR == 4 ? ((lrow >> 2) & 3) : ((lrow >> 3) & 1));   // logical chunk it must fetch
+    const int chunk_byte = (lc >> 1) * G16 + (lc & 1) * 16;        // inside one k-tile of a row (KT = 32: two groups)
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const char* zero_page = reinterpret_cast<const char*>(a.zeros);
+    const unsigned pix_bytes = (unsigned)a.x_ld * 2u * NP;         // one pixel of the input tensor
+    const int ohow = a.oh * a.ow;
+
+    int a_img[UAW], a_iy0[UAW], a_ix0[UAW];
+    int a_rb[UAW];
+#pragma unroll
+    for (int i = 0; i < UAW; ++i) {
+        int rb = wave + i * NW;
+        rb = rb < UA ? rb : UA - 1;                                // surplus slots re-load the last block (same bytes)
+        a_rb[i] = rb;
+        int m = m0 + rb * RPI + lrow;
+        m = m < a.M ? m : a.M - 1;                                 // rows past M: results never stored
+        const int n = m / ohow;
+        const int rem = m - n * ohow;
+        const int oy = rem / a.ow;
+        const int ox = rem - oy * a.ow;
+        a_img[i] = n * a.ih;
+        a_iy0[i] = oy * a.stride - a.pad_t;
+        a_ix0[i] = ox * a.stride - a.pad_l;
+    }
+    // filter tap (fr, fs) and channel fc of this lane's chunk in the NEXT tile to issue
+    int fc = lc * 8, fs = 0, fr = 0;
+    while (fc >= a.cin) { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } }
+    const char* a_ptr[UAW];
+    bool a_ok[UAW];
+    auto locate = [&]() {
+#pragma unroll
+        for (int i = 0; i < UAW; ++i) {
+            const int iyn = a_iy0[i] + fr;
+            const int ixn = a_ix0[i] + fs;
+            const int dmask = (1 << a.dil_shift) - 1;              // zero-dilated input (stride-2 data gradient)
+            const int iy = iyn >> a.dil_shift;
+            const int ix = ixn >> a.dil_shift;
+            const bool ok = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw && fr < a.kh;
+            a_ok[i] = ok;
+            const size_t off = (size_t)((unsigned)(a_img[i] + iy) * (unsigned)a.iw + (unsigned)ix) * pix_bytes +
+                               (size_t)((fc >> 4) * G16 + ((fc >> 3) & 1) * 16);
+            a_ptr[i] = ok ? xb + off : zero_page;
+        }
+    };
+    locate();
+    auto advance = [&]() {
+        fc += KT;
+        if (fc >= a.cin) {
+            do { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } } while (fc >= a.cin);
+            locate();
+        } else {
+#pragma unroll
+            for (int i = 0; i < UAW; ++i) a_ptr[i] += a_ok[i] ? (KT / 16) * G16 : 0;
+        }
+    };
+    const char* b_ptr[UBW];
+    int b_rb[UBW];
+    {
+        const size_t row_bytes = (size_t)(a.Kpad / 16) * G16;
+#pragma unroll
+        for (int i = 0; i < UBW; ++i) {
+            int rb = wave + i * NW;
+            rb = rb < UB ? rb : UB - 1;
+            b_rb[i] = rb;
+            int n = n0 + rb * RPI + lrow;
+            n = n < a.cout ? n : a.cout - 1;                       // columns past cout are never stored
+            b_ptr[i] = reinterpret_cast<const char*>(a.w) + (size_t)n * row_bytes + chunk_byte;
+        }
+    }
+    // DMA instruction d (0 .. LPT-1) of the tile at the current loader state: A units first, then B
+    auto dma_one = [&](int d, char* sb) {
+        if (d < NP * UAW) {
+            const int i = d / NP, p = d % NP;
+            dma16(a_ptr[i] + (a_ok[i] ? p * 32 : 0), sb + p * A_PLANE + a_rb[i] * 1024);
+        } else {
+            const int e = d - NP * UAW;
+            const int i = e / NP, p = e % NP;
+            dma16(b_ptr[i] + p * 32, sb + NP * A_PLANE + p * B_PLANE + b_rb[i] * 1024);
+        }
+    };
+    auto step_state = [&]() {                                      // loader state -> next tile
+        advance();
+#pragma unroll
+        for (int i = 0; i < UBW; ++i) b_ptr[i] += (KT / 16) * G16;
+    };
+    auto issue = [&](int stage) {                                  // (prologue) the tile at the current loader state
+        char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int d = 0; d < LPT; ++d) dma_one(d, sb);
+        step_state();
+    };
+
+    // ---- fragments ------------------------------------------------------------------------------------------------
+    const int fr_row = lane & 31, fr_h = lane >> 5;
+    const int fsw = CPR == 4 ? ((fr_row >> 2) & 3) : ((fr_row >> 3) & 1);
+    int foff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) foff[s] = ((s * 2 + fr_h) ^ fsw) * 16;
+    const int a_frag = (wm * TM * 32 + fr_row) * RBYTES;
+    const int b_frag = NP * A_PLANE + (wn * TN * 32 + fr_row) * RBYTES;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Fragments are double buffered in registers at K-STEP granularity (one k-step = 16 k-values = one MFMA per
+    // accumulator and plane product): while the MFMAs of k-step q run, the fragments of k-step q+1 are already on their
+    // way from LDS.  Inside a tile that needs no synchronisation; the first k-step of tile kt+1 is read right after the
+    // barrier that publishes tile kt+1, which sits BEFORE the last k-step's MFMAs of tile kt — so the barrier wait, the
+    // fragment-read latency and the DMA instructions of the tile ST ahead (issued after that barrier into the stage tile
+    // kt just vacated, spread between the MFMAs) are all covered by matrix work of the same wave.
+    constexpr int NMFS = NPR * TM * TN;                            // MFMAs per k-step
+    constexpr int GAP = NMFS / (LPT + 1) > 0 ? NMFS / (LPT + 1) : 1;
+    u32x4 fa[2][TM][NP], fb[2][TN][NP];
+    auto read_frags = [&](auto setc, int stage, int s) {
+        constexpr int S = decltype(setc)::value;
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                fa[S][i][p] = *reinterpret_cast<const u32x4*>(sb + p * A_PLANE + a_frag + i * 32 * RBYTES + foff[s]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                fb[S][j][p] = *reinterpret_cast<const u32x4*>(sb + p * B_PLANE + b_frag + j * 32 * RBYTES + foff[s]);
+    };
+    auto mfmas = [&](auto setc, bool do_issue, char* nb) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int m = 0; m < NMFS; ++m) {
+            const int t = m / (TM * TN);
+            const int i = (m / TN) % TM, j = m % TN;
+            acc[i][j] = mfma16<T>(fa[S][i][dprod_pa(NP, t)], fb[S][j][dprod_pb(NP, t)], acc[i][j]);
+            if ((m + 1) % GAP == 0 && (m + 1) / GAP <= LPT) {
+                if (do_issue) dma_one((m + 1) / GAP - 1, nb);
+            }
+        }
+        if (do_issue) {
+#pragma unroll
+            for (int d = NMFS / GAP; d < LPT; ++d) dma_one(d, nb);  // (fewer MFMAs than DMA instructions)
+            step_state();
+        }
+    };
+    const int ktiles = a.ktiles;
+    auto wait_tile = [&](int t) {                                  // this wave's DMA of tile t has landed
+        const int last_issued = t + ST - 2 < ktiles - 1 ? t + ST - 2 : ktiles - 1;   // tiles <= t-1+ST-1 were issued so far
+        const int younger = last_issued - t;
+        if (ST >= 4 && younger >= 2) wait_vm<(ST >= 4 ? 2 * LPT : 0)>();
+        else if (ST >= 3 && younger >= 1) wait_vm<(ST >= 3 ? LPT : 0)>();
+        else wait_vm<0>();
+    };
+    // tile kt whose first k-step's fragments sit in register set PAR
+    auto tile_step = [&](auto parc, int kt, int stage) {
+        constexpr int PAR = decltype(parc)::value;
+        const int next = stage + 1 == ST ? 0 : stage + 1;
+#pragma unroll
+        for (int s = 0; s + 1 < KS; ++s) {
+            if (((PAR + s) & 1) == 0) { read_frags(std::integral_constant<int, 1>{}, stage, s + 1); mfmas(std::integral_constant<int, 0>{}, false, nullptr); }
+            else { read_frags(std::integral_constant<int, 0>{}, stage, s + 1); mfmas(std::integral_constant<int, 1>{}, false, nullptr); }
+        }
+        constexpr int LASTSET = (PAR + KS - 1) & 1;
+        const bool more = kt + 1 < ktiles;
+        if (more) {
+            wait_tile(kt + 1);
+            __builtin_amdgcn_s_barrier();                          // tile kt+1 is in LDS; every wave has read all of tile kt
+            read_frags(std::integral_constant<int, LASTSET ^ 1>{}, next, 0);
+        }
+        mfmas(std::integral_constant<int, LASTSET>{}, kt + ST < ktiles, smem + stage * STAGE);
+    };
+
+    // ---- main loop ------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < ST; ++t)
+        if (t < ktiles) issue(t);
+    {
+        const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
+        if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
+        else if (younger == 2) wait_vm<(ST >= 3 ? 2 * LPT : 0)>();
+        else if (younger == 1) wait_vm<LPT>();
+        else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    read_frags(std::integral_constant<int, 0>{}, 0, 0);
+    int stage = 0;
+    if constexpr (KS % 2 == 0) {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            tile_step(std::integral_constant<int, 0>{}, kt, stage);
+            stage = stage + 1 == ST ? 0 : stage + 1;
+        }
+    } else {
+        int kt = 0;
+        for (; kt + 1 < ktiles; kt += 2) {
+            tile_step(std::integral_constant<int, 0>{}, kt, stage);
+            stage = stage + 1 == ST ? 0 : stage + 1;
+            tile_step(std::integral_constant<int, 1>{}, kt + 1, stage);
+            stage = stage + 1 == ST ? 0 : stage + 1;
+        }
+        if (kt < ktiles) tile_step(std::integral_constant<int, 0>{}, kt, stage);
+    }
+
+    __syncthreads();                                               // every wave is done with the ring: reuse it for staging
+    if constexpr (EPI == 0)
+        lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES));
+}
+
+// one zero page per device for the padding taps of the gather (lazily allocated OUTSIDE any stream capture: every
+// engine runs eagerly once before it captures)
+const void* zero_page_for_current_device() {
+    static std::mutex mu;
+    static void* pages[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pages[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        pages[dev] = p;
+    }
+    return pages[dev];
+}
+
+template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+int launch_dma(const ConvArgs& a0, hipStream_t st) {
+    using G = DmaGeom<NP>;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    ConvArgs a = a0;
+    a.Kpad = (a.K + G::KT - 1) / G::KT * G::KT;
+    a.ktiles = a.Kpad / G::KT;
+    a.tiles_n = gv_ceil_div(a.cout, BN);
+    const int64_t nwg = (int64_t)gv_ceil_div(a.M, BM) * a.tiles_n;
+    if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
+    a.zeros = zero_page_for_current_device();
+    if (!a.zeros) return GV_E_UNSUPPORTED;
+    const size_t ring = (size_t)ST * NP * (BM + BN) * G::RBYTES;
+    const size_t epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI>;
+    if (lds > 64 * 1024) {
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024) == hipSuccess;
+        if (!ok) return GV_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
+int launch_dma_lp(int cfg, const ConvArgs& a, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_dma<T, 1, 2, 2, 2, 2, 4, 0>(a, st);      // 128 x 128, 4 waves, 4 stages (64 KB: two per CU)
+        case 1: return launch_dma<T, 1, 4, 2, 2, 2, 3, 0>(a, st);      // 256 x 128, 8 waves
+        case 2: return launch_dma<T, 1, 2, 4, 2, 2, 3, 0>(a, st);      // 128 x 256, 8 waves
+        case 3: return launch_dma<T, 1, 2, 4, 4, 2, 3, 0>(a, st);      // 256 x 256, 8 waves
+        case 4: return launch_dma<T, 1, 2, 2, 2, 3, 4, 0>(a, st);      // 128 x 192
+        case 5: return launch_dma<T, 1, 4, 2, 2, 3, 3, 0>(a, st);      // 256 x 192, 8 waves
+        case 6: return launch_dma<T, 1, 2, 2, 2, 1, 4, 0>(a, st);      // 128 x 64
+        case 7: return launch_dma<T, 1, 2, 2, 1, 2, 4, 0>(a, st);      // 64 x 128
+        case 8: return launch_dma<T, 1, 4, 1, 1, 3, 4, 0>(a, st);      // 128 x 96
+        case 9: return launch_dma<T, 1, 2, 2, 4, 2, 3, 0>(a, st);      // 256 x 128, FOUR waves (128 x 64 each): two per CU
+        case 10: return launch_dma<T, 1, 2, 2, 2, 4, 3, 0>(a, st);     // 128 x 256, four waves
+        case 11: return launch_dma<T, 1, 2, 2, 3, 2, 3, 0>(a, st);     // 192 x 128, four waves
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+namespace gvconv {
+
+int dma_lp_num_cfgs() { return 12; }
+
+// the DMA loader's layer class: whole 8-channel chunks inside one filter tap, 16-byte aligned pixels, 16-bit input
+bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32) {
+    return !generic && !xf32 && a.cin % 8 == 0 && a.x_ld % 8 == 0;
+}
+
+int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st) {
+    if (dtype == GV_BF16) return launch_dma_lp<__bf16>(cfg, a, st);
+    if (dtype == GV_F16) return launch_dma_lp<_Float16>(cfg, a, st);
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace gvconv

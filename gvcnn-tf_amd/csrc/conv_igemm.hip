@@ -372,6 +372,13 @@ static int planes_of(int math_mode) {
     return -1;
 }
 
+// index of the strip / halo kernels of the stem layers among the tile configurations (16-bit storage: math_mode -1)
+extern "C" int gv_conv2d_special_tile_cfg(int32_t math_mode) {
+    if (math_mode == -1) return gvconv::lp_special_cfg();
+    const int np = planes_of(math_mode);
+    return np <= 0 ? GV_E_BADARG : gvconv::bf16s_num_cfgs() - 1;
+}
+
 extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
     if (math_mode == -1) return gvconv::lp_num_cfgs();     // the 16-bit storage kernels
     const int np = planes_of(math_mode);
@@ -470,6 +477,7 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.relu_limit = d->relu_cols > 0 ? d->relu_cols : 0x7fffffff;
     a.tiles_n = 0;
     a.dbg = g_debug;
+    a.zeros = nullptr;
     if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) return GV_E_BADARG;
     a.dil_shift = d->in_dilation == 2 ? 1 : 0;
     if (a.dil_shift && (np == 0 || (d->cin % CH != 0) || d->stride != 1)) return GV_E_UNSUPPORTED;
@@ -484,7 +492,7 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1
                            : ((gvconv::lp_halo_ok(a, generic) || gvconv::lp_stem_ok(a, xf32)) && a.M >= 100000
-                                  ? gvconv::lp_num_cfgs() - 1
+                                  ? gvconv::lp_special_cfg()
                                                                               : gvconv::lp_pick_tile(a.M, a.cout, a.K)));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
     }

@@ -19,169 +19,12 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "conv_lp_epi.h"
 
 namespace {
 
-using gvconv::ConvArgs;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int KT = 32;                      // k-tile depth
 constexpr int RB = 2 * KT + 16;             // LDS row bytes
-
-template <typename T>
-__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
-    if constexpr (std::is_same<T, __bf16>::value)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-template <typename T>
-__device__ __forceinline__ unsigned short to_bits(float v) {
-    const T h = (T)v;
-    return __builtin_bit_cast(unsigned short, h);
-}
-template <typename T>
-__device__ __forceinline__ float from_bits(unsigned short b) {
-    return (float)__builtin_bit_cast(T, b);
-}
-
-// Staged epilogue: each wave transposes its accumulators through a private LDS block (32 rows x CW fp32) so
-// that a lane ends up with 8 CONSECUTIVE channels of one pixel: scale/shift/residual/ReLU are applied to
-// the fp32 values, which are rounded once and leave as 16-byte stores (residual and second output: 16-byte
-// loads / stores as well).  Storing straight from the MFMA layout would issue 2-byte stores, one per lane
-// per row — 8x the store instructions, and the kernel then spends more time storing than multiplying.
-template <int TN> struct EpiGeom {
-    static constexpr int CW = (TN % 2 == 0) ? 64 : 32;     // columns per staging block
-    static constexpr int JB = CW / 32;                     // MFMA tiles per block
-    static constexpr int BYTES = 32 * CW * 4;              // per wave
-};
-
-template <typename T>
-__device__ __forceinline__ void store_chunk(unsigned short* dst, const float (&v)[8], int nvalid, bool vec) {
-    if (vec && nvalid == 8) {
-        u32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
-        *reinterpret_cast<u32x4*>(dst) = o;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < nvalid) dst[j] = to_bits<T>(v[j]);
-    }
-}
-
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                                   int wm, int wn, int lane, float* stage, int rows_valid = 32) {
-    if (a.dbg & 4) {            // timing ablation: keep the accumulators live without storing the tile
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 1.2345e-30f) a.y[0] = t;
-        return;
-    }
-    constexpr int CW = EpiGeom<TN>::CW, JB = EpiGeom<TN>::JB;
-    constexpr int CPR = CW / 8;                            // 8-column chunks per row
-    constexpr int RPP = 64 / CPR;                          // rows per read-back pass
-    const int col_l = lane & 31;
-    const int row_h = 4 * (lane >> 5);
-    const int rrow = lane / CPR, rchunk = lane % CPR;
-    const unsigned short* res = reinterpret_cast<const unsigned short*>(a.res);
-    unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
-    unsigned short* y2 = reinterpret_cast<unsigned short*>(a.y2);
-    const bool dual = y2 != nullptr && a.split == 0;
-    // 16-byte accesses need 8-element aligned rows, slices and boundaries (true for every layer of both
-    // backbones); anything else takes the element-wise branch of store_chunk
-    const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
-                     (y2 == nullptr || ((a.y2_ld % 8 == 0) && ((((uintptr_t)y2) & 15) == 0))) &&
-                     (a.split % 8 == 0) && (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0)));
-#pragma unroll
-    for (int jb = 0; jb < TN / JB; ++jb) {
-        const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;     // this lane's 8 columns
-        const int nvalid = min(8, a.cout - col);                        // <= 0: nothing to store
-        float sc[8], sh[8], sc2[8], sh2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = min(col + e, a.cout - 1);
-            sc[e] = a.scale[c];
-            sh[e] = a.shift[c];
-            sc2[e] = dual ? a.scale2[c] : 0.f;
-            sh2[e] = dual ? a.shift2[c] : 0.f;
-        }
-        // split destination: a chunk lies on one side when split % 8 == 0; otherwise decide per element below
-        const bool to_second = a.split > 0 && col >= a.split;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int jj = 0; jj < JB; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[(row_h + (r & 3) + 8 * (r >> 2)) * CW + jj * 32 + col_l] = acc[i][jb * JB + jj][r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int pass = 0; pass < 32 / RPP; ++pass) {
-                const int row = pass * RPP + rrow;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8 + 4);
-                const int m = m0 + (wm * TM + i) * 32 + row;
-                if (m >= a.M || nvalid <= 0 || row >= rows_valid) continue;
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                if (res) {
-                    const unsigned short* rp = res + (size_t)m * a.res_ld + col;
-                    if (vec && nvalid == 8) {
-                        const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[2 * j] += from_bits<T>((unsigned short)(rv[j] & 0xffffu));
-                            v[2 * j + 1] += from_bits<T>((unsigned short)(rv[j] >> 16));
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (e < nvalid) v[e] += from_bits<T>(rp[e]);
-                    }
-                }
-                if (dual) {
-                    float v2[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v2[e] = v[e] * sc2[e] + sh2[e];
-                        if (a.relu2) v2[e] = fmaxf(v2[e], 0.f);
-                    }
-                    store_chunk<T>(y2 + (size_t)m * a.y2_ld + col, v2, nvalid, vec);
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (col + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
-                }
-                if (a.split > 0 && (a.split % 8) != 0) {          // boundary inside a chunk: element-wise
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (e >= nvalid) continue;
-                        const int c = col + e;
-                        if (c >= a.split) y2[(size_t)m * a.y2_ld + (c - a.split)] = to_bits<T>(v[e]);
-                        else y[(size_t)m * a.y_ld + c] = to_bits<T>(v[e]);
-                    }
-                } else if (to_second) {
-                    store_chunk<T>(y2 + (size_t)m * a.y2_ld + (col - a.split), v, nvalid, vec);
-                } else {
-                    store_chunk<T>(y + (size_t)m * a.y_ld + col, v, nvalid, vec);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
 
 // FDB: fragments double buffered in registers.  The 128x128 tile (2x2 accumulators per wave) reaches three workgroups
 // per CU only with ONE fragment set; the other two waves of the SIMD cover the ds_read latency instead.
@@ -899,7 +742,10 @@ int launch_stem(const ConvArgs& a, hipStream_t st) {
 
 namespace gvconv {
 
-int lp_num_cfgs() { return kNumTiles + 1; }               // + the strip kernels of the stem layers
+// configurations: [0, kNumTiles) register-staged tiles, kNumTiles = the strip / halo kernels of the stem layers,
+// then the LDS-DMA tiles of conv_dma.hip
+int lp_num_cfgs() { return kNumTiles + 1 + dma_lp_num_cfgs(); }
+int lp_special_cfg() { return kNumTiles; }
 
 // the 3-channel stems read from the fp32 images: square 3x3 or 7x7 window, stride 2, <= 64 output channels
 bool lp_stem_ok(const ConvArgs& a, bool xf32) {
@@ -948,6 +794,10 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
         if (dtype == GV_BF16) return launch_halo<__bf16>(a, st);
         if (dtype == GV_F16) return launch_halo<_Float16>(a, st);
         return GV_E_UNSUPPORTED;
+    }
+    if (cfg > kNumTiles) {
+        if (!dma_lp_ok(a, generic, xf32)) return GV_E_UNSUPPORTED;
+        return dma_lp_launch(dtype, cfg - kNumTiles - 1, a, st);
     }
     if (dtype == GV_BF16) return launch_t<__bf16>(cfg, a, generic, xf32, st);
     if (dtype == GV_F16) return launch_t<_Float16>(cfg, a, generic, xf32, st);

@@ -227,20 +227,30 @@ static int run_lanes(gv_plan* p, void* const* bufs, hipStream_t main) {
     }
     GV_HIP_CHECK(hipEventRecord(p->ev_fork, main));
     for (int l = 1; l < nl; ++l) GV_HIP_CHECK(hipStreamWaitEvent(p->lane_streams[(size_t)l], p->ev_fork, 0));
-    for (size_t i = 0; i < p->ops.size(); ++i) {
+    // a failing op must not leave the fork open: the lane streams are ALWAYS joined back into the caller's stream
+    // (an un-joined fork would end a stream capture with hipErrorStreamCaptureUnjoined and let later work on `main`
+    // overtake what the lanes already enqueued)
+    int rc = GV_OK;
+    for (size_t i = 0; i < p->ops.size() && rc == GV_OK; ++i) {
         const Op& o = p->ops[i];
         hipStream_t st = o.lane == 0 ? main : p->lane_streams[(size_t)o.lane];
         for (int32_t d : o.deps)
-            if (p->ops[(size_t)d].lane != o.lane) GV_HIP_CHECK(hipStreamWaitEvent(st, p->op_events[(size_t)d], 0));
-        const int rc = run_op(o, bufs, (void*)st);
-        if (rc != GV_OK) return rc;
-        if (o.signal) GV_HIP_CHECK(hipEventRecord(p->op_events[i], st));
+            if (p->ops[(size_t)d].lane != o.lane && rc == GV_OK) {
+                const hipError_t e = hipStreamWaitEvent(st, p->op_events[(size_t)d], 0);
+                if (e != hipSuccess) rc = (int)e;
+            }
+        if (rc == GV_OK) rc = run_op(o, bufs, (void*)st);
+        if (rc == GV_OK && o.signal) {
+            const hipError_t e = hipEventRecord(p->op_events[i], st);
+            if (e != hipSuccess) rc = (int)e;
+        }
     }
     for (int l = 1; l < nl; ++l) {
-        GV_HIP_CHECK(hipEventRecord(p->ev_join[(size_t)l], p->lane_streams[(size_t)l]));
-        GV_HIP_CHECK(hipStreamWaitEvent(main, p->ev_join[(size_t)l], 0));
+        hipError_t e = hipEventRecord(p->ev_join[(size_t)l], p->lane_streams[(size_t)l]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, p->ev_join[(size_t)l], 0);
+        if (e != hipSuccess && rc == GV_OK) rc = (int)e;
     }
-    return GV_OK;
+    return rc;
 }
 
 extern "C" int gv_plan_run_range(const gv_plan* p, int32_t first, int32_t count,

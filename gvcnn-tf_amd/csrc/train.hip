@@ -352,10 +352,14 @@ __global__ __launch_bounds__(256) void softmax_ce_f32(const float* __restrict__ 
         float se = 0.f;
         for (int j = 0; j < c; ++j) se += expf(l[j] - mx);
         const float lse = logf(se) + mx;
-        const int lab = (int)labels[i];
-        acc += lse - l[lab];
+        // a label outside [0, c) (or an int64 that does not fit an int) never indexes the logits: like TensorFlow's
+        // GPU kernel the row's loss and gradient become NaN, which the trainer's check_numerics (train.py:175) raises on
+        const int64_t lab64 = labels[i];
+        const bool ok = lab64 >= 0 && lab64 < (int64_t)c;
+        const int lab = ok ? (int)lab64 : 0;
+        acc += ok ? lse - l[lab] : NAN;
         for (int j = 0; j < c; ++j)
-            dlogits[(size_t)i * c + j] = (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)n;
+            dlogits[(size_t)i * c + j] = ok ? (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)n : NAN;
     }
     part[threadIdx.x] = acc;
     __syncthreads();

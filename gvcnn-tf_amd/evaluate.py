@@ -27,6 +27,11 @@ class Evaluator:
     def add_batch(self, views, labels, fused=True):
         """views [N,V,H,W,3], labels [N] (int64).  Returns this batch's accuracy (reads one int back)."""
         eng = self.eng
+        with torch.cuda.device(eng.device):
+            return self._add_batch(views, labels, fused)
+
+    def _add_batch(self, views, labels, fused):
+        eng = self.eng
         if fused:
             _, _, logits = eng.forward(views)
         else:                                               # eval.py:176-198, the two-partial_run protocol

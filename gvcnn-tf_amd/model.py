@@ -35,6 +35,24 @@ def _st(stream=None):
     return backbones._stream_ptr(stream)
 
 
+def pin_device(cls):
+    """Class decorator: every public method runs with the engine's OWN device current, so an engine built on cuda:1
+    launches on cuda:1 and its stream whatever the caller's current device is (the C ABI launches on the current
+    device; `_st()` resolves the current stream of the current device)."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def inner(self, *a, **k):
+            with torch.cuda.device(self.device):
+                return fn(self, *a, **k)
+        return inner
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and not name.startswith("_") and not isinstance(fn, (staticmethod, classmethod, type)):
+            setattr(cls, name, wrap(fn))
+    return cls
+
+
 def _dev(device=None):
     if not torch.cuda.is_available():
         raise RuntimeError("gvcnn-tf_amd needs a HIP device (MI355X); there is no CPU fallback")
@@ -168,6 +186,7 @@ def group_fusion(group_descriptors, group_weight):
 # ------------------------------------------------------------------------------------------------
 # the engine: one built "graph" per (backbone, N, V, H, W) like train.py:121-136 builds it once
 # ------------------------------------------------------------------------------------------------
+@pin_device
 class GVCNN:
     """Per-view backbone + grouping module for a fixed batch geometry.
 
@@ -406,9 +425,24 @@ class GVCNN:
         self._graphs.append((handle, views, side))
 
         def replay():
-            _lib.check(self.lib.gv_graph_launch(handle, _st()), "gv_graph_launch")
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.gv_graph_launch(handle, _st()), "gv_graph_launch")
             return (self.scores_ps if self.per_shape else self.scores), self.shape_descriptor, self.logits
+        replay.close = self.close_graphs
         return replay
+
+    def close_graphs(self):
+        """Destroy every captured hipGraph (exec + graph) of this engine; replay functions are dead afterwards."""
+        for handle, _views, side in getattr(self, "_graphs", []):
+            side.synchronize()
+            self.lib.gv_graph_destroy(handle)
+        self._graphs = []
+
+    def __del__(self):
+        try:
+            self.close_graphs()
+        except Exception:
+            pass
 
     def forward_basic(self, views):
         """nets/model.py:169-206 (MVCNN baseline): max over all views -> GAP -> Dense."""

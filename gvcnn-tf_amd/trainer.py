@@ -64,6 +64,17 @@ class Trainer:
             v = float(loss.item())
             if math.isnan(v) or math.isinf(v):
                 raise FloatingPointError("Loss is inf or nan.")
+            # the group-assignment status word of THIS step, in the same synchronising readback: a score of exactly
+            # 1.0 (bin == num_group) or NaN leaves a view in no group with a finite loss; the reference's host
+            # group_scheme raises IndexError / ValueError there (nets/model.py:23, train.py:277)
+            eng = self._engine()
+            st = getattr(eng, "status", None)
+            if st is not None and not getattr(eng, "per_shape", False):
+                from .model import _raise_for_status
+                _raise_for_status(int(st.item()), eng.gidx, eng.G)
+            elif st is not None and int(st.item()):
+                from .model import _raise_for_status
+                _raise_for_status(int(st.item()), eng.gidx_ps.reshape(-1), eng.G)
         return loss
 
     # -- checkpoints (tf.train.Saver: train.py:225-234 restores, train.py:297-302 saves) -------------------------------
@@ -88,8 +99,37 @@ class Trainer:
 
     def save(self, prefix):
         """Writes `prefix.index` + `prefix.data-00000-of-00001` (checkpoint-v2)."""
+        import os
         from . import tf_checkpoint
         tf_checkpoint.write_checkpoint(prefix, {k: np.ascontiguousarray(v) for k, v in self.state_dict().items()})
+        # the `checkpoint` state file tf.train.Saver keeps next to its bundles (a text CheckpointState proto): what
+        # tf.train.latest_checkpoint(--saved_checkpoint_dir) reads (train.py:225-234, eval.py:119-125)
+        d, base = os.path.split(os.path.abspath(prefix))
+        state = os.path.join(d, "checkpoint")
+        older = []
+        if os.path.exists(state):
+            for line in open(state):
+                if line.startswith("all_model_checkpoint_paths:"):
+                    older.append(line.split(":", 1)[1].strip().strip('"'))
+        paths = [p for p in older if p != base] + [base]
+        with open(state, "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % base)
+            for p in paths:
+                f.write('all_model_checkpoint_paths: "%s"\n' % p)
+
+    @staticmethod
+    def latest_checkpoint(checkpoint_dir):
+        """tf.train.latest_checkpoint: the prefix named by `<dir>/checkpoint`, or None."""
+        import os
+        state = os.path.join(checkpoint_dir, "checkpoint")
+        if not os.path.exists(state):
+            return None
+        for line in open(state):
+            if line.startswith("model_checkpoint_path:"):
+                p = line.split(":", 1)[1].strip().strip('"')
+                p = p if os.path.isabs(p) else os.path.join(checkpoint_dir, p)
+                return p if os.path.exists(p + ".index") else None
+        return None
 
     def restore(self, prefix, strict=True):
         """Loads a checkpoint written by save() (or a TF-slim backbone checkpoint with strict=False: whatever names

@@ -24,7 +24,7 @@ from . import _lib
 from . import backbones
 from . import params as _params
 from .backbones import _out_size
-from .model import _st, _dev, _raise_for_status
+from .model import _st, _dev, _raise_for_status, pin_device
 
 
 class TrainPlan(backbones.BackbonePlan):
@@ -137,6 +137,7 @@ class TrainPlan(backbones.BackbonePlan):
         return shapes
 
 
+@pin_device
 class TrainGVCNN:
     """One training step of GVCNN for a fixed batch geometry (views [N, V, H, W, 3] on the device)."""
 

@@ -35,8 +35,13 @@ def st():
 
 
 def special_tile():
-    """Index of the strip kernels (halo-tiled 3x3, 3-channel stems): the last tile configuration."""
-    return lib().gv_conv2d_num_tile_cfgs(-1) - 1
+    """Index of the strip kernels (halo-tiled 3x3, 3-channel stems) among the tile configurations."""
+    return lib().gv_conv2d_special_tile_cfg(-1)
+
+
+def dma_tiles():
+    """The LDS-DMA tile configurations (csrc/conv_dma.hip) follow the strip kernels' index."""
+    return list(range(lib().gv_conv2d_special_tile_cfg(-1) + 1, lib().gv_conv2d_num_tile_cfgs(-1)))
 
 
 def rnd(t, td):
@@ -157,6 +162,54 @@ def test_lp_conv_every_tile_config(tile, cout, ty):
     scale, shift = torch.ones(cout), torch.zeros(cout)
     ref = oracle_conv(x, w, 1, "SAME", scale, shift, False)
     y = run_conv(x, w, 1, (1, 1), (13, 11), scale, shift, False, ty, tile=tile)
+    close(y, ref.numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("tile", list(range(13, 25)))
+@pytest.mark.parametrize("cout", [32, 48, 200])
+def test_lp_conv_every_dma_tile_config(tile, cout, ty):
+    """The LDS-DMA loader (global_load_lds, swizzled LDS image, counted vmcnt ring): all its tile shapes on the same
+    ragged problem as above (M = 286, N not a multiple of 32, K = 360 not a multiple of the k-tile, padding taps
+    through the zero page)."""
+    assert tile in dma_tiles()
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(tile * 100 + cout)
+    x = rnd(torch.randn(2, 13, 11, 40, generator=g), td)
+    w = rnd(torch.randn(3, 3, 40, cout, generator=g) * 0.06, td)
+    scale, shift = torch.ones(cout), torch.zeros(cout)
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, False)
+    y = run_conv(x, w, 1, (1, 1), (13, 11), scale, shift, False, ty, tile=tile)
+    close(y, ref.numpy(), ulp)
+
+
+DMA_COMBOS = [c for c in COMBOS if c[3] % 8 == 0]
+
+
+@pytest.mark.parametrize("tile_i", [0, 3, 8, 9])
+@pytest.mark.parametrize("k,stride,padding,cin,cout", DMA_COMBOS)
+def test_lp_dma_conv_combos_vs_oracle(k, stride, padding, cin, cout, tile_i):
+    """Every (kernel, stride, padding) combination of the two backbones whose input has whole 8-channel chunks,
+    through the LDS-DMA loader (a 4-wave, an 8-wave and a 4x1-wave tile), with residual, second output / split epilogue
+    on a channel-slice destination."""
+    ty = "bf16"
+    code, td, ulp = TYPES[ty]
+    tile = dma_tiles()[tile_i]
+    g = torch.Generator().manual_seed(hash((k, stride, cin, cout)) % 1000)
+    ih, iw = (23, 20) if cin <= 64 else (9, 10)
+    x = rnd(torch.randn(3, ih, iw, cin, generator=g), td)
+    w = rnd(torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5), td)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    if isinstance(padding, str):
+        pads = (tf_pads(ih, k[0], stride, padding), tf_pads(iw, k[1], stride, padding))
+    else:
+        pads = (padding[0], padding[2])
+    ref0 = oracle_conv(x, w, stride, padding, scale, shift, False)
+    res = rnd(torch.randn(ref0.shape, generator=g), td)
+    ref = oracle_conv(x, w, stride, padding, scale, shift, True, residual=res)
+    y = run_conv(x, w, stride, pads, ref.shape[1:3], scale, shift, True, ty, residual=res, tile=tile,
+                 x_ld=cin + 16, x_off=8, y_ld=cout + 24, y_off=16)
     close(y, ref.numpy(), ulp)
 
 

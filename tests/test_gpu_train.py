@@ -4,6 +4,8 @@ oracle/train.py.  fp32; tolerance relative to each tensor's scale (BatchNorm on 
 amplifies rounding noise by 1/sigma, so gradients are held to 2e-3 of their scale)."""
 import ctypes as C
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -548,6 +550,8 @@ def test_trainer_checkpoint_resumes_the_run(tmp_path, storage):
     want = float(tr.step(x, labels))
     eng2 = TrainGVCNN("resnet_v2_50", N, V, size, size, C_, G, device=DEV, seed=99, storage=storage)   # other values
     tr2 = Trainer(eng2, base_learning_rate=1e-3, training_number_of_steps=50, check_every=0)
+    assert Trainer.latest_checkpoint(str(tmp_path)) == prefix          # the `checkpoint` state file (tf.train.latest_checkpoint)
+    assert open(str(tmp_path / "checkpoint")).read().splitlines()[0] == 'model_checkpoint_path: "model.ckpt-2"'
     assert tr2.restore(prefix) == [] and tr2.global_step == 2
     got = float(tr2.step(x, labels))
     assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (got, want)
@@ -555,3 +559,46 @@ def test_trainer_checkpoint_resumes_the_run(tmp_path, storage):
     for k in eng.params:                                 # and lands on the same variables
         a, b = eng2.params[k].float().cpu(), eng.params[k].float().cpu()
         assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-3), k
+
+
+def test_out_of_range_label_is_nan_not_an_out_of_bounds_read():
+    """a label outside [0, C) — or an int64 that does not fit an int — must never index the logits.
+    Like TensorFlow's GPU kernel the row's loss and gradient become NaN; the other rows keep their values and the
+    trainer's check_numerics emulation (train.py:175) raises."""
+    import ctypes as C_
+    from gvcnn_tf_amd import _lib
+    lib = _lib.load()
+    n, c = 5, 7
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(n, c, generator=g).to(DEV)
+    labels = torch.tensor([1, 6, 0, 3, 2], dtype=torch.int64)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.zeros(n, c, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gv_softmax_ce(logits.data_ptr(), labels.to(DEV).data_ptr(), n, c, loss.data_ptr(), dl.data_ptr(), st), "ce")
+    want = torch.nn.functional.cross_entropy(logits.cpu(), labels)
+    assert abs(float(loss.item()) - float(want)) < 1e-6
+    good = dl.cpu().clone()
+    for bad in (7, -1, 2 ** 32 + 1, 2 ** 40):
+        lb = labels.clone()
+        lb[3] = bad
+        _lib.check(lib.gv_softmax_ce(logits.data_ptr(), lb.to(DEV).data_ptr(), n, c, loss.data_ptr(), dl.data_ptr(), st), "ce")
+        assert math.isnan(float(loss.item())), bad
+        d = dl.cpu()
+        assert torch.isnan(d[3]).all() and torch.equal(d[[0, 1, 2, 4]], good[[0, 1, 2, 4]]), bad
+
+
+def test_trainer_raises_like_the_host_group_scheme_on_a_score_of_one():
+    """a view score of exactly 1.0 (bin == num_group) leaves that view in no group while the loss
+    stays finite; the reference's host group_scheme raises IndexError there (nets/model.py:23 via train.py:277).
+    Trainer.step reads the status word of the step in its check."""
+    from gvcnn_tf_amd.trainer import Trainer
+    N, V, size, C_, G = 2, 2, 64, 5, 10
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    labels = torch.tensor([1, 3]).to(DEV)
+    eng = TrainGVCNN("resnet_v2_50", N, V, size, size, C_, G, device=DEV, seed=7)
+    tr = Trainer(eng, base_learning_rate=1e-4, training_number_of_steps=50, check_every=1)
+    tr.step(x, labels)                                            # fine
+    eng.score_bias[0] = 1e9                                       # |r| >= 3e7 rounds sigmoid(log|r|) to exactly 1.0f
+    with pytest.raises(IndexError, match="index 10 is out of bounds for axis 0 with size 10"):
+        tr.step(x, labels)

@@ -24,6 +24,7 @@ ap.add_argument("--tiles", action="store_true")
 ap.add_argument("--json", default=None)
 ap.add_argument("--ablate", action="store_true", help="time ablated kernels (no loads / no LDS writes / no stores)")
 ap.add_argument("--autotune", action="store_true")
+ap.add_argument("--ablate-bits", type=int, default=4)
 ap.add_argument("--no-fuse", action="store_true")
 ap.add_argument("--math", default="f32")
 ap.add_argument("--storage", default="f32")
@@ -63,7 +64,7 @@ for i, op in enumerate(plan.ops):
             row["tile_ms"] = tt
         if a.ablate:
             ab = []
-            for bits in (4,):
+            for bits in (a.ablate_bits,):
                 lib.gv_conv2d_set_debug(bits)
                 ab.append(round(plan.time_range(x, i, 1, 3), 4))
             lib.gv_conv2d_set_debug(0)
@@ -81,5 +82,10 @@ print("total: conv %.3f ms, pool %.3f ms, ssa %.3f ms; conv %.2f TF/s" % (
 whole = plan.time_range(x, 0, len(plan.ops), a.iters)
 print("whole plan back-to-back: %.3f ms (%.2f TF/s), activations %.1f MB" % (
     whole, flops / whole / 1e9, plan.act_bytes / 1e6))
+if a.ablate:
+    lib.gv_conv2d_set_debug(a.ablate_bits)
+    wa = plan.time_range(x, 0, len(plan.ops), a.iters)
+    lib.gv_conv2d_set_debug(0)
+    print("whole plan with ablation bits %d: %.3f ms" % (a.ablate_bits, wa))
 if a.json:
     json.dump({"rows": rows, "totals": tot, "whole_ms": whole}, open(a.json, "w"))
