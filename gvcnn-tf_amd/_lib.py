@@ -11,9 +11,11 @@ LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
 
 GV_F32, GV_BF16, GV_F16 = 0, 1, 2
 GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT, GV_CONV_X_F32 = 1, 2, 4, 8
+GV_CONV_X_P3, GV_CONV_Y_P3, GV_CONV_Y2_P3 = 16, 32, 64
 GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
 GV_POOL_MAX, GV_POOL_AVG, GV_POOL_AVG_RELU = 0, 1, 2
 GV_POOL_BWD_STORE = 0x100
+GV_POOL_X_P3 = 0x200
 GV_ACCUM_ZEROED = 0x100
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1

@@ -56,23 +56,26 @@ def _out_size(in_size, k, s, padding):
 
 
 class TRef:
-    """A [nb,h,w,c] NHWC tensor inside a (virtual) buffer: element offset + pixel stride."""
-    __slots__ = ("vbuf", "off", "nb", "h", "w", "c", "ld")
+    """A [nb,h,w,c] NHWC tensor inside a (virtual) buffer: element offset + pixel stride.  p3: the tensor holds every
+    fp32 value as three bf16 planes, [pixel][channel/16][plane][16] (6 bytes per value: GV_CONV_Y_P3 / GV_CONV_X_P3);
+    offsets and strides stay in channels (multiples of 16)."""
+    __slots__ = ("vbuf", "off", "nb", "h", "w", "c", "ld", "p3")
 
-    def __init__(self, vbuf, off, nb, h, w, c, ld):
-        self.vbuf, self.off, self.nb, self.h, self.w, self.c, self.ld = vbuf, off, nb, h, w, c, ld
+    def __init__(self, vbuf, off, nb, h, w, c, ld, p3=False):
+        self.vbuf, self.off, self.nb, self.h, self.w, self.c, self.ld, self.p3 = vbuf, off, nb, h, w, c, ld, p3
 
     def channels(self, lo, hi):
         assert 0 <= lo < hi <= self.c
-        return TRef(self.vbuf, self.off + lo, self.nb, self.h, self.w, hi - lo, self.ld)
+        assert not self.p3 or (lo % 16 == 0 and hi % 16 == 0), "a three-plane tensor is sliced on 16-channel groups"
+        return TRef(self.vbuf, self.off + lo, self.nb, self.h, self.w, hi - lo, self.ld, self.p3)
 
     @property
     def npix(self):
         return self.nb * self.h * self.w
 
     def __repr__(self):
-        return "TRef(v%d+%d [%d,%d,%d,%d] ld=%d)" % (self.vbuf, self.off, self.nb, self.h, self.w,
-                                                      self.c, self.ld)
+        return "TRef(v%d+%d [%d,%d,%d,%d] ld=%d%s)" % (self.vbuf, self.off, self.nb, self.h, self.w,
+                                                        self.c, self.ld, " p3" if self.p3 else "")
 
 
 class BackbonePlan:
@@ -99,6 +102,11 @@ class BackbonePlan:
         self.keepalive = []
         self.cur_lane = 0
         self.use_lanes = True
+        # fp32 storage + GV_MATH_BF16X3: conv -> conv intermediates are kept as three bf16 planes so that the consumer's
+        # LDS-DMA loader only moves bytes (csrc/conv_dma.hip); everything a pool, the grouping module or a caller reads
+        # stays fp32
+        self.use_p3 = dtype == _lib.GV_F32 and math_mode == _lib.GV_MATH_BF16X3
+        self.p3_blocks = None             # None: every block; else the set of block / stem-layer names that use it
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -118,9 +126,10 @@ class BackbonePlan:
         op["lane"] = self.cur_lane
         self.ops.append(op)
 
-    def new_tensor(self, nb, h, w, c, persistent=False):
-        self.vbufs.append([nb * h * w * c, persistent])
-        return TRef(len(self.vbufs) - 1, 0, nb, h, w, c, c)
+    def new_tensor(self, nb, h, w, c, persistent=False, p3=False):
+        p3 = bool(p3) and self.use_p3 and c % 16 == 0
+        self.vbufs.append([nb * h * w * c, persistent, p3])
+        return TRef(len(self.vbufs) - 1, 0, nb, h, w, c, c, p3)
 
     def keep(self, t):
         if t.vbuf >= 0:
@@ -184,7 +193,8 @@ class BackbonePlan:
         for scope, c in branches:
             self.ss_specs.append(("bn", scope + "/BatchNorm", c, norm[1], norm[2], so + cum, ho + cum))
             cum += c
-        scratch = self.new_tensor(x.nb, x.h, x.w, rest)
+        # the members other than the first feed 3x3 / 5x5 / 1x7 convs (and the commuted average pool): three-plane storage
+        scratch = self.new_tensor(x.nb, x.h, x.w, rest, p3=all(c % 16 == 0 for c in couts[1:]) and couts[0] % 8 == 0)
         self._record(dict(kind="conv", name="+".join(sc for sc, _ in branches), x=x, y=first_out,
                              y2=scratch, res=None, w_off=w_off, scale_off=so, shift_off=ho,
                              scale2_off=0, shift2_off=0, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
@@ -201,12 +211,12 @@ class BackbonePlan:
             out = pooled[3]
             assert (out.nb, out.h, out.w, out.c) == (x.nb, x.h, x.w, pooled[1])
             self._record(dict(kind="pool", name=pooled[2], x=z, y=out, k=3, stride=1, pad_t=1, pad_l=1,
-                              mode=_lib.GV_POOL_AVG_RELU, flops=0.0,
+                              mode=_lib.GV_POOL_AVG_RELU | (_lib.GV_POOL_X_P3 if z.p3 else 0), flops=0.0,
                               bytes=float(self.esz) * 2 * z.npix * z.c))
         return outs
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
-             residual=None, next_preact=None):
+             residual=None, next_preact=None, p3=False):
         """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
         norm = None -> biases, no BN (normalizer_fn=None).  next_preact = (bn_scope, eps) adds the
         second output relu(bn(out)) and returns (out, preact)."""
@@ -214,7 +224,8 @@ class BackbonePlan:
         oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
         ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
         if out is None:
-            out = self.new_tensor(x.nb, oh, ow, cout)
+            # p3: the output only feeds other convolutions (a conv -> conv intermediate)
+            out = self.new_tensor(x.nb, oh, ow, cout, p3=p3 and next_preact is None and residual is None and x.c >= 16)
         assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, cout), (scope, out, oh, ow, cout)
         w_off = self._filter(scope + "/weights", kh, kw, x.c, cout)
         if norm is not None:
@@ -237,6 +248,7 @@ class BackbonePlan:
         return (out, y2) if next_preact is not None else out
 
     def pool(self, x, k, stride, padding, mode, out=None, name="pool"):
+        assert not x.p3, "pools read fp32 (only the commuted Inception branch pool takes three-plane input)"
         oh, pad_t = _out_size(x.h, k, stride, padding)
         ow, pad_l = _out_size(x.w, k, stride, padding)
         if out is None:
@@ -273,6 +285,8 @@ class BackbonePlan:
                     first_def.setdefault(t.vbuf, i)
                     lanes_of.setdefault(t.vbuf, set()).add(op.get("lane", 0))
         phys_sizes = []
+        phys_p3 = []               # a physical buffer holds either fp32 / 16-bit tensors or three-plane tensors
+        self._phys_p3 = phys_p3
         free = []                  # (physical id, op index at which it was released, lanes that touched it)
         vmap = {}
         # A buffer released by one lane is not handed to ANOTHER lane for REUSE_DELAY ops: immediate
@@ -286,7 +300,8 @@ class BackbonePlan:
                 if t is None or t.vbuf in vmap:
                     continue
                 need = self.vbufs[t.vbuf][0]
-                ok = [f for f in free if f[2] == {lane} or f[1] <= i - REUSE_DELAY]
+                fmt = self.vbufs[t.vbuf][2]
+                ok = [f for f in free if (f[2] == {lane} or f[1] <= i - REUSE_DELAY) and phys_p3[f[0]] == fmt]
                 cand = [f for f in ok if phys_sizes[f[0]] >= need]
                 if cand:
                     f = min(cand, key=lambda q: phys_sizes[q[0]])
@@ -300,6 +315,7 @@ class BackbonePlan:
                 else:
                     p = len(phys_sizes)
                     phys_sizes.append(need)
+                    phys_p3.append(fmt)
                 vmap[t.vbuf] = p
             for v, lu in list(last_use.items()):
                 if lu == i and v in vmap and not self.vbufs[v][1]:
@@ -340,6 +356,13 @@ class BackbonePlan:
                     flags |= _lib.GV_CONV_RELU2
                 if lowp and x.vbuf < 0:
                     flags |= _lib.GV_CONV_X_F32               # the images stay fp32; the stem's loader rounds them
+                if x.p3:
+                    flags |= _lib.GV_CONV_X_P3
+                if y.p3:
+                    flags |= _lib.GV_CONV_Y_P3
+                if y2 is not None and y2.p3:
+                    assert split, "a three-plane second destination exists only for fused sibling convs"
+                    flags |= _lib.GV_CONV_Y2_P3
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], y.h, y.w, op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
@@ -365,9 +388,11 @@ class BackbonePlan:
         self.tdtype = TORCH_DTYPES[self.dtype]
         self.weights = torch.zeros(max(self.w_elems, 4), dtype=torch.float32, device=device)   # 4-byte units
         self.ss = torch.zeros(max(self.ss_elems, 4), dtype=torch.float32, device=device)
-        self.act = [torch.empty((n + 7) // 8 * 8, dtype=self.tdtype, device=device) for n in phys_sizes]
+        self.act = [torch.empty(((n + 7) // 8 * 8) * 3, dtype=torch.int16, device=device) if p3_ else
+                    torch.empty((n + 7) // 8 * 8, dtype=self.tdtype, device=device)
+                    for n, p3_ in zip(phys_sizes, self._phys_p3)]
         self._bufs = [None, self.weights, self.ss] + self.act
-        self.act_bytes = sum(phys_sizes) * self.esz
+        self.act_bytes = sum(n * (6 if p3_ else self.esz) for n, p3_ in zip(phys_sizes, self._phys_p3))
         return self
 
     def _schedule(self, vmap):
@@ -417,6 +442,11 @@ class BackbonePlan:
     def view(self, t):
         """torch view [nb,h,w,c] of a plan tensor (strided when it is a channel slice)."""
         base = self._bufs[SLOT_ACT0 + self._phys[t.vbuf]]
+        if t.p3:                                          # three planes: an fp32 COPY (exact sum), not a view
+            from . import p3 as _p3
+            g = torch.as_strided(base, (t.nb, t.h, t.w, t.c // 16, 3, 16),
+                                 (t.h * t.w * t.ld * 3, t.w * t.ld * 3, t.ld * 3, 48, 16, 1), t.off * 3)
+            return _p3.from_p3(g)
         return torch.as_strided(base, (t.nb, t.h, t.w, t.c), (t.h * t.w * t.ld, t.w * t.ld, t.ld, 1),
                                 t.off)
 
@@ -501,7 +531,8 @@ class BackbonePlan:
         the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
         chain sums k in the same order under every configuration, so results are bitwise unchanged."""
         lib = self.lib
-        ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dtype == _lib.GV_F32 else -1)   # -1: 16-bit storage
+        ncfg_plan = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dtype == _lib.GV_F32 else -1)   # -1: 16-bit storage
+        ncfg_p3 = lib.gv_conv2d_num_tile_cfgs(-3)             # three-plane input: the LDS-DMA kernel's own table
         self.run(x)
         chosen = {}
         try:
@@ -509,6 +540,7 @@ class BackbonePlan:
                 if op["kind"] != "conv":
                     continue
                 best, best_ms = 0, float("inf")
+                ncfg = ncfg_p3 if op["x"].p3 else ncfg_plan
                 for t in range(ncfg):
                     lib.gv_conv2d_set_tile_override(t)
                     try:
@@ -566,7 +598,12 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     BN = ("bn", INCEPTION_BN_EPS, False)
     MAX, AVG = _lib.GV_POOL_MAX, _lib.GV_POOL_AVG
 
-    def conv(x, name, cout, k, stride=1, padding="SAME", out=None):
+    def conv(x, name, cout, k, stride=1, padding="SAME", out=None, mid=False):
+        """mid: the output only feeds further convolutions of the same branch -> three-plane storage where the plan
+        uses it (an end point somebody taps stays fp32; `b.p3_blocks` names the blocks that use it: a speed choice)."""
+        blk = name.split("/")[0]
+        if mid and b.use_p3 and name not in keep and (b.p3_blocks is None or blk in b.p3_blocks):
+            return b.conv(x, scope + "/" + name, cout, k, stride, padding, out=out, norm=BN, relu=True, p3=True)
         return b.conv(x, scope + "/" + name, cout, k, stride, padding, out=out, norm=BN, relu=True)
 
     def siblings(x, branches, first_out, pooled=None):
@@ -575,7 +612,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         if not fuse_siblings:
             outs = []
             for i, (name, c) in enumerate(branches):
-                t = conv(x, name, c, 1, out=first_out if i == 0 else None)
+                t = conv(x, name, c, 1, out=first_out if i == 0 else None, mid=i > 0)
                 if i:
                     outs.append(t)
             if pooled is not None:
@@ -588,7 +625,13 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         if pooled is not None:
             s, depth, dst = pooled
             pb = (scope + "/" + s + "Branch_3/Conv2d_0b_1x1", depth, s + "Branch_3/AvgPool_0a_3x3", dst)
-        return b.conv_siblings(x, [(scope + "/" + n, c) for n, c in branches], first_out, BN, pooled=pb)
+        blk = branches[0][0].split("/")[0]
+        saved = b.use_p3
+        b.use_p3 = saved and (b.p3_blocks is None or blk in b.p3_blocks)
+        try:
+            return b.conv_siblings(x, [(scope + "/" + n, c) for n, c in branches], first_out, BN, pooled=pb)
+        finally:
+            b.use_p3 = saved
 
     def done(name, t):
         b.end_points[name] = t
@@ -598,13 +641,13 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
 
     net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
     if done("Conv2d_1a_3x3", net): return net
-    net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID")
+    net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
     if done("Conv2d_2a_3x3", net): return net
     net = conv(net, "Conv2d_2b_3x3", 64, 3, 1, "SAME")
     if done("Conv2d_2b_3x3", net): return net
     net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_3a_3x3")
     if done("MaxPool_3a_3x3", net): return net
-    net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID")
+    net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID", mid=final_endpoint != "Conv2d_3b_1x1")
     if done("Conv2d_3b_1x1", net): return net
     net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID")
     if done("Conv2d_4a_3x3", net): return net
@@ -619,7 +662,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
                           pooled=(s, pool_depth, out.channels(224, 224 + pool_depth)))
         with b.lane(1):
             conv(t1, s + "Branch_1/" + b1b, 64, 5, out=out.channels(64, 128))
-        t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 96, 3)
+        t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 96, 3, mid=True)
         conv(t, s + "Branch_2/Conv2d_0c_3x3", 96, 3, out=out.channels(128, 224))
         return out
 
@@ -637,8 +680,8 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     out = b.new_tensor(net.nb, oh, ow, 384 + 96 + net.c)
     conv(net, s + "Branch_0/Conv2d_1a_1x1", 384, 3, 2, "VALID", out=out.channels(0, 384))
     with b.lane(1):
-        t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 64, 1)
-        t = conv(t, s + "Branch_1/Conv2d_0b_3x3", 96, 3)
+        t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 64, 1, mid=True)
+        t = conv(t, s + "Branch_1/Conv2d_0b_3x3", 96, 3, mid=True)
         conv(t, s + "Branch_1/Conv2d_1a_1x1", 96, 3, 2, "VALID", out=out.channels(384, 480))
     with b.lane(2):
         b.pool(net, 3, 2, "VALID", MAX, out=out.channels(480, 480 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
@@ -652,11 +695,11 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
                               (s + "Branch_2/Conv2d_0a_1x1", d)], out.channels(0, 192),
                           pooled=(s, 192, out.channels(576, 768)))
         with b.lane(1):
-            t = conv(t1, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7))
+            t = conv(t1, s + "Branch_1/Conv2d_0b_1x7", d, (1, 7), mid=True)
             conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), out=out.channels(192, 384))
-        t = conv(t2, s + "Branch_2/Conv2d_0b_7x1", d, (7, 1))
-        t = conv(t, s + "Branch_2/Conv2d_0c_1x7", d, (1, 7))
-        t = conv(t, s + "Branch_2/Conv2d_0d_7x1", d, (7, 1))
+        t = conv(t2, s + "Branch_2/Conv2d_0b_7x1", d, (7, 1), mid=True)
+        t = conv(t, s + "Branch_2/Conv2d_0c_1x7", d, (1, 7), mid=True)
+        t = conv(t, s + "Branch_2/Conv2d_0d_7x1", d, (7, 1), mid=True)
         conv(t, s + "Branch_2/Conv2d_0e_1x7", 192, (1, 7), out=out.channels(384, 576))
         return out
 
@@ -669,12 +712,12 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     oh = (net.h - 3) // 2 + 1
     ow = (net.w - 3) // 2 + 1
     out = b.new_tensor(net.nb, oh, ow, 320 + 192 + net.c)
-    t = conv(net, s + "Branch_0/Conv2d_0a_1x1", 192, 1)
+    t = conv(net, s + "Branch_0/Conv2d_0a_1x1", 192, 1, mid=True)
     conv(t, s + "Branch_0/Conv2d_1a_3x3", 320, 3, 2, "VALID", out=out.channels(0, 320))
     with b.lane(1):
-        t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 192, 1)
-        t = conv(t, s + "Branch_1/Conv2d_0b_1x7", 192, (1, 7))
-        t = conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1))
+        t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 192, 1, mid=True)
+        t = conv(t, s + "Branch_1/Conv2d_0b_1x7", 192, (1, 7), mid=True)
+        t = conv(t, s + "Branch_1/Conv2d_0c_7x1", 192, (7, 1), mid=True)
         conv(t, s + "Branch_1/Conv2d_1a_3x3", 192, 3, 2, "VALID", out=out.channels(320, 512))
     with b.lane(2):
         b.pool(net, 3, 2, "VALID", MAX, out=out.channels(512, 512 + net.c), name=s + "Branch_2/MaxPool_1a_3x3")
@@ -690,7 +733,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         with b.lane(1):
             conv(t1, s + "Branch_1/Conv2d_0b_1x3", 384, (1, 3), out=out.channels(320, 704))
             conv(t1, s + "Branch_1/" + b1_3x1, 384, (3, 1), out=out.channels(704, 1088))
-        t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 384, 3)
+        t = conv(t2, s + "Branch_2/Conv2d_0b_3x3", 384, 3, mid=True)
         conv(t, s + "Branch_2/" + b2_names[0], 384, (1, 3), out=out.channels(1088, 1472))
         conv(t, s + "Branch_2/" + b2_names[1], 384, (3, 1), out=out.channels(1472, 1856))
         return out
@@ -755,6 +798,12 @@ TAPS = {"resnet_v2_50": ("resnet_v2_50/block3", "resnet_v2_50/block4"),
         "inception_v3": ("Mixed_6e", "Mixed_7c")}
 
 
+# where three-plane intermediates pay (measured per block on MI355X, tools/layer_times.py --p3 none|default|all,
+# gpurun_out/r2/lt_x3_p3_*.txt): every Mixed block and Conv2d_3b -> Conv2d_4a; the 32-channel stem pair Conv2d_2a -> 2b
+# runs faster on fp32 storage (halo kernel for 2a; at N = 64 the 9x im2col re-read of a 6-byte operand is L2-bound)
+P3_DEFAULT_BLOCKS = ("Conv2d_3b_1x1", "Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b",
+                     "Mixed_7c")
+
 DTYPES = {"f32": _lib.GV_F32, "bf16": _lib.GV_BF16, "f16": _lib.GV_F16}
 TORCH_DTYPES = {_lib.GV_F32: torch.float32, _lib.GV_BF16: torch.bfloat16, _lib.GV_F16: torch.float16}
 MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": _lib.GV_MATH_BF16X2,
@@ -762,10 +811,20 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True):
+              math="f32", lanes=True, p3=True):
+    """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
+    the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
+    blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere."""
     dtype = DTYPES[dtype] if isinstance(dtype, str) else dtype
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     b.use_lanes = bool(lanes)
+    b.use_p3 = b.use_p3 and bool(p3)
+    if isinstance(p3, (set, frozenset, list, tuple)):
+        b.p3_blocks = set(p3)
+    elif p3 is True:
+        b.p3_blocks = set(P3_DEFAULT_BLOCKS)
+    else:
+        b.p3_blocks = None                 # "all": every conv -> conv intermediate
     raw_tap = raw_tap or TAPS[backbone][0]
     final_tap = final_tap or TAPS[backbone][1]
     if backbone == "inception_v3":

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "conv_x3_epi.h"
 
 namespace {
 
@@ -353,7 +354,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
         mfma_range(I0{}, I0{}, IN{});
     }
 
-    gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
+    if (a.y_p3 | a.y2_p3) {                           // a three-plane destination: the LDS-staged epilogue
+        __syncthreads();                              // every wave is done with the main-loop buffers
+        x3_epilogue_staged<TM, TN>(a, acc, m0, n0, wm, wn, lane,
+                                   reinterpret_cast<float*>(smem_raw + wave * X3EpiGeom<TN>::BYTES));
+    } else {
+        gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -714,7 +721,11 @@ int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
     const int tiles_m = gv_ceil_div(a.M, BM);
     const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t lds = (size_t)(2 * BM + 2 * BN) * (NP * 32 + 16) + (generic ? (size_t)a.Kpad * 8 : 0);
+    size_t lds = (size_t)(2 * BM + 2 * BN) * (NP * 32 + 16) + (generic ? (size_t)a.Kpad * 8 : 0);
+    if (a.y_p3 | a.y2_p3) {
+        const size_t epi = (size_t)(WM * WN) * X3EpiGeom<TN>::BYTES;
+        lds = lds > epi ? lds : epi;
+    }
     if (generic) {
         if (lds > 64 * 1024) {
             static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, true>),
@@ -760,14 +771,14 @@ int bf16s_num_cfgs() { return kNumTiles + 1; }          // + the halo-tiled stem
 
 // the 3-channel stems: square 3x3 or 7x7 window, stride 2, <= 64 output channels, plain epilogue
 bool bf16s_stem_ok(int planes, const ConvArgs& a) {
-    return planes == 3 && a.cin == 3 && a.kh == a.kw && (a.kw == 3 || a.kw == 7) && a.stride == 2 && a.cout <= 64 &&
+    return planes == 3 && !a.y_p3 && a.cin == 3 && a.kh == a.kw && (a.kw == 3 || a.kw == 7) && a.stride == 2 && a.cout <= 64 &&
            a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.res == nullptr &&
            (int64_t)a.nb * a.ih * a.iw * a.x_ld < 0x7fffffffll;
 }
 
 // the halo kernel's layer class: 3x3 / stride 1, 32 input channels, <= 64 output channels, plain epilogue
 bool bf16s_halo_ok(int planes, const ConvArgs& a, bool generic) {
-    return planes == 3 && !generic && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cin == 32 && a.cout <= 64 &&
+    return planes == 3 && !generic && !a.y_p3 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cin == 32 && a.cout <= 64 &&
            a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.oh == a.ih + 2 * a.pad_t - 2 &&
            a.ow == a.iw + 2 * a.pad_l - 2;
 }

@@ -25,6 +25,7 @@ struct ConvArgs {
     int dil_shift;              // 0: plain; 1: input read as zero-dilated by 2 (stride-2 data gradient)
     int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
     const void* zeros;          // conv_dma.hip: a zero page for the padding taps of the gather
+    int y_p3, y2_p3;            // destination format: 0 = fp32, 1 = three bf16 planes (conv_x3_epi.h)
 };
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:
@@ -105,5 +106,9 @@ int lp_special_cfg();           // the strip / halo kernels of the stem layers
 int dma_lp_num_cfgs();
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32);
 int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);
+// fp32 values stored as three bf16 planes ("P3": [pixel][channel/16][plane][16]), GV_MATH_BF16X3
+int dma_x3_num_cfgs();
+bool dma_x3_ok(const ConvArgs& a);
+int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st);
 
 }  // namespace gvconv

@@ -25,6 +25,7 @@
 
 #include "conv_common.h"
 #include "conv_lp_epi.h"
+#include "conv_x3_epi.h"
 
 namespace {
 
@@ -53,7 +54,8 @@ __host__ __device__ constexpr int dprod_count(int np) { return np == 3 ? 6 : 1; 
 __host__ __device__ constexpr int dprod_pa(int np, int t) { return np == 3 ? (t == 0 ? 2 : (t == 2 || t == 3 ? 1 : 0)) : 0; }
 __host__ __device__ constexpr int dprod_pb(int np, int t) { return np == 3 ? (t == 1 ? 2 : (t == 2 || t == 4 ? 1 : 0)) : 0; }
 
-// EPI: 0 = 16-bit output through the LDS-staged epilogue (conv_lp_epi.h)
+// EPI: 0 = 16-bit output through the LDS-staged epilogue (conv_lp_epi.h); 1 = fp32 output straight from the accumulators
+// (conv_common.h); 2 = fp32 or three-plane (P3) output through the staged epilogue of conv_x3_epi.h
 template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     using G = DmaGeom<NP>;
@@ -295,6 +297,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     __syncthreads();                                               // every wave is done with the ring: reuse it for staging
     if constexpr (EPI == 0)
         lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES));
+    else if constexpr (EPI == 1)
+        gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
+    else
+        x3_epilogue_staged<TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * X3EpiGeom<TN>::BYTES));
 }
 
 // one zero page per device for the padding taps of the gather (lazily allocated OUTSIDE any stream capture: every
@@ -327,7 +333,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
     a.zeros = zero_page_for_current_device();
     if (!a.zeros) return GV_E_UNSUPPORTED;
     const size_t ring = (size_t)ST * NP * (BM + BN) * G::RBYTES;
-    const size_t epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
+    const size_t epi = EPI == 1 ? 0 : (size_t)(WM * WN) * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
     const size_t lds = ring > epi ? ring : epi;
     auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI>;
     if (lds > 64 * 1024) {
@@ -359,9 +365,41 @@ int launch_dma_lp(int cfg, const ConvArgs& a, hipStream_t st) {
     return GV_E_UNSUPPORTED;
 }
 
+// fp32 values as three bf16 planes (P3 input); fp32 output straight from the accumulators, or P3 output staged
+template <int EPI>
+int launch_dma_x3_e(int cfg, const ConvArgs& a, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_dma<__bf16, 3, 2, 2, 2, 2, 3, EPI>(a, st);      // 128 x 128, 4 waves, 3 stages of 24 KB: two per CU
+        case 1: return launch_dma<__bf16, 3, 4, 2, 2, 2, 3, EPI>(a, st);      // 256 x 128, 8 waves
+        case 2: return launch_dma<__bf16, 3, 2, 4, 2, 2, 3, EPI>(a, st);      // 128 x 256, 8 waves
+        case 3: return launch_dma<__bf16, 3, 2, 2, 2, 3, 3, EPI>(a, st);      // 128 x 192, 4 waves
+        case 4: return launch_dma<__bf16, 3, 4, 1, 1, 3, 4, EPI>(a, st);      // 128 x 96
+        case 5: return launch_dma<__bf16, 3, 2, 2, 2, 1, 4, EPI>(a, st);      // 128 x 64
+        case 6: return launch_dma<__bf16, 3, 2, 2, 1, 2, 4, EPI>(a, st);      // 64 x 128
+        case 7: return launch_dma<__bf16, 3, 4, 2, 2, 3, 2, EPI>(a, st);      // 256 x 192, 8 waves, 2 stages of 42 KB
+        case 8: return launch_dma<__bf16, 3, 4, 2, 2, 3, 3, EPI>(a, st);      // 256 x 192, 8 waves, 3 stages (126 KB)
+        case 9: return launch_dma<__bf16, 3, 4, 1, 2, 2, 3, EPI>(a, st);      // 256 x 64, 4 waves (64 x 64 each)
+        case 10: return launch_dma<__bf16, 3, 4, 1, 2, 3, 3, EPI>(a, st);     // 256 x 96, 4 waves (64 x 96 each)
+        case 11: return launch_dma<__bf16, 3, 2, 2, 2, 2, 4, EPI>(a, st);     // 128 x 128, 4 stages
+        case 12: return launch_dma<__bf16, 3, 2, 2, 4, 2, 2, EPI>(a, st);     // 256 x 128, FOUR waves (128 x 64 each), 2 stages
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+int launch_dma_x3(int cfg, const ConvArgs& a, hipStream_t st) {
+    return a.y_p3 ? launch_dma_x3_e<2>(cfg, a, st) : launch_dma_x3_e<1>(cfg, a, st);
+}
+
 }  // namespace
 
 namespace gvconv {
+
+int dma_x3_num_cfgs() { return 13; }
+
+// P3 input: whole 16-channel groups inside one filter tap
+bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; }
+
+int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) { return launch_dma_x3(cfg, a, st); }
 
 int dma_lp_num_cfgs() { return 12; }
 

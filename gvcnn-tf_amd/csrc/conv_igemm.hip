@@ -381,6 +381,7 @@ extern "C" int gv_conv2d_special_tile_cfg(int32_t math_mode) {
 
 extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
     if (math_mode == -1) return gvconv::lp_num_cfgs();     // the 16-bit storage kernels
+    if (math_mode == -3) return gvconv::dma_x3_num_cfgs();  // three-plane input (GV_CONV_X_P3)
     const int np = planes_of(math_mode);
     return np < 0 ? GV_E_BADARG : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs());
 }
@@ -453,7 +454,21 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     if ((d->flags & GV_CONV_X_F32) && !lp) return GV_E_BADARG;
     const int np = lp ? 1 : planes_of(d->math_mode);
     if (np < 0) return GV_E_BADARG;
-    const int ncfg = lp ? gvconv::lp_num_cfgs() : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs());
+    const bool xp3 = (d->flags & GV_CONV_X_P3) != 0;
+    const bool yp3 = (d->flags & GV_CONV_Y_P3) != 0, y2p3 = (d->flags & GV_CONV_Y2_P3) != 0;
+    if ((xp3 || yp3 || y2p3) && (lp || np != 3)) return GV_E_BADARG;
+    if (y2p3 && !split) return GV_E_BADARG;
+    if (yp3 || y2p3) {
+        // whole 16-channel groups per destination, 8-column chunks in the staged epilogue, no second activation
+        if (d->cout % 8 != 0 || (y2 && !split) || (residual && d->res_ld % 4 != 0)) return GV_E_UNSUPPORTED;
+        if (yp3 && (d->y_ld % 16 != 0 || (split ? d->split_col : d->cout) % 16 != 0)) return GV_E_UNSUPPORTED;
+        if (y2p3 && (d->y2_ld % 16 != 0 || (d->cout - d->split_col) % 16 != 0 || d->split_col % 8 != 0)) return GV_E_UNSUPPORTED;
+        if (!yp3 && (d->y_ld % 4 != 0 || !gv_aligned16(y))) return GV_E_ALIGN;
+        if (split && !y2p3 && (d->y2_ld % 4 != 0 || !gv_aligned16(y2))) return GV_E_ALIGN;
+        if (split && d->split_col % 8 != 0) return GV_E_UNSUPPORTED;
+    }
+    const int ncfg = lp ? gvconv::lp_num_cfgs()
+                        : (xp3 ? gvconv::dma_x3_num_cfgs() : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs()));
     if (d->tile_cfg < 0 || d->tile_cfg > ncfg) return GV_E_BADARG;
     const int64_t M64 = (int64_t)d->nb * d->oh * d->ow;
     if (M64 > 0x7fffffff || (int64_t)d->nb * d->ih * d->iw > 0x7fffffff) return GV_E_UNSUPPORTED;
@@ -478,6 +493,8 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.tiles_n = 0;
     a.dbg = g_debug;
     a.zeros = nullptr;
+    a.y_p3 = (d->flags & GV_CONV_Y_P3) ? 1 : 0;
+    a.y2_p3 = (d->flags & GV_CONV_Y2_P3) ? 1 : 0;
     if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) return GV_E_BADARG;
     a.dil_shift = d->in_dilation == 2 ? 1 : 0;
     if (a.dil_shift && (np == 0 || (d->cin % CH != 0) || d->stride != 1)) return GV_E_UNSUPPORTED;
@@ -495,6 +512,12 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
                                   ? gvconv::lp_special_cfg()
                                                                               : gvconv::lp_pick_tile(a.M, a.cout, a.K)));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
+    }
+    if (xp3) {                                           // three-plane input: the LDS-DMA kernel
+        if (!gvconv::dma_x3_ok(a) || !gv_aligned16(x) || split || y2) return GV_E_UNSUPPORTED;
+        const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
+                        : (d->tile_cfg > 0 ? d->tile_cfg - 1 : 0);
+        return gvconv::dma_x3_launch(cfg, a, (hipStream_t)stream);
     }
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
     const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);

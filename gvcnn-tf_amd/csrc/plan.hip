@@ -71,16 +71,20 @@ int run_op(const Op& o, void* const* bufs, void* stream) {
     switch (o.kind) {
         case OP_CONV: {
             const size_t es = elem_size(o.conv.dtype);
-            const size_t xes = (o.conv.flags & GV_CONV_X_F32) ? 4 : es;      // fp32 network input
+            // fp32 network input; three-plane operands are 6 bytes per value
+            const size_t xes = (o.conv.flags & GV_CONV_X_F32) ? 4 : ((o.conv.flags & GV_CONV_X_P3) ? 6 : es);
+            const size_t yes = (o.conv.flags & GV_CONV_Y_P3) ? 6 : es;
+            const size_t y2es = (o.conv.flags & GV_CONV_Y2_P3) ? 6 : es;
             return gv_conv2d_fwd(&o.conv, at(bufs, o.x, xes), at(bufs, o.w, es),
                                  (const float*)at(bufs, o.scale, 4), (const float*)at(bufs, o.shift, 4),
-                                 at(bufs, o.res, es), at(bufs, o.y, es), at(bufs, o.y2, es),
+                                 at(bufs, o.res, es), at(bufs, o.y, yes), at(bufs, o.y2, y2es),
                                  (const float*)at(bufs, o.scale2, 4),
                                  (const float*)at(bufs, o.shift2, 4), stream);
         }
         case OP_POOL: {
             const size_t es = elem_size(o.pool.dtype);
-            return gv_pool2d_fwd(&o.pool, at(bufs, o.x, es), at(bufs, o.y, es), stream);
+            const size_t xes = (o.pool.mode & GV_POOL_X_P3) ? 6 : es;
+            return gv_pool2d_fwd(&o.pool, at(bufs, o.x, xes), at(bufs, o.y, es), stream);
         }
         case OP_SSA: {
             const size_t es = elem_size(o.dtype);

@@ -10,6 +10,7 @@
 #include <math.h>
 
 #include "gv_common.h"
+#include "conv_x3_epi.h"
 #include "lowp.h"
 
 namespace {
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
 // nets/inception_v3.py:152,...): one thread produces 4 horizontally adjacent outputs of a 4-channel
 // group from a 3x6 input patch (column sums are shared), i.e. 18 16-byte loads for 4 outputs
 // instead of 36 — the generic kernel is L2-request bound on this op (2.4 TB/s).
+// XP3: the input is in the three-plane layout of GV_CONV_Y_P3 (conv_x3_epi.h); the sum of the planes is the fp32 value.
+template <bool XP3>
 __global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __restrict__ x,
                                                              float* __restrict__ y, int nb, int ih,
                                                              int iw, int c, int x_ld, int y_ld, int relu) {
@@ -111,7 +114,12 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __rest
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int ix = ox0 - 1 + j;
-                if ((unsigned)ix < (unsigned)iw) col[j] += *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * x_ld);
+                if ((unsigned)ix < (unsigned)iw) {
+                    if constexpr (XP3)
+                        col[j] += p3_load4(reinterpret_cast<const char*>(x), (size_t)(n * ih + iy) * iw + ix, x_ld, g * 4);
+                    else
+                        col[j] += *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * x_ld);
+                }
             }
         }
 #pragma unroll
@@ -234,7 +242,20 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
         d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
         return GV_E_BADARG;
     if (d->x_ld < d->c || d->y_ld < d->c) return GV_E_BADARG;
-    if (d->mode != GV_POOL_MAX && d->mode != GV_POOL_AVG && d->mode != GV_POOL_AVG_RELU) return GV_E_BADARG;
+    const bool xp3 = (d->mode & GV_POOL_X_P3) != 0;
+    const int mode = d->mode & ~GV_POOL_X_P3;
+    if (mode != GV_POOL_MAX && mode != GV_POOL_AVG && mode != GV_POOL_AVG_RELU) return GV_E_BADARG;
+    if (xp3) {                                   // three-plane input: only the commuted Inception branch pool needs it
+        if (d->dtype != GV_F32 || mode != GV_POOL_AVG_RELU || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 ||
+            d->pad_l != 1 || d->oh != d->ih || d->ow != d->iw || d->c % 4 != 0 || d->x_ld % 16 != 0 || d->y_ld % 4 != 0 ||
+            !gv_aligned16(x) || !gv_aligned16(y))
+            return GV_E_UNSUPPORTED;
+        const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
+        hipLaunchKernelGGL(avgpool3x3s1_row4_f32<true>, dim3(grid_for(tot4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, 1);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
         return GV_E_BADARG;                   // an output whose window holds no valid tap
     if (d->pad_t >= d->kh || d->pad_l >= d->kw) return GV_E_BADARG;
@@ -246,7 +267,7 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
     if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
         const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
-        hipLaunchKernelGGL(avgpool3x3s1_row4_f32, dim3(grid_for(tot4)), dim3(256), 0, st, (const float*)x,
+        hipLaunchKernelGGL(avgpool3x3s1_row4_f32<false>, dim3(grid_for(tot4)), dim3(256), 0, st, (const float*)x,
                            (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
         GV_LAUNCH_CHECK();
         return GV_OK;

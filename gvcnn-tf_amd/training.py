@@ -31,8 +31,10 @@ class TrainPlan(backbones.BackbonePlan):
     """Symbolic op list for training: un-fused, nothing recycled."""
 
     def __init__(self, nb, height, width, math_mode, dtype=_lib.GV_F32):
+        # (the training plan keeps every tensor in its storage type: no three-plane intermediates)
         super().__init__(nb, height, width, dtype, math_mode)
         self.use_lanes = False
+        self.use_p3 = False
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
              residual=None, next_preact=None):

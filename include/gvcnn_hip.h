@@ -48,6 +48,13 @@ extern "C" {
                                  columns >= split_col (sibling convs fused into one GEMM) */
 #define GV_CONV_X_F32 8       /* 16-bit dtype only: x is fp32 (the network input, nets/model.py:121) and is
                                  rounded to `dtype` by the loader — no separate cast pass over the images */
+#define GV_CONV_X_P3 16       /* GV_F32 + GV_MATH_BF16X3 only: x holds every fp32 value as its three bf16 planes
+                                 a = a0 + a1 + a2, laid out [pixel][channel/16][plane][16] (6 bytes per value; x_ld and
+                                 the channel offset of a slice are multiples of 16 channels).  The producer split the
+                                 value once; the LDS-DMA loader (csrc/conv_dma.hip) then only moves bytes */
+#define GV_CONV_Y_P3 32       /* same dtype / math mode: y is written in that three-plane layout (y_ld, the slice offset
+                                 and cout — with GV_CONV_SPLIT split_col — multiples of 16 channels); residual stays fp32 */
+#define GV_CONV_Y2_P3 64      /* GV_CONV_SPLIT only: the second destination (columns >= split_col) is three-plane */
 
 /* gv_conv_desc.math_mode: how an fp32 convolution is evaluated on the matrix cores */
 #define GV_MATH_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                         */
@@ -60,6 +67,8 @@ extern "C" {
 #define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
 #define GV_POOL_AVG 1         /* divisor = number of VALID taps (slim.avg_pool2d, SAME) */
 #define GV_POOL_BWD_STORE 0x100 /* gv_pool2d_bwd only, OR-ed into mode, 16-bit dtypes: dx = ... instead of dx += ... */
+#define GV_POOL_X_P3 0x200    /* OR-ed into mode, GV_F32 + GV_POOL_AVG_RELU 3x3/1 SAME only: x is in the three-plane layout of
+                                 GV_CONV_Y_P3 (x_ld a multiple of 16 channels); y stays fp32 */
 #define GV_POOL_AVG_RELU 2    /* GV_POOL_AVG followed by ReLU.  avg_pool -> 1x1 conv -> BN -> ReLU
                                  (nets/inception_v3.py:152-154,...) is evaluated as relu(avgpool(BN(conv1x1(x)))):
                                  the 1x1 conv and the BN affine commute with the average (its weights sum to 1),

@@ -1,0 +1,209 @@
+"""Three-plane ("P3") storage of fp32 activations under GV_MATH_BF16X3 (csrc/conv_x3_epi.h, csrc/conv_dma.hip).
+
+Every fp32 value is kept as three bf16 planes whose sum is the value EXACTLY, so P3 is a storage format, not a precision
+change: a convolution that reads P3 through the LDS-DMA loader issues the same six plane products in the same order as the
+register-staged kernel that splits fp32 in its loader.  The tests therefore demand BITWISE equality between the two
+paths (kernel by kernel and for the whole Inception plan) on top of the usual 2e-4 parity with the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvcnn_tf_amd as gv                      # noqa: E402
+from gvcnn_tf_amd import _lib, backbones, p3   # noqa: E402
+from oracle import backbone as OB               # noqa: E402
+
+DEV = "cuda:0"
+X3 = _lib.GV_MATH_BF16X3
+
+
+def lib():
+    return _lib.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack_filter(w):
+    kh, kw, cin, cout = w.shape
+    n = lib().gv_packed_filter_bytes(kh, kw, cin, cout, _lib.GV_F32, X3) // 4
+    out = torch.empty(n, dtype=torch.float32, device=DEV)
+    wd = w.to(DEV).contiguous()
+    _lib.check(lib().gv_pack_filter_hwio(wd.data_ptr(), kh, kw, cin, cout, out.data_ptr(), _lib.GV_F32, X3, st()), "pack")
+    torch.cuda.synchronize()
+    return out
+
+
+def conv(x, w, stride, pads, out_hw, scale, shift, relu, x_p3=False, y_p3=False, split=0, y2_p3=False, relu_cols=0,
+         residual=None, tile=None, x_ld=None, x_off=0, y_ld=None, y_off=0):
+    """x [nb,ih,iw,cin] fp32 cpu.  Returns y (and y2 with split) as fp32 cpu tensors, whatever the storage format."""
+    nb, ih, iw, cin = x.shape
+    kh, kw, _, cout = w.shape
+    oh, ow = out_hw
+    x_ld = x_ld or cin
+    n1 = split if split else cout
+    n2 = cout - split
+    y_ld = y_ld or n1
+    xb = torch.full((nb, ih, iw, x_ld), 7.0)
+    xb[..., x_off:x_off + cin] = x
+    xd = (p3.to_p3(xb) if x_p3 else xb).to(DEV)
+    yd = torch.full((nb, oh, ow, y_ld), -77.0)
+    yd = (p3.to_p3(yd) if y_p3 else yd).to(DEV)
+    y2d = None
+    if split:
+        y2d = torch.full((nb, oh, ow, n2), -55.0)
+        y2d = (p3.to_p3(y2d) if y2_p3 else y2d).to(DEV)
+    wp = pack_filter(w)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    rd = residual.to(DEV).contiguous() if residual is not None else None
+    flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_SPLIT if split else 0) | \
+            (_lib.GV_CONV_X_P3 if x_p3 else 0) | (_lib.GV_CONV_Y_P3 if y_p3 else 0) | (_lib.GV_CONV_Y2_P3 if y2_p3 else 0)
+    d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
+                      cout if residual is not None else 0, n2 if split else 0, flags, _lib.GV_F32, split, 0, X3, 0, relu_cols)
+    if tile is not None:
+        lib().gv_conv2d_set_tile_override(tile)
+    try:
+        rc = lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr() + (6 if x_p3 else 4) * x_off, wp.data_ptr(), sc.data_ptr(),
+                                 sh.data_ptr(), rd.data_ptr() if rd is not None else None,
+                                 yd.data_ptr() + (6 if y_p3 else 4) * y_off, y2d.data_ptr() if split else None, None, None, st())
+    finally:
+        lib().gv_conv2d_set_tile_override(-1)
+    _lib.check(rc, "gv_conv2d_fwd")
+    torch.cuda.synchronize()
+    y = (p3.from_p3(yd) if y_p3 else yd).cpu()
+    if y_ld != n1:                                       # nothing outside the slice may be touched
+        mask = torch.ones(y_ld, dtype=torch.bool)
+        mask[y_off:y_off + n1] = False
+        assert bool((y[..., mask] == -77.0).all())
+    y = y[..., y_off:y_off + n1]
+    if split:
+        return y, (p3.from_p3(y2d) if y2_p3 else y2d).cpu()
+    return y
+
+
+def oracle_conv(x, w, stride, padding, scale, shift, relu):
+    y = OB.conv2d(x, w, stride, padding) * scale + shift
+    return torch.relu(y) if relu else y
+
+
+def close(a, d, tol=2e-4):
+    a, d = np.asarray(a, np.float64), np.asarray(d, np.float64)
+    assert float(np.abs(a - d).max()) <= tol * max(float(np.abs(d).max()), 1e-30)
+
+
+def test_p3_round_trip_is_exact():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 7, 48, generator=g) * torch.logspace(-6, 6, 48)
+    assert torch.equal(p3.from_p3(p3.to_p3(x)), x)
+
+
+P3_COMBOS = [((3, 3), 1, "VALID", 32, 64), ((3, 3), 1, "VALID", 80, 192), ((5, 5), 1, "SAME", 48, 64),
+             ((3, 3), 2, "VALID", 96, 96), ((1, 7), 1, "SAME", 128, 128), ((7, 1), 1, "SAME", 160, 192),
+             ((1, 3), 1, "SAME", 384, 384), ((3, 1), 1, "SAME", 448, 384), ((3, 3), 1, "SAME", 64, 96)]
+
+
+@pytest.mark.parametrize("tile", [0, 3, 4, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize("k,stride,padding,cin,cout", P3_COMBOS)
+def test_dma_conv_on_three_plane_input(k, stride, padding, cin, cout, tile):
+    """The LDS-DMA kernel on P3 input (fp32 output and P3 output) against the CPU oracle and BITWISE against the
+    register-staged kernel on the same values as fp32; input and output are channel slices of wider tensors."""
+    g = torch.Generator().manual_seed(hash((k, stride, cin, cout)) % 1000)
+    ih, iw = (23, 20) if cin <= 64 else (9, 10)
+    x = torch.randn(3, ih, iw, cin, generator=g)
+    w = torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = oracle_conv(x, w, stride, padding, scale, shift, True)
+    pads = (OB.same_pads(ih, k[0], stride)[0], OB.same_pads(iw, k[1], stride)[0]) if padding == "SAME" else (0, 0)
+    hw = ref.shape[1:3]
+    base = conv(x, w, stride, pads, hw, scale, shift, True)                                  # fp32 in, fp32 out
+    y = conv(x, w, stride, pads, hw, scale, shift, True, x_p3=True, tile=tile, x_ld=cin + 32, x_off=16, y_ld=cout + 8, y_off=4)
+    close(y, ref)
+    assert torch.equal(y, base)
+    yp = conv(x, w, stride, pads, hw, scale, shift, True, x_p3=True, y_p3=True, tile=tile, x_ld=cin + 32, x_off=16,
+              y_ld=cout + 32, y_off=16)
+    assert torch.equal(yp, base)
+
+
+@pytest.mark.parametrize("tile", [0, 3, 4, 9])
+def test_staged_kernel_writes_three_planes(tile):
+    """fp32 input through the register-staged kernel, P3 output through the LDS-staged epilogue: the stored planes sum
+    to exactly the value the fp32 epilogue stores."""
+    g = torch.Generator().manual_seed(tile)
+    x = torch.randn(2, 13, 11, 64, generator=g)
+    w = torch.randn(1, 1, 64, 80, generator=g) * 0.1
+    scale, shift = torch.rand(80, generator=g) + 0.5, torch.randn(80, generator=g) * 0.1
+    base = conv(x, w, 1, (0, 0), (13, 11), scale, shift, True, tile=tile)
+    close(base, oracle_conv(x, w, 1, "VALID", scale, shift, True))
+    yp = conv(x, w, 1, (0, 0), (13, 11), scale, shift, True, y_p3=True, tile=tile, y_ld=112, y_off=16)
+    assert torch.equal(yp, base)
+
+
+@pytest.mark.parametrize("tile", [0, 3, 9])
+def test_sibling_gemm_with_three_plane_scratch(tile):
+    """GV_CONV_SPLIT as the Inception plan uses it: the first member's columns into an fp32 concat slice, the other
+    members (and the commuted pooled branch WITHOUT ReLU: relu_cols) into a three-plane scratch tensor."""
+    g = torch.Generator().manual_seed(3)
+    cin, couts = 192, (64, 48, 64, 32)
+    total, split = sum(couts), couts[0]
+    x = torch.randn(2, 9, 10, cin, generator=g)
+    w = torch.randn(1, 1, cin, total, generator=g) * 0.07
+    scale, shift = torch.rand(total, generator=g) + 0.5, torch.randn(total, generator=g) * 0.1
+    relu_cols = total - couts[-1]
+    full = OB.conv2d(x, w, 1, "SAME") * scale + shift
+    ref = torch.cat([torch.relu(full[..., :relu_cols]), full[..., relu_cols:]], dim=3)
+    y0, s0 = conv(x, w, 1, (0, 0), (9, 10), scale, shift, True, split=split, relu_cols=relu_cols, tile=tile)
+    close(torch.cat([y0, s0], dim=3), ref)
+    y1, s1 = conv(x, w, 1, (0, 0), (9, 10), scale, shift, True, split=split, relu_cols=relu_cols, y2_p3=True, tile=tile,
+                  y_ld=256, y_off=32)
+    assert torch.equal(y1, y0) and torch.equal(s1, s0)
+
+
+def test_average_pool_relu_on_three_plane_input():
+    g = torch.Generator().manual_seed(5)
+    nb, h, w, c, ld, off = 2, 12, 11, 32, 144, 112
+    z = torch.randn(nb, h, w, ld, generator=g)
+    outs = []
+    for xp3 in (False, True):
+        zd = (p3.to_p3(z) if xp3 else z).to(DEV)
+        yd = torch.full((nb, h, w, c), -1.0, device=DEV)
+        d = _lib.PoolDesc(nb, h, w, c, ld, 3, 3, 1, 1, 1, h, w, c, _lib.GV_POOL_AVG_RELU | (_lib.GV_POOL_X_P3 if xp3 else 0),
+                          _lib.GV_F32)
+        _lib.check(lib().gv_pool2d_fwd(C.byref(d), zd.data_ptr() + (6 if xp3 else 4) * off, yd.data_ptr(), st()), "pool")
+        torch.cuda.synchronize()
+        outs.append(yd.cpu())
+    ref = torch.relu(OB.avg_pool2d_same3(z[..., off:off + c]))
+    close(outs[0], ref, 1e-5)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("taps", [("Mixed_6e", "Mixed_7c"), ("Conv2d_4a_3x3", "Mixed_5d"), ("Conv2d_2b_3x3", "Mixed_6a"),
+                                  ("Mixed_6c", "Mixed_7a")])
+@pytest.mark.parametrize("size", [75, 107])
+def test_inception_plan_with_and_without_three_plane_intermediates(size, taps):
+    """The whole Inception-v3 plan under GV_MATH_BF16X3 with three-plane conv -> conv intermediates (LDS-DMA kernels) is
+    BITWISE the plan that keeps everything fp32 — at the tapped (pinned) end points, several pairs of them — and both
+    match the CPU oracle."""
+    nb = 3
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(nb, size, size, 3, generator=g) - 0.5)
+    ends = {}
+    for use in (False, "all"):
+        plan = backbones.make_plan("inception_v3", nb, size, size, torch.device(DEV), math="bf16x3", p3=use,
+                                   raw_tap=taps[0], final_tap=taps[1])
+        assert any(op["x"].p3 for op in plan.ops if op["kind"] == "conv") == bool(use)
+        P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
+        plan.bind(P)
+        plan.run(x.to(DEV))
+        torch.cuda.synchronize()
+        ends[use] = {k: plan.view(plan.end_points[k]).clone().cpu() for k in taps}
+    for k in taps:
+        assert torch.equal(ends["all"][k], ends[False][k]), k
+    _, ep = OB.inception_v3_base(x, P, taps[1])
+    for k in taps:
+        d = ep[k].numpy()
+        np.testing.assert_allclose(ends["all"][k].numpy(), d, rtol=1e-3, atol=1e-5 * float(np.abs(d).max()))

@@ -55,7 +55,7 @@ def test_buffer_assignment_never_aliases_live_tensors(name, size):
             t = op.get(key)
             if t is not None and t.vbuf >= 0:
                 last_read[t.vbuf] = i
-    persistent = {v for v, (_, keep) in enumerate(p.vbufs) if keep}
+    persistent = {v for v, vb in enumerate(p.vbufs) if vb[1]}
     owner = {}                       # phys -> vbuf currently stored
     for i, op in enumerate(p.ops):
         for key in ("y", "y2"):
