@@ -76,15 +76,18 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--preset", default="c2", choices=sorted(PRESETS), help="c2 = BASELINE.json configs[1] (the bench line)")
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
+    ap.add_argument("--p3", default="default", choices=["default", "all", "none"],
+                    help="bf16x3 math: conv -> conv intermediates stored as three bf16 planes (value neutral; A/B switch)")
     ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
                     help="how fp32 convolutions are evaluated on the matrix cores (GV_MATH_*)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the real multi-GPU path); gloo + --same-device: control-flow check of the N>1 path "
                          "on a single-GPU box (every rank on cuda:0, collectives through host memory)")
     ap.add_argument("--same-device", action="store_true")
-    ap.add_argument("--dp", default="views", choices=["views", "shapes"],
-                    help="--train with N > 1: shard the views of every shape (BN statistics stay local) or the shapes "
-                         "(every BN layer all-reduces its per-view sums)")
+    ap.add_argument("--dp", default="views", choices=["views", "shapes", "hybrid"],
+                    help="--train with N > 1: shard the views of every shape (BN statistics stay local), the shapes "
+                         "(every BN layer all-reduces its per-view sums), or both (hybrid: view groups x shape shards, "
+                         "equal work on every rank, BN sums only inside a shape group)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph (GVCNN.capture): for small, launch-bound view batches; N = 1 only")
     ap.add_argument("--train", action="store_true",
@@ -228,7 +231,7 @@ def launch_ranks(a):
 
 
 def _is_conv_kernel(n):
-    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n
+    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n
 
 
 def _pmc_rows(path, counter, steps):
@@ -300,6 +303,18 @@ def train_main(a, world, rank, dev):
         x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(0)) - 0.5)[:, lo:hi].contiguous().to(dev)
         labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(1))
         views_per_step, views_local = N * V, N * (hi - lo)
+    elif a.dp == "hybrid":                           # view groups x shape shards, per-rank work fixed (weak scaling)
+        from gvcnn_tf_amd.sharding import hybrid_coords, hybrid_grid
+        vg, shs = hybrid_grid(V, world)
+        gi, si = hybrid_coords(V, world, rank)
+        v_l, n_l = V // vg, N * vg                   # N*vg shapes per shape shard: N*V view images per rank, as at 1 GPU
+        lo, hi = gi * v_l, (gi + 1) * v_l
+        eng = TrainGVCNN(BACKBONE, n_l, v_l, H, W, C, G, device=dev, num_bins=G, head_views=V, view_offset=lo,
+                         storage=a.storage)
+        sh = ShardedTrainGVCNN(eng, mode="hybrid")
+        x = (torch.rand(n_l, V, H, W, 3, generator=torch.Generator().manual_seed(si)) - 0.5)[:, lo:hi].contiguous().to(dev)
+        labels = torch.randint(0, C, (n_l,), generator=torch.Generator().manual_seed(100 + si))
+        views_per_step, views_local = n_l * shs * V, n_l * v_l
     else:                                            # N shapes PER RANK (weak scaling), all their views
         lo, hi = 0, V
         eng = TrainGVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, storage=a.storage)
@@ -405,7 +420,7 @@ def main():
 
     N = a.shapes
     eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math if a.storage == "f32" else "f32",
-                   lanes=not a.no_lanes, storage=a.storage)
+                   lanes=not a.no_lanes, storage=a.storage, p3={"default": True, "all": "all", "none": False}[a.p3])
     P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
     Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
     eng.plan.bind(P)

@@ -16,6 +16,7 @@ GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
 GV_POOL_MAX, GV_POOL_AVG, GV_POOL_AVG_RELU = 0, 1, 2
 GV_POOL_BWD_STORE = 0x100
 GV_POOL_X_P3 = 0x200
+GV_POOL_Y_P3 = 0x400
 GV_ACCUM_ZEROED = 0x100
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1

@@ -211,7 +211,8 @@ class BackbonePlan:
             out = pooled[3]
             assert (out.nb, out.h, out.w, out.c) == (x.nb, x.h, x.w, pooled[1])
             self._record(dict(kind="pool", name=pooled[2], x=z, y=out, k=3, stride=1, pad_t=1, pad_l=1,
-                              mode=_lib.GV_POOL_AVG_RELU | (_lib.GV_POOL_X_P3 if z.p3 else 0), flops=0.0,
+                              mode=_lib.GV_POOL_AVG_RELU | (_lib.GV_POOL_X_P3 if z.p3 else 0) |
+                              (_lib.GV_POOL_Y_P3 if out.p3 else 0), flops=0.0,
                               bytes=float(self.esz) * 2 * z.npix * z.c))
         return outs
 
@@ -247,12 +248,12 @@ class BackbonePlan:
                              bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout)))
         return (out, y2) if next_preact is not None else out
 
-    def pool(self, x, k, stride, padding, mode, out=None, name="pool"):
-        assert not x.p3, "pools read fp32 (only the commuted Inception branch pool takes three-plane input)"
+    def pool(self, x, k, stride, padding, mode, out=None, name="pool", p3=False):
         oh, pad_t = _out_size(x.h, k, stride, padding)
         ow, pad_l = _out_size(x.w, k, stride, padding)
         if out is None:
-            out = self.new_tensor(x.nb, oh, ow, x.c)
+            out = self.new_tensor(x.nb, oh, ow, x.c, p3=p3)
+        mode = mode | (_lib.GV_POOL_X_P3 if x.p3 else 0) | (_lib.GV_POOL_Y_P3 if out.p3 else 0)
         assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, x.c)
         self._record(dict(kind="pool", name=name, x=x, y=out, k=k, stride=stride, pad_t=pad_t,
                              pad_l=pad_l, mode=mode, flops=0.0,
@@ -633,6 +634,11 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
         finally:
             b.use_p3 = saved
 
+    def cat_p3(name):
+        """A block output nobody outside the backbone reads: three-plane storage, so that the next block's sibling GEMM
+        (and Mixed_6a / 7a's strided 3x3) also run on the LDS-DMA kernel.  Tapped end points stay fp32."""
+        return b.use_p3 and name not in keep and (b.p3_blocks is None or "concat" in b.p3_blocks)
+
     def done(name, t):
         b.end_points[name] = t
         if name in keep:
@@ -649,14 +655,14 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     if done("MaxPool_3a_3x3", net): return net
     net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID", mid=final_endpoint != "Conv2d_3b_1x1")
     if done("Conv2d_3b_1x1", net): return net
-    net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID")
+    net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID", mid=cat_p3("Conv2d_4a_3x3") and final_endpoint != "Conv2d_4a_3x3")
     if done("Conv2d_4a_3x3", net): return net
-    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3")
+    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3", **({"p3": True} if cat_p3("MaxPool_5a_3x3") else {}))
     if done("MaxPool_5a_3x3", net): return net
 
     def mixed5(x, name, b1a, b1b, pool_depth):                  # inception_v3.py:137-204
         s = name + "/"
-        out = b.new_tensor(x.nb, x.h, x.w, 64 + 64 + 96 + pool_depth)
+        out = b.new_tensor(x.nb, x.h, x.w, 64 + 64 + 96 + pool_depth, p3=cat_p3(name))
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 64), (s + "Branch_1/" + b1a, 48),
                               (s + "Branch_2/Conv2d_0a_1x1", 64)], out.channels(0, 64),
                           pooled=(s, pool_depth, out.channels(224, 224 + pool_depth)))
@@ -677,7 +683,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     s = "Mixed_6a/"
     oh = (net.h - 3) // 2 + 1
     ow = (net.w - 3) // 2 + 1
-    out = b.new_tensor(net.nb, oh, ow, 384 + 96 + net.c)
+    out = b.new_tensor(net.nb, oh, ow, 384 + 96 + net.c, p3=cat_p3("Mixed_6a"))
     conv(net, s + "Branch_0/Conv2d_1a_1x1", 384, 3, 2, "VALID", out=out.channels(0, 384))
     with b.lane(1):
         t = conv(net, s + "Branch_1/Conv2d_0a_1x1", 64, 1, mid=True)
@@ -690,7 +696,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
 
     def mixed6(x, name, d):                                     # inception_v3.py:226-338
         s = name + "/"
-        out = b.new_tensor(x.nb, x.h, x.w, 768)
+        out = b.new_tensor(x.nb, x.h, x.w, 768, p3=cat_p3(name))
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 192), (s + "Branch_1/Conv2d_0a_1x1", d),
                               (s + "Branch_2/Conv2d_0a_1x1", d)], out.channels(0, 192),
                           pooled=(s, 192, out.channels(576, 768)))
@@ -711,7 +717,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
     s = "Mixed_7a/"
     oh = (net.h - 3) // 2 + 1
     ow = (net.w - 3) // 2 + 1
-    out = b.new_tensor(net.nb, oh, ow, 320 + 192 + net.c)
+    out = b.new_tensor(net.nb, oh, ow, 320 + 192 + net.c, p3=cat_p3("Mixed_7a"))
     t = conv(net, s + "Branch_0/Conv2d_0a_1x1", 192, 1, mid=True)
     conv(t, s + "Branch_0/Conv2d_1a_3x3", 320, 3, 2, "VALID", out=out.channels(0, 320))
     with b.lane(1):
@@ -726,7 +732,7 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
 
     def mixed7(x, name, b1_3x1, b2_names):                      # inception_v3.py:362-409
         s = name + "/"
-        out = b.new_tensor(x.nb, x.h, x.w, 2048)
+        out = b.new_tensor(x.nb, x.h, x.w, 2048, p3=cat_p3(name))
         t1, t2 = siblings(x, [(s + "Branch_0/Conv2d_0a_1x1", 320), (s + "Branch_1/Conv2d_0a_1x1", 384),
                               (s + "Branch_2/Conv2d_0a_1x1", 448)], out.channels(0, 320),
                           pooled=(s, 192, out.channels(1856, 2048)))
@@ -801,7 +807,7 @@ TAPS = {"resnet_v2_50": ("resnet_v2_50/block3", "resnet_v2_50/block4"),
 # where three-plane intermediates pay (measured per block on MI355X, tools/layer_times.py --p3 none|default|all,
 # gpurun_out/r2/lt_x3_p3_*.txt): every Mixed block and Conv2d_3b -> Conv2d_4a; the 32-channel stem pair Conv2d_2a -> 2b
 # runs faster on fp32 storage (halo kernel for 2a; at N = 64 the 9x im2col re-read of a 6-byte operand is L2-bound)
-P3_DEFAULT_BLOCKS = ("Conv2d_3b_1x1", "Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b",
+P3_DEFAULT_BLOCKS = ("concat", "Conv2d_3b_1x1", "Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b",
                      "Mixed_7c")
 
 DTYPES = {"f32": _lib.GV_F32, "bf16": _lib.GV_BF16, "f16": _lib.GV_F16}

@@ -382,19 +382,27 @@ int launch_dma_x3_e(int cfg, const ConvArgs& a, hipStream_t st) {
         case 10: return launch_dma<__bf16, 3, 4, 1, 2, 3, 3, EPI>(a, st);     // 256 x 96, 4 waves (64 x 96 each)
         case 11: return launch_dma<__bf16, 3, 2, 2, 2, 2, 4, EPI>(a, st);     // 128 x 128, 4 stages
         case 12: return launch_dma<__bf16, 3, 2, 2, 4, 2, 2, EPI>(a, st);     // 256 x 128, FOUR waves (128 x 64 each), 2 stages
+        case 13: return launch_dma<__bf16, 3, 8, 1, 1, 5, 3, EPI>(a, st);     // 256 x 160, 8 waves (32 x 160 each): the 160-channel
+                                                                              // 1x7 / 7x1 layers of Mixed_6c / 6d in ONE column tile
+        case 14: return launch_dma<__bf16, 3, 4, 1, 1, 5, 4, EPI>(a, st);     // 128 x 160, 4 waves
+        case 15: return launch_dma<__bf16, 3, 2, 2, 2, 3, 2, EPI>(a, st);     // 128 x 192, 4 waves, 2 stages (61 KB: two per CU)
     }
     return GV_E_UNSUPPORTED;
 }
 
 int launch_dma_x3(int cfg, const ConvArgs& a, hipStream_t st) {
-    return a.y_p3 ? launch_dma_x3_e<2>(cfg, a, st) : launch_dma_x3_e<1>(cfg, a, st);
+    // fp32 destinations with 16-byte aligned rows also take the staged epilogue (16-byte stores); dbg bit 64 forces the
+    // direct one (A/B)
+    const bool vec = (a.y_ld % 4 == 0) && gv_aligned16(a.y) && a.cout % 8 == 0 && (a.res == nullptr || (a.res_ld % 4 == 0 && gv_aligned16(a.res)));
+    if (a.split > 0) return launch_dma_x3_e<2>(cfg, a, st);      // fused siblings: the staged epilogue routes the columns
+    return (a.y_p3 || (vec && !(a.dbg & 64))) ? launch_dma_x3_e<2>(cfg, a, st) : launch_dma_x3_e<1>(cfg, a, st);
 }
 
 }  // namespace
 
 namespace gvconv {
 
-int dma_x3_num_cfgs() { return 13; }
+int dma_x3_num_cfgs() { return 16; }
 
 // P3 input: whole 16-channel groups inside one filter tap
 bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; }

@@ -514,7 +514,10 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
     }
     if (xp3) {                                           // three-plane input: the LDS-DMA kernel
-        if (!gvconv::dma_x3_ok(a) || !gv_aligned16(x) || split || y2) return GV_E_UNSUPPORTED;
+        if (!gvconv::dma_x3_ok(a) || !gv_aligned16(x) || (y2 && !split)) return GV_E_UNSUPPORTED;
+        if (split && (d->split_col % 8 != 0 || d->cout % 8 != 0 || (!yp3 && (d->y_ld % 4 != 0 || !gv_aligned16(y))) ||
+                      (!y2p3 && (d->y2_ld % 4 != 0 || !gv_aligned16(y2)))))
+            return GV_E_UNSUPPORTED;
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1 : 0);
         return gvconv::dma_x3_launch(cfg, a, (hipStream_t)stream);

@@ -68,6 +68,23 @@ __device__ __forceinline__ f32x4 p3_load4(const char* base, size_t pix, int ld, 
     return r;
 }
 
+// 4 consecutive channels (c a multiple of 4) of a P3 pixel <- fp32: three 8-byte stores
+__device__ __forceinline__ void p3_store4(char* base, size_t pix, int ld, int c, f32x4 v) {
+    char* dst = base + (pix * (size_t)ld + (size_t)(c & ~15)) * 6 + (size_t)(c & 15) * 2;
+    float x[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        unsigned long long w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)x[e];
+            w |= (unsigned long long)__builtin_bit_cast(unsigned short, h) << (16 * e);
+            x[e] -= (float)h;
+        }
+        *reinterpret_cast<unsigned long long*>(dst + p * 32) = w;
+    }
+}
+
 template <int TN> struct X3EpiGeom {
     static constexpr int CW = (TN % 2 == 0) ? 64 : 32;     // columns per staging block
     static constexpr int JB = CW / 32;                     // MFMA tiles per block

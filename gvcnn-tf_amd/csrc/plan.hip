@@ -84,7 +84,8 @@ int run_op(const Op& o, void* const* bufs, void* stream) {
         case OP_POOL: {
             const size_t es = elem_size(o.pool.dtype);
             const size_t xes = (o.pool.mode & GV_POOL_X_P3) ? 6 : es;
-            return gv_pool2d_fwd(&o.pool, at(bufs, o.x, xes), at(bufs, o.y, es), stream);
+            const size_t yes = (o.pool.mode & GV_POOL_Y_P3) ? 6 : es;
+            return gv_pool2d_fwd(&o.pool, at(bufs, o.x, xes), at(bufs, o.y, yes), stream);
         }
         case OP_SSA: {
             const size_t es = elem_size(o.dtype);

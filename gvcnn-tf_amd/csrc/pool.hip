@@ -22,7 +22,8 @@ struct VecT<4> { using type = f32x4; };
 template <>
 struct VecT<1> { using type = float; };
 
-template <int VEC>
+// XP3 / YP3 (VEC = 4 only): input / output in the three-plane layout of conv_x3_epi.h (ld in channels, multiples of 16)
+template <int VEC, bool XP3 = false, bool YP3 = false>
 __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, float* __restrict__ y,
                                                   int nb, int ih, int iw, int c, int x_ld, int kh,
                                                   int kw, int stride, int pad_t, int pad_l, int oh,
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
             for (int s = 0; s < kw; ++s) {
                 const int ix = ox * stride + s - pad_l;
                 if ((unsigned)ix >= (unsigned)iw) continue;
-                const V v = *reinterpret_cast<const V*>(x + ((size_t)(n * ih + iy) * iw + ix) * x_ld + g * VEC);
+                V v;
+                if constexpr (XP3) v = p3_load4(reinterpret_cast<const char*>(x), (size_t)(n * ih + iy) * iw + ix, x_ld, g * 4);
+                else v = *reinterpret_cast<const V*>(x + ((size_t)(n * ih + iy) * iw + ix) * x_ld + g * VEC);
                 if (mode == GV_POOL_MAX) {
                     if constexpr (VEC == 4) {
 #pragma unroll
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
                 if (relu) acc = fmaxf(acc, 0.f);
             }
         }
-        *reinterpret_cast<V*>(y + (size_t)pix * y_ld + g * VEC) = acc;
+        if constexpr (YP3) p3_store4(reinterpret_cast<char*>(y), (size_t)pix, y_ld, g * 4, acc);
+        else *reinterpret_cast<V*>(y + (size_t)pix * y_ld + g * VEC) = acc;
     }
 }
 
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void pool2d_f32(const float* __restrict__ x, f
 // group from a 3x6 input patch (column sums are shared), i.e. 18 16-byte loads for 4 outputs
 // instead of 36 — the generic kernel is L2-request bound on this op (2.4 TB/s).
 // XP3: the input is in the three-plane layout of GV_CONV_Y_P3 (conv_x3_epi.h); the sum of the planes is the fp32 value.
-template <bool XP3>
+template <bool XP3, bool YP3 = false>
 __global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __restrict__ x,
                                                              float* __restrict__ y, int nb, int ih,
                                                              int iw, int c, int x_ld, int y_ld, int relu) {
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_row4_f32(const float* __rest
                 v[e] = v[e] / inv;
                 if (relu) v[e] = fmaxf(v[e], 0.f);
             }
-            *reinterpret_cast<f32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 4) = v;
+            if constexpr (YP3) p3_store4(reinterpret_cast<char*>(y), (size_t)(n * ih + oy) * iw + ox, y_ld, g * 4, v);
+            else *reinterpret_cast<f32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 4) = v;
         }
     }
 }
@@ -242,23 +247,35 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
         d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
         return GV_E_BADARG;
     if (d->x_ld < d->c || d->y_ld < d->c) return GV_E_BADARG;
-    const bool xp3 = (d->mode & GV_POOL_X_P3) != 0;
-    const int mode = d->mode & ~GV_POOL_X_P3;
+    const bool xp3 = (d->mode & GV_POOL_X_P3) != 0, yp3 = (d->mode & GV_POOL_Y_P3) != 0;
+    const int mode = d->mode & ~(GV_POOL_X_P3 | GV_POOL_Y_P3);
     if (mode != GV_POOL_MAX && mode != GV_POOL_AVG && mode != GV_POOL_AVG_RELU) return GV_E_BADARG;
-    if (xp3) {                                   // three-plane input: only the commuted Inception branch pool needs it
-        if (d->dtype != GV_F32 || mode != GV_POOL_AVG_RELU || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_t != 1 ||
-            d->pad_l != 1 || d->oh != d->ih || d->ow != d->iw || d->c % 4 != 0 || d->x_ld % 16 != 0 || d->y_ld % 4 != 0 ||
-            !gv_aligned16(x) || !gv_aligned16(y))
+    if (xp3 || yp3) {                            // three-plane input and / or output (fp32 values, GV_MATH_BF16X3 plans)
+        if (d->dtype != GV_F32 || d->c % 4 != 0 || !gv_aligned16(x) || !gv_aligned16(y) ||
+            (xp3 ? d->x_ld % 16 != 0 : d->x_ld % 4 != 0) || (yp3 ? d->y_ld % 16 != 0 : d->y_ld % 4 != 0))
             return GV_E_UNSUPPORTED;
-        const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
-        hipLaunchKernelGGL(avgpool3x3s1_row4_f32<true>, dim3(grid_for(tot4)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)x, (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, 1);
+        hipStream_t st = (hipStream_t)stream;
+        const float* xf = (const float*)x;
+        float* yf = (float*)y;
+        if (mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+            d->oh == d->ih && d->ow == d->iw) {
+            const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
+            const int relu = mode == GV_POOL_AVG_RELU ? 1 : 0;
+#define GV_AVG4(XP, YP) hipLaunchKernelGGL((avgpool3x3s1_row4_f32<XP, YP>), dim3(grid_for(tot4)), dim3(256), 0, st, xf, yf, \
+                                           d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, relu)
+            if (xp3 && yp3) GV_AVG4(true, true); else if (xp3) GV_AVG4(true, false); else GV_AVG4(false, true);
+#undef GV_AVG4
+        } else {
+            const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 4);
+#define GV_POOL4(XP, YP) hipLaunchKernelGGL((pool2d_f32<4, XP, YP>), dim3(grid_for(total)), dim3(256), 0, st, xf, yf, d->nb, \
+                                            d->ih, d->iw, d->c, d->x_ld, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, \
+                                            d->ow, d->y_ld, mode)
+            if (xp3 && yp3) GV_POOL4(true, true); else if (xp3) GV_POOL4(true, false); else GV_POOL4(false, true);
+#undef GV_POOL4
+        }
         GV_LAUNCH_CHECK();
         return GV_OK;
     }
-    if ((d->oh - 1) * d->stride - d->pad_t >= d->ih || (d->ow - 1) * d->stride - d->pad_l >= d->iw)
-        return GV_E_BADARG;                   // an output whose window holds no valid tap
-    if (d->pad_t >= d->kh || d->pad_l >= d->kw) return GV_E_BADARG;
     if (d->dtype != GV_F32) return gvlp::pool2d(d, x, y, (hipStream_t)stream);
     const bool vec = (d->c % 4 == 0) && (d->x_ld % 4 == 0) && (d->y_ld % 4 == 0) && gv_aligned16(x) &&
                      gv_aligned16(y);
@@ -267,7 +284,7 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
     if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
         const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
-        hipLaunchKernelGGL(avgpool3x3s1_row4_f32<false>, dim3(grid_for(tot4)), dim3(256), 0, st, (const float*)x,
+        hipLaunchKernelGGL((avgpool3x3s1_row4_f32<false, false>), dim3(grid_for(tot4)), dim3(256), 0, st, (const float*)x,
                            (float*)y, d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
         GV_LAUNCH_CHECK();
         return GV_OK;

@@ -197,7 +197,7 @@ class GVCNN:
     def __init__(self, backbone="resnet_v2_50", num_shapes=1, num_views=12, height=224, width=224,
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, seed=2,
-                 math="f32", lanes=True, storage="f32", per_shape=False, weight_mode="count"):
+                 math="f32", lanes=True, storage="f32", per_shape=False, weight_mode="count", p3=True):
         """storage: 'f32' (configs c1/c2), 'bf16' (c3/c4) or 'f16' (c5): the type activations, filters and
         descriptors are kept in; accumulation and every epilogue are fp32 (`math` applies to 'f32' only)."""
         self.lib = _lib.load()
@@ -220,7 +220,7 @@ class GVCNN:
         with torch.cuda.device(self.device):
             self.plan = backbones.make_plan(backbone, num_shapes * num_views, height, width,
                                             self.device, raw_tap, final_tap, dtype=self.dtype, math=math,
-                                            lanes=lanes)
+                                            lanes=lanes, p3=p3)
             self.raw = self.plan.end_points[self.plan.raw_tap]
             self.final = self.plan.end_points[self.plan.final_tap]
             if backbone_params is None:

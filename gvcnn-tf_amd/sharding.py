@@ -188,6 +188,40 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def hybrid_grid(num_views, world_size):
+    """(view_groups, shape_shards) with view_groups * shape_shards == world_size: the largest divisor of the world size
+    that also divides the number of views becomes the number of view groups, the rest cuts the shapes.  12 views on 8
+    ranks -> (4, 2): every rank owns 3 views of half the shapes — exactly 1/8 of the work (view sharding alone deals
+    2,2,2,2,1,1,1,1 views: 0.75 efficiency by construction).  Rank r sits at (view group r // shape_shards, shape
+    shard r % shape_shards): the ranks that all-reduce BatchNorm sums (same views) are neighbours."""
+    vg = max(d for d in range(1, world_size + 1) if world_size % d == 0 and num_views % d == 0)
+    return vg, world_size // vg
+
+
+def hybrid_coords(num_views, world_size, rank):
+    vg, sh = hybrid_grid(num_views, world_size)
+    return rank // sh, rank % sh
+
+
+def hybrid_groups(num_views, world_size, rank):
+    """(shape_group, view_group) of `rank` as torch.distributed groups; every rank creates every group, in the same
+    order (a requirement of new_group).  shape_group: the ranks with the SAME views (they share BatchNorm statistics);
+    view_group: the ranks with the SAME shapes (they exchange view descriptors)."""
+    vg, sh = hybrid_grid(num_views, world_size)
+    mine_s = mine_v = None
+    for g in range(vg):
+        ranks = [g * sh + k for k in range(sh)]
+        grp = dist.new_group(ranks)
+        if rank in ranks:
+            mine_s = grp
+    for k in range(sh):
+        ranks = [g * sh + k for g in range(vg)]
+        grp = dist.new_group(ranks)
+        if rank in ranks:
+            mine_v = grp
+    return mine_s, mine_v
+
+
 class ShardedTrainGVCNN:
     """Data-parallel training step around a per-rank TrainGVCNN.
 
@@ -198,10 +232,17 @@ class ShardedTrainGVCNN:
                   per-(view, channel) sums — forward (sum, sum of squares) and backward (sum g, sum g*zhat): two small
                   collectives per layer — and normalises with the GLOBAL counts: exactly the reference's statistics
                   over the whole batch.  The scorer responses are gathered like in inference (batch-mean scores);
-                  pooling, classifier and loss run on the local shapes with the 1/world factor of the global mean."""
+                  pooling, classifier and loss run on the local shapes with the 1/world factor of the global mean.
+    mode='hybrid': view groups x shape shards (hybrid_grid): the engine owns V / view_groups views of N / shape_shards
+                  shapes, so every rank does exactly 1/world of the work for any world size that shares a factor with
+                  V.  BatchNorm sums are all-reduced only inside the shape group (2 ranks for 12 views on 8 GPUs), the
+                  view descriptors are gathered inside the view group, the scorer responses over the whole world;
+                  variable gradients are all-reduced over the world, beta/gamma (already summed over the shapes by the
+                  BatchNorm exchange) over the view group, the classifier (identical inside a view group) over the
+                  shape group."""
 
     def __init__(self, engine, group=None, bucket_bytes=64 << 20, mode="views"):
-        if mode not in ("views", "shapes"):
+        if mode not in ("views", "shapes", "hybrid"):
             raise ValueError(mode)
         self.eng = engine
         self.group = group
@@ -209,7 +250,18 @@ class ShardedTrainGVCNN:
         self.bucket_bytes = bucket_bytes
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if mode == "views":
+        if mode == "hybrid":
+            assert group is None, "hybrid sharding builds its own sub-groups of the default group"
+            self.vg, self.sh = hybrid_grid(engine.Vh, self.world)
+            gi, si = hybrid_coords(engine.Vh, self.world, self.rank)
+            assert engine.V * self.vg == engine.Vh and engine.view_offset == gi * engine.V, "engine built for other views"
+            self.shape_group = self.view_group = None
+            if self.world > 1:
+                self.shape_group, self.view_group = hybrid_groups(engine.Vh, self.world, self.rank)
+            if self.sh > 1:
+                engine.shape_world = self.sh
+                engine.bn_sync = lambda accum: allreduce_sum_(accum, self.shape_group)
+        elif mode == "views":
             assert (engine.view_offset, engine.view_offset + engine.V) == view_shard_range(engine.Vh, self.world, self.rank)
         else:
             assert engine.Vh == engine.V and engine.view_offset == 0
@@ -237,6 +289,47 @@ class ShardedTrainGVCNN:
         eng.apply_momentum(lr, mu, weight_decay)
         return eng.loss
 
+    def _train_step_hybrid(self, views_local, labels_local, lr, mu, weight_decay, check):
+        """views_local [N / shape_shards, V / view_groups, H, W, 3]: this rank's views of this rank's shapes; labels_local
+        [N / shape_shards]."""
+        from . import _lib
+        from .model import _st
+        eng = self.eng
+        f = eng.final
+        n_l, v_l, V = eng.N, eng.V, eng.Vh
+        eng.forward_backbone(views_local)                      # BatchNorm sums meet inside the shape group (bn_sync)
+        r_loc = eng.score_partial().view(n_l, v_l)
+        r_views = gather_views(r_loc, self.view_group, V) if self.vg > 1 else r_loc                    # [N_l, V]
+        r_all = _all_gather_flat(r_views, self.shape_group) if self.sh > 1 else r_views               # [N, V], shape order
+        _lib.check(eng.lib.gv_view_score_finalize(r_all.data_ptr(), n_l * self.sh, V, _lib.GV_ORDER_SHAPE_MAJOR,
+                                                  eng.scores.data_ptr(), _st()), "score finalize (global)")
+        F_loc = eng.view(f).view(n_l, v_l, f.h, f.w, f.c)
+        F_all = gather_views(F_loc, self.view_group, V) if self.vg > 1 else F_loc
+        eng.forward_head(labels_local, check=check, F=F_all if self.vg > 1 else None, r_img=r_views.reshape(-1),
+                         scores_ready=True)
+        if self.vg > 1:
+            dF = torch.zeros_like(F_all)
+            eng.backward_head(dF=dF)
+            lo = eng.view_offset
+            eng.final_grad().copy_(dF[:, lo:lo + v_l])
+        else:
+            eng.backward_head()
+        eng.backward_backbone()
+        bn = [g for k, g in eng.grads.items() if k.endswith(("/beta", "/gamma"))]
+        cls = [eng.grads[k] for k in eng.cls_names]
+        shared = [g for k, g in eng.grads.items() if not k.endswith(("/beta", "/gamma")) and k not in eng.cls_names]
+        allreduce_sum_bucketed(shared, self.bucket_bytes, None)                    # every view, every shape
+        if self.vg > 1:
+            allreduce_sum_bucketed(bn, self.bucket_bytes, self.view_group)         # shapes already summed by bn_sync
+        if self.sh > 1:
+            allreduce_sum_bucketed(cls, self.bucket_bytes, self.shape_group)       # identical inside a view group
+        if self.vg > 1:
+            self.update_moving_averages_views(group=self.view_group)
+        else:
+            eng.update_moving_averages()
+        eng.apply_momentum(lr, mu, weight_decay)
+        return eng.loss
+
     def train_step(self, views_local, labels, lr=1e-3, mu=0.9, weight_decay=0.0, check=False):
         """mode='views': views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all
         ranks).  mode='shapes': views_local [N_l, V, H, W, 3], labels [N_l] (this rank's shapes)."""
@@ -249,6 +342,8 @@ class ShardedTrainGVCNN:
             return eng.loss
         if self.mode == "shapes":
             return self._train_step_shapes(views_local, labels, lr, mu, weight_decay, check)
+        if self.mode == "hybrid":
+            return self._train_step_hybrid(views_local, labels, lr, mu, weight_decay, check)
         eng = self.eng
         f = eng.final
         eng.forward_backbone(views_local)
@@ -267,7 +362,7 @@ class ShardedTrainGVCNN:
         eng.apply_momentum(lr, mu, weight_decay)
         return eng.loss
 
-    def update_moving_averages_views(self, decay=None):
+    def update_moving_averages_views(self, decay=None, group=None):
         """BN moving averages in view-sharded mode: the reference applies one update per view graph copy, so every
         rank needs the batch statistics of ALL views — one all-gather of every layer's [V_l, c] means and variances
         (packed into a single message), then the V sequential updates run identically on every rank."""
@@ -280,7 +375,8 @@ class ShardedTrainGVCNN:
             decay = 0.9997 if eng.backbone == "inception_v3" else 0.997
         bns = [op for op in eng.plan.ops if op["kind"] == "bn"]
         packed = torch.cat([torch.cat([op["stat"]["mean"], op["stat"]["var"]], dim=1) for op in bns], dim=1)  # [V_l, sum 2c]
-        full = gather_views(packed.unsqueeze(0), self.group, eng.Vh)[0]                                        # [V, sum 2c]
+        grp = group if group is not None else self.group
+        full = gather_views(packed.unsqueeze(0), grp, eng.Vh)[0]                                               # [V, sum 2c]
         # ONE launch over all layers: the jobs point straight into the gathered message (row stride = its width)
         full = full.contiguous()
         ld = full.shape[1]

@@ -198,7 +198,7 @@ class TrainGVCNN:
         self.raw, self.final = p.end_points[raw_tap], p.end_points[final_tap]
         f32 = torch.float32
         with torch.cuda.device(dev):
-            self.act = [torch.empty((n + 7) // 8 * 8, dtype=self.tdt, device=dev) for n, _ in p.vbufs]
+            self.act = [torch.empty((n + 7) // 8 * 8, dtype=self.tdt, device=dev) for n, *_ in p.vbufs]
             self.grad = [None] * len(p.vbufs)
             shapes = p.param_shapes()
             if backbone_params is None:

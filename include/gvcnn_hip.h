@@ -67,8 +67,9 @@ extern "C" {
 #define GV_POOL_MAX 0         /* padding value -inf (slim.max_pool2d) */
 #define GV_POOL_AVG 1         /* divisor = number of VALID taps (slim.avg_pool2d, SAME) */
 #define GV_POOL_BWD_STORE 0x100 /* gv_pool2d_bwd only, OR-ed into mode, 16-bit dtypes: dx = ... instead of dx += ... */
-#define GV_POOL_X_P3 0x200    /* OR-ed into mode, GV_F32 + GV_POOL_AVG_RELU 3x3/1 SAME only: x is in the three-plane layout of
-                                 GV_CONV_Y_P3 (x_ld a multiple of 16 channels); y stays fp32 */
+#define GV_POOL_X_P3 0x200    /* OR-ed into mode, GV_F32 only: x is in the three-plane layout of GV_CONV_Y_P3 (x_ld and the
+                                 slice offset multiples of 16 channels, c a multiple of 4) */
+#define GV_POOL_Y_P3 0x400    /* OR-ed into mode, GV_F32 only: y is written in that layout */
 #define GV_POOL_AVG_RELU 2    /* GV_POOL_AVG followed by ReLU.  avg_pool -> 1x1 conv -> BN -> ReLU
                                  (nets/inception_v3.py:152-154,...) is evaluated as relu(avgpool(BN(conv1x1(x)))):
                                  the 1x1 conv and the BN affine commute with the average (its weights sum to 1),

@@ -327,6 +327,7 @@ def from_plan(backbone, size, fuse=True):
                 assert col == op["cout"]
         elif op["kind"] == "pool":
             src = read(x)
+            op = dict(op, mode=op["mode"] & 0xff)                 # (storage-format flags are not architecture)
             if op["mode"] == _lib.GV_POOL_AVG_RELU:
                 # relu(avgpool(BN(conv1x1(x)))) stands for relu(BN(conv1x1(avgpool(x)))) (inception_v3.py:152-154): put the
                 # canonical node back in the reference order

@@ -287,7 +287,7 @@ def test_bench_external_launcher_form_still_works():
     assert j["n_gpus"] == 2 and j["config"]["exchange"] == "scores" and "other_exchange" not in j
 
 
-@pytest.mark.parametrize("dp", ["views", "shapes"])
+@pytest.mark.parametrize("dp", ["views", "shapes", "hybrid"])
 def test_two_rank_training_bench_on_bf16_storage(dp):
     """bench.py --train --preset c3 as two ranks on one device (gloo): the sharded training step on bf16 storage —
     gathers, gradient all-reduce, per-layer BN sum all-reduce (shapes) / the gathered moving-average update (views)."""

@@ -106,7 +106,7 @@ P3_COMBOS = [((3, 3), 1, "VALID", 32, 64), ((3, 3), 1, "VALID", 80, 192), ((5, 5
              ((1, 3), 1, "SAME", 384, 384), ((3, 1), 1, "SAME", 448, 384), ((3, 3), 1, "SAME", 64, 96)]
 
 
-@pytest.mark.parametrize("tile", [0, 3, 4, 7, 8, 9, 10, 12])
+@pytest.mark.parametrize("tile", [0, 3, 4, 7, 8, 9, 10, 12, 13, 14, 15])
 @pytest.mark.parametrize("k,stride,padding,cin,cout", P3_COMBOS)
 def test_dma_conv_on_three_plane_input(k, stride, padding, cin, cout, tile):
     """The LDS-DMA kernel on P3 input (fp32 output and P3 output) against the CPU oracle and BITWISE against the
@@ -161,6 +161,50 @@ def test_sibling_gemm_with_three_plane_scratch(tile):
     y1, s1 = conv(x, w, 1, (0, 0), (9, 10), scale, shift, True, split=split, relu_cols=relu_cols, y2_p3=True, tile=tile,
                   y_ld=256, y_off=32)
     assert torch.equal(y1, y0) and torch.equal(s1, s0)
+
+
+@pytest.mark.parametrize("xp3,yp3", [(True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("mode,k,stride,pad", [(_lib.GV_POOL_MAX, 3, 2, 0), (_lib.GV_POOL_MAX, 1, 2, 0), (_lib.GV_POOL_AVG, 3, 1, 1),
+                                               (_lib.GV_POOL_AVG_RELU, 3, 1, 1)])
+def test_pools_on_three_plane_tensors(mode, k, stride, pad, xp3, yp3):
+    """Max / average pools reading and / or writing three-plane tensors (channel slices of wider ones) equal the fp32
+    pools BITWISE: the planes carry the fp32 value exactly."""
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    nb, h, w, c, x_ld, x_off, y_ld, y_off = 2, 13, 12, 48, 96, 32, 80, 16
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    z = torch.randn(nb, h, w, x_ld, generator=g)
+    outs = []
+    for xp, yp in ((False, False), (xp3, yp3)):
+        zd = (p3.to_p3(z) if xp else z).to(DEV)
+        y0 = torch.full((nb, oh, ow, y_ld), -9.0)
+        yd = (p3.to_p3(y0) if yp else y0).to(DEV)
+        d = _lib.PoolDesc(nb, h, w, c, x_ld, k, k, stride, pad, pad, oh, ow, y_ld,
+                          mode | (_lib.GV_POOL_X_P3 if xp else 0) | (_lib.GV_POOL_Y_P3 if yp else 0), _lib.GV_F32)
+        _lib.check(lib().gv_pool2d_fwd(C.byref(d), zd.data_ptr() + (6 if xp else 4) * x_off,
+                                       yd.data_ptr() + (6 if yp else 4) * y_off, st()), "pool")
+        torch.cuda.synchronize()
+        y = (p3.from_p3(yd) if yp else yd).cpu()
+        assert bool((y[..., :y_off] == -9.0).all()) and bool((y[..., y_off + c:] == -9.0).all())
+        outs.append(y[..., y_off:y_off + c])
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_sibling_gemm_on_three_plane_input_with_mixed_destinations():
+    """The fused sibling GEMM on the LDS-DMA kernel: three-plane block input, first member into a three-plane concat
+    slice, the rest (+ the commuted pooled member without ReLU) into a three-plane scratch — and the fp32 variants."""
+    g = torch.Generator().manual_seed(11)
+    cin, couts = 256, (64, 48, 64, 64)
+    total, split = sum(couts), couts[0]
+    x = torch.randn(2, 9, 10, cin, generator=g)
+    w = torch.randn(1, 1, cin, total, generator=g) * 0.06
+    scale, shift = torch.rand(total, generator=g) + 0.5, torch.randn(total, generator=g) * 0.1
+    relu_cols = total - couts[-1]
+    y0, s0 = conv(x, w, 1, (0, 0), (9, 10), scale, shift, True, split=split, relu_cols=relu_cols)
+    for yp, y2p in ((True, True), (False, True), (False, False)):
+        for tile in (0, 3, 8):
+            y1, s1 = conv(x, w, 1, (0, 0), (9, 10), scale, shift, True, split=split, relu_cols=relu_cols, x_p3=True,
+                          y_p3=yp, y2_p3=y2p, tile=tile, x_ld=cin + 16, x_off=16, y_ld=288, y_off=224)
+            assert torch.equal(y1, y0) and torch.equal(s1, s0), (yp, y2p, tile)
 
 
 def test_average_pool_relu_on_three_plane_input():

@@ -266,6 +266,62 @@ def test_training_step_vs_oracle(backbone, size, N, V):
     assert float(loss1) < l0
 
 
+@pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 107, 16, 2), ("resnet_v2_50", 64, 16, 2)])
+def test_training_step_against_an_fp64_arbiter(backbone, size, N, V, math="bf16x3"):
+    """Which side moves?  The reference's gradient is only defined up to fp32 rounding, and through ~50 train-mode
+    BatchNorm layers of a randomly initialised network that rounding is amplified: the CPU oracle evaluated in fp32
+    and the SAME oracle evaluated in fp64 differ by 1-3 % per gradient tensor (norm-wise; independent of the number of
+    samples per BatchNorm group: measured with 4, 16 and 32 shapes).  north_star's 1e-3 is therefore not a property any
+    fp32 implementation of this step can have — TensorFlow's included.  What CAN be demanded: with the fp64 oracle as
+    arbiter, the engine must be as close to the truth as the fp32 oracle is.  Per gradient tensor
+    |g_engine - g_64| <= 1.5 * |g_oracle32 - g_64| + floor * |g_64|, over the whole gradient vector the engine's error
+    is at most 1.25x the fp32 oracle's (measured: 2.4 % vs 2.8 % on Inception-v3 — the engine's fp64 BatchNorm sums
+    make it the closer of the two), and loss / logits / shape descriptor agree with fp64 to 1e-4.  The floor covers the
+    top-most layers, where the oracle's fp32 is still ~1e-4 from fp64 but ONE flipped ReLU mask among the 64 samples of
+    a (view, channel) BatchNorm group already moves that channel's gradient by ~1 %: floor = 1e-2 (the training engine
+    evaluates fp32 through bf16 planes: its forward is ~1e-6 from fp64 instead of the oracle's ~1e-7, so more values
+    sit within rounding distance of a ReLU threshold; measured worst case 0.8 % on Mixed_7c)."""
+    C_, G = 5, 10
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    shapes = eng.plan.param_shapes()
+    P = gv.params.init_backbone_params(shapes, seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, math=math)
+    floor = 2e-3 if math == "f32" else 1e-2
+    x = torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5
+    labels = torch.arange(N) % C_
+    r32 = OT.loss_and_grads(x, labels.numpy(), P, Hd, G, backbone)
+    r64 = OT.loss_and_grads(x.double(), labels.numpy(), {k: torch.as_tensor(v).double() for k, v in P.items()},
+                            {k: torch.as_tensor(v).double() for k, v in Hd.items()}, G, backbone)
+    assert r32["scheme"].tolist() == r64["scheme"].tolist()
+    scores, S, logits, loss = eng.forward(x.to(DEV), labels)
+    assert eng.scheme.cpu().numpy().tolist() == r64["scheme"].tolist()
+    close(S.cpu(), r64["shape_descriptor"], 1e-4)
+    close(logits.cpu(), r64["logits"], 1e-4)
+    assert abs(float(loss) - r64["loss"]) <= 1e-4 * max(1.0, abs(r64["loss"]))
+    grads = eng.backward()
+    torch.cuda.synchronize()
+    tot_e = tot_o = tot_n = 0.0
+    rows = []
+    big = max(float(g.norm()) for g in r64["grads"].values())
+    for name, g64 in r64["grads"].items():
+        g64 = g64.numpy()
+        n = float(np.linalg.norm(g64))
+        e_eng = float(np.linalg.norm(grads[name].cpu().numpy().astype(np.float64) - g64))
+        e_ora = float(np.linalg.norm(r32["grads"][name].numpy().astype(np.float64) - g64))
+        tot_e += e_eng ** 2
+        tot_o += e_ora ** 2
+        tot_n += n ** 2
+        rows.append((e_eng / max(n, 1e-30), e_ora / max(n, 1e-30), n / big, name))
+    import sys
+    for r in sorted(rows, reverse=True)[:12]:
+        print("ARB %.4f %.4f %.3g %s" % r, file=sys.stderr)
+    print("ARB total engine %.5f oracle32 %.5f" % (tot_e ** 0.5 / tot_n ** 0.5, tot_o ** 0.5 / tot_n ** 0.5), file=sys.stderr)
+    for e_rel, o_rel, w, name in rows:
+        assert e_rel <= 1.5 * o_rel + floor + 1e-5 / max(w, 1e-30), (name, e_rel, o_rel)
+    assert tot_e ** 0.5 <= 1.25 * tot_o ** 0.5, (tot_e ** 0.5 / tot_n ** 0.5, tot_o ** 0.5 / tot_n ** 0.5)
+
+
 @pytest.mark.parametrize("backbone,size", [("inception_v3", 171), ("resnet_v2_50", 129)])
 def test_gradient_is_the_directional_derivative_of_the_loss(backbone, size):
     """Oracle-free check of the assembled backward pass: along the gradient direction the loss must change by
@@ -602,3 +658,94 @@ def test_trainer_raises_like_the_host_group_scheme_on_a_score_of_one():
     eng.score_bias[0] = 1e9                                       # |r| >= 3e7 rounds sigmoid(log|r|) to exactly 1.0f
     with pytest.raises(IndexError, match="index 10 is out of bounds for axis 0 with size 10"):
         tr.step(x, labels)
+
+
+def test_hybrid_sharded_engines_reproduce_the_whole_step():
+    """sharding.ShardedTrainGVCNN(mode='hybrid') emulated on ONE device: 2 view groups x 2 shape shards = four engines,
+    each owning half the views of half the shapes (the layout that gives 8 GPUs 3 of 12 views of half the batch each).
+    BatchNorm sums are added inside a shape group (same views), descriptors gathered inside a view group (same shapes),
+    scores finalised over the whole [N, V] array; variable gradients summed over all four, beta/gamma over the two view
+    groups, the classifier over the two shape shards — and everything equals the unsharded engine's step."""
+    import threading
+    backbone, size, N, V, C_, G = "resnet_v2_50", 64, 4, 4, 5, 10
+    VG, SH = 2, 2
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    P = gv.params.init_backbone_params(full.plan.param_shapes(), seed=5, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, full.raw.c, full.final.c, C_, seed=6, spread_scores=True)
+    full = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(DEV)
+    labels = torch.tensor([0, 3, 1, 2])
+    full.forward(x, labels)
+    ref = {k: v.clone() for k, v in full.backward().items()}
+    Nl, Vl = N // SH, V // VG
+    engs = {(g, k): TrainGVCNN(backbone, Nl, Vl, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV,
+                               head_views=V, view_offset=g * Vl) for g in range(VG) for k in range(SH)}
+    bar_all = threading.Barrier(VG * SH)
+    bar_shape = {g: threading.Barrier(SH) for g in range(VG)}
+    slots = {}
+
+    def make_sync(g, k):                               # the all-reduce inside shape group g
+        def sync(acc):
+            torch.cuda.synchronize()
+            slots[("bn", g, k)] = acc.clone()
+            bar_shape[g].wait()
+            total = slots[("bn", g, 0)] + slots[("bn", g, 1)]
+            bar_shape[g].wait()
+            acc.copy_(total)
+        return sync
+    for (g, k), e in engs.items():
+        e.shape_world = SH
+        e.bn_sync = make_sync(g, k)
+    out, errors = {}, []
+
+    def run(g, k):
+        try:
+            with torch.cuda.device(0):
+                e = engs[(g, k)]
+                f = e.final
+                xs = x[k * Nl:(k + 1) * Nl, g * Vl:(g + 1) * Vl].contiguous()
+                e.forward_backbone(xs)
+                torch.cuda.synchronize()
+                slots[("r", g, k)] = e.score_partial().view(Nl, Vl).clone()
+                slots[("F", g, k)] = e.view(f).view(Nl, Vl, f.h, f.w, f.c).clone()
+                torch.cuda.synchronize()
+                bar_all.wait()
+                r_views = torch.cat([slots[("r", gg, k)] for gg in range(VG)], dim=1)                    # view group gather
+                r_all = torch.cat([torch.cat([slots[("r", gg, kk)] for gg in range(VG)], dim=1) for kk in range(SH)], dim=0)
+                F_all = torch.cat([slots[("F", gg, k)] for gg in range(VG)], dim=1).contiguous()
+                _lib.check(lib().gv_view_score_finalize(r_all.contiguous().data_ptr(), N, V, _lib.GV_ORDER_SHAPE_MAJOR,
+                                                        e.scores.data_ptr(), st()), "finalize")
+                e.forward_head(labels[k * Nl:(k + 1) * Nl], F=F_all, r_img=r_views.contiguous().reshape(-1), scores_ready=True)
+                dF = torch.zeros_like(F_all)
+                e.backward_head(dF=dF)
+                e.final_grad().copy_(dF[:, g * Vl:(g + 1) * Vl])
+                out[(g, k)] = {n: v.clone() for n, v in e.backward_backbone().items()}
+                torch.cuda.synchronize()
+        except Exception as ex:                        # a dead thread must not leave the others at a barrier
+            errors.append(ex)
+            bar_all.abort()
+            for b_ in bar_shape.values():
+                b_.abort()
+    th = [threading.Thread(target=run, args=gk) for gk in engs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert all(engs[gk].scheme.cpu().tolist() == full.scheme.cpu().tolist() for gk in engs)
+    close(sum(engs[(0, k)].loss for k in range(SH)).cpu() / SH, full.loss.cpu(), 1e-5)
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    cls = set(full.cls_names)
+    for name, r_ in ref.items():
+        if name.endswith(("/beta", "/gamma")):          # summed over the shapes by the BatchNorm exchange: view groups add up
+            got = out[(0, 0)][name] + out[(1, 0)][name]
+            close(out[(0, 1)][name].cpu(), out[(0, 0)][name].cpu(), 1e-5)
+        elif name in cls:                               # identical inside a view group: shape shards add up
+            got = out[(0, 0)][name] + out[(0, 1)][name]
+            close(out[(1, 0)][name].cpu(), out[(0, 0)][name].cpu(), 1e-5)
+        else:
+            got = sum(out[gk][name] for gk in engs)
+        scale = float(r_.abs().max())
+        err = float((got - r_).abs().max())
+        if scale < 1e-5 * gmax:
+            assert err < 1e-5 * gmax, name
+        else:
+            assert err <= 2e-4 * scale, (name, err / scale)

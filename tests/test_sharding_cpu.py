@@ -139,3 +139,70 @@ def test_bn_sum_allreduce_helper():
     mp.spawn(_allreduce_worker, args=(port, ret), nprocs=2, join=True)
     for r in range(2):
         assert np.array_equal(ret[r], np.arange(10, dtype=np.float64) * 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# hybrid (view groups x shape shards) layout of the training step: grid, sub-groups, exchanges (world size 4 = 2 x 2)
+# ------------------------------------------------------------------------------------------------
+def test_hybrid_grid_gives_every_rank_the_same_work():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding_h", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    assert sh.hybrid_grid(12, 8) == (4, 2)          # 3 views of half the shapes each: 1/8 of the work per rank
+    assert sh.hybrid_grid(12, 4) == (4, 1) and sh.hybrid_grid(12, 2) == (2, 1) and sh.hybrid_grid(12, 1) == (1, 1)
+    assert sh.hybrid_grid(20, 8) == (4, 2) and sh.hybrid_grid(6, 4) == (2, 2) and sh.hybrid_grid(12, 5) == (1, 5)
+    for V, P in ((12, 8), (20, 8), (6, 4), (12, 6)):
+        vg, s = sh.hybrid_grid(V, P)
+        assert vg * s == P and V % vg == 0
+        cells = {sh.hybrid_coords(V, P, r) for r in range(P)}
+        assert cells == {(g, k) for g in range(vg) for k in range(s)}       # a bijection rank <-> (view group, shape shard)
+    # view sharding alone on 8 ranks: the most loaded rank owns 2 of 12 views -> efficiency 12 / (8 * 2) = 0.75
+    assert max(hi - lo for lo, hi in (sh.view_shard_range(12, 8, r) for r in range(8))) == 2
+
+
+def _hybrid_worker(rank, port, ret):
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding_h", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    V, N, W = 6, 4, 4
+    vg, s = sh.hybrid_grid(V, W)                      # (2, 2)
+    gi, si = sh.hybrid_coords(V, W, rank)
+    shape_group, view_group = sh.hybrid_groups(V, W, rank)
+    v_l, n_l = V // vg, N // s
+    full = torch.arange(N * V * 3, dtype=torch.float32).view(N, V, 3)         # a [N, V, feature] tensor everybody knows
+    mine = full[si * n_l:(si + 1) * n_l, gi * v_l:(gi + 1) * v_l].contiguous()
+    views = sh.gather_views(mine, view_group, V)                               # [N_l, V, 3]: all views of my shapes
+    allsh = sh._all_gather_flat(views, shape_group)                           # [N, V, 3]: every shape, shape order
+    # BatchNorm-style sum inside the shape group (same views, all shapes) and gradient-style sums
+    bn = sh.allreduce_sum_(mine.sum(dim=0).clone(), shape_group)              # [v_l, 3] over all N shapes
+    world_sum = mine.sum().reshape(1).clone()
+    sh.allreduce_sum_bucketed([world_sum], group=None)
+    ret[rank] = dict(views_ok=bool(torch.equal(views, full[si * n_l:(si + 1) * n_l])), all_ok=bool(torch.equal(allsh, full)),
+                     bn_ok=bool(torch.equal(bn, full[:, gi * v_l:(gi + 1) * v_l].sum(dim=0))),
+                     world_ok=float(world_sum) == float(full.sum()), coords=(gi, si))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hybrid_exchanges_on_four_gloo_ranks():
+    """2 view groups x 2 shape shards: descriptors gathered inside the view group give every rank all views of ITS
+    shapes, the scorer responses gathered over both axes give everybody the whole [N, V] array in shape order, a sum
+    inside the shape group covers all N shapes of the rank's views (BatchNorm statistics), a world sum covers everything
+    (shared variables' gradients)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hybrid_worker, args=(port, ret), nprocs=4, join=True)
+    assert {tuple(ret[r]["coords"]) for r in range(4)} == {(0, 0), (0, 1), (1, 0), (1, 1)}
+    for r in range(4):
+        assert ret[r]["views_ok"] and ret[r]["all_ok"] and ret[r]["bn_ok"] and ret[r]["world_ok"], (r, dict(ret[r]))
