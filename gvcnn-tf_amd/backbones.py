@@ -806,8 +806,11 @@ TAPS = {"resnet_v2_50": ("resnet_v2_50/block3", "resnet_v2_50/block4"),
 
 # where three-plane intermediates pay (measured per block on MI355X, tools/layer_times.py --p3 none|default|all,
 # gpurun_out/r2/lt_x3_p3_*.txt): every Mixed block and Conv2d_3b -> Conv2d_4a; the 32-channel stem pair Conv2d_2a -> 2b
-# runs faster on fp32 storage (halo kernel for 2a; at N = 64 the 9x im2col re-read of a 6-byte operand is L2-bound)
-P3_DEFAULT_BLOCKS = ("concat", "Conv2d_3b_1x1", "Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b",
+# runs faster on fp32 storage (halo kernel for 2a; at N = 64 the 9x im2col re-read of a 6-byte operand is L2-bound).
+# "concat" (block outputs / MaxPool_5a in three planes too, so the sibling GEMMs and the strided 3x3 of Mixed_6a / 7a
+# also take the LDS-DMA kernel) is built and tested but measured neutral to slightly negative (the 6-byte stores of
+# every concat writer and the pools cost what the sibling GEMMs gain: gpurun_out/r2/lt_x3_p3c_*.txt): not in the default
+P3_DEFAULT_BLOCKS = ("Conv2d_3b_1x1", "Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b",
                      "Mixed_7c")
 
 DTYPES = {"f32": _lib.GV_F32, "bf16": _lib.GV_BF16, "f16": _lib.GV_F16}

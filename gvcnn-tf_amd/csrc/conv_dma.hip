@@ -197,103 +197,230 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Fragments are double buffered in registers at K-STEP granularity (one k-step = 16 k-values = one MFMA per
-    // accumulator and plane product): while the MFMAs of k-step q run, the fragments of k-step q+1 are already on their
-    // way from LDS.  Inside a tile that needs no synchronisation; the first k-step of tile kt+1 is read right after the
-    // barrier that publishes tile kt+1, which sits BEFORE the last k-step's MFMAs of tile kt — so the barrier wait, the
-    // fragment-read latency and the DMA instructions of the tile ST ahead (issued after that barrier into the stage tile
-    // kt just vacated, spread between the MFMAs) are all covered by matrix work of the same wave.
-    constexpr int NMFS = NPR * TM * TN;                            // MFMAs per k-step
-    constexpr int GAP = NMFS / (LPT + 1) > 0 ? NMFS / (LPT + 1) : 1;
-    u32x4 fa[2][TM][NP], fb[2][TN][NP];
-    auto read_frags = [&](auto setc, int stage, int s) {
-        constexpr int S = decltype(setc)::value;
-        const char* sb = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
+    if constexpr (NP == 1) {
+        // ---- 16-bit storage: branch-free k-tile bodies (compile-time ISSUE / MORE / wait counts), the next k-step's
+        // fragment reads issued one per MFMA behind the matrix instructions --------------------------------------
+        // Fragments are double buffered in registers at K-STEP granularity (one k-step = 16 k-values = one MFMA per
+        // accumulator and plane product): while the MFMAs of k-step q run, the fragments of k-step q+1 are already on their
+        // way from LDS.  Inside a tile that needs no synchronisation; the first k-step of tile kt+1 is read right after the
+        // barrier that publishes tile kt+1, which sits BEFORE the last k-step's MFMAs of tile kt — so the barrier wait, the
+        // fragment-read latency and the DMA instructions of the tile ST ahead (issued after that barrier into the stage tile
+        // kt just vacated, spread between the MFMAs) are all covered by matrix work of the same wave.
+        constexpr int NMFS = NPR * TM * TN;                            // MFMAs per k-step
+        constexpr int NRD = (TM + TN) * NP;                            // fragment reads per k-step
+        constexpr int GAP = NMFS / (LPT + 1) > 0 ? NMFS / (LPT + 1) : 1;
+        u32x4 fa[2][TM][NP], fb[2][TN][NP];
+        // fragment read q (0 .. NRD-1) of k-step s of the tile in `stage`, into register set S
+        auto read_one = [&](auto setc, const char* sb, int s, int q) {
+            constexpr int S = decltype(setc)::value;
+            if (q < TM * NP) {
+                const int i = q / NP, p = q % NP;
                 fa[S][i][p] = *reinterpret_cast<const u32x4*>(sb + p * A_PLANE + a_frag + i * 32 * RBYTES + foff[s]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
+            } else {
+                const int e = q - TM * NP;
+                const int j = e / NP, p = e % NP;
                 fb[S][j][p] = *reinterpret_cast<const u32x4*>(sb + p * B_PLANE + b_frag + j * 32 * RBYTES + foff[s]);
-    };
-    auto mfmas = [&](auto setc, bool do_issue, char* nb) {
-        constexpr int S = decltype(setc)::value;
-#pragma unroll
-        for (int m = 0; m < NMFS; ++m) {
-            const int t = m / (TM * TN);
-            const int i = (m / TN) % TM, j = m % TN;
-            acc[i][j] = mfma16<T>(fa[S][i][dprod_pa(NP, t)], fb[S][j][dprod_pb(NP, t)], acc[i][j]);
-            if ((m + 1) % GAP == 0 && (m + 1) / GAP <= LPT) {
-                if (do_issue) dma_one((m + 1) / GAP - 1, nb);
             }
-        }
-        if (do_issue) {
-#pragma unroll
-            for (int d = NMFS / GAP; d < LPT; ++d) dma_one(d, nb);  // (fewer MFMAs than DMA instructions)
-            step_state();
-        }
-    };
-    const int ktiles = a.ktiles;
-    auto wait_tile = [&](int t) {                                  // this wave's DMA of tile t has landed
-        const int last_issued = t + ST - 2 < ktiles - 1 ? t + ST - 2 : ktiles - 1;   // tiles <= t-1+ST-1 were issued so far
-        const int younger = last_issued - t;
-        if (ST >= 4 && younger >= 2) wait_vm<(ST >= 4 ? 2 * LPT : 0)>();
-        else if (ST >= 3 && younger >= 1) wait_vm<(ST >= 3 ? LPT : 0)>();
-        else wait_vm<0>();
-    };
-    // tile kt whose first k-step's fragments sit in register set PAR
-    auto tile_step = [&](auto parc, int kt, int stage) {
-        constexpr int PAR = decltype(parc)::value;
-        const int next = stage + 1 == ST ? 0 : stage + 1;
-#pragma unroll
-        for (int s = 0; s + 1 < KS; ++s) {
-            if (((PAR + s) & 1) == 0) { read_frags(std::integral_constant<int, 1>{}, stage, s + 1); mfmas(std::integral_constant<int, 0>{}, false, nullptr); }
-            else { read_frags(std::integral_constant<int, 0>{}, stage, s + 1); mfmas(std::integral_constant<int, 1>{}, false, nullptr); }
-        }
-        constexpr int LASTSET = (PAR + KS - 1) & 1;
-        const bool more = kt + 1 < ktiles;
-        if (more) {
-            wait_tile(kt + 1);
-            __builtin_amdgcn_s_barrier();                          // tile kt+1 is in LDS; every wave has read all of tile kt
-            read_frags(std::integral_constant<int, LASTSET ^ 1>{}, next, 0);
-        }
-        mfmas(std::integral_constant<int, LASTSET>{}, kt + ST < ktiles, smem + stage * STAGE);
-    };
+        };
+        auto read_frags = [&](auto setc, int stage, int s) {
+    #pragma unroll
+            for (int q = 0; q < NRD; ++q) read_one(setc, smem + stage * STAGE, s, q);
+        };
+        // The MFMAs of one k-step on register set S.  Between them, one per MFMA: the fragment reads of the NEXT k-step
+        // (into set S^1, from `rsb` / k-step `rs`; READ) and the DMA instructions of the tile ST ahead (ISSUE, spread over
+        // the k-step).  Reads issued BEHIND an MFMA have their latency covered by the matrix pipe; issued in front of the
+        // k-step's first MFMA they cost the wave an LDS round trip per k-tile with nothing to overlap it.
+        auto mfmas = [&](auto setc, auto readc, auto issuec, const char* rsb, int rs, char* nb) {
+            constexpr int S = decltype(setc)::value;
+            constexpr bool READ = decltype(readc)::value, ISSUE = decltype(issuec)::value;
+            constexpr int RD_AT = NP == 3 ? -1 : 0;                    // (NP = 3: all reads first; one per MFMA spills there)
+            if constexpr (READ && RD_AT < 0) {
+    #pragma unroll
+                for (int q = 0; q < NRD; ++q) read_one(std::integral_constant<int, S ^ 1>{}, rsb, rs, q);
+            }
+    #pragma unroll
+            for (int m = 0; m < NMFS; ++m) {
+                const int t = m / (TM * TN);
+                const int i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = mfma16<T>(fa[S][i][dprod_pa(NP, t)], fb[S][j][dprod_pb(NP, t)], acc[i][j]);
+                if constexpr (READ && RD_AT >= 0) {
+                    if (m < NRD) read_one(std::integral_constant<int, S ^ 1>{}, rsb, rs, m);
+                }
+                if constexpr (ISSUE) {
+                    if ((m + 1) % GAP == 0 && (m + 1) / GAP <= LPT) dma_one((m + 1) / GAP - 1, nb);
+                }
+            }
+            if constexpr (READ && RD_AT >= 0) {
+    #pragma unroll
+                for (int q = NMFS; q < NRD; ++q) read_one(std::integral_constant<int, S ^ 1>{}, rsb, rs, q);
+            }
+            if constexpr (ISSUE) {
+    #pragma unroll
+                for (int d = NMFS / GAP; d < LPT; ++d) dma_one(d, nb);  // (fewer MFMAs than DMA instructions)
+                step_state();
+            }
+        };
+        const int ktiles = a.ktiles;
+        using TT = std::true_type;
+        using FF = std::false_type;
+        // tile kt whose first k-step's fragments sit in register set PAR; ISSUE: the tile ST ahead exists and is issued
+        // here; MORE: tile kt+1 exists (its first fragments are read here); YOUNGER: DMA tiles issued after tile kt+1 so far
+        auto tile_step = [&](auto parc, auto issuec, auto morec, auto youngerc, int stage) {
+            constexpr int PAR = decltype(parc)::value;
+            constexpr bool ISSUE = decltype(issuec)::value, MORE = decltype(morec)::value;
+            constexpr int YOUNGER = decltype(youngerc)::value;
+            const int next = stage + 1 == ST ? 0 : stage + 1;
+            const char* sb = smem + stage * STAGE;
+    #pragma unroll
+            for (int s = 0; s + 1 < KS; ++s) {                        // k-steps inside the tile: no synchronisation needed
+                if (((PAR + s) & 1) == 0) mfmas(std::integral_constant<int, 0>{}, TT{}, FF{}, sb, s + 1, nullptr);
+                else mfmas(std::integral_constant<int, 1>{}, TT{}, FF{}, sb, s + 1, nullptr);
+            }
+            constexpr int LASTSET = (PAR + KS - 1) & 1;
+            if constexpr (MORE) {
+                wait_vm<YOUNGER * LPT>();
+                __builtin_amdgcn_s_barrier();                          // tile kt+1 is in LDS; every wave has read all of tile kt
+            }
+            mfmas(std::integral_constant<int, LASTSET>{}, std::integral_constant<bool, MORE>{},
+                  std::integral_constant<bool, ISSUE>{}, smem + next * STAGE, 0, smem + stage * STAGE);
+        };
+        // run tiles [k0, k1) with compile-time flags; handles the set parity for odd KS by pairing tiles
+        auto run_tiles = [&](auto issuec, auto morec, auto youngerc, int k0, int k1, int& stage, int& par) {
+            for (int kt = k0; kt < k1; ++kt) {
+                if (KS % 2 == 0 || par == 0) tile_step(std::integral_constant<int, 0>{}, issuec, morec, youngerc, stage);
+                else tile_step(std::integral_constant<int, 1>{}, issuec, morec, youngerc, stage);
+                if (KS % 2 != 0) par ^= 1;
+                stage = stage + 1 == ST ? 0 : stage + 1;
+            }
+        };
 
-    // ---- main loop ------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < ST; ++t)
-        if (t < ktiles) issue(t);
-    {
-        const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
-        if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
-        else if (younger == 2) wait_vm<(ST >= 3 ? 2 * LPT : 0)>();
-        else if (younger == 1) wait_vm<LPT>();
-        else wait_vm<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    read_frags(std::integral_constant<int, 0>{}, 0, 0);
-    int stage = 0;
-    if constexpr (KS % 2 == 0) {
-        for (int kt = 0; kt < ktiles; ++kt) {
-            tile_step(std::integral_constant<int, 0>{}, kt, stage);
-            stage = stage + 1 == ST ? 0 : stage + 1;
+        // ---- main loop ------------------------------------------------------------------------------------------------
+    #pragma unroll
+        for (int t = 0; t < ST; ++t)
+            if (t < ktiles) issue(t);
+        {
+            const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
+            if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
+            else if (younger == 2) wait_vm<(ST >= 3 ? 2 * LPT : 0)>();
+            else if (younger == 1) wait_vm<LPT>();
+            else wait_vm<0>();
         }
+        __builtin_amdgcn_s_barrier();
+        read_frags(std::integral_constant<int, 0>{}, 0, 0);
+        {
+            int stage = 0, par = 0;
+            // steady state: tile kt+ST exists -> after the barrier of tile kt, tiles kt+2 .. kt+ST-1 are younger than kt+1
+            const int steady = ktiles - ST > 0 ? ktiles - ST : 0;
+            run_tiles(TT{}, TT{}, std::integral_constant<int, ST - 2>{}, 0, steady, stage, par);
+            // drain: nothing left to issue; the number of younger tiles shrinks to zero
+            int kt = steady;
+            if constexpr (ST >= 4) { if (kt < ktiles - 3) { run_tiles(FF{}, TT{}, std::integral_constant<int, 2>{}, kt, kt + 1, stage, par); ++kt; } }
+            if constexpr (ST >= 3) { if (kt < ktiles - 2) { run_tiles(FF{}, TT{}, std::integral_constant<int, 1>{}, kt, kt + 1, stage, par); ++kt; } }
+            if (kt < ktiles - 1) { run_tiles(FF{}, TT{}, std::integral_constant<int, 0>{}, kt, kt + 1, stage, par); ++kt; }
+            run_tiles(FF{}, FF{}, std::integral_constant<int, 0>{}, kt, ktiles, stage, par);
+        }
+
     } else {
-        int kt = 0;
-        for (; kt + 1 < ktiles; kt += 2) {
-            tile_step(std::integral_constant<int, 0>{}, kt, stage);
-            stage = stage + 1 == ST ? 0 : stage + 1;
-            tile_step(std::integral_constant<int, 1>{}, kt + 1, stage);
-            stage = stage + 1 == ST ? 0 : stage + 1;
-        }
-        if (kt < ktiles) tile_step(std::integral_constant<int, 0>{}, kt, stage);
-    }
+        // ---- three-plane operands: the same pipeline with run-time tail handling (the branch-free form above makes one
+        // basic block of 36-48 MFMAs + 18-21 reads per k-tile that the scheduler reorders into hundreds of spilled VGPRs)
+        // Fragments are double buffered in registers at K-STEP granularity (one k-step = 16 k-values = one MFMA per
+        // accumulator and plane product): while the MFMAs of k-step q run, the fragments of k-step q+1 are already on their
+        // way from LDS.  Inside a tile that needs no synchronisation; the first k-step of tile kt+1 is read right after the
+        // barrier that publishes tile kt+1, which sits BEFORE the last k-step's MFMAs of tile kt — so the barrier wait, the
+        // fragment-read latency and the DMA instructions of the tile ST ahead (issued after that barrier into the stage tile
+        // kt just vacated, spread between the MFMAs) are all covered by matrix work of the same wave.
+        constexpr int NMFS = NPR * TM * TN;                            // MFMAs per k-step
+        constexpr int GAP = NMFS / (LPT + 1) > 0 ? NMFS / (LPT + 1) : 1;
+        u32x4 fa[2][TM][NP], fb[2][TN][NP];
+        auto read_frags = [&](auto setc, int stage, int s) {
+            constexpr int S = decltype(setc)::value;
+            const char* sb = smem + stage * STAGE;
+    #pragma unroll
+            for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    fa[S][i][p] = *reinterpret_cast<const u32x4*>(sb + p * A_PLANE + a_frag + i * 32 * RBYTES + foff[s]);
+    #pragma unroll
+            for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    fb[S][j][p] = *reinterpret_cast<const u32x4*>(sb + p * B_PLANE + b_frag + j * 32 * RBYTES + foff[s]);
+        };
+        auto mfmas = [&](auto setc, bool do_issue, char* nb) {
+            constexpr int S = decltype(setc)::value;
+    #pragma unroll
+            for (int m = 0; m < NMFS; ++m) {
+                const int t = m / (TM * TN);
+                const int i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = mfma16<T>(fa[S][i][dprod_pa(NP, t)], fb[S][j][dprod_pb(NP, t)], acc[i][j]);
+                if ((m + 1) % GAP == 0 && (m + 1) / GAP <= LPT) {
+                    if (do_issue) dma_one((m + 1) / GAP - 1, nb);
+                }
+            }
+            if (do_issue) {
+    #pragma unroll
+                for (int d = NMFS / GAP; d < LPT; ++d) dma_one(d, nb);  // (fewer MFMAs than DMA instructions)
+                step_state();
+            }
+        };
+        const int ktiles = a.ktiles;
+        auto wait_tile = [&](int t) {                                  // this wave's DMA of tile t has landed
+            const int last_issued = t + ST - 2 < ktiles - 1 ? t + ST - 2 : ktiles - 1;   // tiles <= t-1+ST-1 were issued so far
+            const int younger = last_issued - t;
+            if (ST >= 4 && younger >= 2) wait_vm<(ST >= 4 ? 2 * LPT : 0)>();
+            else if (ST >= 3 && younger >= 1) wait_vm<(ST >= 3 ? LPT : 0)>();
+            else wait_vm<0>();
+        };
+        // tile kt whose first k-step's fragments sit in register set PAR
+        auto tile_step = [&](auto parc, int kt, int stage) {
+            constexpr int PAR = decltype(parc)::value;
+            const int next = stage + 1 == ST ? 0 : stage + 1;
+    #pragma unroll
+            for (int s = 0; s + 1 < KS; ++s) {
+                if (((PAR + s) & 1) == 0) { read_frags(std::integral_constant<int, 1>{}, stage, s + 1); mfmas(std::integral_constant<int, 0>{}, false, nullptr); }
+                else { read_frags(std::integral_constant<int, 0>{}, stage, s + 1); mfmas(std::integral_constant<int, 1>{}, false, nullptr); }
+            }
+            constexpr int LASTSET = (PAR + KS - 1) & 1;
+            const bool more = kt + 1 < ktiles;
+            if (more) {
+                wait_tile(kt + 1);
+                __builtin_amdgcn_s_barrier();                          // tile kt+1 is in LDS; every wave has read all of tile kt
+                read_frags(std::integral_constant<int, LASTSET ^ 1>{}, next, 0);
+            }
+            mfmas(std::integral_constant<int, LASTSET>{}, kt + ST < ktiles, smem + stage * STAGE);
+        };
 
+        // ---- main loop ------------------------------------------------------------------------------------------------
+    #pragma unroll
+        for (int t = 0; t < ST; ++t)
+            if (t < ktiles) issue(t);
+        {
+            const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
+            if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
+            else if (younger == 2) wait_vm<(ST >= 3 ? 2 * LPT : 0)>();
+            else if (younger == 1) wait_vm<LPT>();
+            else wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        read_frags(std::integral_constant<int, 0>{}, 0, 0);
+        int stage = 0;
+        if constexpr (KS % 2 == 0) {
+            for (int kt = 0; kt < ktiles; ++kt) {
+                tile_step(std::integral_constant<int, 0>{}, kt, stage);
+                stage = stage + 1 == ST ? 0 : stage + 1;
+            }
+        } else {
+            int kt = 0;
+            for (; kt + 1 < ktiles; kt += 2) {
+                tile_step(std::integral_constant<int, 0>{}, kt, stage);
+                stage = stage + 1 == ST ? 0 : stage + 1;
+                tile_step(std::integral_constant<int, 1>{}, kt + 1, stage);
+                stage = stage + 1 == ST ? 0 : stage + 1;
+            }
+            if (kt < ktiles) tile_step(std::integral_constant<int, 0>{}, kt, stage);
+        }
+
+    }
     __syncthreads();                                               // every wave is done with the ring: reuse it for staging
     if constexpr (EPI == 0)
         lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES));
