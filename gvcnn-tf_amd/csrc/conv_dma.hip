@@ -346,13 +346,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
                 for (int p = 0; p < NP; ++p)
                     fb[S][j][p] = *reinterpret_cast<const u32x4*>(sb + p * B_PLANE + b_frag + j * 32 * RBYTES + foff[s]);
         };
-        auto mfmas = [&](auto setc, bool do_issue, char* nb) {
+        // do_read: after the first product group (TM*TN MFMAs) the fragments of the next tile's first k-step are read
+        // into the other register set — BEHIND matrix instructions, so the LDS round trip is covered; in front of the
+        // k-step's first MFMA the compiler's lgkmcnt wait for them idles the wave once per k-tile (the run-time branch
+        // keeps the reads where they are written)
+        auto mfmas = [&](auto setc, bool do_issue, char* nb, bool do_read = false, int rstage = 0) {
             constexpr int S = decltype(setc)::value;
     #pragma unroll
             for (int m = 0; m < NMFS; ++m) {
                 const int t = m / (TM * TN);
                 const int i = (m / TN) % TM, j = m % TN;
                 acc[i][j] = mfma16<T>(fa[S][i][dprod_pa(NP, t)], fb[S][j][dprod_pb(NP, t)], acc[i][j]);
+                if (m + 1 == TM * TN) {
+                    if (do_read) read_frags(std::integral_constant<int, S ^ 1>{}, rstage, 0);
+                }
                 if ((m + 1) % GAP == 0 && (m + 1) / GAP <= LPT) {
                     if (do_issue) dma_one((m + 1) / GAP - 1, nb);
                 }
@@ -385,9 +392,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
             if (more) {
                 wait_tile(kt + 1);
                 __builtin_amdgcn_s_barrier();                          // tile kt+1 is in LDS; every wave has read all of tile kt
-                read_frags(std::integral_constant<int, LASTSET ^ 1>{}, next, 0);
             }
-            mfmas(std::integral_constant<int, LASTSET>{}, kt + ST < ktiles, smem + stage * STAGE);
+            mfmas(std::integral_constant<int, LASTSET>{}, kt + ST < ktiles, smem + stage * STAGE, more, next);
         };
 
         // ---- main loop ------------------------------------------------------------------------------------------------
