@@ -66,6 +66,9 @@ def parse():
                          "descriptors, every rank pools all shapes; 'scores' exchanges only the scorer responses (each "
                          "rank pools the shapes it owns).  The N > 1 line reports the other one too (other_exchange)")
     ap.add_argument("--no-other-exchange", action="store_true", help="N > 1: time only --exchange")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1, --exchange allgather: gather and pool inside the step instead of overlapping the "
+                         "all-gather of step k with the backbone of step k+1 (ShardedGVCNN(overlap=True))")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the in-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE children (roofline.traffic = null)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
@@ -425,7 +428,7 @@ def main():
     Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
     eng.plan.bind(P)
     eng.set_head(Hd)
-    sh = ShardedGVCNN(eng, exchange=a.exchange)
+    sh = ShardedGVCNN(eng, exchange=a.exchange, overlap=not a.no_overlap)
     x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(rank)) - 0.5).to(dev)
 
     def barrier():
@@ -450,10 +453,14 @@ def main():
         """W untimed steps, then exactly K steps between two barrier + synchronize pairs; MAX over the ranks."""
         for _ in range(a.warmup):
             step()
+        if getattr(step, "flush", None):
+            step.flush()                                    # (the warm-up's last head is not part of the timed steps)
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
+        if getattr(step, "flush", None):
+            step.flush()                                    # the overlapped exchange's last head belongs to the timed steps
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -462,7 +469,10 @@ def main():
             dt = float(t.item())
         return dt
 
-    step = (lambda: sh.forward(x, check=False))
+    def step():
+        return sh.forward(x, check=False)
+    if sh.overlap:
+        step.flush = sh.flush
     if a.graph:
         assert world == 1, "--graph is a single-GPU option"
         step = eng.capture(x)
@@ -507,6 +517,8 @@ def main():
             out["config"]["world_size"] = dist.get_world_size()          # what the ranks saw, not the flag
             out["config"]["backend"] = "rccl (torch.distributed nccl)" if a.backend == "nccl" else "gloo (control-flow check)"
             out["config"]["exchange_bytes_per_step"] = xbytes[a.exchange]
+            out["config"]["exchange_overlap"] = ("all-gather of step k in flight under the backbone of step k+1 (results one "
+                                                 "call later; the last head is inside the timed region)") if sh.overlap else "none"
             out["config"]["launched_by"] = "bench.py (self-launched ranks)" if os.environ.get("GVBENCH_SELF") else "external torch.distributed.run"
             if other is not None:
                 ms2 = other[1] / a.steps * 1e3

@@ -63,9 +63,16 @@ def gather_descriptors(F_local, group=None):
 
 
 class ShardedGVCNN:
-    """Wraps a per-rank GVCNN engine built for the LOCAL batch (N_l shapes)."""
+    """Wraps a per-rank GVCNN engine built for the LOCAL batch (N_l shapes).
 
-    def __init__(self, engine, group=None, exchange="allgather"):
+    overlap=True (exchange='allgather' only): the descriptor all-gather of step k is issued asynchronously on RCCL's own
+    stream and its grouping head (view pooling, fusion, classifier over all N_g shapes) runs one call LATER, after the
+    backbone launches of step k+1 have been enqueued — the exchange (78.6 MB sent / 550 MB received per rank and step at
+    configs[1] on 8 GPUs: about 2 ms of ring-bound xGMI against a 15 ms step) then rides under matrix work instead of
+    standing between two steps.  forward() returns the results of the PREVIOUS call (None the first time); flush()
+    returns the last one.  Values are exactly those of the non-overlapped form: the same collectives on the same data."""
+
+    def __init__(self, engine, group=None, exchange="allgather", overlap=False):
         if exchange not in ("allgather", "scores"):
             raise ValueError(exchange)
         self.eng = engine
@@ -73,6 +80,46 @@ class ShardedGVCNN:
         self.exchange = exchange
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.overlap = bool(overlap) and exchange == "allgather" and self.world > 1
+        self._pending = None                  # (work handle | None, F_all, scheme, weight, scores) of the previous step
+        self._slot = 0
+        self._stage = [None, None]            # double-buffered copies of the local final descriptors / gathered tensors
+
+    def _issue_gather(self):
+        """Copy this step's descriptors / grouping state aside and start their all-gather; returns the pending record."""
+        eng = self.eng
+        F_loc = eng.final_view_descriptors()
+        k = self._slot
+        self._slot ^= 1
+        if self._stage[k] is None:
+            self._stage[k] = (torch.empty_like(F_loc),
+                              torch.empty((self.world * F_loc.shape[0],) + tuple(F_loc.shape[1:]), dtype=F_loc.dtype,
+                                          device=F_loc.device))
+        src, dst = self._stage[k]
+        src.copy_(F_loc)                                        # the plan's tap buffer is overwritten by the next step
+        if src.is_cuda and dist.get_backend(self.group) == "gloo":     # control-flow check on one device: through the host
+            h = torch.empty(dst.shape, dtype=dst.dtype)
+            dist.all_gather_into_tensor(h, src.cpu(), group=self.group)
+            dst.copy_(h)
+            work = None
+        else:
+            work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+        return (work, dst, eng.scheme.clone(), eng.weight.clone(), eng.scores.clone())
+
+    def _finish(self, pending):
+        work, F_all, scheme, weight, scores = pending
+        if work is not None:
+            work.wait()                                         # the CURRENT stream waits for the collective; no host sync
+        S, logits = self.eng.pool_fuse_classify(scheme, weight, F=F_all)
+        return scores, S, logits
+
+    def flush(self):
+        """Results of the last overlapped step (None when nothing is pending)."""
+        if self._pending is None:
+            return None
+        out = self._finish(self._pending)
+        self._pending = None
+        return out
 
     def forward(self, views_local, check=True):
         """views_local [N_l, V, H, W, 3].  Returns (scores [V], shape_descriptor, logits): for
@@ -87,6 +134,12 @@ class ShardedGVCNN:
             r_all = gather_scores(eng.r_img, self.group)
             eng.finalize_scores(r_all, eng.N * self.world)     # same array, same order on every rank
         eng.assign_groups(check=False)
+        if self.overlap:
+            now = self._issue_gather()                          # collective of THIS step: in flight under the next backbone
+            prev, self._pending = self._pending, now
+            if check:
+                eng.check_status()
+            return self._finish(prev) if prev is not None else None
         if self.exchange == "allgather" and self.world > 1:
             F_all = gather_descriptors(eng.final_view_descriptors(), self.group)
             S, logits = eng.pool_fuse_classify(eng.scheme, eng.weight, F=F_all)

@@ -206,3 +206,85 @@ def test_hybrid_exchanges_on_four_gloo_ranks():
     assert {tuple(ret[r]["coords"]) for r in range(4)} == {(0, 0), (0, 1), (1, 0), (1, 1)}
     for r in range(4):
         assert ret[r]["views_ok"] and ret[r]["all_ok"] and ret[r]["bn_ok"] and ret[r]["world_ok"], (r, dict(ret[r]))
+
+
+# ------------------------------------------------------------------------------------------------
+# ShardedGVCNN(overlap=True): the descriptor all-gather of step k rides under the backbone of step k+1
+# ------------------------------------------------------------------------------------------------
+class _FakeEngine:
+    """The engine surface ShardedGVCNN drives, with the CPU oracle's grouping functions as compute: per step the
+    'backbone' produces descriptors and scorer responses that depend on the step's input."""
+    per_shape = False
+
+    def __init__(self, world, rank):
+        self.N, self.V, self.G = N_L, V, G
+        self.world, self.rank = world, rank
+        self.r_img = torch.zeros(N_L * V)
+        self.scores = torch.zeros(V)
+        self.scheme = torch.zeros(G, V, dtype=torch.int32)
+        self.weight = torch.zeros(G)
+        self._F = None
+
+    def run_backbone(self, x):                         # x [N_l, V, *SHAPE]: "descriptors" = 2x + 1, responses = mean |x|
+        self._F = x * 2.0 + 1.0
+        self._r = x.abs().mean(dim=(2, 3, 4)) * 4.0 + 0.05
+
+    def compute_scores(self):
+        self.r_img = self._r.reshape(-1).clone()
+
+    def finalize_scores(self, r_all, num_shapes):
+        self.scores = torch.from_numpy(_scores(r_all.numpy().reshape(num_shapes, V)))
+
+    def assign_groups(self, check=False):
+        sch = OG.group_scheme([self.scores.numpy()], G, V)
+        self.scheme = torch.from_numpy(sch.astype(np.int32))
+        self.weight = torch.from_numpy(OG.group_weight(sch))
+
+    def final_view_descriptors(self):
+        return self._F
+
+    def pool_fuse_classify(self, scheme, weight, F=None):
+        F = self._F if F is None else F
+        S = OG.group_fusion(OG.view_pooling([F.numpy()[:, v] for v in range(V)], scheme.numpy()), weight.numpy())
+        return torch.from_numpy(S), torch.from_numpy(S.mean(axis=(1, 2)))
+
+    def check_status(self):
+        pass
+
+
+def _overlap_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding_o", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    rng = np.random.RandomState(100 + rank)
+    xs = [torch.from_numpy(rng.randn(N_L, V, *SHAPE).astype(np.float32)) for _ in range(4)]
+    plain = sh.ShardedGVCNN(_FakeEngine(WORLD, rank), exchange="allgather")
+    want = [tuple(t.clone() for t in plain.forward(x, check=False)) for x in xs]
+    piped = sh.ShardedGVCNN(_FakeEngine(WORLD, rank), exchange="allgather", overlap=True)
+    assert piped.overlap
+    got = []
+    for x in xs:
+        out = piped.forward(x, check=False)            # results of the PREVIOUS call
+        if out is not None:
+            got.append(tuple(t.clone() for t in out))
+    got.append(tuple(t.clone() for t in piped.flush()))
+    assert piped.flush() is None
+    ok = len(got) == len(want) and all(all(torch.equal(a, b) for a, b in zip(g, w)) for g, w in zip(got, want))
+    ret[rank] = (ok, [float(w[2].sum()) for w in want])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_returns_the_same_results_one_call_later():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_overlap_worker, args=(port, ret), nprocs=WORLD, join=True)
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] == ret[1][1]                      # allgather form: every rank holds all logits, identical
