@@ -522,7 +522,8 @@ def test_per_shape_assign_and_fuse_vs_oracle(weight_mode, pool):
     assert int(status.item()) & 1
 
 
-@pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70))])
+@pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70)), (64, 1, (61, 95)),
+                                         (32, 0, (3, 3)), (32, 1, (1, 1))])
 def test_halo_stem_kernel_fp32_storage(cout, pad, hw):
     """The halo-tiled 3x3 kernel of Conv2d_2a/2b on fp32 storage (GV_MATH_BF16X3, tile configuration 11): ragged
     strips, VALID and SAME, residual, channel-slice output — fp32-level agreement with the oracle and with the
@@ -539,6 +540,14 @@ def test_halo_stem_kernel_fp32_storage(cout, pad, hw):
     np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
     y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, residual=res, tile=0, math=1, y_ld=cout + 8, y_off=4)
     np.testing.assert_allclose(y, y0, rtol=2e-5, atol=2e-5)
+    # no residual, whole 32-channel column tiles, aligned rows: the branch-free epilogue (buffer stores); the products
+    # are accumulated in the implicit-GEMM kernel's order, so the two kernels agree BITWISE
+    for relu in (True, False):
+        yp = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, relu, tile=11, math=1)
+        yq = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, relu, tile=0, math=1)
+        assert np.array_equal(yp, yq)
+    ys = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, tile=11, math=1, y_ld=cout + 32, y_off=16)
+    assert np.array_equal(ys, yp if False else run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, tile=0, math=1))
 
 
 @pytest.mark.parametrize("k,pad,cout,hw", [(3, 0, 32, (47, 75)), (7, 3, 64, (47, 75)), (7, 3, 64, (224, 64)), (3, 0, 24, (9, 131))])
