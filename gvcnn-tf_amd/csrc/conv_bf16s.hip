@@ -378,22 +378,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_bf16s(const ConvArgs 
 //   * every tap's A fragments are ds_read_b128 at a shifted pixel of the ring, one k-step ahead of their MFMAs;
 //   * the packed filter ([n][k-tile][plane][16], 55 KB for 32 columns) is LDS resident for the life of the workgroup.
 // Accumulation order (tap, channel half, plane product) is that of the implicit-GEMM kernels: bitwise the same result.
-constexpr int HALO_TW = 30;     // output columns per strip: a 32-pixel halo row is exactly 2 loader chunks per thread
+// RW output rows per wave: 1 = 30-pixel strips (32-pixel halo rows: exactly 2 loader chunks per thread, 4 rows per tile),
+// 2 = 16-pixel strips (18-pixel halo rows, an MFMA block = 2 output rows x 16 pixels, 8 rows per tile, 18-row ring):
+// the narrow form where it saves >= 20 % of the MFMA rows on the image width (narrow images); at 109 columns (4 x 32 = 128
+// rows against 7 x 16 = 112) the two measured equal — the chip holds a higher clock with fewer MFMAs per second.
+constexpr int halo_tw(int rw) { return rw == 1 ? 30 : 16; }
 // ABL: timing ablations (gv_conv2d_set_debug): 4 no epilogue, 16 no fetch, 32 no split / ring stores.
 // PLAIN: 32 | cout, 16-byte aligned rows, no residual, output < 4 GiB: the epilogue is branch-free (buffer stores drop
 // the lanes past the strip / image), so it too issues between the MFMAs; otherwise the general epilogue.
-template <int ABL, bool PLAIN>
+template <int ABL, bool PLAIN, int RW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_halo_x3(const ConvArgs a) {
-    constexpr int TH = 4, TW = HALO_TW, HW = 32, PB = 3 * 64 + 16;  // halo pixel: 3 planes x 32 ch + pad
-    constexpr int R = 10;                                           // ring rows: 6 in use + 4 being written
-    constexpr int ROWB = HW * PB;
-    constexpr int SL = TH * HW * 4 / 256;                           // 8-channel chunks of 4 halo rows per thread: 2
+    constexpr int TH = 4 * RW, TW = halo_tw(RW), HW = RW == 1 ? 32 : 18, PB = 3 * 64 + 16;  // halo pixel: 3 planes x 32 ch + pad
+    constexpr int R = 2 * TH + 2;                                   // ring rows: TH + 2 in use + TH being written
+    constexpr int ROWB = RW == 1 ? HW * PB : (HW * PB + 255) / 256 * 256;   // RW 2: a fragment spans two ring rows, whose
+                                                                            // banks interleave when the pitch is 0 mod 256 B
+    constexpr int NCH = TH * HW * 4;                                // 8-channel chunks of the TH new rows of a tile
+    constexpr int SL = (NCH + 255) / 256;                           // per thread: 2 (RW 1), 3 with the last one 1/4 full (RW 2)
+    constexpr int DUMP = RW == 1 ? 0 : 64 * 16 * 3;                 // where the idle lanes of the last chunk store
     constexpr int WB = 18 * 96 + 16;                                // LDS filter row: 18 k-tiles x 3 planes
     constexpr int SW = 32 + 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* sH = smem_raw;                                                          // [R][HW][PB]
     float* stage = reinterpret_cast<float*>(smem_raw + R * ROWB) + (threadIdx.x >> 6) * (32 * SW);
     char* sW = smem_raw + R * ROWB + 4 * 32 * SW * 4;                             // [32][WB]
+    char* sDump = sW + 32 * WB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int tiles_x = (a.ow + TW - 1) / TW;
     const int nct = (a.cout + 31) / 32;
@@ -430,35 +438,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bool l_ok[SL];
 #pragma unroll
     for (int k = 0; k < SL; ++k) {
-        const int idx = tid + k * 256;
+        const bool live = tid + k * 256 < NCH;             // (the idle lanes repeat the previous chunk's load)
+        const int idx = live ? tid + k * 256 : tid + (k - 1) * 256;
         const int pix = idx >> 2, ch = idx & 3;
         const int hy = pix / HW, hx = pix - hy * HW;
         const int ix = ox0 + hx - a.pad_l;
-        l_hy[k] = hy;
+        l_hy[k] = live ? hy : -1;
         l_ok[k] = (unsigned)ix < (unsigned)a.iw;
         l_goff[k] = min(max(ix, 0), a.iw - 1) * a.x_ld + ch * 8;
-        l_loff[k] = hx * PB + ch * 16;
+        l_loff[k] = live ? hx * PB + ch * 16 : (tid & 63) * 16;
     }
     const float* ximg = a.x + (size_t)n * a.ih * a.iw * a.x_ld;
     const int rowpitch = a.iw * a.x_ld;
 
     f32x4 hr[SL][2], hn[SL][2];                             // rows being split now / rows in flight for the next tile
     bool hok[SL], hnok[SL];
-    // halo rows [h0, h0 + 4) -> registers (halo row h is input row h - pad_t; outside the image: zeros)
+    // halo rows [h0, h0 + TH) -> registers (halo row h is input row h - pad_t; outside the image: zeros)
     auto fetch_one = [&](int k, int h0, f32x4 (&dst)[SL][2], bool (&dok)[SL]) {
-        const int iy = h0 + l_hy[k] - a.pad_t;
+        const int iy = h0 + max(l_hy[k], 0) - a.pad_t;
         const float* p = ximg + (size_t)min(max(iy, 0), a.ih - 1) * rowpitch + l_goff[k];
         dst[k][0] = *reinterpret_cast<const f32x4*>(p);
         dst[k][1] = *reinterpret_cast<const f32x4*>(p + 4);
         dok[k] = l_ok[k] && (unsigned)iy < (unsigned)a.ih;
     };
-    // registers -> ring slots of halo rows [h0, h0 + 4): split once into the three planes
+    // registers -> ring slots of halo rows [h0, h0 + TH): split once into the three planes
     auto put_one = [&](int k, int h0) {
         u32x4 pl[3];
         split8<3>(hr[k][0], hr[k][1], hok[k], pl);
-        char* dst = sH + ((h0 + l_hy[k] + R) % R) * ROWB + l_loff[k];         // plane p of a pixel at +64*p
+        char* dst = l_hy[k] >= 0 ? sH + ((h0 + l_hy[k] + 2 * R) % R) * ROWB + l_loff[k] : sDump + l_loff[k];
+        const int ps = l_hy[k] >= 0 ? 64 : 1024;          // plane p of a pixel at +64*p
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 64) = pl[p];
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * ps) = pl[p];
     };
     // scale / shift / residual / ReLU and store of read-back pass `pass` (8 output pixels x 32 channels) of row oy
     float rlo[4];                                           // ReLU as max(v, rlo): 0 where it applies, -inf elsewhere
@@ -466,8 +476,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int e = 0; e < 4; ++e) rlo[e] = (a.relu && colg + e < a.relu_limit) ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.y, 0, PLAIN ? (int)(unsigned)((size_t)a.M * a.y_ld * 4) : 0, 0x00020000);
-    auto finish_pass = [&](int pass, int oy, f32x4 v4) {
-        const int row = pass * 8 + rrow;
+    auto finish_pass = [&](int pass, int oy0, f32x4 v4) {       // oy0: the wave's first output row of that tile
+        const int mrow = pass * 8 + rrow;                   // MFMA row -> (output row, column in the strip)
+        const int oy = RW == 1 ? oy0 : oy0 + (mrow >> 4);
+        const int row = RW == 1 ? mrow : (mrow & 15);
         float v[4] = {v4[0], v4[1], v4[2], v4[3]};
         if constexpr (PLAIN) {
 #pragma unroll
@@ -501,29 +513,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     const int ntiles = (a.oh + TH - 1) / TH;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {                           // halo rows -2..1 (the first two land in free slots), 2..5
+    for (int g = 0; g < 2; ++g) {                           // halo rows 2-TH..1 (those below 0 land in free slots), 2..TH+1
 #pragma unroll
-        for (int k = 0; k < SL; ++k) fetch_one(k, 4 * g - 2, hr, hok);
+        for (int k = 0; k < SL; ++k) fetch_one(k, TH * g + 2 - TH, hr, hok);
 #pragma unroll
-        for (int k = 0; k < SL; ++k) put_one(k, 4 * g - 2);
+        for (int k = 0; k < SL; ++k) put_one(k, TH * g + 2 - TH);
     }
 #pragma unroll
-    for (int k = 0; k < SL; ++k) fetch_one(k, 6, hr, hok);  // split and stored under tile 0
+    for (int k = 0; k < SL; ++k) fetch_one(k, TH + 2, hr, hok);   // split and stored under tile 0
 
-    const int a_lane = li * PB + 16 * lh;
+    const int a_lane = (RW == 1 ? li : (li & 15)) * PB + 16 * lh;
+    const int a_row = RW == 1 ? wave : 2 * wave + (li >> 4);    // this lane's output row within the tile
     const char* b_lane = sW + li * WB + 16 * lh;
     float accv[16];                                         // the previous tile's accumulators: stored under this tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) accv[r] = 0.f;
-    int rbase = 0;                                          // (4 t) % R
-    for (int t = 0; t < ntiles; ++t, rbase = rbase + 4 >= R ? rbase + 4 - R : rbase + 4) {
+    int rbase = 0;                                          // (TH t) % R
+    for (int t = 0; t < ntiles; ++t, rbase = rbase + TH >= R ? rbase + TH - R : rbase + TH) {
         __syncthreads();                                    // ring rows of this tile written; previous tile's reads done
-        const int oy = t * TH + wave;
-        const int hput = 4 * t + 6;                         // rows past the last tile's need go to released slots: harmless
+        const int oy = t * TH + RW * wave;
+        const int hput = TH * t + TH + 2;                   // rows past the last tile's need go to released slots: harmless
         const char* ar[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int sl = rbase + wave + r;                // (oy + r) % R without a division
+            const int sl = rbase + a_row + r;               // (oy + r) % R without a division
             ar[r] = sH + (sl >= R ? sl - R : sl) * ROWB + a_lane;
         }
         f32x16 acc;
@@ -538,12 +551,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // One wave per SIMD has nobody to hide anything behind, so everything but the MFMAs is dealt out in pieces, one
         // per k-step, each fenced into its k-step (sched_barrier) to issue in the shadow of that step's six MFMAs:
         //   all steps   the fragment reads of k-step ks+1, in FRONT of the MFMAs of k-step ks
-        //   0 .. 4      the PREVIOUS tile's epilogue: accumulators -> per-wave LDS block -> 4 x (8 pixels x 128 bytes)
+        //   0 .. 5      the PREVIOUS tile's epilogue: accumulators -> per-wave LDS block -> 4 x (8 pixels x 128 bytes)
         //   0 .. 9      split (one element pair per step) and ring stores of the 4 rows the next tile needs
-        //   5, 6        fetch of the 4 halo rows the tile after next needs: AFTER the stores, because vmcnt retires in
+        //   6, 7        fetch of the 4 halo rows the tile after next needs: AFTER the stores, because vmcnt retires in
         //               issue order and the wait for these loads (next tile's first split) must not wait on stores
-        float px[2][8];
-        u32x4 ppl[2][3];
+        float px[SL][8];
+        u32x4 ppl[SL][3];
+        f32x4 sv[2];
 #pragma unroll
         for (int ks = 0; ks < 18; ++ks) {                   // k-step = (tap, channel half)
             const int cur = ks & 1, nxt = cur ^ 1;
@@ -561,8 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int q = 0; q < 6; ++q)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][prod_pa(3, q)]),
                                                               __builtin_bit_cast(bf16x8, fb[cur][prod_pb(3, q)]), acc, 0, 0, 0);
-            if (ks >= 5 && ks < 5 + SL && !(ABL & 16)) fetch_one(ks - 5, hput + 4, hn, hnok);
-            if (ks < 2 * 5 && !(ABL & 32)) {                // unit u = ks / 5: pieces 0..3 split a pair each, piece 4 stores
+            if (ks >= 6 && ks < 6 + SL && !(ABL & 16)) fetch_one(ks - 6, hput + TH, hn, hnok);
+            if (ks < SL * 5 && !(ABL & 32)) {               // unit u = ks / 5: pieces 0..3 split a pair each, piece 4 stores
                 const int u = ks / 5, pc = ks - u * 5;
                 if (pc < 4) {
 #pragma unroll
@@ -573,17 +587,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         const bf16x2 pr = {(__bf16)px[u][2 * pc], (__bf16)px[u][2 * pc + 1]};
-                        ppl[u][p][pc] = __builtin_bit_cast(unsigned, pr);
+                        unsigned word = __builtin_bit_cast(unsigned, pr);
+                        asm volatile("" : "+v"(word));     // pins this piece into its k-step (else it sinks to the store)
+                        ppl[u][p][pc] = word;
                         if (p < 2) {
                             px[u][2 * pc] -= (float)pr[0];
                             px[u][2 * pc + 1] -= (float)pr[1];
                         }
                     }
                 } else {
-                    const int sl = rbase + 6 + l_hy[u];     // (hput + l_hy) % R
-                    char* dst = sH + (sl >= R ? sl - R : sl) * ROWB + l_loff[u];
+                    const int sl = rbase + TH + 2 + l_hy[u];        // (hput + l_hy) % R
+                    char* dst = l_hy[u] >= 0 ? sH + (sl >= R ? sl - R : sl) * ROWB + l_loff[u] : sDump + l_loff[u];
+                    const int ps = l_hy[u] >= 0 ? 64 : 1024;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 64) = ppl[u][p];
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * ps) = ppl[u][p];
                 }
             }
             if (!(ABL & 4) && t > 0) {
@@ -591,11 +608,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = accv[r];
                 }
-                if (ks >= 1 && ks < 5) {
-                    if (ks == 1) __builtin_amdgcn_wave_barrier();
-                    const int pass = ks - 1;
-                    finish_pass(pass, oy - TH, *reinterpret_cast<const f32x4*>(stage + (pass * 8 + rrow) * SW + col4));
+                if (ks >= 1 && ks < 5) {                    // read back pass ks-1 now, finish it one k-step later:
+                    if (ks == 1) __builtin_amdgcn_wave_barrier();      // its wait then passes over the younger fragment reads
+                    sv[ks & 1] = *reinterpret_cast<const f32x4*>(stage + ((ks - 1) * 8 + rrow) * SW + col4);
                 }
+                if (ks >= 2 && ks < 6) finish_pass(ks - 2, oy - TH, sv[(ks - 1) & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -615,7 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     if (!(ABL & 4)) {                                       // the last tile's epilogue
-        const int oy = (ntiles - 1) * TH + wave;
+        const int oy = (ntiles - 1) * TH + RW * wave;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = accv[r];
@@ -627,33 +644,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
-    const int tiles_x = (a.ow + HALO_TW - 1) / HALO_TW, nct = (a.cout + 31) / 32;
-    const size_t lds = (size_t)10 * 32 * 208 + 4 * 32 * 36 * 4 + 32 * (18 * 96 + 16);
+    // strips of 30 (one output row per wave) or 16 pixels (two): whichever covers the width with fewer MFMA rows
+    // (measured equal at 12 % fewer rows — Conv2d_2a/2b, 109 columns — so the narrow form needs a 20 % saving)
+    const int rw = gv_ceil_div(a.ow, 16) * 16 * 5 <= gv_ceil_div(a.ow, 30) * 32 * 4 ? 2 : 1;
+    const int tw = halo_tw(rw), hw = rw == 1 ? 32 : 18, ring = 8 * rw + 2;
+    const int tiles_x = (a.ow + tw - 1) / tw, nct = (a.cout + 31) / 32;
+    const size_t lds = (size_t)ring * (rw == 1 ? hw * 208 : (hw * 208 + 255) / 256 * 256) + 4 * 32 * 36 * 4 + 32 * (18 * 96 + 16) +
+                       (rw == 1 ? 0 : 64 * 16 * 3);
     const dim3 grid((unsigned)(a.nb * tiles_x * nct));
     const bool plain = a.cout % 32 == 0 && a.y_ld % 4 == 0 && ((((uintptr_t)a.y) & 15) == 0) && a.res == nullptr &&
                        (uint64_t)a.M * a.y_ld * 4 < 0xffffffffull;
-#define GV_HALO_LAUNCH(B, P)                                                                                        \
+#define GV_HALO_LAUNCH(B, P, W)                                                                                     \
     {                                                                                                               \
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3<B, P>),                 \
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3<B, P, W>),              \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
         if (!ok) return GV_E_UNSUPPORTED;                                                                           \
-        hipLaunchKernelGGL((conv3x3_halo_x3<B, P>), grid, dim3(256), lds, st, a);                                   \
+        hipLaunchKernelGGL((conv3x3_halo_x3<B, P, W>), grid, dim3(256), lds, st, a);                                \
         GV_LAUNCH_CHECK();                                                                                          \
         return GV_OK;                                                                                               \
     }
     if (a.dbg & (4 | 16 | 32)) {                      // timing experiments only
-        if (!plain) return GV_E_UNSUPPORTED;
+        if (!plain || rw != 1) return GV_E_UNSUPPORTED;
         switch (a.dbg & 52) {
-            case 4: GV_HALO_LAUNCH(4, true)
-            case 16: GV_HALO_LAUNCH(16, true)
-            case 32: GV_HALO_LAUNCH(32, true)
-            case 48: GV_HALO_LAUNCH(48, true)
-            case 52: GV_HALO_LAUNCH(52, true)
+            case 4: GV_HALO_LAUNCH(4, true, 1)
+            case 48: GV_HALO_LAUNCH(48, true, 1)
+            case 52: GV_HALO_LAUNCH(52, true, 1)
         }
         return GV_E_UNSUPPORTED;
     }
-    if (plain) GV_HALO_LAUNCH(0, true)
-    GV_HALO_LAUNCH(0, false)
+    if (rw == 2) {
+        if (plain) GV_HALO_LAUNCH(0, true, 2)
+        GV_HALO_LAUNCH(0, false, 2)
+    }
+    if (plain) GV_HALO_LAUNCH(0, true, 1)
+    GV_HALO_LAUNCH(0, false, 1)
 #undef GV_HALO_LAUNCH
 }
 

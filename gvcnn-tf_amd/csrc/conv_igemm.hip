@@ -529,7 +529,7 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1
-                           : (((gvconv::bf16s_halo_ok(np, a, generic) && a.cout <= 32) || gvconv::bf16s_stem_ok(np, a)) &&
+                           : ((gvconv::bf16s_halo_ok(np, a, generic) || gvconv::bf16s_stem_ok(np, a)) &&
                                       a.M >= 100000
                                   ? gvconv::bf16s_num_cfgs() - 1
                                                                                      : gvconv::bf16s_pick_tile(np, a.M, a.cout, a.K)));

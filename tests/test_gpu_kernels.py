@@ -523,11 +523,11 @@ def test_per_shape_assign_and_fuse_vs_oracle(weight_mode, pool):
 
 
 @pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70)), (64, 1, (61, 95)),
-                                         (32, 0, (3, 3)), (32, 1, (1, 1))])
+                                         (32, 0, (3, 3)), (32, 1, (1, 1)), (32, 0, (21, 32)), (64, 1, (13, 60)), (64, 0, (9, 92))])
 def test_halo_stem_kernel_fp32_storage(cout, pad, hw):
     """The halo-tiled 3x3 kernel of Conv2d_2a/2b on fp32 storage (GV_MATH_BF16X3, tile configuration 11): ragged
-    strips, VALID and SAME, residual, channel-slice output — fp32-level agreement with the oracle and with the
-    implicit-GEMM kernel."""
+    strips (widths that pick the 16-pixel two-rows-per-wave form and widths that pick the 30-pixel form), VALID and SAME,
+    residual, channel-slice output — fp32-level agreement with the oracle and with the implicit-GEMM kernel."""
     g = torch.Generator().manual_seed(cout + pad)
     ih, iw = hw
     x = torch.randn(3, ih, iw, 32, generator=g)
