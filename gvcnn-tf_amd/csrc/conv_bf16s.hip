@@ -643,6 +643,275 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same kernel on v_mfma_f32_16x16x32_bf16 (one k-step = one filter tap: 32 channels): the 32 x 32 wave tile is
+// 2 x 2 blocks of 16 x 16, the LDS images keep a plane's 32 channels contiguous (64 bytes; halo pixels 192 bytes with
+// the 8-channel chunks XOR-swizzled by (column >> 1) & 3, filter rows [tap][plane][32] at a 1760-byte pitch: both
+// conflict-free for the 16-lane groups of ds_read_b128 at every tap shift).  Same bytes read from LDS per FLOP and the
+// same cycles per FLOP as the 32x32x16 form; the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS (7)).
+template <int ABL, bool PLAIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_halo_x3_k32(const ConvArgs a) {
+    constexpr int TH = 4, TW = 30, HW = 32, PB = 192;
+    constexpr int R = 2 * TH + 2;
+    constexpr int ROWB = HW * PB;
+    constexpr int SL = 2;
+    constexpr int WB = 9 * 192 + 32;
+    constexpr int SW = 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* sH = smem_raw;                                                          // [R][HW][plane][32 ch]
+    float* stage = reinterpret_cast<float*>(smem_raw + R * ROWB) + (threadIdx.x >> 6) * (32 * SW);
+    char* sW = smem_raw + R * ROWB + 4 * 32 * SW * 4;                             // [32][WB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
+    const int tiles_x = (a.ow + TW - 1) / TW;
+    const int nct = (a.cout + 31) / 32;
+    const int ct = blockIdx.x % nct;
+    const int strip = blockIdx.x / nct;
+    const int n = strip / tiles_x;
+    const int ox0 = (strip % tiles_x) * TW;
+    const int co0 = ct * 32;
+
+    for (int idx = tid; idx < 32 * 108; idx += 256) {      // packed [n][k-tile 16][plane][16] -> LDS [n][tap][plane][32]
+        const int row = idx / 108, ch = idx - row * 108;
+        const int col = min(co0 + row, a.cout - 1);
+        const int kt = ch / 6, rem = ch - kt * 6;
+        *reinterpret_cast<u32x4*>(sW + row * WB + (kt >> 1) * 192 + (rem >> 1) * 64 + (kt & 1) * 32 + (rem & 1) * 16) =
+            *reinterpret_cast<const u32x4*>((const char*)a.w + (size_t)col * a.ktiles * 96 + ch * 16);
+    }
+
+    const int rrow = lane >> 3, col4 = (lane & 7) * 4;
+    const int colg = co0 + col4;
+    const int nvalid = min(4, a.cout - colg);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = min(colg + e, a.cout - 1);
+        sc[e] = a.scale[c];
+        sh[e] = a.shift[c];
+    }
+    const bool vec = (a.y_ld % 4 == 0) && ((((uintptr_t)a.y) & 15) == 0) &&
+                     (a.res == nullptr || ((a.res_ld % 4 == 0) && ((((uintptr_t)a.res) & 15) == 0)));
+    const int ox_end = min(a.ow, ox0 + TW);
+
+    int l_hy[SL], l_goff[SL], l_loff[SL];
+    bool l_ok[SL];
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+        const int idx = tid + k * 256;
+        const int pix = idx >> 2, ch = idx & 3;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int ix = ox0 + hx - a.pad_l;
+        l_hy[k] = hy;
+        l_ok[k] = (unsigned)ix < (unsigned)a.iw;
+        l_goff[k] = min(max(ix, 0), a.iw - 1) * a.x_ld + ch * 8;
+        l_loff[k] = hx * PB + ((ch ^ ((hx >> 1) & 3)) * 16);
+    }
+    const float* ximg = a.x + (size_t)n * a.ih * a.iw * a.x_ld;
+    const int rowpitch = a.iw * a.x_ld;
+
+    f32x4 hr[SL][2], hn[SL][2];
+    bool hok[SL], hnok[SL];
+    auto fetch_one = [&](int k, int h0, f32x4 (&dst)[SL][2], bool (&dok)[SL]) {
+        const int iy = h0 + l_hy[k] - a.pad_t;
+        const float* p = ximg + (size_t)min(max(iy, 0), a.ih - 1) * rowpitch + l_goff[k];
+        dst[k][0] = *reinterpret_cast<const f32x4*>(p);
+        dst[k][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        dok[k] = l_ok[k] && (unsigned)iy < (unsigned)a.ih;
+    };
+    auto put_one = [&](int k, int h0) {
+        u32x4 pl[3];
+        split8<3>(hr[k][0], hr[k][1], hok[k], pl);
+        char* dst = sH + ((h0 + l_hy[k] + 2 * R) % R) * ROWB + l_loff[k];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 64) = pl[p];
+    };
+    float rlo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rlo[e] = (a.relu && colg + e < a.relu_limit) ? 0.f : -__builtin_inff();
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.y, 0, PLAIN ? (int)(unsigned)((size_t)a.M * a.y_ld * 4) : 0, 0x00020000);
+    auto finish_pass = [&](int pass, int oy, f32x4 v4) {
+        const int row = pass * 8 + rrow;
+        float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+        if constexpr (PLAIN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], rlo[e]);
+            const unsigned m = (unsigned)((n * a.oh + oy) * a.ow + ox0 + row);
+            const unsigned off = (oy < a.oh && ox0 + row < ox_end) ? (m * (unsigned)a.y_ld + (unsigned)colg) * 4u : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), yrs, off, 0, 0);
+        } else {
+            if (oy >= a.oh || nvalid <= 0 || ox0 + row >= ox_end) return;
+            const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (a.res) {
+                const float* rp = a.res + m * a.res_ld + colg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nvalid) v[e] += rp[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], rlo[e]);
+            float* yp = a.y + m * a.y_ld + colg;
+            if (vec && nvalid == 4) {
+                *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nvalid) yp[e] = v[e];
+            }
+        }
+    };
+
+    const int ntiles = (a.oh + TH - 1) / TH;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int k = 0; k < SL; ++k) fetch_one(k, TH * g + 2 - TH, hr, hok);
+#pragma unroll
+        for (int k = 0; k < SL; ++k) put_one(k, TH * g + 2 - TH);
+    }
+#pragma unroll
+    for (int k = 0; k < SL; ++k) fetch_one(k, TH + 2, hr, hok);
+
+    // fragment addresses: A block i (pixels 16 i .. 16 i + 15 of the wave's row) at tap column s, B block j
+    int aoff[3][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = l16 + 16 * i + s_;
+            aoff[s_][i] = q * PB + ((lg ^ ((q >> 1) & 3)) * 16);
+        }
+    const char* b_lane[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_lane[j] = sW + (l16 + 16 * j) * WB + lg * 16;
+
+    float accv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accv[r] = 0.f;
+    int rbase = 0;
+    for (int t = 0; t < ntiles; ++t, rbase = rbase + TH >= R ? rbase + TH - R : rbase + TH) {
+        __syncthreads();
+        const int oy = t * TH + wave;
+        const int hput = TH * t + TH + 2;
+        const char* ar[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int sl = rbase + wave + r;
+            ar[r] = sH + (sl >= R ? sl - R : sl) * ROWB;
+        }
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 fa[2][3], fb[2][2][3];                         // A: by half-step parity; B: by tap parity, block j
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            fa[0][p] = *reinterpret_cast<const u32x4*>(ar[0] + aoff[0][0] + p * 64);
+            fb[0][0][p] = *reinterpret_cast<const u32x4*>(b_lane[0] + p * 64);
+            fb[0][1][p] = *reinterpret_cast<const u32x4*>(b_lane[1] + p * 64);
+        }
+        float px[SL][8];
+        u32x4 ppl[SL][3];
+        f32x4 sv[2];
+#pragma unroll
+        for (int hs = 0; hs < 18; ++hs) {                   // half-step = (tap, A block i): 12 MFMAs of 16 cycles
+            const int tap = hs >> 1, i = hs & 1, tp = tap & 1;
+            if (hs + 1 < 18) {
+                const int tap1 = (hs + 1) >> 1, i1 = (hs + 1) & 1;
+                const int r1 = tap1 / 3, s1 = tap1 - r1 * 3;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fa[i1][p] = *reinterpret_cast<const u32x4*>(ar[r1] + aoff[s1][i1] + p * 64);
+            }
+            if (tap + 1 < 9) {                              // the next tap's B block i
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fb[tp ^ 1][i][p] = *reinterpret_cast<const u32x4*>(b_lane[i] + (tap + 1) * 192 + p * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i][prod_pa(3, q)]),
+                                                                       __builtin_bit_cast(bf16x8, fb[tp][j][prod_pb(3, q)]),
+                                                                       acc[i][j], 0, 0, 0);
+            const int ks = hs;
+            if (ks >= 6 && ks < 6 + SL && !(ABL & 16)) fetch_one(ks - 6, hput + TH, hn, hnok);
+            if (ks < SL * 5 && !(ABL & 32)) {
+                const int u = ks / 5, pc = ks - u * 5;
+                if (pc < 4) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float v = pc < 2 ? hr[u][0][2 * pc + e] : hr[u][1][2 * (pc - 2) + e];
+                        px[u][2 * pc + e] = hok[u] ? v : 0.f;
+                    }
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const bf16x2 pr = {(__bf16)px[u][2 * pc], (__bf16)px[u][2 * pc + 1]};
+                        unsigned word = __builtin_bit_cast(unsigned, pr);
+                        asm volatile("" : "+v"(word));
+                        ppl[u][p][pc] = word;
+                        if (p < 2) {
+                            px[u][2 * pc] -= (float)pr[0];
+                            px[u][2 * pc + 1] -= (float)pr[1];
+                        }
+                    }
+                } else {
+                    const int sl = rbase + TH + 2 + l_hy[u];
+                    char* dst = sH + (sl >= R ? sl - R : sl) * ROWB + l_loff[u];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * 64) = ppl[u][p];
+                }
+            }
+            if (!(ABL & 4) && t > 0) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)            // acc[i][j][v]: pixel 16 i + 4 lg + v, channel 16 j + l16
+                        stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * ((r >> 2) & 1) + l16] = accv[r];
+                }
+                if (ks >= 1 && ks < 5) {
+                    if (ks == 1) __builtin_amdgcn_wave_barrier();
+                    sv[ks & 1] = *reinterpret_cast<const f32x4*>(stage + ((ks - 1) * 8 + rrow) * SW + col4);
+                }
+                if (ks >= 2 && ks < 6) finish_pass(ks - 2, oy - TH, sv[(ks - 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ABL & 4) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) tsum += acc[i][j][v];
+            if (tsum == 1.2345e-30f) a.y[0] = tsum;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accv[r] = acc[r >> 3][(r >> 2) & 1][r & 3];
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            hr[k][0] = hn[k][0];
+            hr[k][1] = hn[k][1];
+            hok[k] = hnok[k];
+        }
+    }
+    if (!(ABL & 4)) {
+        const int oy = (ntiles - 1) * TH + wave;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * ((r >> 2) & 1) + l16] = accv[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+            finish_pass(pass, oy, *reinterpret_cast<const f32x4*>(stage + (pass * 8 + rrow) * SW + col4));
+    }
+}
+
 int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
     // strips of 30 (one output row per wave) or 16 pixels (two): whichever covers the width with fewer MFMA rows
     // (measured equal at 12 % fewer rows — Conv2d_2a/2b, 109 columns — so the narrow form needs a 20 % saving)
@@ -663,6 +932,28 @@ int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
         GV_LAUNCH_CHECK();                                                                                          \
         return GV_OK;                                                                                               \
     }
+#define GV_HALO_K32(B, P)                                                                                           \
+    {                                                                                                               \
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_k32<B, P>),             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
+        if (!ok) return GV_E_UNSUPPORTED;                                                                           \
+        hipLaunchKernelGGL((conv3x3_halo_x3_k32<B, P>), grid, dim3(256), lds32, st, a);                             \
+        GV_LAUNCH_CHECK();                                                                                          \
+        return GV_OK;                                                                                               \
+    }
+    const size_t lds32 = (size_t)10 * 32 * 192 + 4 * 32 * 36 * 4 + 32 * (9 * 192 + 32);
+    if (rw == 1 && !(a.dbg & 8)) {                    // (debug bit 8: the 32x32x16 form, for A/B timing)
+        if (a.dbg & (4 | 16 | 32)) {
+            if (!plain) return GV_E_UNSUPPORTED;
+            switch (a.dbg & 52) {
+                case 4: GV_HALO_K32(4, true)
+                case 52: GV_HALO_K32(52, true)
+            }
+            return GV_E_UNSUPPORTED;
+        }
+        if (plain) GV_HALO_K32(0, true)
+        GV_HALO_K32(0, false)
+    }
     if (a.dbg & (4 | 16 | 32)) {                      // timing experiments only
         if (!plain || rw != 1) return GV_E_UNSUPPORTED;
         switch (a.dbg & 52) {
@@ -679,6 +970,7 @@ int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
     if (plain) GV_HALO_LAUNCH(0, true, 1)
     GV_HALO_LAUNCH(0, false, 1)
 #undef GV_HALO_LAUNCH
+#undef GV_HALO_K32
 }
 
 // ---------------------------------------------------------------------------------------------------------------
