@@ -382,7 +382,6 @@ extern "C" int gv_conv2d_special_tile_cfg(int32_t math_mode) {
 extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
     if (math_mode == -1) return gvconv::lp_num_cfgs();     // the 16-bit storage kernels
     if (math_mode == -3) return gvconv::dma_x3_num_cfgs();  // three-plane input (GV_CONV_X_P3)
-    if (math_mode == -4) return gvconv::slab_lp_num_cfgs();  // of the 16-bit configurations, the trailing slab-kernel ones
     const int np = planes_of(math_mode);
     return np < 0 ? GV_E_BADARG : (np == 0 ? kNumTiles : gvconv::bf16s_num_cfgs());
 }

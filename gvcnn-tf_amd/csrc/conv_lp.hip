@@ -744,7 +744,7 @@ namespace gvconv {
 
 // configurations: [0, kNumTiles) register-staged tiles, kNumTiles = the strip / halo kernels of the stem layers,
 // then the LDS-DMA tiles of conv_dma.hip
-int lp_num_cfgs() { return kNumTiles + 1 + dma_lp_num_cfgs() + slab_lp_num_cfgs(); }
+int lp_num_cfgs() { return kNumTiles + 1 + dma_lp_num_cfgs(); }
 int lp_special_cfg() { return kNumTiles; }
 
 // the 3-channel stems read from the fp32 images: square 3x3 or 7x7 window, stride 2, <= 64 output channels
@@ -794,10 +794,6 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
         if (dtype == GV_BF16) return launch_halo<__bf16>(a, st);
         if (dtype == GV_F16) return launch_halo<_Float16>(a, st);
         return GV_E_UNSUPPORTED;
-    }
-    if (cfg > kNumTiles + dma_lp_num_cfgs()) {
-        if (!slab_lp_ok(a, generic, xf32)) return GV_E_UNSUPPORTED;
-        return slab_lp_launch(dtype, cfg - kNumTiles - 1 - dma_lp_num_cfgs(), a, st);
     }
     if (cfg > kNumTiles) {
         if (!dma_lp_ok(a, generic, xf32)) return GV_E_UNSUPPORTED;

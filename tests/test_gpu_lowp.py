@@ -41,13 +41,7 @@ def special_tile():
 
 def dma_tiles():
     """The LDS-DMA tile configurations (csrc/conv_dma.hip) follow the strip kernels' index."""
-    return list(range(lib().gv_conv2d_special_tile_cfg(-1) + 1, lib().gv_conv2d_num_tile_cfgs(-1) - lib().gv_conv2d_num_tile_cfgs(-4)))
-
-
-def slab_tiles():
-    """The slab-kernel configurations (csrc/conv_slab.hip) are the last ones."""
-    n = lib().gv_conv2d_num_tile_cfgs(-1)
-    return list(range(n - lib().gv_conv2d_num_tile_cfgs(-4), n))
+    return list(range(lib().gv_conv2d_special_tile_cfg(-1) + 1, lib().gv_conv2d_num_tile_cfgs(-1)))
 
 
 def rnd(t, td):
@@ -501,45 +495,3 @@ def test_lp_baseline_configs_at_full_size(backbone, V, size, G, ty):
                               Hd["dense_%d/bias" % V].numpy())
     close(S.float().cpu().numpy(), oS, ulp)
     assert rel_l2(logits.cpu().numpy(), oL) < 2 * ulp
-
-
-SLAB_CASES = [  # (kh, kw), padding, cin, cout, (nb, ih, iw)
-    ((3, 3), "SAME", 32, 64, (5, 8, 8)),          # tiles span several whole images
-    ((3, 3), "VALID", 80, 192, (2, 25, 23)),      # Conv2d_4a's class (cin = 5 slabs), ragged image width
-    ((5, 5), "SAME", 48, 64, (2, 35, 35)),        # Mixed_5 5x5
-    ((1, 7), "SAME", 128, 128, (3, 17, 17)),      # Mixed_6 1x7 / 7x1: a tile crosses one image boundary
-    ((7, 1), "SAME", 160, 192, (3, 17, 17)),
-    ((3, 3), "SAME", 64, 96, (1, 71, 40)),        # one image >= 4 tiles: per-image tiling, last tile ragged
-    ((1, 3), "SAME", 384, 200, (7, 8, 8)),        # cout not a multiple of 32
-    ((3, 1), "SAME", 16, 40, (1, 3, 5)),          # a single tiny tile
-]
-
-
-@pytest.mark.parametrize("ty", ["bf16", "f16"])
-@pytest.mark.parametrize("tile_i", list(range(10)))
-@pytest.mark.parametrize("case", list(range(len(SLAB_CASES))))
-def test_lp_slab_conv_vs_oracle(case, tile_i, ty):
-    """The slab kernel (input staged once per 16-channel slab, every filter tap a shifted LDS read): all its tile
-    shapes on the stride-1 k > 1 layer classes of the backbones, with residual and ReLU on a channel-slice destination;
-    a configuration may decline a layer whose slab does not fit its LDS budget (GV_E_UNSUPPORTED), never miscompute."""
-    k, padding, cin, cout, (nb, ih, iw) = SLAB_CASES[case]
-    if ty == "f16" and case not in (1, 3, 5):
-        pytest.skip("f16 shares the code path: three cases")
-    code, td, ulp = TYPES[ty]
-    tile = slab_tiles()[tile_i]
-    g = torch.Generator().manual_seed(case * 31 + tile_i)
-    x = rnd(torch.randn(nb, ih, iw, cin, generator=g), td)
-    w = rnd(torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5), td)
-    scale = torch.rand(cout, generator=g) + 0.5
-    shift = torch.randn(cout, generator=g) * 0.1
-    pads = (tf_pads(ih, k[0], 1, padding), tf_pads(iw, k[1], 1, padding))
-    ref0 = oracle_conv(x, w, 1, padding, scale, shift, False)
-    res = rnd(torch.randn(ref0.shape, generator=g), td)
-    ref = oracle_conv(x, w, 1, padding, scale, shift, True, residual=res)
-    try:
-        y = run_conv(x, w, 1, pads, ref.shape[1:3], scale, shift, True, ty, residual=res, tile=tile, y_ld=cout + 16, y_off=8)
-    except _lib.GvError as e:
-        if e.code == -2:                                   # GV_E_UNSUPPORTED
-            pytest.skip("configuration declines this layer (slab larger than its LDS budget)")
-        raise
-    close(y, ref.numpy(), ulp)
