@@ -26,6 +26,7 @@ struct ConvArgs {
     int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
     const void* zeros;          // conv_dma.hip: a zero page for the padding taps of the gather
     int y_p3, y2_p3;            // destination format: 0 = fp32, 1 = three bf16 planes (conv_x3_epi.h)
+    int korder;                 // conv_dma.hip: 0 = k-tiles tap-major, 1 = channel-chunk-major (filter taps innermost)
 };
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:

@@ -133,7 +133,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
         }
     };
     locate();
+    // k-tile order.  Tap-major (k = tap * cin + channel, the packed filter's order): consecutive k-tiles walk the channels
+    // of one tap, so a workgroup returns to the same input rows only after streaming its whole tile x cin — with 32
+    // workgroups per XCD that working set outruns the 4 MiB L2 and every tap re-fetches the rows from the fabric (measured
+    // 6.5x the input per 1x7 layer).  Chunk-major (a.korder: channel chunk outer, filter tap inner; needs KT | cin): the
+    // taps of one chunk re-read the SAME few KB per workgroup back to back, and they hit L2.  Same products, another
+    // summation order; the filter slice of (chunk, tap) is k-tile tap * cin/KT + chunk of the same packed filter.
+    const int b_tap_step = (a.cin / 16) * G16;                     // bytes between the same chunk of consecutive taps
+    int kt_tap = 0;                                                // chunk-major: tap index of the next tile to issue
     auto advance = [&]() {
+        if (a.korder) {
+            if (++fs == a.kw) { fs = 0; ++fr; }
+            if (++kt_tap == a.kh * a.kw) { kt_tap = 0; fs = 0; fr = 0; fc += KT; }
+            locate();
+            return;
+        }
         fc += KT;
         if (fc >= a.cin) {
             do { fc -= a.cin; if (++fs == a.kw) { fs = 0; ++fr; } } while (fc >= a.cin);
@@ -169,9 +183,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
         }
     };
     auto step_state = [&]() {                                      // loader state -> next tile
+        const bool wrap = a.korder && kt_tap + 1 == a.kh * a.kw;   // (read before advance() moves it)
+        const int bstep = !a.korder ? (KT / 16) * G16 : (wrap ? (KT / 16) * G16 - (a.kh * a.kw - 1) * b_tap_step : b_tap_step);
         advance();
 #pragma unroll
-        for (int i = 0; i < UBW; ++i) b_ptr[i] += (KT / 16) * G16;
+        for (int i = 0; i < UBW; ++i) b_ptr[i] += bstep;
     };
     auto issue = [&](int stage) {                                  // (prologue) the tile at the current loader state
         char* sb = smem + stage * STAGE;
@@ -465,6 +481,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
     a.zeros = zero_page_for_current_device();
     if (!a.zeros) return GV_E_UNSUPPORTED;
+    a.korder = (a.kh * a.kw > 1 && a.cin % G::KT == 0 && a.dil_shift == 0 && !(a.dbg & 128)) ? 1 : 0;   // dbg 128: tap-major (A/B)
     const size_t ring = (size_t)ST * NP * (BM + BN) * G::RBYTES;
     const size_t epi = EPI == 1 ? 0 : (size_t)(WM * WN) * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
     const size_t lds = ring > epi ? ring : epi;

@@ -109,8 +109,8 @@ P3_COMBOS = [((3, 3), 1, "VALID", 32, 64), ((3, 3), 1, "VALID", 80, 192), ((5, 5
 @pytest.mark.parametrize("tile", [0, 3, 4, 7, 8, 9, 10, 12, 13, 14, 15])
 @pytest.mark.parametrize("k,stride,padding,cin,cout", P3_COMBOS)
 def test_dma_conv_on_three_plane_input(k, stride, padding, cin, cout, tile):
-    """The LDS-DMA kernel on P3 input (fp32 output and P3 output) against the CPU oracle and BITWISE against the
-    register-staged kernel on the same values as fp32; input and output are channel slices of wider tensors."""
+    """The LDS-DMA kernel on P3 input (fp32 output and P3 output) against the CPU oracle and against the register-staged
+    kernel on the same values as fp32 (bitwise in the same k order); input and output are channel slices of wider tensors."""
     g = torch.Generator().manual_seed(hash((k, stride, cin, cout)) % 1000)
     ih, iw = (23, 20) if cin <= 64 else (9, 10)
     x = torch.randn(3, ih, iw, cin, generator=g)
@@ -123,10 +123,20 @@ def test_dma_conv_on_three_plane_input(k, stride, padding, cin, cout, tile):
     base = conv(x, w, stride, pads, hw, scale, shift, True)                                  # fp32 in, fp32 out
     y = conv(x, w, stride, pads, hw, scale, shift, True, x_p3=True, tile=tile, x_ld=cin + 32, x_off=16, y_ld=cout + 8, y_off=4)
     close(y, ref)
-    assert torch.equal(y, base)
+    # k-tiles run channel-chunk-major here (filter taps innermost, for L2 locality) where 16 | cin: the same products in
+    # another summation order, so fp32-rounding-level agreement with the tap-major register-staged kernel ...
+    sc = float(base.abs().max())
+    assert float((y - base).abs().max()) <= 4e-6 * sc
     yp = conv(x, w, stride, pads, hw, scale, shift, True, x_p3=True, y_p3=True, tile=tile, x_ld=cin + 32, x_off=16,
               y_ld=cout + 32, y_off=16)
-    assert torch.equal(yp, base)
+    assert torch.equal(yp, y)
+    # ... and BITWISE agreement in the tap-major order (debug bit 128)
+    lib().gv_conv2d_set_debug(128)
+    try:
+        yt = conv(x, w, stride, pads, hw, scale, shift, True, x_p3=True, tile=tile, x_ld=cin + 32, x_off=16, y_ld=cout + 8, y_off=4)
+    finally:
+        lib().gv_conv2d_set_debug(0)
+    assert torch.equal(yt, base)
 
 
 @pytest.mark.parametrize("tile", [0, 3, 4, 9])
@@ -229,9 +239,9 @@ def test_average_pool_relu_on_three_plane_input():
                                   ("Mixed_6c", "Mixed_7a")])
 @pytest.mark.parametrize("size", [75, 107])
 def test_inception_plan_with_and_without_three_plane_intermediates(size, taps):
-    """The whole Inception-v3 plan under GV_MATH_BF16X3 with three-plane conv -> conv intermediates (LDS-DMA kernels) is
-    BITWISE the plan that keeps everything fp32 — at the tapped (pinned) end points, several pairs of them — and both
-    match the CPU oracle."""
+    """The whole Inception-v3 plan under GV_MATH_BF16X3 with three-plane conv -> conv intermediates (LDS-DMA kernels)
+    equals the plan that keeps everything fp32 to fp32 rounding (2e-5 of the end point's scale after ~45 layers) — at the
+    tapped (pinned) end points, several pairs of them — and both match the CPU oracle."""
     nb = 3
     g = torch.Generator().manual_seed(1)
     x = (torch.rand(nb, size, size, 3, generator=g) - 0.5)
@@ -245,8 +255,9 @@ def test_inception_plan_with_and_without_three_plane_intermediates(size, taps):
         plan.run(x.to(DEV))
         torch.cuda.synchronize()
         ends[use] = {k: plan.view(plan.end_points[k]).clone().cpu() for k in taps}
-    for k in taps:
-        assert torch.equal(ends["all"][k], ends[False][k]), k
+    for k in taps:                                         # (summation order differs in the chunk-major layers: fp32 rounding)
+        sc = float(ends[False][k].abs().max())
+        assert float((ends["all"][k] - ends[False][k]).abs().max()) <= 2e-5 * sc, k
     _, ep = OB.inception_v3_base(x, P, taps[1])
     for k in taps:
         d = ep[k].numpy()
