@@ -79,6 +79,7 @@ SIGNATURES = {
     "gv_group_assign_per_shape": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "gv_view_pool_fuse_fwd_per_shape": (C.c_int, [_P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _F, _P, _P, _I, _P]),
     "gv_preprocess_views": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "gv_png_unfilter": (C.c_int, [_P, _I, _I, _I, _P]),
     "gv_eval_metrics": (C.c_int, [_P, _P, _I, _I, _P, _P, _P, _P]),
     "gv_dense_fwd": (C.c_int, [_P, _I, _I, _P, _P, _I, _P, _P]),
     "gv_bn_stats_grouped": (C.c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P]),

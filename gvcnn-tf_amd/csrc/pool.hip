@@ -331,3 +331,35 @@ extern "C" int gv_global_avg_pool(const void* x, int32_t nb, int32_t hw, int32_t
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
+
+// ---- PNG row un-filtering (host code: tf.image.decode_png of train_data.py:55 after zlib inflate) -------------------
+// raw: h rows of (1 filter byte + rowbytes data bytes); out: h x rowbytes.  Filters 0-4 of the PNG specification
+// (None, Sub, Up, Average, Paeth); bpp = bytes per pixel.  Sequential by definition (each byte depends on its left
+// neighbour), which is why it lives here and not in a Python loop.
+extern "C" int gv_png_unfilter(const uint8_t* raw, int32_t h, int32_t rowbytes, int32_t bpp, uint8_t* out) {
+    if (!raw || !out || h <= 0 || rowbytes <= 0 || bpp <= 0) return GV_E_BADARG;
+    const uint8_t* prev = nullptr;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* line = raw + (size_t)y * (rowbytes + 1);
+        uint8_t* cur = out + (size_t)y * rowbytes;
+        const int ft = line[0];
+        ++line;
+        if (ft > 4) return GV_E_BADARG;
+        for (int x = 0; x < rowbytes; ++x) {
+            const int a = x >= bpp ? cur[x - bpp] : 0;
+            const int b = prev ? prev[x] : 0;
+            const int c = (prev && x >= bpp) ? prev[x - bpp] : 0;
+            int p = 0;
+            if (ft == 1) p = a;
+            else if (ft == 2) p = b;
+            else if (ft == 3) p = (a + b) >> 1;
+            else if (ft == 4) {
+                const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+                p = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            cur[x] = (uint8_t)(line[x] + p);
+        }
+        prev = cur;
+    }
+    return GV_OK;
+}

@@ -24,13 +24,15 @@ class Evaluator:
         self.batch_accuracies = []
         self.num_shapes = 0
 
-    def add_batch(self, views, labels, fused=True):
-        """views [N,V,H,W,3], labels [N] (int64).  Returns this batch's accuracy (reads one int back)."""
+    def add_batch(self, views, labels, fused=True, valid=None):
+        """views [N,V,H,W,3], labels [N] (int64).  Returns this batch's accuracy (reads one int back).  valid: the
+        number of real shapes of a padded last batch (ViewBatcher(remainder="pad"): labels of the padding are -1 and are
+        ignored by gv_eval_metrics); the batch then weighs as one batch of `valid` shapes, like eval.py:204."""
         eng = self.eng
         with torch.cuda.device(eng.device):
-            return self._add_batch(views, labels, fused)
+            return self._add_batch(views, labels, fused, eng.N if valid is None else int(valid))
 
-    def _add_batch(self, views, labels, fused):
+    def _add_batch(self, views, labels, fused, valid):
         eng = self.eng
         if fused:
             _, _, logits = eng.forward(views)
@@ -44,9 +46,9 @@ class Evaluator:
         _lib.check(_lib.load().gv_eval_metrics(logits.data_ptr(), lab.data_ptr(), eng.N, self.C, self._pred.data_ptr(),
                                                self.confusion.data_ptr(), self._correct.data_ptr(), _model._st()),
                    "gv_eval_metrics")
-        acc = float(self._correct.item()) / eng.N
+        acc = float(self._correct.item()) / valid
         self.batch_accuracies.append(acc)
-        self.num_shapes += eng.N
+        self.num_shapes += valid
         return acc
 
     def result(self):

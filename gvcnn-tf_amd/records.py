@@ -201,31 +201,13 @@ def decode_png(data):
         elif kind == b"IEND":
             break
     ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, 1 + w * ch)
-    img = np.zeros((h, w * ch), np.uint8)
-    prev = np.zeros(w * ch, np.int32)
-    for y in range(h):
-        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        else:                                   # Sub / Average / Paeth depend on the pixel to the left
-            cur = np.zeros(w * ch, np.int32)
-            for x in range(w * ch):
-                a = cur[x - ch] if x >= ch else 0
-                b = prev[x]
-                c = prev[x - ch] if x >= ch else 0
-                if ft == 1:
-                    p = a
-                elif ft == 3:
-                    p = (a + b) >> 1
-                else:
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[x] = (line[x] + p) & 255
-        img[y] = cur
-        prev = cur
+    raw = np.ascontiguousarray(np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8).reshape(h, 1 + w * ch))
+    img = np.empty((h, w * ch), np.uint8)
+    if not raw[:, 0].any():                     # filter 0 on every line: the bytes are the pixels
+        img[:] = raw[:, 1:]
+    else:                                       # Sub / Average / Paeth are sequential per byte: native helper
+        from . import _lib
+        _lib.check(_lib.load().gv_png_unfilter(raw.ctypes.data, h, w * ch, ch, img.ctypes.data), "gv_png_unfilter")
     img = img.reshape(h, w, ch)
     if ctype == 3:
         return plte[img[..., 0]]
@@ -252,38 +234,85 @@ def encode_png(img):
 class ViewBatcher:
     """TFRecord shapes -> (views [N, V, H, W, 3] fp32 on the device, labels [N]).  All views of a file must share one
     decoded size (the ModelNet renders do).  augment=True draws the flips and the brightness delta of
-    train_data.py:81-84 per view from `rng`."""
+    train_data.py:81-84 per view from `rng`.
 
-    def __init__(self, path, num_views, height, width, batch_size, device, augment=False, seed=0):
+    shuffle_buffer > 0: the streaming shuffle of tf.data (train_data.py:123 uses 1000 + 3 * batch_size): a buffer of that
+    many shapes is filled, each new shape replaces a uniformly drawn one which is emitted, the buffer is drained in
+    random order at the end — the reference's records are written class by class, so without it every batch is
+    class-pure.  remainder: what happens to the last N_total % N shapes — "warn" (default) drops them with a warning and
+    counts them in `dropped`; "pad" repeats the last shape up to N, pads the labels with -1 (ignored by
+    gv_eval_metrics) and sets `last_valid` to the real count, for Evaluator.add_batch(..., valid=batcher.last_valid)
+    (the reference's eval loop counts that short batch, eval.py:204; note that its batch-mean view scores are then taken
+    over the real shapes only, here over the padded batch); "error" raises."""
+
+    def __init__(self, path, num_views, height, width, batch_size, device, augment=False, seed=0, shuffle_buffer=0,
+                 remainder="warn"):
+        if remainder not in ("warn", "pad", "error"):
+            raise ValueError("remainder must be 'warn', 'pad' or 'error'")
         self.path, self.V, self.H, self.W, self.N = path, num_views, height, width, batch_size
         self.device, self.augment = device, augment
         self.rng = np.random.RandomState(seed)
+        self.shuffle_buffer, self.remainder = int(shuffle_buffer), remainder
+        self.dropped, self.last_valid = 0, batch_size
 
-    def __iter__(self):
-        import torch
-        from . import _lib
-        from .model import _st
-        lib = _lib.load()
-        imgs, labels = [], []
+    def _shapes(self):
+        """(views uint8 [V, h0, w0, 3], label) per record, through the shuffle buffer."""
+        buf = []
         for rec in read_tfrecords(self.path):
             ex = parse_example(rec)
             enc = ex["image/encoded"]
             if len(enc) != self.V:
                 raise ValueError("record holds %d views, expected %d" % (len(enc), self.V))
-            imgs.append(np.stack([decode_png(e) for e in enc]))
-            labels.append(int(ex["image/label"][0]))
-            if len(imgs) == self.N:
-                raw = np.stack(imgs)                                    # [N, V, h0, w0, 3] uint8
-                nimg, h0, w0 = self.N * self.V, raw.shape[2], raw.shape[3]
-                src = torch.from_numpy(raw).to(self.device)
-                dst = torch.empty((self.N, self.V, self.H, self.W, 3), dtype=torch.float32, device=self.device)
-                flip = delta = None
-                if self.augment:
-                    flip = torch.from_numpy(self.rng.randint(0, 4, size=nimg).astype(np.int32)).to(self.device)
-                    delta = torch.from_numpy(self.rng.uniform(-1.1, 1.1, size=nimg).astype(np.float32)).to(self.device)
-                _lib.check(lib.gv_preprocess_views(src.data_ptr(), nimg, h0, w0, self.H, self.W,
+            item = (np.stack([decode_png(e) for e in enc]), int(ex["image/label"][0]))
+            if self.shuffle_buffer <= 0:
+                yield item
+            elif len(buf) < self.shuffle_buffer:
+                buf.append(item)
+            else:
+                k = int(self.rng.randint(0, len(buf)))
+                out, buf[k] = buf[k], item
+                yield out
+        while buf:
+            yield buf.pop(int(self.rng.randint(0, len(buf))))
+
+    def _batch(self, imgs, labels):
+        import torch
+        from . import _lib
+        from .model import _st
+        raw = np.stack(imgs)                                            # [N, V, h0, w0, 3] uint8
+        nimg, h0, w0 = self.N * self.V, raw.shape[2], raw.shape[3]
+        src = torch.from_numpy(raw).to(self.device)
+        dst = torch.empty((self.N, self.V, self.H, self.W, 3), dtype=torch.float32, device=self.device)
+        flip = delta = None
+        if self.augment:
+            flip = torch.from_numpy(self.rng.randint(0, 4, size=nimg).astype(np.int32)).to(self.device)
+            delta = torch.from_numpy(self.rng.uniform(-1.1, 1.1, size=nimg).astype(np.float32)).to(self.device)
+        _lib.check(_lib.load().gv_preprocess_views(src.data_ptr(), nimg, h0, w0, self.H, self.W,
                                                    flip.data_ptr() if flip is not None else None,
                                                    delta.data_ptr() if delta is not None else None, dst.data_ptr(),
                                                    _st()), "gv_preprocess_views")
-                yield dst, torch.tensor(labels, dtype=torch.int64)
+        return dst, torch.tensor(labels, dtype=torch.int64)
+
+    def __iter__(self):
+        import warnings
+        imgs, labels = [], []
+        self.dropped, self.last_valid = 0, self.N
+        for img, label in self._shapes():
+            imgs.append(img)
+            labels.append(label)
+            if len(imgs) == self.N:
+                yield self._batch(imgs, labels)
                 imgs, labels = [], []
+        if imgs:
+            if self.remainder == "error":
+                raise ValueError("%d trailing shapes do not fill a batch of %d" % (len(imgs), self.N))
+            if self.remainder == "pad":
+                self.last_valid = len(imgs)
+                while len(imgs) < self.N:
+                    imgs.append(imgs[self.last_valid - 1])
+                    labels.append(-1)
+                yield self._batch(imgs, labels)
+            else:
+                self.dropped = len(imgs)
+                warnings.warn("ViewBatcher: the last %d shapes of %s do not fill a batch of %d and were dropped"
+                              % (len(imgs), self.path, self.N))

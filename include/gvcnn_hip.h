@@ -266,6 +266,11 @@ int gv_dense_fwd(const float* x, int32_t n, int32_t f, const float* kernel, cons
 int gv_preprocess_views(const uint8_t* src, int32_t nimg, int32_t h0, int32_t w0, int32_t height, int32_t width,
                         const int32_t* flip, const float* delta, float* dst, void* stream);
 
+/* PNG row un-filtering on the HOST (the sequential half of tf.image.decode_png, train_data.py:55 / eval_data.py:64,
+ * after zlib inflate): raw = h rows of (filter byte + rowbytes bytes), out = h x rowbytes; filter types 0-4 of the PNG
+ * specification, bpp bytes per pixel.  Both pointers are host memory; no stream. */
+int gv_png_unfilter(const uint8_t* raw, int32_t h, int32_t rowbytes, int32_t bpp, uint8_t* out);
+
 /* ---- evaluation metrics (eval.py:94-99) ---------------------------------------------------------
  * prediction[n] = argmax_c logits[n,c] (first maximum, like tf.argmax); confusion[label, prediction] += 1
  * (tf.math.confusion_matrix, int32 [C,C], ACCUMULATED so a whole evaluation run needs one buffer);

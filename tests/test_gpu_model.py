@@ -360,6 +360,9 @@ def test_eval_harness_metrics_and_protocols():
             ev.add_batch(views(N, V, 64, 64, seed=seed).to(DEV), torch.tensor([seed, 3]), fused=fused)
         acc, cm, count = ev.result()
         assert count == 4 and cm.sum() == 4 and abs(acc - sum(ev.batch_accuracies) / 2) < 1e-12
+        # a padded last batch (ViewBatcher(remainder="pad")): label -1 is ignored, the batch counts its real shapes
+        a3 = ev.add_batch(views(N, V, 64, 64, seed=0).to(DEV), torch.tensor([0, -1]), fused=fused, valid=1)
+        assert ev.num_shapes == 5 and int(ev.confusion.sum()) == 5 and a3 in (0.0, 1.0)
         accs.append((acc, cm.tolist()))
     assert accs[0] == accs[1]
 
@@ -395,6 +398,17 @@ def test_input_pipeline_preprocess_and_batcher(tmp_path):
         want = OP.preprocess_views(np.stack([v for k in (2 * b, 2 * b + 1) for v in shapes[k][0]]), 32, 32)
         np.testing.assert_allclose(x.cpu().numpy().reshape(N * V, 32, 32, 3), want, rtol=0, atol=2e-6)
         assert float(x.min()) >= -0.5 and float(x.max()) <= 0.5 + 1e-6     # 255 * fp32(1/255) - 0.5 = 0.50000006
+    # the trailing N_total % N shapes: dropped WITH a warning by default, padded on request (labels -1, last_valid)
+    bt = R.ViewBatcher(path, V, 32, 32, 3, DEV)
+    with pytest.warns(UserWarning, match="dropped"):
+        assert len(list(bt)) == 1
+    assert bt.dropped == 1
+    bp = R.ViewBatcher(path, V, 32, 32, 3, DEV, remainder="pad")
+    got = list(bp)
+    assert len(got) == 2 and bp.last_valid == 1 and got[1][1].tolist() == [shapes[3][1], -1, -1]
+    assert torch.equal(got[1][0][1], got[1][0][0]) and torch.equal(got[1][0][2], got[1][0][0])
+    with pytest.raises(ValueError):
+        list(R.ViewBatcher(path, V, 32, 32, 3, DEV, remainder="error"))
 
 
 @pytest.mark.parametrize("lanes", [False, True])

@@ -76,3 +76,69 @@ def test_resize_oracle_closed_form_cases():
     assert np.array_equal(down, img[::2, ::2].astype(np.float32))
     out = OP.preprocess_views(img[None], 4, 6, flip=[3], delta=[2.0])
     np.testing.assert_allclose(out[0], (img[::-1, ::-1].astype(np.float32) + 2.0) / 255.0 - 0.5, rtol=0, atol=1e-6)
+
+
+def _png_with_filters(img, filters):
+    """PNG bytes of uint8 [h, w, 3] whose line y is written with filter type filters[y % len(filters)] (an independent,
+    straight-from-the-specification encoder: Sub / Up / Average / Paeth need no library)."""
+    import struct
+    import zlib
+    h, w, ch = img.shape
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    raw = bytearray()
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        cur, prev = rows[y], (rows[y - 1] if y else np.zeros(w * ch, np.int32))
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            p = np.zeros_like(cur)
+        elif ft == 1:
+            p = a
+        elif ft == 2:
+            p = prev
+        elif ft == 3:
+            p = (a + prev) >> 1
+        else:
+            pa, pb, pc = np.abs(prev - c), np.abs(a - c), np.abs(a + prev - 2 * c)
+            p = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw += bytes([ft]) + ((cur - p) & 255).astype(np.uint8).tobytes()
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("filters", [(1,), (2,), (3,), (4,), (0, 1, 2, 3, 4), (4, 3, 1)])
+def test_png_row_filters_through_the_native_helper(filters):
+    """Every PNG filter type (the renders on disk use them all) through gv_png_unfilter — host code of the C-ABI
+    library — against an encoder written from the specification; first line, first pixel and wrap-around cases included."""
+    rng = np.random.RandomState(sum(filters))
+    img = rng.randint(0, 256, size=(13, 17, 3)).astype(np.uint8)
+    img[0, :3] = 255
+    img[5] = 0
+    assert np.array_equal(R.decode_png(_png_with_filters(img, filters)), img)
+
+
+def test_view_batcher_shuffle_buffer_and_remainder_policy(tmp_path):
+    """The streaming shuffle (train_data.py:123) emits every shape exactly once, deterministically per seed, and mixes
+    the class-ordered records; the remainder policy is explicit."""
+    import os
+    V = 2
+    rng = np.random.RandomState(0)
+    shapes = [([rng.randint(0, 256, size=(6, 5, 3)).astype(np.uint8) for _ in range(V)], k) for k in range(23)]
+    path = os.path.join(tmp_path, "s.record")
+    R.write_tfrecords(path, [R.make_example([R.encode_png(v) for v in vs], lab) for vs, lab in shapes])
+    plain = [lab for _, lab in R.ViewBatcher(path, V, 8, 8, 4, "cpu")._shapes()]
+    assert plain == list(range(23))
+    a = [lab for _, lab in R.ViewBatcher(path, V, 8, 8, 4, "cpu", seed=5, shuffle_buffer=8)._shapes()]
+    b = [lab for _, lab in R.ViewBatcher(path, V, 8, 8, 4, "cpu", seed=5, shuffle_buffer=8)._shapes()]
+    c = [lab for _, lab in R.ViewBatcher(path, V, 8, 8, 4, "cpu", seed=6, shuffle_buffer=8)._shapes()]
+    assert sorted(a) == list(range(23)) and a == b and a != plain and a != c
+    # a shape can leave the buffer only after it entered it: emitted position >= record position - buffer
+    assert all(pos + 8 >= lab for pos, lab in enumerate(a))
+    for v, lab in R.ViewBatcher(path, V, 8, 8, 4, "cpu", seed=5, shuffle_buffer=8)._shapes():
+        assert np.array_equal(v, np.stack(shapes[lab][0]))
+    with pytest.raises(ValueError):
+        R.ViewBatcher(path, V, 8, 8, 4, "cpu", remainder="keep")
