@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgvcnn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_bf16s.hip", "conv_lp.hip", "conv_dma.hip", "pool.hip", "lowp.hip", "grouping.hip", "plan.hip", "train.hip", "train_lp.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bf16s.hip", "conv_lp.hip", "conv_dma.hip", "pool.hip", "lowp.hip", "grouping.hip", "plan.hip", "train.hip", "train_lp.hip", "wgrad_dma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

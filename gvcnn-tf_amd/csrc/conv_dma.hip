@@ -552,6 +552,8 @@ int launch_dma_x3(int cfg, const ConvArgs& a, hipStream_t st) {
 
 namespace gvconv {
 
+const void* dma_zero_page() { return zero_page_for_current_device(); }   // (wgrad_dma.hip shares it)
+
 int dma_x3_num_cfgs() { return 16; }
 
 // P3 input: whole 16-channel groups inside one filter tap

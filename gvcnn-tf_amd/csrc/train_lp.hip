@@ -1185,8 +1185,9 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     };
     int ti = side(d->cin), to = side(d->cout);
     int64_t target = 2048;
+    if (d->tile_cfg > 30)                                        // 31..42: LDS-DMA staging (wgrad_dma.hip)
+        return gvlp::conv_wgrad_dma_launch(d, x, dz, dz_ld, dw, d->tile_cfg - 31, st);
     if (d->tile_cfg > 27) {                                      // 28..30: strip form, 1024 / 2048 / 4096 workgroups
-        if (d->tile_cfg > 30) return GV_E_BADARG;
         return strip_t<T>(d, x, dz, dz_ld, dw, 1024 << (d->tile_cfg - 28), st);
     }
     // heuristic: the strip form for the few-channel stem layers (2.5-3.5x there); its general 64x64x9-tap variant

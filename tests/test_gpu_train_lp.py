@@ -269,7 +269,7 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
     dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
     n = lib().gv_conv2d_wgrad_num_cfgs(dt)
-    assert n == 30 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0
+    assert n == 42 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 12 LDS-DMA
     outs = []
     for cfg in range(n + 1):
         dw = torch.zeros(3, 3, cin, cout, device=DEV)
@@ -280,6 +280,39 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
         close(o, outs[0], 2e-5)
     d = _lib.ConvDesc(nb, ih, iw, cin, cin, 3, 3, 1, 1, 1, ih, iw, cout, cout, 0, 0, 0, dt, 0, n + 1, 0, 0)
     assert lib().gv_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), cout, outs[0].to(DEV).data_ptr(), st()) != 0
+
+
+@pytest.mark.parametrize("cfg", [31, 32, 33, 34, 38, 42])
+@pytest.mark.parametrize("k,stride,padding,cin,cout,nb,ih,iw", [c for c in CONVS if c[5] * c[6] * c[7] < 100000])
+def test_wgrad_lds_dma_form_on_every_layer_class(k, stride, padding, cin, cout, nb, ih, iw, cfg):
+    """The LDS-DMA staged filter gradient (csrc/wgrad_dma.hip; tile_cfg 31..42): strided and padded layers, channel
+    counts that do not fill a tile, ragged pixel slices, operands that are channel slices of wider buffers — against
+    autograd on the same 16-bit values (exact products: only the summation order differs)."""
+    dt, tdt, eps = TYPES[0]
+    if cin % 8 or cout % 8:
+        pytest.skip("the 16-bit MFMA filter gradient needs whole 8-channel chunks")
+    g = torch.Generator().manual_seed(hash((k, stride, cin, cfg)) % 997)
+    x = q(torch.randn(nb, ih, iw, cin, generator=g), tdt).requires_grad_(True)
+    w = q(torch.randn(k[0], k[1], cin, cout, generator=g) * 0.1, tdt).requires_grad_(True)
+    z = OB.conv2d(x, w, stride, padding)
+    dz = q(torch.randn(*z.shape, generator=g), tdt)
+    z.backward(dz)
+    oh, ow = z.shape[1:3]
+    if isinstance(padding, str):
+        pt = OB.same_pads(ih, k[0], stride)[0] if padding == "SAME" else 0
+        pl = OB.same_pads(iw, k[1], stride)[0] if padding == "SAME" else 0
+    else:
+        pt, pl = padding[0], padding[2]
+    xld, zld = cin + 8, cout + 16
+    xd = torch.zeros(nb, ih, iw, xld, dtype=tdt, device=DEV)
+    xd[..., :cin] = x.detach().to(tdt).to(DEV)
+    xd[..., cin:] = 3.0                                    # neighbours in the wider buffers must not leak in
+    dzd = torch.full((nb, oh, ow, zld), 5.0, dtype=tdt, device=DEV)
+    dzd[..., :cout] = dz.to(tdt).to(DEV)
+    dw = torch.full((k[0], k[1], cin, cout), 0.5, device=DEV)
+    d = _lib.ConvDesc(nb, ih, iw, cin, xld, k[0], k[1], stride, pt, pl, oh, ow, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
+    _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad")
+    close(dw.cpu() - 0.5, w.grad, 3e-5)
 
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
