@@ -405,8 +405,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int tiles_x = (a.ow + TW - 1) / TW;
     const int nct = (a.cout + 31) / 32;
-    const int ct = blockIdx.x % nct;                       // column tile fastest: the workgroups sharing a halo run together
-    const int strip = blockIdx.x / nct;
+    // column tile fastest, and consecutive LOGICAL ids on one XCD (hardware deals consecutive workgroup ids round-robin over
+    // the 8 XCDs): the two column tiles of a strip then share an L2 and the second one's halo rows hit it
+    const int lid = gv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int ct = lid % nct;
+    const int strip = lid / nct;
     const int n = strip / tiles_x;
     const int ox0 = (strip % tiles_x) * TW;
     const int co0 = ct * 32;
@@ -664,8 +667,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
     const int tiles_x = (a.ow + TW - 1) / TW;
     const int nct = (a.cout + 31) / 32;
-    const int ct = blockIdx.x % nct;
-    const int strip = blockIdx.x / nct;
+    const int lid = gv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int ct = lid % nct;
+    const int strip = lid / nct;
     const int n = strip / tiles_x;
     const int ox0 = (strip % tiles_x) * TW;
     const int co0 = ct * 32;
