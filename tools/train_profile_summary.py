@@ -17,7 +17,7 @@ period = idx[-1] - idx[-2]
 first = idx[-steps] - (idx[-1] - idx[-2]) + (len(rows) - idx[-1])   # same phase as the end of the trace
 first = max(first, 0)
 sel = rows[len(rows) - steps * period:]
-FAM = [("conv fwd/dgrad", ("conv_igemm", "conv3x3_halo", "conv_stem_patch")), ("filter gradient", ("conv_wgrad",)),
+FAM = [("filter gradient", ("conv_wgrad",)), ("conv fwd/dgrad", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma")),
        ("BN sums", ("grouped_sums",)), ("BN apply fwd/bwd", ("bn_stream", "scale_shift_act_grouped", "bn_bwd_apply")),
        ("pool fwd/bwd", ("pool2d", "maxpool3s2")), ("fills/copies", ("FillFunctor", "fillBuffer", "copyBuffer")),
        ("filter re-pack", ("pack_filter", "elementwise_kernel")), ("optimizer", ("sgd_momentum",)),
