@@ -571,3 +571,22 @@ def test_stem_strip_kernel_fp32_storage(k, pad, cout, hw):
     ref = torch.relu(OB.conv2d(xp, w, 2, "VALID") * scale + shift).numpy()
     y = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, True, tile=11, math=1)
     np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_halo_stem_kernel_random_geometries(seed):
+    """The rolling-ring halo kernel against the implicit-GEMM kernel on random image sizes (1 .. 75, both strip forms,
+    partial last tiles in both directions), paddings, output widths and batch sizes."""
+    rng = np.random.RandomState(1000 + seed)
+    pad = int(rng.randint(0, 2))
+    ih, iw = int(rng.randint(3 - 2 * pad, 76)), int(rng.randint(3 - 2 * pad, 76))
+    nb, cout = int(rng.randint(1, 4)), int(rng.choice([32, 64, 24, 48]))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(nb, ih, iw, 32, generator=g)
+    w = torch.randn(3, 3, 32, cout, generator=g) * 0.06
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
+    relu = bool(rng.randint(0, 2))
+    y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, relu, tile=11, math=1)
+    y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, relu, tile=0, math=1)
+    np.testing.assert_allclose(y, y0, rtol=1e-5, atol=1e-5)
