@@ -1014,13 +1014,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_x3(const ConvArgs a) {
     }
     for (int idx = tid; idx < 3 * PR * PITCH / 4; idx += 256) reinterpret_cast<unsigned*>(sP)[idx] = 0u;
 
-    const int rrow = lane >> 2, col8 = (lane & 3) * 8;
-    float sc[TN][8], sh[TN][8];
+    const int rrow = lane >> 3, col4 = (lane & 7) * 4;      // read-back: 8 lanes x 16 bytes = one pixel's 32 channels, so a
+    float sc[TN][4], sh[TN][4];                             // store instruction writes whole 128-byte lines
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = min(j * 32 + col8 + e, a.cout - 1);
+        for (int e = 0; e < 4; ++e) {
+            const int c = min(j * 32 + col4 + e, a.cout - 1);
             sc[j][e] = a.scale[c];
             sh[j][e] = a.shift[c];
         }
@@ -1098,28 +1098,26 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_x3(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
             __builtin_amdgcn_wave_barrier();
-            const int colj = j * 32 + col8;
-            const int nvalid = min(8, a.cout - colj);
+            const int colj = j * 32 + col4;
+            const int nvalid = min(4, a.cout - colj);
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int row = pass * 16 + rrow;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = pass * 8 + rrow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col4);
                 if (oy >= a.oh || nvalid <= 0 || ox0 + row >= a.ow) continue;
                 const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                float v[4] = {lo[0], lo[1], lo[2], lo[3]};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int e = 0; e < 4; ++e) {
                     v[e] = v[e] * sc[j][e] + sh[j][e];
                     if (a.relu && colj + e < a.relu_limit) v[e] = fmaxf(v[e], 0.f);
                 }
                 float* yp = a.y + m * a.y_ld + colj;
-                if (vec && nvalid == 8) {
+                if (vec && nvalid == 4) {
                     *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(yp + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
+                    for (int e = 0; e < 4; ++e)
                         if (e < nvalid) yp[e] = v[e];
                 }
             }
