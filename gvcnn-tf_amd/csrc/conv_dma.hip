@@ -78,6 +78,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN;
     const int wn = wave % WN;
+    // Eight waves = two per SIMD (waves w and w+4: a workgroup's waves go to the SIMDs in a cyclic order), and the k-tile
+    // barrier makes both arrive at their MFMAs together: they then share the matrix pipe and idle together through the next
+    // barrier / fragment reads / DMA issue.  A higher issue priority for one of the two staggers them inside a k-tile —
+    // one runs its MFMAs while the other does everything else: -2 .. -3.5 % on the 256-row tiles (debug bit 256: off, A/B).
+    if (NW == 8 && wave >= 4 && !(a.dbg & 256)) __builtin_amdgcn_s_setprio(2);
 
     const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lid % a.tiles_n;
