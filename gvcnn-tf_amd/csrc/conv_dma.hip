@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     // barrier makes both arrive at their MFMAs together: they then share the matrix pipe and idle together through the next
     // barrier / fragment reads / DMA issue.  A higher issue priority for one of the two staggers them inside a k-tile —
     // one runs its MFMAs while the other does everything else: -2 .. -3.5 % on the 256-row tiles (debug bit 256: off, A/B).
-    if (NW == 8 && wave >= 4 && !(a.dbg & 256)) __builtin_amdgcn_s_setprio(2);
+    if (NW == 8 && NP == 1 && wave >= 4 && !(a.dbg & 256)) __builtin_amdgcn_s_setprio(2);
 
     const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lid % a.tiles_n;
@@ -399,10 +399,61 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
             else if (ST >= 3 && younger >= 1) wait_vm<(ST >= 3 ? LPT : 0)>();
             else wait_vm<0>();
         };
+        // Eight waves, one k-step per tile (NP = 3): the two waves of a SIMD run HALF A TILE OUT OF PHASE.  Every wave's tile
+        // is [first half of the MFMAs, nothing else] [second half + the next tile's fragment reads + the DMA issue]; waves
+        // 0-3 pass the tile barrier in front of the first half, waves 4-7 between the halves.  The barrier releases both at
+        // once, so one wave of each SIMD is in its pure-MFMA half while its partner does everything else, and they swap.
+        // (Same barrier count for every wave; tile kt's stage is overwritten only behind barrier kt+1, by which time both
+        // groups have consumed their fragments of tile kt.)  Debug bit 256: everyone passes the barrier in front (A/B).
+        constexpr bool PHASED = NW == 8 && KS == 1 && (NMFS % 2 == 0);
+        const bool late_barrier = PHASED && wave >= NW / 2 && !(a.dbg & 256);
+        auto mfmas_half = [&](auto setc, auto halfc, bool do_issue, char* nb, bool do_read, int rstage) {
+            constexpr int S = decltype(setc)::value;
+            constexpr int HALF = decltype(halfc)::value;
+            constexpr int H = NMFS / 2;
+            constexpr int GAP2 = H / (LPT + 1) > 0 ? H / (LPT + 1) : 1;
+    #pragma unroll
+            for (int mm = 0; mm < H; ++mm) {
+                const int m = HALF * H + mm;
+                const int t = m / (TM * TN);
+                const int i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = mfma16<T>(fa[S][i][dprod_pa(NP, t)], fb[S][j][dprod_pb(NP, t)], acc[i][j]);
+                if (HALF == 1) {
+                    if (mm == 0) {
+                        if (do_read) read_frags(std::integral_constant<int, S ^ 1>{}, rstage, 0);
+                    }
+                    if ((mm + 1) % GAP2 == 0 && (mm + 1) / GAP2 <= LPT) {
+                        if (do_issue) dma_one((mm + 1) / GAP2 - 1, nb);
+                    }
+                }
+            }
+            if (HALF == 1) {
+                if (do_issue) {
+    #pragma unroll
+                    for (int d = H / GAP2; d < LPT; ++d) dma_one(d, nb);
+                    step_state();
+                }
+            }
+        };
         // tile kt whose first k-step's fragments sit in register set PAR
         auto tile_step = [&](auto parc, int kt, int stage) {
             constexpr int PAR = decltype(parc)::value;
             const int next = stage + 1 == ST ? 0 : stage + 1;
+            if constexpr (PHASED) {
+                const bool more = kt + 1 < ktiles;
+                if (more && !late_barrier) {
+                    wait_tile(kt + 1);
+                    __builtin_amdgcn_s_barrier();
+                }
+                mfmas_half(std::integral_constant<int, PAR>{}, std::integral_constant<int, 0>{}, false, nullptr, false, 0);
+                if (more && late_barrier) {
+                    wait_tile(kt + 1);
+                    __builtin_amdgcn_s_barrier();
+                }
+                mfmas_half(std::integral_constant<int, PAR>{}, std::integral_constant<int, 1>{}, kt + ST < ktiles,
+                           smem + stage * STAGE, more, next);
+                return;
+            }
     #pragma unroll
             for (int s = 0; s + 1 < KS; ++s) {
                 if (((PAR + s) & 1) == 0) { read_frags(std::integral_constant<int, 1>{}, stage, s + 1); mfmas(std::integral_constant<int, 0>{}, false, nullptr); }
