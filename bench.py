@@ -109,7 +109,7 @@ def parse():
     return a
 
 
-def roofline(eng, x, math, iters=5, traffic=None):
+def roofline(eng, x, math, iters=10, traffic=None):
     """Per-launch hipEvent timing (on the launch stream) of every implicit-GEMM conv launch of one
     step; achieved = algorithmic conv FLOPs of the step / summed conv kernel time."""
     plan = eng.plan
