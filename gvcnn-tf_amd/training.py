@@ -147,7 +147,7 @@ class TrainGVCNN:
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2,
                  head_views=None, view_offset=0, per_shape=False, weight_mode="count", storage="f32",
-                 fuse_siblings=True):
+                 fuse_siblings=True, frozen_bn=False):
         """head_views / view_offset: view-sharded data parallelism (sharding.ShardedTrainGVCNN) — this engine
         runs the backbone for views [view_offset, view_offset + num_views) of the head_views views of every shape
         (so each view's BatchNorm statistics stay on one rank, exactly the reference's per-view statistics),
@@ -174,6 +174,13 @@ class TrainGVCNN:
         # per-(view, channel) BatchNorm sums over the ranks, shape_world = number of ranks sharing every view
         self.bn_sync = None
         self.shape_world = 1
+        # frozen_bn: BatchNorm normalises with the MOVING statistics (slim's is_training=False arithmetic) while every
+        # variable still gets its gradient: dz = gamma*inv*g without the two batch-statistics terms.  The reference never
+        # trains this way; it exists because train-mode statistics over a handful of samples amplify rounding
+        # chaotically, and with them frozen the whole assembled step can be held to 1e-3 against the oracle.  Built from
+        # the split entry points: the forward accumulator is FILLED with the sums that reproduce the moving statistics,
+        # the backward accumulator is zeroed between its two halves after beta/gamma took their gradients from it.
+        self.frozen_bn = bool(frozen_bn)
         self.Vh = head_views if head_views is not None else num_views
         self.view_offset = view_offset
         assert 0 <= view_offset and view_offset + num_views <= self.Vh
@@ -613,9 +620,17 @@ class TrainGVCNN:
             hw = x.h * x.w
             acc = op["acc_f"] if self._zacc else self.accum
             zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
-            _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, acc.data_ptr(), self.dt | zf,
-                                                _st()), "bn sums " + op["name"])
-            if self.bn_sync is not None:                  # shape-sharded: reduce the sums over the ranks first
+            if self.frozen_bn:                            # sums that finalize to (moving_mean, moving_variance)
+                mm = self.params[op["name"] + "/moving_mean"].double()
+                mv = self.params[op["name"] + "/moving_variance"].double()
+                cnt = self._count(hw).double().view(V, 1)
+                a = acc[:2 * V * x.c].view(V, x.c, 2)
+                a[..., 0] = cnt * mm
+                a[..., 1] = cnt * (mv + mm * mm)
+            else:
+                _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, acc.data_ptr(), self.dt | zf,
+                                                    _st()), "bn sums " + op["name"])
+            if self.bn_sync is not None and not self.frozen_bn:   # shape-sharded: reduce the sums over the ranks first
                 self.bn_sync(acc[:2 * V * x.c])
             _lib.check(lib.gv_bn_finalize_apply_grouped_t(
                 acc.data_ptr(), self._count(hw).data_ptr(), gamma.data_ptr() if gamma is not None else None,
@@ -778,6 +793,13 @@ class TrainGVCNN:
                 "bn_bwd sums " + op["name"])
             if self.bn_sync is not None:
                 self.bn_sync(accb[:2 * V * x.c])
+            if self.frozen_bn:                            # beta / gamma take their gradients, the statistics terms vanish
+                ab = accb[:2 * V * x.c].view(V, x.c, 2)
+                self.grads[op["name"] + "/beta"] += ab[..., 0].sum(0).float()
+                if gamma is not None:
+                    self.grads[op["name"] + "/gamma"] += ab[..., 1].sum(0).float()
+                ab.zero_()
+                dbeta = dgamma = None
             _lib.check(lib.gv_bn_relu_bwd_apply_grouped_t(
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
                 st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,

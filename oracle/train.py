@@ -33,9 +33,11 @@ def head(stacked, scheme, weight, Wc, bc, labels):
 
 
 def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num_bins=10,
-                   raw_tap=None, final_tap=None):
+                   raw_tap=None, final_tap=None, frozen_bn=False):
     """inputs [N,V,H,W,3] float32, labels [N] int64.  Returns dict(loss, grads{name: tensor}, scores, scheme,
-    weight, logits, shape_descriptor)."""
+    weight, logits, shape_descriptor).  frozen_bn: BatchNorm with the moving statistics (slim's is_training=False
+    arithmetic, inception_utils.py / resnet_utils.py arg scopes) while autograd still differentiates every variable — not a
+    mode the reference trains in; the well-conditioned form of the same graph used to hold the assembled backward pass."""
     n_views = inputs.shape[1]
     raw_tap = raw_tap or M.TAPS[backbone][0]
     final_tap = final_tap or M.TAPS[backbone][1]
@@ -46,7 +48,7 @@ def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num
     views = inputs.permute(1, 0, 2, 3, 4)
     finals, scores = [], []
     for v in range(n_views):
-        mode = B._BNMode(True, groups=[0] * views[v].shape[0])
+        mode = B._BNMode(not frozen_bn, groups=[0] * views[v].shape[0])
         ep = M.run_backbone(backbone, views[v], Pg, mode)
         nm = "dense" if v == 0 else "dense_%d" % v
         s = G.view_score(ep[raw_tap].detach().numpy(), H[nm + "/kernel"].numpy(), float(H[nm + "/bias"][0]))

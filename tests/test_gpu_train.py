@@ -266,6 +266,61 @@ def test_training_step_vs_oracle(backbone, size, N, V):
     assert float(loss1) < l0
 
 
+@pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 171, 4, 2), ("resnet_v2_50", 97, 3, 2)])
+def test_assembled_step_with_frozen_statistics_vs_oracle(backbone, size, N, V, math="bf16x3"):
+    """The WHOLE assembled step — forward, loss, every backward kernel chained through ~50 layers, fused siblings, lazy
+    first-writer stores — against torch autograd through the oracle evaluated in fp64, with BatchNorm normalising by the
+    moving statistics (TrainGVCNN(frozen_bn=True) / oracle loss_and_grads(frozen_bn=True)).  Without the
+    batch-statistics feedback that amplifies rounding (see the fp64-arbiter test) the step is well-conditioned up to ONE
+    discrete effect: an activation within the forward's rounding distance of zero gets a different ReLU mask, and on
+    these small test tensors a single flipped element is 1-3e-3 of a gradient's norm.  Measured per (view, layer): the
+    activation gradients agree with fp64 to 4e-6 from the loss down to the first such element of that view and to 1.5-5e-3
+    below it (ResNet: view 0 down to block2/unit_2, view 1 down to block3/unit_5); the fp32 oracle, whose forward is ~10x
+    closer to fp64, has fewer flips (1e-6 / 3e-3 worst on ResNet / Inception).  Asserted: forward quantities to 1e-4, the
+    classifier and the last block to 1e-4 (above every flip: the chain of kernels itself is exact to rounding), every
+    variable's gradient to 5e-3 norm-wise.  Train-mode BatchNorm itself is held kernel by kernel at 1e-5 above."""
+    C_, G = 5, 10
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    del eng
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, math=math,
+                     frozen_bn=True)
+    x = torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5
+    labels = torch.tensor([1, 4, 2, 0][:N])
+    r32 = OT.loss_and_grads(x, labels.numpy(), P, Hd, G, backbone, frozen_bn=True)
+    r64 = OT.loss_and_grads(x.double(), labels.numpy(), {k: torch.as_tensor(v).double() for k, v in P.items()},
+                            {k: torch.as_tensor(v).double() for k, v in Hd.items()}, G, backbone, frozen_bn=True)
+    scores, S, logits, loss = eng.forward(x.to(DEV), labels)
+    assert eng.scheme.cpu().numpy().tolist() == r64["scheme"].tolist()
+    close(S.cpu(), r64["shape_descriptor"], 1e-4)
+    close(logits.cpu(), r64["logits"], 1e-4)
+    assert abs(float(loss) - r64["loss"]) <= 1e-4 * max(1.0, abs(r64["loss"]))
+    grads = eng.backward()
+    torch.cuda.synchronize()
+    assert set(r64["grads"]) <= set(grads)
+    big = max(float(g.norm()) for g in r64["grads"].values())
+    rows = []
+    for name, g64 in r64["grads"].items():
+        g64 = g64.numpy()
+        n = float(np.linalg.norm(g64))
+        e_abs = float(np.linalg.norm(grads[name].cpu().numpy().astype(np.float64) - g64))
+        if n <= 1e-3 * big:
+            assert e_abs <= 5e-6 * big, (name, e_abs, big)
+            continue
+        e_ora = float(np.linalg.norm(r32["grads"][name].numpy().astype(np.float64) - g64)) / n
+        rows.append((e_abs / n, e_ora, name))
+    rows.sort(reverse=True)
+    import sys
+    print("frozen-statistics step vs fp64, %s: engine median %.2e worst %.2e (%s); oracle32 median %.2e worst %.2e" % (
+        backbone, sorted(r[0] for r in rows)[len(rows) // 2], rows[0][0], rows[0][2],
+        sorted(r[1] for r in rows)[len(rows) // 2], max(r[1] for r in rows)), file=sys.stderr)
+    assert rows[0][0] <= 5e-3, rows[0]
+    top = "resnet_v2_50/block4/unit_3/" if backbone == "resnet_v2_50" else "InceptionV3/Mixed_7c/Branch_0/"
+    tops = [r for r in rows if r[2].startswith(top) or r[2].startswith("dense_")]
+    assert tops and max(r[0] for r in tops) <= 1e-4, tops[:3]
+
+
 @pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 107, 16, 2), ("resnet_v2_50", 64, 16, 2)])
 def test_training_step_against_an_fp64_arbiter(backbone, size, N, V, math="bf16x3"):
     """Which side moves?  The reference's gradient is only defined up to fp32 rounding, and through ~50 train-mode

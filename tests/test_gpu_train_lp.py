@@ -518,6 +518,51 @@ def test_bf16_training_step_tracks_the_fp32_step(backbone, size, N, V):
     assert float(loss1) < l0
 
 
+@pytest.mark.parametrize("backbone,size,N,V", [("inception_v3", 171, 4, 2), ("resnet_v2_50", 97, 3, 2)])
+def test_bf16_step_with_frozen_statistics_tracks_the_fp32_step(backbone, size, N, V):
+    """The non-chaotic whole-step check of the bf16 path: with BatchNorm on its moving statistics (frozen_bn=True) the bf16
+    engine is held against the fp32-storage engine on the same variables, batch and scheme.  Every stored activation and
+    activation gradient is rounded to 8 mantissa bits once (relative 2^-9 = 2e-3 rms-ish per rounding); through ~50 layers
+    forward and ~50 backward these add like a random walk: sqrt(100) * 2e-3 = 2e-2, and a few ReLU masks differ.  Bound:
+    descriptor / logits 5e-2, total gradient 1e-1 in relative L2 with cosine >= 0.99, every value finite.  Measured
+    (Inception / ResNet): descriptor 0.4 % / 1.3 %, logits 0.2 % / 0.7 %, gradient 4.7 % / 7.6 %, cosine 0.9989 / 0.9971 (the
+    same comparison on batch statistics: cosine 0.05); the deepest tensors of the backward pass, the stem filters, carry
+    the largest share (37-42 %)."""
+    C_, G = 5, 10
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C_, seed=3, spread_scores=True)
+    del eng
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
+    labels = torch.tensor([1, 4, 2, 0][:N])
+    e32 = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, frozen_bn=True)
+    _, S32, logits32, loss32 = e32.forward(x, labels)
+    S32, logits32, loss32 = S32.clone(), logits32.clone(), float(loss32)
+    g32 = {k: v.clone() for k, v in e32.backward().items()}
+    scheme, weight = e32.scheme.cpu().numpy(), e32.weight.cpu().numpy()
+    e16 = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage="bf16",
+                     frozen_bn=True)
+    _, S16, logits16, loss16 = e16.forward(x, labels, g_scheme=scheme, g_weight=weight)
+    S16, logits16, loss16 = S16.clone(), logits16.clone(), float(loss16)
+    g16 = e16.backward()
+    torch.cuda.synchronize()
+
+    def rel_l2(a, b):
+        a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+        return float((a - b).norm() / b.norm())
+    names = sorted(g32)
+    a, d = _flat(g16, names), _flat(g32, names)
+    cos = float((a @ d) / (a.norm() * d.norm()))
+    rel = float((a - d).norm() / d.norm())
+    worst = max((rel_l2(g16[k], g32[k]), k) for k in names if float(g32[k].norm()) > 1e-3 * float(d.norm()))
+    print("frozen bf16 vs fp32 step, %s: S %.4f logits %.4f loss %.5f vs %.5f; gradient rel %.4f cos %.5f; worst tensor %.3f (%s)"
+          % (backbone, rel_l2(S16.float(), S32), rel_l2(logits16, logits32), loss16, loss32, rel, cos, worst[0], worst[1]))
+    assert rel_l2(S16.float(), S32) < 5e-2 and rel_l2(logits16, logits32) < 5e-2
+    assert abs(loss16 - loss32) <= 1e-2 * max(1.0, abs(loss32))
+    assert all(bool(torch.isfinite(v).all()) for v in g16.values())
+    assert rel < 1e-1 and cos > 0.99
+
+
 def test_bf16_step_at_the_real_c3_geometry_beside_the_fp32_step():
     """configs[2] at its real geometry (12 views x 224 x 224, N = 8) on bf16 storage beside the fp32-storage engine, same
     variables, batch and scheme.  What this CAN hold on a randomly initialised network: train-mode BatchNorm re-normalises
