@@ -228,6 +228,53 @@ def allreduce_sum_bucketed(tensors, bucket_bytes=64 << 20, group=None):
     return len(buckets)
 
 
+class OverlappedFlatAllReduce:
+    """Sum over the ranks of flat[0:hi] — a gradient buffer that becomes final from its END towards offset 0 while the
+    backward pass runs (TrainGVCNN.backward_backbone(progress=...)).  progress(lo) says "flat[lo:hi] is final": whenever
+    at least bucket_bytes have become final since the last launch, that slice is all-reduced IN PLACE, asynchronously
+    (no staging copy: the bucket IS the slice); finish() launches what is left and waits for everything.  On RCCL the
+    collectives run on the communicator's stream behind the kernels enqueued so far and overlap the rest of the backward
+    pass; xGMI is point-to-point, so few large slices (64 MiB) are used, not one message per variable.  A gloo group with
+    device tensors (the one-device control-flow checks) falls back to one synchronous reduction in finish()."""
+
+    def __init__(self, flat, hi, bucket_bytes=64 << 20, group=None):
+        self.flat, self.hi, self.group = flat, int(hi), group
+        self.bucket = max(1, int(bucket_bytes) // flat.element_size())
+        self.sent_lo = self.hi                                # flat[sent_lo:hi] has been launched
+        self.pending = []
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.sync_only = self.world > 1 and flat.is_cuda and dist.get_backend(group) == "gloo"
+        self.launches = 0
+
+    def _launch(self, lo, hi):
+        if hi > lo:
+            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.launches += 1
+
+    def progress(self, lo):
+        lo = max(0, min(int(lo), self.sent_lo))
+        if self.world == 1 or self.sync_only:
+            return
+        if self.sent_lo - lo >= self.bucket:
+            self._launch(lo, self.sent_lo)
+            self.sent_lo = lo
+
+    def finish(self):
+        if self.world == 1:
+            return 0
+        if self.sync_only:
+            h = self.flat[:self.hi].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat[:self.hi].copy_(h)
+            return 1
+        self._launch(0, self.sent_lo)
+        self.sent_lo = 0
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        return self.launches
+
+
 def allreduce_sum_(t, group=None):
     """In-place sum over the ranks (a gloo group is fed through host memory)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -294,13 +341,14 @@ class ShardedTrainGVCNN:
                   BatchNorm exchange) over the view group, the classifier (identical inside a view group) over the
                   shape group."""
 
-    def __init__(self, engine, group=None, bucket_bytes=64 << 20, mode="views"):
+    def __init__(self, engine, group=None, bucket_bytes=64 << 20, mode="views", overlap_grads=True):
         if mode not in ("views", "shapes", "hybrid"):
             raise ValueError(mode)
         self.eng = engine
         self.group = group
         self.mode = mode
         self.bucket_bytes = bucket_bytes
+        self.overlap_grads = bool(overlap_grads)   # filter gradients are all-reduced while the backward pass still runs
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if mode == "hybrid":
@@ -322,6 +370,16 @@ class ShardedTrainGVCNN:
                 engine.shape_world = self.world
                 engine.bn_sync = lambda accum: allreduce_sum_(accum, self.group)
 
+    def _filter_reducer(self, group):
+        """The conv filters' gradients — the first _n_wd elements of the engine's flat gradient buffer, >95 % of the bytes —
+        are reduced WHILE the backward pass runs (OverlappedFlatAllReduce); None when the engine cannot report progress
+        (branch lanes) or there is nobody to reduce with."""
+        eng = self.eng
+        if self.world <= 1 or not self.overlap_grads or not hasattr(eng, "_flat_g") or not getattr(eng, "_g_monotone", False) \
+                or getattr(eng, "_lane_streams", None) is not None:
+            return None
+        return OverlappedFlatAllReduce(eng._flat_g, eng._n_wd, self.bucket_bytes, group)
+
     def _train_step_shapes(self, views_local, labels_local, lr, mu, weight_decay, check):
         eng = self.eng
         eng.forward_backbone(views_local)
@@ -334,9 +392,12 @@ class ShardedTrainGVCNN:
                                eng.scores.data_ptr(), _st()), "score finalize (global)")
         eng.forward_head(labels_local, check=check, r_img=None, scores_ready=True)
         eng.backward_head()
-        eng.backward_backbone()
+        red = self._filter_reducer(self.group)
+        eng.backward_backbone(progress=red.progress if red else None)
         # BN beta/gamma gradients come out of the all-reduced sums: already global.  Everything else is a local sum.
-        local = [g for k, g in eng.grads.items() if not k.endswith(("/beta", "/gamma"))]
+        local = [g for k, g in eng.grads.items() if not k.endswith(("/beta", "/gamma")) and not (red and k.endswith("/weights"))]
+        if red:
+            red.finish()
         allreduce_sum_bucketed(local, self.bucket_bytes, self.group)
         eng.update_moving_averages()
         eng.apply_momentum(lr, mu, weight_decay)
@@ -367,10 +428,14 @@ class ShardedTrainGVCNN:
             eng.final_grad().copy_(dF[:, lo:lo + v_l])
         else:
             eng.backward_head()
-        eng.backward_backbone()
+        red = self._filter_reducer(None)
+        eng.backward_backbone(progress=red.progress if red else None)
         bn = [g for k, g in eng.grads.items() if k.endswith(("/beta", "/gamma"))]
         cls = [eng.grads[k] for k in eng.cls_names]
-        shared = [g for k, g in eng.grads.items() if not k.endswith(("/beta", "/gamma")) and k not in eng.cls_names]
+        shared = [g for k, g in eng.grads.items() if not k.endswith(("/beta", "/gamma")) and k not in eng.cls_names
+                  and not (red and k.endswith("/weights"))]
+        if red:
+            red.finish()
         allreduce_sum_bucketed(shared, self.bucket_bytes, None)                    # every view, every shape
         if self.vg > 1:
             allreduce_sum_bucketed(bn, self.bucket_bytes, self.view_group)         # shapes already summed by bn_sync
@@ -407,9 +472,12 @@ class ShardedTrainGVCNN:
         eng.backward_head(dF=dF)
         lo = eng.view_offset
         eng.final_grad().copy_(dF[:, lo:lo + eng.V])
-        eng.backward_backbone()
+        red = self._filter_reducer(self.group)
+        eng.backward_backbone(progress=red.progress if red else None)
         # classifier gradients are identical on every rank (the head ran on the gathered data): not reduced
-        shared = [g for k, g in eng.grads.items() if k not in eng.cls_names]
+        shared = [g for k, g in eng.grads.items() if k not in eng.cls_names and not (red and k.endswith("/weights"))]
+        if red:
+            red.finish()
         allreduce_sum_bucketed(shared, self.bucket_bytes, self.group)
         self.update_moving_averages_views()
         eng.apply_momentum(lr, mu, weight_decay)

@@ -252,6 +252,15 @@ class TrainGVCNN:
                 offs[k] = total
                 total += (init[k].numel() + 15) // 16 * 16
             self._n_wd = offs.pop("n_wd", total)
+            # where each conv's filter gradient starts in the flat buffer: the filters come first, in layer order, so a
+            # backward pass finalises that region from its end towards offset 0 (backward_backbone(progress=...))
+            lows = []
+            for op in p.ops:
+                if op["kind"] == "conv":
+                    op["g_lo"] = op["flat_off"] if op.get("members") else offs.get(op["name"] + "/weights")
+                    if op["g_lo"] is not None:
+                        lows.append(op["g_lo"])
+            self._g_monotone = all(a < b for a, b in zip(lows, lows[1:]))
             self._flat_p, self._flat_g, self._flat_m = (torch.zeros(total, dtype=f32, device=dev) for _ in range(3))
             self.params, self.grads, self.momentum = {}, {}, {}
             for k in train:
@@ -756,10 +765,17 @@ class TrainGVCNN:
         self._claim(f)                                        # (the caller writes all of it)
         return self.view(f, grad=True).view(self.N, self.V, f.h, f.w, f.c)
 
-    def backward_backbone(self):
-        """Backbone backward from the gradient held in the final tap's gradient buffer."""
+    def backward_backbone(self, progress=None):
+        """Backbone backward from the gradient held in the final tap's gradient buffer.
+        progress(lo): called after a convolution's backward has been ENQUEUED with the flat-buffer offset from which on
+        every filter gradient is final, i.e. self._flat_g[lo:self._n_wd] will not be written again in this pass (the
+        filters are laid out in layer order and the pass runs from the last layer to the first) — the hook a data-parallel
+        wrapper uses to start reducing gradients while the rest of the backward pass still runs.  Only on the single
+        launch stream (with branch lanes the enqueue order is not the execution order)."""
         if self._zacc:
             self._accum_b.zero_()                         # every layer's backward sums: one fill
+        if progress is not None and (self._lane_streams is not None or not self._g_monotone):
+            progress = None
         self._phase_begin()
         for op in reversed(self.plan.ops):
             y = op["y"]
@@ -767,6 +783,8 @@ class TrainGVCNN:
                 continue                                  # nothing downstream of the final tap reaches it
             outs = (op["x"], op.get("res"))
             self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op, self._zacc))
+            if progress is not None and op["kind"] == "conv" and op.get("g_lo") is not None:
+                progress(op["g_lo"])
         self._phase_end()
         return self.grads
 

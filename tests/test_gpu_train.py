@@ -469,6 +469,37 @@ def _view_sharded_step(storage):
             assert err < 2e-4 * scale, (k, err, scale)   # same kernels; only atomic summation order differs
 
 
+@pytest.mark.parametrize("backbone,size", [("inception_v3", 107), ("resnet_v2_50", 64)])
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_backward_progress_frontier_is_final(backbone, size, storage):
+    """backward_backbone(progress=cb): when cb(lo) is called, the filter-gradient region flat_g[lo:n_wd] must already hold
+    its FINAL values (stream order) — nothing enqueued later writes it.  That is what lets a data-parallel wrapper start
+    all-reducing that slice while the rest of the backward pass runs (sharding.OverlappedFlatAllReduce).  Checked by
+    snapshotting the region at every call (a device-side copy on the same stream) and comparing with the end of the pass;
+    the frontier must also reach 0 and shrink monotonically, and every '/weights' gradient must lie inside the region."""
+    N, V, C_, G = 2, 2, 5, 10
+    eng = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV, storage=storage)
+    assert eng._g_monotone
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    eng.forward(x, torch.tensor([1, 3]))
+    eng.backward_head()
+    snaps, los = [], []
+
+    def cb(lo):
+        los.append(lo)
+        if len(snaps) < 12 or lo == 0:                       # a dozen early frontiers + the last one
+            snaps.append((lo, eng._flat_g[lo:eng._n_wd].clone()))
+    eng.backward_backbone(progress=cb)
+    torch.cuda.synchronize()
+    assert los and los[-1] == 0 and all(a > b for a, b in zip(los, los[1:]))
+    for lo, snap in snaps:
+        assert torch.equal(snap, eng._flat_g[lo:eng._n_wd]), lo
+    base = eng._flat_g.data_ptr()
+    for k, g in eng.grads.items():
+        inside = 0 <= (g.data_ptr() - base) // 4 < eng._n_wd
+        assert inside == k.endswith("/weights"), k
+
+
 def test_bn_moving_average_update():
     """UPDATE_OPS of train.py:178-186: V sequential updates with the unbiased variance; and end to end through
     TrainGVCNN (moving statistics after one step == oracle formula on the engine's own batch statistics)."""

@@ -288,3 +288,42 @@ def test_overlapped_exchange_returns_the_same_results_one_call_later():
     mp.spawn(_overlap_worker, args=(port, ret), nprocs=WORLD, join=True)
     assert ret[0][0] and ret[1][0]
     assert ret[0][1] == ret[1][1]                      # allgather form: every rank holds all logits, identical
+
+
+# ------------------------------------------------------------------------------------------------
+# OverlappedFlatAllReduce: the filter gradients are reduced slice by slice while they become final
+# ------------------------------------------------------------------------------------------------
+def _flat_reduce_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding_f", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    n, hi = 100003, 90001                                   # the tail [hi, n) is NOT part of the reduced region
+    base = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    flat = base.clone()
+    red = sh.OverlappedFlatAllReduce(flat, hi, bucket_bytes=4 * 7000)
+    # the backward pass finalises the region from its end: decreasing, irregular frontiers (and a repeated one)
+    for lo in (88000, 87990, 70000, 69000, 69000, 41000, 40000, 12345, 3):
+        flat[lo:hi] += 0.0                                   # (stands for "these values are final now")
+        red.progress(lo)
+        assert red.sent_lo >= lo
+    launches = red.finish()
+    want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(WORLD))
+    ok = torch.equal(flat[:hi], want[:hi]) and torch.equal(flat[hi:], base[hi:]) and red.sent_lo == 0
+    ret[rank] = (ok, launches)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_flat_all_reduce_sums_every_element_exactly_once():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_flat_reduce_worker, args=(port, ret), nprocs=WORLD, join=True)
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] == ret[1][1] and 4 <= ret[0][1] <= 9    # several slices, fewer than the progress calls
