@@ -88,10 +88,11 @@ def parse():
                     help="nccl = RCCL (the real multi-GPU path); gloo + --same-device: control-flow check of the N>1 path "
                          "on a single-GPU box (every rank on cuda:0, collectives through host memory)")
     ap.add_argument("--same-device", action="store_true")
-    ap.add_argument("--dp", default="views", choices=["views", "shapes", "hybrid"],
-                    help="--train with N > 1: shard the views of every shape (BN statistics stay local), the shapes "
-                         "(every BN layer all-reduces its per-view sums), or both (hybrid: view groups x shape shards, "
-                         "equal work on every rank, BN sums only inside a shape group)")
+    ap.add_argument("--dp", default="hybrid", choices=["views", "shapes", "hybrid"],
+                    help="--train with N > 1: hybrid (default: view groups x shape shards, equal work on every rank, BN "
+                         "sums only inside a shape group; pure view sharding whenever N divides the 12 views), views "
+                         "(shard the views of every shape, BN statistics stay local; 8 ranks get 2,2,2,2,1,1,1,1) or "
+                         "shapes (every BN layer all-reduces its per-view sums)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph (GVCNN.capture): for small, launch-bound view batches; N = 1 only")
     ap.add_argument("--train", action="store_true",
