@@ -37,6 +37,7 @@ import torch.distributed as dist                # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3                    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0                  # MI355X_MICROARCH.md: bf16 MFMA dense (spec)
+HBM_PEAK = 8.0e12                               # MI355X_MICROARCH.md: HBM3E bytes/s (spec)
 # fp32 products evaluated as N bf16 MFMA passes (GV_MATH_*): the ceiling in ALGORITHMIC fp32 FLOPs
 MATH = {"f32": ("conv_igemm_f32", PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 (exact fp32 chain)"),
         "bf16x3": ("the bf16x3 convolution family: conv_dma<NP=3> (LDS-DMA, three-plane input), conv3x3_halo_x3_k32 (stem 3x3), "
@@ -129,10 +130,18 @@ def roofline(eng, x, math, iters=10, traffic=None):
             worst = (op["name"], ms, tf)
     achieved = flops / (t_ms * 1e-3) / 1e12
     kname, peak, how = MATH[math]
+    # per-launch ceiling: a launch can finish no sooner than its FLOPs at the MFMA peak or its algorithmic bytes at the
+    # HBM peak, whichever is later; `attainable` is the step's FLOPs over the sum of those times (== peak when no launch
+    # is HBM-bound: ResNet's 64-channel 1x1 layers are, and cap the whole step well below the MFMA peak)
+    t_min = sum(max(op["flops"] / (peak * 1e12), op["bytes"] / HBM_PEAK) for op in plan.ops if op["kind"] == "conv")
+    n_hbm = sum(1 for op in plan.ops if op["kind"] == "conv" and op["bytes"] / HBM_PEAK > op["flops"] / (peak * 1e12))
+    attainable = flops / t_min / 1e12
     alg_bytes = sum(op["bytes"] for op in plan.ops if op["kind"] == "conv") / n
     return {"bound": "mfma", "kernel": "%s; %d launches/step, every one timed" % (kname, n), "math": how,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
+            "attainable": round(attainable, 1), "frac_of_attainable": round(achieved / attainable, 4),
+            "hbm_bound_launches": n_hbm,
             "traffic": round(traffic["conv_hbm_bytes_per_launch"]) if traffic and "conv_hbm_bytes_per_launch" in traffic else None,
             "traffic_note": (traffic or {}).get("note", "not measured (--no-traffic)"),
             "algorithmic_bytes_per_launch": round(alg_bytes),

@@ -245,7 +245,8 @@ class BackbonePlan:
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
                              split=0, cout=cout,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
-                             bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout)))
+                             bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout *
+                                                      (1 + (residual is not None) + (y2 is not None)))))
         return (out, y2) if next_preact is not None else out
 
     def pool(self, x, k, stride, padding, mode, out=None, name="pool", p3=False):
