@@ -67,6 +67,7 @@ SIGNATURES = {
     "gv_packed_filter_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "gv_pack_filter_hwio": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gv_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_conv2d_fwd_xpre": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gv_pool2d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
     "gv_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "gv_global_avg_pool": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "gv_plan_add_conv": (C.c_int, [_P, C.POINTER(ConvDesc), _I, _L, _I, _L, _I, _L, _L, _I, _L, _I, _L,
                                    _I, _L, _L, _L]),
     "gv_plan_set_conv_tile": (C.c_int, [_P, _I, _I]),
+    "gv_plan_set_conv_xpre": (C.c_int, [_P, _I, _L, _L]),
     "gv_plan_set_schedule": (C.c_int, [_P, _I, _I, C.POINTER(_I), _I]),
     "gv_plan_add_pool": (C.c_int, [_P, C.POINTER(PoolDesc), _I, _L, _I, _L]),
     "gv_plan_add_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _L, _I, _L, _L, _I, _L]),

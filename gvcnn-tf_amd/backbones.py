@@ -78,6 +78,15 @@ class TRef:
                                                         self.c, self.ld, " p3" if self.p3 else "")
 
 
+class DeferredPreact:
+    """relu(bn(t)) that no kernel has written: the scale / shift offsets of the folded BatchNorm travel with the tensor
+    and the consuming convolution's loader applies them (BackbonePlan.conv, gv_conv2d_fwd_xpre)."""
+    __slots__ = ("t", "scale_off", "shift_off")
+
+    def __init__(self, t, scale_off, shift_off):
+        self.t, self.scale_off, self.shift_off = t, scale_off, shift_off
+
+
 class BackbonePlan:
     """Collects ops symbolically, then lowers them to a native gv_plan."""
 
@@ -107,6 +116,10 @@ class BackbonePlan:
         # stays fp32
         self.use_p3 = dtype == _lib.GV_F32 and math_mode == _lib.GV_MATH_BF16X3
         self.p3_blocks = None             # None: every block; else the set of block / stem-layer names that use it
+        # 16-bit storage: the pre-activation of a ResNet-v2 identity unit is applied by the loader of the unit's conv1
+        # (gv_conv2d_fwd_xpre) instead of being stored by the unit before it: that conv3 is HBM-bound and writes 9 instead
+        # of 13 channel-quanta per pixel.  Off: the second-output form everywhere (A/B switch; fp32 storage always)
+        self.defer_preact = dtype != _lib.GV_F32
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -217,10 +230,14 @@ class BackbonePlan:
         return outs
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
-             residual=None, next_preact=None, p3=False):
+             residual=None, next_preact=None, p3=False, defer=False):
         """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
         norm = None -> biases, no BN (normalizer_fn=None).  next_preact = (bn_scope, eps) adds the
-        second output relu(bn(out)) and returns (out, preact)."""
+        second output relu(bn(out)) and returns (out, preact); with defer=True no second output is written and
+        `preact` is a DeferredPreact(out, scale/shift offsets) that a 1x1 unpadded conv accepts as its input."""
+        xpre = None
+        if isinstance(x, DeferredPreact):
+            x, xpre = x.t, (x.scale_off, x.shift_off)
         kh, kw = (k, k) if isinstance(k, int) else k
         oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
         ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
@@ -236,18 +253,23 @@ class BackbonePlan:
         y2 = None
         s2 = h2 = 0
         if next_preact is not None:
-            y2 = self.new_tensor(x.nb, oh, ow, cout)
             s2, h2 = self._scale_shift("bn", next_preact[0], cout, next_preact[1], True)
+            if not defer:
+                y2 = self.new_tensor(x.nb, oh, ow, cout)
+        if xpre is not None:
+            assert kh == kw == 1 and pad_t == 0 and pad_l == 0 and self.dtype != _lib.GV_F32, scope
         if residual is not None:
             assert (residual.nb, residual.h, residual.w, residual.c) == (x.nb, oh, ow, cout)
         self._record(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
-                             split=0, cout=cout,
+                             split=0, cout=cout, xpre=xpre,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
                              bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout *
                                                       (1 + (residual is not None) + (y2 is not None)))))
-        return (out, y2) if next_preact is not None else out
+        if next_preact is not None:
+            return (out, DeferredPreact(out, s2, h2) if defer else y2)
+        return out
 
     def pool(self, x, k, stride, padding, mode, out=None, name="pool", p3=False):
         oh, pad_t = _out_size(x.h, k, stride, padding)
@@ -376,6 +398,9 @@ class BackbonePlan:
                                                 SLOT_SS, op["scale_off"], op["shift_off"], rs, ro,
                                                 ys, yo, y2s, y2o, op["scale2_off"], op["shift2_off"]),
                            "gv_plan_add_conv(%s)" % op["name"])
+                if op.get("xpre") is not None:
+                    _lib.check(lib.gv_plan_set_conv_xpre(plan, lib.gv_plan_num_ops(plan) - 1, *op["xpre"]),
+                               "gv_plan_set_conv_xpre(%s)" % op["name"])
             elif op["kind"] == "pool":
                 d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"],
                                   op["pad_t"], op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dtype)
@@ -788,11 +813,17 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         pad = "SAME" if stride == 1 else ((1, 1), (1, 1))                          # resnet_utils.py:94-105
         r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
         nxt = None
+        kw = {}
         if i + 1 < len(units):
-            nb_, _, nu, _, _ = units[i + 1]
+            nb_, nbase, nu, _, _ = units[i + 1]
             nxt = ("%s/%s/unit_%d/bottleneck_v2/preact" % (scope, nb_, nu + 1), RESNET_BN_EPS)
+            # the next unit keeps this depth (identity shortcut): its conv1 is the pre-activation's only reader.  Not in
+            # block4 (2048 channels over 7x7 maps): its conv3 is no longer HBM-bound and the conv1 loses more on the
+            # register-staged loader than the conv3 gains (measured: gpurun_out/r2/lt_res_xpre.txt vs lt_res_stored.txt)
+            if getattr(b, "defer_preact", False) and nbase * 4 == depth and depth <= 1024:
+                kw["defer"] = True
         res = b.conv(r, sc + "/conv3", depth, 1, 1, "SAME", norm=None, relu=False,
-                     residual=shortcut, next_preact=nxt)                           # :87-91
+                     residual=shortcut, next_preact=nxt, **kw)                     # :87-91
         net, preact = res if nxt is not None else (res, None)
         b.end_points[sc] = net
         if u == n_units - 1:
@@ -825,7 +856,7 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True):
+              math="f32", lanes=True, p3=True, defer_preact=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere."""
@@ -833,6 +864,7 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     b.use_lanes = bool(lanes)
     b.use_p3 = b.use_p3 and bool(p3)
+    b.defer_preact = b.defer_preact and bool(defer_preact)      # (A/B switch: False = every pre-activation stored)
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:

@@ -27,6 +27,8 @@ struct ConvArgs {
     const void* zeros;          // conv_dma.hip: a zero page for the padding taps of the gather
     int y_p3, y2_p3;            // destination format: 0 = fp32, 1 = three bf16 planes (conv_x3_epi.h)
     int korder;                 // conv_dma.hip: 0 = k-tiles tap-major, 1 = channel-chunk-major (filter taps innermost)
+    const float* xscale;        // conv_lp.hip (gv_conv2d_fwd_xpre): the input is read as relu(x*xscale[c] + xshift[c]);
+    const float* xshift;        // nullptr = the input as stored
 };
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:
@@ -95,6 +97,8 @@ int64_t bf16s_packed_bytes(int kh, int kw, int cin, int cout, int planes);
 // conv_lp.hip (16-bit storage)
 int lp_num_cfgs();
 int lp_pick_tile(int M, int N, int K);
+bool lp_xpre_cfg_ok(int cfg);   // register-staged tiles instantiated with the pre-activation-on-load loader
+int lp_xpre_pick(int M, int N);
 bool lp_halo_ok(const ConvArgs& a, bool generic);
 bool lp_stem_ok(const ConvArgs& a, bool xf32);
 int lp_launch(int dtype, int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st);

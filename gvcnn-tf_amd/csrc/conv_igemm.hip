@@ -424,10 +424,28 @@ extern "C" int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_
     return gvconv::lp_pack_filters_batched(jobs_dev, block_job_dev, num_blocks, dtype, (hipStream_t)stream);
 }
 
+static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
+                           const void* w_packed, const float* scale, const float* shift, const void* residual,
+                           void* y, void* y2, const float* scale2, const float* shift2, void* stream);
+
 extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
                              const float* scale, const float* shift, const void* residual,
                              void* y, void* y2, const float* scale2, const float* shift2,
                              void* stream) {
+    return conv2d_fwd_impl(d, x, nullptr, nullptr, w_packed, scale, shift, residual, y, y2, scale2, shift2, stream);
+}
+
+extern "C" int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
+                                  const void* w_packed, const float* scale, const float* shift,
+                                  const void* residual, void* y, void* y2, const float* scale2,
+                                  const float* shift2, void* stream) {
+    if (!xscale || !xshift) return GV_E_BADARG;
+    return conv2d_fwd_impl(d, x, xscale, xshift, w_packed, scale, shift, residual, y, y2, scale2, shift2, stream);
+}
+
+static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
+                           const void* w_packed, const float* scale, const float* shift, const void* residual,
+                           void* y, void* y2, const float* scale2, const float* shift2, void* stream) {
     if (!d || !x || !w_packed || !scale || !shift || !y) return GV_E_BADARG;
     if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 ||
         d->kw <= 0 || d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
@@ -478,6 +496,7 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
     a.x = (const float*)x; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.res = (const float*)residual; a.y = (float*)y; a.y2 = (float*)y2;
     a.scale2 = scale2; a.shift2 = shift2;
+    a.xscale = xscale; a.xshift = xshift;
     a.nb = d->nb; a.ih = d->ih; a.iw = d->iw; a.cin = d->cin; a.x_ld = d->x_ld;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.oh = d->oh; a.ow = d->ow; a.cout = d->cout; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
@@ -506,6 +525,16 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
         if (a.dil_shift && generic) return GV_E_UNSUPPORTED;
         // the vector loader keeps 32-bit element offsets
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
+        if (xscale) {
+            // pre-activation on load: the register-staged loader of the 1x1 / unpadded class (a padding tap would have
+            // to read relu(xshift), not 0), (scale, shift) table of the input channels in LDS
+            const int want = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override : d->tile_cfg - 1;
+            if (generic || d->kh != 1 || d->kw != 1 || d->pad_t != 0 || d->pad_l != 0 || a.dil_shift ||
+                d->cin > 2048 || (want >= 0 && !gvconv::lp_xpre_cfg_ok(want)))
+                return GV_E_UNSUPPORTED;
+            const int cfg = want >= 0 ? want : gvconv::lp_xpre_pick(a.M, a.cout);
+            return gvconv::lp_launch(d->dtype, cfg, a, false, false, (hipStream_t)stream);
+        }
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1
                            : ((gvconv::lp_halo_ok(a, generic) || gvconv::lp_stem_ok(a, xf32)) && a.M >= 100000
@@ -513,6 +542,7 @@ extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w
                                                                               : gvconv::lp_pick_tile(a.M, a.cout, a.K)));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);
     }
+    if (xscale) return GV_E_UNSUPPORTED;                 // pre-activation on load: 16-bit storage only
     if (xp3) {                                           // three-plane input: the LDS-DMA kernel
         if (!gvconv::dma_x3_ok(a) || !gv_aligned16(x) || (y2 && !split)) return GV_E_UNSUPPORTED;
         if (split && (d->split_col % 8 != 0 || d->cout % 8 != 0 || (!yp3 && (d->y_ld % 4 != 0 || !gv_aligned16(y))) ||

@@ -31,11 +31,15 @@ constexpr int RB = 2 * KT + 16;             // LDS row bytes
 template <int WM, int WN, int TM, int TN>
 constexpr bool lp_fdb() { return !(WM * WN == 4 && TM * TN == 4); }
 
-template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
+// XPRE: the input is read as relu(x * xscale[c] + xshift[c]) (fp32 arithmetic on the staged registers, rounded once
+// more to T): the pre-activation of a ResNet-v2 unit (nets/resnet_v2.py:75) applied by its CONSUMER, so that the unit
+// before it stores the sum once instead of the sum and its pre-activation.  1x1 / unpadded launches only.
+template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2) : 1)) void conv_igemm_lp(const ConvArgs a) {
     constexpr bool FDB = lp_fdb<WM, WN, TM, TN>();
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     static_assert(GENERIC || !XF32, "fp32 input only on the gather path");
+    static_assert(!XPRE || !GENERIC, "pre-activation on load: vector loader only");
     constexpr int NT = WM * WN * 64;                 // threads
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -111,6 +115,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
             a_base[i] = a_iy0[i] > -(1 << 27) ? ((a_img[i] + a_iy0[i]) * a.iw + a_ix0[i]) * a.x_ld : 0;
         __syncthreads();
     }
+    // XPRE: (scale, shift) of every input channel, read back 8 channels (this thread's chunk) at a time
+    float2* xss = reinterpret_cast<float2*>(smem_raw + (2 * BM + 2 * BN) * RB);
+    if constexpr (XPRE) {
+        for (int c = tid; c < a.cin; c += NT) xss[c] = make_float2(a.xscale[c], a.xshift[c]);
+        __syncthreads();
+    }
+    int xc[2] = {0, 0};                               // first channel of the chunk staged in register set 0 / 1
     const char* b_ptr[B_SLOTS];
     bool b_ok[B_SLOTS];
 #pragma unroll
@@ -152,6 +163,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
 
     auto load_tile = [&](auto rsc, int kt) {
         constexpr int RS = decltype(rsc)::value;
+        if constexpr (XPRE) xc[RS] = min(fc, a.cin - 8);       // (a chunk past the last channel is zeroed by its mask)
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -201,11 +213,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
     };
     auto store_tile = [&](auto rsc, int buf) {
         constexpr int RS = decltype(rsc)::value;
+        f32x4 xp[4];                                      // XPRE: (scale, shift) x 8 channels, the same for every slot
+        if constexpr (XPRE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xp[j] = reinterpret_cast<const f32x4*>(xss + xc[RS])[j];
+        }
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int idx = tid + i * NT;
             if (A_SLOTS * NT == BM * 4 || idx < BM * 4) {
                 u32x4 v = ra[RS][i];
+                if constexpr (XPRE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 p = xp[j];                    // scale, shift of channels 2j and 2j + 1
+                        const float lo = fmaxf(from_bits<T>((unsigned short)(v[j] & 0xffffu)) * p[0] + p[1], 0.f);
+                        const float hi = fmaxf(from_bits<T>((unsigned short)(v[j] >> 16)) * p[2] + p[3], 0.f);
+                        v[j] = (unsigned)to_bits<T>(lo) | ((unsigned)to_bits<T>(hi) << 16);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = ra_ok[RS][i] ? v[j] : 0u;
                 *reinterpret_cast<u32x4*>(sA + buf * BM * RB + slot_row(idx) * RB + 16 * q) = v;
@@ -656,16 +682,23 @@ constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 1
                               {256, 192}};                          // 8 waves: least operand traffic per flop (Conv2d_4a)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32>
+template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false>
 int launch_one(const ConvArgs& a, int64_t nwg, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32>),
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!ok) return GV_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;
+}
+
+// the tiles the pre-activation-on-load loader is instantiated for: 128 / 256 rows x 64 / 128 / 256 columns (the conv1 of a
+// ResNet unit has 64 ... 512 output channels)
+constexpr bool xpre_cfg(int wm, int wn, int tm, int tn) {
+    return (wm == 2 && wn == 2 && tm == 2 && (tn == 2 || tn == 1)) || (wm == 4 && wn == 2 && tm == 2 && (tn == 2 || tn == 1)) ||
+           (wm == 2 && wn == 4 && tm == 2 && tn == 2);
 }
 
 template <typename T, int WM, int WN, int TM, int TN>
@@ -676,9 +709,14 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     const int tiles_m = gv_ceil_div(a.M, BM);
     const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB + ((generic || xf32) ? (size_t)a.Kpad * 8 : 0);
+    const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB + ((generic || xf32) ? (size_t)a.Kpad * 8 : 0) +
+                            (a.xscale ? (size_t)a.cin * 8 : 0);
     const size_t lds_epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    if (a.xscale) {
+        if constexpr (xpre_cfg(WM, WN, TM, TN)) return launch_one<T, WM, WN, TM, TN, false, false, true>(a, nwg, lds, st);
+        else return GV_E_UNSUPPORTED;
+    }
     if (xf32) return launch_one<T, WM, WN, TM, TN, true, true>(a, nwg, lds, st);
     if (generic) return launch_one<T, WM, WN, TM, TN, true, false>(a, nwg, lds, st);
     return launch_one<T, WM, WN, TM, TN, false, false>(a, nwg, lds, st);
@@ -761,6 +799,9 @@ bool lp_halo_ok(const ConvArgs& a, bool generic) {
            a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.oh == a.ih + 2 * a.pad_t - 2 &&
            a.ow == a.iw + 2 * a.pad_l - 2;
 }
+
+bool lp_xpre_cfg_ok(int cfg) { return cfg == 0 || cfg == 1 || cfg == 6 || cfg == 7 || cfg == 8; }
+int lp_xpre_pick(int /*M*/, int N) { return N <= 64 ? 1 : 0; }
 
 int lp_pick_tile(int M, int N, int /*K*/) {
     int best = 0;

@@ -28,6 +28,7 @@ struct Op {
     int64_t npix;
     int32_t c, x_ld, y_ld, relu, dtype;
     Ref x, w, scale, shift, res, y, y2, scale2, shift2;
+    Ref xscale{-1, 0}, xshift{-1, 0};      // gv_plan_set_conv_xpre: pre-activation applied by this conv's loader
     // schedule: launch lane (0 = the caller's stream) and the earlier ops on OTHER lanes this op
     // must wait for (data or buffer-reuse hazards); same-lane order is stream order.
     int32_t lane = 0;
@@ -75,6 +76,12 @@ int run_op(const Op& o, void* const* bufs, void* stream) {
             const size_t xes = (o.conv.flags & GV_CONV_X_F32) ? 4 : ((o.conv.flags & GV_CONV_X_P3) ? 6 : es);
             const size_t yes = (o.conv.flags & GV_CONV_Y_P3) ? 6 : es;
             const size_t y2es = (o.conv.flags & GV_CONV_Y2_P3) ? 6 : es;
+            if (o.xscale.slot >= 0)
+                return gv_conv2d_fwd_xpre(&o.conv, at(bufs, o.x, xes), (const float*)at(bufs, o.xscale, 4),
+                                          (const float*)at(bufs, o.xshift, 4), at(bufs, o.w, es),
+                                          (const float*)at(bufs, o.scale, 4), (const float*)at(bufs, o.shift, 4),
+                                          at(bufs, o.res, es), at(bufs, o.y, yes), at(bufs, o.y2, y2es),
+                                          (const float*)at(bufs, o.scale2, 4), (const float*)at(bufs, o.shift2, 4), stream);
             return gv_conv2d_fwd(&o.conv, at(bufs, o.x, xes), at(bufs, o.w, es),
                                  (const float*)at(bufs, o.scale, 4), (const float*)at(bufs, o.shift, 4),
                                  at(bufs, o.res, es), at(bufs, o.y, yes), at(bufs, o.y2, y2es),
@@ -154,6 +161,16 @@ extern "C" int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_
     Op& o = p->ops[(size_t)op_index];
     if (o.kind != OP_CONV) return GV_E_BADARG;
     o.conv.tile_cfg = tile_cfg;
+    return GV_OK;
+}
+
+extern "C" int gv_plan_set_conv_xpre(gv_plan* p, int32_t op_index, int64_t xscale_off, int64_t xshift_off) {
+    if (!p) return GV_E_PLAN;
+    if (op_index < 0 || (size_t)op_index >= p->ops.size() || xscale_off < 0 || xshift_off < 0) return GV_E_BADARG;
+    Op& o = p->ops[(size_t)op_index];
+    if (o.kind != OP_CONV) return GV_E_BADARG;
+    o.xscale = {o.scale.slot, xscale_off};            // the table that holds this op's own scale / shift
+    o.xshift = {o.scale.slot, xshift_off};
     return GV_OK;
 }
 

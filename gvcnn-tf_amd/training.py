@@ -35,6 +35,7 @@ class TrainPlan(backbones.BackbonePlan):
         super().__init__(nb, height, width, dtype, math_mode)
         self.use_lanes = False
         self.use_p3 = False
+        self.defer_preact = False          # BatchNorm is its own op here (batch statistics)
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
              residual=None, next_preact=None):

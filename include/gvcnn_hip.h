@@ -176,6 +176,15 @@ int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_jobs, const
 int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
                   const float* scale, const float* shift, const void* residual,
                   void* y, void* y2, const float* scale2, const float* shift2, void* stream);
+/* The same convolution over x' = relu(x * xscale[ci] + xshift[ci]) (xscale/xshift: fp32 [cin], BN fold as above),
+ * x' computed by the kernel's loader in fp32 and rounded once to the storage type: the `preact` slim.batch_norm of a
+ * ResNet-v2 unit (nets/resnet_v2.py:75) applied by the convolution that consumes it (conv1, nets/resnet_v2.py:83), so
+ * that the unit before it writes `shortcut + residual` (nets/resnet_v2.py:91) once and no pre-activation tensor exists.
+ * 16-bit storage (GV_BF16 / GV_F16), 1x1 window, no padding, cin a multiple of 8 and <= 2048, 16-byte aligned pixels;
+ * tile_cfg 0 or one of the register-staged tiles {1, 2, 7, 8, 9}; anything else: GV_E_UNSUPPORTED. */
+int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
+                       const void* w_packed, const float* scale, const float* shift, const void* residual,
+                       void* y, void* y2, const float* scale2, const float* shift2, void* stream);
 
 /* ---- pooling -------------------------------------------------------------
  * slim.max_pool2d / slim.avg_pool2d: nets/inception_v3.py:112,127,152,219,355,...;
@@ -446,6 +455,8 @@ int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d,
                      int32_t y2_slot, int64_t y2_off, int64_t scale2_off, int64_t shift2_off);
 /* Set gv_conv_desc.tile_cfg of conv op `op_index` (plan-time autotuning; speed only). */
 int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg);
+/* Conv op `op_index` runs as gv_conv2d_fwd_xpre: xscale / xshift at these fp32 offsets of the op's scale/shift slot. */
+int gv_plan_set_conv_xpre(gv_plan* p, int32_t op_index, int64_t xscale_off, int64_t xshift_off);
 /* Branch-level concurrency: put op `op_index` on launch lane `lane` (0 = the caller's stream, 1..7 =
  * plan-owned streams) and name the EARLIER ops it must wait for (producers of its inputs, and ops
  * still using a buffer it overwrites).  A whole-plan run then forks the lanes off `stream` and joins

@@ -70,6 +70,9 @@ def test_bad_arguments_return_codes(lib):
     d.dtype = _lib.GV_F32
     d.y_ld = 8                                   # pixel stride smaller than cout
     assert lib.gv_conv2d_fwd(C.byref(d), 16, 16, 16, 16, None, 16, None, None, None, None) == -1
+    d.y_ld = 16                                  # pre-activation on load without its scale / shift; on a null plan
+    assert lib.gv_conv2d_fwd_xpre(C.byref(d), 16, None, None, 16, 16, 16, None, 16, None, None, None, None) == -1
+    assert lib.gv_plan_set_conv_xpre(None, 0, 0, 0) == -4
     p = _lib.PoolDesc(1, 8, 8, 4, 4, 3, 3, 2, 0, 0, 3, 3, 4, 5, _lib.GV_F32)   # bad mode
     assert lib.gv_pool2d_fwd(C.byref(p), 16, 16, None) == -1
     assert lib.gv_group_assign(None, 6, 10, 10, None, None, None, None, None) == -1

@@ -66,7 +66,7 @@ def pack(w, code):
 
 
 def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, second=None, split=0,
-             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0):
+             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0, xpre=None, tile_cfg=0, expect=None):
     code, td, _ = TYPES[ty]
     nb, ih, iw, cin = x.shape
     kh, kw, _, cout = w.shape
@@ -89,7 +89,20 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0) | \
             (_lib.GV_CONV_SPLIT if split else 0) | (_lib.GV_CONV_X_F32 if x_f32 else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
-                      cout if residual is not None else 0, n2 if y2d is not None else 0, flags, code, split, 0, 0, 0)
+                      cout if residual is not None else 0, n2 if y2d is not None else 0, flags, code, split, tile_cfg, 0, 0)
+    if xpre is not None:                    # the input is read as relu(x * xscale + xshift) (gv_conv2d_fwd_xpre)
+        xs, xh = xpre[0].to(DEV), xpre[1].to(DEV)
+        rc = lib().gv_conv2d_fwd_xpre(C.byref(d), xd.data_ptr() + xes * x_off, xs.data_ptr(), xh.data_ptr(), wp.data_ptr(),
+                                      sc.data_ptr(), sh.data_ptr(), rd.data_ptr() if rd is not None else None,
+                                      yd.data_ptr() + 2 * y_off, y2d.data_ptr() if y2d is not None else None,
+                                      sc2.data_ptr() if second else None, sh2.data_ptr() if second else None, st())
+        if expect is not None:
+            assert rc == expect, rc
+            return None
+        _lib.check(rc, "gv_conv2d_fwd_xpre")
+        torch.cuda.synchronize()
+        y = yd.float().cpu().numpy()[..., y_off:y_off + n1]
+        return (y, y2d.float().cpu().numpy()) if y2d is not None else y
     if tile is not None:
         lib().gv_conv2d_set_tile_override(tile)
     try:
@@ -290,6 +303,53 @@ def test_lp_conv_residual_dual_and_slices(ty):
     y = run_conv(x, w[:, :, :, :96], 1, (0, 0), (7, 9), torch.ones(96), bias[:96], True, ty, x_ld=70, x_off=3,
                  y_ld=101, y_off=5)
     close(y, oracle_conv(x, w[:, :, :, :96], 1, "SAME", torch.ones(96), bias[:96], True).numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("tile_cfg", [0, 1, 2, 7, 8, 9])
+@pytest.mark.parametrize("cin,cout,stride,hw", [(256, 64, 1, (13, 21)), (1024, 256, 1, (7, 7)), (72, 40, 2, (15, 9)),
+                                                (8, 200, 1, (5, 31))])
+def test_lp_conv_preactivation_on_load(ty, tile_cfg, cin, cout, stride, hw):
+    """gv_conv2d_fwd_xpre: conv1 of a ResNet-v2 unit (resnet_v2.py:83) over relu(bn(x)) (resnet_v2.py:75) with the
+    pre-activation applied by the loader.  Reference: the oracle's conv over the pre-activation computed in fp32 and
+    rounded to the storage type (what the unit before it used to store); and the kernel's own stored-input form on that
+    tensor, which it must match except where one fp32 fused-multiply-add rounds the other way (counted)."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(cin + cout + stride)
+    x = rnd(torch.randn(3, hw[0], hw[1], cin, generator=g), td)
+    w = rnd(torch.randn(1, 1, cin, cout, generator=g) * (cin ** -0.5), td)
+    xs, xh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    pre = rnd(torch.relu((x.double() * xs.double() + xh.double()).float()), td)
+    oh, ow = (hw[0] - 1) // stride + 1, (hw[1] - 1) // stride + 1
+    y = run_conv(x, w, stride, (0, 0), (oh, ow), scale, shift, True, ty, xpre=(xs, xh), tile_cfg=tile_cfg)
+    close(y, oracle_conv(pre, w, stride, "VALID", scale, shift, True).numpy(), ulp, extra=1e-3)
+    stored = run_conv(pre, w, stride, (0, 0), (oh, ow), scale, shift, True, ty, tile=max(tile_cfg - 1, 0))
+    assert (y != stored).mean() < 2e-3, (y != stored).mean()
+    # with the residual and in / out channel slices (the shortcut conv of a unit would read the same tensor)
+    if tile_cfg == 0:
+        res = rnd(torch.randn(3, oh, ow, cout, generator=g), td)
+        y = run_conv(x, w, stride, (0, 0), (oh, ow), scale, shift, False, ty, residual=res, xpre=(xs, xh), x_ld=cin + 8,
+                     x_off=8, y_ld=cout + 16, y_off=8)
+        close(y, oracle_conv(pre, w, stride, "VALID", scale, shift, False, residual=res).numpy(), ulp, extra=1e-3)
+
+
+def test_lp_conv_preactivation_on_load_rejects_what_it_cannot_do():
+    g = torch.Generator().manual_seed(1)
+    x, one = torch.randn(1, 6, 6, 64, generator=g), torch.ones(64)
+    w3, w1 = torch.randn(3, 3, 64, 64, generator=g), torch.randn(1, 1, 64, 64, generator=g)
+    bad = dict(xpre=(one, one), expect=-2)
+    assert run_conv(x, w3, 1, (1, 1), (6, 6), one, one, True, "bf16", **bad) is None          # 3x3 window
+    assert run_conv(x, w1, 1, (1, 1), (7, 7), one, one, True, "bf16", **bad) is None          # padded 1x1
+    assert run_conv(x, w1, 1, (0, 0), (6, 6), one, one, True, "bf16", tile_cfg=4, **bad) is None   # no such instantiation
+    assert run_conv(x, w1, 1, (0, 0), (6, 6), one, one, True, "bf16", tile_cfg=14, **bad) is None  # an LDS-DMA tile
+    assert run_conv(x, w1, 1, (0, 0), (6, 6), one, one, True, "bf16", x_ld=70, x_off=3, **bad) is None   # gather path
+    d = _lib.ConvDesc(1, 6, 6, 64, 64, 1, 1, 1, 0, 0, 6, 6, 64, 64, 0, 0, 0, _lib.GV_BF16, 0, 0, 0, 0)
+    assert lib().gv_conv2d_fwd_xpre(C.byref(d), 16, None, None, 16, 16, 16, None, 16, None, None, None, st()) == -1
+    d32 = _lib.ConvDesc(1, 6, 6, 64, 64, 1, 1, 1, 0, 0, 6, 6, 64, 64, 0, 0, 0, _lib.GV_F32, 0, 0, 0, 0)
+    buf = torch.zeros(1 << 16, device=DEV)
+    p = buf.data_ptr()
+    assert lib().gv_conv2d_fwd_xpre(C.byref(d32), p, p, p, p, p, p, None, p, None, None, None, st()) == -2
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])

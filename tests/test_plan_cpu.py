@@ -174,3 +174,21 @@ def test_lane_schedule_orders_every_hazard():
     # single-lane plans carry no schedule
     q = backbones.make_plan("inception_v3", 1, 75, 75, torch.device("cpu"), lanes=False)
     assert all(not op.get("deps") for op in q.ops)
+
+
+def test_resnet_16bit_plan_defers_the_preactivation_of_identity_units():
+    """16-bit storage: conv3 of a unit followed by an identity unit writes the sum only, and that unit's conv1 carries
+    the folded pre-activation BatchNorm for its loader (the 10 identity boundaries of block1-block3; the block boundaries,
+    where the projection shortcut reads the pre-activation too, and block4 keep the stored second output).  fp32 storage: the stored form everywhere."""
+    p = backbones.make_plan("resnet_v2_50", 2, 64, 64, torch.device("cpu"), dtype="bf16")
+    convs = [op for op in p.ops if op["kind"] == "conv"]
+    pre = [op for op in convs if op.get("xpre") is not None]
+    assert len(pre) == 10 and all(op["name"].endswith("/conv1") and op["kh"] == 1 and op["pad_t"] == 0 for op in pre)
+    assert sum(1 for op in convs if op["y2"] is not None) == 5
+    for op in pre:                                   # the input of such a conv1 is the previous unit's sum itself
+        prev = convs[convs.index(op) - 1]
+        assert prev["name"].endswith("/conv3") and prev["y"] is op["x"] and prev["y2"] is None
+        assert op["xpre"] == (prev["scale2_off"], prev["shift2_off"])
+    q = backbones.make_plan("resnet_v2_50", 2, 64, 64, torch.device("cpu"))
+    assert all(op.get("xpre") is None for op in q.ops) and sum(1 for op in q.ops if op.get("y2") is not None) == 15
+    assert p.param_shapes() == q.param_shapes()

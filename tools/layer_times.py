@@ -25,6 +25,7 @@ ap.add_argument("--json", default=None)
 ap.add_argument("--ablate", action="store_true", help="time ablated kernels (no loads / no LDS writes / no stores)")
 ap.add_argument("--autotune", action="store_true")
 ap.add_argument("--ablate-bits", type=int, default=4)
+ap.add_argument("--stored-preact", action="store_true", help="16-bit ResNet: every pre-activation stored by the unit before (A/B)")
 ap.add_argument("--p3", default="default", help="three-plane intermediates: default | all | none | comma separated block names")
 ap.add_argument("--no-fuse", action="store_true")
 ap.add_argument("--math", default="f32")
@@ -34,7 +35,8 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 nb = a.shapes * a.views
 p3 = {"default": True, "all": "all", "none": False}.get(a.p3, tuple(a.p3.split(",")))
-plan = backbones.make_plan(a.backbone, nb, a.size, a.size, dev, math=a.math, dtype=a.storage, p3=p3)
+plan = backbones.make_plan(a.backbone, nb, a.size, a.size, dev, math=a.math, dtype=a.storage, p3=p3,
+                           defer_preact=not a.stored_preact)
 P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
 plan.bind(P)
 x = (torch.rand(nb, a.size, a.size, 3) - 0.5).to(dev)
