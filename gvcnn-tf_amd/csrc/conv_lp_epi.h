@@ -86,6 +86,26 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
     const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
                      (y2 == nullptr || ((a.y2_ld % 8 == 0) && ((((uintptr_t)y2) & 15) == 0))) &&
                      (a.split % 8 == 0) && (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0)));
+    // The residual chunks of a block's read-back passes are requested ONE BLOCK AHEAD (those of the first block before it
+    // is staged): issued one per pass next to their use, every pass of an HBM-bound ResNet conv3 (K = 64 ... 256, 4x the
+    // output channels) waits out one full memory round trip (the y stores in between may alias, so the compiler cannot
+    // hoist the loads itself).  conv3 of block1: 0.365 -> 0.305 ms with the block's own chunks up front.
+    constexpr int NPASS = 32 / RPP;
+    u32x4 rvp[2][NPASS];
+    auto res_fetch = [&](int b, u32x4 (&dst)[NPASS]) {
+        const int jb = b / TM, i = b % TM;
+        const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;
+        if (res != nullptr && vec && a.cout - col >= 8) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int row = pass * RPP + rrow;
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                dst[pass] = (m < a.M && row < rows_valid) ? *reinterpret_cast<const u32x4*>(res + (size_t)m * a.res_ld + col)
+                                                          : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    res_fetch(0, rvp[0]);
 #pragma unroll
     for (int jb = 0; jb < TN / JB; ++jb) {
         const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;     // this lane's 8 columns
@@ -103,14 +123,16 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
         const bool to_second = a.split > 0 && col >= a.split;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int b = jb * TM + i;
 #pragma unroll
             for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     stage[(row_h + (r & 3) + 8 * (r >> 2)) * CW + jj * 32 + col_l] = acc[i][jb * JB + jj][r];
             __builtin_amdgcn_wave_barrier();
+            if (b + 1 < TM * (TN / JB)) res_fetch(b + 1, rvp[(b + 1) & 1]);
 #pragma unroll
-            for (int pass = 0; pass < 32 / RPP; ++pass) {
+            for (int pass = 0; pass < NPASS; ++pass) {
                 const int row = pass * RPP + rrow;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8 + 4);
@@ -122,7 +144,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 if (res) {
                     const unsigned short* rp = res + (size_t)m * a.res_ld + col;
                     if (vec && nvalid == 8) {
-                        const u32x4 rv = *reinterpret_cast<const u32x4*>(rp);
+                        const u32x4 rv = rvp[b & 1][pass];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             v[2 * j] += from_bits<T>((unsigned short)(rv[j] & 0xffffu));
