@@ -31,6 +31,9 @@ int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, c
                               float eps, const void* x, int nb, int hw, int c, int x_ld, int G, int relu, void* y,
                               int y_ld, float* mean, float* var, float* inv, float* scale, float* shift, hipStream_t st);
 int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, void* dx, int dx_ld, hipStream_t st);
+int pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* y, unsigned char* arg, hipStream_t st);
+int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const void* dy, int dy_ld, void* dx, int dx_ld,
+                      hipStream_t st);
 int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,
                        const int* scheme, int G, const float* weight, int mode, void* dF, hipStream_t st,
                        int64_t scheme_stride, int64_t weight_stride);

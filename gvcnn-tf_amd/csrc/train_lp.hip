@@ -602,6 +602,185 @@ __global__ __launch_bounds__(256) void pool2d_bwd_lp(const E* __restrict__ x, in
     }
 }
 
+// ---- max pool with a recorded argmax ---------------------------------------------------------------------------------
+// Forward: y = max over the window AND, per output element, the row-major tap index of the FIRST maximum (one byte).
+// Backward: an input pixel receives dy of every window whose recorded tap is that pixel — no input re-read, no
+// nine-tap compare chain: 3x3 / stride 2 costs 2 loads per input pixel (a thread owns a 2x2 block and reads the four
+// windows that touch it once) against the 11 of the recomputing kernel above, and the HBM side drops the forward input
+// (MaxPool_3a at 32 x 12 views: 1.45 GB -> 0.8 GB).
+template <typename E, typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_argmax_fwd(const E* __restrict__ x, int x_ld, int nb, int ih, int iw, int c,
+                                                          int kh, int kw, int stride, int pad_t, int pad_l, int oh, int ow,
+                                                          E* __restrict__ y, int y_ld, unsigned char* __restrict__ arg) {
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * oh * ow * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t opix = idx / cg;
+        const int ox = (int)(opix % ow);
+        const int64_t t = opix / ow;
+        const int oy = (int)(t % oh);
+        const int n = (int)(t / oh);
+        float best[8];
+        int a[8];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; a[e] = -1; }
+        for (int r = 0; r < kh; ++r) {
+            const int yy = oy * stride - pad_t + r;
+            if ((unsigned)yy >= (unsigned)ih) continue;
+            for (int s_ = 0; s_ < kw; ++s_) {
+                const int xx = ox * stride - pad_l + s_;
+                if ((unsigned)xx >= (unsigned)iw) continue;
+                float v[8];
+                load_v<T, VEC>(x + ((int64_t)(n * ih + yy) * iw + xx) * x_ld + q * VEC, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (v[e] > best[e] || a[e] < 0) { best[e] = v[e]; a[e] = r * kw + s_; }
+            }
+        }
+        store_v<T, VEC>(y + opix * y_ld + q * VEC, best);
+        unsigned char* ap = arg + opix * c + q * VEC;
+        if constexpr (VEC == 8) {
+            uint2 w;
+            w.x = (unsigned)a[0] | ((unsigned)a[1] << 8) | ((unsigned)a[2] << 16) | ((unsigned)a[3] << 24);
+            w.y = (unsigned)a[4] | ((unsigned)a[5] << 8) | ((unsigned)a[6] << 16) | ((unsigned)a[7] << 24);
+            *reinterpret_cast<uint2*>(ap) = w;
+        } else if constexpr (VEC == 4) {
+            *reinterpret_cast<unsigned*>(ap) = (unsigned)a[0] | ((unsigned)a[1] << 8) | ((unsigned)a[2] << 16) | ((unsigned)a[3] << 24);
+        } else {
+            ap[0] = (unsigned char)a[0];
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_arg(const unsigned char* p, int (&a)[8]) {
+    if constexpr (VEC == 8) {
+        const uint2 w = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (w.x >> (8 * e)) & 0xff; a[4 + e] = (w.y >> (8 * e)) & 0xff; }
+    } else if constexpr (VEC == 4) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = (w >> (8 * e)) & 0xff;
+    } else {
+        a[0] = p[0];
+    }
+}
+
+// any window: one input pixel x VEC channels per thread, the windows that contain it
+template <typename E, typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_argmax_bwd(const unsigned char* __restrict__ arg, const E* __restrict__ dy,
+                                                          int dy_ld, int nb, int ih, int iw, int c, int kh, int kw,
+                                                          int stride, int pad_t, int pad_l, int oh, int ow, int store,
+                                                          E* __restrict__ dx, int dx_ld) {
+    const int cg = c / VEC;
+    const int64_t total = (int64_t)nb * ih * iw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        const int64_t pix = idx / cg;
+        const int ix = (int)(pix % iw);
+        const int64_t t = pix / iw;
+        const int iy = (int)(t % ih);
+        const int n = (int)(t / ih);
+        float sum[8];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum[e] = 0.f;
+        const int py = iy + pad_t, px = ix + pad_l;
+        const int oy_hi = min(oh - 1, py / stride), ox_hi = min(ow - 1, px / stride);
+        const int oy_lo = py - kh + 1 <= 0 ? 0 : (py - kh + stride) / stride;      // ceil((py - kh + 1) / stride)
+        const int ox_lo = px - kw + 1 <= 0 ? 0 : (px - kw + stride) / stride;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const int tap = (py - oy * stride) * kw + (px - ox * stride);
+                const int64_t opix = (int64_t)(n * oh + oy) * ow + ox;
+                int a[8];
+                float g[8];
+                load_arg<VEC>(arg + opix * c + q * VEC, a);
+                load_v<T, VEC>(dy + opix * dy_ld + q * VEC, g);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sum[e] += a[e] == tap ? g[e] : 0.f;
+            }
+        E* dp = dx + pix * dx_ld + q * VEC;
+        float d[8];
+        if (store) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+        } else {
+            load_v<T, VEC>(dp, d);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[e] += sum[e];
+        store_v<T, VEC>(dp, d);
+    }
+}
+
+// 3x3 / stride 2 / VALID: the 2x2 input block (2a..2a+1, 2b..2b+1) and the four windows (a-1..a, b-1..b) touching it
+template <typename E, typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool3s2_argmax_bwd(const unsigned char* __restrict__ arg, const E* __restrict__ dy,
+                                                             int dy_ld, int nb, int ih, int iw, int c, int oh, int ow,
+                                                             int store, E* __restrict__ dx, int dx_ld) {
+    const int cg = c / VEC, ah = (ih + 1) / 2, aw = (iw + 1) / 2;
+    const int64_t total = (int64_t)nb * ah * aw * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int b = (int)(t % aw);
+        t /= aw;
+        const int a = (int)(t % ah);
+        const int n = (int)(t / ah);
+        float sum[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum[k][e] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = a - 1 + wy, ox = b - 1 + wx;
+                if ((unsigned)oy >= (unsigned)oh || (unsigned)ox >= (unsigned)ow) continue;
+                const int64_t opix = (int64_t)(n * oh + oy) * ow + ox;
+                int am[8];
+                float g[8];
+                load_arg<VEC>(arg + opix * c + q * VEC, am);
+                load_v<T, VEC>(dy + opix * dy_ld + q * VEC, g);
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const int tr = py + 2 * (1 - wy), tc = px + 2 * (1 - wx);
+                        if (tr > 2 || tc > 2) continue;
+                        const int tap = tr * 3 + tc;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) sum[2 * py + px][e] += am[e] == tap ? g[e] : 0.f;
+                    }
+            }
+        }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int iy = 2 * a + py, ix = 2 * b + px;
+                if (iy >= ih || ix >= iw) continue;
+                E* dp = dx + ((int64_t)(n * ih + iy) * iw + ix) * dx_ld + q * VEC;
+                float d[8];
+                if (store) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+                } else {
+                    load_v<T, VEC>(dp, d);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) d[e] += sum[2 * py + px][e];
+                store_v<T, VEC>(dp, d);
+            }
+    }
+}
+
 // 3x3 / stride 2 / VALID max pool (every max pool of Inception-v3): a thread owns the 2x2 input pixels (2a..2a+1,
 // 2b..2b+1) x 8 channels and visits the four windows (a-1..a, b-1..b) that touch them ONCE each — argmax per window
 // from its nine taps, then the gradient goes to whichever of the thread's pixels is that tap: 11 loads per input pixel
@@ -1422,6 +1601,72 @@ int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, 
         GV_POOL_BWD(unsigned short, T, 1, xs, g, o);
     });
 #undef GV_POOL_BWD
+}
+
+// forward max pool + argmax bytes ([nb, oh, ow, c] dense), any storage type
+int pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* y, unsigned char* arg, hipStream_t st) {
+    const int64_t opix = (int64_t)d->nb * d->oh * d->ow;
+#define GV_AMAX_F(E, T, VEC, XS, YS)                                                                                        \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((maxpool_argmax_fwd<E, T, VEC>), dim3(grid_for(opix * (d->c / VEC))), dim3(256), 0, st, XS, d->x_ld, \
+                           d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, YS, d->y_ld, \
+                           arg);                                                                                            \
+        GV_LAUNCH_CHECK();                                                                                                  \
+        return GV_OK;                                                                                                       \
+    } while (0)
+    if (d->dtype == GV_F32) {
+        const float* xs = (const float*)x;
+        float* ys = (float*)y;
+        const bool v4 = (d->c % 4 == 0) && gv_aligned16(xs) && d->x_ld % 4 == 0 && gv_aligned16(ys) && d->y_ld % 4 == 0 &&
+                        (((uintptr_t)arg) & 3) == 0;
+        if (v4) GV_AMAX_F(float, float, 4, xs, ys);
+        GV_AMAX_F(float, float, 1, xs, ys);
+    }
+    const unsigned short* xs = (const unsigned short*)x;
+    unsigned short* ys = (unsigned short*)y;
+    const bool v = (d->c % 8 == 0) && vec8(xs, d->x_ld) && vec8(ys, d->y_ld) && (((uintptr_t)arg) & 7) == 0;
+    GV_LP_DISPATCH(d->dtype, {
+        if (v) GV_AMAX_F(unsigned short, T, 8, xs, ys);
+        GV_AMAX_F(unsigned short, T, 1, xs, ys);
+    });
+#undef GV_AMAX_F
+}
+
+int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const void* dy, int dy_ld, void* dx, int dx_ld,
+                      hipStream_t st) {
+    const int store = (d->mode & GV_POOL_BWD_STORE) ? 1 : 0;
+    const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
+    const bool m3s2 = d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 && d->pad_l == 0 &&
+                      d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
+    const int64_t nblk2 = (int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2);
+#define GV_AMAX_B(E, T, VEC, G_, O_)                                                                                        \
+    do {                                                                                                                    \
+        if (m3s2)                                                                                                           \
+            hipLaunchKernelGGL((maxpool3s2_argmax_bwd<E, T, VEC>), dim3(grid_for(nblk2 * (d->c / VEC))), dim3(256), 0, st, arg, \
+                               G_, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, store, O_, dx_ld);                       \
+        else                                                                                                                \
+            hipLaunchKernelGGL((maxpool_argmax_bwd<E, T, VEC>), dim3(grid_for(npix * (d->c / VEC))), dim3(256), 0, st, arg, G_, \
+                               dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, \
+                               store, O_, dx_ld);                                                                           \
+        GV_LAUNCH_CHECK();                                                                                                  \
+        return GV_OK;                                                                                                       \
+    } while (0)
+    if (d->dtype == GV_F32) {
+        const float* g = (const float*)dy;
+        float* o = (float*)dx;
+        const bool v4 = (d->c % 4 == 0) && gv_aligned16(g) && dy_ld % 4 == 0 && gv_aligned16(o) && dx_ld % 4 == 0 &&
+                        (((uintptr_t)arg) & 3) == 0;
+        if (v4) GV_AMAX_B(float, float, 4, g, o);
+        GV_AMAX_B(float, float, 1, g, o);
+    }
+    const unsigned short* g = (const unsigned short*)dy;
+    unsigned short* o = (unsigned short*)dx;
+    const bool v = (d->c % 8 == 0) && vec8(g, dy_ld) && vec8(o, dx_ld) && (((uintptr_t)arg) & 7) == 0;
+    GV_LP_DISPATCH(d->dtype, {
+        if (v) GV_AMAX_B(unsigned short, T, 8, g, o);
+        GV_AMAX_B(unsigned short, T, 1, g, o);
+    });
+#undef GV_AMAX_B
 }
 
 int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,

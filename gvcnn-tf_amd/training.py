@@ -165,6 +165,7 @@ class TrainGVCNN:
         # backward in store mode; ops that can only add get that one tensor zeroed first), later ones add; and the
         # ReLU mask of a BatchNorm backward is recomputed from z instead of read from y.
         self._lazy = True                                 # (False: the plain zero-fill + accumulate form, kept for tests)
+        self.pool_argmax = True                           # max pools record their argmax (False: backward re-reads x; A/B)
         self._zacc = self.es == 2                         # pre-zeroed per-layer fp64 accumulators (16-bit entry points)
         self._written = set()
         self._lane_streams = None
@@ -650,7 +651,15 @@ class TrainGVCNN:
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
-            _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
+            if op["mode"] == _lib.GV_POOL_MAX and self.pool_argmax:
+                # the winning tap of every window is recorded (one byte per output element): the backward pass routes dy
+                # by it and never re-reads x
+                if "argmax" not in op:
+                    op["argmax"] = torch.empty(y.nb * y.h * y.w * y.c, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.gv_pool2d_fwd_argmax(C.byref(d), self._ptr(x), self._ptr(y), op["argmax"].data_ptr(), _st()),
+                           "pool+argmax " + op["name"])
+            else:
+                _lib.check(lib.gv_pool2d_fwd(C.byref(d), self._ptr(x), self._ptr(y), _st()), "pool " + op["name"])
 
     def score_partial(self):
         """Scorer responses r_img [N*V] of this engine's views (model.py:144-145); no gradient flows through the
@@ -853,8 +862,12 @@ class TrainGVCNN:
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
             if self._claim(x):                                # first contribution: the gather kernels store
                 d.mode |= _lib.GV_POOL_BWD_STORE
-            _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
-                                         x.ld, _st()), "pool_bwd " + op["name"])
+            if "argmax" in op:
+                _lib.check(lib.gv_pool2d_bwd_argmax(C.byref(d), op["argmax"].data_ptr(), self._ptr(y, True), y.ld,
+                                                    self._ptr(x, True), x.ld, _st()), "pool_bwd (argmax) " + op["name"])
+            else:
+                _lib.check(lib.gv_pool2d_bwd(C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, self._ptr(x, True),
+                                             x.ld, _st()), "pool_bwd " + op["name"])
 
     def apply_momentum(self, lr, mu=0.9, weight_decay=0.0):
         """tf.train.MomentumOptimizer(lr, 0.9); the slim L2 term (wd * w) applies to conv weights only."""

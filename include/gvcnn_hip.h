@@ -371,6 +371,14 @@ int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int32_
  * avg -> dy / #valid taps.  x is the forward input (max only).  x, dy, dx in d->dtype. */
 int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t dy_ld, void* dx,
                   int32_t dx_ld, void* stream);
+/* Max pool for the training step (slim.max_pool2d, nets/inception_v3.py:112,127 / nets/resnet_v2.py:181, under a
+ * gradient tape): the forward also records, per output element, the row-major window tap of its FIRST maximum
+ * (argmax: uint8 [nb, oh, ow, c], dense), and the backward routes dy by that record — same result as gv_pool2d_bwd
+ * (tf MaxPoolGrad: first maximum) without re-reading the forward input.  d: the forward descriptor, mode GV_POOL_MAX
+ * (| GV_POOL_BWD_STORE in the backward: dx = instead of dx +=), kh*kw <= 255; x, y, dy, dx in d->dtype. */
+int gv_pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* y, uint8_t* argmax, void* stream);
+int gv_pool2d_bwd_argmax(const gv_pool_desc* d, const uint8_t* argmax, const void* dy, int32_t dy_ld, void* dx,
+                         int32_t dx_ld, void* stream);
 /* Backward of gv_view_pool_fuse_fwd: dF += ... (tf.reduce_max splits equally among ties). */
 int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
                           int64_t view_stride, int64_t shape_stride, const int32_t* scheme,

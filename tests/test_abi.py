@@ -73,6 +73,12 @@ def test_bad_arguments_return_codes(lib):
     d.y_ld = 16                                  # pre-activation on load without its scale / shift; on a null plan
     assert lib.gv_conv2d_fwd_xpre(C.byref(d), 16, None, None, 16, 16, 16, None, 16, None, None, None, None) == -1
     assert lib.gv_plan_set_conv_xpre(None, 0, 0, 0) == -4
+    pm = _lib.PoolDesc(1, 8, 8, 4, 4, 3, 3, 2, 0, 0, 3, 3, 4, _lib.GV_POOL_AVG, _lib.GV_F32)   # argmax pools: max only
+    assert lib.gv_pool2d_fwd_argmax(C.byref(pm), 16, 16, 16, None) == -1
+    assert lib.gv_pool2d_bwd_argmax(C.byref(pm), 16, 16, 4, 16, 4, None) == -1
+    pm.mode = _lib.GV_POOL_MAX
+    assert lib.gv_pool2d_fwd_argmax(C.byref(pm), 16, 16, None, None) == -1
+    assert lib.gv_pool2d_bwd_argmax(C.byref(pm), None, 16, 4, 16, 4, None) == -1
     p = _lib.PoolDesc(1, 8, 8, 4, 4, 3, 3, 2, 0, 0, 3, 3, 4, 5, _lib.GV_F32)   # bad mode
     assert lib.gv_pool2d_fwd(C.byref(p), 16, 16, None) == -1
     assert lib.gv_group_assign(None, 6, 10, 10, None, None, None, None, None) == -1

@@ -168,6 +168,64 @@ def test_pool_backward_typed(dt, tdt, eps, k, stride, padding, mode, c):
         close(dx32.cpu(), x.grad, 1e-5)                  # (torch splits differently only where windows tie)
 
 
+@pytest.mark.parametrize("dt,tdt", [(_lib.GV_BF16, torch.bfloat16), (_lib.GV_F16, torch.float16), (_lib.GV_F32, torch.float32)])
+@pytest.mark.parametrize("k,stride,padding", [(3, 2, "VALID"), (3, 2, "SAME"), (3, 1, "SAME"), (1, 2, "VALID"), (2, 2, "VALID")])
+@pytest.mark.parametrize("c,ld", [(16, 16), (24, 40), (5, 7)])
+def test_max_pool_with_recorded_argmax(dt, tdt, k, stride, padding, c, ld):
+    """gv_pool2d_fwd_argmax / gv_pool2d_bwd_argmax (the training step's max pools): the forward output is that of
+    gv_pool2d_fwd bit for bit, the recorded byte is the row-major tap of the FIRST maximum of the window (ties planted),
+    and the backward, which never sees x, reproduces gv_pool2d_bwd (tf MaxPoolGrad) bit for bit in both its accumulate and
+    its store form."""
+    g = torch.Generator().manual_seed(k * 10 + stride + c)
+    nb, ih, iw = 2, 11, 9
+    x = q(torch.randn(nb, ih, iw, c, generator=g), tdt)
+    x[0, 2:6, 2:6, :] = 0.5                              # ties
+    x[1, :, :, 0] = -3.0
+    pt = OB.same_pads(ih, k, stride)[0] if padding == "SAME" else 0
+    pl = OB.same_pads(iw, k, stride)[0] if padding == "SAME" else 0
+    yref = OB.max_pool2d(x, k, stride, padding)
+    oh, ow = yref.shape[1], yref.shape[2]
+    xd = torch.zeros(nb, ih, iw, ld, dtype=tdt, device=DEV)
+    xd[..., :c] = x.to(tdt).to(DEV)
+    d = _lib.PoolDesc(nb, ih, iw, c, ld, k, k, stride, pt, pl, oh, ow, ld, _lib.GV_POOL_MAX, dt)
+    y0 = torch.zeros(nb, oh, ow, ld, dtype=tdt, device=DEV)
+    y1 = torch.zeros_like(y0)
+    arg = torch.full((nb, oh, ow, c), 255, dtype=torch.uint8, device=DEV)
+    _lib.check(lib().gv_pool2d_fwd(C.byref(d), xd.data_ptr(), y0.data_ptr(), st()), "pool")
+    _lib.check(lib().gv_pool2d_fwd_argmax(C.byref(d), xd.data_ptr(), y1.data_ptr(), arg.data_ptr(), st()), "pool+argmax")
+    assert torch.equal(y0, y1) and torch.equal(y1[..., :c].float().cpu(), yref)
+    # the first maximum in scan order, by hand
+    xp = torch.full((nb, ih + 2 * k, iw + 2 * k, c), float("-inf"))
+    xp[:, pt:pt + ih, pl:pl + iw] = x
+    want = torch.zeros(nb, oh, ow, c, dtype=torch.uint8)
+    for oy in range(oh):
+        for ox in range(ow):
+            win = xp[:, oy * stride:oy * stride + k, ox * stride:ox * stride + k].reshape(nb, k * k, c)
+            want[:, oy, ox] = (win == win.max(dim=1, keepdim=True).values).to(torch.uint8).argmax(dim=1).to(torch.uint8)
+    assert torch.equal(arg.cpu(), want)
+    dy = torch.zeros(nb, oh, ow, ld, dtype=tdt, device=DEV)
+    dy[..., :c] = q(torch.randn(nb, oh, ow, c, generator=g), tdt).to(tdt).to(DEV)
+    for store in (0, _lib.GV_POOL_BWD_STORE):
+        if store and dt == _lib.GV_F32:
+            continue                                     # (gv_pool2d_bwd has the store form for 16-bit storage only)
+        d.mode = _lib.GV_POOL_MAX | store
+        dx0 = torch.full((nb, ih, iw, ld), 0.25, dtype=tdt, device=DEV)
+        dx1 = dx0.clone()
+        _lib.check(lib().gv_pool2d_bwd(C.byref(d), xd.data_ptr(), dy.data_ptr(), ld, dx0.data_ptr(), ld, st()), "pool_bwd")
+        _lib.check(lib().gv_pool2d_bwd_argmax(C.byref(d), arg.data_ptr(), dy.data_ptr(), ld, dx1.data_ptr(), ld, st()),
+                   "pool_bwd (argmax)")
+        assert torch.equal(dx0[..., :c], dx1[..., :c])
+        assert (dx1[..., c:] == 0.25).all()
+    if dt == _lib.GV_F32:                                # the store form exists here for every storage type
+        d.mode = _lib.GV_POOL_MAX | _lib.GV_POOL_BWD_STORE
+        dxs = torch.full((nb, ih, iw, ld), float("nan"), dtype=tdt, device=DEV)
+        _lib.check(lib().gv_pool2d_bwd_argmax(C.byref(d), arg.data_ptr(), dy.data_ptr(), ld, dxs.data_ptr(), ld, st()), "store")
+        d.mode = _lib.GV_POOL_MAX
+        dxz = torch.zeros(nb, ih, iw, ld, dtype=tdt, device=DEV)
+        _lib.check(lib().gv_pool2d_bwd_argmax(C.byref(d), arg.data_ptr(), dy.data_ptr(), ld, dxz.data_ptr(), ld, st()), "add")
+        assert torch.equal(dxs[..., :c], dxz[..., :c])
+
+
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
 def test_accumulate_and_bias_grad_typed(dt, tdt, eps):
     g = torch.Generator().manual_seed(5)
