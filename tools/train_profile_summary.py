@@ -19,7 +19,7 @@ first = max(first, 0)
 sel = rows[len(rows) - steps * period:]
 FAM = [("filter gradient", ("conv_wgrad",)), ("conv fwd/dgrad", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma")),
        ("BN sums", ("grouped_sums",)), ("BN apply fwd/bwd", ("bn_stream", "scale_shift_act_grouped", "bn_bwd_apply")),
-       ("pool fwd/bwd", ("pool2d", "maxpool3s2")), ("fills/copies", ("FillFunctor", "fillBuffer", "copyBuffer")),
+       ("pool fwd/bwd", ("pool2d", "maxpool", "avgpool3x3")), ("fills/copies", ("FillFunctor", "fillBuffer", "copyBuffer")),
        ("filter re-pack", ("pack_filter", "elementwise_kernel")), ("optimizer", ("sgd_momentum",)),
        ("BN small", ("bn_param_grads", "bn_finalize", "bn_update_moving"))]
 tot = defaultdict(float)
