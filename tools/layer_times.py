@@ -58,7 +58,7 @@ for i, op in enumerate(plan.ops):
                    gbs=op["bytes"] / ms / 1e6)
         if a.tiles:
             tt = []
-            for t in range(ncfg):
+            for t in range(lib.gv_conv2d_num_tile_cfgs(-3) if xx.p3 else ncfg):       # (three-plane input: the LDS-DMA kernel's own table)
                 lib.gv_conv2d_set_tile_override(t)
                 try:
                     tt.append(round(plan.time_range(x, i, 1, 3), 4))
