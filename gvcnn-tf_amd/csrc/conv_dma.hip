@@ -592,6 +592,12 @@ int launch_dma_x3_e(int cfg, const ConvArgs& a, hipStream_t st) {
                                                                               // 1x7 / 7x1 layers of Mixed_6c / 6d in ONE column tile
         case 14: return launch_dma<__bf16, 3, 4, 1, 1, 5, 4, EPI>(a, st);     // 128 x 160, 4 waves
         case 15: return launch_dma<__bf16, 3, 2, 2, 2, 3, 2, EPI>(a, st);     // 128 x 192, 4 waves, 2 stages (61 KB: two per CU)
+        // two-stage forms of the narrow tiles: a second (third) workgroup per CU covers a workgroup's barriers and epilogue
+        // better than a third stage covers its loads — Mixed_5's 64- / 96-column layers -9 ... -15 % (128 x 96, 128 x 64,
+        // 256 x 128 and 256 x 160 on two stages were measured too and won nowhere)
+        case 16: return launch_dma<__bf16, 3, 4, 1, 2, 3, 2, EPI>(a, st);     // 256 x 96, 4 waves, 2 stages (66 KB: two per CU)
+        case 17: return launch_dma<__bf16, 3, 4, 1, 2, 2, 2, EPI>(a, st);     // 256 x 64, 4 waves, 2 stages (60 KB: two per CU)
+        case 18: return launch_dma<__bf16, 3, 2, 2, 2, 2, 2, EPI>(a, st);     // 128 x 128, 2 stages (48 KB: three per CU)
     }
     return GV_E_UNSUPPORTED;
 }
@@ -610,7 +616,7 @@ namespace gvconv {
 
 const void* dma_zero_page() { return zero_page_for_current_device(); }   // (wgrad_dma.hip shares it)
 
-int dma_x3_num_cfgs() { return 16; }
+int dma_x3_num_cfgs() { return 19; }
 
 // P3 input: whole 16-channel groups inside one filter tap
 bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; }

@@ -106,7 +106,7 @@ P3_COMBOS = [((3, 3), 1, "VALID", 32, 64), ((3, 3), 1, "VALID", 80, 192), ((5, 5
              ((1, 3), 1, "SAME", 384, 384), ((3, 1), 1, "SAME", 448, 384), ((3, 3), 1, "SAME", 64, 96)]
 
 
-@pytest.mark.parametrize("tile", [0, 3, 4, 7, 8, 9, 10, 12, 13, 14, 15])
+@pytest.mark.parametrize("tile", [0, 3, 4, 7, 8, 9, 10, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("k,stride,padding,cin,cout", P3_COMBOS)
 def test_dma_conv_on_three_plane_input(k, stride, padding, cin, cout, tile):
     """The LDS-DMA kernel on P3 input (fp32 output and P3 output) against the CPU oracle and against the register-staged
