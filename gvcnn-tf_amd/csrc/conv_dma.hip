@@ -56,6 +56,20 @@ __host__ __device__ constexpr int dprod_pb(int np, int t) { return np == 3 ? (t 
 
 // EPI: 0 = 16-bit output through the LDS-staged epilogue (conv_lp_epi.h); 1 = fp32 output straight from the accumulators
 // (conv_common.h); 2 = fp32 or three-plane (P3) output through the staged epilogue of conv_x3_epi.h
+// byte offset of the epilogue's scale / shift table: behind the ring and the per-wave staging blocks (which alias the ring)
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+constexpr int dma_ss_off() {
+    constexpr int ring = ST * NP * (WM * TM * 32 + WN * TN * 32) * DmaGeom<NP>::RBYTES;
+    constexpr int epi = EPI == 1 ? 0 : WM * WN * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
+    return ((ring > epi ? ring : epi) + 15) / 16 * 16;
+}
+// ... unless the table's bytes would cost a resident workgroup (128 x 192 on four 16-bit stages is exactly half a CU's LDS)
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+constexpr bool dma_use_ss() {
+    constexpr int base = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>(), with = base + 16 * WN * TN * 32, cu = 160 * 1024;
+    return EPI != 1 && cu / base == cu / with;
+}
+
 template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     using G = DmaGeom<NP>;
@@ -78,6 +92,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN;
     const int wn = wave % WN;
+    // The epilogue's per-column constants (scale, shift, and scale2 / shift2 of a second output) live in LDS behind the
+    // ring / staging area: requested here, written once the ring's first stages are on their way, read back by the staged
+    // epilogue as 16-byte LDS reads.  Loaded from global memory inside the epilogue they cost every read-back block of
+    // every tile one exposed memory round trip (16 - 32 scalar loads issued and awaited between the last MFMA and the
+    // first store), which the short-K HBM-bound launches (ResNet conv3: K = 64) cannot hide behind anything.
+    constexpr int SS_OFF = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>();
+    static_assert(WM * WN * 64 >= WN * TN * 32, "one thread per tile column");
+    constexpr bool USE_SS = dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>();
+    float* sstab = USE_SS && !(a.dbg & 512) ? reinterpret_cast<float*>(smem + SS_OFF) : nullptr;   // dbg 512: constants from global (A/B)
+    float ss_v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool ss_dual = EPI == 0 && a.y2 != nullptr && a.split == 0;
+    if (USE_SS && tid < WN * TN * 32) {
+        const int lid0 = gv_xcd_remap(blockIdx.x, gridDim.x);
+        const int cc = min((lid0 % a.tiles_n) * (WN * TN * 32) + tid, a.cout - 1);
+        ss_v[0] = a.scale[cc];
+        ss_v[1] = a.shift[cc];
+        if (ss_dual) { ss_v[2] = a.scale2[cc]; ss_v[3] = a.shift2[cc]; }
+    }
+    auto ss_publish = [&]() {
+        if (USE_SS && tid < WN * TN * 32) {
+            constexpr int BN_ = WN * TN * 32;
+            sstab[tid] = ss_v[0];
+            sstab[BN_ + tid] = ss_v[1];
+            if (ss_dual) { sstab[2 * BN_ + tid] = ss_v[2]; sstab[3 * BN_ + tid] = ss_v[3]; }
+        }
+    };
     // Eight waves = two per SIMD (waves w and w+4: a workgroup's waves go to the SIMDs in a cyclic order), and the k-tile
     // barrier makes both arrive at their MFMAs together: they then share the matrix pipe and idle together through the next
     // barrier / fragment reads / DMA issue.  A higher issue priority for one of the two staggers them inside a k-tile —
@@ -319,6 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     #pragma unroll
         for (int t = 0; t < ST; ++t)
             if (t < ktiles) issue(t);
+        ss_publish();
         {
             const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
             if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
@@ -472,6 +513,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     #pragma unroll
         for (int t = 0; t < ST; ++t)
             if (t < ktiles) issue(t);
+        ss_publish();
         {
             const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
             if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
@@ -501,11 +543,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     }
     __syncthreads();                                               // every wave is done with the ring: reuse it for staging
     if constexpr (EPI == 0)
-        lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES));
+        lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES), 32,
+                                      sstab, BN);
     else if constexpr (EPI == 1)
         gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
     else
-        x3_epilogue_staged<TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * X3EpiGeom<TN>::BYTES));
+        x3_epilogue_staged<TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * X3EpiGeom<TN>::BYTES),
+                                   sstab, BN);
 }
 
 // one zero page per device for the padding taps of the gather (lazily allocated OUTSIDE any stream capture: every
@@ -540,7 +584,10 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
     a.korder = (a.kh * a.kw > 1 && a.cin % G::KT == 0 && a.dil_shift == 0 && !(a.dbg & 128)) ? 1 : 0;   // dbg 128: tap-major (A/B)
     const size_t ring = (size_t)ST * NP * (BM + BN) * G::RBYTES;
     const size_t epi = EPI == 1 ? 0 : (size_t)(WM * WN) * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
-    const size_t lds = ring > epi ? ring : epi;
+    static_assert(dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() >= (int)((size_t)ST * NP * (BM + BN) * G::RBYTES), "table behind the ring");
+    (void)ring; (void)epi;
+    const size_t lds = (size_t)dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() +
+                       (dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() ? 4 * BN * sizeof(float) : 0);
     auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI>;
     if (lds > 64 * 1024) {
         static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

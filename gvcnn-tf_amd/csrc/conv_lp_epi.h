@@ -59,7 +59,8 @@ __device__ __forceinline__ void store_chunk(unsigned short* dst, const float (&v
 
 template <typename T, int TM, int TN>
 __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                                   int wm, int wn, int lane, float* stage, int rows_valid = 32) {
+                                                   int wm, int wn, int lane, float* stage, int rows_valid = 32,
+                                                   const float* sstab = nullptr, int bn = 0) {
     if (a.dbg & 4) {            // timing ablation: keep the accumulators live without storing the tile
         float t = 0.f;
 #pragma unroll
@@ -111,13 +112,29 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
         const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;     // this lane's 8 columns
         const int nvalid = min(8, a.cout - col);                        // <= 0: nothing to store
         float sc[8], sh[8], sc2[8], sh2[8];
+        if (sstab) {                                        // the tile's constants in LDS (conv_dma.hip): 16-byte reads
+            const float* t = sstab + (wn * TN + jb * JB) * 32 + rchunk * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = min(col + e, a.cout - 1);
-            sc[e] = a.scale[c];
-            sh[e] = a.shift[c];
-            sc2[e] = dual ? a.scale2[c] : 0.f;
-            sh2[e] = dual ? a.shift2[c] : 0.f;
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(t + 4 * h);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(t + bn + 4 * h);
+                f32x4 v2 = {0.f, 0.f, 0.f, 0.f}, v3 = v2;
+                if (dual) {
+                    v2 = *reinterpret_cast<const f32x4*>(t + 2 * bn + 4 * h);
+                    v3 = *reinterpret_cast<const f32x4*>(t + 3 * bn + 4 * h);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[4 * h + e] = v0[e]; sh[4 * h + e] = v1[e]; sc2[4 * h + e] = v2[e]; sh2[4 * h + e] = v3[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = min(col + e, a.cout - 1);
+                sc[e] = a.scale[c];
+                sh[e] = a.shift[c];
+                sc2[e] = dual ? a.scale2[c] : 0.f;
+                sh2[e] = dual ? a.shift2[c] : 0.f;
+            }
         }
         // split destination: a chunk lies on one side when split % 8 == 0; otherwise decide per element below
         const bool to_second = a.split > 0 && col >= a.split;

@@ -95,7 +95,8 @@ template <int TN> struct X3EpiGeom {
 // 8-aligned column counts and, for a P3 destination, 16-aligned strides / split / slice offsets (checked by the host).
 template <int TM, int TN>
 __device__ __forceinline__ void x3_epilogue_staged(const gvconv::ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                                   int wm, int wn, int lane, float* stage) {
+                                                   int wm, int wn, int lane, float* stage, const float* sstab = nullptr,
+                                                   int bn = 0) {
     if (a.dbg & 4) {            // timing ablation: keep the accumulators live without storing the tile
         float t = 0.f;
 #pragma unroll
@@ -118,11 +119,22 @@ __device__ __forceinline__ void x3_epilogue_staged(const gvconv::ConvArgs& a, co
         const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;     // this lane's 8 columns
         const bool live = col < a.cout;                                 // (cout % 8 == 0: a chunk is whole or absent)
         float sc[8], sh[8];
+        if (sstab) {                                        // the tile's constants in LDS (conv_dma.hip): 16-byte reads
+            const float* t = sstab + (wn * TN + jb * JB) * 32 + rchunk * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = min(col + e, a.cout - 1);
-            sc[e] = a.scale[c];
-            sh[e] = a.shift[c];
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(t + 4 * h);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(t + bn + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[4 * h + e] = v0[e]; sh[4 * h + e] = v1[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = min(col + e, a.cout - 1);
+                sc[e] = a.scale[c];
+                sh[e] = a.shift[c];
+            }
         }
         const bool to_second = a.split > 0 && col >= a.split;
         const int dcol = to_second ? col - a.split : col;
