@@ -115,6 +115,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
             a_base[i] = a_iy0[i] > -(1 << 27) ? ((a_img[i] + a_iy0[i]) * a.iw + a_ix0[i]) * a.x_ld : 0;
         __syncthreads();
     }
+    // The epilogue's per-column constants go to LDS behind everything else (main buffers + gather / pre-activation table,
+    // or the per-wave staging blocks where those are larger): requested here, written after the first tile's loads are
+    // issued, read back as 16-byte LDS reads (see conv_dma.hip: loaded from global memory inside the epilogue, every
+    // read-back block waits out a memory round trip, which the short-K launches cannot hide)
+    static_assert(NT >= BN, "one thread per tile column");
+    float* sstab;
+    {
+        const int main_b = (2 * BM + 2 * BN) * RB + (GENERIC ? a.Kpad * 8 : 0) + (XPRE ? a.cin * 8 : 0);
+        const int epi_b = WM * WN * EpiGeom<TN>::BYTES;
+        sstab = reinterpret_cast<float*>(smem_raw + ((main_b > epi_b ? main_b : epi_b) + 15) / 16 * 16);
+    }
+    float ss_v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool ss_dual = a.y2 != nullptr && a.split == 0;
+    if (tid < BN) {
+        const int cc = min(n0 + tid, a.cout - 1);
+        ss_v[0] = a.scale[cc];
+        ss_v[1] = a.shift[cc];
+        if (ss_dual) { ss_v[2] = a.scale2[cc]; ss_v[3] = a.shift2[cc]; }
+    }
     // XPRE: (scale, shift) of every input channel, read back 8 channels (this thread's chunk) at a time
     float2* xss = reinterpret_cast<float2*>(smem_raw + (2 * BM + 2 * BN) * RB);
     if constexpr (XPRE) {
@@ -304,6 +323,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
     load_tile(I1{}, 1);
     advance_tap();
     load_tile(I0{}, 2);
+    if (tid < BN) {
+        sstab[tid] = ss_v[0];
+        sstab[BN + tid] = ss_v[1];
+        if (ss_dual) { sstab[2 * BN + tid] = ss_v[2]; sstab[3 * BN + tid] = ss_v[3]; }
+    }
     __syncthreads();
     read_frags(I0{}, 0);
     int kt = 0;
@@ -339,7 +363,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
 
     __syncthreads();                                  // every wave is done with the main-loop buffers
     lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane,
-                                  reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES));
+                                  reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES), 32,
+                                  (a.dbg & 512) ? nullptr : sstab, BN);      // dbg 512: constants from global memory (A/B)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -712,7 +737,7 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB + ((generic || xf32) ? (size_t)a.Kpad * 8 : 0) +
                             (a.xscale ? (size_t)a.cin * 8 : 0);
     const size_t lds_epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
-    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    const size_t lds = ((lds_main > lds_epi ? lds_main : lds_epi) + 15) / 16 * 16 + 16 * BN;   // + the epilogue's constants
     if (a.xscale) {
         if constexpr (xpre_cfg(WM, WN, TM, TN)) return launch_one<T, WM, WN, TM, TN, false, false, true>(a, nwg, lds, st);
         else return GV_E_UNSUPPORTED;
