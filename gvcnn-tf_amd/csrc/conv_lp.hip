@@ -376,12 +376,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
 // fragment is a ds_read_b128 at a shifted pixel, and the whole filter (9 taps x 2 k-steps x TN fragments) lives in
 // REGISTERS for the life of the workgroup.  The next tile's halo is loaded into registers under this tile's
 // MFMAs.  Epilogue: the staged 16-byte path above.
-template <typename T, int TN>
+// RPW: output rows per wave and tile (wave w owns rows w and w + 4): with two, the two barriers, the halo hand-over and the
+// filter fragment reads of a tile are shared by twice the MFMAs and the halo overlap drops from 6/4 to 10/8 input rows
+// per output row.
+template <typename T, int TN, int RPW>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
-    constexpr int TH = 4, TW = 32, HH = TH + 2, HW = TW + 2, PB = 80;       // halo pixel = 64 B + 16 B pad
+    constexpr int TH = 4 * RPW, TW = 32, HH = TH + 2, HW = TW + 2, PB = 80;  // halo pixel = 64 B + 16 B pad
     constexpr int NCH = HH * HW * 4;                                          // 16-byte chunks of one halo
     constexpr int SL = (NCH + 255) / 256;
-    constexpr bool BREG = TN == 1;                                            // filter fragments in registers
+    constexpr bool BREG = TN == 1;                                            // filter fragments in registers (TN = 2: 144 VGPRs
+                                                                              // of filter spill and run Conv2d_2b 0.295 -> 0.45 ms)
     constexpr int WB = 288 * 2 + 16;                                          // LDS filter row: K = 288 values + pad
     constexpr int SW = 32 + 4;                                                // staging row: one 32-column tile (+ pad)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -403,10 +407,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = min(li, a.cout - 1);
-                fb[t][c][0] = *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + t * 32 + c * 16 + 8 * lh);
-            }
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = min(j * 32 + li, a.cout - 1);
+                    fb[t][c][j] = *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + t * 32 + c * 16 + 8 * lh);
+                }
     } else {
         for (int idx = tid; idx < 32 * TN * 36; idx += 256) {                 // 36 chunks of 16 B per filter row
             const int row = idx / 36, ch = idx - row * 36;
@@ -457,33 +463,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
         }
         __syncthreads();
         if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under the MFMAs below
-        f32x16 acc[TN];
+        f32x16 acc[RPW][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int q = 0; q < RPW; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int r = t / 3, s_ = t - r * 3;
             const char* ap = sH + ((wave + r) * HW + li + s_) * PB + 16 * lh;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const u32x4 fa = *reinterpret_cast<const u32x4*>(ap + c * 32);
+                u32x4 fa[RPW];
+#pragma unroll
+                for (int q = 0; q < RPW; ++q) fa[q] = *reinterpret_cast<const u32x4*>(ap + q * 4 * HW * PB + c * 32);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     u32x4 b;
                     if constexpr (BREG) b = fb[t][c][j];
                     else b = *reinterpret_cast<const u32x4*>(sW + (j * 32 + li) * WB + (t * 32 + c * 16 + 8 * lh) * 2);
-                    acc[j] = mfma16<T>(fa, b, acc[j]);
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q) acc[q][j] = mfma16<T>(fa[q], b, acc[q][j]);
                 }
             }
         }
-        const int oy = oy0 + wave;
         // transposing epilogue (see lp_epilogue_staged): accumulators -> private LDS block -> 8 channels per lane
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int qj = 0; qj < RPW * TN; ++qj) {
+            const int q = qj / TN, j = qj % TN;
+            const int oy = oy0 + wave + 4 * q;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
+            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[q][j][r];
             __builtin_amdgcn_wave_barrier();
             const int colj = j * 32 + col8;
             const int nvalid = min(8, a.cout - colj);
@@ -766,23 +778,31 @@ int launch_t(int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st
     return GV_E_UNSUPPORTED;
 }
 
-template <typename T>
-int launch_halo(const ConvArgs& a, hipStream_t st) {
+template <typename T, int RPW>
+int launch_halo_r(const ConvArgs& a, hipStream_t st) {
     const int tiles_x = (a.ow + 31) / 32;
     const dim3 grid((unsigned)(a.nb * tiles_x));
-    const size_t halo = (size_t)6 * 34 * 80;
+    const size_t halo = (size_t)(4 * RPW + 2) * 34 * 80;
     if (a.cout <= 32) {
         const size_t lds = halo + 4 * 32 * (32 + 4) * 4;
-        hipLaunchKernelGGL((conv3x3_halo_lp<T, 1>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, RPW>), grid, dim3(256), lds, st, a);
     } else {
         const size_t lds = halo + 4 * 32 * (32 + 4) * 4 + 64 * (288 * 2 + 16);
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 2>),
+        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 2, RPW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!ok) return GV_E_UNSUPPORTED;
-        hipLaunchKernelGGL((conv3x3_halo_lp<T, 2>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv3x3_halo_lp<T, 2, RPW>), grid, dim3(256), lds, st, a);
     }
     GV_LAUNCH_CHECK();
     return GV_OK;
+}
+
+template <typename T>
+int launch_halo(const ConvArgs& a, hipStream_t st) {
+    // two rows per wave where the filter lives in registers (<= 32 output channels: 45 KB of LDS, three workgroups per CU;
+    // Conv2d_2a 0.225 -> 0.154 ms).  With the 64-column filter in LDS the taller halo costs the second resident
+    // workgroup (83 KB) and Conv2d_2b runs 0.295 -> 0.385 ms: one row per wave there.  Debug bit 1024: one row (A/B)
+    return (a.oh >= 8 && a.cout <= 32 && !(a.dbg & 1024)) ? launch_halo_r<T, 2>(a, st) : launch_halo_r<T, 1>(a, st);
 }
 
 template <typename T, int TN, int KW>
