@@ -379,19 +379,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
 // RPW: output rows per wave and tile (wave w owns rows w and w + 4): with two, the two barriers, the halo hand-over and the
 // filter fragment reads of a tile are shared by twice the MFMAs and the halo overlap drops from 6/4 to 10/8 input rows
 // per output row.
-template <typename T, int TN, int RPW>
+// CIN: 32 (Conv2d_2a / 2b forward) or 64 (the data gradient of Conv2d_2b: 64 -> 32 channels over the padded map; filter of
+// 9 x 64 values per output channel in LDS).
+template <typename T, int TN, int RPW, int CIN = 32>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
-    constexpr int TH = 4 * RPW, TW = 32, HH = TH + 2, HW = TW + 2, PB = 80;  // halo pixel = 64 B + 16 B pad
-    constexpr int NCH = HH * HW * 4;                                          // 16-byte chunks of one halo
+    constexpr int TH = 4 * RPW, TW = 32, HH = TH + 2, HW = TW + 2, PB = CIN * 2 + 16;   // halo pixel + 16 B pad
+    constexpr int CPP = CIN / 8, KS = CIN / 16;                               // 16-byte chunks / MFMA k-steps per pixel
+    constexpr int NCH = HH * HW * CPP;                                        // 16-byte chunks of one halo
     constexpr int SL = (NCH + 255) / 256;
-    constexpr bool BREG = TN == 1;                                            // filter fragments in registers (TN = 2: 144 VGPRs
+    constexpr bool BREG = TN == 1 && CIN == 32;                               // filter fragments in registers (TN = 2: 144 VGPRs
                                                                               // of filter spill and run Conv2d_2b 0.295 -> 0.45 ms)
-    constexpr int WB = 288 * 2 + 16;                                          // LDS filter row: K = 288 values + pad
+    constexpr int WB = 9 * CIN * 2 + 16;                                      // LDS filter row: K = 9 * CIN values + pad
     constexpr int SW = 32 + 4;                                                // staging row: one 32-column tile (+ pad)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // CIN = 64: the per-wave staging blocks ALIAS the halo (one more barrier per tile, between the MFMAs and the epilogue):
+    // 67 instead of 85 KB, i.e. two resident workgroups
+    constexpr bool ALIAS = CIN == 64 || (TN == 2 && RPW == 2);               // (64 columns, two rows per wave: 65 instead of 84 KB)
+    static_assert(!ALIAS || 4 * 32 * SW * 4 <= HH * HW * PB, "staging fits the halo");
     char* sH = smem_raw;                                                      // [HH*HW][PB]
-    float* stage = reinterpret_cast<float*>(smem_raw + HH * HW * PB) + (threadIdx.x >> 6) * (32 * SW);
-    char* sW = smem_raw + HH * HW * PB + 4 * 32 * SW * 4;                     // [32*TN][WB]   (!BREG)
+    float* stage = reinterpret_cast<float*>(smem_raw + (ALIAS ? 0 : HH * HW * PB)) + (threadIdx.x >> 6) * (32 * SW);
+    char* sW = smem_raw + HH * HW * PB + (ALIAS ? 0 : 4 * 32 * SW * 4);       // [32*TN][WB]   (!BREG)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int tiles_x = (a.ow + TW - 1) / TW;
     const int n = blockIdx.x / tiles_x;
@@ -402,20 +409,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
     unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
 
     // the filter: B fragment of tap t, k-step c, column tile j = 8 values k = t*32 + c*16 + 8*lh .. of row n = j*32 + li
-    u32x4 fb[BREG ? 9 : 1][2][TN];
+    u32x4 fb[BREG ? 9 : 1][KS][TN];
     if constexpr (BREG) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < KS; ++c)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = min(j * 32 + li, a.cout - 1);
-                    fb[t][c][j] = *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + t * 32 + c * 16 + 8 * lh);
+                    fb[t][c][j] = *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + t * CIN + c * 16 + 8 * lh);
                 }
     } else {
-        for (int idx = tid; idx < 32 * TN * 36; idx += 256) {                 // 36 chunks of 16 B per filter row
-            const int row = idx / 36, ch = idx - row * 36;
+        constexpr int FCH = 9 * CPP;                                          // 16-byte chunks per filter row
+        for (int idx = tid; idx < 32 * TN * FCH; idx += 256) {
+            const int row = idx / FCH, ch = idx - row * FCH;
             const int col = min(row, a.cout - 1);
             *reinterpret_cast<u32x4*>(sW + row * WB + ch * 16) =
                 *reinterpret_cast<const u32x4*>(wp + (size_t)col * a.Kpad + ch * 8);
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
             const int idx = tid + k * 256;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (idx < NCH) {
-                const int pix = idx >> 2, ch = idx & 3;
+                const int pix = idx / CPP, ch = idx % CPP;
                 const int hy = pix / HW, hx = pix - hy * HW;
                 const int iy = oy0 + hy - a.pad_t, ix = ox0 + hx - a.pad_l;
                 if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < SL; ++k) {
             const int idx = tid + k * 256;
-            if (idx < NCH) *reinterpret_cast<u32x4*>(sH + (idx >> 2) * PB + (idx & 3) * 16) = hr[k];
+            if (idx < NCH) *reinterpret_cast<u32x4*>(sH + (idx / CPP) * PB + (idx % CPP) * 16) = hr[k];
         }
         __syncthreads();
         if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under the MFMAs below
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
             const int r = t / 3, s_ = t - r * 3;
             const char* ap = sH + ((wave + r) * HW + li + s_) * PB + 16 * lh;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < KS; ++c) {
                 u32x4 fa[RPW];
 #pragma unroll
                 for (int q = 0; q < RPW; ++q) fa[q] = *reinterpret_cast<const u32x4*>(ap + q * 4 * HW * PB + c * 32);
@@ -483,12 +491,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
                 for (int j = 0; j < TN; ++j) {
                     u32x4 b;
                     if constexpr (BREG) b = fb[t][c][j];
-                    else b = *reinterpret_cast<const u32x4*>(sW + (j * 32 + li) * WB + (t * 32 + c * 16 + 8 * lh) * 2);
+                    else b = *reinterpret_cast<const u32x4*>(sW + (j * 32 + li) * WB + (t * CIN + c * 16 + 8 * lh) * 2);
 #pragma unroll
                     for (int q = 0; q < RPW; ++q) acc[q][j] = mfma16<T>(fa[q], b, acc[q][j]);
                 }
             }
         }
+        if constexpr (ALIAS) __syncthreads();              // every wave has read its fragments: the halo becomes staging
         // transposing epilogue (see lp_epilogue_staged): accumulators -> private LDS block -> 8 channels per lane
 #pragma unroll
         for (int qj = 0; qj < RPW * TN; ++qj) {
@@ -787,7 +796,7 @@ int launch_halo_r(const ConvArgs& a, hipStream_t st) {
         const size_t lds = halo + 4 * 32 * (32 + 4) * 4;
         hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, RPW>), grid, dim3(256), lds, st, a);
     } else {
-        const size_t lds = halo + 4 * 32 * (32 + 4) * 4 + 64 * (288 * 2 + 16);
+        const size_t lds = halo + (RPW == 2 ? 0 : 4 * 32 * (32 + 4) * 4) + 64 * (288 * 2 + 16);   // (RPW = 2: staging aliases the halo)
         static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 2, RPW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!ok) return GV_E_UNSUPPORTED;
@@ -798,11 +807,24 @@ int launch_halo_r(const ConvArgs& a, hipStream_t st) {
 }
 
 template <typename T>
+int launch_halo64(const ConvArgs& a, hipStream_t st) {                       // 64 input channels, <= 32 output channels
+    const int tiles_x = (a.ow + 31) / 32;
+    const size_t lds = (size_t)6 * 34 * (64 * 2 + 16) + 32 * (9 * 64 * 2 + 16);      // (staging aliases the halo)
+    static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 1, 1, 64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!ok) return GV_E_UNSUPPORTED;
+    hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, 1, 64>), dim3((unsigned)(a.nb * tiles_x)), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+template <typename T>
 int launch_halo(const ConvArgs& a, hipStream_t st) {
-    // two rows per wave where the filter lives in registers (<= 32 output channels: 45 KB of LDS, three workgroups per CU;
-    // Conv2d_2a 0.225 -> 0.154 ms).  With the 64-column filter in LDS the taller halo costs the second resident
-    // workgroup (83 KB) and Conv2d_2b runs 0.295 -> 0.385 ms: one row per wave there.  Debug bit 1024: one row (A/B)
-    return (a.oh >= 8 && a.cout <= 32 && !(a.dbg & 1024)) ? launch_halo_r<T, 2>(a, st) : launch_halo_r<T, 1>(a, st);
+    if (a.cin == 64) return launch_halo64<T>(a, st);
+    // two rows per wave wherever the map has them: Conv2d_2a 0.225 -> 0.150 ms.  With the 64-column filter in LDS the taller
+    // halo would cost the second resident workgroup (84 KB: Conv2d_2b 0.295 -> 0.385 ms), so that form lets the staging
+    // blocks alias the halo (65 KB): 0.335 -> 0.283 ms.  Debug bit 1024: one row per wave (A/B)
+    return (a.oh >= 8 && !(a.dbg & 1024)) ? launch_halo_r<T, 2>(a, st) : launch_halo_r<T, 1>(a, st);
 }
 
 template <typename T, int TN, int KW>
@@ -840,7 +862,8 @@ bool lp_stem_ok(const ConvArgs& a, bool xf32) {
 // the halo kernel's layer class: 3x3 / stride 1, 32 input channels in 16-byte aligned pixels, <= 64 output channels,
 // plain epilogue (Conv2d_2a_3x3, Conv2d_2b_3x3)
 bool lp_halo_ok(const ConvArgs& a, bool generic) {
-    return !generic && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cin == 32 && a.cout <= 64 && a.cout % 8 == 0 &&
+    return !generic && a.kh == 3 && a.kw == 3 && a.stride == 1 && ((a.cin == 32 && a.cout <= 64) || (a.cin == 64 && a.cout <= 32)) &&
+           a.cout % 8 == 0 &&
            a.dil_shift == 0 && a.split == 0 && a.y2 == nullptr && a.oh == a.ih + 2 * a.pad_t - 2 &&
            a.ow == a.iw + 2 * a.pad_l - 2;
 }

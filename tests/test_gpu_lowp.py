@@ -227,20 +227,22 @@ def test_lp_dma_conv_combos_vs_oracle(k, stride, padding, cin, cout, tile_i):
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
-@pytest.mark.parametrize("cout,pad,hw", [(32, 0, (23, 41)), (64, 1, (23, 41)), (64, 1, (8, 32)), (48, 0, (5, 70))])
-def test_lp_halo_stem_kernel(ty, cout, pad, hw):
+@pytest.mark.parametrize("cout,pad,hw,cin", [(32, 0, (23, 41), 32), (64, 1, (23, 41), 32), (64, 1, (8, 32), 32), (48, 0, (5, 70), 32),
+                                             (32, 0, (36, 70), 32), (24, 1, (17, 33), 32),          # two rows per wave
+                                             (32, 2, (21, 37), 64), (32, 1, (9, 40), 64), (24, 0, (12, 66), 64)])   # 64 -> 32 (data gradient of Conv2d_2b)
+def test_lp_halo_stem_kernel(ty, cout, pad, hw, cin):
     """The halo-tiled 3x3 kernel of Conv2d_2a/2b (the last tile configuration): ragged strips (width not a multiple of
-    32, height not a multiple of 4), VALID and SAME, with a residual, into a channel slice — equal to the
-    implicit-GEMM kernel's result up to fp32 summation order."""
+    32, height not a multiple of 4 / 8), VALID, SAME and the full padding of a data gradient, 32 and 64 input channels,
+    with a residual, into a channel slice — equal to the implicit-GEMM kernel's result up to fp32 summation order."""
     code, td, ulp = TYPES[ty]
-    g = torch.Generator().manual_seed(cout + pad)
+    g = torch.Generator().manual_seed(cout + pad + cin)
     ih, iw = hw
-    x = rnd(torch.randn(3, ih, iw, 32, generator=g), td)
-    w = rnd(torch.randn(3, 3, 32, cout, generator=g) * 0.06, td)
+    x = rnd(torch.randn(3, ih, iw, cin, generator=g), td)
+    w = rnd(torch.randn(3, 3, cin, cout, generator=g) * 0.06, td)
     scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
     res = rnd(torch.randn(3, oh, ow, cout, generator=g), td)
-    ref = oracle_conv(x, w, 1, "SAME" if pad else "VALID", scale, shift, True, residual=res)
+    ref = oracle_conv(x, w, 1, (pad, pad, pad, pad) if pad == 2 else ("SAME" if pad else "VALID"), scale, shift, True, residual=res)
     y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=special_tile(), y_ld=cout + 16, y_off=8)
     close(y, ref.numpy(), ulp)
     y0 = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, residual=res, tile=0, y_ld=cout + 16, y_off=8)
