@@ -1364,7 +1364,7 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     };
     int ti = side(d->cin), to = side(d->cout);
     int64_t target = 2048;
-    if (d->tile_cfg > 30)                                        // 31..42: LDS-DMA staging (wgrad_dma.hip)
+    if (d->tile_cfg > 30)                                        // 31..54: LDS-DMA staging (wgrad_dma.hip)
         return gvlp::conv_wgrad_dma_launch(d, x, dz, dz_ld, dw, d->tile_cfg - 31, st);
     if (d->tile_cfg > 27) {                                      // 28..30: strip form, 1024 / 2048 / 4096 workgroups
         return strip_t<T>(d, x, dz, dz_ld, dw, 1024 << (d->tile_cfg - 28), st);
@@ -1373,6 +1373,13 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     // runs at one wave per SIMD and loses to the tap-per-workgroup tiles — autotune may still pick it (cfg 13-15)
     if (d->tile_cfg == 0 && g_strip_default && d->cin <= 32) {
         const int rc = strip_t<T>(d, x, dz, dz_ld, dw, 2048, st);
+        if (rc != GV_E_UNSUPPORTED) return rc;
+    }
+    if (d->tile_cfg == 0) {
+        // un-tuned default: the two-stage LDS-DMA form (fastest on 64 of Inception-v3's 67 layers), 128-channel sides
+        // where the layer has them, ~2048 workgroups; the tap-per-workgroup tiles below where it does not take the layer
+        const int shape = (d->cin >= 128 ? 1 : 0) + (d->cout >= 128 ? 2 : 0);
+        const int rc = gvlp::conv_wgrad_dma_launch(d, x, dz, dz_ld, dw, 12 + 4 + shape, st);
         if (rc != GV_E_UNSUPPORTED) return rc;
     }
     if (d->tile_cfg > 0) {                                       // 1..27: tile (TI, TO) in {1,2,3}^2 x workgroup target

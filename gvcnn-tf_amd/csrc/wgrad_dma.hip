@@ -284,19 +284,25 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
 
 namespace gvlp {
 
-// k = 0..11: (TI, TO) in {1,2}^2 x workgroup target 1024 / 2048 / 4096
-int wgrad_dma_num_cfgs() { return 12; }
+// k = 0..11: (TI, TO) in {1,2}^2 x workgroup target 1024 / 2048 / 4096 on a four-stage ring (16 - 64 KB: two to four
+// workgroups per CU); k = 12..23: the same on TWO stages (8 - 32 KB: five and more per CU — as in the forward kernels a
+// resident neighbour covers a workgroup's barriers and its atomic epilogue better than ring depth does)
+int wgrad_dma_num_cfgs() { return 24; }
 
 int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, int k, hipStream_t st) {
-    if (k < 0 || k >= 12) return GV_E_BADARG;
-    const int shape = k % 4;
-    const int64_t target = 1024ll << (k / 4);
+    if (k < 0 || k >= 24) return GV_E_BADARG;
+    const int shape = k % 4 + (k >= 12 ? 4 : 0);
+    const int64_t target = 1024ll << ((k % 12) / 4);
 #define GV_WD(T)                                                                                        \
     switch (shape) {                                                                                    \
         case 0: return launch_wgrad_dma<T, 1, 1, 4>(d, x, dz, dz_ld, dw, target, st);                   \
         case 1: return launch_wgrad_dma<T, 2, 1, 4>(d, x, dz, dz_ld, dw, target, st);                   \
         case 2: return launch_wgrad_dma<T, 1, 2, 4>(d, x, dz, dz_ld, dw, target, st);                   \
-        default: return launch_wgrad_dma<T, 2, 2, 4>(d, x, dz, dz_ld, dw, target, st);                  \
+        case 3: return launch_wgrad_dma<T, 2, 2, 4>(d, x, dz, dz_ld, dw, target, st);                   \
+        case 4: return launch_wgrad_dma<T, 1, 1, 2>(d, x, dz, dz_ld, dw, target, st);                   \
+        case 5: return launch_wgrad_dma<T, 2, 1, 2>(d, x, dz, dz_ld, dw, target, st);                   \
+        case 6: return launch_wgrad_dma<T, 1, 2, 2>(d, x, dz, dz_ld, dw, target, st);                   \
+        default: return launch_wgrad_dma<T, 2, 2, 2>(d, x, dz, dz_ld, dw, target, st);                  \
     }
     if (d->dtype == GV_BF16) { GV_WD(__bf16) }
     if (d->dtype == GV_F16) { GV_WD(_Float16) }

@@ -327,7 +327,7 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
     dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
     n = lib().gv_conv2d_wgrad_num_cfgs(dt)
-    assert n == 42 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 12 LDS-DMA
+    assert n == 54 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 24 LDS-DMA
     outs = []
     for cfg in range(n + 1):
         dw = torch.zeros(3, 3, cin, cout, device=DEV)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer time of the 16-bit filter gradient: best tile-per-tap cfg (1..27), best strip cfg (28..30), best LDS-DMA cfg
-(31..42).    python tools/wgrad_cfg_probe.py [--shapes 32]"""
+(31..42 four stages, 43..54 two stages).    python tools/wgrad_cfg_probe.py [--shapes 32]"""
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +20,7 @@ eng.backward()
 torch.cuda.synchronize()
 st = torch.cuda.current_stream().cuda_stream
 n = lib.gv_conv2d_wgrad_num_cfgs(eng.dt)
-tot = [0.0, 0.0, 0.0, 0.0]
+tot = [0.0, 0.0, 0.0, 0.0, 0.0]
 for op in eng.plan.ops:
     if op["kind"] != "conv":
         continue
@@ -40,16 +40,16 @@ for op in eng.plan.ops:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
-        fam = 0 if cfg == 0 else (1 if cfg <= 27 else (2 if cfg <= 30 else 3))
+        fam = 0 if cfg == 0 else (1 if cfg <= 27 else (2 if cfg <= 30 else (3 if cfg <= 42 else 4)))
         if fam not in best or ms < best[fam][0]:
             best[fam] = (ms, cfg)
     op["tile_w"] = 0
     flops = 2.0 * y.nb * y.h * y.w * op["kh"] * op["kw"] * xx.c * y.c
     row = " ".join("%s %.4f(c%d)" % (nm, best[f][0], best[f][1]) if f in best else "%s --" % nm
-                   for f, nm in enumerate(("default", "tile", "strip", "dma")))
+                   for f, nm in enumerate(("default", "tile", "strip", "dma", "dma2")))
     print("%-52s cin=%4d cout=%4d k=%dx%d s%d M=%8d  %s  best %.0f TF/s" % (
         op["name"][-52:], xx.c, y.c, op["kh"], op["kw"], op["stride"], y.nb * y.h * y.w, row,
         flops / min(v[0] for v in best.values()) / 1e9))
-    for f in range(4):
+    for f in range(5):
         tot[f] += best[f][0] if f in best else min(v[0] for v in best.values())
-print("sum: default %.3f  tile %.3f  strip %.3f  dma %.3f ms" % tuple(tot))
+print("sum: default %.3f  tile %.3f  strip %.3f  dma %.3f  dma2 %.3f ms" % tuple(tot))
