@@ -752,6 +752,37 @@ def test_stream_lanes_reproduce_the_single_stream_step(storage):
                     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("backbone,storage,size", [("inception_v3", "bf16", 171), ("resnet_v2_50", "bf16", 96), ("inception_v3", "f32", 139)])
+def test_recorded_argmax_pools_reproduce_the_recomputing_step(backbone, storage, size):
+    """TrainGVCNN.pool_argmax (the max pools record their winners in the forward pass, the backward pass routes dy by the
+    record) against the form that recomputes the winners from x: the same loss, activations and (16-bit storage: both
+    backward forms are deterministic gathers of the same values) activation gradients bit for bit, the same parameter
+    gradients to the rounding of their atomic sums."""
+    N, V = 3, 2
+    x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(7)) - 0.5).to(DEV)
+    labels = torch.tensor([1, 4, 2]).to(DEV)
+    out = []
+    for amax in (True, False):
+        eng = TrainGVCNN(backbone, N, V, size, size, 5, 10, device=DEV, storage=storage, seed=5)
+        eng.pool_argmax = amax
+        eng.forward(x, labels, check=False)
+        eng.backward()
+        torch.cuda.synchronize()
+        assert any("argmax" in op for op in eng.plan.ops) == amax
+        out.append((float(eng.loss), eng._flat_g.clone(), [a.clone() for a in eng.act],
+                    [g.clone() if g is not None else None for g in eng.grad]))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][2], out[1][2]):
+        assert torch.equal(a, b)
+    if storage == "bf16":                                 # activation gradients: the same values gathered in the same order
+        for a, b in zip(out[0][3], out[1][3]):
+            if b is not None:
+                mask = ~torch.isnan(b.float())            # (unwritten regions keep whatever they held)
+                assert torch.equal(a[mask], b[mask])
+    # parameter gradients: the filter gradient adds its pixel slices with fp32 atomics, so two runs agree to rounding only
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-5 * float(out[1][1].abs().max())
+
+
 def test_bf16_training_autotune_and_per_shape_step_runs():
     eng = TrainGVCNN("inception_v3", 2, 3, 139, 139, 10, 10, device=DEV, storage="bf16", per_shape=True)
     x = (torch.rand(2, 3, 139, 139, 3, generator=torch.Generator().manual_seed(4)) - 0.5).to(DEV)
