@@ -929,8 +929,7 @@ int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
                        (uint64_t)a.M * a.y_ld * 4 < 0xffffffffull;
 #define GV_HALO_LAUNCH(B, P, W)                                                                                     \
     {                                                                                                               \
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3<B, P, W>),              \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
+        const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_x3<B, P, W>), 160 * 1024);                                   \
         if (!ok) return GV_E_UNSUPPORTED;                                                                           \
         hipLaunchKernelGGL((conv3x3_halo_x3<B, P, W>), grid, dim3(256), lds, st, a);                                \
         GV_LAUNCH_CHECK();                                                                                          \
@@ -938,8 +937,7 @@ int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
     }
 #define GV_HALO_K32(B, P)                                                                                           \
     {                                                                                                               \
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_x3_k32<B, P>),             \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
+        const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_x3_k32<B, P>), 160 * 1024);                                   \
         if (!ok) return GV_E_UNSUPPORTED;                                                                           \
         hipLaunchKernelGGL((conv3x3_halo_x3_k32<B, P>), grid, dim3(256), lds32, st, a);                             \
         GV_LAUNCH_CHECK();                                                                                          \
@@ -1132,8 +1130,7 @@ int launch_stem_x3_one(const ConvArgs& a, hipStream_t st) {
     constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;
     const size_t lds = (size_t)3 * PR * PITCH + 4 * 32 * 36 * 4 + (size_t)3 * 32 * TN * (NG * 16 + 16);
     if (lds > 64 * 1024) {
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_patch_x3<TN, KW>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        const bool ok = GV_BIG_LDS_OK((&conv_stem_patch_x3<TN, KW>), 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
     }
     hipLaunchKernelGGL((conv_stem_patch_x3<TN, KW>), dim3((unsigned)(a.nb * ((a.ow + 31) / 32))), dim3(256), lds, st, a);
@@ -1186,15 +1183,13 @@ int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
     }
     if (generic) {
         if (lds > 64 * 1024) {
-            static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            const bool ok = GV_BIG_LDS_OK((&conv_igemm_bf16s<WM, WN, TM, TN, NP, true>), 160 * 1024);
             if (!ok) return GV_E_UNSUPPORTED;
         }
         hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, true>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
     } else {
         if (lds > 64 * 1024) {
-            static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_bf16s<WM, WN, TM, TN, NP, false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            const bool ok = GV_BIG_LDS_OK((&conv_igemm_bf16s<WM, WN, TM, TN, NP, false>), 160 * 1024);
             if (!ok) return GV_E_UNSUPPORTED;
         }
         hipLaunchKernelGGL((conv_igemm_bf16s<WM, WN, TM, TN, NP, false>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);

@@ -590,8 +590,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
                        (dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() ? 4 * BN * sizeof(float) : 0);
     auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI>;
     if (lds > 64 * 1024) {
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             160 * 1024) == hipSuccess;
+        const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);

@@ -307,11 +307,7 @@ int launch_cfg(const ConvArgs& a0, bool generic, hipStream_t st) {
         }
     }
     if (lds > 64 * 1024) {
-        static bool once = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_f32<WM, WN, TM, TN, NCH, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        }();
-        if (!once) return GV_E_UNSUPPORTED;
+        if (!GV_BIG_LDS_OK((&conv_igemm_f32<WM, WN, TM, TN, NCH, false>), 160 * 1024)) return GV_E_UNSUPPORTED;
     }
     hipLaunchKernelGGL((conv_igemm_f32<WM, WN, TM, TN, NCH, false>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     GV_LAUNCH_CHECK();

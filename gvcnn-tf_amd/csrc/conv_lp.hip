@@ -731,8 +731,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false>
 int launch_one(const ConvArgs& a, int64_t nwg, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        const bool ok = GV_BIG_LDS_OK((&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>), 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
     }
     hipLaunchKernelGGL((conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
@@ -797,8 +796,7 @@ int launch_halo_r(const ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, RPW>), grid, dim3(256), lds, st, a);
     } else {
         const size_t lds = halo + (RPW == 2 ? 0 : 4 * 32 * (32 + 4) * 4) + 64 * (288 * 2 + 16);   // (RPW = 2: staging aliases the halo)
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 2, RPW>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 2, RPW>), 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
         hipLaunchKernelGGL((conv3x3_halo_lp<T, 2, RPW>), grid, dim3(256), lds, st, a);
     }
@@ -810,8 +808,7 @@ template <typename T>
 int launch_halo64(const ConvArgs& a, hipStream_t st) {                       // 64 input channels, <= 32 output channels
     const int tiles_x = (a.ow + 31) / 32;
     const size_t lds = (size_t)6 * 34 * (64 * 2 + 16) + 32 * (9 * 64 * 2 + 16);      // (staging aliases the halo)
-    static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_lp<T, 1, 1, 64>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 1, 1, 64>), 160 * 1024);
     if (!ok) return GV_E_UNSUPPORTED;
     hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, 1, 64>), dim3((unsigned)(a.nb * tiles_x)), dim3(256), lds, st, a);
     GV_LAUNCH_CHECK();

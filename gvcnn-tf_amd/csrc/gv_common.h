@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "gvcnn_hip.h"
 
 #define GV_HIP_CHECK(expr)                           \
@@ -17,8 +19,41 @@
         if (_e != hipSuccess) return (int)_e;        \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting and one process may drive several GPUs
+// (model.pin_device): remember its outcome per device, not per process.
+struct GvPerDeviceOnce {
+    std::atomic<signed char> state[64] = {};                     // 0 = not tried, 1 = ok, -1 = failed
+    template <typename F>
+    bool ok(F&& set) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+        signed char v = state[dev].load(std::memory_order_acquire);
+        if (v == 0) {
+            v = set() == hipSuccess ? 1 : -1;
+            state[dev].store(v, std::memory_order_release);
+        }
+        return v > 0;
+    }
+};
+// true when `kernel` may be launched with `bytes` of dynamic LDS on the current device
+#define GV_BIG_LDS_OK(kernel, bytes)                                                                              \
+    ([&] {                                                                                                        \
+        static GvPerDeviceOnce once_;                                                                             \
+        return once_.ok([&] {                                                                                     \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)(bytes));                                                             \
+        });                                                                                                       \
+    }())
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Every pooling window must hold at least one valid tap (else an average divides 0 by 0 and a max writes -inf / a 0xff
+// argmax byte): the last window starts inside the image and the padding is smaller than the window.
+static inline bool gv_pool_geometry_ok(const gv_pool_desc* d) {
+    return d->pad_t < d->kh && d->pad_l < d->kw && (int64_t)(d->oh - 1) * d->stride - d->pad_t < d->ih &&
+           (int64_t)(d->ow - 1) * d->stride - d->pad_l < d->iw;
+}
 
 static inline int gv_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool gv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -9,6 +9,7 @@
 #include <new>
 #include <vector>
 
+#include "conv_common.h"
 #include "gv_common.h"
 
 namespace {
@@ -330,6 +331,9 @@ struct gv_graph {
 
 extern "C" int gv_capture_begin(void* stream) {
     if (!stream) return GV_E_BADARG;                       // the legacy default stream cannot be captured
+    // the LDS-DMA kernels' zero page is allocated (hipMalloc + hipMemset) on first use: do that BEFORE the capture
+    // starts, or the first such launch under capture would invalidate it
+    if (!gvconv::dma_zero_page()) return GV_E_UNSUPPORTED;
     GV_HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
     return GV_OK;
 }

@@ -247,6 +247,7 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
         d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
         return GV_E_BADARG;
     if (d->x_ld < d->c || d->y_ld < d->c) return GV_E_BADARG;
+    if (!gv_pool_geometry_ok(d)) return GV_E_BADARG;             // (every dtype and storage form: checked before any branch)
     const bool xp3 = (d->mode & GV_POOL_X_P3) != 0, yp3 = (d->mode & GV_POOL_Y_P3) != 0;
     const int mode = d->mode & ~(GV_POOL_X_P3 | GV_POOL_Y_P3);
     if (mode != GV_POOL_MAX && mode != GV_POOL_AVG && mode != GV_POOL_AVG_RELU) return GV_E_BADARG;

@@ -994,6 +994,7 @@ extern "C" int gv_pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* 
     if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->c <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->oh <= 0 ||
         d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0 || d->x_ld < d->c || d->y_ld < d->c || d->mode != GV_POOL_MAX)
         return GV_E_BADARG;
+    if (!gv_pool_geometry_ok(d)) return GV_E_BADARG;
     if (d->kh * d->kw > 255) return GV_E_UNSUPPORTED;               // the tap index is one byte
     if (d->dtype != GV_F32 && d->dtype != GV_BF16 && d->dtype != GV_F16) return GV_E_UNSUPPORTED;
     return gvlp::pool2d_fwd_argmax(d, x, y, argmax, (hipStream_t)stream);
@@ -1006,6 +1007,7 @@ extern "C" int gv_pool2d_bwd_argmax(const gv_pool_desc* d, const uint8_t* argmax
         d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0 || dy_ld < d->c || dx_ld < d->c ||
         (d->mode & ~GV_POOL_BWD_STORE) != GV_POOL_MAX)
         return GV_E_BADARG;
+    if (!gv_pool_geometry_ok(d)) return GV_E_BADARG;
     if (d->dtype != GV_F32 && d->dtype != GV_BF16 && d->dtype != GV_F16) return GV_E_UNSUPPORTED;
     return gvlp::pool2d_bwd_argmax(d, argmax, dy, dy_ld, dx, dx_ld, (hipStream_t)stream);
 }

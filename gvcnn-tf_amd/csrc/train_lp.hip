@@ -1327,8 +1327,7 @@ int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned 
     splits = (gm.stages + gm.stages_per_block - 1) / gm.stages_per_block;
     const size_t lds = (size_t)32 * (BO == 32 ? 64 : 2 * BO + 64) + (size_t)gm.xrows * (BI == 32 ? 64 : 2 * BI + 64);
     auto kern = conv_wgrad_strip_lp<T, WI, WJ, WT, NTW>;
-    static bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           64 * 1024) == hipSuccess;
+    const bool attr = GV_BIG_LDS_OK(kern, 64 * 1024);
     (void)attr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, x, dz, gm, tpg, dw);
     GV_LAUNCH_CHECK();

@@ -247,6 +247,9 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
     if (M >= 0x7fffffff || (int64_t)d->nb * d->ih * d->iw * d->x_ld * 2 >= 0x7fffffffffffll) return GV_E_UNSUPPORTED;
     if (d->ow >= 32768 || d->oh >= 32768) return GV_E_UNSUPPORTED;
+    // ceil(2^32 / 1) does not fit 32 bits (wmagic(1) == 0: the pixel walk would never carry into oy / n and every stage
+    // after the first would read the zero page): 1-wide / 1-high maps go to the tap-per-workgroup tiles
+    if (d->ow < 2 || d->oh < 2) return GV_E_UNSUPPORTED;
     WgradGeo g;
     g.x = (const unsigned short*)x;
     g.dz = (const unsigned short*)dz;
@@ -271,9 +274,7 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
     const size_t lds = (size_t)ST * 32 * 2 * (BI + BO);
     auto kern = &conv_wgrad_dma<T, TI, TO, ST>;
     if (lds > 64 * 1024) {
-        static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             160 * 1024) == hipSuccess;
-        if (!ok) return GV_E_UNSUPPORTED;
+        if (!GV_BIG_LDS_OK(kern, 160 * 1024)) return GV_E_UNSUPPORTED;      // (per device)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, g);
     GV_LAUNCH_CHECK();

@@ -506,10 +506,14 @@ class ShardedTrainGVCNN:
         jobs, blocks, off = [], [], 0
         for op in bns:
             c, hw = op["x"].c, op["x"].h * op["x"].w
-            if hw not in self._mv_counts:
-                self._mv_counts[hw] = torch.full((eng.Vh,), eng.N * hw, dtype=torch.int32, device=full.device)
+            # samples per (view, channel) statistic: the sums were reduced over the rank's shape group (bn_sync), so the
+            # count — and the unbiased-variance factor n/(n-1) of the update — is the GLOBAL one, as eng._count() uses
+            key = (hw, eng.shape_world)
+            if key not in self._mv_counts:
+                self._mv_counts[key] = torch.full((eng.Vh,), eng.N * eng.shape_world * hw, dtype=torch.int32,
+                                                  device=full.device)
             jobs.append(_lib.BnMovingJob(full.data_ptr() + 4 * off, full.data_ptr() + 4 * (off + c),
-                                         self._mv_counts[hw].data_ptr(),
+                                         self._mv_counts[key].data_ptr(),
                                          eng.params[op["name"] + "/moving_mean"].data_ptr(),
                                          eng.params[op["name"] + "/moving_variance"].data_ptr(), c, len(blocks), ld, 0))
             blocks.extend([len(jobs) - 1] * ((c + 255) // 256))

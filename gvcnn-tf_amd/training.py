@@ -862,7 +862,7 @@ class TrainGVCNN:
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
             if self._claim(x):                                # first contribution: the gather kernels store
                 d.mode |= _lib.GV_POOL_BWD_STORE
-            if "argmax" in op:
+            if self.pool_argmax and "argmax" in op:          # (a record left by an earlier pool_argmax = True pass is stale)
                 _lib.check(lib.gv_pool2d_bwd_argmax(C.byref(d), op["argmax"].data_ptr(), self._ptr(y, True), y.ld,
                                                     self._ptr(x, True), x.ld, _st()), "pool_bwd (argmax) " + op["name"])
             else:

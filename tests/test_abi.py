@@ -81,6 +81,17 @@ def test_bad_arguments_return_codes(lib):
     assert lib.gv_pool2d_bwd_argmax(C.byref(pm), None, 16, 4, 16, 4, None) == -1
     p = _lib.PoolDesc(1, 8, 8, 4, 4, 3, 3, 2, 0, 0, 3, 3, 4, 5, _lib.GV_F32)   # bad mode
     assert lib.gv_pool2d_fwd(C.byref(p), 16, 16, None) == -1
+    # a window without a valid tap (0/0 in an average, -inf / a 0xff argmax byte in a max) is a bad descriptor for every
+    # dtype and storage form: last window starting past the image, padding >= window
+    for mode in (_lib.GV_POOL_MAX, _lib.GV_POOL_AVG, _lib.GV_POOL_AVG | _lib.GV_POOL_X_P3):
+        for dt in (_lib.GV_F32, _lib.GV_BF16):
+            past = _lib.PoolDesc(1, 8, 8, 16, 16, 3, 3, 2, 0, 0, 6, 3, 16, mode, dt)      # (6-1)*2 = 10 >= ih = 8
+            assert lib.gv_pool2d_fwd(C.byref(past), 16, 16, None) == -1
+            wide = _lib.PoolDesc(1, 8, 8, 16, 16, 3, 3, 1, 1, 3, 8, 8, 16, mode, dt)      # pad_l = 3 >= kw = 3
+            assert lib.gv_pool2d_fwd(C.byref(wide), 16, 16, None) == -1
+    past = _lib.PoolDesc(1, 8, 8, 16, 16, 3, 3, 2, 0, 0, 3, 6, 16, _lib.GV_POOL_MAX, _lib.GV_BF16)
+    assert lib.gv_pool2d_fwd_argmax(C.byref(past), 16, 16, 16, None) == -1
+    assert lib.gv_pool2d_bwd_argmax(C.byref(past), 16, 16, 16, 16, 16, None) == -1
     assert lib.gv_group_assign(None, 6, 10, 10, None, None, None, None, None) == -1
     assert lib.gv_group_assign(16, 65, 10, 10, 16, 16, 16, 16, None) == -2        # V > 64
     assert lib.gv_view_pool_fuse_fwd(16, 6, 2, 64, 64, 384, 16, 10, 16, 9, 1.0, None, 16, 0, None) == -1
