@@ -68,6 +68,10 @@ def parse():
                          "descriptors, every rank pools all shapes; 'scores' exchanges only the scorer responses (each "
                          "rank pools the shapes it owns).  The N > 1 line reports the other one too (other_exchange)")
     ap.add_argument("--no-other-exchange", action="store_true", help="N > 1: time only --exchange")
+    ap.add_argument("--gather", default="collective", choices=["collective", "direct"],
+                    help="N > 1: how a gather travels — 'collective' = RCCL all_gather_into_tensor (the library picks ring / "
+                         "tree), 'direct' = one point-to-point send to and receive from EVERY peer (each xGMI link carries "
+                         "one shard: SURVEY 8e's one-shot all-gather).  The N > 1 line times the other one too (other_gather)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, --exchange allgather: gather and pool inside the step instead of overlapping the "
                          "all-gather of step k with the backbone of step k+1 (ShardedGVCNN(overlap=True))")
@@ -112,16 +116,18 @@ def parse():
 
 
 def roofline(eng, x, math, iters=10, traffic=None):
-    """Per-launch hipEvent timing (on the launch stream) of every implicit-GEMM conv launch of one
-    step; achieved = algorithmic conv FLOPs of the step / summed conv kernel time."""
+    """Every implicit-GEMM conv launch of one step timed IN SEQUENCE (gv_plan_time_each: `iters` whole passes of the
+    plan in launch order, an event behind every op — a launch is timed behind its real predecessor, not as a warm
+    repeat of itself); achieved = algorithmic conv FLOPs of the step / summed conv launch time."""
     plan = eng.plan
     flops = t_ms = 0.0
     n = 0
     worst = None
+    each = plan.time_each(x, iters)
     for i, op in enumerate(plan.ops):
         if op["kind"] != "conv":
             continue
-        ms = plan.time_range(x, i, 1, iters)
+        ms = each[i]
         flops += op["flops"]
         t_ms += ms
         n += 1
@@ -137,7 +143,8 @@ def roofline(eng, x, math, iters=10, traffic=None):
     n_hbm = sum(1 for op in plan.ops if op["kind"] == "conv" and op["bytes"] / HBM_PEAK > op["flops"] / (peak * 1e12))
     attainable = flops / t_min / 1e12
     alg_bytes = sum(op["bytes"] for op in plan.ops if op["kind"] == "conv") / n
-    return {"bound": "mfma", "kernel": "%s; %d launches/step, every one timed" % (kname, n), "math": how,
+    return {"bound": "mfma", "kernel": "%s; %d launches/step, every one timed in sequence" % (kname, n), "math": how,
+            "timing": "hipEvents behind every op over %d whole passes of the plan in launch order (single lane)" % iters,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "attainable": round(attainable, 1), "frac_of_attainable": round(achieved / attainable, 4),
@@ -248,11 +255,11 @@ def _is_conv_kernel(n):
     return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n
 
 
-def _pmc_rows(path, counter, steps):
+def _pmc_rows(path, counter, steps, marker="dense_f32"):
     import csv
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ends = [i for i, r in enumerate(rows) if "dense_f32" in r["Kernel_Name"]]   # one step ends with the classifier
+    ends = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]   # one step ends with the classifier (forward) / the optimizer (training)
     start = ends[-steps - 1] + 1 if len(ends) > steps else 0
     return rows[start:]
 
@@ -304,7 +311,128 @@ def measure_traffic(a, tiles_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def train_main(a, world, rank, dev):
+TRAIN_FAMILIES = (("wgrad", ("conv_wgrad",)), ("conv", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma")),
+                  ("bn", ("grouped_sums", "bn_stream", "scale_shift_act_grouped", "bn_bwd_apply")),
+                  ("pool", ("pool2d", "maxpool", "avgpool3x3")))
+
+
+def _train_family(kernel_name):
+    for fam, keys in TRAIN_FAMILIES:
+        if any(k in kernel_name for k in keys):
+            return fam
+    return "other"
+
+
+def measure_traffic_train(a):
+    """HBM bytes per step of the training step, by kernel family, from two rocprofv3 --pmc child passes (FETCH_SIZE x2
+    gfx950 correction, WRITE_SIZE; KiB units: MI355X_MICROARCH.md, HBM) of this same command; run BEFORE this process
+    touches the GPU, program directly behind `--`."""
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return {"note": "rocprofv3 not found: traffic not measured"}
+    steps = 2
+    tmp = tempfile.mkdtemp(prefix="gvbench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    base = [sys.executable, os.path.abspath(__file__), "--train", "--pmc-child", "1", "--preset", a.preset, "--storage",
+            a.storage, "--shapes", str(a.shapes), "--steps", str(steps), "--warmup", "1"]
+    fam_bytes = {}
+    try:
+        for tag, counter, mult in (("f", "FETCH_SIZE", 2048.0), ("w", "WRITE_SIZE", 1024.0)):
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, tag), "-o", tag,
+                   "--output-format", "csv", "--"] + base
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                               timeout=600)
+            files = glob.glob(os.path.join(tmp, tag, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"note": "rocprofv3 --pmc %s pass failed (rc %d): traffic not measured: %s"
+                                % (counter, r.returncode, r.stderr[-200:].replace("\n", " "))}
+            for row in _pmc_rows(files[0], counter, steps, marker="sgd_momentum"):
+                fam = _train_family(row["Kernel_Name"])
+                d = fam_bytes.setdefault(fam, {"fetch": 0.0, "write": 0.0, "launches": 0})
+                d["fetch" if tag == "f" else "write"] += float(row["Counter_Value"]) * mult / steps
+                if tag == "f":
+                    d["launches"] += 1
+        for d in fam_bytes.values():
+            d["launches"] = d["launches"] / steps
+        return {"families": fam_bytes, "steps": steps,
+                "note": "measured in this run: HBM bytes per step and kernel family from two rocprofv3 --kernel-trace --pmc "
+                        "child passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE; KiB units) over %d steps of this same "
+                        "command" % steps}
+    except Exception as e:                                  # the profiler must never take the bench line down
+        return {"note": "traffic not measured: %s" % (str(e)[:200],)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def train_roofline(eng, x, labels, storage, traffic, steps=3):
+    """`roofline` of the training line.  Every launch of `steps` whole steps is timed IN SEQUENCE (gvcnn_tf_amd.steptime:
+    an event pair around every entry-point call while a real step runs).  MFMA side: the algorithmic FLOPs of the
+    convolution-shaped launches — forward, data gradient (every convolution but the first), filter gradient, 2*M*N*K
+    each — over their summed launch time, against the dense 16-bit MFMA peak.  HBM side: BatchNorm and pooling launches,
+    algorithmic bytes over their summed time against 8 TB/s; a train-mode BatchNorm is priced at what it cannot avoid
+    once its sums ride on the launches that produce z and dy: read z + write y forward, read dy + read z + write dz
+    backward = 5 elements moved per activation element (the separate sums passes move 3 more)."""
+    from gvcnn_tf_amd import steptime
+    es = 4 if storage == "f32" else 2
+    recs = steptime.timed_step(eng, x, labels, steps=steps)
+    fam = {}
+    for st in recs:
+        for k, (ms, n) in steptime.by_family(st).items():
+            t, c = fam.get(k, (0.0, 0))
+            fam[k] = (t + ms / steps, c + n / steps)
+    ops = eng.plan.ops
+    f_fwd = sum(op["flops"] for op in ops if op["kind"] == "conv")
+    f_dg = sum(op["flops"] for op in ops if op["kind"] == "conv" and op["x"].vbuf >= 0)
+    flops = {"conv": f_fwd, "dgrad": f_dg, "wgrad": f_fwd}
+    peak = PEAK_BF16_MFMA_TFLOPS if storage != "f32" else PEAK_BF16_MFMA_TFLOPS / 6
+    tr = (traffic or {}).get("families", {})
+
+    def mfma(keys):
+        t = sum(fam.get(k, (0.0, 0))[0] for k in keys)
+        n = sum(fam.get(k, (0.0, 0))[1] for k in keys)
+        fl = sum(flops[k] for k in keys)
+        ach = fl / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "flops_per_step": fl, "ms_per_step": round(t, 3), "launches_per_step": round(n)}
+    bn_el = sum(op["x"].npix * op["x"].c for op in ops if op["kind"] == "bn")
+    pool_b = 0.0
+    for op in ops:
+        if op["kind"] == "pool":
+            i, o = op["x"].npix * op["x"].c, op["y"].npix * op["y"].c
+            arg = o if op["mode"] == 0 else 0                        # the recorded argmax byte of a max pool
+            pool_b += (i + o) * es + arg + (o * es + arg + i * es)
+
+    def hbm(key, nbytes, traffic_keys):
+        t, n = fam.get(key, (0.0, 0))
+        ach = nbytes / (t * 1e-3) / 1e9 if t > 0 else 0.0
+        got = [tr[k] for k in traffic_keys if k in tr]
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(ach / (HBM_PEAK / 1e9), 4), "algorithmic_bytes_per_step": nbytes, "ms_per_step": round(t, 3),
+                "launches_per_step": round(n),
+                "traffic": round(sum(g["fetch"] + g["write"] for g in got)) if got else None}
+    allm = mfma(("conv", "dgrad", "wgrad"))
+    got = [tr[k] for k in ("conv", "wgrad") if k in tr]
+    out = dict(allm)
+    out["kernel"] = ("all convolution-shaped launches of the step: forward + data gradient (conv_dma<NP=1> / conv_igemm_lp / "
+                     "halo / strip kernels) and filter gradient (conv_wgrad_dma / conv_wgrad_lp)")
+    out["traffic"] = round(sum(g["fetch"] + g["write"] for g in got)) if got else None
+    out["traffic_note"] = (traffic or {}).get("note", "not measured")
+    out["timing"] = "hipEvent pair around every launch of %d whole steps, in sequence (gvcnn_tf_amd/steptime.py)" % steps
+    out["conv"] = mfma(("conv", "dgrad"))
+    out["wgrad"] = mfma(("wgrad",))
+    out["bn"] = hbm("bn", 5.0 * bn_el * es, ("bn",))
+    out["bn"]["folded_sums"] = {"forward": sum(1 for op in ops if op.get("_st_f_done")),
+                                "backward": sum(1 for op in ops if op.get("_st_b_done")),
+                                "batchnorm_layers": sum(1 for op in ops if op["kind"] == "bn")}
+    out["pool"] = hbm("pool", pool_b, ("pool",))
+    out["in_sequence_ms_per_step"] = {k: round(v[0], 3) for k, v in sorted(fam.items())}
+    return out
+
+
+def train_main(a, world, rank, dev, traffic=None):
     """One JSON line for the training step (not the driver's bench line)."""
     from gvcnn_tf_amd.training import TrainGVCNN
     from gvcnn_tf_amd.sharding import ShardedTrainGVCNN, view_shard_range
@@ -351,6 +479,8 @@ def train_main(a, world, rank, dev):
         sh.train_step(x, labels, lr=1e-6)
     barrier()
     dt = time.perf_counter() - t0
+    if a.pmc_child:
+        return
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -360,7 +490,10 @@ def train_main(a, world, rank, dev):
     if rank == 0:
         ms = dt / a.steps * 1e3
         flops = 3.0 * sum(op.get("flops", 0) for op in eng.plan.ops) * world
-        print(json.dumps({
+        roof = {}
+        if world == 1 and not a.no_roofline:
+            roof = {"roofline": train_roofline(eng, x, labels, a.storage, traffic)}
+        print(json.dumps({**{
             "metric": "views/sec (training step)", "value": round(views_per_step / (ms * 1e-3), 1), "unit": "views/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong" if a.dp == "views" else "weak", "vs_baseline": None,
@@ -371,7 +504,7 @@ def train_main(a, world, rank, dev):
                                                        "fp32 storage, bf16x3 math" if a.storage == "f32" else
                                                        a.storage + " activations and gradients on the 16-bit MFMA, fp32 "
                                                        "master weights", a.dp), "views_per_gpu": views_local},
-            "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}), flush=True)
+            "step_tflops": round(flops / (ms * 1e-3) / 1e12, 2)}, **roof}), flush=True)
 
 
 def main():
@@ -416,6 +549,9 @@ def main():
         else:
             traffic = {"note": "traffic not measured: no tile table from the tuning child"}
 
+    if world == 1 and a.train and not a.pmc_child and not a.no_roofline and not a.no_traffic:
+        traffic = measure_traffic_train(a)                  # (children; this process has not touched the GPU yet)
+
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if a.same_device:
         local_rank = 0
@@ -430,7 +566,7 @@ def main():
     import gvcnn_tf_amd as gv
     from gvcnn_tf_amd.sharding import ShardedGVCNN
     if a.train:
-        return train_main(a, world, rank, dev)
+        return train_main(a, world, rank, dev, traffic)
 
     N = a.shapes
     eng = gv.GVCNN(BACKBONE, N, V, H, W, C, G, device=dev, num_bins=G, math=a.math if a.storage == "f32" else "f32",
@@ -439,7 +575,7 @@ def main():
     Hd = gv.params.init_head_params(V, eng.raw.c, eng.final.c, C, seed=3, spread_scores=True)
     eng.plan.bind(P)
     eng.set_head(Hd)
-    sh = ShardedGVCNN(eng, exchange=a.exchange, overlap=not a.no_overlap)
+    sh = ShardedGVCNN(eng, exchange=a.exchange, overlap=not a.no_overlap, gather_mode=a.gather)
     x = (torch.rand(N, V, H, W, 3, generator=torch.Generator().manual_seed(rank)) - 0.5).to(dev)
 
     def barrier():
@@ -491,12 +627,19 @@ def main():
     eng.check_status()
     if a.pmc_child:
         return
-    other = None
+    other = other_g = None
     if world > 1 and not a.no_other_exchange:
         name = "scores" if a.exchange == "allgather" else "allgather"
-        sh2 = ShardedGVCNN(eng, exchange=name)
+        sh2 = ShardedGVCNN(eng, exchange=name, gather_mode=a.gather)
         dt2 = timed(lambda: sh2.forward(x, check=False))
         other = (name, dt2)
+        if a.exchange == "allgather":                       # the same exchange, the other way of moving it
+            gname = "direct" if a.gather == "collective" else "collective"
+            sh3 = ShardedGVCNN(eng, exchange="allgather", overlap=not a.no_overlap, gather_mode=gname)
+            step3 = lambda: sh3.forward(x, check=False)     # noqa: E731
+            if sh3.overlap:
+                step3.flush = sh3.flush
+            other_g = (gname, timed(step3))
 
     out = None
     if rank == 0:
@@ -528,6 +671,8 @@ def main():
             out["config"]["world_size"] = dist.get_world_size()          # what the ranks saw, not the flag
             out["config"]["backend"] = "rccl (torch.distributed nccl)" if a.backend == "nccl" else "gloo (control-flow check)"
             out["config"]["exchange_bytes_per_step"] = xbytes[a.exchange]
+            out["config"]["gather"] = a.gather + (": one send to / receive from every peer (batch_isend_irecv)"
+                                                  if a.gather == "direct" else ": RCCL all_gather_into_tensor")
             out["config"]["exchange_overlap"] = ("all-gather of step k in flight under the backbone of step k+1 (results one "
                                                  "call later; the last head is inside the timed region)") if sh.overlap else "none"
             out["config"]["launched_by"] = "bench.py (self-launched ranks)" if os.environ.get("GVBENCH_SELF") else "external torch.distributed.run"
@@ -536,6 +681,10 @@ def main():
                 out["other_exchange"] = {"exchange": other[0], "value": round(views_per_step / (ms2 * 1e-3), 1),
                                          "unit": "views/s", "ms_per_step": round(ms2, 3),
                                          "exchange_bytes_per_step": xbytes[other[0]]}
+            if other_g is not None:
+                ms3 = other_g[1] / a.steps * 1e3
+                out["other_gather"] = {"gather": other_g[0], "value": round(views_per_step / (ms3 * 1e-3), 1),
+                                       "unit": "views/s", "ms_per_step": round(ms3, 3)}
         step_tflops = eng.plan.total_flops / (ms * 1e-3) / 1e12
         out["step_tflops_per_gpu"] = round(step_tflops, 2)
         if not a.no_roofline:

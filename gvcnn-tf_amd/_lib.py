@@ -18,6 +18,9 @@ GV_POOL_BWD_STORE = 0x100
 GV_POOL_X_P3 = 0x200
 GV_POOL_Y_P3 = 0x400
 GV_ACCUM_ZEROED = 0x100
+GV_ACCUM_RAW_Z = 0x200
+GV_BN_STATS_FWD, GV_BN_STATS_BWD, GV_BN_STATS_MAX_SEG = 1, 2, 8
+GV_E_UNSUPPORTED = -2
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
 GV_WEIGHT_COUNT, GV_WEIGHT_MEAN_SCORE = 0, 1
@@ -49,6 +52,16 @@ class BnMovingJob(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class BnStatsSeg(C.Structure):
+    _fields_ = [("c0", C.c_int32), ("c1", C.c_int32), ("z_ld", C.c_int32), ("reserved", C.c_int32), ("z", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("acc", C.c_void_p)]
+
+
+class BnStats(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("groups", C.c_int32), ("nseg", C.c_int32), ("reserved", C.c_int32),
+                ("seg", BnStatsSeg * 8)]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "c", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
@@ -68,6 +81,7 @@ SIGNATURES = {
     "gv_pack_filter_hwio": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gv_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gv_conv2d_fwd_xpre": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_conv2d_fwd_bnstats": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.POINTER(BnStats), _P]),
     "gv_pool2d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
     "gv_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "gv_global_avg_pool": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
@@ -136,6 +150,7 @@ SIGNATURES = {
     "gv_graph_destroy": (None, [_P]),
     "gv_conv2d_time": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, C.POINTER(_F), _P]),
     "gv_plan_time": (C.c_int, [_P, _I, _I, C.POINTER(_P), _I, _I, C.POINTER(_F), _P]),
+    "gv_plan_time_each": (C.c_int, [_P, C.POINTER(_P), _I, _I, C.POINTER(_F), _P]),
 }
 # tuning hooks (exported, not part of the drop-in surface)
 TUNING = {

@@ -597,6 +597,14 @@ class BackbonePlan:
                                          C.byref(ms), _stream_ptr(stream)), "gv_plan_time")
         return ms.value
 
+    def time_each(self, x, iters, stream=None):
+        """[ms per op] with every op timed IN SEQUENCE over `iters` whole passes (single launch lane)."""
+        ptrs = self._ptr_table(x)
+        out = (C.c_float * len(self.ops))()
+        _lib.check(self.lib.gv_plan_time_each(self._plan, ptrs, len(self._bufs), iters, out, _stream_ptr(stream)),
+                   "gv_plan_time_each")
+        return list(out)
+
     def __del__(self):
         try:
             if self._plan is not None:

@@ -2,6 +2,7 @@
 // conv_bf16s.hip: fp32 data split into bf16 planes on the bf16 MFMA).
 #pragma once
 #include "gv_common.h"
+#include "conv_stats.h"
 
 namespace gvconv {
 
@@ -29,6 +30,7 @@ struct ConvArgs {
     int korder;                 // conv_dma.hip: 0 = k-tiles tap-major, 1 = channel-chunk-major (filter taps innermost)
     const float* xscale;        // conv_lp.hip (gv_conv2d_fwd_xpre): the input is read as relu(x*xscale[c] + xshift[c]);
     const float* xshift;        // nullptr = the input as stored
+    ConvStats st;               // train-mode BatchNorm sums folded into the epilogue (conv_stats.h); mode 0 = off
 };
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:

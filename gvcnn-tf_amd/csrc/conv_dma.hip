@@ -70,7 +70,8 @@ constexpr bool dma_use_ss() {
     return EPI != 1 && cu / base == cu / with;
 }
 
-template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+// STATS (16-bit output only): train-mode BatchNorm sums of the stored tensor folded into the epilogue (conv_stats.h).
+template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int STATS = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     using G = DmaGeom<NP>;
     constexpr int NW = WM * WN;
@@ -129,6 +130,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     const int tile_m = lid / a.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
+    static_assert(STATS == 0 || EPI == 0, "BatchNorm sums: the 16-bit staged epilogue");
+    int st_b0 = 0;                                                 // STATS: image of the tile's first pixel
+    if constexpr (STATS != 0) st_b0 = m0 / a.st.hw;
 
     // ---- loader state -------------------------------------------------------------------------------------------
     const int lrow = lane / CPR;                                   // row inside a row block
@@ -542,10 +546,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
 
     }
     __syncthreads();                                               // every wave is done with the ring: reuse it for staging
-    if constexpr (EPI == 0)
-        lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES), 32,
-                                      sstab, BN);
-    else if constexpr (EPI == 1)
+    if constexpr (EPI == 0) {
+        if constexpr (STATS != 0) {                                // the sums table (in the freed ring where it fits)
+            gvconv::stat_table_init<STATS>(a.st, smem, tid, NW * 64, BN, n0, a.cout, st_b0);
+            __syncthreads();
+        }
+        lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES), 32,
+                                             sstab, BN, smem, st_b0 * (STATS != 0 ? a.st.hw : 0));
+        if constexpr (STATS != 0) {
+            if (!(a.st.dbg & 16384)) __syncthreads();              // every lane's runs are in the table
+            const int last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
+            gvconv::stat_publish<STATS>(a.st, smem, tid, BN, n0, a.cout, st_b0, min(last / a.st.hw - st_b0 + 1, a.st.slots));
+        }
+    } else if constexpr (EPI == 1)
         gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
     else
         x3_epilogue_staged<TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * X3EpiGeom<TN>::BYTES),
@@ -586,16 +599,41 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
     const size_t epi = EPI == 1 ? 0 : (size_t)(WM * WN) * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
     static_assert(dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() >= (int)((size_t)ST * NP * (BM + BN) * G::RBYTES), "table behind the ring");
     (void)ring; (void)epi;
-    const size_t lds = (size_t)dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() +
-                       (dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() ? 4 * BN * sizeof(float) : 0);
-    auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI>;
-    if (lds > 64 * 1024) {
-        const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
-        if (!ok) return GV_E_UNSUPPORTED;
+    size_t lds = (size_t)dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() +
+                 (dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() ? 4 * BN * sizeof(float) : 0);
+    auto go = [&](auto mode) -> int {                              // (one instantiation, and one attribute cache, per kernel)
+        auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI, decltype(mode)::value>;
+        if (lds > 160 * 1024) return GV_E_UNSUPPORTED;
+        if (lds > 64 * 1024) {
+            const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
+            if (!ok) return GV_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    };
+    if (a.st.mode != gvconv::STAT_OFF) {                           // BatchNorm sums in the epilogue (conv_stats.h)
+        if constexpr (EPI == 0 && NP == 1) {
+            if (!gvconv::stat_tile_ok(a.st, BM, a.cout, TM * 32)) return GV_E_UNSUPPORTED;
+            a.st.slots = gvconv::stat_rows(BM, a.st.hw, a.st.G);
+            a.st.fold = gvconv::stat_slots(BM, a.st.hw) > a.st.G ? 1 : 0;
+            // the tables live in the ring the epilogue has freed, behind the waves' staging blocks, where they fit in
+            // front of the epilogue's constants; else behind everything (more LDS per workgroup)
+            const size_t tab = gvconv::stat_lds_bytes(a.st.mode, a.st.slots, BN);
+            constexpr size_t epi_b = (size_t)WM * WN * EpiGeom<TN>::BYTES, ss_off = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>();
+            if (epi_b + tab <= ss_off) {
+                a.st.lds_off = (int)epi_b;
+            } else {
+                a.st.lds_off = (int)((lds + 15) / 16 * 16);
+                lds = (size_t)a.st.lds_off + tab;
+            }
+            if (a.st.mode == gvconv::STAT_FWD) return go(std::integral_constant<int, gvconv::STAT_FWD>{});
+            return go(std::integral_constant<int, gvconv::STAT_BWD>{});
+        } else {
+            return GV_E_UNSUPPORTED;
+        }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
-    GV_LAUNCH_CHECK();
-    return GV_OK;
+    return go(std::integral_constant<int, 0>{});
 }
 
 template <typename T>

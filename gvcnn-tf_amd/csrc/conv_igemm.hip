@@ -422,7 +422,8 @@ extern "C" int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_
 
 static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
                            const void* w_packed, const float* scale, const float* shift, const void* residual,
-                           void* y, void* y2, const float* scale2, const float* shift2, void* stream);
+                           void* y, void* y2, const float* scale2, const float* shift2, void* stream,
+                           const gv_bn_stats* stats = nullptr);
 
 extern "C" int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
                              const float* scale, const float* shift, const void* residual,
@@ -439,9 +440,17 @@ extern "C" int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const fl
     return conv2d_fwd_impl(d, x, xscale, xshift, w_packed, scale, shift, residual, y, y2, scale2, shift2, stream);
 }
 
+extern "C" int gv_conv2d_fwd_bnstats(const gv_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                                     const float* shift, const void* residual, void* y, const gv_bn_stats* stats,
+                                     void* stream) {
+    if (!stats) return GV_E_BADARG;
+    return conv2d_fwd_impl(d, x, nullptr, nullptr, w_packed, scale, shift, residual, y, nullptr, nullptr, nullptr, stream, stats);
+}
+
 static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
                            const void* w_packed, const float* scale, const float* shift, const void* residual,
-                           void* y, void* y2, const float* scale2, const float* shift2, void* stream) {
+                           void* y, void* y2, const float* scale2, const float* shift2, void* stream,
+                           const gv_bn_stats* stats) {
     if (!d || !x || !w_packed || !scale || !shift || !y) return GV_E_BADARG;
     if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 ||
         d->kw <= 0 || d->stride <= 0 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0)
@@ -513,6 +522,32 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
     if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) return GV_E_BADARG;
     a.dil_shift = d->in_dilation == 2 ? 1 : 0;
     if (a.dil_shift && (np == 0 || (d->cin % CH != 0) || d->stride != 1)) return GV_E_UNSUPPORTED;
+    if (stats) {
+        // BatchNorm sums in the epilogue: 16-bit storage, one plain destination (the sums are those of the stored values)
+        if (stats->mode != GV_BN_STATS_FWD && stats->mode != GV_BN_STATS_BWD) return GV_E_BADARG;
+        if (stats->groups <= 0 || stats->nseg <= 0 || stats->nseg > GV_BN_STATS_MAX_SEG) return GV_E_BADARG;
+        if (!lp || split || y2 || (d->flags & (GV_CONV_RELU | GV_CONV_RELU2))) return GV_E_UNSUPPORTED;
+        // whole 16-byte chunks of 8 channels everywhere (the lean epilogue of the instantiations that fold the sums)
+        if (d->cout % 8 != 0 || d->y_ld % 8 != 0 || !gv_aligned16(y) || (residual && (d->res_ld % 8 != 0 || !gv_aligned16(residual))))
+            return GV_E_UNSUPPORTED;
+        a.st.mode = stats->mode == GV_BN_STATS_FWD ? gvconv::STAT_FWD : gvconv::STAT_BWD;
+        a.st.hw = d->oh * d->ow;
+        a.st.G = stats->groups;
+        a.st.nseg = stats->nseg;
+        a.st.hw_magic = a.st.hw > 1 ? (unsigned)((0x100000000ull + (unsigned)a.st.hw - 1) / (unsigned)a.st.hw) : 0u;
+        a.st.lds_off = a.st.slots = a.st.fold = a.st.pad_ = 0;
+        a.st.dbg = g_debug;
+        for (int i = 0; i < stats->nseg; ++i) {
+            const gv_bn_stats_seg& g = stats->seg[i];
+            if (g.c0 < 0 || g.c1 <= g.c0 || g.c1 > d->cout) return GV_E_BADARG;
+            if (stats->mode == GV_BN_STATS_BWD && g.acc && (!g.z || g.z_ld < g.c1 - g.c0 || (g.scale == nullptr) != (g.shift == nullptr)))
+                return GV_E_BADARG;
+            if (stats->mode == GV_BN_STATS_BWD && g.acc && (g.z_ld % 8 != 0 || !gv_aligned16(g.z))) return GV_E_ALIGN;
+            a.st.seg[i].c0 = g.c0; a.st.seg[i].c1 = g.c1; a.st.seg[i].z_ld = g.z_ld; a.st.seg[i].pad_ = 0;
+            a.st.seg[i].z = (const unsigned short*)g.z; a.st.seg[i].scale = g.scale; a.st.seg[i].shift = g.shift;
+            a.st.seg[i].acc = g.acc;
+        }
+    }
 
     if (lp) {
         // vector loader: 8-channel (16-byte) chunks inside one filter tap, 16-byte aligned pixels

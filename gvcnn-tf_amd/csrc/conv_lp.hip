@@ -34,8 +34,9 @@ constexpr bool lp_fdb() { return !(WM * WN == 4 && TM * TN == 4); }
 // XPRE: the input is read as relu(x * xscale[c] + xshift[c]) (fp32 arithmetic on the staged registers, rounded once
 // more to T): the pre-activation of a ResNet-v2 unit (nets/resnet_v2.py:75) applied by its CONSUMER, so that the unit
 // before it stores the sum once instead of the sum and its pre-activation.  1x1 / unpadded launches only.
-template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2) : 1)) void conv_igemm_lp(const ConvArgs a) {
+// STATS: train-mode BatchNorm sums of the stored tensor folded into the epilogue (conv_stats.h).
+template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false, int STATS = 0>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STATS != gvconv::STAT_BWD ? 3 : 2) : 1)) void conv_igemm_lp(const ConvArgs a) {
     constexpr bool FDB = lp_fdb<WM, WN, TM, TN>();
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     static_assert(GENERIC || !XF32, "fp32 input only on the gather path");
@@ -63,6 +64,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
     const int tile_m = lid / a.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
+    int st_b0 = 0;                                   // STATS: image of the tile's first pixel
+    if constexpr (STATS != 0) st_b0 = m0 / a.st.hw;
 
     const int q = tid & 3;                           // this thread's 16-byte chunk of every row it loads
     // slot -> row: an 8-lane ds_write_b128 group covers rows R and R+4 (80-byte rows: 16 banks apart mod 32)
@@ -362,9 +365,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 ? 3 : 2
     }
 
     __syncthreads();                                  // every wave is done with the main-loop buffers
-    lp_epilogue_staged<T, TM, TN>(a, acc, m0, n0, wm, wn, lane,
-                                  reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES), 32,
-                                  (a.dbg & 512) ? nullptr : sstab, BN);      // dbg 512: constants from global memory (A/B)
+    if constexpr (STATS != 0) {                       // the sums table (in the freed main-loop space where it fits)
+        if (!(a.st.dbg & 16384)) {
+        gvconv::stat_table_init<STATS>(a.st, smem_raw, tid, NT, BN, n0, a.cout, st_b0);
+        __syncthreads();
+        }
+    }
+    lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane,
+                                         reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES), 32,
+                                         (a.dbg & 512) ? nullptr : sstab, BN,      // dbg 512: constants from global memory (A/B)
+                                         smem_raw, st_b0 * (STATS != 0 ? a.st.hw : 0));
+    if constexpr (STATS != 0) {
+        if (!(a.st.dbg & 16384)) __syncthreads();     // every lane's runs are in the table
+        const int last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
+        gvconv::stat_publish<STATS>(a.st, smem_raw, tid, BN, n0, a.cout, st_b0, min(last / a.st.hw - st_b0 + 1, a.st.slots));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -728,13 +743,14 @@ constexpr TileCfg kTiles[] = {{128, 128}, {128, 64}, {64, 64}, {128, 96}, {64, 1
                               {256, 192}};                          // 8 waves: least operand traffic per flop (Conv2d_4a)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false>
+template <typename T, int WM, int WN, int TM, int TN, bool GENERIC, bool XF32, bool XPRE = false, int STATS = 0>
 int launch_one(const ConvArgs& a, int64_t nwg, size_t lds, hipStream_t st) {
+    if (lds > 160 * 1024) return GV_E_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        const bool ok = GV_BIG_LDS_OK((&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>), 160 * 1024);
+        const bool ok = GV_BIG_LDS_OK((&conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE, STATS>), 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_lp<T, WM, WN, TM, TN, GENERIC, XF32, XPRE, STATS>), dim3((unsigned)nwg), dim3(WM * WN * 64), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
@@ -757,7 +773,23 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     const size_t lds_main = (size_t)(2 * BM + 2 * BN) * RB + ((generic || xf32) ? (size_t)a.Kpad * 8 : 0) +
                             (a.xscale ? (size_t)a.cin * 8 : 0);
     const size_t lds_epi = (size_t)(WM * WN) * EpiGeom<TN>::BYTES;
-    const size_t lds = ((lds_main > lds_epi ? lds_main : lds_epi) + 15) / 16 * 16 + 16 * BN;   // + the epilogue's constants
+    size_t lds = ((lds_main > lds_epi ? lds_main : lds_epi) + 15) / 16 * 16 + 16 * BN;   // + the epilogue's constants
+    if (a.st.mode != gvconv::STAT_OFF) {              // BatchNorm sums in the epilogue: vector loader, plain epilogue
+        if (a.xscale || xf32 || generic || !gvconv::stat_tile_ok(a.st, BM, a.cout, TM * 32)) return GV_E_UNSUPPORTED;
+        a.st.slots = gvconv::stat_rows(BM, a.st.hw, a.st.G);
+        a.st.fold = gvconv::stat_slots(BM, a.st.hw) > a.st.G ? 1 : 0;
+        // the tables live in the main-loop buffers the epilogue has freed, behind the waves' staging blocks, where they
+        // fit in front of the epilogue's constants; else behind everything (more LDS per workgroup)
+        const size_t tab = gvconv::stat_lds_bytes(a.st.mode, a.st.slots, BN), ss_off = ((lds_main > lds_epi ? lds_main : lds_epi) + 15) / 16 * 16;
+        if (lds_epi + tab <= ss_off) {
+            a.st.lds_off = (int)lds_epi;
+        } else {
+            a.st.lds_off = (int)lds;
+            lds += tab;
+        }
+        if (a.st.mode == gvconv::STAT_FWD) return launch_one<T, WM, WN, TM, TN, false, false, false, gvconv::STAT_FWD>(a, nwg, lds, st);
+        return launch_one<T, WM, WN, TM, TN, false, false, false, gvconv::STAT_BWD>(a, nwg, lds, st);
+    }
     if (a.xscale) {
         if constexpr (xpre_cfg(WM, WN, TM, TN)) return launch_one<T, WM, WN, TM, TN, false, false, true>(a, nwg, lds, st);
         else return GV_E_UNSUPPORTED;
@@ -891,6 +923,7 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
     if (cfg == kNumTiles) {
+        if (a.st.mode != STAT_OFF) return GV_E_UNSUPPORTED;      // (the strip / halo kernels do not fold BatchNorm sums)
         if (lp_stem_ok(a, xf32)) {
             if (dtype == GV_BF16) return launch_stem<__bf16>(a, st);
             if (dtype == GV_F16) return launch_stem<_Float16>(a, st);

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "conv_stats.h"
 
 namespace {
 
@@ -57,10 +58,14 @@ __device__ __forceinline__ void store_chunk(unsigned short* dst, const float (&v
     }
 }
 
-template <typename T, int TM, int TN>
+// STATS (conv_stats.h): the launch also produces the train-mode BatchNorm sums of the tensor it stores, from the rounded
+// values it stores (smem: the workgroup's dynamic LDS, which holds the tables; mbase: first pixel of the image the
+// tile's first row lies in).  STAT_BWD reads the BatchNorm's input z next to every chunk it stores.
+template <typename T, int TM, int TN, int STATS = 0>
 __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0,
                                                    int wm, int wn, int lane, float* stage, int rows_valid = 32,
-                                                   const float* sstab = nullptr, int bn = 0) {
+                                                   const float* sstab = nullptr, int bn = 0, char* smem = nullptr,
+                                                   int mbase = 0) {
     if (a.dbg & 4) {            // timing ablation: keep the accumulators live without storing the tile
         float t = 0.f;
 #pragma unroll
@@ -81,12 +86,17 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
     const unsigned short* res = reinterpret_cast<const unsigned short*>(a.res);
     unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
     unsigned short* y2 = reinterpret_cast<unsigned short*>(a.y2);
-    const bool dual = y2 != nullptr && a.split == 0;
+    // LEAN (the STATS instantiations): ONE destination, no activation, whole 16-byte aligned 8-column chunks — the entry
+    // point checks it — so none of the second-output / split / ReLU / element-wise branches is compiled in: the unrolled
+    // epilogue is straight-line code that every workgroup runs once, and past the instruction cache's 64 KB it is fetched
+    // again for every workgroup (the 128 x 192 LDS-DMA tile: 50 KB plain, 80 KB with every branch AND the sums).
+    constexpr bool LEAN = STATS != 0;
+    const bool dual = !LEAN && y2 != nullptr && a.split == 0;
     // 16-byte accesses need 8-element aligned rows, slices and boundaries (true for every layer of both
     // backbones); anything else takes the element-wise branch of store_chunk
-    const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
+    const bool vec = LEAN || ((a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
                      (y2 == nullptr || ((a.y2_ld % 8 == 0) && ((((uintptr_t)y2) & 15) == 0))) &&
-                     (a.split % 8 == 0) && (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0)));
+                     (a.split % 8 == 0) && (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0))));
     // The residual chunks of a block's read-back passes are requested ONE BLOCK AHEAD (those of the first block before it
     // is staged): issued one per pass next to their use, every pass of an HBM-bound ResNet conv3 (K = 64 ... 256, 4x the
     // output channels) waits out one full memory round trip (the y stores in between may alias, so the compiler cannot
@@ -107,10 +117,64 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
         }
     };
     res_fetch(0, rvp[0]);
+    // STATS: everything that comes from the kernel arguments is fetched HERE, once — a scalar load inside the loops
+    // below would wait (lgkmcnt) for every LDS access in flight with it.  Per column block: does this lane's chunk / this
+    // lane's read column belong to a segment; STAT_BWD: where its z lives.  The z chunks of a block are requested a
+    // block ahead, like the residual's.
+    constexpr int NJB = TN / JB;
+    unsigned long long* st_sums = nullptr;
+    const float2* st_ss = nullptr;
+    unsigned st_on_mask = 0, st_col_mask = 0;
+    int st_dbg = 0;
+    const unsigned short* st_z[STATS == gvconv::STAT_BWD ? NJB : 1];
+    int st_zld[STATS == gvconv::STAT_BWD ? NJB : 1];
+    u32x4 zvp[STATS == gvconv::STAT_BWD ? 2 : 1][STATS == gvconv::STAT_BWD ? NPASS : 1];
+    auto z_fetch = [&](int b, u32x4 (&dst)[STATS == gvconv::STAT_BWD ? NPASS : 1]) {
+        if constexpr (STATS == gvconv::STAT_BWD) {
+            const int jb = b / TM, i = b % TM;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int row = pass * RPP + rrow;
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                dst[pass] = (((st_on_mask >> jb) & 1u) && m < a.M && row < rows_valid)
+                                ? *reinterpret_cast<const u32x4*>(st_z[jb] + (size_t)m * st_zld[jb])
+                                : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    gvconv::StatWave<STATS == 0 ? gvconv::STAT_FWD : STATS> sw;
+    const int st_mw0 = m0 + wm * TM * 32;                             // the wave's first pixel
+    bool st_has_b = false;
+    if constexpr (STATS != 0) {
+        st_sums = reinterpret_cast<unsigned long long*>(smem + a.st.lds_off);
+        st_ss = reinterpret_cast<const float2*>(smem + a.st.lds_off + (size_t)a.st.slots * bn * 16);
+        st_dbg = a.st.dbg;
+#pragma unroll
+        for (int jb = 0; jb < NJB; ++jb) {
+            const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;
+            const int k = a.cout - col >= 8 ? gvconv::stat_seg_of(a.st, col) : -1;
+            if (k >= 0) st_on_mask |= 1u << jb;
+            const int rcol = n0 + (wn * TN + jb * JB) * 32 + lane;
+            if (lane < CW && rcol < a.cout && gvconv::stat_seg_of(a.st, rcol) >= 0) st_col_mask |= 1u << jb;
+            if constexpr (STATS == gvconv::STAT_BWD) {
+                st_z[jb] = k >= 0 ? a.st.seg[k].z + (col - a.st.seg[k].c0) : nullptr;
+                st_zld[jb] = k >= 0 ? a.st.seg[k].z_ld : 0;
+            }
+        }
+        sw.begin_wave(a.st, st_mw0, mbase);
+        st_has_b = sw.e1 < min(st_mw0 + TM * 32, a.M);
+        z_fetch(0, zvp[0]);
+    }
 #pragma unroll
     for (int jb = 0; jb < TN / JB; ++jb) {
         const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;     // this lane's 8 columns
         const int nvalid = min(8, a.cout - col);                        // <= 0: nothing to store
+        const int st_lcol = (wn * TN + jb * JB) * 32 + rchunk * 8;
+        bool st_on = false;
+        if constexpr (STATS != 0) {
+            st_on = ((st_on_mask >> jb) & 1u) != 0;
+            sw.begin_block(st_ss, bn, st_lcol);
+        }
         float sc[8], sh[8], sc2[8], sh2[8];
         if (sstab) {                                        // the tile's constants in LDS (conv_dma.hip): 16-byte reads
             const float* t = sstab + (wn * TN + jb * JB) * 32 + rchunk * 8;
@@ -137,7 +201,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
             }
         }
         // split destination: a chunk lies on one side when split % 8 == 0; otherwise decide per element below
-        const bool to_second = a.split > 0 && col >= a.split;
+        const bool to_second = !LEAN && a.split > 0 && col >= a.split;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int b = jb * TM + i;
@@ -148,6 +212,9 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                     stage[(row_h + (r & 3) + 8 * (r >> 2)) * CW + jj * 32 + col_l] = acc[i][jb * JB + jj][r];
             __builtin_amdgcn_wave_barrier();
             if (b + 1 < TM * (TN / JB)) res_fetch(b + 1, rvp[(b + 1) & 1]);
+            if constexpr (STATS == gvconv::STAT_BWD) {
+                if (b + 1 < TM * (TN / JB)) z_fetch(b + 1, zvp[(b + 1) & 1]);
+            }
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int row = pass * RPP + rrow;
@@ -160,7 +227,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
                 if (res) {
                     const unsigned short* rp = res + (size_t)m * a.res_ld + col;
-                    if (vec && nvalid == 8) {
+                    if (LEAN || (vec && nvalid == 8)) {
                         const u32x4 rv = rvp[b & 1][pass];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -182,11 +249,33 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                     }
                     store_chunk<T>(y2 + (size_t)m * a.y2_ld + col, v2, nvalid, vec);
                 }
-                if (a.relu) {
+                if (!LEAN && a.relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (col + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
                 }
-                if (a.split > 0 && (a.split % 8) != 0) {          // boundary inside a chunk: element-wise
+                if constexpr (STATS != 0) {
+                    if (st_on && !(st_dbg & 8192)) {              // sums of the values exactly as stored below
+                        float rr[8], zv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rr[e] = from_bits<T>(to_bits<T>(v[e]));
+                        if constexpr (STATS == gvconv::STAT_BWD) {
+                            const u32x4 zq = zvp[b & 1][pass];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                zv[2 * j] = from_bits<T>((unsigned short)(zq[j] & 0xffffu));
+                                zv[2 * j + 1] = from_bits<T>((unsigned short)(zq[j] >> 16));
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) zv[e] = 0.f;
+                        }
+                        const int step0 = st_mw0 + i * 32 + pass * RPP;
+                        sw.add(rr, zv, m, step0, step0 + RPP);
+                    }
+                }
+                if constexpr (LEAN) {
+                    store_chunk<T>(y + (size_t)m * a.y_ld + col, v, 8, true);
+                } else if (a.split > 0 && (a.split % 8) != 0) {   // boundary inside a chunk: element-wise
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (e >= nvalid) continue;
@@ -201,6 +290,10 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (STATS != 0) {                   // the block's column totals: wave -> workgroup table
+            const int lcol0 = (wn * TN + jb * JB) * 32;
+            sw.template end_block<CW>(st_sums, stage, bn, lane, rrow, rchunk, lcol0, ((st_col_mask >> jb) & 1u) != 0, st_has_b, st_dbg);
         }
     }
 }

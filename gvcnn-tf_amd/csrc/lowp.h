@@ -26,7 +26,7 @@ int scale_shift_act_grouped(int dtype, const void* x, int nb, int hw, int c, int
 int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, const void* z, int z_ld,
                          const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
                          const float* scale, const float* shift, int accumulate, int nb, int hw, int c, int G, void* dz,
-                         int dz_ld, float* dbeta, float* dgamma, bool* param_grads_done, hipStream_t st);
+                         int dz_ld, float* dbeta, float* dgamma, bool* param_grads_done, hipStream_t st, int raw_z = 0);
 int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, const float* gamma, const float* beta,
                               float eps, const void* x, int nb, int hw, int c, int x_ld, int G, int relu, void* y,
                               int y_ld, float* mean, float* var, float* inv, float* scale, float* shift, hipStream_t st);

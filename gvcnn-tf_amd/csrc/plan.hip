@@ -323,6 +323,48 @@ extern "C" int gv_plan_time(const gv_plan* p, int32_t first, int32_t count, void
     return rc;
 }
 
+// Every op of the plan timed IN SEQUENCE: `iters` whole passes on the caller's stream (single launch lane), an event in
+// front of the first op and one behind every op, so a launch is timed where it sits in the step — behind its real
+// predecessor, on whatever that left in the caches — not as a warm repeat of itself.  ms_per_op_host[i] = the average
+// over the passes of (event behind op i) - (event behind op i-1).
+extern "C" int gv_plan_time_each(const gv_plan* p, void* const* buffers_host, int32_t num_slots, int32_t iters,
+                                 float* ms_per_op_host, void* stream) {
+    if (!p) return GV_E_PLAN;
+    if (!buffers_host || !ms_per_op_host || iters <= 0) return GV_E_BADARG;
+    if (num_slots <= p->max_slot) return GV_E_PLAN;
+    for (int32_t i = 0; i <= p->max_slot; ++i)
+        if (!buffers_host[i]) return GV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = p->ops.size();
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    int rc = GV_OK;
+    for (size_t i = 0; i <= n && rc == GV_OK; ++i) {
+        const hipError_t e = hipEventCreate(&ev[i]);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    for (size_t i = 0; i < n; ++i) ms_per_op_host[i] = 0.f;
+    for (size_t i = 0; i < n && rc == GV_OK; ++i) rc = run_op(p->ops[i], buffers_host, stream);   // warm pass
+    for (int it = 0; it < iters && rc == GV_OK; ++it) {
+        (void)hipEventRecord(ev[0], st);
+        for (size_t i = 0; i < n && rc == GV_OK; ++i) {
+            rc = run_op(p->ops[i], buffers_host, stream);
+            (void)hipEventRecord(ev[i + 1], st);
+        }
+        if (rc == GV_OK) {
+            const hipError_t e = hipEventSynchronize(ev[n]);
+            if (e != hipSuccess) rc = (int)e;
+        }
+        for (size_t i = 0; i < n && rc == GV_OK; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            ms_per_op_host[i] += ms / (float)iters;
+        }
+    }
+    for (size_t i = 0; i <= n; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
 // ---- hipGraph capture of whatever the caller enqueues on a stream (gvcnn_hip.h) --------------------------------
 struct gv_graph {
     hipGraph_t graph = nullptr;

@@ -1275,8 +1275,11 @@ extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, con
                                               int32_t c, int32_t num_groups, const double* accum, void* dz,
                                               int32_t dz_ld, float* dbeta, float* dgamma, const float* scale,
                                               const float* shift, int32_t accumulate, int32_t dtype, void* stream) {
+    const int raw_z = (dtype & GV_ACCUM_RAW_Z) ? 1 : 0;
+    dtype &= ~GV_ACCUM_RAW_Z;
     if (dtype == GV_F32) {
         if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
+        if (raw_z) return GV_E_UNSUPPORTED;
         return bn_bwd_apply_f32((const float*)dy, dy_ld, (const float*)y, y_ld, (const float*)z, z_ld, mean, inv, gamma,
                                 counts, nb, hw, c, num_groups, accum, (float*)dz, dz_ld, dbeta, dgamma, scale, shift,
                                 accumulate, stream);
@@ -1289,7 +1292,7 @@ extern "C" int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, con
     bool done = false;                                           // (the streaming kernel also sums dbeta / dgamma)
     const int rc = gvlp::bn_bwd_apply_grouped(dtype, dy, dy_ld, y, y_ld, z, z_ld, mean, inv, gamma, accum, counts, scale,
                                               shift, accumulate, nb, hw, c, num_groups, dz, dz_ld, dbeta, dgamma, &done,
-                                              st);
+                                              st, raw_z);
     if (rc != GV_OK) return rc;
     if ((dbeta || dgamma) && !done)
         hipLaunchKernelGGL(bn_param_grads, dim3((c + 255) / 256), dim3(256), 0, st, accum, num_groups, c, dbeta,

@@ -10,6 +10,7 @@
 // ds_read_b64_tr_b16, which hands lane (channel i) four consecutive pixels of its column.
 #include <math.h>
 
+#include "conv_stats.h"
 #include "lowp.h"
 #include "lp_elem.h"
 
@@ -128,8 +129,11 @@ __global__ __launch_bounds__(256) void grouped_sums_lp(const unsigned short* __r
         double a = 0.0, b = 0.0;
         for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
-        atomicAdd(&acc[o], a);
-        if (MODE != 2) atomicAdd(&acc[o + 1], b);
+        // the block's partial on the fixed grid of conv_stats.h: the fp64 additions are then exact, so the sums do not
+        // depend on the order the blocks arrive in (bitwise reproducible run to run)
+        const double q0 = MODE == 0 ? gvconv::STAT_Q_FWD0 : gvconv::STAT_Q_BWD, q1 = MODE == 0 ? gvconv::STAT_Q_FWD1 : gvconv::STAT_Q_BWD;
+        atomicAdd(&acc[o], rint(a * q0) / q0);
+        if (MODE != 2) atomicAdd(&acc[o + 1], rint(b * q1) / q1);
     }
 }
 
@@ -337,8 +341,11 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const E* __restrict__ z, 
         double a = 0.0, b = 0.0;
         for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
-        atomicAdd(&acc[o], a);
-        if (MODE != 2) atomicAdd(&acc[o + 1], b);
+        // the block's partial on the fixed grid of conv_stats.h: the fp64 additions are then exact, so the sums do not
+        // depend on the order the blocks arrive in (bitwise reproducible run to run)
+        const double q0 = MODE == 0 ? gvconv::STAT_Q_FWD0 : gvconv::STAT_Q_BWD, q1 = MODE == 0 ? gvconv::STAT_Q_FWD1 : gvconv::STAT_Q_BWD;
+        atomicAdd(&acc[o], rint(a * q0) / q0);
+        if (MODE != 2) atomicAdd(&acc[o + 1], rint(b * q1) / q1);
     }
 }
 
@@ -409,8 +416,10 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const E* __restrict__ x, int
             double a = 0.0, b2 = 0.0;
 #pragma unroll 4
             for (int gg = 0; gg < G; ++gg) {
-                a += acc[((size_t)gg * c + cht) * 2];
-                b2 += acc[((size_t)gg * c + cht) * 2 + 1];
+                const double a0 = acc[((size_t)gg * c + cht) * 2], a1 = acc[((size_t)gg * c + cht) * 2 + 1];
+                a += a0;
+                // relu != 0 (backward): accum holds sum g*z, not sum g*zhat (GV_ACCUM_RAW_Z; p0f = mean, p1f = inv)
+                b2 += relu ? (double)p1f[gg * c + cht] * (a1 - (double)p0f[gg * c + cht] * a0) : a1;
             }
             if (ex.dbeta) ex.dbeta[cht] += (float)a;
             if (ex.dgamma) ex.dgamma[cht] += (float)b2;
@@ -427,7 +436,8 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const E* __restrict__ x, int
         if constexpr (BWD) {                                     // p0f = mean, p1f = inv
             const float iv = p1f[gi], mu = p0f[gi];
             const float rm = 1.f / (float)counts[g];
-            const float s1 = (float)acc[(size_t)gi * 2], s2 = (float)acc[(size_t)gi * 2 + 1];
+            const double a0 = acc[(size_t)gi * 2], a1 = acc[(size_t)gi * 2 + 1];
+            const float s1 = (float)a0, s2 = (float)(relu ? (double)iv * (a1 - (double)mu * a0) : a1);   // (relu: GV_ACCUM_RAW_Z)
             A[e] = (gamma ? gamma[ch + e] : 1.f) * iv;
             B[e] = -A[e] * iv * s2 * rm;
             Cc[e] = A[e] * (mu * iv * s2 - s1) * rm;
@@ -1532,9 +1542,10 @@ int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, c
 int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, int y_ld, const void* z, int z_ld,
                          const float* mean, const float* inv, const float* gamma, const double* acc, const int* counts,
                          const float* scale, const float* shift, int accumulate, int nb, int hw, int c, int G, void* dz,
-                         int dz_ld, float* dbeta, float* dgamma, bool* param_grads_done, hipStream_t st) {
+                         int dz_ld, float* dbeta, float* dgamma, bool* param_grads_done, hipStream_t st, int raw_z) {
     if (dtype == GV_F32) {
         *param_grads_done = false;
+        if (raw_z) return GV_E_UNSUPPORTED;
         if (!((c % 4 == 0) && vec4(dy, dy_ld) && vec4(y, y_ld) && vec4(z, z_ld) && vec4(dz, dz_ld) &&
               (int64_t)((nb + G - 1) / G) * hw < 0x7fffffffll))
             return GV_E_UNSUPPORTED;
@@ -1556,11 +1567,12 @@ int bn_bwd_apply_grouped(int dtype, const void* dy, int dy_ld, const void* y, in
     BnExtra ex{};
     ex.dbeta = dbeta; ex.dgamma = dgamma;
     *param_grads_done = v;
+    if (raw_z && !v) return GV_E_UNSUPPORTED;                    // (sum g*z accumulators: the streaming kernel converts them)
     GV_LP_DISPATCH(dtype, {
         if (v)
             hipLaunchKernelGGL((bn_stream_v8<unsigned short, T, true>), dim3((c + 63) / 64, stream_splits(nb, hw, G, c), G), dim3(256), 0, st,
                                zz, z_ld, a, dy_ld, b, y_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c,
-                               G, 0, o, dz_ld, ex);
+                               G, raw_z ? 1 : 0, o, dz_ld, ex);
         else
             hipLaunchKernelGGL((bn_bwd_apply_grouped_lp<T, 1>), dim3(grid_for((int64_t)nb * hw * c)), dim3(256), 0, st, a,
                                dy_ld, b, y_ld, zz, z_ld, mean, inv, gamma, acc, counts, scale, shift, accumulate, nb, hw, c, G,

@@ -228,6 +228,15 @@ def encode_png(img):
             chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
 
 
+def _decode_record(rec, num_views):
+    """One tf.Example -> (views uint8 [V, h0, w0, 3], label): the unit of work of ViewBatcher's decode workers."""
+    ex = parse_example(rec)
+    enc = ex["image/encoded"]
+    if len(enc) != num_views:
+        raise ValueError("record holds %d views, expected %d" % (len(enc), num_views))
+    return np.stack([decode_png(e) for e in enc]), int(ex["image/label"][0])
+
+
 # ------------------------------------------------------------------------------------------------
 # batches for the engine
 # ------------------------------------------------------------------------------------------------
@@ -243,10 +252,17 @@ class ViewBatcher:
     counts them in `dropped`; "pad" repeats the last shape up to N, pads the labels with -1 (ignored by
     gv_eval_metrics) and sets `last_valid` to the real count, for Evaluator.add_batch(..., valid=batcher.last_valid)
     (the reference's eval loop counts that short batch, eval.py:204; note that its batch-mean view scores are then taken
-    over the real shapes only, here over the padded batch); "error" raises."""
+    over the real shapes only, here over the padded batch); "error" raises.
+
+    workers > 0: the PNG inflate + unfilter of the records runs in that many decoder PROCESSES (tf.data's
+    num_parallel_calls, train_data.py:95-104) — one Python process decodes ~0.5 k views/s, one GPU consumes 15 - 85 k.
+    The outer GZIP stream is read by this process (it is one serial stream), records are dealt to the pool with a bounded
+    window in flight and come back IN ORDER, so batches are identical to the workers = 0 ones.  The pool is a `spawn`
+    pool: its processes never inherit an initialised GPU runtime (create the batcher — or at least start iterating —
+    wherever convenient; nothing is forked)."""
 
     def __init__(self, path, num_views, height, width, batch_size, device, augment=False, seed=0, shuffle_buffer=0,
-                 remainder="warn"):
+                 remainder="warn", workers=0):
         if remainder not in ("warn", "pad", "error"):
             raise ValueError("remainder must be 'warn', 'pad' or 'error'")
         self.path, self.V, self.H, self.W, self.N = path, num_views, height, width, batch_size
@@ -254,16 +270,43 @@ class ViewBatcher:
         self.rng = np.random.RandomState(seed)
         self.shuffle_buffer, self.remainder = int(shuffle_buffer), remainder
         self.dropped, self.last_valid = 0, batch_size
+        self.workers = int(workers)
+        self._pool = None
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.terminate()
+            self._pool.join()
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _decoded(self):
+        """(views, label) per record in file order; workers > 0: decoded by the pool, a bounded window ahead."""
+        if self.workers <= 0:
+            for rec in read_tfrecords(self.path):
+                yield _decode_record(rec, self.V)
+            return
+        if self._pool is None:
+            import multiprocessing as mp
+            self._pool = mp.get_context("spawn").Pool(self.workers)
+        from collections import deque
+        window, pending = 4 * self.workers, deque()
+        for rec in read_tfrecords(self.path):
+            pending.append(self._pool.apply_async(_decode_record, (rec, self.V)))
+            if len(pending) >= window:
+                yield pending.popleft().get()
+        while pending:
+            yield pending.popleft().get()
 
     def _shapes(self):
         """(views uint8 [V, h0, w0, 3], label) per record, through the shuffle buffer."""
         buf = []
-        for rec in read_tfrecords(self.path):
-            ex = parse_example(rec)
-            enc = ex["image/encoded"]
-            if len(enc) != self.V:
-                raise ValueError("record holds %d views, expected %d" % (len(enc), self.V))
-            item = (np.stack([decode_png(e) for e in enc]), int(ex["image/label"][0]))
+        for item in self._decoded():
             if self.shuffle_buffer <= 0:
                 yield item
             elif len(buf) < self.shuffle_buffer:

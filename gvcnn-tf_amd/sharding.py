@@ -34,32 +34,75 @@ def shard_range(num_shapes_global, world_size, rank):
     return rank * n_l, (rank + 1) * n_l
 
 
-def _all_gather_flat(t_local, group=None):
-    """all_gather_into_tensor along dim 0.  RCCL takes device tensors directly; a gloo group (CPU tests, and the
-    single-device control-flow check `bench.py --backend gloo`) is fed through host memory."""
+# How a gather travels ("direct one-shot all-gather on the full mesh ... ring would be 7x that"):
+#   "collective"  dist.all_gather_into_tensor — the library picks the algorithm (RCCL: ring / tree by size);
+#   "direct"      every rank posts ONE send of its shard to EACH peer and one receive from each (batch_isend_irecv):
+#                 on the xGMI mesh every pair of GPUs has its own link, so the P-1 transfers of a rank leave on P-1
+#                 different links at once and the gather takes shard / link-rate instead of (P-1) ring steps.
+# A process-wide default (set_gather_mode) that ShardedGVCNN / ShardedTrainGVCNN can override per instance; the RCCL
+# collective stays the default until a node has shown the direct form to be faster.  Same bytes, same result.
+_GATHER_MODE = "collective"
+
+
+def set_gather_mode(mode):
+    global _GATHER_MODE
+    if mode not in ("collective", "direct"):
+        raise ValueError(mode)
+    _GATHER_MODE = mode
+
+
+def direct_all_gather(out, src, group=None, async_op=False):
+    """out [world * n, ...] <- every rank's src [n, ...], as point-to-point transfers to and from every peer.
+    Returns the list of work handles when async_op (wait on each), else waits itself."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = src.shape[0]
+    out[rank * n:(rank + 1) * n].copy_(src)
+    ops = []
+    for d in range(1, world):                               # peer order rotated by rank: no two ranks start on one peer
+        peer = (rank + d) % world
+        gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+        ops.append(dist.P2POp(dist.isend, src, gpeer, group))
+        frm = (rank - d) % world
+        gfrm = dist.get_global_rank(group, frm) if group is not None else frm
+        ops.append(dist.P2POp(dist.irecv, out[frm * n:(frm + 1) * n], gfrm, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return works
+    for w in works:
+        w.wait()
+    return None
+
+
+def _all_gather_flat(t_local, group=None, mode=None):
+    """All-gather along dim 0 (mode: "collective" | "direct", default the process-wide one).  RCCL takes device tensors
+    directly; a gloo group (CPU tests, and the single-device control-flow check `bench.py --backend gloo`) is fed
+    through host memory."""
     world = dist.get_world_size(group)
     t_local = t_local.contiguous()
     via_host = t_local.is_cuda and dist.get_backend(group) == "gloo"
     src = t_local.cpu() if via_host else t_local
     out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-    dist.all_gather_into_tensor(out, src, group=group)
+    if (mode or _GATHER_MODE) == "direct":
+        direct_all_gather(out, src, group)
+    else:
+        dist.all_gather_into_tensor(out, src, group=group)
     return out.to(t_local.device) if via_host else out
 
 
-def gather_scores(r_img_local, group=None):
+def gather_scores(r_img_local, group=None, mode=None):
     """All-gather the local scorer responses [N_l*V] -> [P*N_l*V] (global shape-major order)."""
     world = dist.get_world_size(group)
     if world == 1:
         return r_img_local
-    return _all_gather_flat(r_img_local.reshape(-1), group)
+    return _all_gather_flat(r_img_local.reshape(-1), group, mode)
 
 
-def gather_descriptors(F_local, group=None):
+def gather_descriptors(F_local, group=None, mode=None):
     """All-gather final view descriptors [N_l, V, h, w, C] -> [P*N_l, V, h, w, C]."""
     world = dist.get_world_size(group)
     if world == 1:
         return F_local
-    return _all_gather_flat(F_local, group)
+    return _all_gather_flat(F_local, group, mode)
 
 
 class ShardedGVCNN:
@@ -72,12 +115,15 @@ class ShardedGVCNN:
     standing between two steps.  forward() returns the results of the PREVIOUS call (None the first time); flush()
     returns the last one.  Values are exactly those of the non-overlapped form: the same collectives on the same data."""
 
-    def __init__(self, engine, group=None, exchange="allgather", overlap=False):
+    def __init__(self, engine, group=None, exchange="allgather", overlap=False, gather_mode=None):
         if exchange not in ("allgather", "scores"):
             raise ValueError(exchange)
+        if gather_mode not in (None, "collective", "direct"):
+            raise ValueError(gather_mode)
         self.eng = engine
         self.group = group
         self.exchange = exchange
+        self.gather_mode = gather_mode        # None: the process-wide default (set_gather_mode)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.overlap = bool(overlap) and exchange == "allgather" and self.world > 1
@@ -102,14 +148,16 @@ class ShardedGVCNN:
             dist.all_gather_into_tensor(h, src.cpu(), group=self.group)
             dst.copy_(h)
             work = None
+        elif (self.gather_mode or _GATHER_MODE) == "direct":
+            work = direct_all_gather(dst, src, self.group, async_op=True)
         else:
             work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
         return (work, dst, eng.scheme.clone(), eng.weight.clone(), eng.scores.clone())
 
     def _finish(self, pending):
         work, F_all, scheme, weight, scores = pending
-        if work is not None:
-            work.wait()                                         # the CURRENT stream waits for the collective; no host sync
+        for w in (work if isinstance(work, (list, tuple)) else ([work] if work is not None else [])):
+            w.wait()                                            # the CURRENT stream waits for the transfer; no host sync
         S, logits = self.eng.pool_fuse_classify(scheme, weight, F=F_all)
         return scores, S, logits
 
@@ -131,7 +179,7 @@ class ShardedGVCNN:
         eng.run_backbone(views_local)
         eng.compute_scores()                                   # fills eng.r_img (local) + local scores
         if self.world > 1:
-            r_all = gather_scores(eng.r_img, self.group)
+            r_all = gather_scores(eng.r_img, self.group, self.gather_mode)
             eng.finalize_scores(r_all, eng.N * self.world)     # same array, same order on every rank
         eng.assign_groups(check=False)
         if self.overlap:
@@ -141,7 +189,7 @@ class ShardedGVCNN:
                 eng.check_status()
             return self._finish(prev) if prev is not None else None
         if self.exchange == "allgather" and self.world > 1:
-            F_all = gather_descriptors(eng.final_view_descriptors(), self.group)
+            F_all = gather_descriptors(eng.final_view_descriptors(), self.group, self.gather_mode)
             S, logits = eng.pool_fuse_classify(eng.scheme, eng.weight, F=F_all)
         else:
             S, logits = eng.pool_fuse_classify(eng.scheme, eng.weight)

@@ -12,7 +12,7 @@ import torch
 
 # entry point -> family of the training step
 FAMILY = {
-    "gv_conv2d_fwd": "conv", "gv_conv2d_fwd_xpre": "conv", "gv_conv2d_wgrad": "wgrad",
+    "gv_conv2d_fwd": "conv", "gv_conv2d_fwd_xpre": "conv", "gv_conv2d_fwd_bnstats": "conv", "gv_conv2d_wgrad": "wgrad",
     "gv_conv2d_dgrad_s2": "conv",
     "gv_bn_sums_grouped_t": "bn", "gv_bn_finalize_apply_grouped_t": "bn", "gv_bn_relu_bwd_sums_grouped_t": "bn",
     "gv_bn_relu_bwd_apply_grouped_t": "bn", "gv_bn_finalize_t": "bn", "gv_bn_bwd_finalize_t": "bn",
@@ -65,13 +65,13 @@ def timed_step(eng, views, labels, steps=1):
     tl = TimedLib(lib0, eng.device)
     fwd0, bwd0 = eng._forward_op, eng._backward_op
 
-    def fwd(op, zeroed=False):
+    def fwd(op, zeroed=False, part="all"):
         tl.tag, tl.phase = (op["name"], op["kind"]), "fwd"
-        return fwd0(op, zeroed)
+        return fwd0(op, zeroed, part)
 
-    def bwd(op, zeroed=False):
+    def bwd(op, zeroed=False, part="all"):
         tl.tag, tl.phase = (op["name"], op["kind"]), "bwd"
-        return bwd0(op, zeroed)
+        return bwd0(op, zeroed, part)
 
     if eng._packed_dirty:
         eng.repack()                                      # (not part of a step's launch list)

@@ -175,6 +175,8 @@ class TrainGVCNN:
         # shape-sharded data parallelism (sharding.ShardedTrainGVCNN(mode='shapes')): bn_sync(accum) all-reduces the
         # per-(view, channel) BatchNorm sums over the ranks, shape_world = number of ranks sharing every view
         self.bn_sync = None
+        self.bn_sync_calls = 0                            # statistics all-reduces issued so far (two per BatchNorm and step
+        self.coalesce_bn_sync = True                      # uncoalesced; the members of a fused sibling GEMM share one)
         self.shape_world = 1
         # frozen_bn: BatchNorm normalises with the MOVING statistics (slim's is_training=False arithmetic) while every
         # variable still gets its gradient: dz = gamma*inv*g without the two batch-statistics terms.  The reference never
@@ -334,6 +336,85 @@ class TrainGVCNN:
         self._packed_dirty = True
         self._pack_jobs = None
         self._moving_jobs = None
+        # Train-mode BatchNorm sums folded into the launch that produces the tensor (gv_conv2d_fwd_bnstats): the forward
+        # sums of z in the convolution's epilogue, the backward sums of dy in the epilogue of the data-gradient launch
+        # that writes the FINAL dy (16-bit storage; False: the separate sums passes, kept for A/B and tests)
+        self.fuse_bn_stats = self.es == 2
+        self._plan_bn_fusion()
+
+    # -- BatchNorm sums folded into the producing launch --------------------------------------------------
+    def _plan_bn_fusion(self):
+        """Which launch produces each BatchNorm's sums.  Forward: the convolution whose output (or a channel slice of
+        it: members of a fused sibling GEMM) the BatchNorm reads.  Backward: the data-gradient launch that is the LAST
+        contributor to the gradient of the BatchNorm's output — the backward pass runs the ops in reverse, so that is the
+        FIRST op (in forward order) that reads the tensor; it must be a convolution whose input covers the tensor (a
+        pool or a residual fan-in as last contributor leaves the separate sums pass in place)."""
+        ops = self.plan.ops
+        inside = lambda t, u: t.vbuf == u.vbuf and u.off <= t.off and t.off + t.c <= u.off + u.c
+        overlap = lambda t, u: t.vbuf == u.vbuf and t.off < u.off + u.c and u.off < t.off + t.c
+        for op in ops:
+            op.pop("st_f", None), op.pop("st_b", None), op.pop("fused_f", None), op.pop("fused_b", None)
+        # ops that take part in a backward pass (their output receives a gradient), as backward_backbone decides it
+        reached, live = [self.final], set()
+        for i in range(len(ops) - 1, -1, -1):
+            y = ops[i]["y"]
+            if y.vbuf < 0 or not any(overlap(y, r) for r in reached):
+                continue
+            live.add(i)
+            reached.append(ops[i]["x"])
+            if ops[i].get("res") is not None:
+                reached.append(ops[i]["res"])
+        for bi, b in enumerate(ops):
+            if b["kind"] != "bn":
+                continue
+            # forward: the producer of b.x
+            for c in ops[:bi]:
+                if c["kind"] == "conv" and b["x"].vbuf >= 0 and inside(b["x"], c["y"]) and c.get("res") is None:
+                    c.setdefault("st_f", []).append(b)
+                    b["fused_f"] = c
+            # backward: the first reader of b.y among the ops that run in the backward pass
+            if bi not in live:
+                continue
+            readers = [(i, o) for i, o in enumerate(ops) if i in live and i > bi and
+                       (overlap(o["x"], b["y"]) or (o.get("res") is not None and overlap(o["res"], b["y"])))]
+            if not readers:
+                continue
+            if any(not inside(b["y"], o["x"]) or (o.get("res") is not None and overlap(o["res"], b["y"])) for _, o in readers):
+                continue                                      # a reader of a part of it, or a residual fan-in
+            first = readers[0][1]
+            if first["kind"] == "conv" and first["x"].vbuf >= 0:
+                first.setdefault("st_b", []).append(b)
+                b["fused_b"] = first
+        for op in ops:
+            for key in ("st_f", "st_b"):
+                if len(op.get(key, ())) > _lib.GV_BN_STATS_MAX_SEG:
+                    for b in op.pop(key):
+                        b.pop("fused_f" if key == "st_f" else "fused_b")
+
+    def _bn_stats(self, op, key):
+        """The gv_bn_stats of convolution `op` (key 'st_f': forward sums of its output; 'st_b': backward sums of its
+        data gradient), built once: every pointer in it is fixed for the life of the engine."""
+        cache = "_" + key + "_struct"
+        if cache not in op:
+            fwd = key == "st_f"
+            base = op["y"] if fwd else op["x"]
+            st = _lib.BnStats()
+            st.mode = _lib.GV_BN_STATS_FWD if fwd else _lib.GV_BN_STATS_BWD
+            st.groups, st.nseg = self.V, len(op[key])
+            for i, b in enumerate(op[key]):
+                t = b["x"] if fwd else b["y"]
+                sg = st.seg[i]
+                sg.c0, sg.c1 = t.off - base.off, t.off - base.off + t.c
+                sg.acc = (b["acc_f"] if fwd else b["acc_b"]).data_ptr()
+                if not fwd:
+                    sg.z, sg.z_ld = self._ptr(b["x"]), b["x"].ld
+                    if b["relu"]:
+                        sg.scale, sg.shift = b["stat"]["scale"].data_ptr(), b["stat"]["shift"].data_ptr()
+            op[cache] = st
+        return op[cache]
+
+    def _fusing(self):
+        return self.fuse_bn_stats and self._zacc and self._lazy and not self.frozen_bn
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _ptr(self, t, grad=False):
@@ -494,6 +575,35 @@ class TrainGVCNN:
             self.repack()
         ncfg = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dt == _lib.GV_F32 else -1)
         ms = C.c_float(0)
+        if self._fusing():
+            # what the SEPARATE sums passes of every fusable BatchNorm cost: a tile that cannot fold the sums competes as
+            # plain launch + these
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for op in self.plan.ops:
+                op.pop("_sums_ms_f", None), op.pop("_sums_ms_b", None)
+            for b in self.plan.ops:
+                if b["kind"] != "bn":
+                    continue
+                x, y, st, hw = b["x"], b["y"], b["stat"], b["x"].h * b["x"].w
+                calls = []
+                if b.get("fused_f") is not None:
+                    calls.append(("_sums_ms_f", b["fused_f"], lambda: lib.gv_bn_sums_grouped_t(
+                        self._ptr(x), x.nb, hw, x.c, x.ld, self.V, self.accum.data_ptr(), self.dt, _st())))
+                if b.get("fused_b") is not None:
+                    sc = st["scale"].data_ptr() if b["relu"] else None
+                    sh = st["shift"].data_ptr() if b["relu"] else None
+                    calls.append(("_sums_ms_b", b["fused_b"], lambda: lib.gv_bn_relu_bwd_sums_grouped_t(
+                        self._ptr(y, True), y.ld, None, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(), st["inv"].data_ptr(),
+                        x.nb, hw, x.c, self.V, self.accum.data_ptr(), sc, sh, self.dt, _st())))
+                for key, conv, fn in calls:
+                    if fn() != 0:
+                        continue
+                    ev0.record()
+                    for _ in range(iters):
+                        fn()
+                    ev1.record()
+                    ev1.synchronize()
+                    conv[key] = conv.get(key, 0.0) + ev0.elapsed_time(ev1) / iters
         for op in self.plan.ops:
             if op["kind"] != "conv":
                 continue
@@ -504,14 +614,36 @@ class TrainGVCNN:
             for key, dgrad, src, w, dst in jobs:
                 op[key] = 0
                 best, best_ms = 0, float("inf")
+                # a launch that also produces BatchNorm sums is timed AS that launch (its epilogue differs; a tile that
+                # cannot fold them is timed plain plus nothing: the separate sums pass then costs what it costs)
+                skey = "st_b" if dgrad else "st_f"
+                fused = bool(op.get(skey)) and self._fusing()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 for t in range(ncfg):
                     op[key] = t + 1
                     d = self._conv_desc(op, dgrad=dgrad)
                     d.res_ld = 0
+                    rc = -1
+                    if fused:
+                        args = (C.byref(d), src, w.data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(), None, dst,
+                                C.byref(self._bn_stats(op, skey)), _st())
+                        rc = lib.gv_conv2d_fwd_bnstats(*args)
+                        if rc == 0:
+                            e0.record()
+                            for _ in range(iters):
+                                lib.gv_conv2d_fwd_bnstats(*args)
+                            e1.record()
+                            e1.synchronize()
+                            t_ms = e0.elapsed_time(e1) / iters
+                            if t_ms < best_ms:
+                                best, best_ms = t + 1, t_ms
+                            continue
                     rc = lib.gv_conv2d_time(C.byref(d), src, w.data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(),
                                             dst, iters, C.byref(ms), _st())
-                    if rc == 0 and ms.value < best_ms:
-                        best, best_ms = t + 1, ms.value
+                    # (unfused alternative of a fusable layer: add what its separate sums pass costs, measured once)
+                    extra = op.get("_sums_ms_b" if dgrad else "_sums_ms_f", 0.0) if fused else 0.0
+                    if rc == 0 and ms.value + extra < best_ms:
+                        best, best_ms = t + 1, ms.value + extra
                 op[key] = best
             # filter gradient (16-bit storage): tile and pixel-split choice, timed with events on the launch stream
             nw = lib.gv_conv2d_wgrad_num_cfgs(self.dt)
@@ -607,20 +739,85 @@ class TrainGVCNN:
         if self._zacc:
             self._accum_f.zero_()                         # every layer's forward sums: one fill
         self._phase_begin()
-        for op in self.plan.ops:
-            self._on_lane(op, "a", (op["x"], op.get("res")), (op["y"],), lambda: self._forward_op(op, self._zacc))
+        self._run_pass(list(self.plan.ops), forward=True)
         self._phase_end()
 
-    def _forward_op(self, op, zeroed=False):
+    # -- pass loops: BatchNorm layers that become ready together share ONE statistics all-reduce ------------------------
+    def _bn_sync_call(self, t):
+        self.bn_sync_calls += 1
+        self.bn_sync(t)
+
+    def _run_pass(self, ops, forward, progress=None):
+        """Run `ops` in order (forward ops, or the backward ops of the reversed list).  With a statistics exchange
+        (bn_sync: shape-sharded / hybrid data parallelism) a run of CONSECUTIVE BatchNorm ops none of which reads what
+        another one of the run writes — the member BatchNorms of a fused sibling GEMM — executes as: every member's
+        sums, ONE all-reduce over their (adjacent) accumulators, every member's apply; one collective instead of one per
+        layer and direction."""
+        fn = self._forward_op if forward else self._backward_op
+        kind = "a" if forward else "g"
+        coalesce = (self.bn_sync is not None and self._zacc and not self.frozen_bn and self._lane_streams is None
+                    and self.coalesce_bn_sync)
+        overlap = lambda t, u: t.vbuf == u.vbuf and t.off < u.off + u.c and u.off < t.off + t.c
+        i = 0
+        while i < len(ops):
+            op = ops[i]
+            if not forward and (op["y"].vbuf < 0 or not self._has_grad(op["y"])):
+                i += 1
+                continue                                  # nothing downstream of the final tap reaches it
+            run = [op]
+            if coalesce and op["kind"] == "bn":
+                j = i + 1
+                while j < len(ops) and ops[j]["kind"] == "bn":
+                    o = ops[j]
+                    if not forward and (o["y"].vbuf < 0 or not self._has_grad(o["y"])):
+                        break
+                    # (forward: o reads x, the run wrote its y's; backward: o reads dy, the run wrote its dx's)
+                    if any(overlap(o["x"] if forward else o["y"], r["y"] if forward else r["x"]) for r in run):
+                        break
+                    run.append(o)
+                    j += 1
+            if len(run) == 1:
+                if forward:
+                    self._on_lane(op, kind, (op["x"], op.get("res")), (op["y"],), lambda: fn(op, self._zacc))
+                else:
+                    outs = (op["x"], op.get("res"))
+                    self._on_lane(op, kind, (op["y"],) + outs, outs, lambda: fn(op, self._zacc))
+                    if progress is not None and op["kind"] == "conv" and op.get("g_lo") is not None:
+                        progress(op["g_lo"])
+                i += 1
+                continue
+            for o in run:
+                fn(o, self._zacc, "sums")
+            key = "acc_f" if forward else "acc_b"
+            base = self._accum_f if forward else self._accum_b
+            lo = min(o[key].storage_offset() for o in run)
+            hi = max(o[key].storage_offset() + o[key].numel() for o in run)
+            self._bn_sync_call(base[lo:hi])               # (the members' accumulators are adjacent: allocated in op order)
+            for o in run:
+                fn(o, self._zacc, "apply")
+            i += len(run)
+
+    def _forward_op(self, op, zeroed=False, part="all"):
         """One op of the train-mode forward pass (conv -> z, BatchNorm on batch statistics (+ReLU), pool).
         zeroed: the op's own fp64 accumulator was zero-filled by the caller (the pass loops do that for all layers at
-        once); otherwise the sums call clears it itself, so calling an op on its own is always safe."""
+        once); otherwise the sums call clears it itself, so calling an op on its own is always safe.
+        part (BatchNorm only): "sums" = the statistics pass alone, "apply" = finalize + apply alone — the pass loops use
+        the two halves to all-reduce the sums of several layers in ONE collective (shape-sharded training)."""
         lib, V = self.lib, self.V
         x, y = op["x"], op["y"]
         if op["kind"] == "conv":
             d = self._conv_desc(op)
             shift = self.params[op["bias"]] if op["bias"] else self.zeros
             res = op["res"]
+            op["_st_f_done"] = False
+            if op.get("st_f") and zeroed and self._fusing():  # the BatchNorm sums of z in this launch's epilogue
+                rc = lib.gv_conv2d_fwd_bnstats(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
+                                               shift.data_ptr(), None, self._ptr(y), C.byref(self._bn_stats(op, "st_f")),
+                                               _st())
+                if rc != _lib.GV_E_UNSUPPORTED:               # (unsupported tile / geometry: the plain launch below)
+                    _lib.check(rc, "conv + BN sums " + op["name"])
+                    op["_st_f_done"] = True
+                    return
             _lib.check(lib.gv_conv2d_fwd(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
                                          shift.data_ptr(), self._ptr(res) if res is not None else None,
                                          self._ptr(y), None, None, None, _st()), "conv " + op["name"])
@@ -631,18 +828,22 @@ class TrainGVCNN:
             hw = x.h * x.w
             acc = op["acc_f"] if self._zacc else self.accum
             zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
-            if self.frozen_bn:                            # sums that finalize to (moving_mean, moving_variance)
+            if part == "apply":
+                pass
+            elif self.frozen_bn:                          # sums that finalize to (moving_mean, moving_variance)
                 mm = self.params[op["name"] + "/moving_mean"].double()
                 mv = self.params[op["name"] + "/moving_variance"].double()
                 cnt = self._count(hw).double().view(V, 1)
                 a = acc[:2 * V * x.c].view(V, x.c, 2)
                 a[..., 0] = cnt * mm
                 a[..., 1] = cnt * (mv + mm * mm)
-            else:
+            elif not (zeroed and op.get("fused_f") is not None and op["fused_f"].get("_st_f_done")):
                 _lib.check(lib.gv_bn_sums_grouped_t(self._ptr(x), x.nb, hw, x.c, x.ld, V, acc.data_ptr(), self.dt | zf,
                                                     _st()), "bn sums " + op["name"])
-            if self.bn_sync is not None and not self.frozen_bn:   # shape-sharded: reduce the sums over the ranks first
-                self.bn_sync(acc[:2 * V * x.c])
+            if part == "sums":
+                return
+            if part == "all" and self.bn_sync is not None and not self.frozen_bn:   # shape-sharded: reduce the sums first
+                self._bn_sync_call(acc[:2 * V * x.c])
             _lib.check(lib.gv_bn_finalize_apply_grouped_t(
                 acc.data_ptr(), self._count(hw).data_ptr(), gamma.data_ptr() if gamma is not None else None,
                 beta.data_ptr(), float(op["eps"]), self._ptr(x), x.nb, hw, x.c, x.ld, V, int(op["relu"]), self._ptr(y),
@@ -787,20 +988,13 @@ class TrainGVCNN:
         if progress is not None and (self._lane_streams is not None or not self._g_monotone):
             progress = None
         self._phase_begin()
-        for op in reversed(self.plan.ops):
-            y = op["y"]
-            if y.vbuf < 0 or not self._has_grad(y):
-                continue                                  # nothing downstream of the final tap reaches it
-            outs = (op["x"], op.get("res"))
-            self._on_lane(op, "g", (y,) + outs, outs, lambda: self._backward_op(op, self._zacc))
-            if progress is not None and op["kind"] == "conv" and op.get("g_lo") is not None:
-                progress(op["g_lo"])
+        self._run_pass(list(reversed(self.plan.ops)), forward=False, progress=progress)
         self._phase_end()
         return self.grads
 
-    def _backward_op(self, op, zeroed=False):
+    def _backward_op(self, op, zeroed=False, part="all"):
         """Backward of one op: reads the gradient of its output, ACCUMULATES into the gradient of its input(s) and
-        of its variables."""
+        of its variables.  part (BatchNorm only): "sums" / "apply", see _forward_op."""
         lib, V = self.lib, self.V
         x, y = op["x"], op["y"]
         if op["kind"] == "bn":
@@ -812,15 +1006,20 @@ class TrainGVCNN:
             yptr = self._ptr(y) if op["relu"] and not self._lazy else None
             sc = st["scale"].data_ptr() if op["relu"] and self._lazy else None      # mask from z*scale + shift > 0
             sh = st["shift"].data_ptr() if op["relu"] and self._lazy else None
-            acc = 0 if self._claim(x) else 1
             accb = op["acc_b"] if self._zacc else self.accum
             zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
-            _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
-                self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                st["inv"].data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), sc, sh, self.dt | zf, _st()),
-                "bn_bwd sums " + op["name"])
-            if self.bn_sync is not None:
-                self.bn_sync(accb[:2 * V * x.c])
+            # (sum g, sum g*z) already added by the data-gradient launch that wrote the final dy?
+            raw = zeroed and op.get("fused_b") is not None and op["fused_b"].get("_st_b_done", False)
+            if not raw and part != "apply":
+                _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
+                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                    st["inv"].data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), sc, sh, self.dt | zf, _st()),
+                    "bn_bwd sums " + op["name"])
+            if part == "sums":
+                return
+            acc = 0 if self._claim(x) else 1
+            if part == "all" and self.bn_sync is not None:
+                self._bn_sync_call(accb[:2 * V * x.c])
             if self.frozen_bn:                            # beta / gamma take their gradients, the statistics terms vanish
                 ab = accb[:2 * V * x.c].view(V, x.c, 2)
                 self.grads[op["name"] + "/beta"] += ab[..., 0].sum(0).float()
@@ -832,7 +1031,8 @@ class TrainGVCNN:
                 self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
                 st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
                 self._count(hw).data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), self._ptr(x, True), x.ld,
-                dbeta, dgamma, sc, sh, acc if self._lazy else 1, self.dt, _st()), "bn_bwd apply " + op["name"])
+                dbeta, dgamma, sc, sh, acc if self._lazy else 1, self.dt | (_lib.GV_ACCUM_RAW_Z if raw else 0), _st()),
+                "bn_bwd apply " + op["name"])
         elif op["kind"] == "conv":
             dz = self._ptr(y, True)
             if op["bias"]:
@@ -854,6 +1054,17 @@ class TrainGVCNN:
                 store = self._claim(x)                        # first contribution: no residual read, plain store
                 if store:
                     dd.res_ld = 0
+                op["_st_b_done"] = False
+                if op.get("st_b") and zeroed and self._fusing():
+                    # this launch writes the FINAL gradient of x: the backward sums of the BatchNorm layers that
+                    # produced x leave its epilogue
+                    rc = lib.gv_conv2d_fwd_bnstats(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
+                                                   self.zeros.data_ptr(), None if store else dx, dx,
+                                                   C.byref(self._bn_stats(op, "st_b")), _st())
+                    if rc != _lib.GV_E_UNSUPPORTED:
+                        _lib.check(rc, "dgrad + BN sums " + op["name"])
+                        op["_st_b_done"] = True
+                        return
                 _lib.check(lib.gv_conv2d_fwd(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
                                              self.zeros.data_ptr(), None if store else dx, dx, None, None, None,
                                              _st()), "dgrad " + op["name"])

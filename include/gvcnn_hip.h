@@ -436,6 +436,42 @@ int gv_bn_relu_bwd_apply_grouped_t(const void* dy, int32_t dy_ld, const void* y,
                                    const double* accum, void* dz, int32_t dz_ld, float* dbeta, float* dgamma,
                                    const float* scale, const float* shift, int32_t accumulate, int32_t dtype,
                                    void* stream);
+/* OR-ed into the `dtype` of gv_bn_relu_bwd_apply_grouped_t: accum[g][c][1] holds sum g*z (the raw BatchNorm input, as
+ * gv_conv2d_fwd_bnstats / GV_BN_STATS_BWD produces it) instead of sum g*zhat; the call converts it first:
+ * sum g*zhat = inv * (sum g*z - mean * sum g). */
+#define GV_ACCUM_RAW_Z 0x200
+/* ---- train-mode BatchNorm sums folded into the launch that produces the tensor -------------------------------------
+ * slim.batch_norm(is_training=True) (nets/inception_utils.py:52-62, nets/resnet_utils.py:230) normalises every view's
+ * graph copy over its own values (nets/model.py:129-141): statistics per (view, channel), view of image b = b % groups.
+ * gv_conv2d_fwd_bnstats is gv_conv2d_fwd (16-bit storage, one destination, no activation) whose epilogue also adds the
+ * sums of the values it stores, exactly as stored, into fp64 accumulators [groups][c1-c0][2]:
+ *   GV_BN_STATS_FWD  a forward convolution writing z:           { sum z, sum z^2 }   = what gv_bn_sums_grouped_t adds
+ *   GV_BN_STATS_BWD  a data-gradient launch writing the FINAL dy of a tensor (its last or only contributor):
+ *                    { sum g, sum g*z }, g = dy * [z*scale + shift > 0]; z = the BatchNorm's input, scale / shift
+ *                    [groups][c1-c0] = its folded forward coefficients (NULL: no ReLU) — what
+ *                    gv_bn_relu_bwd_sums_grouped_t adds, with z in place of zhat (GV_ACCUM_RAW_Z).
+ * The output's channels may belong to several BatchNorm layers (members of a fused sibling GEMM; the concat a block's
+ * data gradient writes): one segment each; acc == NULL: no sums for those columns.  Accumulators must be zero on entry
+ * of a pass.  The sums are bitwise reproducible run to run (fixed-point partials, exact fp64 additions).
+ * GV_E_UNSUPPORTED: this tile configuration / geometry cannot fold them (the caller runs the plain convolution and the
+ * separate sums pass instead); nothing has been written in that case. */
+#define GV_BN_STATS_FWD 1
+#define GV_BN_STATS_BWD 2
+#define GV_BN_STATS_MAX_SEG 8
+typedef struct gv_bn_stats_seg {
+    int32_t c0, c1;            /* output columns [c0, c1), multiples of 8 */
+    int32_t z_ld, reserved;    /* BWD: pixel stride of z */
+    const void* z;             /* BWD: BatchNorm input (storage type), channel c0 of the segment at z[pixel * z_ld] */
+    const float* scale;        /* BWD: [groups][c1-c0] */
+    const float* shift;
+    double* acc;               /* [groups][c1-c0][2] */
+} gv_bn_stats_seg;
+typedef struct gv_bn_stats {
+    int32_t mode, groups, nseg, reserved;
+    gv_bn_stats_seg seg[GV_BN_STATS_MAX_SEG];
+} gv_bn_stats;
+int gv_conv2d_fwd_bnstats(const gv_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                          const float* shift, const void* residual, void* y, const gv_bn_stats* stats, void* stream);
 int gv_accumulate_t(const void* src, int32_t src_ld, void* dst, int32_t dst_ld, int64_t npix, int32_t c,
                     int32_t dtype, void* stream);
 int gv_bias_grad_t(const void* dz, int32_t dz_ld, int64_t npix, int32_t c, double* accum, float* dbias,
@@ -505,6 +541,12 @@ int gv_conv2d_time(const gv_conv_desc* d, const void* x, const void* w_packed, c
 /* Same for a whole plan (or a range of it). */
 int gv_plan_time(const gv_plan* p, int32_t first, int32_t count, void* const* buffers_host,
                  int32_t num_slots, int32_t iters, float* ms_avg_host, void* stream);
+/* Every op timed IN SEQUENCE (the number bench.py's `roofline` object is built from): `iters` whole passes of the plan
+ * on `stream` in plan order (single launch lane), an event behind every op; ms_per_op_host [gv_plan_num_ops()] = average
+ * duration of each op where it sits in the step, behind its real predecessor (a launch timed as a warm repeat of itself
+ * finds its filters and part of its input in L2). */
+int gv_plan_time_each(const gv_plan* p, void* const* buffers_host, int32_t num_slots, int32_t iters,
+                      float* ms_per_op_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -142,3 +142,24 @@ def test_view_batcher_shuffle_buffer_and_remainder_policy(tmp_path):
         assert np.array_equal(v, np.stack(shapes[lab][0]))
     with pytest.raises(ValueError):
         R.ViewBatcher(path, V, 8, 8, 4, "cpu", remainder="keep")
+
+
+def test_decode_workers_return_the_same_shapes_in_order(tmp_path):
+    """ViewBatcher(workers=K): the records are decoded by K spawned processes with a bounded window in flight and come
+    back in file order — the decoded stream (and so every batch) equals the single-process one."""
+    rng = np.random.RandomState(3)
+    shapes = []
+    for i in range(23):
+        views = [rng.randint(0, 256, size=(11, 13, 3)).astype(np.uint8) for _ in range(3)]
+        shapes.append((views, i % 5))
+    path = os.path.join(tmp_path, "w.record")
+    R.write_tfrecords(path, [R.make_example([R.encode_png(v) for v in views], lab) for views, lab in shapes])
+    serial = list(R.ViewBatcher(path, 3, 8, 8, 4, "cpu")._decoded())
+    vb = R.ViewBatcher(path, 3, 8, 8, 4, "cpu", workers=3)
+    try:
+        pooled = list(vb._decoded())
+    finally:
+        vb.close()
+    assert len(serial) == len(pooled) == 23
+    for (a, la), (b, lb), (views, lab) in zip(serial, pooled, shapes):
+        assert la == lb == lab and np.array_equal(a, b) and np.array_equal(a, np.stack(views))

@@ -327,3 +327,93 @@ def test_overlapped_flat_all_reduce_sums_every_element_exactly_once():
     mp.spawn(_flat_reduce_worker, args=(port, ret), nprocs=WORLD, join=True)
     assert ret[0][0] and ret[1][0]
     assert ret[0][1] == ret[1][1] and 4 <= ret[0][1] <= 9    # several slices, fewer than the progress calls
+
+
+# ------------------------------------------------------------------------------------------------
+# the node's real world size: 8 ranks — hybrid 4 x 2 grid (12 views), ShardedGVCNN with the direct (point-to-point)
+# gather beside the collective one, uneven view shards (12 views on 8 ranks: 2,2,2,2,1,1,1,1)
+# ------------------------------------------------------------------------------------------------
+def _load_sharding(tag):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(tag, os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    return sh
+
+
+def _world8_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=8)
+    torch.set_num_threads(1)
+    sh = _load_sharding("gv_sharding_w8")
+    out = {}
+    # (1) hybrid grid 4 view groups x 2 shape shards at V = 12: the layout bench.py --train uses on a whole node
+    V12, N, W = 12, 4, 8
+    vg, s = sh.hybrid_grid(V12, W)
+    gi, si = sh.hybrid_coords(V12, W, rank)
+    shape_group, view_group = sh.hybrid_groups(V12, W, rank)
+    v_l, n_l = V12 // vg, N // s
+    full = torch.arange(N * V12 * 3, dtype=torch.float32).view(N, V12, 3)
+    mine = full[si * n_l:(si + 1) * n_l, gi * v_l:(gi + 1) * v_l].contiguous()
+    for mode in ("collective", "direct"):
+        sh.set_gather_mode(mode)
+        views = sh.gather_views(mine, view_group, V12)                          # all 12 views of my 2 shapes
+        allsh = sh._all_gather_flat(views, shape_group)                         # every shape, shape order
+        out["hybrid_" + mode] = bool(torch.equal(views, full[si * n_l:(si + 1) * n_l])) and bool(torch.equal(allsh, full))
+    sh.set_gather_mode("collective")
+    bn = sh.allreduce_sum_(mine.double().sum(dim=0).clone(), shape_group)       # statistics: the 2 ranks that share my views
+    out["bn"] = bool(torch.equal(bn, full[:, gi * v_l:(gi + 1) * v_l].double().sum(dim=0)))
+    out["grid"] = (vg, s, gi, si)
+    # (2) uneven view shards, both gather forms: 12 views on 8 ranks
+    lo, hi = sh.view_shard_range(V12, W, rank)
+    for mode in ("collective", "direct"):
+        sh.set_gather_mode(mode)
+        got = sh.gather_views(full[:, lo:hi].contiguous(), num_views=V12)
+        out["uneven_" + mode] = bool(torch.equal(got, full))
+    out["views"] = (lo, hi)
+    # (3) ShardedGVCNN at world 8, exchange = allgather, in both gather forms and overlapped: identical results
+    rng = np.random.RandomState(200 + rank)
+    xs = [torch.from_numpy(rng.randn(N_L, V, *SHAPE).astype(np.float32)) for _ in range(3)]
+    res = {}
+    for name, kw in (("collective", dict(gather_mode="collective")), ("direct", dict(gather_mode="direct")),
+                     ("direct_overlap", dict(gather_mode="direct", overlap=True))):
+        eng = sh.ShardedGVCNN(_FakeEngine(8, rank), exchange="allgather", **kw)
+        got = []
+        for x in xs:
+            o = eng.forward(x, check=False)
+            if o is not None:
+                got.append(tuple(t.clone() for t in o))
+        if eng.overlap:
+            got.append(tuple(t.clone() for t in eng.flush()))
+        res[name] = got
+    same = all(len(res[k]) == 3 and all(all(torch.equal(a, b) for a, b in zip(g, w))
+                                        for g, w in zip(res[k], res["collective"])) for k in res)
+    out["sharded_same"] = same
+    out["logits"] = [float(g[2].sum()) for g in res["collective"]]
+    out["num_logits"] = int(res["collective"][0][2].numel())
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_hybrid_grid_direct_gather_and_sharded_forward():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_world8_worker, args=(port, ret), nprocs=8, join=True)
+    cells = set()
+    for r in range(8):
+        o = ret[r]
+        assert o["hybrid_collective"] and o["hybrid_direct"] and o["bn"], (r, o)
+        assert o["uneven_collective"] and o["uneven_direct"], (r, o)
+        assert o["sharded_same"], r
+        assert o["num_logits"] == 8 * N_L * SHAPE[2]        # the all-gather form: every rank holds all N_g shapes' rows
+        assert o["logits"] == ret[0]["logits"]              # ... identical everywhere
+        vg, s_, gi, si = o["grid"]
+        assert (vg, s_) == (4, 2)
+        cells.add((gi, si))
+    assert cells == {(g, k) for g in range(4) for k in range(2)}
+    assert [ret[r]["views"] for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 9), (9, 10), (10, 11), (11, 12)]
