@@ -37,13 +37,14 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nb", "ih", "iw", "cin", "x_ld", "kh", "kw", "stride", "pad_t", "pad_l",
         "oh", "ow", "cout", "y_ld", "res_ld", "y2_ld", "flags", "dtype", "split_col", "tile_cfg",
-        "math_mode", "in_dilation", "relu_cols")]
+        "math_mode", "in_dilation", "relu_cols", "y_step", "y_py", "y_px", "y_ih", "y_iw")]
 
 
 class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32), ("k_off", C.c_int32),
-                ("k_total", C.c_int32), ("w_ld", C.c_int32), ("reserved", C.c_int32)]
+                ("k_total", C.c_int32), ("w_ld", C.c_int32), ("sub_step", C.c_int32), ("sub_r0", C.c_int32),
+                ("sub_s0", C.c_int32), ("src_kw", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class BnMovingJob(C.Structure):

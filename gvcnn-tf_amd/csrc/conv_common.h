@@ -31,6 +31,10 @@ struct ConvArgs {
     const float* xscale;        // conv_lp.hip (gv_conv2d_fwd_xpre): the input is read as relu(x*xscale[c] + xshift[c]);
     const float* xshift;        // nullptr = the input as stored
     ConvStats st;               // train-mode BatchNorm sums folded into the epilogue (conv_stats.h); mode 0 = off
+    int y_step = 0;             // 2: output pixel (n, oy, ox) lands on pixel (2*oy + y_py, 2*ox + y_px) of a y_ih x y_iw
+    int y_py = 0, y_px = 0;     //    image (one parity class of a stride-2 data gradient; 16-bit staged epilogue only)
+    int y_ih = 0, y_iw = 0;
+    GvFastDiv y_div_img = {0, -1, 1}, y_div_row = {0, -1, 1};   //    exact m / (oh*ow) and rem / ow
 };
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:

@@ -468,7 +468,7 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
     // the window of the last output must start inside the padded input
     {
         // (a data-gradient launch may legitimately have output rows no window reaches: they get zeros)
-        if (d->in_dilation != 2 && ((d->oh - 1) * d->stride - d->pad_t >= d->ih ||
+        if (d->in_dilation != 2 && d->y_step != 2 && ((d->oh - 1) * d->stride - d->pad_t >= d->ih ||
                                     (d->ow - 1) * d->stride - d->pad_l >= d->iw))
             return GV_E_BADARG;
     }
@@ -522,6 +522,16 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
     if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) return GV_E_BADARG;
     a.dil_shift = d->in_dilation == 2 ? 1 : 0;
     if (a.dil_shift && (np == 0 || (d->cin % CH != 0) || d->stride != 1)) return GV_E_UNSUPPORTED;
+    if (d->y_step != 0) {
+        // one parity class of a stride-2 data gradient: stride-1 launch whose output rows land on every second pixel
+        if (d->y_step != 2 || d->y_py < 0 || d->y_py > 1 || d->y_px < 0 || d->y_px > 1) return GV_E_BADARG;
+        if (2 * (d->oh - 1) + d->y_py >= d->y_ih || 2 * (d->ow - 1) + d->y_px >= d->y_iw) return GV_E_BADARG;
+        if (!lp || split || y2 || d->stride != 1 || a.dil_shift) return GV_E_UNSUPPORTED;
+        if ((int64_t)d->nb * d->y_ih * d->y_iw > 0x7fffffff) return GV_E_UNSUPPORTED;
+        a.y_step = 2; a.y_py = d->y_py; a.y_px = d->y_px; a.y_ih = d->y_ih; a.y_iw = d->y_iw;
+        a.y_div_img = gv_fast_div(d->oh * d->ow);
+        a.y_div_row = gv_fast_div(d->ow);
+    }
     if (stats) {
         // BatchNorm sums in the epilogue: 16-bit storage, one plain destination (the sums are those of the stored values)
         if (stats->mode != GV_BN_STATS_FWD && stats->mode != GV_BN_STATS_BWD) return GV_E_BADARG;

@@ -724,7 +724,12 @@ __global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job
         } else {
             const int tap = k / ci_p, co = k - tap * ci_p;
             const int r = tap / j.kw, sx = tap - r * j.kw;
-            v = j.w[((size_t)((j.kh - 1 - r) * j.kw + (j.kw - 1 - sx)) * j.cin + n) * wld + co];
+            // source tap of packed tap (r, sx): the flipped window — of the whole filter, or (sub_step 2) of the taps one
+            // parity class of a stride-2 data gradient uses
+            const int sr = j.sub_step == 2 ? j.sub_r0 + 2 * (j.kh - 1 - r) : j.kh - 1 - r;
+            const int ss = j.sub_step == 2 ? j.sub_s0 + 2 * (j.kw - 1 - sx) : j.kw - 1 - sx;
+            const int skw = j.sub_step == 2 ? j.src_kw : j.kw;
+            v = j.w[((size_t)(sr * skw + ss) * j.cin + n) * wld + co];
             if (j.k_total > 0) {                                 // one member of a wider fused filter: its column range
                 const int kt = j.kh * j.kw * j.k_total;
                 dst = (int64_t)n * ((kt + KT - 1) / KT * KT) + (int64_t)tap * j.k_total + j.k_off + co;
@@ -923,7 +928,7 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
     if (cfg == kNumTiles) {
-        if (a.st.mode != STAT_OFF) return GV_E_UNSUPPORTED;      // (the strip / halo kernels do not fold BatchNorm sums)
+        if (a.st.mode != STAT_OFF || a.y_step != 0) return GV_E_UNSUPPORTED;   // (not in the strip / halo kernels)
         if (lp_stem_ok(a, xf32)) {
             if (dtype == GV_BF16) return launch_stem<__bf16>(a, st);
             if (dtype == GV_F16) return launch_stem<_Float16>(a, st);

@@ -97,6 +97,16 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
     const bool vec = LEAN || ((a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
                      (y2 == nullptr || ((a.y2_ld % 8 == 0) && ((((uintptr_t)y2) & 15) == 0))) &&
                      (a.split % 8 == 0) && (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0))));
+    // output pixel of GEMM row m: m itself, or (y_step 2: one parity class of a stride-2 data gradient) pixel
+    // (2*oy + y_py, 2*ox + y_px) of image n in a y_ih x y_iw map
+    auto out_pix = [&](int m) -> size_t {
+        if (a.y_step != 2) return (size_t)m;
+        const int n = gv_div(m, a.y_div_img);
+        const int rem = m - n * a.y_div_img.d;
+        const int oy = gv_div(rem, a.y_div_row);
+        const int ox = rem - oy * a.y_div_row.d;
+        return ((size_t)n * a.y_ih + (size_t)(2 * oy + a.y_py)) * a.y_iw + (size_t)(2 * ox + a.y_px);
+    };
     // The residual chunks of a block's read-back passes are requested ONE BLOCK AHEAD (those of the first block before it
     // is staged): issued one per pass next to their use, every pass of an HBM-bound ResNet conv3 (K = 64 ... 256, 4x the
     // output channels) waits out one full memory round trip (the y stores in between may alias, so the compiler cannot
@@ -111,7 +121,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int row = pass * RPP + rrow;
                 const int m = m0 + (wm * TM + i) * 32 + row;
-                dst[pass] = (m < a.M && row < rows_valid) ? *reinterpret_cast<const u32x4*>(res + (size_t)m * a.res_ld + col)
+                dst[pass] = (m < a.M && row < rows_valid) ? *reinterpret_cast<const u32x4*>(res + out_pix(m) * a.res_ld + col)
                                                           : u32x4{0u, 0u, 0u, 0u};
             }
         }
@@ -137,7 +147,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 const int row = pass * RPP + rrow;
                 const int m = m0 + (wm * TM + i) * 32 + row;
                 dst[pass] = (((st_on_mask >> jb) & 1u) && m < a.M && row < rows_valid)
-                                ? *reinterpret_cast<const u32x4*>(st_z[jb] + (size_t)m * st_zld[jb])
+                                ? *reinterpret_cast<const u32x4*>(st_z[jb] + out_pix(m) * st_zld[jb])
                                 : u32x4{0u, 0u, 0u, 0u};
             }
         }
@@ -223,10 +233,11 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 const int m = m0 + (wm * TM + i) * 32 + row;
                 if (m >= a.M || nvalid <= 0 || row >= rows_valid) continue;
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const size_t mp = out_pix(m);                     // (m itself unless a parity-class launch)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
                 if (res) {
-                    const unsigned short* rp = res + (size_t)m * a.res_ld + col;
+                    const unsigned short* rp = res + mp * a.res_ld + col;
                     if (LEAN || (vec && nvalid == 8)) {
                         const u32x4 rv = rvp[b & 1][pass];
 #pragma unroll
@@ -247,7 +258,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                         v2[e] = v[e] * sc2[e] + sh2[e];
                         if (a.relu2) v2[e] = fmaxf(v2[e], 0.f);
                     }
-                    store_chunk<T>(y2 + (size_t)m * a.y2_ld + col, v2, nvalid, vec);
+                    store_chunk<T>(y2 + mp * a.y2_ld + col, v2, nvalid, vec);
                 }
                 if (!LEAN && a.relu) {
 #pragma unroll
@@ -274,19 +285,19 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                     }
                 }
                 if constexpr (LEAN) {
-                    store_chunk<T>(y + (size_t)m * a.y_ld + col, v, 8, true);
+                    store_chunk<T>(y + mp * a.y_ld + col, v, 8, true);
                 } else if (a.split > 0 && (a.split % 8) != 0) {   // boundary inside a chunk: element-wise
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (e >= nvalid) continue;
                         const int c = col + e;
-                        if (c >= a.split) y2[(size_t)m * a.y2_ld + (c - a.split)] = to_bits<T>(v[e]);
-                        else y[(size_t)m * a.y_ld + c] = to_bits<T>(v[e]);
+                        if (c >= a.split) y2[mp * a.y2_ld + (c - a.split)] = to_bits<T>(v[e]);
+                        else y[mp * a.y_ld + c] = to_bits<T>(v[e]);
                     }
                 } else if (to_second) {
-                    store_chunk<T>(y2 + (size_t)m * a.y2_ld + (col - a.split), v, nvalid, vec);
+                    store_chunk<T>(y2 + mp * a.y2_ld + (col - a.split), v, nvalid, vec);
                 } else {
-                    store_chunk<T>(y + (size_t)m * a.y_ld + col, v, nvalid, vec);
+                    store_chunk<T>(y + mp * a.y_ld + col, v, nvalid, vec);
                 }
             }
             __builtin_amdgcn_wave_barrier();

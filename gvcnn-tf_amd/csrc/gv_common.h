@@ -55,6 +55,28 @@ static inline bool gv_pool_geometry_ok(const gv_pool_desc* d) {
            (int64_t)(d->ow - 1) * d->stride - d->pad_l < d->iw;
 }
 
+// Exact division of a 31-bit dividend by a constant (Granlund-Montgomery, 31-bit precision): q = hi32(m * mul) >> sh.
+struct GvFastDiv {
+    unsigned mul;
+    int sh;                                                      // -1: divisor 1 (q = m)
+    int d;
+};
+static inline GvFastDiv gv_fast_div(int d) {
+    GvFastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mul = 0; f.sh = -1; return f; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;                                  // l = ceil(log2 d) >= 1
+    f.mul = (unsigned)(((1ull << (31 + l)) + (unsigned)d - 1) / (unsigned)d);
+    f.sh = l - 1;
+    return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int gv_div(int m, const GvFastDiv& f) {
+    return f.sh < 0 ? m : (int)(__umulhi((unsigned)m, f.mul) >> f.sh);
+}
+#endif
+
 static inline int gv_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool gv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 

@@ -343,7 +343,12 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const E* __restrict__ z, 
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
         // the block's partial on the fixed grid of conv_stats.h: the fp64 additions are then exact, so the sums do not
         // depend on the order the blocks arrive in (bitwise reproducible run to run)
-        const double q0 = MODE == 0 ? gvconv::STAT_Q_FWD0 : gvconv::STAT_Q_BWD, q1 = MODE == 0 ? gvconv::STAT_Q_FWD1 : gvconv::STAT_Q_BWD;
+        // (fp32 storage: grids 2^-40 / 2^-36 / 2^-60 — far below fp32 resolution; exactness then holds for smaller
+        // totals only, beyond them the additions are ordinary fp64 additions)
+        const double q0 = sizeof(E) == 4 ? (MODE == 0 ? 1099511627776.0 : 1152921504606846976.0)
+                                         : (MODE == 0 ? gvconv::STAT_Q_FWD0 : gvconv::STAT_Q_BWD);
+        const double q1 = sizeof(E) == 4 ? (MODE == 0 ? 68719476736.0 : 1152921504606846976.0)
+                                         : (MODE == 0 ? gvconv::STAT_Q_FWD1 : gvconv::STAT_Q_BWD);
         atomicAdd(&acc[o], rint(a * q0) / q0);
         if (MODE != 2) atomicAdd(&acc[o + 1], rint(b * q1) / q1);
     }

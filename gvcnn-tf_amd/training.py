@@ -313,6 +313,29 @@ class TrainGVCNN:
                     nd = self.lib.gv_packed_filter_bytes(kh, kw, cout, cin, self.dt, self.math_mode)
                     op["w_fwd"] = torch.zeros(nf, dtype=torch.uint8, device=dev)
                     op["w_dgrad"] = torch.zeros(nd, dtype=torch.uint8, device=dev) if op["x"].vbuf >= 0 else None
+                    # stride-2 layer on 16-bit storage: its data gradient as FOUR parity classes (gv_conv_desc.y_step):
+                    # dX at rows of parity py / columns of parity px only receives the taps r = (py + pad) mod 2, +2, ...
+                    # — a small stride-1 convolution over the un-dilated dZ per class, 1/4 of the multiply-adds of the
+                    # zero-dilated form.  (th, tw): taps per class; pad: zero rows in front of dZ; (A, B): class outputs
+                    if op["stride"] == 2 and self.es == 2 and op["x"].vbuf >= 0 and not op.get("members"):
+                        cls = []
+                        for py in (0, 1):
+                            for px in (0, 1):
+                                r0, s0 = (py + op["pad_t"]) % 2, (px + op["pad_l"]) % 2
+                                th, tw = len(range(r0, kh, 2)), len(range(s0, kw, 2))
+                                pt = (th - 1) - (py + op["pad_t"] - r0) // 2
+                                pl = (tw - 1) - (px + op["pad_l"] - s0) // 2
+                                A, B = len(range(py, op["x"].h, 2)), len(range(px, op["x"].w, 2))
+                                if th < 1 or tw < 1 or pt < 0 or pl < 0 or A < 1 or B < 1:
+                                    cls = None
+                                    break
+                                nb_ = self.lib.gv_packed_filter_bytes(th, tw, cout, cin, self.dt, self.math_mode)
+                                cls.append(dict(py=py, px=px, r0=r0, s0=s0, th=th, tw=tw, pad_t=pt, pad_l=pl, A=A, B=B, tile=0,
+                                                w=torch.zeros(nb_, dtype=torch.uint8, device=dev)))
+                            if cls is None:
+                                break
+                        if cls:
+                            op["s2"] = cls
             nbv = nb
             self.r_img = torch.empty(nbv, dtype=f32, device=dev)
             self.scores = torch.empty(self.Vh, dtype=f32, device=dev)
@@ -340,6 +363,7 @@ class TrainGVCNN:
         # sums of z in the convolution's epilogue, the backward sums of dy in the epilogue of the data-gradient launch
         # that writes the FINAL dy (16-bit storage; False: the separate sums passes, kept for A/B and tests)
         self.fuse_bn_stats = self.es == 2
+        self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
         self._plan_bn_fusion()
 
     # -- BatchNorm sums folded into the producing launch --------------------------------------------------
@@ -566,6 +590,14 @@ class TrainGVCNN:
                              op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, self.dt, 0,
                              op.get("tile_d", 0), self.math_mode, op["stride"] if op["stride"] > 1 else 0)
 
+    def _conv_desc_s2(self, op, c_, accumulate):
+        """Descriptor of ONE parity class of a stride-2 layer's data gradient: a stride-1 convolution over dZ whose
+        output pixel (a, b) is dX pixel (2a + py, 2b + px)."""
+        x, y = op["x"], op["y"]
+        return _lib.ConvDesc(y.nb, y.h, y.w, y.c, y.ld, c_["th"], c_["tw"], 1, c_["pad_t"], c_["pad_l"], c_["A"], c_["B"],
+                             x.c, x.ld, x.ld if accumulate else 0, 0, 0, self.dt, 0, c_["tile"], self.math_mode, 0, 0,
+                             2, c_["py"], c_["px"], x.h, x.w)
+
     def autotune(self, iters=2):
         """Measure, per convolution, the fastest tile configuration of the forward launch and of the data-gradient
         launch (hipEvents on the launch stream, this engine's own buffers; gradients buffers are scratch here).
@@ -645,6 +677,36 @@ class TrainGVCNN:
                     if rc == 0 and ms.value + extra < best_ms:
                         best, best_ms = t + 1, ms.value + extra
                 op[key] = best
+                op["_" + key + "_ms"] = best_ms
+            # the parity classes of a stride-2 layer's data gradient: one tile choice each
+            for c_ in op.get("s2", ()) if self.s2_classes else ():
+                fused = bool(op.get("st_b")) and self._fusing()
+                best, best_ms = 0, float("inf")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for t in range(ncfg):
+                    c_["tile"] = t + 1
+                    dc = self._conv_desc_s2(op, c_, False)
+                    src, dst = self._ptr(y, True), self._ptr(x, True)
+                    if fused:
+                        args = (C.byref(dc), src, c_["w"].data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(), None, dst,
+                                C.byref(self._bn_stats(op, "st_b")), _st())
+                        if lib.gv_conv2d_fwd_bnstats(*args) == 0:
+                            e0.record()
+                            for _ in range(iters):
+                                lib.gv_conv2d_fwd_bnstats(*args)
+                            e1.record()
+                            e1.synchronize()
+                            if e0.elapsed_time(e1) / iters < best_ms:
+                                best, best_ms = t + 1, e0.elapsed_time(e1) / iters
+                        continue                              # (classes must all fold, or none: only folding tiles compete)
+                    rc = lib.gv_conv2d_time(C.byref(dc), src, c_["w"].data_ptr(), self.ones.data_ptr(),
+                                            self.zeros.data_ptr(), dst, iters, C.byref(ms), _st())
+                    if rc == 0 and ms.value < best_ms:
+                        best, best_ms = t + 1, ms.value
+                c_["tile"] = best
+                c_["ms"] = best_ms
+            if op.get("s2") and self.s2_classes:              # four class launches or the one zero-dilated launch?
+                op["_s2_use"] = sum(c_["ms"] for c_ in op["s2"]) < op.get("_tile_d_ms", float("inf"))
             # filter gradient (16-bit storage): tile and pixel-split choice, timed with events on the launch stream
             nw = lib.gv_conv2d_wgrad_num_cfgs(self.dt)
             if nw:
@@ -693,6 +755,12 @@ class TrainGVCNN:
                             jobs.append(_lib.PackJob(w.data_ptr(), out, kh, kw, cin, cout, flipped, len(blocks),
                                                      col if flipped and fused else 0, total if flipped and fused else 0,
                                                      w_ld))
+                            blocks.extend([len(jobs) - 1] * nblk)
+                        for c_ in op.get("s2", ()):                   # the taps of one parity class, flipped
+                            kc = c_["th"] * c_["tw"] * cout
+                            nblk = (cin * ((kc + 31) // 32 * 32) + 255) // 256
+                            jobs.append(_lib.PackJob(w.data_ptr(), c_["w"].data_ptr(), c_["th"], c_["tw"], cin, cout, 1,
+                                                     len(blocks), 0, 0, 0, 2, c_["r0"], c_["s0"], kw))
                             blocks.extend([len(jobs) - 1] * nblk)
                 raw = b"".join(bytes(j) for j in jobs)
                 self._pack_jobs = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device), len(jobs),
@@ -1055,6 +1123,30 @@ class TrainGVCNN:
                 if store:
                     dd.res_ld = 0
                 op["_st_b_done"] = False
+                if op.get("s2") and self.s2_classes and op.get("_s2_use", x.npix >= 100000):
+                    # four parity classes instead of one launch over the zero-dilated dZ (where that is faster: four
+                    # launches of a quarter of the pixels each fill the chip only on the larger maps — autotune() measures
+                    # both forms, the default goes by size); the BatchNorm sums of the
+                    # layers that produced x ride on all four (each adds the pixels it writes) or on none
+                    fuse = bool(op.get("st_b")) and zeroed and self._fusing() and op.get("_s2_stats_ok", True)
+                    for ci, c_ in enumerate(op["s2"]):
+                        dc = self._conv_desc_s2(op, c_, not store)
+                        rc = _lib.GV_E_UNSUPPORTED
+                        if fuse:
+                            rc = lib.gv_conv2d_fwd_bnstats(C.byref(dc), dz, c_["w"].data_ptr(), self.ones.data_ptr(),
+                                                           self.zeros.data_ptr(), None if store else dx, dx,
+                                                           C.byref(self._bn_stats(op, "st_b")), _st())
+                            if rc == _lib.GV_E_UNSUPPORTED:   # this class' tile cannot fold them: nobody does (from now on)
+                                fuse = op["_s2_stats_ok"] = False
+                                if ci:
+                                    for b in op["st_b"]:
+                                        b["acc_b"].zero_()
+                        if rc == _lib.GV_E_UNSUPPORTED:
+                            rc = lib.gv_conv2d_fwd(C.byref(dc), dz, c_["w"].data_ptr(), self.ones.data_ptr(),
+                                                   self.zeros.data_ptr(), None if store else dx, dx, None, None, None, _st())
+                        _lib.check(rc, "dgrad (parity class %d) %s" % (ci, op["name"]))
+                    op["_st_b_done"] = fuse
+                    return
                 if op.get("st_b") and zeroed and self._fusing():
                     # this launch writes the FINAL gradient of x: the backward sums of the BatchNorm layers that
                     # produced x leave its epilogue

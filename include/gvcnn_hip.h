@@ -111,6 +111,14 @@ typedef struct gv_conv_desc {
     int32_t relu_cols;         /* 0: GV_CONV_RELU applies to every output column.  n > 0: only to columns < n — the
                                   trailing columns leave the GEMM as BN(conv) without ReLU (an Inception pooled branch
                                   computed as relu(avgpool(BN(conv1x1(x)))), see GV_POOL_AVG_RELU) */
+    int32_t y_step;            /* 0: output pixel (n, oy, ox) is pixel (n*oh + oy)*ow + ox of y.  2: it is pixel
+                                  (2*oy + y_py, 2*ox + y_px) of an image of y_ih x y_iw pixels — ONE PARITY CLASS of the
+                                  data gradient of a stride-2 convolution (16-bit storage): dX at rows of parity y_py
+                                  and columns of parity y_px only receives the taps r = (y_py + pad_t) mod 2, +2, ...
+                                  (likewise s), so each class is a small stride-1 convolution over the UN-dilated dZ
+                                  with those taps; four launches cover dX with 1/4 of the multiply-adds the zero-dilated
+                                  form (in_dilation = 2) spends.  The residual, if any, is read at the same pixels. */
+    int32_t y_py, y_px, y_ih, y_iw;
 } gv_conv_desc;
 
 typedef struct gv_pool_desc {
@@ -154,7 +162,10 @@ typedef struct gv_pack_job {
                                    GEMM; its data-gradient image has rows of kh*kw*k_total, padding zeroed by the caller) */
     int32_t w_ld;               /* row stride of `w` in elements (0 = cout): a member filter stored as a column slice of
                                    the fused [kh,kw,cin,k_total] variable block */
-    int32_t reserved;
+    int32_t sub_step;           /* flipped only; 0 / 1: every tap.  2: ONE PARITY CLASS of a stride-2 data gradient
+                                   (gv_conv_desc.y_step): kh x kw are the class's tap counts and tap (u, v) of the packed
+                                   image is W[sub_r0 + 2*(kh-1-u), sub_s0 + 2*(kw-1-v)] of the src_kw-wide variable */
+    int32_t sub_r0, sub_s0, src_kw, reserved2;
 } gv_pack_job;
 int gv_pack_filters_batched(const gv_pack_job* jobs_dev, int32_t num_jobs, const int32_t* block_job_dev,
                             int32_t num_blocks, int32_t dtype, void* stream);

@@ -286,7 +286,7 @@ def test_engine_with_folded_sums_reproduces_the_separate_passes(backbone, size, 
         tol = 1e-5 if li < 3 else 0.3
         assert float((ma - mb).abs().max()) <= tol * max(float(ma.abs().max()), 1e-3), li
         assert float((va - vb).abs().max()) <= tol * max(float(va.abs().max()), 1e-3), li
-    assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(a["loss"])
+    assert abs(a["loss"] - b["loss"]) <= 3e-2 * abs(a["loss"])
     ga, gb = a["flat"].double(), b["flat"].double()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     print("folded vs separate sums: loss %.6f / %.6f, cosine of the filter gradients %.4f" % (a["loss"], b["loss"], cos))

@@ -432,6 +432,12 @@ def _view_sharded_step(storage):
     P = gv.params.init_backbone_params(full.plan.param_shapes(), seed=5, perturb_bn=True)
     Hd = gv.params.init_head_params(V, full.raw.c, full.final.c, C_, seed=6, spread_scores=True)
     full = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage=storage)
+    # The separate statistics passes sum every view over ITS pixels in a fixed split, whatever the engine's view count:
+    # sharded and unsharded engines are then bit-identical per view and this test can hold the fp32 tolerance on 16-bit
+    # storage too.  The sums folded into the convolution epilogues (fuse_bn_stats) are grouped by row tile, i.e. they
+    # depend on how the views interleave in the batch: equal to summation order only (test_gpu_bn_fusion.py), which the
+    # train-mode statistics of a random network then amplify.
+    full.fuse_bn_stats = False
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(DEV)
     labels = torch.tensor([0, 3, 1])
     full.forward(x, labels)
@@ -439,6 +445,8 @@ def _view_sharded_step(storage):
     Vl = V // 2
     engs = [TrainGVCNN(backbone, N, Vl, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV,
                        head_views=V, view_offset=r * Vl, storage=storage) for r in range(2)]
+    for e in engs:
+        e.fuse_bn_stats = False
     f = engs[0].final
     for r, e in enumerate(engs):
         e.forward_backbone(x[:, r * Vl:(r + 1) * Vl].contiguous())

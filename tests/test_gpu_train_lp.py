@@ -675,6 +675,10 @@ def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V
     always accumulate, mask read from y) on the same forward pass the gradients must be IDENTICAL: same addends,
     same order, same masks."""
     eng = TrainGVCNN(backbone, N, V, size, size, 5, 10, device=DEV, storage=storage)
+    # (the plain form cannot fold its BatchNorm sums into the data-gradient launches — it takes its masks from y — so
+    # the folded sums, equal to the separate ones to summation order only, are switched off on both sides: this test is
+    # about WHICH addends reach a gradient buffer, bit for bit)
+    eng.fuse_bn_stats = False
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
     labels = torch.tensor([1, 4, 2, 0][:N])
     eng.forward(x, labels, check=False)
@@ -809,3 +813,84 @@ def test_16bit_training_runs_at_other_geometries(backbone, storage, N, V, size, 
     grads = eng.backward()
     assert all(np.isfinite(l) for l in losses) and losses[-1] < losses[0], losses
     assert all(bool(torch.isfinite(v).all()) for v in grads.values())
+
+
+# ---- stride-2 data gradient by parity classes (gv_conv_desc.y_step) -----------------------------------------------------
+S2_CONVS = [((3, 3), (0, 0), 288, 384, 3, 25, 25),       # Mixed_6a/Branch_0 (nets/inception_v3.py:210): 25 -> 12, VALID
+            ((3, 3), (0, 0), 96, 96, 4, 12, 13),         # odd and even maps, rows no window reaches
+            ((3, 3), (1, 1), 64, 64, 3, 14, 14),         # ResNet conv2 of a stride-2 unit: pad(1,1) + VALID
+            ((3, 3), (0, 0), 192, 320, 5, 4, 4)]         # a 4x4 map (Mixed_7a at a 96-pixel input): 1x1 output
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("k,pads,cin,cout,nb,ih,iw", S2_CONVS)
+def test_stride2_data_gradient_by_parity_classes(dt, tdt, eps, k, pads, cin, cout, nb, ih, iw):
+    """dX of a stride-2 convolution as FOUR stride-1 launches over the un-dilated dZ, one per (row parity, column parity)
+    of dX, each with the taps that reach that parity and a two-level output stride — against torch autograd through the
+    oracle's convolution (the zero-dilated single launch is held to the same reference above), in store and in
+    accumulate mode, filters packed by gv_pack_filters_batched's sub_step form straight from the HWIO variable."""
+    g = torch.Generator().manual_seed(5)
+    x = q(torch.randn(nb, ih, iw, cin, generator=g), tdt).requires_grad_(True)
+    w = q(torch.randn(k[0], k[1], cin, cout, generator=g) * 0.1, tdt).requires_grad_(True)
+    z = OB.conv2d(x, w, 2, (pads[0], pads[0], pads[1], pads[1]))
+    dz = q(torch.randn(*z.shape, generator=g), tdt)
+    z.backward(dz)
+    oh, ow = z.shape[1:3]
+    xld, zld = cin + 8, cout + 16
+    dzd = torch.zeros(nb, oh, ow, zld, dtype=tdt, device=DEV)
+    dzd[..., :cout] = dz.to(tdt).to(DEV)
+    wd = w.detach().to(DEV).contiguous()
+    classes, jobs, blocks = [], [], []
+    for py in (0, 1):
+        for px in (0, 1):
+            r0, s0 = (py + pads[0]) % 2, (px + pads[1]) % 2
+            th, tw = len(range(r0, k[0], 2)), len(range(s0, k[1], 2))
+            pt, pl = (th - 1) - (py + pads[0] - r0) // 2, (tw - 1) - (px + pads[1] - s0) // 2
+            A, B = len(range(py, ih, 2)), len(range(px, iw, 2))
+            assert th >= 1 and tw >= 1 and pt >= 0 and pl >= 0
+            buf = torch.zeros(lib().gv_packed_filter_bytes(th, tw, cout, cin, dt, 0), dtype=torch.uint8, device=DEV)
+            kc = th * tw * cout
+            jobs.append(_lib.PackJob(wd.data_ptr(), buf.data_ptr(), th, tw, cin, cout, 1, len(blocks), 0, 0, 0, 2, r0, s0, k[1]))
+            blocks.extend([len(jobs) - 1] * ((cin * ((kc + 31) // 32 * 32) + 255) // 256))
+            classes.append((py, px, th, tw, pt, pl, A, B, buf))
+    jd = torch.frombuffer(bytearray(b"".join(bytes(j) for j in jobs)), dtype=torch.uint8).to(DEV)
+    bj = torch.tensor(blocks, dtype=torch.int32, device=DEV)
+    _lib.check(lib().gv_pack_filters_batched(jd.data_ptr(), len(jobs), bj.data_ptr(), bj.numel(), dt, st()), "pack")
+    ones, zeros = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+    for accumulate in (0, 1):
+        dx = torch.full((nb, ih, iw, xld), 0.25, dtype=tdt, device=DEV)
+        for tile in (0, 2, 14):
+            dx.fill_(0.25)
+            for py, px, th, tw, pt, pl, A, B, buf in classes:
+                d = _lib.ConvDesc(nb, oh, ow, cout, zld, th, tw, 1, pt, pl, A, B, cin, xld, xld if accumulate else 0, 0, 0, dt,
+                                  0, tile, 0, 0, 0, 2, py, px, ih, iw)
+                _lib.check(lib().gv_conv2d_fwd(C.byref(d), dzd.data_ptr(), buf.data_ptr(), ones.data_ptr(), zeros.data_ptr(),
+                                               dx.data_ptr() if accumulate else None, dx.data_ptr(), None, None, None, st()),
+                           "parity class (%d, %d)" % (py, px))
+            got = dx[..., :cin].float().cpu() - (0.25 if accumulate else 0.0)
+            close(got, x.grad, 2 * eps)
+            assert float((dx[..., cin:].float() - 0.25).abs().max()) == 0.0     # the wider buffer's other channels untouched
+
+
+def test_wgrad_on_one_pixel_wide_maps():
+    """1-wide / 1-high output maps (the last blocks at small inputs): the LDS-DMA filter gradient's pixel walk divides by
+    the map size with a 32-bit reciprocal that does not exist for 1 — those layers must take the other tiles (advisor
+    finding of round 2: every pixel past the first 32 of a workgroup's slice was dropped)."""
+    dt, tdt = _lib.GV_BF16, torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    for (ih, iw, kh, kw, pt, pl) in ((1, 1, 1, 1, 0, 0), (1, 5, 1, 3, 0, 1), (7, 1, 3, 1, 1, 0)):
+        nb, cin, cout = 80, 64, 96                          # 80 images: more than 32 pixels per workgroup slice
+        x = q(torch.randn(nb, ih, iw, cin, generator=g), tdt).requires_grad_(True)
+        w = q(torch.randn(kh, kw, cin, cout, generator=g) * 0.1, tdt).requires_grad_(True)
+        z = OB.conv2d(x, w, 1, (pt, pt, pl, pl))
+        dz = q(torch.randn(*z.shape, generator=g), tdt)
+        z.backward(dz)
+        xd, dzd = x.detach().to(tdt).to(DEV), dz.to(tdt).to(DEV)
+        for cfg in (0, 1, 31, 43, 47):
+            dw = torch.zeros(kh, kw, cin, cout, device=DEV)
+            d = _lib.ConvDesc(nb, ih, iw, cin, cin, kh, kw, 1, pt, pl, ih, iw, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
+            rc = lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), cout, dw.data_ptr(), st())
+            if rc == _lib.GV_E_UNSUPPORTED and cfg >= 31:
+                continue                                    # the LDS-DMA forms decline 1-wide maps
+            _lib.check(rc, "wgrad cfg %d" % cfg)
+            close(dw.cpu(), w.grad, 3e-5)
