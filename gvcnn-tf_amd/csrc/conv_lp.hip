@@ -396,7 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STAT
 // per output row.
 // CIN: 32 (Conv2d_2a / 2b forward) or 64 (the data gradient of Conv2d_2b: 64 -> 32 channels over the padded map; filter of
 // 9 x 64 values per output channel in LDS).
-template <typename T, int TN, int RPW, int CIN = 32>
+template <typename T, int TN, int RPW, int CIN = 32, int STATS = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
     constexpr int TH = 4 * RPW, TW = 32, HH = TH + 2, HW = TW + 2, PB = CIN * 2 + 16;   // halo pixel + 16 B pad
     constexpr int CPP = CIN / 8, KS = CIN / 16;                               // 16-byte chunks / MFMA k-steps per pixel
@@ -460,6 +460,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
     const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0) &&
                      (res == nullptr || ((a.res_ld % 8 == 0) && ((((uintptr_t)res) & 15) == 0)));
 
+    // STATS: the train-mode BatchNorm sums of the tensor this launch stores (conv_stats.h): the whole strip is one image
+    gvconv::StatStrip<STATS == 0 ? gvconv::STAT_FWD : STATS, TN> sstat;
+    const int sgrp = STATS != 0 ? n % a.st.G : 0;
+    if constexpr (STATS != 0) sstat.init(a.st, sgrp, col8, a.cout);
+
     u32x4 hr[SL];
     auto fetch = [&](int oy0) {
 #pragma unroll
@@ -486,6 +491,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
         }
         __syncthreads();
         if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under the MFMAs below
+        // STAT_BWD: the z chunks this tile's epilogue will need, requested here so that they too travel under the MFMAs
+        // (fetched inside the epilogue every row-chunk waited out a memory round trip: Conv2d_2a's data gradient 0.145 ->
+        // 0.29 ms instead of -> 0.19)
+        u32x4 zpre[STATS == gvconv::STAT_BWD ? RPW * TN : 1][2];
+        if constexpr (STATS == gvconv::STAT_BWD) {
+#pragma unroll
+            for (int qj = 0; qj < RPW * TN; ++qj) {
+                const int q = qj / TN, j = qj % TN;
+                const int oy = oy0 + wave + 4 * q;
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int row = pass * 16 + rrow;
+                    const bool ok = oy < a.oh && ox0 + row < a.ow && j * 32 + col8 + 8 <= a.cout;
+                    const size_t m = (size_t)(n * a.oh + (ok ? oy : 0)) * a.ow + (ok ? ox0 + row : 0);
+                    zpre[qj][pass] = ok ? *reinterpret_cast<const u32x4*>(sstat.zb[j] + m * sstat.zld) : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
         f32x16 acc[RPW][TN];
 #pragma unroll
         for (int q = 0; q < RPW; ++q)
@@ -552,11 +575,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (colj + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
                 }
+                if constexpr (STATS != 0) {               // sums of the values exactly as stored below
+                    if (nvalid == 8 && !(a.st.dbg & 8192)) {
+                        float rr[8];
+                        unsigned zq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rr[e] = from_bits<T>(to_bits<T>(v[e]));
+                        if constexpr (STATS == gvconv::STAT_BWD) {
+                            const u32x4 zz = zpre[qj][pass];
+                            zq[0] = zz[0]; zq[1] = zz[1]; zq[2] = zz[2]; zq[3] = zz[3];
+                        }
+                        if (j == 0) sstat.template add<T, 0>(rr, zq);
+                        else sstat.template add<T, (TN > 1 ? 1 : 0)>(rr, zq);
+                    }
+                }
                 store_chunk<T>(y + m * a.y_ld + colj, v, nvalid, vec);
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (STATS != 0) sstat.finish(a.st, stage, lane, sgrp, a.cout);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -568,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 // owns KR = 16 (3x3) or 24 (7x7) slots of which KW*3 are real — so the 8 values of an MFMA fragment are 8
 // CONSECUTIVE patch elements: four ds_read_b32 (lane stride 12 B: conflict-free), no per-element addressing at all.
 // The filter is re-ordered the same way into LDS once per workgroup.
-template <typename T, int TN, int KW>
+template <typename T, int TN, int KW, int STATS = 0>
 __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
     constexpr int KR = KW == 3 ? 16 : 24;                   // k slots per filter row (multiple of 8)
     constexpr int NG = (KW * KR / 8 + 1) / 2 * 2;           // 8-value groups, padded to whole 16-deep k-steps
@@ -611,6 +649,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
             sh[j][e] = a.shift[c];
         }
     const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0);
+
+    gvconv::StatStrip<gvconv::STAT_FWD, TN> sstat;          // STATS (forward sums only: this kernel has no data-gradient use)
+    const int sgrp = STATS != 0 ? n % a.st.G : 0;
+    if constexpr (STATS != 0) sstat.init(a.st, sgrp, col8, a.cout);
 
     float pr_[SL];
     auto fetch = [&](int oy0) {
@@ -682,11 +724,22 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
                     v[e] = v[e] * sc[j][e] + sh[j][e];
                     if (a.relu && colj + e < a.relu_limit) v[e] = fmaxf(v[e], 0.f);
                 }
+                if constexpr (STATS != 0) {               // sums of the values exactly as stored below
+                    if (nvalid == 8 && !(a.st.dbg & 8192)) {
+                        float rr[8];
+                        const unsigned zq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rr[e] = from_bits<T>(to_bits<T>(v[e]));
+                        if (j == 0) sstat.template add<T, 0>(rr, zq);
+                        else sstat.template add<T, (TN > 1 ? 1 : 0)>(rr, zq);
+                    }
+                }
                 store_chunk<T>(y + m * a.y_ld + colj, v, nvalid, vec);
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (STATS != 0) sstat.finish(a.st, stage, lane, sgrp, a.cout);
 }
 
 // [kh][kw][cin][cout] fp32 -> [cout][Kpad] T, k = (r*kw+s)*cin + c, zero filled to a multiple of 32
@@ -823,58 +876,75 @@ int launch_t(int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st
     return GV_E_UNSUPPORTED;
 }
 
-template <typename T, int RPW>
+// (STATS: the instantiation that also produces the train-mode BatchNorm sums of its output, conv_stats.h)
+template <typename T, int RPW, int STATS>
 int launch_halo_r(const ConvArgs& a, hipStream_t st) {
     const int tiles_x = (a.ow + 31) / 32;
     const dim3 grid((unsigned)(a.nb * tiles_x));
     const size_t halo = (size_t)(4 * RPW + 2) * 34 * 80;
     if (a.cout <= 32) {
         const size_t lds = halo + 4 * 32 * (32 + 4) * 4;
-        hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, RPW>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, RPW, 32, STATS>), grid, dim3(256), lds, st, a);
     } else {
         const size_t lds = halo + (RPW == 2 ? 0 : 4 * 32 * (32 + 4) * 4) + 64 * (288 * 2 + 16);   // (RPW = 2: staging aliases the halo)
-        const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 2, RPW>), 160 * 1024);
+        const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 2, RPW, 32, STATS>), 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
-        hipLaunchKernelGGL((conv3x3_halo_lp<T, 2, RPW>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv3x3_halo_lp<T, 2, RPW, 32, STATS>), grid, dim3(256), lds, st, a);
     }
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
 
-template <typename T>
+template <typename T, int STATS>
 int launch_halo64(const ConvArgs& a, hipStream_t st) {                       // 64 input channels, <= 32 output channels
     const int tiles_x = (a.ow + 31) / 32;
     const size_t lds = (size_t)6 * 34 * (64 * 2 + 16) + 32 * (9 * 64 * 2 + 16);      // (staging aliases the halo)
-    const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 1, 1, 64>), 160 * 1024);
+    const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 1, 1, 64, STATS>), 160 * 1024);
     if (!ok) return GV_E_UNSUPPORTED;
-    hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, 1, 64>), dim3((unsigned)(a.nb * tiles_x)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_lp<T, 1, 1, 64, STATS>), dim3((unsigned)(a.nb * tiles_x)), dim3(256), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
 
-template <typename T>
-int launch_halo(const ConvArgs& a, hipStream_t st) {
-    if (a.cin == 64) return launch_halo64<T>(a, st);
+template <typename T, int STATS>
+int launch_halo_s(const ConvArgs& a, hipStream_t st) {
+    if (a.cin == 64) return launch_halo64<T, STATS>(a, st);
     // two rows per wave wherever the map has them: Conv2d_2a 0.225 -> 0.150 ms.  With the 64-column filter in LDS the taller
     // halo would cost the second resident workgroup (84 KB: Conv2d_2b 0.295 -> 0.385 ms), so that form lets the staging
     // blocks alias the halo (65 KB): 0.335 -> 0.283 ms.  Debug bit 1024: one row per wave (A/B)
-    return (a.oh >= 8 && !(a.dbg & 1024)) ? launch_halo_r<T, 2>(a, st) : launch_halo_r<T, 1>(a, st);
+    return (a.oh >= 8 && !(a.dbg & 1024)) ? launch_halo_r<T, 2, STATS>(a, st) : launch_halo_r<T, 1, STATS>(a, st);
 }
 
-template <typename T, int TN, int KW>
+template <typename T>
+int launch_halo(const ConvArgs& a, hipStream_t st) {
+    if (a.st.mode == gvconv::STAT_FWD) return launch_halo_s<T, gvconv::STAT_FWD>(a, st);
+    // The BACKWARD sums are not folded into this kernel: they need z next to every chunk of dy it stores, and one wave per
+    // SIMD with its loads retiring in order has nothing to hide 290 MB of extra reads behind — measured on the data
+    // gradients of Conv2d_2a / 2b: 0.145 -> 0.29 ms fetched in the epilogue, 0.34 ms prefetched in front of the MFMAs,
+    // against 0.14 ms for the separate sums pass it would replace (the code path exists: STATS = STAT_BWD compiles)
+    if (a.st.mode == gvconv::STAT_BWD) return GV_E_UNSUPPORTED;
+    return launch_halo_s<T, 0>(a, st);
+}
+
+template <typename T, int TN, int KW, int STATS>
 int launch_stem_one(const ConvArgs& a, hipStream_t st) {
     constexpr int KR = KW == 3 ? 16 : 24, NG = (KW * KR / 8 + 1) / 2 * 2, PR = 3 * 2 + KW + 1, PC = 31 * 2 + KW;
     constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;
     const size_t lds = (size_t)PR * PITCH + 4 * 32 * 36 * 4 + (size_t)32 * TN * (NG * 16 + 16);
-    hipLaunchKernelGGL((conv_stem_patch_lp<T, TN, KW>), dim3((unsigned)(a.nb * ((a.ow + 31) / 32))), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_stem_patch_lp<T, TN, KW, STATS>), dim3((unsigned)(a.nb * ((a.ow + 31) / 32))), dim3(256), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;
 }
 
 template <typename T>
 int launch_stem(const ConvArgs& a, hipStream_t st) {
-    if (a.kw == 3) return a.cout <= 32 ? launch_stem_one<T, 1, 3>(a, st) : launch_stem_one<T, 2, 3>(a, st);
-    return a.cout <= 32 ? launch_stem_one<T, 1, 7>(a, st) : launch_stem_one<T, 2, 7>(a, st);
+    if (a.st.mode == gvconv::STAT_BWD) return GV_E_UNSUPPORTED;             // (a first layer has no data gradient)
+    if (a.st.mode == gvconv::STAT_FWD) {
+        if (a.kw == 3) return a.cout <= 32 ? launch_stem_one<T, 1, 3, gvconv::STAT_FWD>(a, st) : launch_stem_one<T, 2, 3, gvconv::STAT_FWD>(a, st);
+        return a.cout <= 32 ? launch_stem_one<T, 1, 7, gvconv::STAT_FWD>(a, st) : launch_stem_one<T, 2, 7, gvconv::STAT_FWD>(a, st);
+    }
+    if (a.kw == 3) return a.cout <= 32 ? launch_stem_one<T, 1, 3, 0>(a, st) : launch_stem_one<T, 2, 3, 0>(a, st);
+    return a.cout <= 32 ? launch_stem_one<T, 1, 7, 0>(a, st) : launch_stem_one<T, 2, 7, 0>(a, st);
 }
 
 }  // namespace
@@ -928,7 +998,9 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
     if (cfg == kNumTiles) {
-        if (a.st.mode != STAT_OFF || a.y_step != 0) return GV_E_UNSUPPORTED;   // (not in the strip / halo kernels)
+        if (a.y_step != 0) return GV_E_UNSUPPORTED;              // (the strip / halo kernels have no two-level output stride)
+        // BatchNorm sums: one segment over every output column (these kernels own whole images: no slot table)
+        if (a.st.mode != STAT_OFF && !stat_strip_ok_host(a.st, a.cout)) return GV_E_UNSUPPORTED;
         if (lp_stem_ok(a, xf32)) {
             if (dtype == GV_BF16) return launch_stem<__bf16>(a, st);
             if (dtype == GV_F16) return launch_stem<_Float16>(a, st);

@@ -216,6 +216,81 @@ struct StatWave {
     }
 };
 
+// The strip kernels (conv3x3_halo_lp, conv_stem_patch_lp): a workgroup walks down a column strip of ONE image, so a lane
+// (16 row lanes x 4 chunks of 8 channels per 32-column tile) keeps its sums in registers for the whole walk and the
+// statistics leave the workgroup once, at the end: per wave a transposition through its private staging block (fixed
+// order), then 64 lanes add one column total each to the fp64 accumulators (rounded to the grid: exact additions).
+// One segment covering every output column (the launcher checks).
+template <int MODE, int TN>
+struct StatStrip {
+    float s0[TN][8], s1[TN][8];
+    float sc[TN][8], sh[TN][8];                                      // STAT_BWD: mask constants of the image's group
+    const unsigned short* zb[TN];                                    // STAT_BWD: z at this lane's 8 channels of tile j
+    int zld;
+    __device__ __forceinline__ void init(const ConvStats& s, int g, int col8, int cout) {
+        zld = s.seg[0].z_ld;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = j * 32 + col8;
+            zb[j] = s.seg[0].z ? s.seg[0].z + c : nullptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s0[j][e] = s1[j][e] = 0.f;
+                const int cc = c + e < cout ? c + e : cout - 1;
+                sc[j][e] = (MODE == STAT_BWD && s.seg[0].scale) ? s.seg[0].scale[(size_t)g * cout + cc] : 0.f;
+                sh[j][e] = (MODE == STAT_BWD && s.seg[0].scale) ? s.seg[0].shift[(size_t)g * cout + cc] : 1.f;
+            }
+        }
+    }
+    // r[e]: the stored (rounded) values of pixel m, column tile J; zq: the 16 bytes of z at that chunk (STAT_BWD)
+    template <typename T, int J>
+    __device__ __forceinline__ void add(const float (&r)[8], const unsigned (&zq)[4]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (MODE == STAT_FWD) {
+                s0[J][e] += r[e];
+                s1[J][e] = fmaf(r[e], r[e], s1[J][e]);
+            } else {
+                const unsigned short b = (unsigned short)((e & 1) ? (zq[e >> 1] >> 16) : (zq[e >> 1] & 0xffffu));
+                const float zv = (float)__builtin_bit_cast(T, b);
+                const float g = fmaf(zv, sc[J][e], sh[J][e]) > 0.f ? r[e] : 0.f;
+                s0[J][e] += g;
+                s1[J][e] = fmaf(g, zv, s1[J][e]);
+            }
+        }
+    }
+    // stage: the wave's private block (>= 1024 floats); lane = (row lane rrow = lane >> 2, chunk c4 = lane & 3)
+    __device__ __forceinline__ void finish(const ConvStats& s, float* stage, int lane, int g, int cout) {
+        if (s.dbg & 4096) return;
+        const double q0 = MODE == STAT_FWD ? STAT_Q_FWD0 : STAT_Q_BWD, q1 = MODE == STAT_FWD ? STAT_Q_FWD1 : STAT_Q_BWD;
+        const int rrow = lane >> 2, c4 = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            __builtin_amdgcn_wave_barrier();
+            f32x4* w = reinterpret_cast<f32x4*>(stage + (rrow * 4 + c4) * 16);
+            w[0] = f32x4{s0[j][0], s1[j][0], s0[j][1], s1[j][1]};
+            w[1] = f32x4{s0[j][2], s1[j][2], s0[j][3], s1[j][3]};
+            w[2] = f32x4{s0[j][4], s1[j][4], s0[j][5], s1[j][5]};
+            w[3] = f32x4{s0[j][6], s1[j][6], s0[j][7], s1[j][7]};
+            __builtin_amdgcn_wave_barrier();
+            const int oc4 = lane >> 4, oe = (lane >> 1) & 7, ok = lane & 1;     // this lane's output: (chunk, channel, which sum)
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += stage[(r * 4 + oc4) * 16 + oe * 2 + ok];
+            const int col = j * 32 + oc4 * 8 + oe;
+            if (col < cout && t != 0.f) {
+                const double q = ok ? q1 : q0;
+                atomicAdd(s.seg[0].acc + ((size_t)g * cout + col) * 2 + ok, rint((double)t * q) / q);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+};
+// one segment with an accumulator over every output column: what the strip kernels fold
+static inline bool stat_strip_ok_host(const ConvStats& s, int cout) {
+    return s.nseg == 1 && s.seg[0].c0 == 0 && s.seg[0].c1 == cout && s.seg[0].acc != nullptr && cout % 8 == 0 && s.G >= 1;
+}
+
 // Workgroup epilogue (after a barrier behind the last flush): one thread per tile column adds the table to the fp64
 // accumulators, partials rounded to the grid first.  slots_used: slots the tile's rows actually reach.
 template <int MODE>

@@ -582,9 +582,12 @@ class TrainGVCNN:
                                  op["pad_l"], y.h, y.w, y.c, y.ld, 0, 0, 0, self.dt, 0, op.get("tile_w", 0),
                                  self.math_mode, 0)
         if not dgrad:
+            # the first layer of a 16-bit engine reads the fp32 images themselves (GV_CONV_X_F32: rounded by the loader to
+            # the very values the 16-bit copy holds), which is what the strip kernel of the 3-channel stems takes
+            xf32 = _lib.GV_CONV_X_F32 if (x.vbuf < 0 and self.es == 2) else 0
             return _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"], op["pad_t"],
                                  op["pad_l"], y.h, y.w, y.c, y.ld, op["res"].ld if op["res"] is not None else 0,
-                                 0, 0, self.dt, 0, op.get("tile_f", 0), self.math_mode, 0)
+                                 0, xf32, self.dt, 0, op.get("tile_f", 0), self.math_mode, 0)
         # data gradient: dX = conv(dilate(dZ, stride), flip(W)^T), pad' = k-1-pad, accumulate into dX
         return _lib.ConvDesc(y.nb, y.h, y.w, y.c, y.ld, op["kh"], op["kw"], 1, op["kh"] - 1 - op["pad_t"],
                              op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, self.dt, 0,
@@ -640,7 +643,8 @@ class TrainGVCNN:
             if op["kind"] != "conv":
                 continue
             x, y = op["x"], op["y"]
-            jobs = [("tile_f", False, self._ptr(x), op["w_fwd"], self._ptr(y))]
+            jobs = [("tile_f", False, self._x32.data_ptr() + 4 * x.off if (x.vbuf < 0 and self.es == 2) else self._ptr(x),
+                     op["w_fwd"], self._ptr(y))]
             if x.vbuf >= 0:
                 jobs.append(("tile_d", True, self._ptr(y, True), op["w_dgrad"], self._ptr(x, True)))
             for key, dgrad, src, w, dst in jobs:
@@ -802,6 +806,7 @@ class TrainGVCNN:
         lib = self.lib
         assert tuple(views.shape) == (self.N, self.V, self.H, self.W, 3) and views.is_cuda
         self._x = views.to(self.tdt).contiguous()
+        self._x32 = views.float().contiguous()            # (what the first convolution's forward launch reads)
         if self._packed_dirty:
             self.repack()
         if self._zacc:
@@ -878,15 +883,16 @@ class TrainGVCNN:
             shift = self.params[op["bias"]] if op["bias"] else self.zeros
             res = op["res"]
             op["_st_f_done"] = False
+            xin = self._x32.data_ptr() + 4 * x.off if (x.vbuf < 0 and self.es == 2) else self._ptr(x)
             if op.get("st_f") and zeroed and self._fusing():  # the BatchNorm sums of z in this launch's epilogue
-                rc = lib.gv_conv2d_fwd_bnstats(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
+                rc = lib.gv_conv2d_fwd_bnstats(C.byref(d), xin, op["w_fwd"].data_ptr(), self.ones.data_ptr(),
                                                shift.data_ptr(), None, self._ptr(y), C.byref(self._bn_stats(op, "st_f")),
                                                _st())
                 if rc != _lib.GV_E_UNSUPPORTED:               # (unsupported tile / geometry: the plain launch below)
                     _lib.check(rc, "conv + BN sums " + op["name"])
                     op["_st_f_done"] = True
                     return
-            _lib.check(lib.gv_conv2d_fwd(C.byref(d), self._ptr(x), op["w_fwd"].data_ptr(), self.ones.data_ptr(),
+            _lib.check(lib.gv_conv2d_fwd(C.byref(d), xin, op["w_fwd"].data_ptr(), self.ones.data_ptr(),
                                          shift.data_ptr(), self._ptr(res) if res is not None else None,
                                          self._ptr(y), None, None, None, _st()), "conv " + op["name"])
         elif op["kind"] == "bn":

@@ -291,3 +291,62 @@ def test_engine_with_folded_sums_reproduces_the_separate_passes(backbone, size, 
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     print("folded vs separate sums: loss %.6f / %.6f, cosine of the filter gradients %.4f" % (a["loss"], b["loss"], cos))
     assert cos > 0.2, cos                                 # (coarse: same direction; see the note above)
+
+
+# ---- the strip kernels of the stem (conv3x3_halo_lp, conv_stem_patch_lp): whole-image strips, sums leave once per workgroup
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,hw,nb,mode", [(32, 32, (23, 41), 6, _lib.GV_BN_STATS_FWD), (32, 64, (23, 41), 6, _lib.GV_BN_STATS_FWD),
+                                                 (32, 64, (6, 70), 5, _lib.GV_BN_STATS_FWD), (32, 32, (23, 41), 6, _lib.GV_BN_STATS_BWD),
+                                                 (64, 32, (19, 37), 6, _lib.GV_BN_STATS_BWD)])
+def test_fused_sums_in_the_halo_kernel(ty, cin, cout, hw, nb, mode):
+    """Conv2d_2a / 2b (3x3, 32 input channels) run on the halo-tiled strip kernel; it folds the FORWARD sums per image
+    strip.  Same checks as the tile kernels: the stored tensor equals the plain launch's, the sums are those of the stored
+    tensor.  The backward sums are declined (measured slower than the separate pass: csrc/conv_lp.hip launch_halo)."""
+    special = lib().gv_conv2d_special_tile_cfg(-1) + 1
+    V = 3
+    rc, yd, accs, ctx = run_fused(ty, nb, hw, cin, cout, 3, 1, V, special, [(0, cout)], mode, seed=9)
+    if mode == _lib.GV_BN_STATS_BWD:
+        assert rc == _lib.GV_E_UNSUPPORTED and float(yd.float().min()) == -7.0 and float(accs[0].abs().max()) == 0.0
+        return
+    _lib.check(rc, "halo kernel with folded sums")
+    plain = torch.full_like(yd, -3.0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(ctx["d"]), ctx["x"].data_ptr(), ctx["wp"].data_ptr(), ctx["ones"].data_ptr(),
+                                   ctx["zeros"].data_ptr(), None, plain.data_ptr(), None, None, None, st()), "plain")
+    torch.cuda.synchronize()
+    assert torch.equal(plain, yd)
+    check_sums(accs, reference_sums(ty, yd, [(0, cout)], V, mode, ctx))
+    # two segments: the strip kernels decline (they keep one accumulator set per lane)
+    rc2, yd2, accs2, _ = run_fused(ty, nb, hw, cin, cout, 3, 1, V, special, [(0, 16), (16, cout)], mode, seed=9)
+    assert rc2 == _lib.GV_E_UNSUPPORTED and float(yd2.float().min()) == -7.0
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_fused_sums_in_the_stem_strip_kernel(ty):
+    """Conv2d_1a 3x3/2 on the fp32 images (GV_CONV_X_F32) with the forward sums folded in."""
+    code, td = TYPES[ty]
+    special = lib().gv_conv2d_special_tile_cfg(-1) + 1
+    g = torch.Generator().manual_seed(2)
+    nb, h, w, cout, V = 5, 47, 75, 32, 4
+    x = (torch.rand(nb, h, w, 3, generator=g) - 0.5).to(DEV)
+    wt = (torch.randn(3, 3, 3, cout, generator=g) * 0.3).to(td).float()
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    wp = pack(wt, code)
+    ones, zeros = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    outs = []
+    for fused in (True, False):
+        yd = torch.full((nb, oh, ow, cout), -7.0, dtype=td, device=DEV)
+        acc = torch.zeros(V * cout * 2, dtype=torch.float64, device=DEV)
+        d = _lib.ConvDesc(nb, h, w, 3, 3, 3, 3, 2, 0, 0, oh, ow, cout, cout, 0, 0, _lib.GV_CONV_X_F32, code, 0, special, 0, 0)
+        if fused:
+            stt = _lib.BnStats()
+            stt.mode, stt.groups, stt.nseg = _lib.GV_BN_STATS_FWD, V, 1
+            stt.seg[0].c0, stt.seg[0].c1, stt.seg[0].acc = 0, cout, acc.data_ptr()
+            _lib.check(lib().gv_conv2d_fwd_bnstats(C.byref(d), x.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(),
+                                                   None, yd.data_ptr(), C.byref(stt), st()), "stem strip + sums")
+        else:
+            _lib.check(lib().gv_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None,
+                                           yd.data_ptr(), None, None, None, st()), "stem strip")
+        torch.cuda.synchronize()
+        outs.append((yd, acc))
+    assert torch.equal(outs[0][0], outs[1][0])
+    check_sums([outs[0][1]], reference_sums(ty, outs[0][0], [(0, cout)], V, _lib.GV_BN_STATS_FWD, {}))

@@ -49,7 +49,8 @@ for op in eng.plan.ops:
             d.res_ld = 0
             src, w, dst = eng._ptr(op["y"], True), op["w_dgrad"], eng._ptr(op["x"], True)
         else:
-            src, w, dst = eng._ptr(op["x"]), op["w_fwd"], eng._ptr(op["y"])
+            src = eng._x32.data_ptr() if op["x"].vbuf < 0 else eng._ptr(op["x"])
+            w, dst = op["w_fwd"], eng._ptr(op["y"])
         stt = eng._bn_stats(op, key)
         plain = lambda: lib.gv_conv2d_fwd(C.byref(d), src, w.data_ptr(), eng.ones.data_ptr(), eng.zeros.data_ptr(), None, dst, None, None, None, st)
         fused = lambda: lib.gv_conv2d_fwd_bnstats(C.byref(d), src, w.data_ptr(), eng.ones.data_ptr(), eng.zeros.data_ptr(), None, dst, C.byref(stt), st)
