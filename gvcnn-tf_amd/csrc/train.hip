@@ -1168,6 +1168,10 @@ extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void*
         // lose the prefetch, 7-13 ms against ~1 ms)
         if (!g_wgrad_lp_f32 && gvlp::wgrad_mfma_ok(d, x, dz, dz_ld))
             return gvlp::conv_wgrad(d, x, dz, dz_ld, dw_hwio, st);
+        if (!g_wgrad_lp_f32 && d->cin <= 4) {             // the 3-channel stems: row strips on the 16-bit MFMA
+            const int rc = gvlp::conv_wgrad_stem(d, x, dz, dz_ld, dw_hwio, st);
+            if (rc != GV_E_UNSUPPORTED) return rc;
+        }
         if (d->dtype == GV_BF16) return wgrad_f32mfma<__bf16>(d, (const __bf16*)x, (const __bf16*)dz, dz_ld, dw_hwio, st);
         return wgrad_f32mfma<_Float16>(d, (const _Float16*)x, (const _Float16*)dz, dz_ld, dw_hwio, st);
     }

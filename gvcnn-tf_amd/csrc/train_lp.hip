@@ -1431,6 +1431,202 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     return GV_OK;
 }
 
+
+// ---- filter gradient of the 3-channel stems (Conv2d_1a 3x3/2, ResNet conv1 7x7/2) on the 16-bit MFMA -----------------------
+// dW[rho][co] = sum over pixels of X[pixel shifted by tap(rho)][ci(rho)] * dZ[pixel][co], rho = tap*cin + ci: 27 (147)
+// rows of 32 (64) columns over millions of pixels — a reduction, HBM-bound by construction (Conv2d_1a: 116 MB of
+// images + 303 MB of dZ per step).  The direct kernel (train.hip: conv_wgrad_direct_f32) gathers both operands with
+// 2-byte loads, one per lane and pixel, and multiplies on the fp32 MFMA (2 pixels per instruction): 0.48 ms at 17 TFLOP/s.
+// Here a WAVE owns a run of (image, output row) units.  Per unit it copies the kh input rows and the one dZ row into its
+// private LDS area with 16-byte loads (both are contiguous in memory), one unit ahead in registers, and multiplies
+// 16 pixels per v_mfma_f32_32x32x16: the dZ operand comes back through the transposing ds_read_b64_tr_b16 (lane =
+// channel, 4 consecutive pixels per read), the image operand as 8 two-byte LDS reads per lane at a 2*stride*cin-byte
+// pitch (row rho of the operand is one (filter row, column, channel) = one fixed offset into the staged rows).  No
+// barrier inside the loop (a wave reads only what it wrote); the four waves' accumulators are summed in LDS and
+// leave as one fp32 atomic per (rho, co) and workgroup.
+template <typename T, int NRT, int NCT>
+__global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned short* __restrict__ x,
+                                                               const unsigned short* __restrict__ dz, int dz_ld, int nb,
+                                                               int ih, int iw, int cin, int kh, int kw, int stride,
+                                                               int pad_t, int pad_l, int oh, int ow, int cout, int xrow_b,
+                                                               int zrows, int units_per_wave, float* __restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int ZB = NCT * 64;                                       // bytes of one dZ pixel row in LDS
+    const int wave_b = kh * xrow_b + zrows * ZB;                   // this wave's area: kh image rows, then the dZ row
+    unsigned char* sXw = smem_w + wave * wave_b;
+    unsigned char* sZw = sXw + kh * xrow_b;
+    for (int i = lane * 16; i < wave_b; i += 1024) *reinterpret_cast<u32x4*>(sXw + i) = u32x4{0u, 0u, 0u, 0u};
+    const int R = kh * kw * cin;
+    int abase[NRT];                                                // byte offset of operand row rho at output column 0
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+        const int rho = min(t * 32 + li, R - 1);                   // (rows past R: any finite data; never stored)
+        const int tap = rho / cin, ci = rho - tap * cin;
+        const int r = tap / kw, sx = tap - r * kw;
+        abase[t] = r * xrow_b + (sx * cin + ci) * 2;
+    }
+    const int apitch = stride * cin * 2;                           // bytes between consecutive output columns
+    // transposed-read address of this lane inside a (16-pixel, 32-channel) block of the dZ row (see conv_wgrad_lp)
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int zoff = (8 * (g16 >> 1) + q4) * ZB + 2 * (16 * (g16 & 1) + 4 * p4);
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t units = (int64_t)nb * oh;
+    const int64_t u0 = wid * units_per_wave;
+    const int64_t u1 = u0 + units_per_wave < units ? u0 + units_per_wave : units;
+    f32x16 acc[NRT][NCT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int u = 0; u < NCT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    constexpr int XL = NRT == 1 ? 6 : 10, ZL = 10;                 // 16-byte loads per lane: image rows / dZ row (capacity)
+    const int xbytes = iw * cin * 2;                               // one image row (contiguous: x_ld == cin)
+    const int xchunks = (kh * xbytes + 15) / 16, zchunks = ow * (NCT * 4);
+    u32x4 xr[XL], zr[ZL];
+    auto fetch = [&](int64_t u) {
+        const int n = (int)(u / oh), oy = (int)(u - (int64_t)n * oh);
+        const int iy0 = oy * stride - pad_t;
+#pragma unroll
+        for (int k = 0; k < XL; ++k) {
+            const int c = lane + 64 * k;                           // chunk c covers bytes [16c, 16c + 16) of the kh rows
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (c < xchunks) {
+                const int row = (c * 16) / xbytes;                 // (a chunk may straddle two rows: both must be inside)
+                const int row2 = (c * 16 + 15) / xbytes;
+                const int iyA = iy0 + row, iyB = iy0 + (row2 < kh ? row2 : kh - 1);
+                if (iyA >= 0 && iyB < ih)
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(x) +
+                                                        ((size_t)n * ih + iy0) * xbytes + (size_t)c * 16);
+            }
+            xr[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < ZL; ++k) {
+            const int c = lane + 64 * k;                           // (pixel, 8-channel chunk)
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (c < zchunks) {
+                const int px = c / (NCT * 4), ch = (c - px * (NCT * 4)) * 8;
+                if (ch < cout) v = *reinterpret_cast<const u32x4*>(dz + ((size_t)u * ow + px) * dz_ld + ch);
+            }
+            zr[k] = v;
+        }
+    };
+    auto stage = [&]() {                                           // registers -> this wave's LDS area
+#pragma unroll
+        for (int k = 0; k < XL; ++k) {
+            const int c = lane + 64 * k;
+            if (c < xchunks) {
+                // image rows sit pad_l pixels into their LDS rows (the left padding stays zero), xrow_b apart
+                const int b0 = c * 16;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {                   // 4-byte pieces: a chunk may straddle two rows
+                    const int b = b0 + 4 * w4, row = b / xbytes, off = b - row * xbytes;
+                    if (row < kh) *reinterpret_cast<unsigned*>(sXw + row * xrow_b + pad_l * cin * 2 + off) = xr[k][w4];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ZL; ++k) {
+            const int c = lane + 64 * k;
+            if (c < zchunks) *reinterpret_cast<u32x4*>(sZw + (c / (NCT * 4)) * ZB + (c % (NCT * 4)) * 16) = zr[k];
+        }
+    };
+    if (u0 < u1) fetch(u0);
+    for (int64_t u = u0; u < u1; ++u) {
+        __builtin_amdgcn_wave_barrier();
+        stage();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (u + 1 < u1) fetch(u + 1);                              // in flight under this unit's reads and MFMAs
+        for (int k0 = 0; k0 < ow; k0 += 16) {
+            s16x8 bv[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const unsigned char* pb = sZw + zoff + k0 * ZB + c * 64;
+                const s16x4 lo = lds_read_tr(pb), hi = lds_read_tr(pb + 4 * ZB);
+                bv[c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                s16x8 av;
+                const unsigned char* pa = sXw + abase[t] + (k0 + 8 * lh) * apitch;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const short*>(pa + j * apitch);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[t][c] = mfma16<T>(av, bv[c], acc[t][c]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every read of this unit done before it is overwritten
+    }
+    // the four waves' tiles -> LDS -> one atomic per element
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_w);                 // [4][NRT*NCT][32 x 32]
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[((wave * NRT + t) * NCT + c) * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[t][c][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NRT * NCT * 1024; i += 256) {
+        const int tc = i >> 10, e = i & 1023;
+        const int t = tc / NCT, c = tc - t * NCT;
+        const int rho = t * 32 + (e >> 5), co = c * 32 + (e & 31);
+        if (rho < R && co < cout) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(w * NRT * NCT + tc) * 1024 + e];
+            atomicAdd(&dw[(size_t)rho * cout + co], v);
+        }
+    }
+}
+
+// the stems this kernel takes: 3 input channels stored densely (x_ld == cin), stride 2, <= 64 output channels, rows that
+// fit the per-lane staging registers; 0 on success, GV_E_UNSUPPORTED otherwise
+template <typename T>
+int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+                    hipStream_t st) {
+    const int R = d->kh * d->kw * d->cin;
+    const int nrt = (R + 31) / 32, nct = (d->cout + 31) / 32;
+    if (d->cin > 4 || d->x_ld != d->cin || d->stride != 2 || (nrt != 1 && nrt != 5) || nct > 2 || d->cout % 8 != 0 ||
+        dz_ld % 8 != 0 || !gv_aligned16(x) || !gv_aligned16(dz) || (d->iw * d->cin * 2) % 16 != 0)
+        return GV_E_UNSUPPORTED;
+    const int xbytes = d->iw * d->cin * 2;
+    // what a lane's staging registers hold (XL / ZL of the kernel), and 4-byte aligned rows behind the left padding
+    if ((d->kh * xbytes + 15) / 16 > (nrt == 1 ? 6 : 10) * 64 || d->ow * nct * 4 > 10 * 64 || (d->pad_l * d->cin * 2) % 4 != 0)
+        return GV_E_UNSUPPORTED;
+    // LDS row of the image: left padding + iw pixels + the columns the last (padded to 16) output pixels reach
+    const int owp = (d->ow + 15) / 16 * 16;
+    const int need_px = (owp - 1) * d->stride + d->kw;
+    const int row_px = need_px > d->iw + d->pad_l ? need_px : d->iw + d->pad_l;
+    const int xrow_b = (row_px * d->cin * 2 + 15) / 16 * 16 + 16;
+    const int zrows = owp;
+    const size_t wave_b = (size_t)d->kh * xrow_b + (size_t)zrows * nct * 64;
+    size_t lds = 4 * wave_b;
+    const size_t red_b = (size_t)4 * nrt * nct * 1024 * 4;
+    if (red_b > lds) lds = red_b;
+    if (lds > 64 * 1024) return GV_E_UNSUPPORTED;
+    const int64_t units = (int64_t)d->nb * d->oh;
+    int64_t waves = 256 * 3 * 4;                                   // three workgroups per CU
+    int64_t per = (units + waves - 1) / waves;
+    if (per < 4) per = 4;
+    const int64_t nwg = ((units + per - 1) / per + 3) / 4;
+#define GV_WSTEM(NRT, NCT)                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_stem_rows_lp<T, NRT, NCT>), dim3((unsigned)nwg), dim3(256), lds, st, x, dz, dz_ld,     \
+                       d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout,   \
+                       xrow_b, zrows, (int)per, dw)
+    if (nrt == 1 && nct == 1) GV_WSTEM(1, 1);
+    else if (nrt == 1) GV_WSTEM(1, 2);
+    else if (nct == 1) GV_WSTEM(5, 1);
+    else GV_WSTEM(5, 2);
+#undef GV_WSTEM
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 }  // namespace
 
 extern "C" void gv_conv2d_wgrad_set_strip_taps(int n) { g_strip_ntw = n; }
@@ -1713,6 +1909,11 @@ bool wgrad_mfma_ok(const gv_conv_desc* d, const void* x, const void* dz, int dz_
 
 int conv_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st) {
     GV_LP_DISPATCH(d->dtype, return wgrad_t<T>(d, (const unsigned short*)x, (const unsigned short*)dz, dz_ld, dw, st));
+}
+
+// the 3-channel stems on the 16-bit MFMA (conv_wgrad_stem_rows_lp); GV_E_UNSUPPORTED: not such a layer
+int conv_wgrad_stem(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st) {
+    GV_LP_DISPATCH(d->dtype, return wgrad_stem_rows<T>(d, (const unsigned short*)x, (const unsigned short*)dz, dz_ld, dw, st));
 }
 
 }  // namespace gvlp

@@ -894,3 +894,35 @@ def test_wgrad_on_one_pixel_wide_maps():
                 continue                                    # the LDS-DMA forms decline 1-wide maps
             _lib.check(rc, "wgrad cfg %d" % cfg)
             close(dw.cpu(), w.grad, 3e-5)
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("k,pad,cout,nb,ih,iw", [(3, 0, 32, 37, 23, 40), (3, 0, 64, 9, 47, 72), (7, 2, 64, 5, 33, 48),
+                                                 (3, 0, 32, 3, 224, 224)])
+def test_stem_filter_gradient_on_row_strips(dt, tdt, eps, k, pad, cout, nb, ih, iw):
+    """The 3-channel stems' filter gradient (Conv2d_1a 3x3/2, nets/inception_v3.py:97; a 7x7/2 with padding) on
+    conv_wgrad_stem_rows_lp — image rows and the dZ row through LDS, 16-bit MFMA — against torch autograd through the
+    oracle's convolution; products of 16-bit values are exact in fp32, so only the summation order differs."""
+    g = torch.Generator().manual_seed(k * 100 + cout)
+    x = q(torch.rand(nb, ih, iw, 3, generator=g) - 0.5, tdt).requires_grad_(True)
+    w = q(torch.randn(k, k, 3, cout, generator=g) * 0.2, tdt).requires_grad_(True)
+    big = nb * ih * iw > 100000
+    dev = DEV if big else "cpu"
+    z = OB.conv2d(x.to(dev), w.to(dev), 2, (pad, pad, pad, pad))
+    dz = q(torch.randn(*z.shape, generator=g), tdt)
+    z.backward(dz.to(z.device))
+    oh, ow = z.shape[1:3]
+    zld = cout + 16
+    xd = x.detach().to(tdt).to(DEV).contiguous()
+    dzd = torch.zeros(nb, oh, ow, zld, dtype=tdt, device=DEV)
+    dzd[..., :cout] = dz.to(tdt).to(DEV)
+    outs = []
+    for f32 in (0, 1):                                   # the new kernel, then the fp32-MFMA direct kernel it replaces
+        lib().gv_conv2d_wgrad_set_lp_f32(f32)
+        dw = torch.full((k, k, 3, cout), 0.5, device=DEV)
+        d = _lib.ConvDesc(nb, ih, iw, 3, 3, k, k, 2, pad, pad, oh, ow, cout, cout, 0, 0, 0, dt, 0, 0, 0, 0)
+        _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad")
+        outs.append(dw.cpu() - 0.5)
+    lib().gv_conv2d_wgrad_set_lp_f32(0)
+    close(outs[0], w.grad.cpu(), 5e-5 if not big else 3e-4)
+    close(outs[0], outs[1], 5e-5 if not big else 3e-4)
