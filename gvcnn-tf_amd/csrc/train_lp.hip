@@ -430,26 +430,46 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const E* __restrict__ x, int
             if (ex.dgamma) ex.dgamma[cht] += (float)b2;
         }
     }
-    if (ch >= c || p0 + pl >= p1) return;
-    float A[8], B[8], Cc[8], sc[8], sh[8];
     const bool rmask = BWD && !yact && scale;                    // ReLU mask recomputed from z (x here)
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int gi = g * c + ch + e;
-        sc[e] = rmask ? scale[gi] : 0.f;
-        sh[e] = rmask ? shift[gi] : 0.f;
-        if constexpr (BWD) {                                     // p0f = mean, p1f = inv
-            const float iv = p1f[gi], mu = p0f[gi];
+    // backward: the folded coefficients of the block's 64 channels — ONE thread per channel reads mean / inv / the sums /
+    // gamma and does the fp64 conversion, everybody else picks A, B, C (and the mask constants) up from LDS: the small
+    // late layers are latency-bound, and 256 threads each fetching 7 values for each of their 8 channels before the first
+    // activation load was most of their prologue
+    __shared__ float sBw[5][64];
+    if constexpr (BWD) {
+        const int cht = blockIdx.x * 64 + threadIdx.x;
+        if (threadIdx.x < 64 && cht < c) {
+            const int gi = g * c + cht;
+            const float iv = p1f[gi], mu = p0f[gi];              // p0f = mean, p1f = inv
             const float rm = 1.f / (float)counts[g];
             const double a0 = acc[(size_t)gi * 2], a1 = acc[(size_t)gi * 2 + 1];
             const float s1 = (float)a0, s2 = (float)(relu ? (double)iv * (a1 - (double)mu * a0) : a1);   // (relu: GV_ACCUM_RAW_Z)
-            A[e] = (gamma ? gamma[ch + e] : 1.f) * iv;
-            B[e] = -A[e] * iv * s2 * rm;
-            Cc[e] = A[e] * (mu * iv * s2 - s1) * rm;
+            const float A_ = (gamma ? gamma[cht] : 1.f) * iv;
+            sBw[0][threadIdx.x] = A_;
+            sBw[1][threadIdx.x] = -A_ * iv * s2 * rm;
+            sBw[2][threadIdx.x] = A_ * (mu * iv * s2 - s1) * rm;
+            sBw[3][threadIdx.x] = rmask ? scale[gi] : 0.f;
+            sBw[4][threadIdx.x] = rmask ? shift[gi] : 0.f;
+        }
+        __syncthreads();
+    }
+    if (ch >= c || p0 + pl >= p1) return;
+    float A[8], B[8], Cc[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int gi = g * c + ch + e;
+        if constexpr (BWD) {
+            A[e] = sBw[0][cl * NE + e];
+            B[e] = sBw[1][cl * NE + e];
+            Cc[e] = sBw[2][cl * NE + e];
+            sc[e] = sBw[3][cl * NE + e];
+            sh[e] = sBw[4][cl * NE + e];
         } else if (ex.fin_acc) {                                 // finalized above
+            sc[e] = sh[e] = 0.f;
             A[e] = sA[cl * NE + e];
             B[e] = sB[cl * NE + e];
         } else {                                                 // p0f = scale, p1f = shift
+            sc[e] = sh[e] = 0.f;
             A[e] = p0f[gi];
             B[e] = p1f[gi];
         }

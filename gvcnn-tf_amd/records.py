@@ -237,6 +237,24 @@ def _decode_record(rec, num_views):
     return np.stack([decode_png(e) for e in enc]), int(ex["image/label"][0])
 
 
+_SHM_CACHE = {}
+
+
+def _decode_record_into(rec, num_views, shm_name, offset, nbytes):
+    """Worker side of the shared-memory hand-over: decode one record straight into its slot of the parent's shared
+    segment (2.4 MB of pixels per 12-view shape do not travel through a pipe); returns (shape, label)."""
+    views, label = _decode_record(rec, num_views)
+    if views.nbytes != nbytes:
+        raise ValueError("views of %d bytes, the batcher's slots hold %d (all shapes of a file share one size)"
+                         % (views.nbytes, nbytes))
+    shm = _SHM_CACHE.get(shm_name)
+    if shm is None:
+        from multiprocessing import shared_memory
+        shm = _SHM_CACHE[shm_name] = shared_memory.SharedMemory(name=shm_name)
+    np.ndarray(views.shape, np.uint8, buffer=shm.buf, offset=offset)[...] = views
+    return views.shape, label
+
+
 # ------------------------------------------------------------------------------------------------
 # batches for the engine
 # ------------------------------------------------------------------------------------------------
@@ -272,12 +290,20 @@ class ViewBatcher:
         self.dropped, self.last_valid = 0, batch_size
         self.workers = int(workers)
         self._pool = None
+        self._shm = None
 
     def close(self):
         if self._pool is not None:
             self._pool.terminate()
             self._pool.join()
             self._pool = None
+        if getattr(self, "_shm", None) is not None:
+            try:
+                self._shm.close()
+                self._shm.unlink()
+            except Exception:
+                pass
+            self._shm = None
 
     def __del__(self):
         try:
@@ -295,13 +321,33 @@ class ViewBatcher:
             import multiprocessing as mp
             self._pool = mp.get_context("spawn").Pool(self.workers)
         from collections import deque
+        from multiprocessing import shared_memory
         window, pending = 4 * self.workers, deque()
-        for rec in read_tfrecords(self.path):
-            pending.append(self._pool.apply_async(_decode_record, (rec, self.V)))
-            if len(pending) >= window:
-                yield pending.popleft().get()
+        records = read_tfrecords(self.path)
+        first = next(records, None)
+        if first is None:
+            return
+        views0, label0 = _decode_record(first, self.V)             # the slot size: every shape of a file has this one
+        nbytes = views0.nbytes
+        if getattr(self, "_shm", None) is None or self._shm.size < window * nbytes:
+            if getattr(self, "_shm", None) is not None:
+                self._shm.close()
+                self._shm.unlink()
+            self._shm = shared_memory.SharedMemory(create=True, size=window * nbytes)
+        yield views0, label0
+
+        def take(slot, res):
+            shape, label = res.get()
+            return np.ndarray(shape, np.uint8, buffer=self._shm.buf, offset=slot * nbytes).copy(), label   # slot free again
+        slot = 0
+        for rec in records:
+            if len(pending) >= window:                             # the slot about to be reused must have been read out
+                yield take(*pending.popleft())
+            pending.append((slot, self._pool.apply_async(_decode_record_into, (rec, self.V, self._shm.name, slot * nbytes,
+                                                                              nbytes))))
+            slot = (slot + 1) % window
         while pending:
-            yield pending.popleft().get()
+            yield take(*pending.popleft())
 
     def _shapes(self):
         """(views uint8 [V, h0, w0, 3], label) per record, through the shuffle buffer."""
@@ -322,9 +368,21 @@ class ViewBatcher:
         import torch
         from . import _lib
         from .model import _st
-        raw = np.stack(imgs)                                            # [N, V, h0, w0, 3] uint8
-        nimg, h0, w0 = self.N * self.V, raw.shape[2], raw.shape[3]
-        src = torch.from_numpy(raw).to(self.device)
+        nimg, h0, w0 = self.N * self.V, imgs[0].shape[1], imgs[0].shape[2]
+        # the decoded bytes go through ONE page-locked staging buffer (two, alternating: the copy of batch k may still be
+        # in flight when batch k+1 is assembled) and an asynchronous copy; on a CPU "device" (tests) plain stacking
+        if str(self.device).startswith("cuda"):
+            shape = (self.N, self.V, h0, w0, 3)
+            if getattr(self, "_pin", None) is None or tuple(self._pin[0].shape) != shape:
+                self._pin, self._pin_k = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)], 0
+            stage = self._pin[self._pin_k]
+            self._pin_k ^= 1
+            view = stage.numpy()
+            for i, im in enumerate(imgs):
+                view[i] = im
+            src = stage.to(self.device, non_blocking=True)
+        else:
+            src = torch.from_numpy(np.stack(imgs)).to(self.device)       # [N, V, h0, w0, 3] uint8
         dst = torch.empty((self.N, self.V, self.H, self.W, 3), dtype=torch.float32, device=self.device)
         flip = delta = None
         if self.augment:

@@ -34,7 +34,9 @@ def main():
     ap.add_argument("--workers", type=int, nargs="+", default=[0, 4, 8, 16, 32, 64])
     ap.add_argument("--batch", type=int, default=32)
     a = ap.parse_args()
-    from gvcnn_tf_amd import records as R           # (no GPU call before the worker pools exist: they are spawn pools anyway)
+    import torch
+    import gvcnn_tf_amd                              # noqa: F401  (same import order as every other entry point)
+    from gvcnn_tf_amd import records as R           # (the decoder pools are spawn pools: nothing inherits a GPU context)
     try:
         from PIL import Image
     except ImportError:
@@ -56,7 +58,6 @@ def main():
     print("synthetic set: %d shapes x %d views, 256x256 PNG (%s), %.1f KB per view, file %.1f MB; host cores %d"
           % (a.shapes, a.views, "Pillow, adaptive filters" if Image is not None else "filter 0",
              sum(len(e) for e in encoded) / len(encoded) / 1e3, os.path.getsize(path) / 1e6, os.cpu_count()))
-    import torch
     dev = "cuda:0" if torch.cuda.is_available() else "cpu"
     for size in a.sizes:
         for w in a.workers:
