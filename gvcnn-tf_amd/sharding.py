@@ -336,6 +336,14 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def moving_average_count(num_shapes_local, shape_world, hw):
+    """Samples behind one (view, channel) batch statistic of a step: the LOCAL shapes times the ranks that share the view
+    (their sums were all-reduced: TrainGVCNN.bn_sync) times the pixels — the n of the unbiased-variance factor n / (n-1)
+    that the moving-variance update uses (fused batch norm, SURVEY a-note 4); the same number TrainGVCNN._count() feeds
+    the normalisation."""
+    return int(num_shapes_local) * int(shape_world) * int(hw)
+
+
 def hybrid_grid(num_views, world_size):
     """(view_groups, shape_shards) with view_groups * shape_shards == world_size: the largest divisor of the world size
     that also divides the number of views becomes the number of view groups, the rest cuts the shapes.  12 views on 8
@@ -558,8 +566,8 @@ class ShardedTrainGVCNN:
             # count — and the unbiased-variance factor n/(n-1) of the update — is the GLOBAL one, as eng._count() uses
             key = (hw, eng.shape_world)
             if key not in self._mv_counts:
-                self._mv_counts[key] = torch.full((eng.Vh,), eng.N * eng.shape_world * hw, dtype=torch.int32,
-                                                  device=full.device)
+                self._mv_counts[key] = torch.full((eng.Vh,), moving_average_count(eng.N, eng.shape_world, hw),
+                                                  dtype=torch.int32, device=full.device)
             jobs.append(_lib.BnMovingJob(full.data_ptr() + 4 * off, full.data_ptr() + 4 * (off + c),
                                          self._mv_counts[key].data_ptr(),
                                          eng.params[op["name"] + "/moving_mean"].data_ptr(),

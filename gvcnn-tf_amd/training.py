@@ -364,6 +364,9 @@ class TrainGVCNN:
         # that writes the FINAL dy (16-bit storage; False: the separate sums passes, kept for A/B and tests)
         self.fuse_bn_stats = self.es == 2
         self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
+        self.s2_concurrent = False                        # ... their four launches side by side on extra streams: measured
+                                                          # 15.66 k against 15.89 k views/s in sequence (fork / join cost more
+                                                          # than the overlap returns); kept as an A/B switch
         self._plan_bn_fusion()
 
     # -- BatchNorm sums folded into the producing launch --------------------------------------------------
@@ -592,6 +595,28 @@ class TrainGVCNN:
         return _lib.ConvDesc(y.nb, y.h, y.w, y.c, y.ld, op["kh"], op["kw"], 1, op["kh"] - 1 - op["pad_t"],
                              op["kw"] - 1 - op["pad_l"], x.h, x.w, x.c, x.ld, x.ld, 0, 0, self.dt, 0,
                              op.get("tile_d", 0), self.math_mode, op["stride"] if op["stride"] > 1 else 0)
+
+    def _s2_streams(self):
+        if getattr(self, "_s2_side", None) is None:
+            self._s2_side = [torch.cuda.Stream(self.device) for _ in range(3)]
+            self._s2_events = [torch.cuda.Event() for _ in range(4)]
+        return self._s2_side
+
+    def _s2_class(self, op, ci, c_, dz, dx, store, fuse):
+        """One parity-class launch of a stride-2 layer's data gradient (with or without the folded BatchNorm sums)."""
+        lib = self.lib
+        dc = self._conv_desc_s2(op, c_, not store)
+        rc = _lib.GV_E_UNSUPPORTED
+        if fuse and op.get("_s2_stats_ok", True):
+            rc = lib.gv_conv2d_fwd_bnstats(C.byref(dc), dz, c_["w"].data_ptr(), self.ones.data_ptr(),
+                                           self.zeros.data_ptr(), None if store else dx, dx,
+                                           C.byref(self._bn_stats(op, "st_b")), _st())
+            if rc == _lib.GV_E_UNSUPPORTED:       # this class' tile cannot fold the sums: nobody does (from the next step on)
+                op["_s2_stats_ok"] = False
+        if rc == _lib.GV_E_UNSUPPORTED:
+            rc = lib.gv_conv2d_fwd(C.byref(dc), dz, c_["w"].data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(),
+                                   None if store else dx, dx, None, None, None, _st())
+        _lib.check(rc, "dgrad (parity class %d) %s" % (ci, op["name"]))
 
     def _conv_desc_s2(self, op, c_, accumulate):
         """Descriptor of ONE parity class of a stride-2 layer's data gradient: a stride-1 convolution over dZ whose
@@ -1135,23 +1160,32 @@ class TrainGVCNN:
                     # both forms, the default goes by size); the BatchNorm sums of the
                     # layers that produced x ride on all four (each adds the pixels it writes) or on none
                     fuse = bool(op.get("st_b")) and zeroed and self._fusing() and op.get("_s2_stats_ok", True)
+                    # The four launches are independent (disjoint pixels of dX, commutative exact sums) and each covers a
+                    # quarter of the pixels — under one wave of workgroups on the 12x12 maps — so they run side by side on
+                    # three extra streams, forked from and joined back into the launch stream (eager steps only: the
+                    # multi-stream capture problem of enable_lanes() applies).
+                    side = self._s2_streams() if (self.s2_concurrent and self._lane_streams is None and
+                                                  not torch.cuda.is_current_stream_capturing()) else None
+                    main = torch.cuda.current_stream(self.device)
+                    if side is not None:
+                        ev0 = self._s2_events[0]
+                        ev0.record(main)
                     for ci, c_ in enumerate(op["s2"]):
-                        dc = self._conv_desc_s2(op, c_, not store)
-                        rc = _lib.GV_E_UNSUPPORTED
-                        if fuse:
-                            rc = lib.gv_conv2d_fwd_bnstats(C.byref(dc), dz, c_["w"].data_ptr(), self.ones.data_ptr(),
-                                                           self.zeros.data_ptr(), None if store else dx, dx,
-                                                           C.byref(self._bn_stats(op, "st_b")), _st())
-                            if rc == _lib.GV_E_UNSUPPORTED:   # this class' tile cannot fold them: nobody does (from now on)
-                                fuse = op["_s2_stats_ok"] = False
-                                if ci:
-                                    for b in op["st_b"]:
-                                        b["acc_b"].zero_()
-                        if rc == _lib.GV_E_UNSUPPORTED:
-                            rc = lib.gv_conv2d_fwd(C.byref(dc), dz, c_["w"].data_ptr(), self.ones.data_ptr(),
-                                                   self.zeros.data_ptr(), None if store else dx, dx, None, None, None, _st())
-                        _lib.check(rc, "dgrad (parity class %d) %s" % (ci, op["name"]))
-                    op["_st_b_done"] = fuse
+                        stream = main if side is None or ci == 0 else side[ci - 1]
+                        if stream is not main:
+                            stream.wait_event(ev0)
+                        with torch.cuda.stream(stream):
+                            self._s2_class(op, ci, c_, dz, dx, store, fuse)
+                        if stream is not main:
+                            self._s2_events[ci].record(stream)
+                    if side is not None:
+                        for ci in range(1, len(op["s2"])):
+                            main.wait_event(self._s2_events[ci])
+                    ok = fuse and op.get("_s2_stats_ok", True)
+                    if fuse and not ok:                       # a class declined the sums after others had added theirs
+                        for b in op["st_b"]:
+                            b["acc_b"].zero_()
+                    op["_st_b_done"] = ok
                     return
                 if op.get("st_b") and zeroed and self._fusing():
                     # this launch writes the FINAL gradient of x: the backward sums of the BatchNorm layers that

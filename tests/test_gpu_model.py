@@ -455,3 +455,32 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+
+
+def test_roofline_timing_is_in_sequence_and_the_training_line_has_a_roofline():
+    """gv_plan_time_each (what bench.py's `roofline` is built from): one duration per op of the plan, measured over whole
+    passes in launch order; their sum is the single-lane step time.  And `bench.py --train --preset c3` carries a
+    `roofline` object with the MFMA side (conv / wgrad) and the HBM side (bn / pool), every fraction = achieved / peak."""
+    import json
+    import os
+    import subprocess
+    import sys
+    eng = gv.GVCNN("inception_v3", 2, 3, 139, 139, 10, 5, device=DEV, num_bins=5, lanes=False)
+    P = gv.params.init_backbone_params(eng.plan.param_shapes(), seed=2, perturb_bn=True)
+    eng.plan.bind(P)
+    x = (torch.rand(6, 139, 139, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
+    each = eng.plan.time_each(x, 3)
+    assert len(each) == len(eng.plan.ops) and all(t > 0 for t in each)
+    whole = eng.plan.time_range(x, 0, len(eng.plan.ops), 3)
+    assert 0.5 * whole <= sum(each) <= 3.0 * whole + 1.0, (sum(each), whole)     # (event pairs add a little per op)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--train", "--preset", "c3", "--steps", "2",
+                          "--warmup", "1", "--shapes", "2", "--no-traffic"], capture_output=True, text=True, timeout=900,
+                         cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    r = j["roofline"]
+    assert j["dtype"] == "bf16" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and "traffic" in r
+    for key, bound in (("conv", "mfma"), ("wgrad", "mfma"), ("bn", "hbm"), ("pool", "hbm")):
+        assert r[key]["bound"] == bound and abs(r[key]["frac"] - r[key]["achieved"] / r[key]["peak"]) < 1e-3, key
+    assert r["bn"]["folded_sums"]["batchnorm_layers"] == 94

@@ -417,3 +417,15 @@ def test_eight_gloo_ranks_hybrid_grid_direct_gather_and_sharded_forward():
         cells.add((gi, si))
     assert cells == {(g, k) for g in range(4) for k in range(2)}
     assert [ret[r]["views"] for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 9), (9, 10), (10, 11), (11, 12)]
+
+
+def test_moving_average_count_is_the_global_sample_count():
+    """Hybrid / shape-sharded training: a view's batch statistics are reduced over the ranks that share it, so the sample
+    count of the moving-variance update (n / (n - 1)) is local shapes x shape shards x pixels (advisor finding of round 2:
+    the local count was used)."""
+    sh = _load_sharding("gv_sharding_mv")
+    assert sh.moving_average_count(16, 1, 49) == 16 * 49
+    assert sh.moving_average_count(16, 2, 49) == 32 * 49              # 8 ranks = 4 view groups x 2 shape shards
+    vg, s = sh.hybrid_grid(12, 8)
+    n_global = 32
+    assert sh.moving_average_count(n_global // s, s, 144) == n_global * 144    # what the unsharded engine counts
