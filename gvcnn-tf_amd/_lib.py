@@ -115,6 +115,8 @@ SIGNATURES = {
     "gv_pool2d_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _I, _P, _I, _P]),
     "gv_pool2d_fwd_argmax": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "gv_pool2d_bwd_argmax": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _I, _P, _I, _P]),
+    "gv_bn_bwd_coeffs_t": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "gv_pool2d_bwd_argmax_bn": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "gv_view_pool_fuse_bwd": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P]),
     "gv_view_pool_fuse_bwd_per_shape": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _P, _I, _P, _I, _P, _P]),
     "gv_global_avg_pool_bwd": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),

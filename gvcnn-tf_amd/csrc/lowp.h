@@ -33,7 +33,11 @@ int bn_finalize_apply_grouped(int dtype, const double* acc, const int* counts, c
 int pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int dy_ld, void* dx, int dx_ld, hipStream_t st);
 int pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* y, unsigned char* arg, hipStream_t st);
 int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const void* dy, int dy_ld, void* dx, int dx_ld,
-                      hipStream_t st);
+                      hipStream_t st, const void* bn_z = nullptr, int bn_z_ld = 0, int bn_G = 1, const float* bn_A = nullptr,
+                      const float* bn_B = nullptr, const float* bn_C = nullptr, const float* bn_scale = nullptr,
+                      const float* bn_shift = nullptr);
+int bn_bwd_coeffs_launch(const double* acc, const int* counts, const float* mean, const float* inv, const float* gamma,
+                         int c, int G, int raw_z, float* A, float* B, float* Cc, float* dbeta, float* dgamma, hipStream_t st);
 int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,
                        const int* scheme, int G, const float* weight, int mode, void* dF, hipStream_t st,
                        int64_t scheme_stride, int64_t weight_stride);

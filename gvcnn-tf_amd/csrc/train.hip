@@ -1000,6 +1000,30 @@ extern "C" int gv_pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* 
     return gvlp::pool2d_fwd_argmax(d, x, y, argmax, (hipStream_t)stream);
 }
 
+extern "C" int gv_bn_bwd_coeffs_t(const double* accum, const int32_t* counts, const float* mean, const float* inv,
+                                  const float* gamma, int32_t c, int32_t num_groups, int32_t raw_z, float* coef_a,
+                                  float* coef_b, float* coef_c, float* dbeta, float* dgamma, void* stream) {
+    if (!accum || !counts || !mean || !inv || !coef_a || !coef_b || !coef_c || c <= 0 || num_groups <= 0) return GV_E_BADARG;
+    return gvlp::bn_bwd_coeffs_launch(accum, counts, mean, inv, gamma, c, num_groups, raw_z ? 1 : 0, coef_a, coef_b, coef_c,
+                                      dbeta, dgamma, (hipStream_t)stream);
+}
+
+extern "C" int gv_pool2d_bwd_argmax_bn(const gv_pool_desc* d, const uint8_t* argmax, const void* dy, int32_t dy_ld,
+                                       const void* z, int32_t z_ld, int32_t num_groups, const float* coef_a,
+                                       const float* coef_b, const float* coef_c, const float* scale, const float* shift,
+                                       void* dz, int32_t dz_ld, void* stream) {
+    if (!d || !argmax || !dy || !z || !dz || !coef_a || !coef_b || !coef_c || num_groups <= 0) return GV_E_BADARG;
+    if ((scale == nullptr) != (shift == nullptr)) return GV_E_BADARG;
+    if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->c <= 0 || d->oh <= 0 || d->ow <= 0 || dy_ld < d->c || dz_ld < d->c ||
+        z_ld < d->c || (d->mode & ~GV_POOL_BWD_STORE) != GV_POOL_MAX)
+        return GV_E_BADARG;
+    if (!gv_pool_geometry_ok(d)) return GV_E_BADARG;
+    if (d->dtype != GV_BF16 && d->dtype != GV_F16) return GV_E_UNSUPPORTED;
+    if (d->c % 8 != 0 || z_ld % 8 != 0 || !gv_aligned16(z)) return GV_E_UNSUPPORTED;
+    return gvlp::pool2d_bwd_argmax(d, argmax, dy, dy_ld, dz, dz_ld, (hipStream_t)stream, z, z_ld, num_groups, coef_a, coef_b,
+                                   coef_c, scale, shift);
+}
+
 extern "C" int gv_pool2d_bwd_argmax(const gv_pool_desc* d, const uint8_t* argmax, const void* dy, int32_t dy_ld, void* dx,
                                     int32_t dx_ld, void* stream) {
     if (!d || !argmax || !dy || !dx) return GV_E_BADARG;

@@ -535,6 +535,34 @@ __global__ __launch_bounds__(256) void bn_stream_v8(const E* __restrict__ x, int
     }
 }
 
+// A, B, C of dz = A*g + B*z + C per (group, channel) from the backward sums (the arithmetic of bn_stream_v8<BWD>), and
+// dbeta / dgamma += the sums over the groups: what a kernel other than bn_stream_v8 needs to finish a BatchNorm backward.
+__global__ __launch_bounds__(256) void bn_bwd_coeffs(const double* __restrict__ acc, const int* __restrict__ counts,
+                                                     const float* __restrict__ mean, const float* __restrict__ inv,
+                                                     const float* __restrict__ gamma, int c, int G, int raw_z,
+                                                     float* __restrict__ A, float* __restrict__ B, float* __restrict__ Cc,
+                                                     float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double sa = 0.0, sb = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const int gi = g * c + ch;
+        const float iv = inv[gi], mu = mean[gi];
+        const float rm = 1.f / (float)counts[g];
+        const double a0 = acc[(size_t)gi * 2], a1 = acc[(size_t)gi * 2 + 1];
+        const double s2d = raw_z ? (double)iv * (a1 - (double)mu * a0) : a1;
+        const float s1 = (float)a0, s2 = (float)s2d;
+        const float A_ = (gamma ? gamma[ch] : 1.f) * iv;
+        A[gi] = A_;
+        B[gi] = -A_ * iv * s2 * rm;
+        Cc[gi] = A_ * (mu * iv * s2 - s1) * rm;
+        sa += a0;
+        sb += s2d;
+    }
+    if (dbeta) dbeta[ch] += (float)sa;
+    if (dgamma) dgamma[ch] += (float)sb;
+}
+
 // Pixel splits of a streaming BN launch: ~32 pixels per thread on the big layers, but at least ~1024 workgroups in
 // total while a thread still gets 4 pixels — the small late layers are latency-bound, a longer per-thread loop only
 // adds to their time.
@@ -753,10 +781,21 @@ __global__ __launch_bounds__(256) void maxpool_argmax_bwd(const unsigned char* _
 }
 
 // 3x3 / stride 2 / VALID: the 2x2 input block (2a..2a+1, 2b..2b+1) and the four windows (a-1..a, b-1..b) touching it
+// BnTail (z != nullptr): the max pool follows relu(BN_train(z)) and pools z itself (BN + ReLU with a positive scale are
+// monotone: max(relu(bn(z))) = relu(bn(max z)), same winner) — the gradient this kernel gathers is then the gradient of
+// the BatchNorm's OUTPUT at that pixel, and instead of storing it the kernel finishes the BatchNorm backward pass:
+// dz = A*g + B*z + C with g = dy*[z*scale + shift > 0] and the per-(group, channel) coefficients of gv_bn_bwd_coeffs_t.
+// The activation y and its gradient are never materialised at the un-pooled size.
+struct BnTail {
+    const void* z;
+    int z_ld, G;
+    const float *A, *B, *C, *scale, *shift;                          // [G][c]
+};
+
 template <typename E, typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool3s2_argmax_bwd(const unsigned char* __restrict__ arg, const E* __restrict__ dy,
                                                              int dy_ld, int nb, int ih, int iw, int c, int oh, int ow,
-                                                             int store, E* __restrict__ dx, int dx_ld) {
+                                                             int store, E* __restrict__ dx, int dx_ld, BnTail bn) {
     const int cg = c / VEC, ah = (ih + 1) / 2, aw = (iw + 1) / 2;
     const int64_t total = (int64_t)nb * ah * aw * cg;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -795,6 +834,16 @@ __global__ __launch_bounds__(256) void maxpool3s2_argmax_bwd(const unsigned char
                     }
             }
         }
+        float cA[8], cB[8], cC[8], cs[8], ch_[8];
+        if (bn.z) {
+            const int gi = (n % bn.G) * c + q * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                cA[e] = bn.A[gi + e]; cB[e] = bn.B[gi + e]; cC[e] = bn.C[gi + e];
+                cs[e] = bn.scale ? bn.scale[gi + e] : 0.f;
+                ch_[e] = bn.scale ? bn.shift[gi + e] : 1.f;
+            }
+        }
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -803,6 +852,17 @@ __global__ __launch_bounds__(256) void maxpool3s2_argmax_bwd(const unsigned char
                 if (iy >= ih || ix >= iw) continue;
                 E* dp = dx + ((int64_t)(n * ih + iy) * iw + ix) * dx_ld + q * VEC;
                 float d[8];
+                if (bn.z) {                                      // dz = A*g + B*z + C, stored
+                    float zv[8];
+                    load_v<T, VEC>(reinterpret_cast<const E*>(bn.z) + ((int64_t)(n * ih + iy) * iw + ix) * bn.z_ld + q * VEC, zv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float g = fmaf(zv[e], cs[e], ch_[e]) > 0.f ? sum[2 * py + px][e] : 0.f;
+                        d[e] = fmaf(cA[e], g, fmaf(cB[e], zv[e], cC[e]));
+                    }
+                    store_v<T, VEC>(dp, d);
+                    continue;
+                }
                 if (store) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) d[e] = 0.f;
@@ -1872,17 +1932,20 @@ int pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* y, unsigned ch
 }
 
 int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const void* dy, int dy_ld, void* dx, int dx_ld,
-                      hipStream_t st) {
+                      hipStream_t st, const void* bn_z, int bn_z_ld, int bn_G, const float* bn_A, const float* bn_B,
+                      const float* bn_C, const float* bn_scale, const float* bn_shift) {
+    BnTail bn{bn_z, bn_z_ld, bn_G, bn_A, bn_B, bn_C, bn_scale, bn_shift};
     const int store = (d->mode & GV_POOL_BWD_STORE) ? 1 : 0;
     const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
     const bool m3s2 = d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 && d->pad_l == 0 &&
                       d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
+    if (bn_z && !m3s2) return GV_E_UNSUPPORTED;                  // the BatchNorm tail exists in the 3x3 / 2 kernel only
     const int64_t nblk2 = (int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2);
 #define GV_AMAX_B(E, T, VEC, G_, O_)                                                                                        \
     do {                                                                                                                    \
         if (m3s2)                                                                                                           \
             hipLaunchKernelGGL((maxpool3s2_argmax_bwd<E, T, VEC>), dim3(grid_for(nblk2 * (d->c / VEC))), dim3(256), 0, st, arg, \
-                               G_, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, store, O_, dx_ld);                       \
+                               G_, dy_ld, d->nb, d->ih, d->iw, d->c, d->oh, d->ow, store, O_, dx_ld, bn);                   \
         else                                                                                                                \
             hipLaunchKernelGGL((maxpool_argmax_bwd<E, T, VEC>), dim3(grid_for(npix * (d->c / VEC))), dim3(256), 0, st, arg, G_, \
                                dy_ld, d->nb, d->ih, d->iw, d->c, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, \
@@ -1906,6 +1969,14 @@ int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const voi
         GV_AMAX_B(unsigned short, T, 1, g, o);
     });
 #undef GV_AMAX_B
+}
+
+int bn_bwd_coeffs_launch(const double* acc, const int* counts, const float* mean, const float* inv, const float* gamma,
+                         int c, int G, int raw_z, float* A, float* B, float* Cc, float* dbeta, float* dgamma, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_coeffs, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, st, acc, counts, mean, inv, gamma, c, G,
+                       raw_z, A, B, Cc, dbeta, dgamma);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
 }
 
 int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, int64_t E, int64_t vs, int64_t ss,

@@ -17,6 +17,7 @@ FAMILY = {
     "gv_bn_sums_grouped_t": "bn", "gv_bn_finalize_apply_grouped_t": "bn", "gv_bn_relu_bwd_sums_grouped_t": "bn",
     "gv_bn_relu_bwd_apply_grouped_t": "bn", "gv_bn_finalize_t": "bn", "gv_bn_bwd_finalize_t": "bn",
     "gv_pool2d_fwd": "pool", "gv_pool2d_fwd_argmax": "pool", "gv_pool2d_bwd": "pool", "gv_pool2d_bwd_argmax": "pool",
+    "gv_bn_bwd_coeffs_t": "bn", "gv_pool2d_bwd_argmax_bn": "bn",
     "gv_accumulate_t": "elementwise", "gv_bias_grad_t": "elementwise",
 }
 

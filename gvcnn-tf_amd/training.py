@@ -363,6 +363,7 @@ class TrainGVCNN:
         # sums of z in the convolution's epilogue, the backward sums of dy in the epilogue of the data-gradient launch
         # that writes the FINAL dy (16-bit storage; False: the separate sums passes, kept for A/B and tests)
         self.fuse_bn_stats = self.es == 2
+        self.fuse_bn_pool = self.es == 2                  # BatchNorm -> max pool pairs of the stem as pool -> BatchNorm (A/B)
         self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
         self.s2_concurrent = False                        # ... their four launches side by side on extra streams: measured
                                                           # 15.66 k against 15.89 k views/s in sequence (fork / join cost more
@@ -417,6 +418,30 @@ class TrainGVCNN:
                 if len(op.get(key, ())) > _lib.GV_BN_STATS_MAX_SEG:
                     for b in op.pop(key):
                         b.pop("fused_f" if key == "st_f" else "fused_b")
+        # BatchNorm (+ReLU, no gamma: a positive scale) whose ONLY reader is a 3x3/2 VALID max pool (Conv2d_2b ->
+        # MaxPool_3a, Conv2d_4a -> MaxPool_5a): the pool takes z itself, the BatchNorm is applied to the pooled tensor and
+        # its backward pass is finished by the pool's backward kernel (gv_pool2d_bwd_argmax_bn) — neither the activation
+        # nor its gradient exists at the un-pooled size
+        same = lambda t, u: t.vbuf == u.vbuf and t.off == u.off and t.c == u.c
+        for op in ops:
+            op.pop("pool_after", None), op.pop("bn_before", None)
+        if self.es == 2:
+            for bi, b in enumerate(ops):
+                if b["kind"] != "bn" or not b["relu"] or b["has_gamma"] or b["y"].vbuf < 0:
+                    continue
+                readers = [o for o in ops[bi + 1:] if overlap(o["x"], b["y"]) or
+                           (o.get("res") is not None and overlap(o["res"], b["y"]))]
+                taps = [t for t in (self.raw, self.final) if overlap(t, b["y"])]
+                if len(readers) != 1 or taps:
+                    continue
+                p_ = readers[0]
+                if (p_["kind"] == "pool" and p_["mode"] == _lib.GV_POOL_MAX and p_["k"] == 3 and p_["stride"] == 2 and
+                        p_["pad_t"] == 0 and p_["pad_l"] == 0 and same(p_["x"], b["y"]) and b["x"].c % 8 == 0):
+                    b["pool_after"], p_["bn_before"] = p_, b
+                    c = b["x"].c
+                    if "pz" not in p_:
+                        p_["pz"] = torch.empty(p_["y"].npix * c, dtype=self.tdt, device=self.device)
+                        b["coef"] = [torch.empty((self.V, c), dtype=torch.float32, device=self.device) for _ in range(3)]
 
     def _bn_stats(self, op, key):
         """The gv_bn_stats of convolution `op` (key 'st_f': forward sums of its output; 'st_b': backward sums of its
@@ -442,6 +467,11 @@ class TrainGVCNN:
 
     def _fusing(self):
         return self.fuse_bn_stats and self._zacc and self._lazy and not self.frozen_bn
+
+    def _pool_fused(self, op):
+        """Is this BatchNorm / max pool executed as the fused pair (pool z, normalise the pooled tensor)?"""
+        return (self.fuse_bn_pool and self._zacc and self._lazy and not self.frozen_bn and self.pool_argmax and
+                (op.get("pool_after") is not None or op.get("bn_before") is not None))
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _ptr(self, t, grad=False):
@@ -943,6 +973,8 @@ class TrainGVCNN:
                 return
             if part == "all" and self.bn_sync is not None and not self.frozen_bn:   # shape-sharded: reduce the sums first
                 self._bn_sync_call(acc[:2 * V * x.c])
+            if self._pool_fused(op):                      # normalised after the max pool that follows (see the pool op)
+                return
             _lib.check(lib.gv_bn_finalize_apply_grouped_t(
                 acc.data_ptr(), self._count(hw).data_ptr(), gamma.data_ptr() if gamma is not None else None,
                 beta.data_ptr(), float(op["eps"]), self._ptr(x), x.nb, hw, x.c, x.ld, V, int(op["relu"]), self._ptr(y),
@@ -951,6 +983,23 @@ class TrainGVCNN:
         else:
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
+            if self._pool_fused(op):
+                # pool z (BN + ReLU with a positive scale are monotone: same winner, same value after normalising), then
+                # BatchNorm + ReLU on the POOLED tensor with the statistics of the whole z
+                b = op["bn_before"]
+                bx, st = b["x"], b["stat"]
+                dz_ = _lib.PoolDesc(bx.nb, bx.h, bx.w, bx.c, bx.ld, 3, 3, 2, 0, 0, y.h, y.w, bx.c, _lib.GV_POOL_MAX, self.dt)
+                if "argmax" not in op:
+                    op["argmax"] = torch.empty(y.nb * y.h * y.w * y.c, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.gv_pool2d_fwd_argmax(C.byref(dz_), self._ptr(bx), op["pz"].data_ptr(), op["argmax"].data_ptr(),
+                                                    _st()), "pool z + argmax " + op["name"])
+                accf = b["acc_f"] if self._zacc else self.accum
+                _lib.check(lib.gv_bn_finalize_apply_grouped_t(
+                    accf.data_ptr(), self._count(bx.h * bx.w).data_ptr(), None, self.params[b["name"] + "/beta"].data_ptr(),
+                    float(b["eps"]), op["pz"].data_ptr(), y.nb, y.h * y.w, bx.c, bx.c, V, 1, self._ptr(y), y.ld,
+                    st["mean"].data_ptr(), st["var"].data_ptr(), st["inv"].data_ptr(), st["scale"].data_ptr(),
+                    st["shift"].data_ptr(), self.dt, _st()), "bn finalize + apply (pooled) " + b["name"])
+                return
             if op["mode"] == _lib.GV_POOL_MAX and self.pool_argmax:
                 # the winning tap of every window is recorded (one byte per output element): the backward pass routes dy
                 # by it and never re-reads x
@@ -1107,6 +1156,32 @@ class TrainGVCNN:
             sh = st["shift"].data_ptr() if op["relu"] and self._lazy else None
             accb = op["acc_b"] if self._zacc else self.accum
             zf = _lib.GV_ACCUM_ZEROED if zeroed else 0
+            if self._pool_fused(op):
+                # BatchNorm -> max pool pair: only a window's winner carries a gradient, so the sums run over the POOLED
+                # tensors (the pool's output gradient, the pooled z); the pool's backward kernel then gathers every input
+                # pixel's gradient, masks it and finishes dz = A*g + B*z + C
+                p_ = op["pool_after"]
+                py = p_["y"]
+                if part != "apply":
+                    _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
+                        self._ptr(py, True), py.ld, None, py.ld, p_["pz"].data_ptr(), x.c, st["mean"].data_ptr(),
+                        st["inv"].data_ptr(), py.nb, py.h * py.w, x.c, V, accb.data_ptr(), st["scale"].data_ptr(),
+                        st["shift"].data_ptr(), self.dt | zf, _st()), "bn_bwd sums (pooled) " + op["name"])
+                if part == "sums":
+                    return
+                if part == "all" and self.bn_sync is not None:
+                    self._bn_sync_call(accb[:2 * V * x.c])
+                assert self._claim(x), "the BatchNorm input of a fused pair has one reader"
+                ca, cb, cc = op["coef"]
+                _lib.check(lib.gv_bn_bwd_coeffs_t(accb.data_ptr(), self._count(hw).data_ptr(), st["mean"].data_ptr(),
+                                                  st["inv"].data_ptr(), None, x.c, V, 0, ca.data_ptr(), cb.data_ptr(),
+                                                  cc.data_ptr(), dbeta, None, _st()), "bn_bwd coefficients " + op["name"])
+                dp = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, 3, 3, 2, 0, 0, py.h, py.w, py.ld, _lib.GV_POOL_MAX, self.dt)
+                _lib.check(lib.gv_pool2d_bwd_argmax_bn(C.byref(dp), p_["argmax"].data_ptr(), self._ptr(py, True), py.ld,
+                                                       self._ptr(x), x.ld, V, ca.data_ptr(), cb.data_ptr(), cc.data_ptr(),
+                                                       st["scale"].data_ptr(), st["shift"].data_ptr(), self._ptr(x, True),
+                                                       x.ld, _st()), "pool_bwd + bn_bwd apply " + op["name"])
+                return
             # (sum g, sum g*z) already added by the data-gradient launch that wrote the final dy?
             raw = zeroed and op.get("fused_b") is not None and op["fused_b"].get("_st_b_done", False)
             if not raw and part != "apply":
@@ -1201,6 +1276,9 @@ class TrainGVCNN:
                                              self.zeros.data_ptr(), None if store else dx, dx, None, None, None,
                                              _st()), "dgrad " + op["name"])
         else:
+            if self._pool_fused(op):                          # its backward is part of the BatchNorm's (see there): the gradient
+                self._claim(x)                                # of x is never materialised, only marked as produced
+                return
             d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"], op["pad_t"],
                               op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dt)
             if self._claim(x):                                # first contribution: the gather kernels store

@@ -390,6 +390,22 @@ int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t 
 int gv_pool2d_fwd_argmax(const gv_pool_desc* d, const void* x, void* y, uint8_t* argmax, void* stream);
 int gv_pool2d_bwd_argmax(const gv_pool_desc* d, const uint8_t* argmax, const void* dy, int32_t dy_ld, void* dx,
                          int32_t dx_ld, void* stream);
+/* A max pool that directly follows relu(BatchNorm_train(z)) with a positive BatchNorm scale (slim's Inception arg scope:
+ * no gamma — nets/inception_utils.py:36; Conv2d_2b -> MaxPool_3a, Conv2d_4a -> MaxPool_5a: nets/inception_v3.py:107-128)
+ * may pool z ITSELF: BN + ReLU are monotone there, so max(relu(bn(z))) = relu(bn(max z)) with the same winner, bit for
+ * bit.  Forward: gv_pool2d_fwd_argmax on z, then gv_bn_finalize_apply_grouped_t on the POOLED tensor with the sums and
+ * counts of the whole z (a quarter of the elements to normalise, and the activation at the un-pooled size never exists).
+ * Backward: the BatchNorm sums are sums over the pooled elements (gv_bn_relu_bwd_sums_grouped_t on (d pooled, pooled z):
+ * only a window's winner carries a gradient), gv_bn_bwd_coeffs_t turns them into the per-(group, channel) coefficients of
+ * dz = A*g + B*z + C (and adds dbeta / dgamma), and gv_pool2d_bwd_argmax_bn gathers every input pixel's gradient g from
+ * the windows that elected it (as gv_pool2d_bwd_argmax), masks it with [z*scale + shift > 0] and stores dz — the gradient
+ * of the activation is never materialised either.  3x3 / stride 2 / VALID windows, 16-bit storage. */
+int gv_bn_bwd_coeffs_t(const double* accum, const int32_t* counts, const float* mean, const float* inv, const float* gamma,
+                       int32_t c, int32_t num_groups, int32_t raw_z, float* coef_a, float* coef_b, float* coef_c,
+                       float* dbeta, float* dgamma, void* stream);
+int gv_pool2d_bwd_argmax_bn(const gv_pool_desc* d, const uint8_t* argmax, const void* dy, int32_t dy_ld, const void* z,
+                            int32_t z_ld, int32_t num_groups, const float* coef_a, const float* coef_b, const float* coef_c,
+                            const float* scale, const float* shift, void* dz, int32_t dz_ld, void* stream);
 /* Backward of gv_view_pool_fuse_fwd: dF += ... (tf.reduce_max splits equally among ties). */
 int gv_view_pool_fuse_bwd(const float* F, const float* dS, int32_t num_views, int32_t num_shapes, int64_t E,
                           int64_t view_stride, int64_t shape_stride, const int32_t* scheme,
