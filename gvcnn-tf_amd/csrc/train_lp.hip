@@ -800,12 +800,13 @@ __global__ __launch_bounds__(256) void maxpool3s2_argmax_bwd(const unsigned char
     const int64_t total = (int64_t)nb * ah * aw * cg;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(idx % cg);
-        int64_t t = idx / cg;
-        const int b = (int)(t % aw);
-        t /= aw;
-        const int a = (int)(t % ah);
-        const int n = (int)(t / ah);
+        const unsigned per_img = (unsigned)(ah * aw * cg);           // (one image's work fits 32 bits: checked by the launcher)
+        const int n = (int)(idx / per_img);
+        unsigned t = (unsigned)(idx - (int64_t)n * per_img);
+        const int q = (int)(t % (unsigned)cg);
+        t /= (unsigned)cg;
+        const int b = (int)(t % (unsigned)aw);
+        const int a = (int)(t / (unsigned)aw);
         float sum[4][8];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -837,11 +838,23 @@ __global__ __launch_bounds__(256) void maxpool3s2_argmax_bwd(const unsigned char
         float cA[8], cB[8], cC[8], cs[8], ch_[8];
         if (bn.z) {
             const int gi = (n % bn.G) * c + q * VEC;
+            auto ld = [&](const float* p, float* o) {                // (c % VEC == 0 and 16-byte aligned tables: vector loads)
+                if constexpr (VEC % 4 == 0) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                cA[e] = bn.A[gi + e]; cB[e] = bn.B[gi + e]; cC[e] = bn.C[gi + e];
-                cs[e] = bn.scale ? bn.scale[gi + e] : 0.f;
-                ch_[e] = bn.scale ? bn.shift[gi + e] : 1.f;
+                    for (int e = 0; e < VEC; e += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(p + gi + e);
+                        o[e] = v.x; o[e + 1] = v.y; o[e + 2] = v.z; o[e + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] = p[gi + e];
+                }
+            };
+            ld(bn.A, cA); ld(bn.B, cB); ld(bn.C, cC);
+            if (bn.scale) { ld(bn.scale, cs); ld(bn.shift, ch_); }
+            else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { cs[e] = 0.f; ch_[e] = 1.f; }
             }
         }
 #pragma unroll
@@ -1940,6 +1953,10 @@ int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const voi
     const bool m3s2 = d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 && d->pad_l == 0 &&
                       d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
     if (bn_z && !m3s2) return GV_E_UNSUPPORTED;                  // the BatchNorm tail exists in the 3x3 / 2 kernel only
+    if (bn_z && !(gv_aligned16(bn_A) && gv_aligned16(bn_B) && gv_aligned16(bn_C) && gv_aligned16(bn_scale) &&
+                  gv_aligned16(bn_shift)))
+        return GV_E_BADARG;                                          // (the coefficient tables are read as float4)
+    if (m3s2 && (int64_t)((d->ih + 1) / 2) * ((d->iw + 1) / 2) * d->c > 0x7fffffff) return GV_E_UNSUPPORTED;
     const int64_t nblk2 = (int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 1) / 2);
 #define GV_AMAX_B(E, T, VEC, G_, O_)                                                                                        \
     do {                                                                                                                    \

@@ -769,6 +769,7 @@ def test_recorded_argmax_pools_reproduce_the_recomputing_step(backbone, storage,
     for amax in (True, False):
         eng = TrainGVCNN(backbone, N, V, size, size, 5, 10, device=DEV, storage=storage, seed=5)
         eng.pool_argmax = amax
+        eng.fuse_bn_pool = False                         # (the pool -> BatchNorm pairs need the record: tests/test_gpu_bn_pool.py)
         eng.forward(x, labels, check=False)
         eng.backward()
         torch.cuda.synchronize()

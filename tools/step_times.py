@@ -48,6 +48,8 @@ for fn, name, phase, kind, ms in avg:
         order.append(name)
     rows[name][phase].append((fn.replace("gv_", "").replace("_grouped_t", "").replace("conv2d_", ""), ms))
 els = {op["name"]: (op["y"].npix, op["y"].c) for op in eng.plan.ops}
+kdim = {op["name"]: op["kh"] * op["kw"] * op["x"].c for op in eng.plan.ops if op["kind"] == "conv"}
+tiles = {op["name"]: (op.get("tile", 0), op.get("tile_d", 0), op.get("tile_w", 0)) for op in eng.plan.ops if op["kind"] == "conv"}
 for name in order:
     r = rows[name]
     if a.kind != "all" and r["kind"] != a.kind:
@@ -55,7 +57,13 @@ for name in order:
     npix, c = els.get(name, (0, 0))
     f = " ".join("%s %.3f" % fm for fm in r["fwd"])
     b = " ".join("%s %.3f" % fm for fm in r["bwd"])
-    print("%-58s %-5s M=%8d c=%4d | fwd: %s | bwd: %s" % (name[-58:], r["kind"], npix, c, f, b))
+    extra = ""
+    if name in kdim:                                      # GEMM depth, launch configurations (fwd, dgrad, wgrad) and the
+        gf = 2.0 * npix * c * kdim[name] * 1e-9           # rate of each of the three GEMMs (all launches of a pass summed)
+        tf = lambda ls: gf / max(sum(ms for fn, ms in ls if fn.startswith("fwd")), 1e-9)
+        tw = gf / max(sum(ms for fn, ms in r["bwd"] if fn == "wgrad"), 1e-9)
+        extra = " | K=%d cfg=%s TF/s fwd %.0f dgrad %.0f wgrad %.0f" % (kdim[name], tiles[name], tf(r["fwd"]), tf(r["bwd"]), tw)
+    print("%-58s %-5s M=%8d c=%4d | fwd: %s | bwd: %s%s" % (name[-58:], r["kind"], npix, c, f, b, extra))
 fam = steptime.by_family(avg)
 tot = sum(t for t, _ in fam.values())
 print("in-sequence sum %.2f ms: " % tot + ", ".join("%s %.2f ms / %d" % (k, t, cnt) for k, (t, cnt) in sorted(fam.items(), key=lambda kv: -kv[1][0])))
