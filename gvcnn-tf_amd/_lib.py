@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgvcnn_hip.so")
+# (GVCNN_HIP_LIB: another build of the SAME library, e.g. the profiling build of tools/phase_times.py — never a fallback)
+LIB_PATH = os.environ.get("GVCNN_HIP_LIB") or os.path.join(_HERE, "libgvcnn_hip.so")
 
 GV_F32, GV_BF16, GV_F16 = 0, 1, 2
 GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT, GV_CONV_X_F32 = 1, 2, 4, 8

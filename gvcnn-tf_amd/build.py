@@ -11,10 +11,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libgvcnn_hip.so")
+# GV_PHASE_TIMES=1: the profiling build of tools/phase_times.py (per-workgroup phase timestamps inside conv_dma): its own
+# object directory and library name — never the product library
+PT = os.environ.get("GV_PHASE_TIMES") == "1"
+LIB = os.path.join(HERE, "libgvcnn_hip_pt.so" if PT else "libgvcnn_hip.so")
+BUILD = "build_pt" if PT else "build"
 SOURCES = ["conv_igemm.hip", "conv_bf16s.hip", "conv_lp.hip", "conv_dma.hip", "pool.hip", "lowp.hip", "grouping.hip", "plan.hip", "train.hip", "train_lp.hip", "wgrad_dma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + (["-DGV_PHASE_TIMES"] if PT else [])
 
 
 def _stale(target, deps):
@@ -31,10 +35,10 @@ def build(force=False, verbose=False):
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, BUILD), exist_ok=True)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        obj = os.path.join(HERE, BUILD, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]

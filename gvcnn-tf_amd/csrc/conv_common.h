@@ -24,6 +24,9 @@ struct ConvArgs {
     int relu_limit;             // ReLU only for columns < relu_limit
     int tiles_n;
     int dil_shift;              // 0: plain; 1: input read as zero-dilated by 2 (stride-2 data gradient)
+#ifdef GV_PHASE_TIMES
+    unsigned long long* phase_buf = nullptr;   // profiling build: per-wave phase timestamps (conv_dma.hip)
+#endif
     int dbg;                    // ablation bit (timing experiments only): 4 = no epilogue stores
     const void* zeros;          // conv_dma.hip: a zero page for the padding taps of the gather
     int y_p3, y2_p3;            // destination format: 0 = fp32, 1 = three bf16 planes (conv_x3_epi.h)
@@ -36,6 +39,13 @@ struct ConvArgs {
     int y_ih = 0, y_iw = 0;
     GvFastDiv y_div_img = {0, -1, 1}, y_div_row = {0, -1, 1};   //    exact m / (oh*ow) and rem / ow
 };
+
+// May this launch take the lean 16-bit staged epilogue (conv_stats.h STAT_LEAN)?  dbg bit 2: always the full one (A/B).
+inline bool lp_epilogue_lean_ok(const ConvArgs& a) {
+    return !(a.dbg & 2) && a.y2 == nullptr && a.split == 0 && a.cout % 8 == 0 && a.y_ld % 8 == 0 &&
+           (((uintptr_t)a.y) & 15) == 0 && (a.res == nullptr || (a.res_ld % 8 == 0 && (((uintptr_t)a.res) & 15) == 0)) &&
+           (!a.relu || a.relu_limit >= a.cout);
+}
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:
 // col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):

@@ -70,6 +70,17 @@ constexpr bool dma_use_ss() {
     return EPI != 1 && cu / base == cu / with;
 }
 
+// ... in which case the table is published LATE into the ring the main loop has freed, behind the waves' staging blocks
+// (where it fits there: the 128 x 128 tile on two stages stages exactly a ring's worth)
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+constexpr int dma_late_off() { return WM * WN * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES); }
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+constexpr bool dma_late_ss() {
+    constexpr int ring = ST * NP * (WM * TM * 32 + WN * TN * 32) * DmaGeom<NP>::RBYTES;
+    return EPI != 1 && !dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() &&
+           dma_late_off<NP, WM, WN, TM, TN, ST, EPI>() + 16 * WN * TN * 32 <= ring;
+}
+
 // STATS (16-bit output only): train-mode BatchNorm sums of the stored tensor folded into the epilogue (conv_stats.h).
 template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int STATS = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
@@ -87,6 +98,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     constexpr int NPR = dprod_count(NP);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef GV_PHASE_TIMES                                              // profiling build only (tools/phase_times.py): per-workgroup
+    unsigned long long gv_pt[7], gv_pi[4] = {0, 0, 0, 0};                                   // timestamps of the kernel's phases
+#define GV_PT(i) gv_pt[i] = __builtin_amdgcn_s_memtime()
+#else
+#define GV_PT(i)
+#endif
+    GV_PT(0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,10 +119,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     constexpr int SS_OFF = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>();
     static_assert(WM * WN * 64 >= WN * TN * 32, "one thread per tile column");
     constexpr bool USE_SS = dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>();
-    float* sstab = USE_SS && !(a.dbg & 512) ? reinterpret_cast<float*>(smem + SS_OFF) : nullptr;   // dbg 512: constants from global (A/B)
+    // ... in which case the table is published LATE, into the ring the main loop has freed (behind the waves' staging
+    // blocks): the values wait in four registers meanwhile.  (Without a table every lane of the epilogue fetches its 16
+    // constants per column block from global memory — 48 loads and ~250 address instructions per wave of a 128 x 192 tile.)
+    constexpr bool LATE_SS = dma_late_ss<NP, WM, WN, TM, TN, ST, EPI>();
+    constexpr int LATE_OFF = dma_late_off<NP, WM, WN, TM, TN, ST, EPI>();
+    constexpr bool ANY_SS = USE_SS || LATE_SS;
+    float* sstab = ANY_SS && !(a.dbg & 512) ? reinterpret_cast<float*>(smem + (LATE_SS ? LATE_OFF : SS_OFF)) : nullptr;   // dbg 512: constants from global (A/B)
     float ss_v[4] = {0.f, 0.f, 0.f, 0.f};
     const bool ss_dual = EPI == 0 && a.y2 != nullptr && a.split == 0;
-    if (USE_SS && tid < WN * TN * 32) {
+    if (ANY_SS && tid < WN * TN * 32) {
         const int lid0 = gv_xcd_remap(blockIdx.x, gridDim.x);
         const int cc = min((lid0 % a.tiles_n) * (WN * TN * 32) + tid, a.cout - 1);
         ss_v[0] = a.scale[cc];
@@ -112,7 +136,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
         if (ss_dual) { ss_v[2] = a.scale2[cc]; ss_v[3] = a.shift2[cc]; }
     }
     auto ss_publish = [&]() {
-        if (USE_SS && tid < WN * TN * 32) {
+        if (ANY_SS && sstab != nullptr && tid < WN * TN * 32) {
             constexpr int BN_ = WN * TN * 32;
             sstab[tid] = ss_v[0];
             sstab[BN_ + tid] = ss_v[1];
@@ -130,9 +154,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     const int tile_m = lid / a.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
-    static_assert(STATS == 0 || EPI == 0, "BatchNorm sums: the 16-bit staged epilogue");
+    static_assert(STATS == 0 || EPI == 0, "BatchNorm sums / lean form: the 16-bit staged epilogue");
+    constexpr bool HAS_SUMS = gvconv::stat_has(STATS);
     int st_b0 = 0;                                                 // STATS: image of the tile's first pixel
-    if constexpr (STATS != 0) st_b0 = m0 / a.st.hw;
+    if constexpr (HAS_SUMS) st_b0 = m0 / a.st.hw;
 
     // ---- loader state -------------------------------------------------------------------------------------------
     const int lrow = lane / CPR;                                   // row inside a row block
@@ -360,10 +385,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
         };
 
         // ---- main loop ------------------------------------------------------------------------------------------------
+        GV_PT(5);
     #pragma unroll
-        for (int t = 0; t < ST; ++t)
+        for (int t = 0; t < ST; ++t) {
             if (t < ktiles) issue(t);
-        ss_publish();
+#ifdef GV_PHASE_TIMES
+            gv_pi[t] = __builtin_amdgcn_s_memtime();
+#endif
+        }
+        GV_PT(6);
+        if constexpr (USE_SS) ss_publish();
         {
             const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
             if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
@@ -372,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
             else wait_vm<0>();
         }
         __builtin_amdgcn_s_barrier();
+        GV_PT(1);
         read_frags(std::integral_constant<int, 0>{}, 0, 0);
         {
             int stage = 0, par = 0;
@@ -517,7 +549,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     #pragma unroll
         for (int t = 0; t < ST; ++t)
             if (t < ktiles) issue(t);
-        ss_publish();
+        if constexpr (USE_SS) ss_publish();
         {
             const int younger = (ktiles < ST ? ktiles : ST) - 1;      // tiles issued after tile 0
             if (younger >= 3) wait_vm<(ST >= 4 ? 3 * LPT : 0)>();
@@ -545,26 +577,53 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
         }
 
     }
+    GV_PT(2);
     __syncthreads();                                               // every wave is done with the ring: reuse it for staging
+    if constexpr (LATE_SS) ss_publish();                           // (the ring is free now)
     if constexpr (EPI == 0) {
-        if constexpr (STATS != 0) {                                // the sums table (in the freed ring where it fits)
+        if constexpr (HAS_SUMS) {                                  // the sums table (in the freed ring where it fits)
             gvconv::stat_table_init<STATS>(a.st, smem, tid, NW * 64, BN, n0, a.cout, st_b0);
+            __syncthreads();
+        } else if constexpr (LATE_SS) {
             __syncthreads();
         }
         lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES), 32,
-                                             sstab, BN, smem, st_b0 * (STATS != 0 ? a.st.hw : 0));
-        if constexpr (STATS != 0) {
+                                             sstab, BN, smem, st_b0 * (HAS_SUMS ? a.st.hw : 0));
+        if constexpr (HAS_SUMS) {
             if (!(a.st.dbg & 16384)) __syncthreads();              // every lane's runs are in the table
             const int last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
             gvconv::stat_publish<STATS>(a.st, smem, tid, BN, n0, a.cout, st_b0, min(last / a.st.hw - st_b0 + 1, a.st.slots));
         }
     } else if constexpr (EPI == 1)
         gvconv::conv_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane);
-    else
+    else {
+        if constexpr (LATE_SS) __syncthreads();
         x3_epilogue_staged<TM, TN>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * X3EpiGeom<TN>::BYTES),
                                    sstab, BN);
+    }
+#ifdef GV_PHASE_TIMES
+    GV_PT(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GV_PT(4);
+    if (a.phase_buf && lane == 0) {                                // [workgroup][wave][8]: t0..t4, HW_ID, XCC_ID
+        unsigned long long* o = a.phase_buf + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = gv_pt[i];
+        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        {                                                          // per prologue tile: 16-bit clock counts
+            unsigned long long prev = gv_pt[5], w = 0;
+            for (int i = 0; i < 4; ++i) {
+                const unsigned long long dt = gv_pi[i] > prev ? gv_pi[i] - prev : 0;
+                w = (w << 16) | (dt > 65535 ? 65535 : dt);
+                if (gv_pi[i]) prev = gv_pi[i];
+            }
+            o[6] = w;
+        }
+        o[7] = ((gv_pt[5] - gv_pt[0]) << 32) | ((gv_pt[6] - gv_pt[5]) & 0xffffffffull);   // setup | DMA issue (NP = 1)
+    }
+#endif
 }
 
+#ifndef GV_KERNEL_ONLY     // (tools/kernel_asm.sh compiles single instantiations of the kernel above: no launchers)
 // one zero page per device for the padding taps of the gather (lazily allocated OUTSIDE any stream capture: every
 // engine runs eagerly once before it captures)
 const void* zero_page_for_current_device() {
@@ -621,8 +680,9 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
             // front of the epilogue's constants; else behind everything (more LDS per workgroup)
             const size_t tab = gvconv::stat_lds_bytes(a.st.mode, a.st.slots, BN);
             constexpr size_t epi_b = (size_t)WM * WN * EpiGeom<TN>::BYTES, ss_off = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>();
-            if (epi_b + tab <= ss_off) {
-                a.st.lds_off = (int)epi_b;
+            constexpr size_t late = dma_late_ss<NP, WM, WN, TM, TN, ST, EPI>() ? (size_t)16 * BN : 0;   // (the late constants table)
+            if (epi_b + late + tab <= ss_off) {
+                a.st.lds_off = (int)(epi_b + late);
             } else {
                 a.st.lds_off = (int)((lds + 15) / 16 * 16);
                 lds = (size_t)a.st.lds_off + tab;
@@ -632,6 +692,9 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
         } else {
             return GV_E_UNSUPPORTED;
         }
+    }
+    if constexpr (EPI == 0 && NP == 1) {                           // 16-bit output: the lean epilogue where the launch allows it
+        if (gvconv::lp_epilogue_lean_ok(a)) return go(std::integral_constant<int, gvconv::STAT_LEAN>{});
     }
     return go(std::integral_constant<int, 0>{});
 }
@@ -651,6 +714,11 @@ int launch_dma_lp(int cfg, const ConvArgs& a, hipStream_t st) {
         case 9: return launch_dma<T, 1, 2, 2, 4, 2, 3, 0>(a, st);      // 256 x 128, FOUR waves (128 x 64 each): two per CU
         case 10: return launch_dma<T, 1, 2, 2, 2, 4, 3, 0>(a, st);     // 128 x 256, four waves
         case 11: return launch_dma<T, 1, 2, 2, 3, 2, 3, 0>(a, st);     // 192 x 128, four waves
+        // two-stage rings: a third (fourth) workgroup per CU instead of a third stage
+        case 12: return launch_dma<T, 1, 2, 2, 3, 2, 2, 0>(a, st);     // 192 x 128, 2 stages (40 KB: three per CU)
+        case 13: return launch_dma<T, 1, 2, 2, 2, 2, 2, 0>(a, st);     // 128 x 128, 2 stages (32 KB: four per CU)
+        case 14: return launch_dma<T, 1, 2, 2, 2, 3, 2, 0>(a, st);     // 128 x 192, 2 stages (40 KB)
+        case 15: return launch_dma<T, 1, 2, 2, 4, 2, 2, 0>(a, st);     // 256 x 128, four waves, 2 stages (48 KB: three per CU)
     }
     return GV_E_UNSUPPORTED;
 }
@@ -707,7 +775,7 @@ bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; 
 
 int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) { return launch_dma_x3(cfg, a, st); }
 
-int dma_lp_num_cfgs() { return 12; }
+int dma_lp_num_cfgs() { return 16; }
 
 // the DMA loader's layer class: whole 8-channel chunks inside one filter tap, 16-byte aligned pixels, 16-bit input
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32) {
@@ -721,3 +789,7 @@ int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st) {
 }
 
 }  // namespace gvconv
+
+#else
+}  // namespace
+#endif

@@ -358,6 +358,10 @@ int pick_tile(int M, int N, int K) {
 
 extern "C" void gv_conv2d_set_tile_override(int cfg) { g_tile_override = cfg; }
 extern "C" void gv_conv2d_set_debug(int bits) { g_debug = bits; }
+#ifdef GV_PHASE_TIMES
+unsigned long long* g_phase_buf = nullptr;
+extern "C" void gv_conv2d_set_phase_buffer(void* p) { g_phase_buf = (unsigned long long*)p; }
+#endif
 static int planes_of(int math_mode) {
     switch (math_mode) {
         case GV_MATH_F32: return 0;
@@ -516,6 +520,9 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
     a.relu_limit = d->relu_cols > 0 ? d->relu_cols : 0x7fffffff;
     a.tiles_n = 0;
     a.dbg = g_debug;
+#ifdef GV_PHASE_TIMES
+    a.phase_buf = g_phase_buf;
+#endif
     a.zeros = nullptr;
     a.y_p3 = (d->flags & GV_CONV_Y_P3) ? 1 : 0;
     a.y2_p3 = (d->flags & GV_CONV_Y2_P3) ? 1 : 0;

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STAT
     const int tile_m = lid / a.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
+    constexpr bool HAS_SUMS = gvconv::stat_has(STATS);
     int st_b0 = 0;                                   // STATS: image of the tile's first pixel
-    if constexpr (STATS != 0) st_b0 = m0 / a.st.hw;
+    if constexpr (HAS_SUMS) st_b0 = m0 / a.st.hw;
 
     const int q = tid & 3;                           // this thread's 16-byte chunk of every row it loads
     // slot -> row: an 8-lane ds_write_b128 group covers rows R and R+4 (80-byte rows: 16 banks apart mod 32)
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STAT
     }
 
     __syncthreads();                                  // every wave is done with the main-loop buffers
-    if constexpr (STATS != 0) {                       // the sums table (in the freed main-loop space where it fits)
+    if constexpr (HAS_SUMS) {                         // the sums table (in the freed main-loop space where it fits)
         if (!(a.st.dbg & 16384)) {
         gvconv::stat_table_init<STATS>(a.st, smem_raw, tid, NT, BN, n0, a.cout, st_b0);
         __syncthreads();
@@ -374,8 +375,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STAT
     lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane,
                                          reinterpret_cast<float*>(smem_raw + wave * EpiGeom<TN>::BYTES), 32,
                                          (a.dbg & 512) ? nullptr : sstab, BN,      // dbg 512: constants from global memory (A/B)
-                                         smem_raw, st_b0 * (STATS != 0 ? a.st.hw : 0));
-    if constexpr (STATS != 0) {
+                                         smem_raw, st_b0 * (HAS_SUMS ? a.st.hw : 0));
+    if constexpr (HAS_SUMS) {
         if (!(a.st.dbg & 16384)) __syncthreads();     // every lane's runs are in the table
         const int last = (m0 + BM < a.M ? m0 + BM : a.M) - 1;
         gvconv::stat_publish<STATS>(a.st, smem_raw, tid, BN, n0, a.cout, st_b0, min(last / a.st.hw - st_b0 + 1, a.st.slots));
@@ -854,6 +855,7 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     }
     if (xf32) return launch_one<T, WM, WN, TM, TN, true, true>(a, nwg, lds, st);
     if (generic) return launch_one<T, WM, WN, TM, TN, true, false>(a, nwg, lds, st);
+    if (gvconv::lp_epilogue_lean_ok(a)) return launch_one<T, WM, WN, TM, TN, false, false, false, gvconv::STAT_LEAN>(a, nwg, lds, st);
     return launch_one<T, WM, WN, TM, TN, false, false>(a, nwg, lds, st);
 }
 

@@ -44,18 +44,50 @@ template <int TN> struct EpiGeom {
     static constexpr int BYTES = 32 * CW * 4;              // per wave
 };
 
+// Two fp32 values -> one dword of two 16-bit values, round to nearest even: ONE v_cvt_pk_bf16_f32 (bf16; two scalar
+// conversions cost a conversion each plus the shift / or that packs them).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    if constexpr (std::is_same<T, __bf16>::value) return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2_t));
+}
 template <typename T>
 __device__ __forceinline__ void store_chunk(unsigned short* dst, const float (&v)[8], int nvalid, bool vec) {
     if (vec && nvalid == 8) {
         u32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (unsigned)to_bits<T>(v[2 * j]) | ((unsigned)to_bits<T>(v[2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) o[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
         *reinterpret_cast<u32x4*>(dst) = o;
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (j < nvalid) dst[j] = to_bits<T>(v[j]);
     }
+}
+
+// The lean epilogue's store: eight values as one 16-byte store; ReLU on the PACKED words — a negative bf16 / f16 is a
+// negative int16, so max(x, 0) is one v_pk_max_i16 per two values (fmaxf on the fp32 values: two v_max each, the first
+// one canonicalising).  -0.0 and negative NaNs become +0.
+template <typename T>
+__device__ __forceinline__ void store_chunk_lean(unsigned short* dst, const float (&v)[8], bool relu) {
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
+    if (relu) {
+        // (inline asm: __builtin_elementwise_max on the bit-cast short2 words is miscompiled by this hipcc — ONE v_pk_max_i16,
+        // of word 0, feeds all four results)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned r;
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(o[j]));
+            o[j] = r;
+        }
+    }
+    *reinterpret_cast<u32x4*>(dst) = o;
 }
 
 // STATS (conv_stats.h): the launch also produces the train-mode BatchNorm sums of the tensor it stores, from the rounded
@@ -90,7 +122,8 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
     // point checks it — so none of the second-output / split / ReLU / element-wise branches is compiled in: the unrolled
     // epilogue is straight-line code that every workgroup runs once, and past the instruction cache's 64 KB it is fetched
     // again for every workgroup (the 128 x 192 LDS-DMA tile: 50 KB plain, 80 KB with every branch AND the sums).
-    constexpr bool LEAN = STATS != 0;
+    constexpr bool LEAN = STATS != 0;                  // (STAT_LEAN: the same epilogue without the sums)
+    constexpr bool HAS = gvconv::stat_has(STATS);
     const bool dual = !LEAN && y2 != nullptr && a.split == 0;
     // 16-byte accesses need 8-element aligned rows, slices and boundaries (true for every layer of both
     // backbones); anything else takes the element-wise branch of store_chunk
@@ -112,18 +145,31 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
     // output channels) waits out one full memory round trip (the y stores in between may alias, so the compiler cannot
     // hoist the loads itself).  conv3 of block1: 0.365 -> 0.305 ms with the block's own chunks up front.
     constexpr int NPASS = 32 / RPP;
+    // This lane's rows: (block row i, read-back pass) -> output pixel and "is stored", computed ONCE (the residual fetch,
+    // the z fetch of the backward sums and the stores all use them; a wave issues one instruction per 4 cycles at
+    // best, so every instruction of this once-per-workgroup code is 4 clocks of a workgroup's life).
+    unsigned mpix[TM][NPASS];
+    unsigned mvalid = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = pass * RPP + rrow;
+            const int m = m0 + (wm * TM + i) * 32 + row;
+            const bool ok = m < a.M && row < rows_valid;
+            mpix[i][pass] = (unsigned)out_pix(ok ? m : m0);
+            if (ok) mvalid |= 1u << (i * NPASS + pass);
+        }
     u32x4 rvp[2][NPASS];
     auto res_fetch = [&](int b, u32x4 (&dst)[NPASS]) {
         const int jb = b / TM, i = b % TM;
         const int col = n0 + (wn * TN + jb * JB) * 32 + rchunk * 8;
         if (res != nullptr && vec && a.cout - col >= 8) {
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int row = pass * RPP + rrow;
-                const int m = m0 + (wm * TM + i) * 32 + row;
-                dst[pass] = (m < a.M && row < rows_valid) ? *reinterpret_cast<const u32x4*>(res + out_pix(m) * a.res_ld + col)
-                                                          : u32x4{0u, 0u, 0u, 0u};
-            }
+            for (int pass = 0; pass < NPASS; ++pass)
+                dst[pass] = ((mvalid >> (i * NPASS + pass)) & 1u)
+                                ? *reinterpret_cast<const u32x4*>(res + (size_t)mpix[i][pass] * a.res_ld + col)
+                                : u32x4{0u, 0u, 0u, 0u};
         }
     };
     res_fetch(0, rvp[0]);
@@ -143,19 +189,16 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
         if constexpr (STATS == gvconv::STAT_BWD) {
             const int jb = b / TM, i = b % TM;
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int row = pass * RPP + rrow;
-                const int m = m0 + (wm * TM + i) * 32 + row;
-                dst[pass] = (((st_on_mask >> jb) & 1u) && m < a.M && row < rows_valid)
-                                ? *reinterpret_cast<const u32x4*>(st_z[jb] + out_pix(m) * st_zld[jb])
+            for (int pass = 0; pass < NPASS; ++pass)
+                dst[pass] = (((st_on_mask >> jb) & 1u) && ((mvalid >> (i * NPASS + pass)) & 1u))
+                                ? *reinterpret_cast<const u32x4*>(st_z[jb] + (size_t)mpix[i][pass] * st_zld[jb])
                                 : u32x4{0u, 0u, 0u, 0u};
-            }
         }
     };
-    gvconv::StatWave<STATS == 0 ? gvconv::STAT_FWD : STATS> sw;
+    gvconv::StatWave<HAS ? STATS : gvconv::STAT_FWD> sw;
     const int st_mw0 = m0 + wm * TM * 32;                             // the wave's first pixel
     bool st_has_b = false;
-    if constexpr (STATS != 0) {
+    if constexpr (HAS) {
         st_sums = reinterpret_cast<unsigned long long*>(smem + a.st.lds_off);
         st_ss = reinterpret_cast<const float2*>(smem + a.st.lds_off + (size_t)a.st.slots * bn * 16);
         st_dbg = a.st.dbg;
@@ -181,7 +224,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
         const int nvalid = min(8, a.cout - col);                        // <= 0: nothing to store
         const int st_lcol = (wn * TN + jb * JB) * 32 + rchunk * 8;
         bool st_on = false;
-        if constexpr (STATS != 0) {
+        if constexpr (HAS) {
             st_on = ((st_on_mask >> jb) & 1u) != 0;
             sw.begin_block(st_ss, bn, st_lcol);
         }
@@ -231,9 +274,9 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * CW + rchunk * 8 + 4);
                 const int m = m0 + (wm * TM + i) * 32 + row;
-                if (m >= a.M || nvalid <= 0 || row >= rows_valid) continue;
+                if (!((mvalid >> (i * NPASS + pass)) & 1u) || nvalid <= 0) continue;
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const size_t mp = out_pix(m);                     // (m itself unless a parity-class launch)
+                const size_t mp = mpix[i][pass];                  // (m itself unless a parity-class launch)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
                 if (res) {
@@ -264,7 +307,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (col + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
                 }
-                if constexpr (STATS != 0) {
+                if constexpr (HAS) {
                     if (st_on && !(st_dbg & 8192)) {              // sums of the values exactly as stored below
                         float rr[8], zv[8];
 #pragma unroll
@@ -284,7 +327,9 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                         sw.add(rr, zv, m, step0, step0 + RPP);
                     }
                 }
-                if constexpr (LEAN) {
+                if constexpr (STATS == gvconv::STAT_LEAN) {
+                    store_chunk_lean<T>(y + mp * (unsigned)a.y_ld + col, v, a.relu != 0);
+                } else if constexpr (LEAN) {
                     store_chunk<T>(y + mp * a.y_ld + col, v, 8, true);
                 } else if (a.split > 0 && (a.split % 8) != 0) {   // boundary inside a chunk: element-wise
 #pragma unroll
@@ -302,7 +347,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (STATS != 0) {                   // the block's column totals: wave -> workgroup table
+        if constexpr (HAS) {                   // the block's column totals: wave -> workgroup table
             const int lcol0 = (wn * TN + jb * JB) * 32;
             sw.template end_block<CW>(st_sums, stage, bn, lane, rrow, rchunk, lcol0, ((st_col_mask >> jb) & 1u) != 0, st_has_b, st_dbg);
         }

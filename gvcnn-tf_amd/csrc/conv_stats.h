@@ -26,6 +26,13 @@ namespace gvconv {
 constexpr int STAT_MAX_SEG = 8;
 constexpr int STAT_MAX_SLOTS = 64;           // images one row tile may span (before folding by group)
 constexpr int STAT_OFF = 0, STAT_FWD = 1, STAT_BWD = 2;
+// Kernel template value only (never a ConvStats::mode): no sums, but the LEAN staged epilogue the sums instantiations
+// use — one 16-bit destination in whole aligned 8-column chunks, optional residual, uniform ReLU.  Nearly every launch
+// of both backbones qualifies (lp_epilogue_lean_ok); the full epilogue (second output, split destination, partial ReLU,
+// element-wise stores) is 12 - 30 KB more straight-line code that every workgroup streams through once, and the larger
+// tiles then exceed the 64 KB instruction cache.
+constexpr int STAT_LEAN = 3;
+constexpr bool stat_has(int s) { return s == STAT_FWD || s == STAT_BWD; }
 // grid of the partial sums: 2^-30 for sum z (totals exact below 2^23), 2^-24 for sum z^2 (2^29); the backward sums
 // are sums of gradients, orders of magnitude smaller: 2^-40 (exact below 2^13)
 constexpr double STAT_Q_FWD0 = 1073741824.0, STAT_Q_FWD1 = 16777216.0, STAT_Q_BWD = 1099511627776.0;

@@ -460,6 +460,7 @@ def test_bf16_engine_op_by_op_against_the_fp32_engine(backbone, size, N, V):
     labels = torch.tensor([1, 4, 2, 0][:N])
     e32 = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV)
     e16 = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage="bf16")
+    e16.fuse_bn_pool = False                             # (op by op: the fused pool -> BatchNorm pairs are tests/test_gpu_bn_pool.py's)
     e32.forward(x, labels)
     e32.backward()
     e16.forward(x, labels, g_scheme=e32.scheme.cpu().numpy(), g_weight=e32.weight.cpu().numpy())
@@ -679,6 +680,8 @@ def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V
     # the folded sums, equal to the separate ones to summation order only, are switched off on both sides: this test is
     # about WHICH addends reach a gradient buffer, bit for bit)
     eng.fuse_bn_stats = False
+    eng.fuse_bn_pool = False                              # (the pool -> BatchNorm pairs never materialise the BN output this test
+                                                          # compares buffer by buffer: tests/test_gpu_bn_pool.py covers them)
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
     labels = torch.tensor([1, 4, 2, 0][:N])
     eng.forward(x, labels, check=False)
@@ -725,6 +728,7 @@ def test_stream_lanes_reproduce_the_single_stream_step(storage):
     tools/lanes_capture_probe.py; the single-stream step captures fine.)"""
     N, V, size = 4, 3, 171
     eng = TrainGVCNN("inception_v3", N, V, size, size, 5, 10, device=DEV, storage=storage)
+    eng.fuse_bn_pool = False                              # (every activation buffer is compared: see tests/test_gpu_bn_pool.py)
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
     labels = torch.tensor([1, 4, 2, 0]).to(DEV)
 
