@@ -206,7 +206,57 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
             a_ptr[i] = ok ? xb + off : zero_page;
         }
     };
-    locate();
+    // Chunk-major order (a.korder, below) visits another tap of the SAME channel chunk every k-tile: the general locate()
+    // — ~50 vector instructions and two divergent branches for a wave's row blocks — would run per k-tile, next to 12 - 16
+    // MFMAs (a wave issues one instruction per 4 clocks: that is MFMA time).  For it, everything that depends on the row is
+    // computed ONCE: the row's base address (tap (0, 0), this lane's chunk; may lie in front of the tensor: only added to)
+    // and a bit per tap "inside the image"; a k-tile then adds one wave-uniform offset (tap + channel chunk, scalar ALU)
+    // and tests one bit — 6 vector instructions per row block.  (Needs <= 32 taps and no dilation: ConvArgs::korder.)
+    // The three per-row registers of the general form are REUSED for it (both forms live in one kernel, and their
+    // registers would add up: six more than the 168 that let three of the two-stage workgroups share a CU):
+    // (a_img, a_iy0) := the base address, a_ix0 := the tap mask.
+    int q_fr = 0, q_fs = 0;                                        // chunk-major: tap of the next tile to issue (wave-uniform)
+    unsigned q_chunk = 0;                                          //              byte offset of its channel chunk
+    if (a.korder) {
+        // (the taps inside the image form a rectangle [r_lo, r_hi) x [c_lo, c_hi): one row of bits, placed once per
+        // filter row — kh iterations, not kh * kw)
+        unsigned tapmask[UAW], rowbits[UAW];
+        int r_lo[UAW], r_hi[UAW];
+#pragma unroll
+        for (int i = 0; i < UAW; ++i) {
+            r_lo[i] = max(0, -a_iy0[i]);
+            r_hi[i] = min(a.kh, a.ih - a_iy0[i]);
+            const int c_lo = max(0, -a_ix0[i]), c_hi = min(a.kw, a.iw - a_ix0[i]);
+            rowbits[i] = c_hi > c_lo ? (1u << c_hi) - (1u << c_lo) : 0u;
+            tapmask[i] = 0u;
+        }
+        for (int r = 0; r < a.kh; ++r) {
+#pragma unroll
+            for (int i = 0; i < UAW; ++i)
+                if (r >= r_lo[i] && r < r_hi[i]) tapmask[i] |= rowbits[i] << (r * a.kw);
+        }
+#pragma unroll
+        for (int i = 0; i < UAW; ++i) {
+            const long long pix0 = (long long)(a_img[i] + a_iy0[i]) * a.iw + a_ix0[i];
+            const unsigned long long base = (unsigned long long)(xb + pix0 * (long long)pix_bytes + chunk_byte);
+            a_img[i] = (int)(unsigned)base;
+            a_iy0[i] = (int)(unsigned)(base >> 32);
+            a_ix0[i] = (int)tapmask[i];
+        }
+    }
+    int kt_tap = 0;                                                // chunk-major: tap index of the next tile to issue
+    auto locate_fast = [&]() {
+        const unsigned soff = (unsigned)(q_fr * a.iw + q_fs) * pix_bytes + q_chunk;
+        const unsigned bit = 1u << kt_tap;
+#pragma unroll
+        for (int i = 0; i < UAW; ++i) {
+            const char* base = reinterpret_cast<const char*>(((unsigned long long)(unsigned)a_iy0[i] << 32) | (unsigned)a_img[i]);
+            a_ok[i] = ((unsigned)a_ix0[i] & bit) != 0u;
+            a_ptr[i] = a_ok[i] ? base + soff : zero_page;
+        }
+    };
+    if (a.korder) locate_fast();
+    else locate();
     // k-tile order.  Tap-major (k = tap * cin + channel, the packed filter's order): consecutive k-tiles walk the channels
     // of one tap, so a workgroup returns to the same input rows only after streaming its whole tile x cin — with 32
     // workgroups per XCD that working set outruns the 4 MiB L2 and every tap re-fetches the rows from the fabric (measured
@@ -214,12 +264,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     // taps of one chunk re-read the SAME few KB per workgroup back to back, and they hit L2.  Same products, another
     // summation order; the filter slice of (chunk, tap) is k-tile tap * cin/KT + chunk of the same packed filter.
     const int b_tap_step = (a.cin / 16) * G16;                     // bytes between the same chunk of consecutive taps
-    int kt_tap = 0;                                                // chunk-major: tap index of the next tile to issue
     auto advance = [&]() {
         if (a.korder) {
-            if (++fs == a.kw) { fs = 0; ++fr; }
-            if (++kt_tap == a.kh * a.kw) { kt_tap = 0; fs = 0; fr = 0; fc += KT; }
-            locate();
+            if (++q_fs == a.kw) { q_fs = 0; ++q_fr; }
+            if (++kt_tap == a.kh * a.kw) { kt_tap = 0; q_fs = 0; q_fr = 0; q_chunk += (KT / 16) * G16; }
+            locate_fast();
             return;
         }
         fc += KT;
@@ -653,7 +702,7 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
     a.zeros = zero_page_for_current_device();
     if (!a.zeros) return GV_E_UNSUPPORTED;
-    a.korder = (a.kh * a.kw > 1 && a.cin % G::KT == 0 && a.dil_shift == 0 && !(a.dbg & 128)) ? 1 : 0;   // dbg 128: tap-major (A/B)
+    a.korder = (a.kh * a.kw > 1 && a.kh * a.kw <= 32 && a.kw < 32 && a.cin % G::KT == 0 && a.dil_shift == 0 && !(a.dbg & 128)) ? 1 : 0;   // dbg 128: tap-major (A/B)
     const size_t ring = (size_t)ST * NP * (BM + BN) * G::RBYTES;
     const size_t epi = EPI == 1 ? 0 : (size_t)(WM * WN) * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
     static_assert(dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() >= (int)((size_t)ST * NP * (BM + BN) * G::RBYTES), "table behind the ring");
