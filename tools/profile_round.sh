@@ -2,7 +2,7 @@
 # Round profile on the GPU box: the driver's bench line, rocprofv3 kernel stats of the same command (single launch lane, so
 # kernel durations are comparable with bench.py's per-launch hipEvent timing), the other presets, the training steps.
 # Usage: bash tools/profile_round.sh TAG      (writes gpurun_out/prof_TAG/, copy what is to be judged into profiles/)
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
