@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
     }
 }
 
+#ifndef GV_KERNEL_ONLY     // (single instantiations of the kernel above for instruction counts: no launchers)
 unsigned wmagic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 template <typename T, int TI, int TO, int ST>
@@ -312,3 +313,6 @@ int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, 
 }
 
 }  // namespace gvlp
+#else
+}  // namespace
+#endif
