@@ -670,7 +670,7 @@ class TrainGVCNN:
             # plain launch + these
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for op in self.plan.ops:
-                op.pop("_sums_ms_f", None), op.pop("_sums_ms_b", None)
+                op.pop("_sums_ms_f", None), op.pop("_sums_ms_b", None), op.pop("_nofuse_f", None), op.pop("_nofuse_b", None)
             for b in self.plan.ops:
                 if b["kind"] != "bn":
                     continue
@@ -710,6 +710,7 @@ class TrainGVCNN:
                 skey = "st_b" if dgrad else "st_f"
                 fused = bool(op.get(skey)) and self._fusing()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                best_fused = False
                 for t in range(ncfg):
                     op[key] = t + 1
                     d = self._conv_desc(op, dgrad=dgrad)
@@ -727,16 +728,19 @@ class TrainGVCNN:
                             e1.synchronize()
                             t_ms = e0.elapsed_time(e1) / iters
                             if t_ms < best_ms:
-                                best, best_ms = t + 1, t_ms
-                            continue
+                                best, best_ms, best_fused = t + 1, t_ms, True
+                    # the plain launch of the same tile — of a fusable layer too: plus what its separate sums pass costs
+                    # (measured once).  A folding epilogue can cost more than the pass it saves (Conv2d_1a's strip kernel:
+                    # 0.27 ms folded against 0.12 + 0.08), so the layer then keeps the separate pass (op["_nofuse_*"]).
                     rc = lib.gv_conv2d_time(C.byref(d), src, w.data_ptr(), self.ones.data_ptr(), self.zeros.data_ptr(),
                                             dst, iters, C.byref(ms), _st())
-                    # (unfused alternative of a fusable layer: add what its separate sums pass costs, measured once)
                     extra = op.get("_sums_ms_b" if dgrad else "_sums_ms_f", 0.0) if fused else 0.0
                     if rc == 0 and ms.value + extra < best_ms:
-                        best, best_ms = t + 1, ms.value + extra
+                        best, best_ms, best_fused = t + 1, ms.value + extra, False
                 op[key] = best
                 op["_" + key + "_ms"] = best_ms
+                if fused:
+                    op["_nofuse_b" if dgrad else "_nofuse_f"] = not best_fused
             # the parity classes of a stride-2 layer's data gradient: one tile choice each
             for c_ in op.get("s2", ()) if self.s2_classes else ():
                 fused = bool(op.get("st_b")) and self._fusing()
@@ -939,7 +943,7 @@ class TrainGVCNN:
             res = op["res"]
             op["_st_f_done"] = False
             xin = self._x32.data_ptr() + 4 * x.off if (x.vbuf < 0 and self.es == 2) else self._ptr(x)
-            if op.get("st_f") and zeroed and self._fusing():  # the BatchNorm sums of z in this launch's epilogue
+            if op.get("st_f") and zeroed and self._fusing() and not op.get("_nofuse_f"):   # the BatchNorm sums of z in this launch's epilogue
                 rc = lib.gv_conv2d_fwd_bnstats(C.byref(d), xin, op["w_fwd"].data_ptr(), self.ones.data_ptr(),
                                                shift.data_ptr(), None, self._ptr(y), C.byref(self._bn_stats(op, "st_f")),
                                                _st())
@@ -1262,7 +1266,7 @@ class TrainGVCNN:
                             b["acc_b"].zero_()
                     op["_st_b_done"] = ok
                     return
-                if op.get("st_b") and zeroed and self._fusing():
+                if op.get("st_b") and zeroed and self._fusing() and not op.get("_nofuse_b"):
                     # this launch writes the FINAL gradient of x: the backward sums of the BatchNorm layers that
                     # produced x leave its epilogue
                     rc = lib.gv_conv2d_fwd_bnstats(C.byref(dd), dz, op["w_dgrad"].data_ptr(), self.ones.data_ptr(),
