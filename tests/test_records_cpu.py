@@ -163,3 +163,34 @@ def test_decode_workers_return_the_same_shapes_in_order(tmp_path):
     assert len(serial) == len(pooled) == 23
     for (a, la), (b, lb), (views, lab) in zip(serial, pooled, shapes):
         assert la == lb == lab and np.array_equal(a, b) and np.array_equal(a, np.stack(views))
+
+
+def test_a_list_of_record_files_is_interleaved_the_same_with_and_without_workers(tmp_path):
+    """ViewBatcher([files]): one record of each file in turn, files of different lengths (train_data.py:22-24 reads its
+    files in parallel); reader threads + decode workers return exactly the single-process stream."""
+    rng = np.random.RandomState(5)
+    shapes = [([rng.randint(0, 256, size=(7, 9, 3)).astype(np.uint8) for _ in range(2)], i) for i in range(19)]
+    cuts = [(0, 4), (4, 13), (13, 19)]
+    paths = []
+    for k, (a, b) in enumerate(cuts):
+        paths.append(os.path.join(tmp_path, "f%d.record" % k))
+        R.write_tfrecords(paths[-1], [R.make_example([R.encode_png(v) for v in vs], lab) for vs, lab in shapes[a:b]])
+    serial = list(R.ViewBatcher(paths, 2, 8, 8, 4, "cpu")._decoded())
+    want = []                                              # round-robin over the three files until each runs out
+    its = [iter(range(a, b)) for a, b in cuts]
+    while its:
+        for it in list(its):
+            i = next(it, None)
+            if i is None:
+                its.remove(it)
+            else:
+                want.append(i)
+    assert [lab for _, lab in serial] == want
+    vb = R.ViewBatcher(paths, 2, 8, 8, 4, "cpu", workers=3)
+    try:
+        pooled = list(vb._decoded())
+    finally:
+        vb.close()
+    assert len(pooled) == 19
+    for (a, la), (b, lb) in zip(serial, pooled):
+        assert la == lb and np.array_equal(a, b) and np.array_equal(a, np.stack(shapes[la][0]))

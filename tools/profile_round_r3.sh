@@ -13,7 +13,7 @@ bash $R/tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 cd $R
 python3 tools/step_times.py --tune > $O/step_times_train_c3_bf16.txt 2>&1
 [ -f gvcnn-tf_amd/libgvcnn_hip_pt.so ] && python3 tools/phase_times.py > $O/phase_times_bf16.txt 2>&1
-python3 tools/pipeline_bench.py --sizes 224 --workers 0 8 16 32 > $O/pipeline_bench.txt 2>&1
+python3 tools/pipeline_bench.py --sizes 224 --workers 32 64 --files 1 4 > $O/pipeline_bench.txt 2>&1
 python3 tools/conv_probe_lp.py bf16 > $O/conv_probe_bf16.txt 2>&1
 GRAFT_REPO_ROOT=$R bash tools/profile_train.sh bf16 1 > $O/profile_train_bf16.log 2>&1
 cp $R/gpurun_out/prof_train_bf16/summary.txt $O/train_bf16_summary.txt 2>/dev/null
