@@ -6,12 +6,13 @@ export GV_NO_TUNE=1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $O/p1 -o p --output-format csv -- python3 $R/tools/train_bench.py --shapes 32 --steps 1 --storage bf16 > $O/p1.log 2>&1
 python3 - <<PY > $O/summary.txt
 import csv, glob, collections
-FAM = [("conv fwd/dgrad (conv_igemm_lp, halo, stem)", ("conv_igemm_lp", "conv3x3_halo", "conv_stem_patch")),
+FAM = [("conv fwd/dgrad, LDS-DMA tiles (conv_dma)", ("conv_dma",)),
+       ("conv fwd/dgrad, register-staged / halo / stem (conv_igemm_lp, conv3x3_halo_lp, conv_stem_patch_lp)", ("conv_igemm_lp", "conv3x3_halo", "conv_stem_patch")),
+       ("filter gradient, LDS-DMA (conv_wgrad_dma)", ("conv_wgrad_dma",)),
        ("filter gradient, tap per workgroup (conv_wgrad_lp)", ("conv_wgrad_lp",)),
-       ("filter gradient, strip form (conv_wgrad_strip_lp)", ("conv_wgrad_strip",)),
-       ("filter gradient, 3-channel stem (conv_wgrad_direct)", ("conv_wgrad_direct",)),
+       ("filter gradient, strip / stem forms", ("conv_wgrad_strip", "conv_wgrad_stem", "conv_wgrad_direct")),
        ("BN sums (grouped_sums_v8)", ("grouped_sums",)), ("BN apply (bn_stream_v8)", ("bn_stream",)),
-       ("max-pool backward (maxpool3s2_bwd_lp)", ("maxpool3s2",))]
+       ("max pools (argmax forward / backward, with the BatchNorm tail)", ("maxpool",)), ("other pools", ("pool2d", "avgpool"))]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(int)
 for path in glob.glob("$O/p1/**/*counter_collection.csv", recursive=True):
@@ -29,7 +30,7 @@ for fam, _ in FAM:
     if not c:
         continue
     gui = c["GRBM_GUI_ACTIVE"] / 8.0
-    print("%-55s launches %4d  MFMA pipe %5.1f %%  LDS conflicts %5.1f %% of LDS-active  busy cycles %.3g"
+    print("%-100s launches %4d  MFMA pipe %5.1f %%  LDS conflicts %5.1f %% of LDS-active  busy cycles %.3g"
           % (fam, cnt[fam], 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024) if gui else 0,
              100 * c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c["SQ_LDS_IDX_ACTIVE"] else 0, c["SQ_BUSY_CYCLES"]))
 PY
