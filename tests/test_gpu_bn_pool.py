@@ -154,3 +154,35 @@ def test_engine_with_pooled_batchnorm_reproduces_the_unfused_step(size):
     cosw = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     print("pool->bn vs bn->pool: loss %.6f, cosine dz(Conv2d_4a) %.5f, all filter gradients %.5f" % (a["loss"], cos, cosw))
     assert cosw > 0.95, cosw
+
+
+def test_pool_backward_with_the_batchnorm_tail_rejects_what_it_cannot_do():
+    """gv_pool2d_bwd_argmax_bn exists for 3x3 / stride 2 / VALID windows on 16-bit storage with 16-byte aligned coefficient
+    tables: anything else is refused (GV_E_UNSUPPORTED / GV_E_BADARG) and nothing is written."""
+    code, td = TYPES["bf16"]
+    nb, h, w, c, V = 2, 9, 9, 32, 2
+    oh = ow = 4
+    z = torch.randn(nb, h, w, c).to(td).to(DEV)
+    dy = torch.randn(nb, oh, ow, c).to(td).to(DEV)
+    arg = torch.zeros(nb, oh, ow, c, dtype=torch.uint8, device=DEV)
+    tab = torch.ones(5 * V * c + 4, device=DEV)
+    t = [tab[i * V * c:(i + 1) * V * c] for i in range(5)]
+    dz = torch.full_like(z, 3.0)
+    L = lib()
+
+    def call(d, tables=t):
+        return L.gv_pool2d_bwd_argmax_bn(C.byref(d), arg.data_ptr(), dy.data_ptr(), c, z.data_ptr(), c, V, tables[0].data_ptr(),
+                                         tables[1].data_ptr(), tables[2].data_ptr(), tables[3].data_ptr(), tables[4].data_ptr(),
+                                         dz.data_ptr(), c, st())
+    good = _lib.PoolDesc(nb, h, w, c, c, 3, 3, 2, 0, 0, oh, ow, c, _lib.GV_POOL_MAX, code)
+    assert call(good) == 0
+    torch.cuda.synchronize()
+    dz.fill_(3.0)
+    stride1 = _lib.PoolDesc(nb, h, w, c, c, 3, 3, 1, 1, 1, h, w, c, _lib.GV_POOL_MAX, code)
+    assert call(stride1) != 0
+    f32 = _lib.PoolDesc(nb, h, w, c, c, 3, 3, 2, 0, 0, oh, ow, c, _lib.GV_POOL_MAX, _lib.GV_F32)
+    assert call(f32) != 0
+    misaligned = [tab[1 + i * V * c:1 + (i + 1) * V * c] for i in range(5)]      # 4-byte, not 16-byte aligned
+    assert call(good, misaligned) != 0
+    torch.cuda.synchronize()
+    assert float(dz.float().min()) == 3.0 and float(dz.float().max()) == 3.0, "a refused call wrote to dz"
