@@ -60,7 +60,9 @@ struct WgradGeo {
     unsigned magic_ow, magic_oh;       // ceil(2^32 / d): exact for the small dividends of the incremental pixel walk
 };
 
-template <int P> __device__ __forceinline__ int seg_key(int row) { return P == 128 ? ((row >> 1) & 1) : (row & 3); }
+// (384-byte rows — 192-channel sides — are 96 banks apart: rows r and r + 2 of a read's four rows would share banks;
+// swapping the 64-byte segments pairwise on every second row pair moves them 16 banks apart, and 0..5 stays 0..5)
+template <int P> __device__ __forceinline__ int seg_key(int row) { return P == 256 ? (row & 3) : ((row >> 1) & 1); }
 
 template <typename T, int TI, int TO, int ST>
 __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
     constexpr int UX = X_BYTES / 1024, UZ = Z_BYTES / 1024;    // DMA instructions per stage
     constexpr int UXW = (UX + 3) / 4, UZW = (UZ + 3) / 4;      // per wave
     constexpr int LPT = UXW + UZW;
-    static_assert(TI >= 1 && TI <= 2 && TO >= 1 && TO <= 2, "64- or 128-channel sides");
+    static_assert(TI >= 1 && TI <= 3 && TO >= 1 && TO <= 3, "64-, 128- or 192-channel sides");
     static_assert(ST >= 2 && ST <= 4 && (ST - 1) * LPT < 64, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -97,8 +99,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
     const char* zero_page = reinterpret_cast<const char*>(g.zeros);
 
     // ---- loader slots.  X: instruction u covers stage rows [u*RX, (u+1)*RX), lane -> (row, 16-byte unit of the row)
-    constexpr int LX = PX / 16, RX = 64 / LX;                  // lanes per row, rows per instruction
-    constexpr int LZ = PZ / 16, RZ = 64 / LZ;
+    // (lane -> (row, unit) through the stage-linear 16-byte index u * 64 + lane: a 384-byte row is 24 units, so an
+    // instruction's 64 lanes do not cover whole rows there)
+    constexpr int LX = PX / 16, LZ = PZ / 16;                  // 16-byte units (lanes) per row
+    auto x_rowof = [&](int u) { return (u * 64 + lane) / LX; };
+    auto x_unitof = [&](int u) { return (u * 64 + lane) % LX; };
+    auto z_rowof = [&](int u) { return (u * 64 + lane) / LZ; };
+    auto z_unitof = [&](int u) { return (u * 64 + lane) % LZ; };
     int x_u[UXW], x_n[UXW], x_oy[UXW], x_ox[UXW], x_choff[UXW];
     bool x_chok[UXW];
     const int ohow = g.oh * g.ow;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
         int u = wave + s * 4;
         u = u < UX ? u : UX - 1;                               // surplus slots re-load the last block (same bytes)
         x_u[s] = u;
-        const int row = u * RX + lane / LX, unit = lane % LX;
+        const int row = x_rowof(u), unit = x_unitof(u);
         const int lseg = (unit >> 2) ^ seg_key<PX>(row);
         const int ch = (lseg * 4 + (unit & 3)) * 8;            // channel of this lane's 8 values inside the tile
         x_choff[s] = (ci0 + ch) * 2;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
         int u = wave + s * 4;
         u = u < UZ ? u : UZ - 1;
         z_u[s] = u;
-        const int row = u * RZ + lane / LZ, unit = lane % LZ;
+        const int row = z_rowof(u), unit = z_unitof(u);
         const int lseg = (unit >> 2) ^ seg_key<PZ>(row);
         const int ch = (lseg * 4 + (unit & 3)) * 8;
         z_row[s] = row;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
         const int mt = m0 + issued_stage * PT;
 #pragma unroll
         for (int s = 0; s < UXW; ++s) {
-            const int row = x_u[s] * RX + lane / LX;
+            const int row = x_rowof(x_u[s]);
             const int iy = x_oy[s] * g.stride + fr - g.pad_t, ix = x_ox[s] * g.stride + fs - g.pad_l;
             const bool ok = x_chok[s] && mt + row < m1 && (unsigned)iy < (unsigned)g.ih && (unsigned)ix < (unsigned)g.iw;
             const size_t off = ((size_t)((unsigned)(x_n[s] * g.ih + iy) * (unsigned)g.iw + (unsigned)ix)) * (size_t)g.x_ld * 2 + x_choff[s];
@@ -289,10 +296,29 @@ namespace gvlp {
 // k = 0..11: (TI, TO) in {1,2}^2 x workgroup target 1024 / 2048 / 4096 on a four-stage ring (16 - 64 KB: two to four
 // workgroups per CU); k = 12..23: the same on TWO stages (8 - 32 KB: five and more per CU — as in the forward kernels a
 // resident neighbour covers a workgroup's barriers and its atomic epilogue better than ring depth does)
-int wgrad_dma_num_cfgs() { return 24; }
+// k = 24..33 (round 3): 192-channel sides on two stages — (TI, TO) = (3,3), (3,1), (1,3), (3,2), (2,3) at 1024 then 2048
+// workgroups.  A 192-channel side on 128-wide tiles is one full and one half-empty tile: a 192 x 192 layer (Mixed_6e's
+// 1x7 / 7x1 pairs, Mixed_7a) did 16/9 of its work, loads and instructions included.
+int wgrad_dma_num_cfgs() { return 34; }
 
 int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, int k, hipStream_t st) {
-    if (k < 0 || k >= 24) return GV_E_BADARG;
+    if (k < 0 || k >= 34) return GV_E_BADARG;
+    if (k >= 24) {
+        const int q = (k - 24) % 5;
+        const int64_t t3 = k - 24 < 5 ? 1024 : 2048;
+#define GV_WD3(T)                                                                                       \
+    switch (q) {                                                                                        \
+        case 0: return launch_wgrad_dma<T, 3, 3, 2>(d, x, dz, dz_ld, dw, t3, st);                       \
+        case 1: return launch_wgrad_dma<T, 3, 1, 2>(d, x, dz, dz_ld, dw, t3, st);                       \
+        case 2: return launch_wgrad_dma<T, 1, 3, 2>(d, x, dz, dz_ld, dw, t3, st);                       \
+        case 3: return launch_wgrad_dma<T, 3, 2, 2>(d, x, dz, dz_ld, dw, t3, st);                       \
+        default: return launch_wgrad_dma<T, 2, 3, 2>(d, x, dz, dz_ld, dw, t3, st);                      \
+    }
+        if (d->dtype == GV_BF16) { GV_WD3(__bf16) }
+        if (d->dtype == GV_F16) { GV_WD3(_Float16) }
+#undef GV_WD3
+        return GV_E_UNSUPPORTED;
+    }
     const int shape = k % 4 + (k >= 12 ? 4 : 0);
     const int64_t target = 1024ll << ((k % 12) / 4);
 #define GV_WD(T)                                                                                        \
