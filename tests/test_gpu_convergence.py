@@ -15,7 +15,8 @@ steps of converged runs — and the filter gradients are summed with fp32 atomic
 differ; the bands are set for that):
   * both losses (mean of the last 30 steps) fall below 50 % of their starting level (mean of the first 10; measured:
     5 - 25 %);
-  * the bf16 run's final loss is at most 3x the fp32 run's + 0.5;
+  * the bf16 run's final loss is at most 3x the fp32 run's + a quarter of its own starting level (the last-30-step mean
+    of a converged ResNet run is anywhere in 0.0000 ... 0.70 — it spikes — so a fixed + 0.5 failed once in ~25 runs);
   * eval-mode accuracy on 128 held-out shapes: chance is 1/C = 0.25 (sigma 0.04 on 128 shapes), both runs reach >= 0.35
     (measured over ~20 runs: Inception 0.48 - 1.00 for EITHER storage type — two runs of the same engine differ by up
     to 0.5 — ResNet 0.8 - 1.0), and bf16 is at most 0.4 below fp32 (a band of 0.25 failed once in ~10 runs on exactly that spread:
@@ -95,5 +96,5 @@ def test_bf16_run_trains_like_the_fp32_run(backbone, S, steps, lr):
         assert last < 0.5 * first, "%s: loss %.4f -> %.4f" % (storage, first, last)
         assert acc >= 0.35, "%s: eval-mode accuracy %.3f (chance 0.25)" % (storage, acc)
     f32, b16 = out["f32"], out["bf16"]
-    assert b16[1] <= 3.0 * f32[1] + 0.5, (f32, b16)
+    assert b16[1] <= 3.0 * f32[1] + 0.25 * b16[0], (f32, b16)
     assert b16[2] >= f32[2] - 0.4, (f32, b16)
