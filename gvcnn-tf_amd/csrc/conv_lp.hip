@@ -850,8 +850,12 @@ int launch_cfg(const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
         return launch_one<T, WM, WN, TM, TN, false, false, false, gvconv::STAT_BWD>(a, nwg, lds, st);
     }
     if (a.xscale) {
-        if constexpr (xpre_cfg(WM, WN, TM, TN)) return launch_one<T, WM, WN, TM, TN, false, false, true>(a, nwg, lds, st);
-        else return GV_E_UNSUPPORTED;
+        if constexpr (xpre_cfg(WM, WN, TM, TN)) {
+            if (gvconv::lp_epilogue_lean_ok(a)) return launch_one<T, WM, WN, TM, TN, false, false, true, gvconv::STAT_LEAN>(a, nwg, lds, st);
+            return launch_one<T, WM, WN, TM, TN, false, false, true>(a, nwg, lds, st);
+        } else {
+            return GV_E_UNSUPPORTED;
+        }
     }
     if (xf32) return launch_one<T, WM, WN, TM, TN, true, true>(a, nwg, lds, st);
     if (generic) return launch_one<T, WM, WN, TM, TN, true, false>(a, nwg, lds, st);
