@@ -42,9 +42,14 @@ struct ConvArgs {
 
 // May this launch take the lean 16-bit staged epilogue (conv_stats.h STAT_LEAN)?  dbg bit 2: always the full one (A/B).
 inline bool lp_epilogue_lean_ok(const ConvArgs& a) {
-    return !(a.dbg & 2) && a.y2 == nullptr && a.split == 0 && a.cout % 8 == 0 && a.y_ld % 8 == 0 &&
+    const bool one = a.y2 == nullptr && a.split == 0;
+    // ... or the two destinations of a fused sibling GEMM, split on a chunk boundary (no second ACTIVATION: that is the
+    // full epilogue's dual output)
+    const bool two = a.y2 != nullptr && a.split > 0 && a.split % 8 == 0 && a.y2_ld % 8 == 0 && (((uintptr_t)a.y2) & 15) == 0 &&
+                     !a.y2_p3;
+    return !(a.dbg & 2) && (one || two) && a.cout % 8 == 0 && a.y_ld % 8 == 0 &&
            (((uintptr_t)a.y) & 15) == 0 && (a.res == nullptr || (a.res_ld % 8 == 0 && (((uintptr_t)a.res) & 15) == 0)) &&
-           (!a.relu || a.relu_limit >= a.cout);
+           (!a.relu || a.relu_limit >= a.cout || a.relu_limit % 8 == 0);
 }
 
 // Epilogue straight from 32x32 MFMA accumulators (C/D layout is dtype independent on gfx950:

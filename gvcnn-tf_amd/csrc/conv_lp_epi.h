@@ -328,7 +328,11 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                     }
                 }
                 if constexpr (STATS == gvconv::STAT_LEAN) {
-                    store_chunk_lean<T>(y + mp * (unsigned)a.y_ld + col, v, a.relu != 0);
+                    // (a fused sibling GEMM: columns >= split go to the second destination, columns >= relu_limit — the
+                    // pooled branch, activated after its pool — keep their sign; both boundaries are chunk aligned here)
+                    const bool second = a.split > 0 && col >= a.split;
+                    unsigned short* dst = second ? y2 + mp * (unsigned)a.y2_ld + (col - a.split) : y + mp * (unsigned)a.y_ld + col;
+                    store_chunk_lean<T>(dst, v, a.relu != 0 && col < a.relu_limit);
                 } else if constexpr (LEAN) {
                     store_chunk<T>(y + mp * a.y_ld + col, v, 8, true);
                 } else if (a.split > 0 && (a.split % 8) != 0) {   // boundary inside a chunk: element-wise
