@@ -178,9 +178,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
         a_rb[i] = rb;
         int m = m0 + rb * RPI + lrow;
         m = m < a.M ? m : a.M - 1;                                 // rows past M: results never stored
-        const int n = m / ohow;
+        const int n = gv_div(m, a.y_div_img);
         const int rem = m - n * ohow;
-        const int oy = rem / a.ow;
+        const int oy = gv_div(rem, a.y_div_row);
         const int ox = rem - oy * a.ow;
         a_img[i] = n * a.ih;
         a_iy0[i] = oy * a.stride - a.pad_t;

@@ -536,9 +536,11 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
         if (!lp || split || y2 || d->stride != 1 || a.dil_shift) return GV_E_UNSUPPORTED;
         if ((int64_t)d->nb * d->y_ih * d->y_iw > 0x7fffffff) return GV_E_UNSUPPORTED;
         a.y_step = 2; a.y_py = d->y_py; a.y_px = d->y_px; a.y_ih = d->y_ih; a.y_iw = d->y_iw;
-        a.y_div_img = gv_fast_div(d->oh * d->ow);
-        a.y_div_row = gv_fast_div(d->ow);
     }
+    // exact m / (oh*ow) and rem / ow by multiplication: the loaders' row -> (image, y, x) walk (four 32-bit divisions per
+    // lane of every workgroup's prologue otherwise, ~35 instructions each) and the parity-class epilogue
+    a.y_div_img = gv_fast_div(d->oh * d->ow);
+    a.y_div_row = gv_fast_div(d->ow);
     if (stats) {
         // BatchNorm sums in the epilogue: 16-bit storage, one plain destination (the sums are those of the stored values)
         if (stats->mode != GV_BN_STATS_FWD && stats->mode != GV_BN_STATS_BWD) return GV_E_BADARG;

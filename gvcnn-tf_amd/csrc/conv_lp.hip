@@ -83,9 +83,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STAT
         const int row = slot_row(tid + i * NT);
         const int m = m0 + row;
         if (row < BM && m < a.M) {
-            const int n = m / ohow;
+            const int n = gv_div(m, a.y_div_img);
             const int rem = m - n * ohow;
-            const int oy = rem / a.ow;
+            const int oy = gv_div(rem, a.y_div_row);
             const int ox = rem - oy * a.ow;
             a_img[i] = n * a.ih;
             a_iy0[i] = oy * a.stride - a.pad_t;
