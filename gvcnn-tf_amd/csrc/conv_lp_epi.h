@@ -255,6 +255,13 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
         }
         // split destination: a chunk lies on one side when split % 8 == 0; otherwise decide per element below
         const bool to_second = !LEAN && a.split > 0 && col >= a.split;
+        // STAT_LEAN: this column block's destination, once per block (a fused sibling GEMM: columns >= split go to the
+        // second destination, columns >= relu_limit — the pooled branch, activated after its pool — keep their sign; both
+        // boundaries are chunk aligned there)
+        const bool lean_second = STATS == gvconv::STAT_LEAN && a.split > 0 && col >= a.split;
+        unsigned short* const lean_base = lean_second ? y2 + (col - a.split) : y + col;
+        const unsigned lean_ld = lean_second ? (unsigned)a.y2_ld : (unsigned)a.y_ld;
+        const bool lean_relu = a.relu != 0 && col < a.relu_limit;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int b = jb * TM + i;
@@ -328,11 +335,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                     }
                 }
                 if constexpr (STATS == gvconv::STAT_LEAN) {
-                    // (a fused sibling GEMM: columns >= split go to the second destination, columns >= relu_limit — the
-                    // pooled branch, activated after its pool — keep their sign; both boundaries are chunk aligned here)
-                    const bool second = a.split > 0 && col >= a.split;
-                    unsigned short* dst = second ? y2 + mp * (unsigned)a.y2_ld + (col - a.split) : y + mp * (unsigned)a.y_ld + col;
-                    store_chunk_lean<T>(dst, v, a.relu != 0 && col < a.relu_limit);
+                    store_chunk_lean<T>(lean_base + mp * lean_ld, v, lean_relu);
                 } else if constexpr (LEAN) {
                     store_chunk<T>(y + mp * a.y_ld + col, v, 8, true);
                 } else if (a.split > 0 && (a.split % 8) != 0) {   // boundary inside a chunk: element-wise
