@@ -314,11 +314,17 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (col + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
                 }
-                if constexpr (HAS) {
+                u32x4 packed;                                     // (sums instantiations: the chunk, rounded and packed ONCE —
+                if constexpr (HAS) {                              //  the same words are summed and stored)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) packed[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
                     if (st_on && !(st_dbg & 8192)) {              // sums of the values exactly as stored below
                         float rr[8], zv[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rr[e] = from_bits<T>(to_bits<T>(v[e]));
+                        for (int j = 0; j < 4; ++j) {
+                            rr[2 * j] = from_bits<T>((unsigned short)(packed[j] & 0xffffu));
+                            rr[2 * j + 1] = from_bits<T>((unsigned short)(packed[j] >> 16));
+                        }
                         if constexpr (STATS == gvconv::STAT_BWD) {
                             const u32x4 zq = zvp[b & 1][pass];
 #pragma unroll
@@ -337,7 +343,7 @@ __device__ __forceinline__ void lp_epilogue_staged(const ConvArgs& a, const f32x
                 if constexpr (STATS == gvconv::STAT_LEAN) {
                     store_chunk_lean<T>(lean_base + mp * lean_ld, v, lean_relu);
                 } else if constexpr (LEAN) {
-                    store_chunk<T>(y + mp * a.y_ld + col, v, 8, true);
+                    *reinterpret_cast<u32x4*>(y + mp * a.y_ld + col) = packed;
                 } else if (a.split > 0 && (a.split % 8) != 0) {   // boundary inside a chunk: element-wise
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
