@@ -255,13 +255,28 @@ def _is_conv_kernel(n):
     return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n
 
 
-def _pmc_rows(path, counter, steps, marker="dense_f32"):
+def _pmc_rows(path, counter, steps, marker="dense_f32", total_steps=None):
+    """The dispatches of the last `steps` steps of a child run.  A step ends with its last `marker` kernel (the classifier
+    of a forward pass, the optimizer of a training step); a step may launch the marker SEVERAL times (apply_momentum:
+    one launch for the decayed range, one for the rest), so the launches per step are counted — marker dispatches over
+    the steps the child ran (total_steps = warmup + steps) — instead of assumed to be one."""
     import csv
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ends = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]   # one step ends with the classifier (forward) / the optimizer (training)
-    start = ends[-steps - 1] + 1 if len(ends) > steps else 0
-    return rows[start:]
+    ends = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    per_step = 1
+    if total_steps:
+        if not ends or len(ends) % total_steps:
+            raise RuntimeError("%d '%s' dispatches over %d steps: cannot delimit the steps" % (len(ends), marker, total_steps))
+        per_step = len(ends) // total_steps
+    if not ends:
+        return rows
+    last = ends[-1]
+    start = ends[-per_step * steps - 1] + 1 if len(ends) > per_step * steps else 0
+    window = rows[start:last + 1]
+    if len(window) % steps:
+        raise RuntimeError("%d dispatches in a window of %d steps: not a whole number per step" % (len(window), steps))
+    return window
 
 
 def measure_traffic(a, tiles_path):
@@ -349,7 +364,7 @@ def measure_traffic_train(a):
             if r.returncode != 0 or not files:
                 return {"note": "rocprofv3 --pmc %s pass failed (rc %d): traffic not measured: %s"
                                 % (counter, r.returncode, r.stderr[-200:].replace("\n", " "))}
-            for row in _pmc_rows(files[0], counter, steps, marker="sgd_momentum"):
+            for row in _pmc_rows(files[0], counter, steps, marker="sgd_momentum", total_steps=steps + 2):   # (the child: one step before autotune, one warm-up, `steps` timed)
                 fam = _train_family(row["Kernel_Name"])
                 d = fam_bytes.setdefault(fam, {"fetch": 0.0, "write": 0.0, "launches": 0})
                 d["fetch" if tag == "f" else "write"] += float(row["Counter_Value"]) * mult / steps

@@ -113,6 +113,7 @@ SIGNATURES = {
     "gv_accumulate": (C.c_int, [_P, _I, _P, _I, _L, _I, _P]),
     "gv_bias_grad": (C.c_int, [_P, _I, _L, _I, _P, _P, _P]),
     "gv_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P]),
+    "gv_conv2d_wgrad_ws": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, C.c_int64, _P]),
     "gv_pool2d_bwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _I, _P, _I, _P]),
     "gv_pool2d_fwd_argmax": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P, _P]),
     "gv_pool2d_bwd_argmax": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _I, _P, _I, _P]),

@@ -80,6 +80,43 @@ __device__ __forceinline__ int gv_div(int m, const GvFastDiv& f) {
 static inline int gv_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool gv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- where a filter-gradient launch puts its partial tiles ------------------------------------------------------
+// A filter gradient splits the pixel axis over workgroups ("slices"); every slice produces a partial of each
+// element of dW it owns.  Two ways to combine them:
+//   part == nullptr   fp32 atomic adds into dw (the order the slices arrive in decides the rounding: two runs differ in
+//                     the last bits) — or, with ONE slice, the plain sum: a single adder per element;
+//   part != nullptr   slice s STORES its partials into part + s * stride (an image of dW per slice), and a second launch
+//                     (gv_dw_finish) adds the slices in index order into dw: the same bits every run, whatever the
+//                     dispatch order.  (gv_conv2d_wgrad_ws; reference: the deterministic CPU gradients of
+//                     utils/train_utils.py:217-259.)
+struct GvDw {
+    float* dw;
+    float* part;
+    size_t stride;                                               // elements between two slices' images (multiple of 4)
+    size_t cap_bytes;                                            // host side: size of the workspace behind `part`
+};
+static inline GvDw gv_dw_plain(float* dw) { return GvDw{dw, nullptr, 0, 0}; }
+// The slices a launch may use with this sink: a workspace holds cap_bytes / image slices; without room for two the
+// launch runs un-split (one adder per element is deterministic as well).
+static inline int64_t gv_dw_clamp(const GvDw& o, size_t elems, int64_t splits) {
+    if (!o.part) return splits;
+    const int64_t cap = (int64_t)(o.cap_bytes / (((elems + 3) / 4 * 4) * sizeof(float)));
+    return cap < 2 ? 1 : (splits < cap ? splits : cap);
+}
+// The sink the KERNEL gets for `splits` slices (the plain one for a single slice) ...
+static inline GvDw gv_dw_sink(const GvDw& o, size_t elems, int64_t splits) {
+    if (!o.part || splits <= 1) return GvDw{o.dw, nullptr, 0, 0};
+    return GvDw{o.dw, o.part, (elems + 3) / 4 * 4, o.cap_bytes};
+}
+// ... and the launch that follows it: dw[i] += part[0][i] + part[1][i] + ... in slice order (nothing to do for a plain sink)
+int gv_dw_finish(const GvDw& o, size_t elems, int64_t splits, hipStream_t st);      // train.hip
+#if defined(__HIPCC__)
+__device__ __forceinline__ void gv_dw_put(const GvDw& o, int64_t slice, size_t idx, float v) {
+    if (o.part) o.part[(size_t)slice * o.stride + idx] = v;      // (wave-uniform branch)
+    else atomicAdd(&o.dw[idx], v);
+}
+#endif
+
 // Bijective XCD-aware remap of a 1-D grid: blocks with equal (bid % 8) share an XCD (and its
 // L2) under round-robin dispatch, so give each XCD one contiguous chunk of logical tile ids.
 // Placement only changes speed, never results.

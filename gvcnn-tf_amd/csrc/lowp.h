@@ -42,10 +42,10 @@ int view_pool_fuse_bwd(int dtype, const void* F, const float* dS, int V, int N, 
                        const int* scheme, int G, const float* weight, int mode, void* dF, hipStream_t st,
                        int64_t scheme_stride, int64_t weight_stride);
 bool wgrad_mfma_ok(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld);
-int conv_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st);
-int conv_wgrad_stem(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st);
+int conv_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, hipStream_t st);
+int conv_wgrad_stem(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, hipStream_t st);
 // wgrad_dma.hip: the same filter gradient with LDS-DMA operand staging (tile_cfg 31 .. 30 + wgrad_dma_num_cfgs())
 int wgrad_dma_num_cfgs();
-int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, int k, hipStream_t st);
+int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, int k, hipStream_t st);
 
 }  // namespace gvlp

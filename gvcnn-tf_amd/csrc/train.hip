@@ -113,8 +113,11 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
         double a = 0.0, b = 0.0;
         for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
-        atomicAdd(&acc[o], a);
-        if (MODE != 2) atomicAdd(&acc[o + 1], b);
+        // the block's partial on the fixed grids of conv_stats.h (2^-30 / 2^-24 forward, 2^-40 backward): exact fp64
+        // additions, so the totals do not depend on the order the blocks arrive in
+        const double q0 = MODE == 0 ? 1073741824.0 : 1099511627776.0, q1 = MODE == 0 ? 16777216.0 : 1099511627776.0;
+        atomicAdd(&acc[o], rint(a * q0) / q0);
+        if (MODE != 2) atomicAdd(&acc[o + 1], rint(b * q1) / q1);
     }
 }
 
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float* __restrict__ 
                                                       const float* __restrict__ dz, int dz_ld, int nb, int ih,
                                                       int iw, int cin, int kh, int kw, int stride, int pad_t,
                                                       int pad_l, int oh, int ow, int cout, int64_t M,
-                                                      int64_t m_per_block, float* __restrict__ dw) {
+                                                      int64_t m_per_block, const GvDw dw) {
     constexpr int PT = 32;                              // pixels per LDS tile
     __shared__ __attribute__((aligned(16))) float sX[PT][64 + 4];
     __shared__ __attribute__((aligned(16))) float sZ[PT][64 + 4];
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (ci < cin) atomicAdd(&dw[((size_t)tap * cin + ci) * cout + col], acc[r]);
+            if (ci < cin) gv_dw_put(dw, blockIdx.y, ((size_t)tap * cin + ci) * cout + col, acc[r]);
         }
     }
 }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const S* __restrict__ x, 
                                                        const S* __restrict__ dz, int dz_ld, int nb, int ih,
                                                        int iw, int cin, int kh, int kw, int stride, int pad_t,
                                                        int pad_l, int oh, int ow, int cout, int64_t M,
-                                                       int64_t m_per_block, float* __restrict__ dw) {
+                                                       int64_t m_per_block, const GvDw dw) {
     constexpr int PT = (TI * TO == 1) ? 32 : 16, BI = 64 * TI, BO = 64 * TO;   // pixels per step
     constexpr int XV = PT * BI / 4 / 256, ZV = PT * BO / 4 / 256;      // float4 loads per thread and step
     __shared__ __attribute__((aligned(16))) float sX[2][PT][BI];
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2_f32(const S* __restrict__ x, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + (wi * TI + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ci < cin) atomicAdd(&dw[((size_t)tap * cin + ci) * cout + col], acc[t][u][r]);
+                if (ci < cin) gv_dw_put(dw, logical / tiles, ((size_t)tap * cin + ci) * cout + col, acc[t][u][r]);
             }
     }
 }
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const S* __restrict
                                                              const S* __restrict__ dz, int dz_ld, int ih, int iw,
                                                              int cin, int kh, int kw, int stride, int pad_t,
                                                              int pad_l, int oh, int ow, int cout, int64_t M,
-                                                             int64_t m_per_wave, float* __restrict__ dw) {
+                                                             int64_t m_per_wave, const GvDw dw) {
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     // column tile fastest: the workgroups that share a pixel range (and re-read the same x) run side by side
     const int nct = (cout + 31) / 32;
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_f32(const S* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rho = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (rho < R) atomicAdd(&dw[(size_t)rho * cout + co], acc[t][r]);
+                if (rho < R) gv_dw_put(dw, w, (size_t)rho * cout + co, acc[t][r]);
             }
     }
 }
@@ -1128,26 +1131,28 @@ static bool wgrad_direct_ok(const gv_conv_desc* d) {
 // the fp32-MFMA filter gradient for storage type S (float; 16-bit: stems and shapes the 16-bit MFMA kernel
 // does not take)
 template <typename S>
-static int wgrad_f32mfma(const gv_conv_desc* d, const S* x, const S* dz, int32_t dz_ld, float* dw_hwio, hipStream_t st) {
+static int wgrad_f32mfma(const gv_conv_desc* d, const S* x, const S* dz, int32_t dz_ld, const GvDw& dw, hipStream_t st) {
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
     const int R = d->kh * d->kw * d->cin;
+    const size_t elems = (size_t)R * d->cout;
     if (wgrad_direct_ok(d)) {
         const int nrt = (R + 31) / 32;
-        const int64_t waves = 256 * 4 * (nrt == 1 ? 6 : (nrt <= 5 ? 2 : 1));
+        const int64_t waves = gv_dw_clamp(dw, elems, 256 * 4 * (nrt == 1 ? 6 : (nrt <= 5 ? 2 : 1)));   // (a wave is a slice)
         int64_t per = (M + waves - 1) / waves;
         per = (per + 1) / 2 * 2;
         const int64_t nw = (M + per - 1) / per;
+        const GvDw sink = gv_dw_sink(dw, elems, nw);
         const dim3 grid((unsigned)(((nw + 3) / 4) * ((d->cout + 31) / 32)));
 #define GV_WGRAD_D(NRT, U)                                                                                          \
         hipLaunchKernelGGL((conv_wgrad_direct_f32<S, NRT, U>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->ih,  \
                            d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per,  \
-                           dw_hwio)
+                           sink)
         if (nrt == 1) GV_WGRAD_D(1, 8);
         else if (nrt <= 5) GV_WGRAD_D(5, 4);
         else GV_WGRAD_D(9, 8);
 #undef GV_WGRAD_D
         GV_LAUNCH_CHECK();
-        return GV_OK;
+        return gv_dw_finish(dw, elems, nw, st);
     }
     // 128 channels on a side only where that wastes no more rows than 64-wide tiles would
     const int ti = (d->cin + 127) / 128 * 128 == (d->cin + 63) / 64 * 64 ? 2 : 1;
@@ -1158,21 +1163,23 @@ static int wgrad_f32mfma(const gv_conv_desc* d, const S* x, const S* dz, int32_t
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
+    splits = gv_dw_clamp(dw, elems, splits);
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
     const dim3 grid((unsigned)(tiles * splits));
+    const GvDw sink = gv_dw_sink(dw, elems, splits);
 #define GV_WGRAD2(TI, TO)                                                                                          \
     hipLaunchKernelGGL((conv_wgrad2_f32<S, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih,    \
                        d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per,     \
-                       dw_hwio)
+                       sink)
     if (ti == 2 && to == 2) GV_WGRAD2(2, 2);
     else if (ti == 2) GV_WGRAD2(2, 1);
     else if (to == 2) GV_WGRAD2(1, 2);
     else GV_WGRAD2(1, 1);
 #undef GV_WGRAD2
     GV_LAUNCH_CHECK();
-    return GV_OK;
+    return gv_dw_finish(dw, elems, splits, st);
 }
 
 /* tuning hook: number of launch configurations gv_conv2d_wgrad accepts in gv_conv_desc.tile_cfg for `dtype` */
@@ -1182,40 +1189,95 @@ static int g_wgrad_lp_f32 = 0;
 /* tuning hook: 16-bit storage filter gradients on the fp32 MFMA (typed loads) instead of the 16-bit MFMA kernel */
 extern "C" void gv_conv2d_wgrad_set_lp_f32(int on) { g_wgrad_lp_f32 = on; }
 
-extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld,
-                               float* dw_hwio, void* stream) {
-    if (!d || !x || !dz || !dw_hwio) return GV_E_BADARG;
+// ---- the slices of a filter gradient, added in slice order (the deterministic form: gv_common.h, GvDw) ----------------
+// dw[i] += part[0][i] + part[1][i] + ... : a workgroup owns 64 (float4) or 256 (scalar) consecutive elements and splits the
+// slices over its four waves (wave w: slices w, w + 4, ...), whose sums are added in wave order — a fixed tree, whatever
+// the dispatch order.  Reads are 1 KiB per wave-instruction, 4 in flight per lane.
+template <typename V>
+__global__ __launch_bounds__(256) void dw_reduce_slices(const V* __restrict__ part, size_t stride, int splits,
+                                                        V* __restrict__ dw, size_t n) {
+    const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + cl;
+    V s0 = {}, s1 = {};
+    if (i < n) {
+        int k = sg;
+        for (; k + 4 < splits; k += 8) {
+            const V a = part[(size_t)k * stride + i], b = part[(size_t)(k + 4) * stride + i];
+            s0 += a;
+            s1 += b;
+        }
+        if (k < splits) s0 += part[(size_t)k * stride + i];
+    }
+    __shared__ V red[4][64];
+    red[sg][cl] = s0 + s1;
+    __syncthreads();
+    if (sg == 0 && i < n) dw[i] += (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+int gv_dw_finish(const GvDw& o, size_t elems, int64_t splits, hipStream_t st) {
+    if (!o.part || splits <= 1) return GV_OK;
+    const size_t stride = (elems + 3) / 4 * 4;
+    if (splits > 0x7fffffff) return GV_E_UNSUPPORTED;
+    if (elems % 4 == 0 && gv_aligned16(o.dw) && gv_aligned16(o.part)) {
+        const size_t n = elems / 4;
+        hipLaunchKernelGGL(dw_reduce_slices<f32x4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st,
+                           (const f32x4*)o.part, stride / 4, (int)splits, (f32x4*)o.dw, n);
+    } else {
+        hipLaunchKernelGGL(dw_reduce_slices<float>, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st,
+                           (const float*)o.part, stride, (int)splits, o.dw, elems);
+    }
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+static int wgrad_dispatch(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld, const GvDw& dw,
+                          hipStream_t st) {
+    if (!d || !x || !dz || !dw.dw) return GV_E_BADARG;
     if (d->nb <= 0 || d->cin <= 0 || d->cout <= 0 || dz_ld < d->cout || d->x_ld < d->cin) return GV_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
     if (d->dtype == GV_BF16 || d->dtype == GV_F16) {
         // (the 16-bit MFMA kernel also takes the 32-channel stem layers: the direct kernel's scalar 16-bit loads
         // lose the prefetch, 7-13 ms against ~1 ms)
         if (!g_wgrad_lp_f32 && gvlp::wgrad_mfma_ok(d, x, dz, dz_ld))
-            return gvlp::conv_wgrad(d, x, dz, dz_ld, dw_hwio, st);
+            return gvlp::conv_wgrad(d, x, dz, dz_ld, dw, st);
         if (!g_wgrad_lp_f32 && d->cin <= 4) {             // the 3-channel stems: row strips on the 16-bit MFMA
-            const int rc = gvlp::conv_wgrad_stem(d, x, dz, dz_ld, dw_hwio, st);
+            const int rc = gvlp::conv_wgrad_stem(d, x, dz, dz_ld, dw, st);
             if (rc != GV_E_UNSUPPORTED) return rc;
         }
-        if (d->dtype == GV_BF16) return wgrad_f32mfma<__bf16>(d, (const __bf16*)x, (const __bf16*)dz, dz_ld, dw_hwio, st);
-        return wgrad_f32mfma<_Float16>(d, (const _Float16*)x, (const _Float16*)dz, dz_ld, dw_hwio, st);
+        if (d->dtype == GV_BF16) return wgrad_f32mfma<__bf16>(d, (const __bf16*)x, (const __bf16*)dz, dz_ld, dw, st);
+        return wgrad_f32mfma<_Float16>(d, (const _Float16*)x, (const _Float16*)dz, dz_ld, dw, st);
     }
     if (d->dtype != GV_F32) return GV_E_UNSUPPORTED;
-    if (!g_wgrad_v1) return wgrad_f32mfma<float>(d, (const float*)x, (const float*)dz, dz_ld, dw_hwio, st);
+    if (!g_wgrad_v1) return wgrad_f32mfma<float>(d, (const float*)x, (const float*)dz, dz_ld, dw, st);
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
     const int tiles = d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
     int64_t splits = (4096 + tiles - 1) / tiles;                // ~4k workgroups in flight
     const int64_t max_splits = (M + 255) / 256;                 // at least 256 pixels per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
+    splits = gv_dw_clamp(dw, elems, splits);
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
     hipLaunchKernelGGL(conv_wgrad_f32, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, (const float*)x,
                        d->x_ld, (const float*)dz, dz_ld, d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t,
-                       d->pad_l, d->oh, d->ow, d->cout, M, per, dw_hwio);
+                       d->pad_l, d->oh, d->ow, d->cout, M, per, gv_dw_sink(dw, elems, splits));
     GV_LAUNCH_CHECK();
-    return GV_OK;
+    return gv_dw_finish(dw, elems, splits, st);
+}
+
+extern "C" int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld,
+                               float* dw_hwio, void* stream) {
+    return wgrad_dispatch(d, x, dz, dz_ld, gv_dw_plain(dw_hwio), (hipStream_t)stream);
+}
+
+/* The deterministic form: pixel slices store their partial tiles into `workspace` and are added in slice order. */
+extern "C" int gv_conv2d_wgrad_ws(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld,
+                                  float* dw_hwio, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < 0 || !gv_aligned16(workspace)) return GV_E_BADARG;
+    return wgrad_dispatch(d, x, dz, dz_ld, GvDw{dw_hwio, (float*)workspace, 0, (size_t)workspace_bytes},
+                          (hipStream_t)stream);
 }
 
 // ---- storage-typed forms (16-bit training step; GV_F32 forwards to the fp32 entry points) ---------------------------

@@ -343,12 +343,12 @@ __global__ __launch_bounds__(256) void grouped_sums_v8(const E* __restrict__ z, 
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
         // the block's partial on the fixed grid of conv_stats.h: the fp64 additions are then exact, so the sums do not
         // depend on the order the blocks arrive in (bitwise reproducible run to run)
-        // (fp32 storage: grids 2^-40 / 2^-36 / 2^-60 — far below fp32 resolution; exactness then holds for smaller
-        // totals only, beyond them the additions are ordinary fp64 additions)
-        const double q0 = sizeof(E) == 4 ? (MODE == 0 ? 1099511627776.0 : 1152921504606846976.0)
-                                         : (MODE == 0 ? gvconv::STAT_Q_FWD0 : gvconv::STAT_Q_BWD);
-        const double q1 = sizeof(E) == 4 ? (MODE == 0 ? 68719476736.0 : 1152921504606846976.0)
-                                         : (MODE == 0 ? gvconv::STAT_Q_FWD1 : gvconv::STAT_Q_BWD);
+        // (fp32 storage uses the same grids, 2^-30 / 2^-24 forward and 2^-40 backward: a block's partial moves by at most
+        // half a grid step — 5e-10 on a sum of thousands of values, far below what an fp32 mean or variance resolves —
+        // and the additions stay exact up to totals of 2^23 / 2^29 / 2^13: round 3's finer grids, 2^-40 / 2^-36 / 2^-60,
+        // left exactness, and with it run-to-run reproducibility, to totals below 2^13 / 2^17 / 2^-7)
+        const double q0 = MODE == 0 ? gvconv::STAT_Q_FWD0 : gvconv::STAT_Q_BWD;
+        const double q1 = MODE == 0 ? gvconv::STAT_Q_FWD1 : gvconv::STAT_Q_BWD;
         atomicAdd(&acc[o], rint(a * q0) / q0);
         if (MODE != 2) atomicAdd(&acc[o + 1], rint(b * q1) / q1);
     }
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_lp(const unsigned short* __res
                                                      const unsigned short* __restrict__ dz, int dz_ld, int nb, int ih,
                                                      int iw, int cin, int kh, int kw, int stride, int pad_t,
                                                      int pad_l, int oh, int ow, int cout, int64_t M,
-                                                     int64_t m_per_block, float* __restrict__ dw) {
+                                                     int64_t m_per_block, const GvDw dw) {
     constexpr int PT = 32, BI = 64 * TI, BO = 64 * TO;
     constexpr int SX = 2 * BI + 64, SZ = 2 * BO + 64;                  // row strides in bytes
     constexpr int XV = PT * BI / 8 / 256, ZV = PT * BO / 8 / 256;      // 16-byte loads per thread and stage
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_lp(const unsigned short* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + (wi * TI + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ci < cin) atomicAdd(&dw[((size_t)tap * cin + ci) * cout + col], acc[t][u][r]);
+                if (ci < cin) gv_dw_put(dw, slice, ((size_t)tap * cin + ci) * cout + col, acc[t][u][r]);
             }
     }
 }
@@ -1198,7 +1198,7 @@ struct StripGeom {
 template <typename T, int WI, int WJ, int WT, int NTW>
 __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ dz, StripGeom gm,
-                                                           int taps_per_group, float* __restrict__ dw) {
+                                                           int taps_per_group, const GvDw dw) {
     static_assert(WI * WJ * WT == 4, "four waves");
     constexpr int BI = 32 * WI, BO = 32 * WJ;
     // row strides: the four rows a transposed read touches per 16-lane group must start 16 dwords apart; a 32-channel
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ci < gm.cin) atomicAdd(&dw[((size_t)tap * gm.cin + ci) * gm.cout + col], acc[i][r]);
+                if (ci < gm.cin) gv_dw_put(dw, logical / tiles, ((size_t)tap * gm.cin + ci) * gm.cout + col, acc[i][r]);
             }
         }
     }
@@ -1418,7 +1418,7 @@ inline bool strip_geom(const gv_conv_desc* d, int dz_ld, int bi, StripGeom* gm) 
 }
 
 template <typename T, int WI, int WJ, int WT, int NTW>
-int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, const GvDw& dw,
                  int target_wgs, hipStream_t st) {
     constexpr int BI = 32 * WI, BO = 32 * WJ;
     StripGeom gm;
@@ -1431,21 +1431,24 @@ int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned 
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
+    const size_t elems = (size_t)taps * d->cin * d->cout;
+    splits = gv_dw_clamp(dw, elems, splits);
     gm.stages_per_block = (int)((gm.stages + splits - 1) / splits);
     splits = (gm.stages + gm.stages_per_block - 1) / gm.stages_per_block;
     const size_t lds = (size_t)32 * (BO == 32 ? 64 : 2 * BO + 64) + (size_t)gm.xrows * (BI == 32 ? 64 : 2 * BI + 64);
     auto kern = conv_wgrad_strip_lp<T, WI, WJ, WT, NTW>;
     const bool attr = GV_BIG_LDS_OK(kern, 64 * 1024);
     (void)attr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, x, dz, gm, tpg, dw);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, x, dz, gm, tpg,
+                       gv_dw_sink(dw, elems, splits));
     GV_LAUNCH_CHECK();
-    return GV_OK;
+    return gv_dw_finish(dw, elems, splits, st);
 }
 
 int g_strip_ntw = 5;     // taps per workgroup of the general strip variant: 5 keeps two waves per SIMD (9: one)
 
 template <typename T>
-int strip_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+int strip_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, const GvDw& dw,
             int target_wgs, hipStream_t st) {
     if (d->cin <= 32 && d->cout <= 32) return strip_launch<T, 1, 1, 4, 3>(d, x, dz, dz_ld, dw, target_wgs, st);
     if (d->cin <= 32) return strip_launch<T, 1, 2, 2, 5>(d, x, dz, dz_ld, dw, target_wgs, st);
@@ -1458,7 +1461,7 @@ int strip_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
 int g_strip_default = 1;
 
 template <typename T>
-int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, const GvDw& dw,
             hipStream_t st) {
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
     // side width 64 / 128 / 192 channels (TI, TO = 1..3): the widest that pads no more channels than 64-wide tiles
@@ -1501,13 +1504,16 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    splits = gv_dw_clamp(dw, elems, splits);
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
     const dim3 grid((unsigned)(tiles * splits));
+    const GvDw sink = gv_dw_sink(dw, elems, splits);
 #define GV_WGRAD_LP(TI, TO)                                                                                          \
     hipLaunchKernelGGL((conv_wgrad_lp<T, TI, TO>), grid, dim3(256), 0, st, x, d->x_ld, dz, dz_ld, d->nb, d->ih, d->iw, \
-                       d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, dw)
+                       d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, M, per, sink)
     switch (ti * 10 + to) {
         case 11: GV_WGRAD_LP(1, 1); break;
         case 12: GV_WGRAD_LP(1, 2); break;
@@ -1521,7 +1527,7 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     }
 #undef GV_WGRAD_LP
     GV_LAUNCH_CHECK();
-    return GV_OK;
+    return gv_dw_finish(dw, elems, splits, st);
 }
 
 
@@ -1542,7 +1548,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned sh
                                                                const unsigned short* __restrict__ dz, int dz_ld, int nb,
                                                                int ih, int iw, int cin, int kh, int kw, int stride,
                                                                int pad_t, int pad_l, int oh, int ow, int cout, int xrow_b,
-                                                               int zrows, int units_per_wave, float* __restrict__ dw) {
+                                                               int zrows, int units_per_wave, const GvDw dw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     const int ZB = NCT * 64;                                       // bytes of one dZ pixel row in LDS
@@ -1672,7 +1678,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned sh
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += red[(w * NRT * NCT + tc) * 1024 + e];
-            atomicAdd(&dw[(size_t)rho * cout + co], v);
+            gv_dw_put(dw, blockIdx.x, (size_t)rho * cout + co, v);
         }
     }
 }
@@ -1680,7 +1686,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned sh
 // the stems this kernel takes: 3 input channels stored densely (x_ld == cin), stride 2, <= 64 output channels, rows that
 // fit the per-lane staging registers; 0 on success, GV_E_UNSUPPORTED otherwise
 template <typename T>
-int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, float* dw,
+int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, const GvDw& dw,
                     hipStream_t st) {
     const int R = d->kh * d->kw * d->cin;
     const int nrt = (R + 31) / 32, nct = (d->cout + 31) / 32;
@@ -1706,18 +1712,25 @@ int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsign
     int64_t waves = 256 * 3 * 4;                                   // three workgroups per CU
     int64_t per = (units + waves - 1) / waves;
     if (per < 4) per = 4;
-    const int64_t nwg = ((units + per - 1) / per + 3) / 4;
+    int64_t nwg = ((units + per - 1) / per + 3) / 4;
+    const size_t elems = (size_t)R * d->cout;
+    if (gv_dw_clamp(dw, elems, nwg) < nwg) {                      // fewer workgroups (slices) than wanted: what the workspace holds
+        nwg = gv_dw_clamp(dw, elems, nwg);
+        per = (units + 4 * nwg - 1) / (4 * nwg);
+        nwg = ((units + per - 1) / per + 3) / 4;
+    }
+    const GvDw sink = gv_dw_sink(dw, elems, nwg);
 #define GV_WSTEM(NRT, NCT)                                                                                           \
     hipLaunchKernelGGL((conv_wgrad_stem_rows_lp<T, NRT, NCT>), dim3((unsigned)nwg), dim3(256), lds, st, x, dz, dz_ld,     \
                        d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout,   \
-                       xrow_b, zrows, (int)per, dw)
+                       xrow_b, zrows, (int)per, sink)
     if (nrt == 1 && nct == 1) GV_WSTEM(1, 1);
     else if (nrt == 1) GV_WSTEM(1, 2);
     else if (nct == 1) GV_WSTEM(5, 1);
     else GV_WSTEM(5, 2);
 #undef GV_WSTEM
     GV_LAUNCH_CHECK();
-    return GV_OK;
+    return gv_dw_finish(dw, elems, nwg, st);
 }
 
 }  // namespace
@@ -2015,12 +2028,12 @@ bool wgrad_mfma_ok(const gv_conv_desc* d, const void* x, const void* dz, int dz_
            gv_aligned16(dz);
 }
 
-int conv_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st) {
+int conv_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, hipStream_t st) {
     GV_LP_DISPATCH(d->dtype, return wgrad_t<T>(d, (const unsigned short*)x, (const unsigned short*)dz, dz_ld, dw, st));
 }
 
 // the 3-channel stems on the 16-bit MFMA (conv_wgrad_stem_rows_lp); GV_E_UNSUPPORTED: not such a layer
-int conv_wgrad_stem(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, hipStream_t st) {
+int conv_wgrad_stem(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, hipStream_t st) {
     GV_LP_DISPATCH(d->dtype, return wgrad_stem_rows<T>(d, (const unsigned short*)x, (const unsigned short*)dz, dz_ld, dw, st));
 }
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ void wwait_vm() {
 struct WgradGeo {
     const unsigned short* x;
     const unsigned short* dz;
-    float* dw;
+    GvDw dw;
     const void* zeros;
     int x_ld, dz_ld, nb, ih, iw, cin, kh, kw, stride, pad_t, pad_l, oh, ow, cout;
     int M, m_per_block;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = ci0 + (wi * TI + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ci < g.cin) atomicAdd(&g.dw[((size_t)tap * g.cin + ci) * g.cout + col], acc[t][u][r]);
+                if (ci < g.cin) gv_dw_put(g.dw, slice, ((size_t)tap * g.cin + ci) * g.cout + col, acc[t][u][r]);
             }
     }
 }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
 unsigned wmagic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 template <typename T, int TI, int TO, int ST>
-int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, int64_t target,
+int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, int64_t target,
                      hipStream_t st) {
     constexpr int BI = 64 * TI, BO = 64 * TO;
     const int64_t M = (int64_t)d->nb * d->oh * d->ow;
@@ -261,7 +261,6 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
     WgradGeo g;
     g.x = (const unsigned short*)x;
     g.dz = (const unsigned short*)dz;
-    g.dw = dw;
     g.zeros = gvconv::dma_zero_page();
     if (!g.zeros) return GV_E_UNSUPPORTED;
     g.x_ld = d->x_ld; g.dz_ld = dz_ld; g.nb = d->nb; g.ih = d->ih; g.iw = d->iw; g.cin = d->cin; g.kh = d->kh; g.kw = d->kw;
@@ -274,11 +273,14 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
     const int64_t max_splits = (M + 511) / 512;                  // at least 512 pixels per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    splits = gv_dw_clamp(dw, elems, splits);
     int64_t per = (M + splits - 1) / splits;
     per = (per + 31) / 32 * 32;
     splits = (M + per - 1) / per;
     if ((int64_t)tiles * splits > 0x7fffffff) return GV_E_UNSUPPORTED;
     g.m_per_block = (int)per;
+    g.dw = gv_dw_sink(dw, elems, splits);
     const size_t lds = (size_t)ST * 32 * 2 * (BI + BO);
     auto kern = &conv_wgrad_dma<T, TI, TO, ST>;
     if (lds > 64 * 1024) {
@@ -286,7 +288,7 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, g);
     GV_LAUNCH_CHECK();
-    return GV_OK;
+    return gv_dw_finish(dw, elems, splits, st);
 }
 
 }  // namespace
@@ -301,7 +303,7 @@ namespace gvlp {
 // 1x7 / 7x1 pairs, Mixed_7a) did 16/9 of its work, loads and instructions included.
 int wgrad_dma_num_cfgs() { return 34; }
 
-int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, float* dw, int k, hipStream_t st) {
+int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, int k, hipStream_t st) {
     if (k < 0 || k >= 34) return GV_E_BADARG;
     if (k >= 24) {
         const int q = (k - 24) % 5;

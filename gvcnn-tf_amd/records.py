@@ -396,17 +396,26 @@ class ViewBatcher:
         yield views0, label0
 
         def take(slot, res):
-            shape, label = res.get()
+            shape, label = res.get(timeout=300)                       # (a worker that died — e.g. SIGBUS on a full /dev/shm — raises here)
             return np.ndarray(shape, np.uint8, buffer=self._shm.buf, offset=slot * nbytes).copy(), label   # slot free again
         slot = 0
-        for rec in records:
-            if len(pending) >= window:                             # the slot about to be reused must have been read out
+        try:
+            for rec in records:
+                if len(pending) >= window:                         # the slot about to be reused must have been read out
+                    yield take(*pending.popleft())
+                pending.append((slot, self._pool.apply_async(_decode_record_into, (rec, self.V, self._shm.name,
+                                                                                  slot * nbytes, nbytes))))
+                slot = (slot + 1) % window
+            while pending:
                 yield take(*pending.popleft())
-            pending.append((slot, self._pool.apply_async(_decode_record_into, (rec, self.V, self._shm.name, slot * nbytes,
-                                                                              nbytes))))
-            slot = (slot + 1) % window
-        while pending:
-            yield take(*pending.popleft())
+        finally:
+            # an abandoned iteration: the tasks still in flight write into shared-memory slots the next __iter__ hands out
+            # again from slot 0 — wait for them (bounded: a dead worker must not block the caller forever)
+            for _, res in pending:
+                try:
+                    res.wait(60)
+                except Exception:
+                    pass
 
     def _shapes(self):
         """(views uint8 [V, h0, w0, 3], label) per record, through the shuffle buffer."""
@@ -434,12 +443,20 @@ class ViewBatcher:
             shape = (self.N, self.V, h0, w0, 3)
             if getattr(self, "_pin", None) is None or tuple(self._pin[0].shape) != shape:
                 self._pin, self._pin_k = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)], 0
+                self._pin_ev = [None, None]
             stage = self._pin[self._pin_k]
-            self._pin_k ^= 1
+            # the host may only write into a staging buffer once the asynchronous copy that last read it has finished
+            # (a consumer that does not synchronise every step lets the decode pool run two batches ahead of the stream)
+            if self._pin_ev[self._pin_k] is not None:
+                self._pin_ev[self._pin_k].synchronize()
             view = stage.numpy()
             for i, im in enumerate(imgs):
                 view[i] = im
             src = stage.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._pin_ev[self._pin_k] = ev
+            self._pin_k ^= 1
         else:
             src = torch.from_numpy(np.stack(imgs)).to(self.device)       # [N, V, h0, w0, 3] uint8
         dst = torch.empty((self.N, self.V, self.H, self.W, 3), dtype=torch.float32, device=self.device)

@@ -13,6 +13,7 @@ import torch
 # entry point -> family of the training step
 FAMILY = {
     "gv_conv2d_fwd": "conv", "gv_conv2d_fwd_xpre": "conv", "gv_conv2d_fwd_bnstats": "conv", "gv_conv2d_wgrad": "wgrad",
+    "gv_conv2d_wgrad_ws": "wgrad",
     "gv_conv2d_dgrad_s2": "conv",
     "gv_bn_sums_grouped_t": "bn", "gv_bn_finalize_apply_grouped_t": "bn", "gv_bn_relu_bwd_sums_grouped_t": "bn",
     "gv_bn_relu_bwd_apply_grouped_t": "bn", "gv_bn_finalize_t": "bn", "gv_bn_bwd_finalize_t": "bn",

@@ -148,12 +148,19 @@ class TrainGVCNN:
                  num_classes=40, num_group=10, backbone_params=None, head_params=None, device=None,
                  raw_tap=None, final_tap=None, num_bins=10, pool="max", empty_fill=1.0, math="bf16x3", seed=2,
                  head_views=None, view_offset=0, per_shape=False, weight_mode="count", storage="f32",
-                 fuse_siblings=True, frozen_bn=False):
+                 fuse_siblings=True, frozen_bn=False, deterministic=True, dw_workspace_mb=256):
         """head_views / view_offset: view-sharded data parallelism (sharding.ShardedTrainGVCNN) — this engine
         runs the backbone for views [view_offset, view_offset + num_views) of the head_views views of every shape
         (so each view's BatchNorm statistics stay on one rank, exactly the reference's per-view statistics),
         while the grouping head works on all head_views views."""
         self.lib = _lib.load()
+        # deterministic: every filter gradient through gv_conv2d_wgrad_ws — pixel slices store their partial images of dW
+        # into one workspace shared by all layers and are added in slice order, so two runs of a step give the same bits
+        # (the reference's CPU gradients are deterministic, utils/train_utils.py:217-259; False: fp32 atomics, A/B).
+        # The workspace is re-used layer after layer, which keeps it in the 256 MiB Infinity Cache.
+        self.deterministic = bool(deterministic)
+        self._dw_ws_bytes = int(dw_workspace_mb) << 20
+        self._dw_ws = None
         # storage: element type of activations and activation gradients in HBM.  "bf16" is BASELINE configs[2]
         # (bf16 forward + backward): 16-bit MFMA convolutions (forward, data and filter gradient), fp32 master
         # weights / parameter gradients / optimizer state, fp64 batch statistics.
@@ -565,6 +572,15 @@ class TrainGVCNN:
             lst.append((t.off, t.c, ev, lane, self._ev_next))
             self._ready[(kind, t.vbuf)] = lst
 
+    def _wgrad(self, d, x_ptr, dz_ptr, dz_ld, dw_ptr):
+        """One filter-gradient launch (plus, deterministic, the launch that adds its slices in order)."""
+        if not self.deterministic:
+            return self.lib.gv_conv2d_wgrad(C.byref(d), x_ptr, dz_ptr, dz_ld, dw_ptr, _st())
+        if self._dw_ws is None:
+            self._dw_ws = torch.empty(self._dw_ws_bytes, dtype=torch.uint8, device=self.device)
+        return self.lib.gv_conv2d_wgrad_ws(C.byref(d), x_ptr, dz_ptr, dz_ld, dw_ptr, self._dw_ws.data_ptr(),
+                                           self._dw_ws.numel(), _st())
+
     def _members(self, op):
         """[(variable name, first column, columns)] of a convolution: one entry, or the members of a fused sibling GEMM."""
         return op.get("members") or [(op["name"] + "/weights", 0, op["y"].c)]
@@ -779,12 +795,12 @@ class TrainGVCNN:
                 for t in range(nw + 1):
                     op["tile_w"] = t
                     d = self._conv_desc(op, wgrad=True)
-                    args = (C.byref(d), self._ptr(x), self._ptr(y, True), y.ld, dw.data_ptr(), _st())
-                    if lib.gv_conv2d_wgrad(*args) != 0:
+                    args = (d, self._ptr(x), self._ptr(y, True), y.ld, dw.data_ptr())
+                    if self._wgrad(*args) != 0:
                         continue
                     e0.record()
                     for _ in range(iters):
-                        lib.gv_conv2d_wgrad(*args)
+                        self._wgrad(*args)
                     e1.record()
                     e1.synchronize()
                     if e0.elapsed_time(e1) < best_ms:
@@ -1223,8 +1239,7 @@ class TrainGVCNN:
                 _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
                            "res grad")
             d = self._conv_desc(op, wgrad=True)
-            _lib.check(lib.gv_conv2d_wgrad(C.byref(d), self._ptr(x), dz, y.ld, self._dw(op).data_ptr(), _st()),
-                       "wgrad " + op["name"])
+            _lib.check(self._wgrad(d, self._ptr(x), dz, y.ld, self._dw(op).data_ptr()), "wgrad " + op["name"])
             # (a fused sibling GEMM: its gradient block IS the members' gradients, column by column)
             if x.vbuf >= 0:
                 dd = self._conv_desc(op, dgrad=True)

@@ -378,6 +378,14 @@ int gv_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t c, double
  * x and dz in d->dtype (GV_F32: exact fp32 MFMA; GV_BF16 / GV_F16: 16-bit MFMA, fp32 accumulation); dW is fp32. */
 int gv_conv2d_wgrad(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld, float* dw_hwio,
                     void* stream);
+/* The same gradient, bitwise reproducible (the reference's CPU gradients are: utils/train_utils.py:217-259; the plain
+ * form combines its pixel slices with fp32 atomics, whose arrival order decides the last bits).  Every pixel slice
+ * STORES its partial image of dW into `workspace` (caller-owned device memory, 16-byte aligned, workspace_bytes long;
+ * contents are scratch) and one more launch adds the slices into dw_hwio in slice order.  The number of slices is
+ * limited to the images the workspace holds (workspace_bytes / (4 * kh*kw*cin*cout)); with room for fewer than two the
+ * launch runs un-split.  Same descriptor, same tile_cfg values, same result up to fp32 summation order. */
+int gv_conv2d_wgrad_ws(const gv_conv_desc* d, const void* x, const void* dz, int32_t dz_ld, float* dw_hwio,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 /* Pool backward (descriptor of the forward pool): max -> first maximum of each window (tf MaxPoolGrad),
  * avg -> dy / #valid taps.  x is the forward input (max only).  x, dy, dx in d->dtype. */
 int gv_pool2d_bwd(const gv_pool_desc* d, const void* x, const void* dy, int32_t dy_ld, void* dx,

@@ -110,6 +110,10 @@ def view_score(raw_descriptor, kernel, bias):
 
     raw_descriptor [N,h,w,Cr]; kernel [Cr,1] / [Cr]; bias scalar.
     r_n = GAP(raw)[n] . k + b ; r = mean_n r_n ; score = sigmoid(log(|r|)).
+
+    The dot product and the batch mean are accumulated in fp64 and rounded to fp32 once; TensorFlow's Dense / reduce_mean
+    accumulate in fp32 in an unspecified order.  The two differ by a few fp32 ulps of r — far inside the path's 1e-3
+    tolerance and irrelevant to the binning tests, which feed identical fp32 scores (SURVEY hard part (v)).
     """
     gap = global_average_pool(raw_descriptor).astype(np.float64)
     r_n = gap @ np.asarray(kernel, dtype=np.float64).reshape(-1) + float(bias)
@@ -126,7 +130,8 @@ def score_from_r(r):
 
 
 def dense(x, kernel, bias):
-    """tf.keras.layers.Dense(C) (model.py:164): x[N,F] @ kernel[F,C] + bias[C]."""
+    """tf.keras.layers.Dense(C) (model.py:164): x[N,F] @ kernel[F,C] + bias[C].  (fp64 accumulation, one rounding to
+    fp32: TF accumulates in fp32 — a difference of fp32 ulps, inside the path's tolerance.)"""
     y = np.asarray(x, dtype=np.float64) @ np.asarray(kernel, dtype=np.float64)
     return (y + np.asarray(bias, dtype=np.float64)).astype(F32)
 

@@ -3,8 +3,9 @@
 The reference gets fused batch norm from slim (nets/inception_utils.py:52-62, nets/resnet_utils.py:230) with one
 graph copy — one set of batch statistics — per view (nets/model.py:129-141).  The separate passes
 (gv_bn_sums_grouped_t, gv_bn_relu_bwd_sums_grouped_t) are pinned to the oracle's autograd in test_gpu_train_lp.py; here
-the fused forms are held against them on the SAME stored tensors (so only the summation order differs), against the
-oracle directly, and shown bitwise reproducible run to run."""
+the fused forms are held against them on the SAME stored tensors (so only the summation order differs), against an
+fp64 recount of the stored tensors, and shown bitwise reproducible run to run.  (Product against product: this file is
+collected AFTER the oracle-parity files, tests/conftest.py.)"""
 import ctypes as C
 
 import numpy as np
@@ -15,7 +16,6 @@ pytestmark = pytest.mark.gpu
 
 from gvcnn_tf_amd import _lib                       # noqa: E402
 from gvcnn_tf_amd.training import TrainGVCNN        # noqa: E402
-from oracle import backbone as OB                   # noqa: E402
 
 DEV = "cuda:0"
 TYPES = {"bf16": (_lib.GV_BF16, torch.bfloat16), "f16": (_lib.GV_F16, torch.float16)}
