@@ -21,7 +21,7 @@ GV_POOL_Y_P3 = 0x400
 GV_ACCUM_ZEROED = 0x100
 GV_ACCUM_RAW_Z = 0x200
 GV_BN_STATS_FWD, GV_BN_STATS_BWD, GV_BN_STATS_MAX_SEG = 1, 2, 8
-GV_E_UNSUPPORTED = -2
+GV_OK, GV_E_BADARG, GV_E_UNSUPPORTED, GV_E_ALIGN, GV_E_PLAN = 0, -1, -2, -3, -4
 GV_VIEWPOOL_MAX, GV_VIEWPOOL_MEAN = 0, 1
 GV_ORDER_SHAPE_MAJOR, GV_ORDER_VIEW_MAJOR = 0, 1
 GV_WEIGHT_COUNT, GV_WEIGHT_MEAN_SCORE = 0, 1

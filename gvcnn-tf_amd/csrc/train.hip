@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void grouped_sums_f32(const float* __restrict_
         double a = 0.0, b = 0.0;
         for (int q = 0; q < PL; ++q) { a += red[0][q][threadIdx.x]; b += red[1][q][threadIdx.x]; }
         const size_t o = ((size_t)g * c + blockIdx.x * 64 + threadIdx.x) * 2;
-        // the block's partial on the fixed grids of conv_stats.h (2^-30 / 2^-24 forward, 2^-40 backward): exact fp64
-        // additions, so the totals do not depend on the order the blocks arrive in
-        const double q0 = MODE == 0 ? 1073741824.0 : 1099511627776.0, q1 = MODE == 0 ? 16777216.0 : 1099511627776.0;
+        // the block's partial on fixed grids (2^-40 / 2^-36 forward, 2^-52 backward: grouped_sums_v8 in train_lp.hip says
+        // why): exact fp64 additions within their range, so the totals do not depend on the order the blocks arrive in
+        const double q0 = MODE == 0 ? 1099511627776.0 : 4503599627370496.0, q1 = MODE == 0 ? 68719476736.0 : 4503599627370496.0;
         atomicAdd(&acc[o], rint(a * q0) / q0);
         if (MODE != 2) atomicAdd(&acc[o + 1], rint(b * q1) / q1);
     }

@@ -1342,6 +1342,33 @@ class TrainGVCNN:
         _lib.check(self.lib.gv_bn_update_moving_batched(jd.data_ptr(), nj, bj.data_ptr(), bj.numel(), self.V,
                                                         float(decay), _st()), "bn_update_moving_batched")
 
+    def recalibrate_moving_averages(self, batches):
+        """Replace every BatchNorm's moving statistics by the AVERAGE of the per-view batch statistics of `batches`
+        (an iterable of view tensors [N, V, H, W, 3]) under the current variables: forward only, nothing is trained.
+        This is what the V sequential moving-average updates per step (update_moving_averages, train.py:178-186) converge
+        to once the variables stand still — the reference gets there by its arg-scope decay of 0.9997 over tens of
+        thousands of steps.  After a SHORT run (or with a small decay) the moving statistics are an exponential window
+        over the last few, noisy steps of a still-moving network, the last view's weighted most; eval-mode accuracy then
+        swings between runs although the train-mode network classifies well (tools/convergence_diag.py,
+        tests/test_gpu_convergence.py).  Not a call the reference has; a checkpoint written after it is an ordinary one."""
+        bns = [op for op in self.plan.ops if op["kind"] == "bn"]
+        m_sum = [torch.zeros(op["x"].c, dtype=torch.float64, device=self.device) for op in bns]
+        v_sum = [torch.zeros(op["x"].c, dtype=torch.float64, device=self.device) for op in bns]
+        n = 0
+        for views in batches:
+            self.forward_backbone(views)
+            for i, op in enumerate(bns):
+                cnt = self.N * op["x"].h * op["x"].w * self.shape_world
+                m_sum[i] += op["stat"]["mean"].double().mean(0)
+                v_sum[i] += op["stat"]["var"].double().mean(0) * (cnt / max(cnt - 1, 1))   # the unbiased estimate, as the update
+            n += 1
+        if n == 0:
+            raise ValueError("recalibrate_moving_averages needs at least one batch")
+        for i, op in enumerate(bns):
+            self.params[op["name"] + "/moving_mean"].copy_((m_sum[i] / n).float())
+            self.params[op["name"] + "/moving_variance"].copy_((v_sum[i] / n).float())
+        return n
+
     def train_step(self, views, labels, lr=1e-3, mu=0.9, weight_decay=0.0, update_moving=True):
         self.forward(views, labels, check=False)
         self.backward()

@@ -33,11 +33,13 @@ def head(stacked, scheme, weight, Wc, bc, labels):
 
 
 def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num_bins=10,
-                   raw_tap=None, final_tap=None, frozen_bn=False):
+                   raw_tap=None, final_tap=None, frozen_bn=False, scheme=None, weight=None):
     """inputs [N,V,H,W,3] float32, labels [N] int64.  Returns dict(loss, grads{name: tensor}, scores, scheme,
     weight, logits, shape_descriptor).  frozen_bn: BatchNorm with the moving statistics (slim's is_training=False
     arithmetic, inception_utils.py / resnet_utils.py arg scopes) while autograd still differentiates every variable — not a
-    mode the reference trains in; the well-conditioned form of the same graph used to hold the assembled backward pass."""
+    mode the reference trains in; the well-conditioned form of the same graph used to hold the assembled backward pass.
+    scheme / weight: fed instead of derived from this call's own scores — they are placeholders of the backward pass in the
+    reference too (train.py:127-128, 277-288), so a sub-batch can be differentiated under the scheme of the batch it came from."""
     n_views = inputs.shape[1]
     raw_tap = raw_tap or M.TAPS[backbone][0]
     final_tap = final_tap or M.TAPS[backbone][1]
@@ -55,8 +57,11 @@ def loss_and_grads(inputs, labels, P, H, num_group, backbone="resnet_v2_50", num
         scores.append(np.float32(s))
         ep[final_tap].retain_grad()
         finals.append(ep[final_tap])
-    scheme = G.group_scheme([np.array(scores, dtype=np.float32)], num_group, n_views, num_bins)
-    weight = G.group_weight(scheme)
+    if scheme is None:
+        scheme = G.group_scheme([np.array(scores, dtype=np.float32)], num_group, n_views, num_bins)
+        weight = G.group_weight(scheme)
+    else:
+        scheme, weight = np.asarray(scheme), np.asarray(weight, dtype=np.float32)
     stacked = torch.stack(finals, dim=0)                                   # [V,N,h,w,C]
     loss, logits, S = head(stacked, scheme, weight, Wc, bc, labels)
     loss.backward()

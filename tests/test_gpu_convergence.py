@@ -5,22 +5,35 @@ The whole-step comparisons of test_gpu_train_lp.py can only be loose: on a rando
 train-mode BatchNorm any perturbation grows from layer to layer, so one bf16 step and one fp32 step have nearly
 unrelated total gradients (cosine 0.05 at the c3 geometry) although every op agrees with the oracle.  What matters is
 whether that is harmless.  Here both engines start from the SAME initialisation and run the same 150 Momentum steps on
-a synthetic, learnable multi-view stream (class- and view-dependent mean image + noise, a fresh batch every step, at a
-learning rate where both runs are smooth: at 4x the rate both oscillate and differ run to run); then the trained
-variables are bound to the inference engine (moving-average BatchNorm, the `forward` path of eval.py) and held-out
-shapes are classified.
+a synthetic, learnable multi-view stream (class- and view-dependent mean image + noise, a fresh batch every step);
+then the trained variables are bound to the inference engine (moving-average BatchNorm, the `forward` path of
+eval.py) and 128 held-out shapes are classified.
 
-Stated bands (measured values are printed; the per-batch loss of 8 fresh shapes is noisy — 0.02 ... 1.2 in the last
-steps of converged runs — and the filter gradients are summed with fp32 atomics, so two runs of the SAME engine
-differ; the bands are set for that):
-  * both losses (mean of the last 30 steps) fall below 50 % of their starting level (mean of the first 10; measured:
-    5 - 25 %);
-  * the bf16 run's final loss is at most 3x the fp32 run's + a quarter of its own starting level (the last-30-step mean
-    of a converged ResNet run is anywhere in 0.0000 ... 0.70 — it spikes — so a fixed + 0.5 failed once in ~25 runs);
-  * eval-mode accuracy on 128 held-out shapes: chance is 1/C = 0.25 (sigma 0.04 on 128 shapes), both runs reach >= 0.35
-    (measured over ~20 runs: Inception 0.48 - 1.00 for EITHER storage type — two runs of the same engine differ by up
-    to 0.5 — ResNet 0.8 - 1.0), and bf16 is at most 0.4 below fp32 (a band of 0.25 failed once in ~10 runs on exactly that spread:
-    fp32 0.96, bf16 0.69, the next run 0.70 / 0.80 the other way round).
+Round 3's version of this test failed on the driver's box (fp32 run: loss 2.21 -> 0.09, eval-mode accuracy 0.24 =
+chance).  What tools/convergence_diag.py found (gpurun_out of round 4, profiles/r4_convergence_diag.txt):
+  * no batch was dropped by the IndexError branch (it is counted and asserted zero now);
+  * the SAME trained variables classify the held-out shapes at 0.91 - 0.97 with train-mode BatchNorm (per-view batch
+    statistics): the network had learned, the kernels and the inference binding were right (at 128 x 128 input and for
+    ResNet the eval-mode engine reached 1.000 with the same code);
+  * the eval-mode number swung 0.51 - 1.00 between runs of one engine, for either storage type, because (a) the filter
+    gradients were summed with fp32 atomics (two runs differed in the last bits, amplified chaotically over 150 steps),
+    (b) at 96 x 96 input Mixed_7's maps are 1 x 1, so a view's batch statistics are taken over 8 values, and (c) the
+    moving averages at decay 0.9 are a window over the last ~10 such steps with the last of the V sequential updates
+    weighted most — they do not describe the trained network.
+Fixed since: (a) training is bitwise reproducible (gv_conv2d_wgrad_ws, tests/test_gpu_wgrad_det.py) and this test
+asserts it over the whole run; (b) Inception runs at 128 x 128 (2 x 2 maps in Mixed_7: 32 values per statistic);
+(c) the eval-mode check follows a recalibration pass (TrainGVCNN.recalibrate_moving_averages: forward only, fixed
+variables, 16 fresh batches) — the stand-in for the reference's decay of 0.9997 over tens of thousands of steps.
+
+Bands (measured over 8 initialisation / data seeds per backbone and storage type on two boxes; the test's own seed is
+fixed and its run deterministic, so the driver's box computes the very numbers this box did):
+  * both losses (mean of the last 30 steps) fall below 50 % of their starting level (mean of the first 10; measured
+    0.1 - 37 %: the per-batch loss of 8 fresh shapes is noisy);
+  * recalibrated eval-mode accuracy on 128 held-out shapes >= 0.75 for both storage types (chance 0.25; measured
+    0.938 - 1.000 over 16 Inception and 12 ResNet runs; one sigma of a 128-shape accuracy near 0.95 is 0.02: the floor
+    sits 9 sigma below the worst run seen), and bf16 at most 0.15 below fp32;
+  * the accuracy with train-mode BatchNorm on the held-out batches >= 0.75 (measured 0.805 - 1.000);
+  * the plain moving averages are reported, not asserted (measured 0.70 - 1.00 for Inception, 1.00 for ResNet).
 """
 import numpy as np
 import pytest
@@ -51,21 +64,8 @@ def prototypes(C, V, S, seed=7):
     return (0.3 * p).to(DEV)
 
 
-def run(backbone, S, storage, steps, lr, bn_decay):
-    C, V, N, G = 4, 4, 8, 5
-    protos = prototypes(C, V, S)
-    test_x, test_y = make_set(128, V, S, C, 12, protos)
-    eng = TrainGVCNN(backbone, N, V, S, S, C, G, device=DEV, num_bins=G, storage=storage, seed=5)
-    losses = []
-    for it in range(steps):
-        xb, yb = make_set(N, V, S, C, 1000 + it, protos)     # a fresh batch every step: nothing to memorise
-        eng.forward(xb, yb, check=False)
-        eng.backward()
-        eng.update_moving_averages(decay=bn_decay)      # (the arg-scope decay 0.997 / 0.9997 needs thousands of steps)
-        eng.apply_momentum(lr, 0.9, 1e-4)
-        losses.append(float(eng.loss))
-    assert all(np.isfinite(losses)), "non-finite loss"
-    # the trained variables on the inference path: BatchNorm from the moving averages, scheme from the device scorer
+def bind_inference(eng, backbone, N, V, S, C, G, storage):
+    """The trained variables on the inference path: BatchNorm from the moving statistics, scheme from the device scorer."""
     inf = gv.GVCNN(backbone, N, V, S, S, C, G, device=DEV, num_bins=G, storage=storage)
     inf.plan.bind({k: v.detach().float().cpu() for k, v in eng.params.items() if k not in eng.cls_names})
     H = {}
@@ -74,27 +74,72 @@ def run(backbone, S, storage, steps, lr, bn_decay):
         H[kn], H[bn] = eng.score_kernel[v].cpu().reshape(-1, 1), eng.score_bias[v:v + 1].cpu()
     H[eng.cls_names[0]], H[eng.cls_names[1]] = eng.params[eng.cls_names[0]].cpu(), eng.params[eng.cls_names[1]].cpu()
     inf.set_head(H)
-    correct = 0
+    return inf
+
+
+def eval_accuracy(inf, test_x, test_y, N):
+    correct, dropped = 0, 0
     for b in range(0, test_x.shape[0], N):
         try:
             _, _, logits = inf.forward(test_x[b:b + N].contiguous())
         except IndexError:                              # a score of exactly 1.0: the reference raises here too
+            dropped += 1
             continue
         correct += int((logits.argmax(1) == test_y[b:b + N]).sum())
-    return losses, correct / test_x.shape[0]
+    return correct / test_x.shape[0], dropped
 
 
-@pytest.mark.parametrize("backbone,S,steps,lr", [("resnet_v2_50", 64, 150, 0.004), ("inception_v3", 96, 150, 0.005)])
+def train(backbone, S, storage, steps, lr, bn_decay, protos, C, V, N, G):
+    eng = TrainGVCNN(backbone, N, V, S, S, C, G, device=DEV, num_bins=G, storage=storage, seed=5)
+    losses = []
+    for it in range(steps):
+        xb, yb = make_set(N, V, S, C, 1000 + it, protos)     # a fresh batch every step: nothing to memorise
+        eng.forward(xb, yb, check=False)
+        eng.backward()
+        eng.update_moving_averages(decay=bn_decay)      # (the arg-scope decay 0.997 / 0.9997 needs thousands of steps)
+        eng.apply_momentum(lr, 0.9, 1e-4)
+        losses.append(eng.loss.clone())
+    return eng, torch.cat(losses)
+
+
+def run(backbone, S, storage, steps, lr, bn_decay, check_repeat=False):
+    C, V, N, G = 4, 4, 8, 5
+    protos = prototypes(C, V, S)
+    test_x, test_y = make_set(128, V, S, C, 12, protos)
+    eng, losses_t = train(backbone, S, storage, steps, lr, bn_decay, protos, C, V, N, G)
+    assert bool(torch.isfinite(losses_t).all()), "non-finite loss"
+    if check_repeat:                                    # the whole run again: the same bits, step by step
+        eng2, losses2 = train(backbone, S, storage, steps, lr, bn_decay, protos, C, V, N, G)
+        assert torch.equal(losses_t, losses2), "two runs of the same engine differ from step %d on" % int(
+            (losses_t != losses2).nonzero()[0])
+        assert torch.equal(eng._flat_p, eng2._flat_p)
+        del eng2
+    losses = losses_t.cpu().numpy()
+    acc_moving, dropped = eval_accuracy(bind_inference(eng, backbone, N, V, S, C, G, storage), test_x, test_y, N)
+    # the held-out shapes with train-mode BatchNorm (per-view batch statistics, what the training loss measures)
+    correct = 0
+    for b in range(0, test_x.shape[0], N):
+        _, _, logits, _ = eng.forward(test_x[b:b + N].contiguous(), test_y[b:b + N], check=False)
+        correct += int((logits.argmax(1) == test_y[b:b + N]).sum())
+    acc_train_mode = correct / test_x.shape[0]
+    # recalibration on 16 fresh batches (not the held-out ones), then the eval-mode engine again
+    eng.recalibrate_moving_averages(make_set(N, V, S, C, 5000 + k, protos)[0] for k in range(16))
+    acc_recal, dropped2 = eval_accuracy(bind_inference(eng, backbone, N, V, S, C, G, storage), test_x, test_y, N)
+    return dict(first=float(np.mean(losses[:10])), last=float(np.mean(losses[-30:])), moving=acc_moving,
+                train_mode=acc_train_mode, recal=acc_recal, dropped=dropped + dropped2)
+
+
+@pytest.mark.parametrize("backbone,S,steps,lr", [("resnet_v2_50", 64, 150, 0.004), ("inception_v3", 128, 150, 0.005)])
 def test_bf16_run_trains_like_the_fp32_run(backbone, S, steps, lr):
     out = {}
     for storage in ("f32", "bf16"):
-        losses, acc = run(backbone, S, storage, steps, lr, bn_decay=0.9)
-        first, last = float(np.mean(losses[:10])), float(np.mean(losses[-30:]))
-        out[storage] = (first, last, acc)
-        print("%s %s: loss %.4f -> %.4f, eval-mode accuracy on held-out shapes %.3f" % (backbone, storage, first, last, acc))
-    for storage, (first, last, acc) in out.items():
-        assert last < 0.5 * first, "%s: loss %.4f -> %.4f" % (storage, first, last)
-        assert acc >= 0.35, "%s: eval-mode accuracy %.3f (chance 0.25)" % (storage, acc)
-    f32, b16 = out["f32"], out["bf16"]
-    assert b16[1] <= 3.0 * f32[1] + 0.25 * b16[0], (f32, b16)
-    assert b16[2] >= f32[2] - 0.4, (f32, b16)
+        r = out[storage] = run(backbone, S, storage, steps, lr, bn_decay=0.9, check_repeat=(storage == "bf16"))
+        print("%s %s: loss %.4f -> %.4f; held-out accuracy: train-mode BatchNorm %.3f, moving averages %.3f, recalibrated "
+              "%.3f (batches dropped by IndexError: %d)" % (backbone, storage, r["first"], r["last"], r["train_mode"],
+                                                            r["moving"], r["recal"], r["dropped"]))
+    for storage, r in out.items():
+        assert r["dropped"] == 0, "%s: %d evaluation batches raised IndexError" % (storage, r["dropped"])
+        assert r["last"] < 0.5 * r["first"], "%s: loss %.4f -> %.4f" % (storage, r["first"], r["last"])
+        assert r["train_mode"] >= 0.75, "%s: accuracy with train-mode BatchNorm %.3f (chance 0.25)" % (storage, r["train_mode"])
+        assert r["recal"] >= 0.75, "%s: recalibrated eval-mode accuracy %.3f (chance 0.25)" % (storage, r["recal"])
+    assert out["bf16"]["recal"] >= out["f32"]["recal"] - 0.15, out

@@ -9,7 +9,7 @@
   * the eval-mode accuracy after a recalibration pass (forward only, fixed variables, K held-out batches, the moving
     statistics REPLACED by the mean of the per-view batch statistics, i.e. what V sequential updates converge to).
 
-usage: python tools/convergence_diag.py [backbone] [S] [storage] [runs] [N]
+usage: python tools/convergence_diag.py [backbone] [S] [storage] [runs] [N] [seed0]
 """
 import os
 import sys
@@ -58,15 +58,17 @@ def main():
     storage = sys.argv[3] if len(sys.argv) > 3 else "f32"
     runs = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     N = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+    seed0 = int(sys.argv[6]) if len(sys.argv) > 6 else None      # given: run r uses engine seed seed0 + r (training is
+                                                                 # deterministic now, so repeated runs of ONE seed are equal)
     steps, lr, decay = 150, 0.005 if backbone == "inception_v3" else 0.004, 0.9
     C, V, G = 4, 4, 5
     protos = prototypes(C, V, S)
     test_x, test_y = make_set(128, V, S, C, 12, protos)
     for r in range(runs):
-        eng = TrainGVCNN(backbone, N, V, S, S, C, G, device=DEV, num_bins=G, storage=storage, seed=5)
+        eng = TrainGVCNN(backbone, N, V, S, S, C, G, device=DEV, num_bins=G, storage=storage, seed=5 if seed0 is None else seed0 + r)
         losses = []
         for it in range(steps):
-            xb, yb = make_set(N, V, S, C, 1000 + it, protos)
+            xb, yb = make_set(N, V, S, C, 1000 + it + (0 if seed0 is None else 7919 * (seed0 + r)), protos)
             eng.forward(xb, yb, check=False)
             eng.backward()
             eng.update_moving_averages(decay=decay)
