@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--preset", default="c2", choices=sorted(PRESETS), help="c2 = BASELINE.json configs[1] (the bench line)")
     ap.add_argument("--no-lanes", action="store_true", help="single-stream launch order (no branch concurrency)")
+    ap.add_argument("--no-tune", action="store_true",
+                    help="skip the per-launch tile measurement (default tiles): control-flow checks of the N > 1 path, never a "
+                         "line to quote")
     ap.add_argument("--p3", default="default", choices=["default", "all", "none"],
                     help="bf16x3 math: conv -> conv intermediates stored as three bf16 planes (value neutral; A/B switch)")
     ap.add_argument("--math", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16x1"],
@@ -602,6 +605,8 @@ def main():
     # table written by an earlier run so that a profiled run contains no tuning launches
     if a.tile_cache and os.path.exists(a.tile_cache):
         eng.plan.apply_tiles(json.load(open(a.tile_cache)))
+    elif a.no_tune:
+        pass
     else:
         chosen = eng.plan.autotune(x.view(N * V, H, W, 3))
         if a.tile_cache and rank == 0:
@@ -707,6 +712,8 @@ def main():
         out["config"]["math"] = a.math + ": " + MATH[a.math][2]
         out["config"]["branch_lanes"] = eng.plan.lanes_used if not a.no_lanes else 1
         out["config"]["launch"] = "hipGraph replay" if a.graph else "eager"
+        if a.no_tune:
+            out["config"]["tiles"] = "default (--no-tune: a control-flow check, not a line to quote)"
 
         if world == 1 and a.math != "f32" and not a.no_exact:
             # the same step on the exact fp32 MFMA path, for reference (short run, same inputs)

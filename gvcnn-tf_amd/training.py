@@ -371,6 +371,7 @@ class TrainGVCNN:
         # that writes the FINAL dy (16-bit storage; False: the separate sums passes, kept for A/B and tests)
         self.fuse_bn_stats = self.es == 2
         self.fuse_bn_pool = self.es == 2                  # BatchNorm -> max pool pairs of the stem as pool -> BatchNorm (A/B)
+        self.alias_residual_grad = True                   # residual fan-in: the shortcut's gradient shares dy's buffer (False: copy; A/B)
         self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
         self.s2_concurrent = False                        # ... their four launches side by side on extra streams: measured
                                                           # 15.66 k against 15.89 k views/s in sequence (fork / join cost more
@@ -608,6 +609,12 @@ class TrainGVCNN:
             if o <= pos < o + c:
                 pos = o + c
         return pos >= t.off + t.c
+
+    def _can_alias_grad(self, r, y):
+        """May the gradient of r share the buffer of the gradient of y (same geometry, each alone in its buffer)?"""
+        return (self.alias_residual_grad and self._lazy and self._lane_streams is None and r.vbuf >= 0 and
+                r.vbuf != y.vbuf and (r.nb, r.h, r.w, r.c) == (y.nb, y.h, y.w, y.c) and r.off == 0 and y.off == 0 and
+                r.ld == r.c and y.ld == y.c and self.act[r.vbuf].numel() == self.act[y.vbuf].numel())
 
     def _zero_grad_of(self, t):
         self._ptr(t, grad=True)
@@ -1233,11 +1240,23 @@ class TrainGVCNN:
                 _lib.check(lib.gv_bias_grad_t(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
                                               self.grads[op["bias"]].data_ptr(), self.dt, _st()), "bias_grad")
             if op["res"] is not None:
+                # y = conv(x) + r: the gradient of r receives dy.  Where this op is the FIRST contributor to it (always, in
+                # ResNet-v2: a unit's conv3 is the last reader of its shortcut), the gradient of r simply IS dy's buffer
+                # from here on — nothing reads dy after this op, and the later contributions (the unit's pre-activation,
+                # the subsampling pool, the shortcut convolution's own backward) add to / read it in place.  Otherwise
+                # (or with the A/B switch off) dy is added into r's own buffer: 16 copy passes of 100 - 800 MB per step.
                 r = op["res"]
-                if self._claim(r):
-                    self._zero_grad_of(r)
-                _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
-                           "res grad")
+                first = self._claim(r)
+                if first and self._can_alias_grad(r, y):
+                    self._ptr(y, True)
+                    self.grad[r.vbuf] = self.grad[y.vbuf]
+                else:
+                    if self.grad[r.vbuf] is not None and self.grad[r.vbuf] is self.grad[y.vbuf]:
+                        self.grad[r.vbuf] = None                  # (aliased by an earlier pass: its own buffer again)
+                    if first:
+                        self._zero_grad_of(r)
+                    _lib.check(lib.gv_accumulate_t(dz, y.ld, self._ptr(r, True), r.ld, y.npix, y.c, self.dt, _st()),
+                               "res grad")
             d = self._conv_desc(op, wgrad=True)
             _lib.check(self._wgrad(d, self._ptr(x), dz, y.ld, self._dw(op).data_ptr()), "wgrad " + op["name"])
             # (a fused sibling GEMM: its gradient block IS the members' gradients, column by column)

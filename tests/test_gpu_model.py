@@ -276,6 +276,37 @@ def test_bench_two_rank_control_flow_on_one_device():
     assert j["other_exchange"]["exchange"] == "scores" and j["other_exchange"]["value"] > 0
 
 
+@pytest.mark.parametrize("preset,V,hw,esz", [("c4", 12, 7, 2), ("c5", 20, 8, 2)])
+def test_bench_eight_rank_control_flow_of_the_8gpu_configs(preset, V, hw, esz):
+    """BASELINE.json configs[3] / configs[4] as the driver's scaling run types them, `python bench.py --gpus 8`, at their
+    per-GPU share (4 shapes = 48 / 80 views per rank): eight self-launched ranks over a gloo group on cuda:0 (control
+    flow only: RCCL needs eight devices).  The line must carry what the ranks saw (world size 8), weak scaling over
+    8 x 4 shapes, the exchange volume of the north_star form — every rank sends its scorer responses and final
+    descriptors: 9.6 MB (c4) / 21 MB (c5) — and both ways of moving it (one collective, point-to-point sends)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--same-device", "--preset",
+           preset, "--steps", "1", "--warmup", "1", "--shapes", "4", "--no-roofline", "--no-tune", "--no-lanes"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["world_size"] == 8 and j["scaling"] == "weak"
+    assert j["config"]["views_per_gpu"] == 4 * V and j["config"]["global_views"] == 8 * 4 * V and j["value"] > 0
+    sent = 4 * V * 4 + 4 * V * hw * hw * 2048 * esz
+    assert j["config"]["exchange"] == "allgather"
+    assert j["config"]["exchange_bytes_per_step"] == {"sent_per_rank": sent, "received_per_rank": 7 * sent}
+    assert abs(sent - (9.6e6 if preset == "c4" else 21e6)) < 0.05 * sent          # SURVEY §8e's message sizes
+    assert j["other_exchange"]["exchange"] == "scores" and j["other_exchange"]["value"] > 0
+    assert j["config"]["gather"].startswith("collective") and j["other_gather"]["gather"] == "direct"
+    assert j["other_gather"]["value"] > 0
+
+
 def test_bench_external_launcher_form_still_works():
     """The other form the contract names: the driver's own `python -m torch.distributed.run ... bench.py --gpus N`."""
     import json

@@ -160,3 +160,26 @@ def test_training_steps_are_bitwise_reproducible(backbone, S, storage):
         assert torch.equal(u, v), "%s %s: %s differ between two runs (max |d| %.3e)" % (
             backbone, storage, name, float((u - v).abs().max()))
     assert bool(torch.isfinite(a[3]).all())
+
+
+@pytest.mark.parametrize("storage", ["bf16", "f32"])
+def test_residual_gradient_aliasing_is_bitwise_neutral(storage):
+    """ResNet-v2's `shortcut + residual` (nets/resnet_v2.py:91) sends dy to both addends.  TrainGVCNN lets the shortcut's
+    gradient SHARE dy's buffer where the unit's conv3 is its first contributor (alias_residual_grad) instead of copying
+    dy into a buffer of its own: 0 + dy is exact, so every gradient must keep its bits."""
+    N, V, S, C_, G = 3, 2, 96, 5, 5
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.rand(N, V, S, S, 3, generator=g, device=DEV) - 0.5
+    y = torch.randint(0, C_, (N,), generator=g, device=DEV)
+    outs = []
+    for alias in (True, False):
+        eng = TrainGVCNN("resnet_v2_50", N, V, S, S, C_, G, device=DEV, num_bins=G, storage=storage, seed=3)
+        eng.alias_residual_grad = alias
+        for _ in range(2):                                  # (the second pass re-uses whatever the first one aliased)
+            eng.forward(x, y, check=False)
+            eng.backward()
+        outs.append(eng._flat_g.clone())
+        shared = sum(1 for op in eng.plan.ops if op["kind"] == "conv" and op.get("res") is not None and
+                     eng.grad[op["res"].vbuf] is eng.grad[op["y"].vbuf])
+        assert shared == (16 if alias else 0)               # every unit of the four blocks
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
