@@ -329,7 +329,7 @@ def measure_traffic(a, tiles_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-TRAIN_FAMILIES = (("wgrad", ("conv_wgrad",)), ("conv", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma")),
+TRAIN_FAMILIES = (("wgrad", ("conv_wgrad", "dw_reduce_slices")), ("conv", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma")),
                   ("bn", ("grouped_sums", "bn_stream", "scale_shift_act_grouped", "bn_bwd_apply")),
                   ("pool", ("pool2d", "maxpool", "avgpool3x3")))
 

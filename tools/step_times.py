@@ -61,7 +61,7 @@ for name in order:
     if name in kdim:                                      # GEMM depth, launch configurations (fwd, dgrad, wgrad) and the
         gf = 2.0 * npix * c * kdim[name] * 1e-9           # rate of each of the three GEMMs (all launches of a pass summed)
         tf = lambda ls: gf / max(sum(ms for fn, ms in ls if fn.startswith("fwd")), 1e-9)
-        tw = gf / max(sum(ms for fn, ms in r["bwd"] if fn == "wgrad"), 1e-9)
+        tw = gf / max(sum(ms for fn, ms in r["bwd"] if fn in ("wgrad", "wgrad_ws")), 1e-9)
         extra = " | K=%d cfg=%s TF/s fwd %.0f dgrad %.0f wgrad %.0f" % (kdim[name], tiles[name], tf(r["fwd"]), tf(r["bwd"]), tw)
     print("%-58s %-5s M=%8d c=%4d | fwd: %s | bwd: %s%s" % (name[-58:], r["kind"], npix, c, f, b, extra))
 fam = steptime.by_family(avg)
