@@ -139,6 +139,23 @@ def roofline(eng, x, math, iters=10, traffic=None):
             worst = (op["name"], ms, tf)
     achieved = flops / (t_ms * 1e-3) / 1e12
     kname, peak, how = MATH[math]
+    # the same ratio per STAGE of the backbone (north_star asks for the conv stages; SURVEY hard part (i): the Cin = 3 /
+    # 32-channel stem is HBM-bound by construction, the 5x5 maps of Mixed_7 are tiny-M GEMMs): algorithmic FLOPs of the
+    # stage's conv launches over their in-sequence time, and how much of that time the stage's HBM-bound launches take
+    stages = {}
+    for i, op in enumerate(plan.ops):
+        if op["kind"] != "conv":
+            continue
+        sname = stage_of(op["name"])
+        d = stages.setdefault(sname, {"flops": 0.0, "ms": 0.0, "launches": 0, "hbm_ms": 0.0})
+        d["flops"] += op["flops"]
+        d["ms"] += each[i]
+        d["launches"] += 1
+        if op["bytes"] / HBM_PEAK > op["flops"] / (peak * 1e12):
+            d["hbm_ms"] += each[i]
+    per_stage = {k: {"frac": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / peak, 4),
+                     "achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1), "ms": round(d["ms"], 3),
+                     "launches": d["launches"], "hbm_bound_ms": round(d["hbm_ms"], 3)} for k, d in stages.items()}
     # per-launch ceiling: a launch can finish no sooner than its FLOPs at the MFMA peak or its algorithmic bytes at the
     # HBM peak, whichever is later; `attainable` is the step's FLOPs over the sum of those times (== peak when no launch
     # is HBM-bound: ResNet's 64-channel 1x1 layers are, and cap the whole step well below the MFMA peak)
@@ -157,7 +174,20 @@ def roofline(eng, x, math, iters=10, traffic=None):
             "algorithmic_bytes_per_launch": round(alg_bytes),
             "flops_per_step": flops, "avg_launch_us": round(t_ms * 1e3 / n, 2),
             "conv_ms_per_step": round(t_ms, 3),
+            "stages": per_stage,
             "longest_launch": {"name": worst[0], "ms": round(worst[1], 4), "tflops": round(worst[2], 2)}}
+
+
+def stage_of(op_name):
+    """Backbone stage of a conv launch: Inception-v3's stem (Conv2d_1a .. 4a), Mixed_5 (35x35-equivalent maps), Mixed_6
+    (17x17-equivalent, Mixed_6a's reduction included), Mixed_7 (8x8-equivalent); ResNet-v2-50's conv1 and blocks 1 - 4."""
+    first = op_name.split("+")[0]                            # (a fused sibling GEMM: its first member's name)
+    parts = first.split("/")
+    if len(parts) > 1 and parts[0] == "InceptionV3":
+        return parts[1][:7] if parts[1].startswith("Mixed_") else "stem"
+    if len(parts) > 1 and parts[0] == "resnet_v2_50":
+        return parts[1] if parts[1].startswith("block") else "stem"
+    return parts[0]
 
 
 def cpu_model():
@@ -714,6 +744,9 @@ def main():
         out["config"]["launch"] = "hipGraph replay" if a.graph else "eager"
         if a.no_tune:
             out["config"]["tiles"] = "default (--no-tune: a control-flow check, not a line to quote)"
+        elif getattr(eng.plan, "autotune_moved", None) is not None:
+            out["config"]["tiles"] = ("measured per launch: warm repeats shortlist four, timed in sequence the launch keeps "
+                                      "the fastest (%d launches left their warm-repeat choice)" % eng.plan.autotune_moved)
 
         if world == 1 and a.math != "f32" and not a.no_exact:
             # the same step on the exact fp32 MFMA path, for reference (short run, same inputs)

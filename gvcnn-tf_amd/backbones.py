@@ -553,15 +553,25 @@ class BackbonePlan:
                 op["tile"] = int(table[op["name"]]) + 1
                 _lib.check(self.lib.gv_plan_set_conv_tile(self._plan, i, op["tile"]), "gv_plan_set_conv_tile")
 
-    def autotune(self, x, iters=3, verbose=False):
+    def autotune(self, x, iters=3, verbose=False, in_sequence=4):
         """Pick, per conv launch, the fastest tile configuration by timing each on this device with
         the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
-        chain sums k in the same order under every configuration, so results are bitwise unchanged."""
+        chain sums k in the same order under every configuration, so results are bitwise unchanged.
+
+        Two passes.  (1) Every configuration of every launch as a WARM REPEAT of itself (gv_plan_time): cheap, but a
+        repeated launch finds its input and its filter in the XCD's L2, which the launch inside the network does not —
+        there the input was just written by another kernel and comes from the Infinity Cache or HBM, and a tile whose
+        short ring is the fastest on L2 hits (two stages, three workgroups per CU) can lose to a deeper one.  Isolated
+        repeats of the Mixed_6 layers run at 600 - 830 TFLOP/s, the same launches in sequence at 400 - 550
+        (profiles/r3_conv_probe_bf16.txt against r3_step_times_*).  So (2) the `in_sequence` best configurations of pass 1
+        are timed IN SEQUENCE (gv_plan_time_each: an event pair behind every op over whole passes of the plan; round r
+        gives every launch its r-th candidate) and each launch keeps the candidate that was fastest where it actually
+        runs.  in_sequence <= 1: pass 1 only (round 3's behaviour)."""
         lib = self.lib
         ncfg_plan = lib.gv_conv2d_num_tile_cfgs(self.math_mode if self.dtype == _lib.GV_F32 else -1)   # -1: 16-bit storage
         ncfg_p3 = lib.gv_conv2d_num_tile_cfgs(-3)             # three-plane input: the LDS-DMA kernel's own table
         self.run(x)
-        chosen = {}
+        chosen, cands = {}, {}
         try:
             for i, op in enumerate(self.ops):
                 if op["kind"] != "conv":
@@ -582,11 +592,34 @@ class BackbonePlan:
                 best_ms, best = min(finals) if finals else (float("inf"), 0)
                 op["tile"] = best + 1
                 chosen[op["name"]] = (best, best_ms)
+                order = [best] + [t for _, t in sorted(timed) if t != best]
+                cands[i] = order[:max(int(in_sequence), 1)]
                 _lib.check(lib.gv_plan_set_conv_tile(self._plan, i, best + 1), "gv_plan_set_conv_tile")
                 if verbose:
                     print("autotune %-60s cfg %2d  %.4f ms" % (op["name"][-60:], best, best_ms))
         finally:
             lib.gv_conv2d_set_tile_override(-1)
+        if int(in_sequence) > 1 and cands:
+            seq = {i: {} for i in cands}                          # op -> {tile: in-sequence ms}
+            for r in range(int(in_sequence)):
+                for i, c in cands.items():
+                    _lib.check(lib.gv_plan_set_conv_tile(self._plan, i, c[min(r, len(c) - 1)] + 1), "gv_plan_set_conv_tile")
+                each = [min(a, b) for a, b in zip(self.time_each(x, 2 * iters), self.time_each(x, 2 * iters))]
+                for i, c in cands.items():
+                    t = c[min(r, len(c) - 1)]
+                    seq[i][t] = min(each[i], seq[i].get(t, float("inf")))
+            moved = 0
+            for i, c in cands.items():
+                op = self.ops[i]
+                best = min(c, key=lambda t: (seq[i][t], c.index(t)))
+                moved += best != c[0]
+                op["tile"] = best + 1
+                chosen[op["name"]] = (best, seq[i][best])
+                _lib.check(lib.gv_plan_set_conv_tile(self._plan, i, best + 1), "gv_plan_set_conv_tile")
+                if verbose:
+                    print("in sequence %-57s cfg %2d  %.4f ms  (warm-repeat choice cfg %2d: %.4f ms in sequence)"
+                          % (op["name"][-57:], best, seq[i][best], c[0], seq[i][c[0]]))
+            self.autotune_moved = moved                           # launches whose in-sequence winner is not the warm-repeat one
         return chosen
 
     def time_range(self, x, first, count, iters, stream=None):

@@ -370,6 +370,7 @@ class TrainGVCNN:
         # sums of z in the convolution's epilogue, the backward sums of dy in the epilogue of the data-gradient launch
         # that writes the FINAL dy (16-bit storage; False: the separate sums passes, kept for A/B and tests)
         self.fuse_bn_stats = self.es == 2
+        self.fuse_bn_stats_res = True                     # ... also where the producing convolution adds a residual (ResNet conv3; A/B)
         self.fuse_bn_pool = self.es == 2                  # BatchNorm -> max pool pairs of the stem as pool -> BatchNorm (A/B)
         self.alias_residual_grad = True                   # residual fan-in: the shortcut's gradient shares dy's buffer (False: copy; A/B)
         self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
@@ -405,7 +406,7 @@ class TrainGVCNN:
                 continue
             # forward: the producer of b.x
             for c in ops[:bi]:
-                if c["kind"] == "conv" and b["x"].vbuf >= 0 and inside(b["x"], c["y"]) and c.get("res") is None:
+                if c["kind"] == "conv" and b["x"].vbuf >= 0 and inside(b["x"], c["y"]) and (c.get("res") is None or self.fuse_bn_stats_res):
                     c.setdefault("st_f", []).append(b)
                     b["fused_f"] = c
             # backward: the first reader of b.y among the ops that run in the backward pass
@@ -967,9 +968,10 @@ class TrainGVCNN:
             op["_st_f_done"] = False
             xin = self._x32.data_ptr() + 4 * x.off if (x.vbuf < 0 and self.es == 2) else self._ptr(x)
             if op.get("st_f") and zeroed and self._fusing() and not op.get("_nofuse_f"):   # the BatchNorm sums of z in this launch's epilogue
+                # (a ResNet unit's conv3: the sums are those of shortcut + residual, the tensor the next pre-activation reads)
                 rc = lib.gv_conv2d_fwd_bnstats(C.byref(d), xin, op["w_fwd"].data_ptr(), self.ones.data_ptr(),
-                                               shift.data_ptr(), None, self._ptr(y), C.byref(self._bn_stats(op, "st_f")),
-                                               _st())
+                                               shift.data_ptr(), self._ptr(res) if res is not None else None, self._ptr(y),
+                                               C.byref(self._bn_stats(op, "st_f")), _st())
                 if rc != _lib.GV_E_UNSUPPORTED:               # (unsupported tile / geometry: the plain launch below)
                     _lib.check(rc, "conv + BN sums " + op["name"])
                     op["_st_f_done"] = True

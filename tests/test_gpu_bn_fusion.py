@@ -248,8 +248,8 @@ def test_engine_with_folded_sums_reproduces_the_separate_passes(backbone, size, 
     """The whole bf16 training step with the sums folded into the producing launches against the same engine running the
     separate sums passes (the form pinned to the oracle in test_gpu_train_lp.py): same loss, same statistics to
     summation order, gradients within the rounding the two forms may differ by; and every BatchNorm sum of the folded
-    step — forward and backward, hence every activation and activation gradient — is bitwise reproducible run to run
-    (the FILTER gradients are not: their pixel slices are combined with fp32 atomics)."""
+    step — forward and backward, hence every activation and activation gradient — and, since the filter gradients add
+    their pixel slices in slice order (gv_conv2d_wgrad_ws), EVERY gradient is bitwise reproducible run to run."""
     N, V = 4, 3
     g = torch.Generator().manual_seed(0)
     x = (torch.rand(N, V, size, size, 3, generator=g) - 0.5).to(DEV)
@@ -271,8 +271,7 @@ def test_engine_with_folded_sums_reproduces_the_separate_passes(backbone, size, 
             a = res[True]
             assert out["loss"] == a["loss"], "the folded step is not reproducible"
             assert torch.equal(out["accf"], a["accf"]) and torch.equal(out["accb"], a["accb"])
-            nw = eng._n_wd                                   # beta / gamma gradients come from the sums alone
-            assert torch.equal(out["flat"][nw:], a["flat"][nw:])
+            assert torch.equal(out["flat"], a["flat"])
         res[fuse] = out
     a, b = res[False], res[True]
     assert a["nf"] == 0 and a["nb"] == 0

@@ -682,6 +682,9 @@ def test_first_writer_stores_equal_zero_fill_and_accumulate(backbone, size, N, V
     eng.fuse_bn_stats = False
     eng.fuse_bn_pool = False                              # (the pool -> BatchNorm pairs never materialise the BN output this test
                                                           # compares buffer by buffer: tests/test_gpu_bn_pool.py covers them)
+    eng.alias_residual_grad = False                       # (a ResNet shortcut's gradient otherwise LIVES in dy's buffer, which then
+                                                          # holds another tensor's gradient at the end of the pass; that form has
+                                                          # its own bit-for-bit test in tests/test_gpu_wgrad_det.py)
     x = (torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5).to(DEV)
     labels = torch.tensor([1, 4, 2, 0][:N])
     eng.forward(x, labels, check=False)

@@ -28,6 +28,7 @@ eng = TrainGVCNN(a.backbone, a.shapes, a.views, a.size, a.size, 40, 7, device=de
 for kv in filter(None, a.set.split(",")):
     k, v = kv.split("=")
     setattr(eng, k, type(getattr(eng, k))(int(v)))
+eng._plan_bn_fusion()                                     # (the fusion switches are read when the plan is laid out)
 x = (torch.rand(a.shapes, a.views, a.size, a.size, 3, device=dev) - 0.5)
 labels = torch.randint(0, 40, (a.shapes,), device=dev)
 eng.train_step(x, labels, lr=1e-6)
