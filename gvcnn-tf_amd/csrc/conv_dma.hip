@@ -29,13 +29,24 @@
 
 namespace {
 
-template <int NP> struct DmaGeom {
-    static constexpr int KT = NP == 1 ? 32 : 16;       // k-tile depth
+// KTX: k-tile depth of the 16-bit form (0 = the default below).  KT = 64 makes an LDS row 128 bytes = ONE cache line of
+// the source tensor per row and k-tile: a DMA instruction then fetches 8 whole lines instead of 16 half lines (the
+// second half of each is fetched a whole tap sweep later, long after the line left the 32 KiB L1) — the programming
+// guide prices half-line, fragment-shaped staging loads at +18 ... 45 % with the vector-memory path twice as busy for
+// the same L2 / HBM traffic.  Needs cin % 64 == 0 (whole 64-channel chunks inside one filter tap).
+template <int NP, int KTX = 0> struct DmaGeom {
+    static constexpr int KT = KTX ? KTX : (NP == 1 ? 32 : 16);       // k-tile depth
     static constexpr int RBYTES = KT * 2;               // one plane of one LDS row
     static constexpr int RPI = 1024 / RBYTES;           // rows per DMA instruction
     static constexpr int CPR = RBYTES / 16;             // 16-byte chunks per row
     static constexpr int G16 = NP * 32;                 // bytes of one 16-value group in global memory (all planes)
     static constexpr int KSTEPS = KT / 16;              // MFMA k-steps per k-tile
+    // XOR swizzle of a row's 16-byte chunks (applied to the SOURCE address by the loader, to the read address by the
+    // fragment reads): 32-byte rows (r >> 3) & 1, 64-byte rows (r >> 2) & 3, 128-byte rows (r >> 1) & 7 — with the last, the
+    // 16 rows of every ds_read_b128 service group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper-half twins)
+    // land on 16 distinct 4-bank groups: 8 distinct chunks among the even rows, the same 8 among the odd rows, and a
+    // row's parity selects the half of the 256-byte bank row.
+    __host__ __device__ static constexpr int swz(int r) { return CPR == 8 ? ((r >> 1) & 7) : (CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1)); }
 };
 
 __device__ __forceinline__ void dma16(const char* gsrc, char* lds_dst) {
@@ -57,34 +68,34 @@ __host__ __device__ constexpr int dprod_pb(int np, int t) { return np == 3 ? (t 
 // EPI: 0 = 16-bit output through the LDS-staged epilogue (conv_lp_epi.h); 1 = fp32 output straight from the accumulators
 // (conv_common.h); 2 = fp32 or three-plane (P3) output through the staged epilogue of conv_x3_epi.h
 // byte offset of the epilogue's scale / shift table: behind the ring and the per-wave staging blocks (which alias the ring)
-template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int KTX = 0>
 constexpr int dma_ss_off() {
-    constexpr int ring = ST * NP * (WM * TM * 32 + WN * TN * 32) * DmaGeom<NP>::RBYTES;
+    constexpr int ring = ST * NP * (WM * TM * 32 + WN * TN * 32) * DmaGeom<NP, KTX>::RBYTES;
     constexpr int epi = EPI == 1 ? 0 : WM * WN * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
     return ((ring > epi ? ring : epi) + 15) / 16 * 16;
 }
 // ... unless the table's bytes would cost a resident workgroup (128 x 192 on four 16-bit stages is exactly half a CU's LDS)
-template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int KTX = 0>
 constexpr bool dma_use_ss() {
-    constexpr int base = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>(), with = base + 16 * WN * TN * 32, cu = 160 * 1024;
+    constexpr int base = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI, KTX>(), with = base + 16 * WN * TN * 32, cu = 160 * 1024;
     return EPI != 1 && cu / base == cu / with;
 }
 
 // ... in which case the table is published LATE into the ring the main loop has freed, behind the waves' staging blocks
 // (where it fits there: the 128 x 128 tile on two stages stages exactly a ring's worth)
-template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int KTX = 0>
 constexpr int dma_late_off() { return WM * WN * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES); }
-template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+template <int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int KTX = 0>
 constexpr bool dma_late_ss() {
-    constexpr int ring = ST * NP * (WM * TM * 32 + WN * TN * 32) * DmaGeom<NP>::RBYTES;
-    return EPI != 1 && !dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() &&
-           dma_late_off<NP, WM, WN, TM, TN, ST, EPI>() + 16 * WN * TN * 32 <= ring;
+    constexpr int ring = ST * NP * (WM * TM * 32 + WN * TN * 32) * DmaGeom<NP, KTX>::RBYTES;
+    return EPI != 1 && !dma_use_ss<NP, WM, WN, TM, TN, ST, EPI, KTX>() &&
+           dma_late_off<NP, WM, WN, TM, TN, ST, EPI, KTX>() + 16 * WN * TN * 32 <= ring;
 }
 
 // STATS (16-bit output only): train-mode BatchNorm sums of the stored tensor folded into the epilogue (conv_stats.h).
-template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int STATS = 0>
+template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int STATS = 0, int KTX = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
-    using G = DmaGeom<NP>;
+    using G = DmaGeom<NP, KTX>;
     constexpr int NW = WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int KT = G::KT, RBYTES = G::RBYTES, RPI = G::RPI, CPR = G::CPR, G16 = G::G16, KS = G::KSTEPS;
@@ -116,14 +127,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     // epilogue as 16-byte LDS reads.  Loaded from global memory inside the epilogue they cost every read-back block of
     // every tile one exposed memory round trip (16 - 32 scalar loads issued and awaited between the last MFMA and the
     // first store), which the short-K HBM-bound launches (ResNet conv3: K = 64) cannot hide behind anything.
-    constexpr int SS_OFF = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>();
+    constexpr int SS_OFF = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI, KTX>();
     static_assert(WM * WN * 64 >= WN * TN * 32, "one thread per tile column");
-    constexpr bool USE_SS = dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>();
+    constexpr bool USE_SS = dma_use_ss<NP, WM, WN, TM, TN, ST, EPI, KTX>();
     // ... in which case the table is published LATE, into the ring the main loop has freed (behind the waves' staging
     // blocks): the values wait in four registers meanwhile.  (Without a table every lane of the epilogue fetches its 16
     // constants per column block from global memory — 48 loads and ~250 address instructions per wave of a 128 x 192 tile.)
-    constexpr bool LATE_SS = dma_late_ss<NP, WM, WN, TM, TN, ST, EPI>();
-    constexpr int LATE_OFF = dma_late_off<NP, WM, WN, TM, TN, ST, EPI>();
+    constexpr bool LATE_SS = dma_late_ss<NP, WM, WN, TM, TN, ST, EPI, KTX>();
+    constexpr int LATE_OFF = dma_late_off<NP, WM, WN, TM, TN, ST, EPI, KTX>();
     constexpr bool ANY_SS = USE_SS || LATE_SS;
     float* sstab = ANY_SS && !(a.dbg & 512) ? reinterpret_cast<float*>(smem + (LATE_SS ? LATE_OFF : SS_OFF)) : nullptr;   // dbg 512: constants from global (A/B)
     float ss_v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -162,8 +173,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
     // ---- loader state -------------------------------------------------------------------------------------------
     const int lrow = lane / CPR;                                   // row inside a row block
     const int pc = lane % CPR;                                     // physical chunk this lane's 16 bytes land in
-    const int lc = pc ^ (CPR == 4 ? ((lrow >> 2) & 3) : ((lrow >> 3) & 1));   // logical chunk it must fetch
+    // logical chunk it must fetch: pc ^ swz(row).  Rows of a block are RPI-aligned, so only 128-byte rows (RPI = 8, swizzle
+    // bits 1..3 of the row) see the block's index: odd row blocks flip chunk bit 2 = byte 64 of the source offset
+    // (x_flip / b_flip below; a wave's blocks wave, wave + NW, ... share their parity while NW is even)
+    const int lc = pc ^ G::swz(lrow);
     const int chunk_byte = (lc >> 1) * G16 + (lc & 1) * 16;        // inside one k-tile of a row (KT = 32: two groups)
+    constexpr bool RB_SWZ = CPR == 8;
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* zero_page = reinterpret_cast<const char*>(a.zeros);
     const unsigned pix_bytes = (unsigned)a.x_ld * 2u * NP;         // one pixel of the input tensor
@@ -171,11 +186,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
 
     int a_img[UAW], a_iy0[UAW], a_ix0[UAW];
     int a_rb[UAW];
+    int a_flip[RB_SWZ ? UAW : 1];                                   // 128-byte rows: 64 where the row block is odd
 #pragma unroll
     for (int i = 0; i < UAW; ++i) {
         int rb = wave + i * NW;
         rb = rb < UA ? rb : UA - 1;                                // surplus slots re-load the last block (same bytes)
         a_rb[i] = rb;
+        if constexpr (RB_SWZ) a_flip[i] = (rb & 1) ? 64 : 0;
         int m = m0 + rb * RPI + lrow;
         m = m < a.M ? m : a.M - 1;                                 // rows past M: results never stored
         const int n = gv_div(m, a.y_div_img);
@@ -201,8 +218,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
             const int ix = ixn >> a.dil_shift;
             const bool ok = iyn >= 0 && ixn >= 0 && ((iyn | ixn) & dmask) == 0 && iy < a.ih && ix < a.iw && fr < a.kh;
             a_ok[i] = ok;
+            // (odd row blocks of 128-byte rows fetch the chunk 32 channels away inside the same 64-channel group: cin % 64 == 0)
+            const int fce = RB_SWZ ? (fc ^ (a_flip[i] >> 1)) : fc;
             const size_t off = (size_t)((unsigned)(a_img[i] + iy) * (unsigned)a.iw + (unsigned)ix) * pix_bytes +
-                               (size_t)((fc >> 4) * G16 + ((fc >> 3) & 1) * 16);
+                               (size_t)((fce >> 4) * G16 + ((fce >> 3) & 1) * 16);
             a_ptr[i] = ok ? xb + off : zero_page;
         }
     };
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < UAW; ++i) {
             const long long pix0 = (long long)(a_img[i] + a_iy0[i]) * a.iw + a_ix0[i];
-            const unsigned long long base = (unsigned long long)(xb + pix0 * (long long)pix_bytes + chunk_byte);
+            const unsigned long long base = (unsigned long long)(xb + pix0 * (long long)pix_bytes + (RB_SWZ ? (chunk_byte ^ a_flip[i]) : chunk_byte));
             a_img[i] = (int)(unsigned)base;
             a_iy0[i] = (int)(unsigned)(base >> 32);
             a_ix0[i] = (int)tapmask[i];
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
             b_rb[i] = rb;
             int n = n0 + rb * RPI + lrow;
             n = n < a.cout ? n : a.cout - 1;                       // columns past cout are never stored
-            b_ptr[i] = reinterpret_cast<const char*>(a.w) + (size_t)n * row_bytes + chunk_byte;
+            b_ptr[i] = reinterpret_cast<const char*>(a.w) + (size_t)n * row_bytes + (RB_SWZ && (rb & 1) ? (chunk_byte ^ 64) : chunk_byte);
         }
     }
     // DMA instruction d (0 .. LPT-1) of the tile at the current loader state: A units first, then B
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_dma(const ConvArgs a) {
 
     // ---- fragments ------------------------------------------------------------------------------------------------
     const int fr_row = lane & 31, fr_h = lane >> 5;
-    const int fsw = CPR == 4 ? ((fr_row >> 2) & 3) : ((fr_row >> 3) & 1);
+    const int fsw = G::swz(fr_row);
     int foff[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) foff[s] = ((s * 2 + fr_h) ^ fsw) * 16;
@@ -690,9 +709,12 @@ const void* zero_page_for_current_device() {
     return pages[dev];
 }
 
-template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI>
+template <typename T, int NP, int WM, int WN, int TM, int TN, int ST, int EPI, int KTX = 0>
 int launch_dma(const ConvArgs& a0, hipStream_t st) {
-    using G = DmaGeom<NP>;
+    using G = DmaGeom<NP, KTX>;
+    if constexpr (KTX == 64) {                                     // whole 64-channel chunks inside one tap, no K padding
+        if (a0.cin % 64 != 0 || a0.x_ld % 8 != 0) return GV_E_UNSUPPORTED;
+    }
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     ConvArgs a = a0;
     a.Kpad = (a.K + G::KT - 1) / G::KT * G::KT;
@@ -705,12 +727,12 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
     a.korder = (a.kh * a.kw > 1 && a.kh * a.kw <= 32 && a.kw < 32 && a.cin % G::KT == 0 && a.dil_shift == 0 && !(a.dbg & 128)) ? 1 : 0;   // dbg 128: tap-major (A/B)
     const size_t ring = (size_t)ST * NP * (BM + BN) * G::RBYTES;
     const size_t epi = EPI == 1 ? 0 : (size_t)(WM * WN) * (EPI == 0 ? EpiGeom<TN>::BYTES : X3EpiGeom<TN>::BYTES);
-    static_assert(dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() >= (int)((size_t)ST * NP * (BM + BN) * G::RBYTES), "table behind the ring");
+    static_assert(dma_ss_off<NP, WM, WN, TM, TN, ST, EPI, KTX>() >= (int)((size_t)ST * NP * (BM + BN) * G::RBYTES), "table behind the ring");
     (void)ring; (void)epi;
-    size_t lds = (size_t)dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>() +
-                 (dma_use_ss<NP, WM, WN, TM, TN, ST, EPI>() ? 4 * BN * sizeof(float) : 0);
+    size_t lds = (size_t)dma_ss_off<NP, WM, WN, TM, TN, ST, EPI, KTX>() +
+                 (dma_use_ss<NP, WM, WN, TM, TN, ST, EPI, KTX>() ? 4 * BN * sizeof(float) : 0);
     auto go = [&](auto mode) -> int {                              // (one instantiation, and one attribute cache, per kernel)
-        auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI, decltype(mode)::value>;
+        auto kern = &conv_dma<T, NP, WM, WN, TM, TN, ST, EPI, decltype(mode)::value, KTX>;
         if (lds > 160 * 1024) return GV_E_UNSUPPORTED;
         if (lds > 64 * 1024) {
             const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
@@ -728,8 +750,8 @@ int launch_dma(const ConvArgs& a0, hipStream_t st) {
             // the tables live in the ring the epilogue has freed, behind the waves' staging blocks, where they fit in
             // front of the epilogue's constants; else behind everything (more LDS per workgroup)
             const size_t tab = gvconv::stat_lds_bytes(a.st.mode, a.st.slots, BN);
-            constexpr size_t epi_b = (size_t)WM * WN * EpiGeom<TN>::BYTES, ss_off = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI>();
-            constexpr size_t late = dma_late_ss<NP, WM, WN, TM, TN, ST, EPI>() ? (size_t)16 * BN : 0;   // (the late constants table)
+            constexpr size_t epi_b = (size_t)WM * WN * EpiGeom<TN>::BYTES, ss_off = dma_ss_off<NP, WM, WN, TM, TN, ST, EPI, KTX>();
+            constexpr size_t late = dma_late_ss<NP, WM, WN, TM, TN, ST, EPI, KTX>() ? (size_t)16 * BN : 0;   // (the late constants table)
             if (epi_b + late + tab <= ss_off) {
                 a.st.lds_off = (int)(epi_b + late);
             } else {
@@ -768,6 +790,13 @@ int launch_dma_lp(int cfg, const ConvArgs& a, hipStream_t st) {
         case 13: return launch_dma<T, 1, 2, 2, 2, 2, 2, 0>(a, st);     // 128 x 128, 2 stages (32 KB: four per CU)
         case 14: return launch_dma<T, 1, 2, 2, 2, 3, 2, 0>(a, st);     // 128 x 192, 2 stages (40 KB)
         case 15: return launch_dma<T, 1, 2, 2, 4, 2, 2, 0>(a, st);     // 256 x 128, four waves, 2 stages (48 KB: three per CU)
+        // round 4: 64-deep k-tiles (128-byte LDS rows = whole cache lines of the source per row; DmaGeom): cin % 64 == 0
+        case 16: return launch_dma<T, 1, 2, 2, 2, 3, 2, 0, 64>(a, st); // 128 x 192, 2 stages (80 KB: two per CU)
+        case 17: return launch_dma<T, 1, 4, 2, 2, 3, 2, 0, 64>(a, st); // 256 x 192, 8 waves, 2 stages (112 KB)
+        case 18: return launch_dma<T, 1, 2, 2, 2, 2, 2, 0, 64>(a, st); // 128 x 128, 2 stages (64 KB: two per CU)
+        case 19: return launch_dma<T, 1, 2, 2, 2, 2, 3, 0, 64>(a, st); // 128 x 128, 3 stages (96 KB)
+        case 20: return launch_dma<T, 1, 4, 2, 2, 2, 2, 0, 64>(a, st); // 256 x 128, 8 waves, 2 stages (96 KB)
+        case 21: return launch_dma<T, 1, 2, 4, 4, 2, 2, 0, 64>(a, st); // 256 x 256, 8 waves, 2 stages (128 KB)
     }
     return GV_E_UNSUPPORTED;
 }
@@ -824,7 +853,7 @@ bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; 
 
 int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) { return launch_dma_x3(cfg, a, st); }
 
-int dma_lp_num_cfgs() { return 16; }
+int dma_lp_num_cfgs() { return 22; }
 
 // the DMA loader's layer class: whole 8-channel chunks inside one filter tap, 16-byte aligned pixels, 16-bit input
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32) {

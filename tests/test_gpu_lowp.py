@@ -112,6 +112,11 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
                                  sc2.data_ptr() if second else None, sh2.data_ptr() if second else None, st())
     finally:
         lib().gv_conv2d_set_tile_override(-1)
+    if expect is not None:
+        assert rc == expect, rc
+        torch.cuda.synchronize()
+        assert (yd.float() == -77.0).all()              # nothing was written
+        return None
     _lib.check(rc, "gv_conv2d_fwd")
     torch.cuda.synchronize()
     y = yd.float().cpu().numpy()
@@ -224,6 +229,46 @@ def test_lp_dma_conv_combos_vs_oracle(k, stride, padding, cin, cout, tile_i):
     y = run_conv(x, w, stride, pads, ref.shape[1:3], scale, shift, True, ty, residual=res, tile=tile,
                  x_ld=cin + 16, x_off=8, y_ld=cout + 24, y_off=16)
     close(y, ref.numpy(), ulp)
+
+
+K64_COMBOS = [c for c in COMBOS if c[3] % 64 == 0] + [((3, 3), 1, "SAME", 64, 96), ((7, 1), 1, "SAME", 192, 192)]
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("tile_i", [16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("k,stride,padding,cin,cout", K64_COMBOS)
+def test_lp_dma_k64_tiles_vs_oracle(k, stride, padding, cin, cout, tile_i, ty):
+    """The 64-deep k-tile form of the LDS-DMA loader (round 4: 128-byte LDS rows = whole cache lines of the source, the
+    chunk swizzle reaching the row block's parity): every such tile on every layer class with whole 64-channel chunks,
+    with residual, ReLU and channel-slice operands whose pixels are only 16-byte aligned."""
+    code, td, ulp = TYPES[ty]
+    tile = dma_tiles()[tile_i]
+    g = torch.Generator().manual_seed(hash((k, stride, cin, cout, tile_i)) % 1000)
+    ih, iw = (23, 20) if cin <= 64 else (9, 10)
+    x = rnd(torch.randn(3, ih, iw, cin, generator=g), td)
+    w = rnd(torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5), td)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    if isinstance(padding, str):
+        pads = (tf_pads(ih, k[0], stride, padding), tf_pads(iw, k[1], stride, padding))
+    else:
+        pads = (padding[0], padding[2])
+    ref0 = oracle_conv(x, w, stride, padding, scale, shift, False)
+    res = rnd(torch.randn(ref0.shape, generator=g), td)
+    ref = oracle_conv(x, w, stride, padding, scale, shift, True, residual=res)
+    y = run_conv(x, w, stride, pads, ref.shape[1:3], scale, shift, True, ty, residual=res, tile=tile,
+                 x_ld=cin + 16, x_off=8, y_ld=cout + 24, y_off=16)
+    close(y, ref.numpy(), ulp)
+
+
+def test_lp_dma_k64_tiles_decline_other_channel_counts():
+    """cin % 64 != 0: the 64-deep tiles return GV_E_UNSUPPORTED (the autotuner skips them), nothing is written."""
+    g = torch.Generator().manual_seed(3)
+    x = rnd(torch.randn(2, 9, 10, 96, generator=g), torch.bfloat16)
+    w = rnd(torch.randn(3, 3, 96, 64, generator=g) * 0.05, torch.bfloat16)
+    for tile_i in (16, 21):
+        run_conv(x, w, 1, (1, 1), (9, 10), torch.ones(64), torch.zeros(64), False, "bf16", tile=dma_tiles()[tile_i],
+                 expect=_lib.GV_E_UNSUPPORTED)
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
