@@ -797,6 +797,10 @@ int launch_dma_lp(int cfg, const ConvArgs& a, hipStream_t st) {
         case 19: return launch_dma<T, 1, 2, 2, 2, 2, 3, 0, 64>(a, st); // 128 x 128, 3 stages (96 KB)
         case 20: return launch_dma<T, 1, 4, 2, 2, 2, 2, 0, 64>(a, st); // 256 x 128, 8 waves, 2 stages (96 KB)
         case 21: return launch_dma<T, 1, 2, 4, 4, 2, 2, 0, 64>(a, st); // 256 x 256, 8 waves, 2 stages (128 KB)
+        // tall tiles for the 64- / 96-column layers of Mixed_5 (M = 240 000): the 128 x 96 tile reads 55 flop per staged byte
+        case 22: return launch_dma<T, 1, 4, 1, 2, 3, 2, 0>(a, st);     // 256 x 96, 4 waves (64 x 96 each), 2 stages (44 KB: three per CU)
+        case 23: return launch_dma<T, 1, 4, 1, 2, 2, 2, 0>(a, st);     // 256 x 64, 4 waves (64 x 64 each), 2 stages (40 KB)
+        case 24: return launch_dma<T, 1, 4, 1, 2, 3, 2, 0, 64>(a, st); // 256 x 96, 64-deep k-tiles (88 KB)
     }
     return GV_E_UNSUPPORTED;
 }
@@ -853,7 +857,7 @@ bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; 
 
 int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) { return launch_dma_x3(cfg, a, st); }
 
-int dma_lp_num_cfgs() { return 22; }
+int dma_lp_num_cfgs() { return 25; }
 
 // the DMA loader's layer class: whole 8-channel chunks inside one filter tap, 16-byte aligned pixels, 16-bit input
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32) {

@@ -204,7 +204,7 @@ def test_lp_conv_every_dma_tile_config(tile, cout, ty):
 DMA_COMBOS = [c for c in COMBOS if c[3] % 8 == 0]
 
 
-@pytest.mark.parametrize("tile_i", [0, 3, 8, 9])
+@pytest.mark.parametrize("tile_i", [0, 3, 8, 9, 22, 23])
 @pytest.mark.parametrize("k,stride,padding,cin,cout", DMA_COMBOS)
 def test_lp_dma_conv_combos_vs_oracle(k, stride, padding, cin, cout, tile_i):
     """Every (kernel, stride, padding) combination of the two backbones whose input has whole 8-channel chunks,
@@ -235,7 +235,7 @@ K64_COMBOS = [c for c in COMBOS if c[3] % 64 == 0] + [((3, 3), 1, "SAME", 64, 96
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
-@pytest.mark.parametrize("tile_i", [16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("tile_i", [16, 17, 18, 19, 20, 21, 24])
 @pytest.mark.parametrize("k,stride,padding,cin,cout", K64_COMBOS)
 def test_lp_dma_k64_tiles_vs_oracle(k, stride, padding, cin, cout, tile_i, ty):
     """The 64-deep k-tile form of the LDS-DMA loader (round 4: 128-byte LDS rows = whole cache lines of the source, the

@@ -54,9 +54,11 @@ def probe(name, nb, h, w, cin, cout, kh, kw, dbgs=(0, 2, 128, 4), iters=20):
 
 if __name__ == "__main__":
     print("LDS-DMA tiles: 128x128 256x128/8w 128x256/8w 256x256/8w 128x192 256x192/8w 128x64 64x128 128x96 256x128/4w 128x256/4w "
-          "192x128 | two stages: 192x128 128x128 128x192 256x128/4w | 64-deep k-tiles: 128x192 256x192/8w 128x128 128x128/3st 256x128/8w 256x256/8w")
+          "192x128 | two stages: 192x128 128x128 128x192 256x128/4w | 64-deep k-tiles: 128x192 256x192/8w 128x128 128x128/3st 256x128/8w 256x256/8w | 256x96/4w 256x64/4w 256x96/4w/k64")
     probe("Mixed_6c 7x1", 384, 12, 12, 160, 160, 7, 1)
     probe("Mixed_6e 1x7", 384, 12, 12, 192, 192, 1, 7)
     probe("Mixed_6 fused 1x1 siblings", 384, 12, 12, 768, 704, 1, 1)
     probe("Mixed_5 3x3", 384, 25, 25, 64, 96, 3, 3)
+    probe("Mixed_5 3x3 96", 384, 25, 25, 96, 96, 3, 3)
+    probe("Mixed_5 5x5", 384, 25, 25, 48, 64, 5, 5)
     probe("Conv2d_4a-shaped 3x3", 384, 52, 52, 80, 192, 3, 3)
