@@ -301,10 +301,32 @@ namespace gvlp {
 // k = 24..33 (round 3): 192-channel sides on two stages — (TI, TO) = (3,3), (3,1), (1,3), (3,2), (2,3) at 1024 then 2048
 // workgroups.  A 192-channel side on 128-wide tiles is one full and one half-empty tile: a 192 x 192 layer (Mixed_6e's
 // 1x7 / 7x1 pairs, Mixed_7a) did 16/9 of its work, loads and instructions included.
-int wgrad_dma_num_cfgs() { return 34; }
+// k = 34..42 (round 4): the two-stage tiles (TI, TO) in {1,2}^2 and the 192-channel tiles at a target of 512 workgroups.  With
+// the slices STORED and reduced (gv_conv2d_wgrad_ws) every workgroup writes its whole fp32 tile and the reduce reads it
+// back: on the 12 x 12 maps (7 tiles of 192 x 192 x 4 B over ~100 slices) that traffic is 2.6x the operands'.
+int wgrad_dma_num_cfgs() { return 43; }
 
 int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, int k, hipStream_t st) {
-    if (k < 0 || k >= 34) return GV_E_BADARG;
+    if (k < 0 || k >= 43) return GV_E_BADARG;
+    if (k >= 34) {
+        const int q = k - 34;
+#define GV_WD5(T)                                                                                       \
+    switch (q) {                                                                                        \
+        case 0: return launch_wgrad_dma<T, 1, 1, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 1: return launch_wgrad_dma<T, 2, 1, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 2: return launch_wgrad_dma<T, 1, 2, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 3: return launch_wgrad_dma<T, 2, 2, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 4: return launch_wgrad_dma<T, 3, 3, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 5: return launch_wgrad_dma<T, 3, 1, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 6: return launch_wgrad_dma<T, 1, 3, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        case 7: return launch_wgrad_dma<T, 3, 2, 2>(d, x, dz, dz_ld, dw, 512, st);                      \
+        default: return launch_wgrad_dma<T, 2, 3, 2>(d, x, dz, dz_ld, dw, 512, st);                     \
+    }
+        if (d->dtype == GV_BF16) { GV_WD5(__bf16) }
+        if (d->dtype == GV_F16) { GV_WD5(_Float16) }
+#undef GV_WD5
+        return GV_E_UNSUPPORTED;
+    }
     if (k >= 24) {
         const int q = (k - 24) % 5;
         const int64_t t3 = k - 24 < 5 ? 1024 : 2048;
