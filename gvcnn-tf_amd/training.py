@@ -1230,12 +1230,24 @@ class TrainGVCNN:
                     self.grads[op["name"] + "/gamma"] += ab[..., 1].sum(0).float()
                 ab.zero_()
                 dbeta = dgamma = None
-            _lib.check(lib.gv_bn_relu_bwd_apply_grouped_t(
-                self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
-                st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
-                self._count(hw).data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), self._ptr(x, True), x.ld,
-                dbeta, dgamma, sc, sh, acc if self._lazy else 1, self.dt | (_lib.GV_ACCUM_RAW_Z if raw else 0), _st()),
-                "bn_bwd apply " + op["name"])
+            def apply(flag):
+                return lib.gv_bn_relu_bwd_apply_grouped_t(
+                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                    st["inv"].data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                    self._count(hw).data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), self._ptr(x, True), x.ld,
+                    dbeta, dgamma, sc, sh, acc if self._lazy else 1, self.dt | flag, _st())
+            rc = apply(_lib.GV_ACCUM_RAW_Z if raw else 0)
+            if raw and rc == _lib.GV_E_UNSUPPORTED and self.bn_sync is None:
+                # the apply kernel cannot convert (sum g, sum g*z) for this geometry (its non-vector path): nothing was
+                # written — take the sums from the separate pass after all, and remember it for the next steps
+                accb[:2 * V * x.c].zero_()
+                _lib.check(lib.gv_bn_relu_bwd_sums_grouped_t(
+                    self._ptr(y, True), y.ld, yptr, y.ld, self._ptr(x), x.ld, st["mean"].data_ptr(),
+                    st["inv"].data_ptr(), x.nb, hw, x.c, V, accb.data_ptr(), sc, sh, self.dt | _lib.GV_ACCUM_ZEROED, _st()),
+                    "bn_bwd sums " + op["name"])
+                op["fused_b"]["_nofuse_b"] = True
+                rc = apply(0)
+            _lib.check(rc, "bn_bwd apply " + op["name"])
         elif op["kind"] == "conv":
             dz = self._ptr(y, True)
             if op["bias"]:
