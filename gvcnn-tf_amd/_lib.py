@@ -168,6 +168,7 @@ TUNING = {
     "gv_conv2d_wgrad_num_cfgs": (C.c_int, [C.c_int]),
     "gv_conv2d_wgrad_set_strip_taps": (None, [C.c_int]),
     "gv_pool2d_bwd_set_scatter": (None, [C.c_int]),
+    "gv_pool2d_set_rows": (None, [C.c_int]),
 }
 
 _lib = None

@@ -116,6 +116,123 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_row4_lp(const unsigned short
     }
 }
 
+// 3x3 / stride 2 / VALID max pool, RH vertically adjacent outputs of an 8-channel group per thread: the window rows
+// 2*oy .. 2*oy + 2 of consecutive outputs share a row, so a thread that walks down RH outputs reads 2*RH + 1 input rows
+// instead of 3*RH — and, what matters more, the shared rows are not re-fetched by ANOTHER workgroup on another XCD
+// (pool2d_lp: one output per thread, L2 hit 0.32, 1.5x the algorithmic bytes from the fabric; r3_pmc / r4_pmc).
+// Giving every workgroup one contiguous span of pool2d_lp's index instead was measured and dropped (round 4: the pools
+// of a step 1.10 -> 1.25 ms — 4096 spans in flight at once walk 4096 far-apart regions).
+template <typename T, int RH>
+__global__ __launch_bounds__(256) void maxpool3x3s2_rows_lp(const unsigned short* __restrict__ x,
+                                                            unsigned short* __restrict__ y, int nb, int ih, int iw,
+                                                            int c, int x_ld, int oh, int ow, int y_ld) {
+    const int cg = c >> 3;
+    const int nob = (oh + RH - 1) / RH;
+    const int64_t total = (int64_t)nb * nob * ow * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int ox = (int)(t % ow);
+        t /= ow;
+        const int ob = (int)(t % nob);
+        const int n = (int)(t / nob);
+        const int oy0 = ob * RH;
+        const int nr = min(RH, oh - oy0);                          // output rows of this thread
+        const unsigned short* xp = x + ((size_t)(n * ih + 2 * oy0) * iw + 2 * ox) * x_ld + g * 8;
+        unsigned short* yp = y + ((size_t)(n * oh + oy0) * ow + ox) * y_ld + g * 8;
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r <= 2 * RH; ++r) {
+            if (r > 2 * nr) break;                                 // (VALID: input row 2*oy + 2 exists for every oy < oh)
+            const unsigned short* rp = xp + (size_t)r * iw * x_ld;
+            float a[8], b[8], d_[8], hm[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(rp), a);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(rp + x_ld), b);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(rp + 2 * x_ld), d_);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hm[e] = fmaxf(fmaxf(a[e], b[e]), d_[e]);
+            if (r == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = hm[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], hm[e]);
+                if ((r & 1) == 0) {                                // the third row of output r/2 - 1 = the first of output r/2
+                    *reinterpret_cast<u32x4*>(yp + (size_t)(r / 2 - 1) * ow * y_ld) = pack8<T>(acc);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = hm[e];
+                }
+            }
+        }
+    }
+}
+
+// 3x3 / stride 1 / SAME average pool, a 4 x 4 block of outputs of an 8-channel group per thread: 6 x 6 inputs for 16
+// outputs (the row-of-4 form above: 18 for 4), horizontal 3-sums of a row shared by the three output rows it belongs to.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3x3s1_blk4_lp(const unsigned short* __restrict__ x,
+                                                            unsigned short* __restrict__ y, int nb, int ih, int iw,
+                                                            int c, int x_ld, int y_ld, int relu) {
+    const int cg = c >> 3;
+    const int wg = (iw + 3) >> 2, hg = (ih + 3) >> 2;
+    const int64_t total = (int64_t)nb * hg * wg * cg;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % cg);
+        int64_t t = idx / cg;
+        const int xg = (int)(t % wg);
+        t /= wg;
+        const int yg = (int)(t % hg);
+        const int n = (int)(t / hg);
+        const int ox0 = xg * 4, oy0 = yg * 4;
+        float hs[3][4][8];                                         // horizontal 3-sums of the last three input rows
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {                              // input rows oy0 - 1 .. oy0 + 4
+            const int iy = oy0 - 1 + r;
+            const int slot = r % 3;
+            const bool rok = (unsigned)iy < (unsigned)ih;
+            float col[6][8];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int ix = ox0 - 1 + j;
+                if (rok && (unsigned)ix < (unsigned)iw) {
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * ih + iy) * iw + ix) * x_ld + g * 8), col[j]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) col[j][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hs[slot][j][e] = col[j][e] + col[j + 1][e] + col[j + 2][e];
+            if (r >= 2) {                                          // output row oy0 + r - 2: input rows r - 2, r - 1, r
+                const int oy = oy0 + r - 2;
+                if (oy < ih) {
+                    const int rows = 1 + (oy > 0 ? 1 : 0) + (oy + 1 < ih ? 1 : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ox = ox0 + j;
+                        if (ox < iw) {
+                            const int cols = 1 + (ox > 0 ? 1 : 0) + (ox + 1 < iw ? 1 : 0);
+                            const float inv = (float)(rows * cols);
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                // (the three rows in the order the row-of-4 kernel adds them: iy - 1, iy, iy + 1)
+                                v[e] = (hs[(r - 2) % 3][j][e] + hs[(r - 1) % 3][j][e] + hs[r % 3][j][e]) / inv;
+                                if (relu) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            *reinterpret_cast<u32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 8) = pack8<T>(v);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void scale_shift_act_lp(const unsigned short* __restrict__ x, int64_t npix, int c,
                                                           int x_ld, const float* __restrict__ scale,
@@ -268,6 +385,8 @@ __global__ __launch_bounds__(256) void view_pool_fuse_lp(const unsigned short* _
     }
 }
 
+int g_pool_rows = 1;      // multi-row forms of the 3x3 pools (gv_pool2d_set_rows: 0 = one output (row of 4) per thread; A/B)
+
 inline unsigned grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     const int64_t cap = 256 * 16;
@@ -279,9 +398,21 @@ int pool2d_t(const gv_pool_desc* d, const unsigned short* x, unsigned short* y, 
     const bool vec = (d->c % 8 == 0) && (d->x_ld % 8 == 0) && (d->y_ld % 8 == 0) && gv_aligned16(x) && gv_aligned16(y);
     if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
-        const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
-        hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
-                           d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
+        if (g_pool_rows) {
+            const int64_t tot16 = (int64_t)d->nb * ((d->ih + 3) / 4) * ((d->iw + 3) / 4) * (d->c / 8);
+            hipLaunchKernelGGL(avgpool3x3s1_blk4_lp<T>, dim3(grid_for(tot16)), dim3(256), 0, st, x, y, d->nb, d->ih,
+                               d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
+        } else {
+            const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
+            hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
+                               d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
+        }
+    } else if (vec && g_pool_rows && d->mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
+               d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1) {
+        constexpr int RH = 4;
+        const int64_t tot = (int64_t)d->nb * ((d->oh + RH - 1) / RH) * d->ow * (d->c / 8);
+        hipLaunchKernelGGL((maxpool3x3s2_rows_lp<T, RH>), dim3(grid_for(tot)), dim3(256), 0, st, x, y, d->nb, d->ih, d->iw,
+                           d->c, d->x_ld, d->oh, d->ow, d->y_ld);
     } else if (vec) {
         const int64_t total = (int64_t)d->nb * d->oh * d->ow * (d->c / 8);
         hipLaunchKernelGGL((pool2d_lp<T, 8>), dim3(grid_for(total)), dim3(256), 0, st, x, y, d->nb, d->ih, d->iw,
@@ -386,3 +517,5 @@ int view_pool_fuse(int dtype, const void* F, int V, int N, int64_t E, int64_t vs
 }
 
 }  // namespace gvlp
+
+extern "C" void gv_pool2d_set_rows(int on) { g_pool_rows = on; }

@@ -449,6 +449,32 @@ def test_lp_pools(ty, c):
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("hw", [(3, 3), (9, 11), (10, 9), (17, 21), (35, 35), (12, 7)])
+def test_lp_multi_row_pool_forms(ty, hw):
+    """The multi-row forms of the two 3x3 pools (round 4: four vertically adjacent max-pool outputs / a 4 x 4 block of
+    average-pool outputs per thread) on maps whose height and width are and are not multiples of four, into a channel slice
+    of a wider buffer: the max pool bit for bit against the oracle and against the one-output form, the average pool within
+    one rounding of the oracle (nets/inception_v3.py:112,152)."""
+    code, td, ulp = TYPES[ty]
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = rnd(torch.randn(3, h, w, 72, generator=g), td)
+    oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    outs = []
+    for rows in (1, 0):
+        lib().gv_pool2d_set_rows(rows)
+        try:
+            ym = run_pool(x, 3, 2, (0, 0), (oh, ow), _lib.GV_POOL_MAX, ty, y_ld=72 + 16, y_off=8)
+            ya = run_pool(x, 3, 1, (1, 1), (h, w), _lib.GV_POOL_AVG, ty, y_ld=72 + 8, y_off=8)
+        finally:
+            lib().gv_pool2d_set_rows(1)
+        assert np.array_equal(ym, OB.max_pool2d(x, 3, 2, "VALID").numpy())
+        close(ya, OB.avg_pool2d_same3(x).numpy(), ulp)
+        outs.append((ym, ya))
+    assert np.array_equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
 def test_lp_scale_shift_gap_and_scorer(ty):
     code, td, ulp = TYPES[ty]
     g = torch.Generator().manual_seed(3)
