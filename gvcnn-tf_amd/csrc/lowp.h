@@ -6,6 +6,7 @@
 namespace gvlp {
 
 int pool2d(const gv_pool_desc* d, const void* x, void* y, hipStream_t st);
+int pool_rows();                                                  // A/B switch of the multi-row max pool (gv_pool2d_set_rows)
 int scale_shift_act(int dtype, const void* x, int64_t npix, int c, int x_ld, const float* scale, const float* shift,
                     int relu, void* y, int y_ld, hipStream_t st);
 int global_avg_pool(int dtype, const void* x, int nb, int hw, int c, int x_ld, float* y, hipStream_t st);

@@ -168,70 +168,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_rows_lp(const unsigned short
     }
 }
 
-// 3x3 / stride 1 / SAME average pool, a 4 x 4 block of outputs of an 8-channel group per thread: 6 x 6 inputs for 16
-// outputs (the row-of-4 form above: 18 for 4), horizontal 3-sums of a row shared by the three output rows it belongs to.
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool3x3s1_blk4_lp(const unsigned short* __restrict__ x,
-                                                            unsigned short* __restrict__ y, int nb, int ih, int iw,
-                                                            int c, int x_ld, int y_ld, int relu) {
-    const int cg = c >> 3;
-    const int wg = (iw + 3) >> 2, hg = (ih + 3) >> 2;
-    const int64_t total = (int64_t)nb * hg * wg * cg;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(idx % cg);
-        int64_t t = idx / cg;
-        const int xg = (int)(t % wg);
-        t /= wg;
-        const int yg = (int)(t % hg);
-        const int n = (int)(t / hg);
-        const int ox0 = xg * 4, oy0 = yg * 4;
-        float hs[3][4][8];                                         // horizontal 3-sums of the last three input rows
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {                              // input rows oy0 - 1 .. oy0 + 4
-            const int iy = oy0 - 1 + r;
-            const int slot = r % 3;
-            const bool rok = (unsigned)iy < (unsigned)ih;
-            float col[6][8];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int ix = ox0 - 1 + j;
-                if (rok && (unsigned)ix < (unsigned)iw) {
-                    unpack8<T>(*reinterpret_cast<const u32x4*>(x + ((size_t)(n * ih + iy) * iw + ix) * x_ld + g * 8), col[j]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) col[j][e] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hs[slot][j][e] = col[j][e] + col[j + 1][e] + col[j + 2][e];
-            if (r >= 2) {                                          // output row oy0 + r - 2: input rows r - 2, r - 1, r
-                const int oy = oy0 + r - 2;
-                if (oy < ih) {
-                    const int rows = 1 + (oy > 0 ? 1 : 0) + (oy + 1 < ih ? 1 : 0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ox = ox0 + j;
-                        if (ox < iw) {
-                            const int cols = 1 + (ox > 0 ? 1 : 0) + (ox + 1 < iw ? 1 : 0);
-                            const float inv = (float)(rows * cols);
-                            float v[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                // (the three rows in the order the row-of-4 kernel adds them: iy - 1, iy, iy + 1)
-                                v[e] = (hs[(r - 2) % 3][j][e] + hs[(r - 1) % 3][j][e] + hs[r % 3][j][e]) / inv;
-                                if (relu) v[e] = fmaxf(v[e], 0.f);
-                            }
-                            *reinterpret_cast<u32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 8) = pack8<T>(v);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
+// (A 4 x 4 block of outputs per thread for the 3x3 / stride-1 AVERAGE pool — 36 loads for 16 outputs instead of the row
+// form's 18 for 4 — was measured and dropped in round 4: 0.027 -> 0.038 ms on a Mixed_5 branch, 0.018 -> 0.024 ms on a
+// Mixed_6 one: a quarter of the threads and 96 live partial sums each.)
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void scale_shift_act_lp(const unsigned short* __restrict__ x, int64_t npix, int c,
@@ -385,7 +324,7 @@ __global__ __launch_bounds__(256) void view_pool_fuse_lp(const unsigned short* _
     }
 }
 
-int g_pool_rows = 1;      // multi-row forms of the 3x3 pools (gv_pool2d_set_rows: 0 = one output (row of 4) per thread; A/B)
+int g_pool_rows = 1;      // multi-row form of the 3x3 / stride-2 max pool (gv_pool2d_set_rows: 0 = one output per thread; A/B)
 
 inline unsigned grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
@@ -398,15 +337,9 @@ int pool2d_t(const gv_pool_desc* d, const unsigned short* x, unsigned short* y, 
     const bool vec = (d->c % 8 == 0) && (d->x_ld % 8 == 0) && (d->y_ld % 8 == 0) && gv_aligned16(x) && gv_aligned16(y);
     if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
-        if (g_pool_rows) {
-            const int64_t tot16 = (int64_t)d->nb * ((d->ih + 3) / 4) * ((d->iw + 3) / 4) * (d->c / 8);
-            hipLaunchKernelGGL(avgpool3x3s1_blk4_lp<T>, dim3(grid_for(tot16)), dim3(256), 0, st, x, y, d->nb, d->ih,
-                               d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
-        } else {
-            const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
-            hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
-                               d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
-        }
+        const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
+        hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
+                           d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
     } else if (vec && g_pool_rows && d->mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
                d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1) {
         constexpr int RH = 4;
@@ -518,4 +451,5 @@ int view_pool_fuse(int dtype, const void* F, int V, int N, int64_t E, int64_t vs
 
 }  // namespace gvlp
 
+namespace gvlp { int pool_rows() { return g_pool_rows; } }
 extern "C" void gv_pool2d_set_rows(int on) { g_pool_rows = on; }

@@ -226,7 +226,7 @@ def test_conv_exact_small_integers():
 
 @pytest.mark.parametrize("k,stride,padding,mode", [(3, 2, "VALID", "max"), (3, 2, "SAME", "max"),
                                                     (3, 1, "SAME", "avg"), (1, 2, "VALID", "max")])
-@pytest.mark.parametrize("shape", [(2, 14, 14, 64), (3, 9, 7, 6), (1, 5, 5, 2048)])
+@pytest.mark.parametrize("shape", [(2, 14, 14, 64), (3, 9, 7, 6), (1, 5, 5, 2048), (2, 23, 17, 32), (1, 35, 36, 8)])
 def test_pool_vs_oracle(k, stride, padding, mode, shape):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(*shape, generator=g)

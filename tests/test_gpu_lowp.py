@@ -451,10 +451,10 @@ def test_lp_pools(ty, c):
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
 @pytest.mark.parametrize("hw", [(3, 3), (9, 11), (10, 9), (17, 21), (35, 35), (12, 7)])
 def test_lp_multi_row_pool_forms(ty, hw):
-    """The multi-row forms of the two 3x3 pools (round 4: four vertically adjacent max-pool outputs / a 4 x 4 block of
-    average-pool outputs per thread) on maps whose height and width are and are not multiples of four, into a channel slice
-    of a wider buffer: the max pool bit for bit against the oracle and against the one-output form, the average pool within
-    one rounding of the oracle (nets/inception_v3.py:112,152)."""
+    """The multi-row form of the 3x3 / stride-2 max pool (round 4: four vertically adjacent outputs per thread) on maps
+    whose height and width are and are not multiples of four, into a channel slice of a wider buffer: bit for bit against
+    the oracle and against the one-output form; the average pool (row-of-4 form) beside it within one rounding of the oracle
+    (nets/inception_v3.py:112,152)."""
     code, td, ulp = TYPES[ty]
     h, w = hw
     g = torch.Generator().manual_seed(h * 100 + w)
