@@ -318,9 +318,11 @@ class ViewBatcher:
         is inflated by its own reader THREAD (zlib releases the GIL: one GZIP stream inflates at ~17 k views/s on the GPU
         box's host, four at ~35 k), the order is the same."""
         paths = [self.path] if isinstance(self.path, (str, bytes)) or hasattr(self.path, "__fspath__") else list(self.path)
-        if len(paths) == 1:
+        if len(paths) == 1 and self.workers <= 0:
             yield from read_tfrecords(paths[0])
             return
+        # (with decode workers ONE file goes through a reader thread as well: inflating it in the consumer's thread held the
+        # whole pipeline at the ~17 k views/s of one GZIP stream minus everything else that thread does)
         if self.workers <= 0:
             its = [read_tfrecords(p) for p in paths]
             while its:
@@ -370,8 +372,10 @@ class ViewBatcher:
         finally:
             stop.set()
 
-    def _decoded(self):
-        """(views, label) per record in _records() order; workers > 0: decoded by the pool, a bounded window ahead."""
+    def _decoded(self, zero_copy=False):
+        """(views, label) per record in _records() order; workers > 0: decoded by the pool, a bounded window ahead.
+        zero_copy (what __iter__ asks for): the views are VIEWS of the shared-memory ring, valid until N + 1 further
+        items have been taken — a caller that keeps them longer (list(...)) must leave it off."""
         if self.workers <= 0:
             for rec in self._records():
                 yield _decode_record(rec, self.V)
@@ -382,22 +386,29 @@ class ViewBatcher:
         from collections import deque
         from multiprocessing import shared_memory
         window, pending = 4 * self.workers, deque()
+        # Without a shuffle buffer a decoded shape is handed out as a VIEW of its shared-memory slot (no 2.4 MB copy in the
+        # consumer's thread, which at ~1 ms per shape capped the pipeline near 12 k views/s whatever the workers did): the
+        # consumer copies it into the pinned staging buffer when its batch is complete, at most N - 1 records later, so a
+        # slot may only be written again N + 1 hand-outs after its own — the ring has that many slots more than the window.
+        zero_copy = bool(zero_copy) and self.shuffle_buffer <= 0
+        nslots = window + (self.N + 1 if zero_copy else 0)
         records = self._records()
         first = next(records, None)
         if first is None:
             return
         views0, label0 = _decode_record(first, self.V)             # the slot size: every shape of a file has this one
         nbytes = views0.nbytes
-        if getattr(self, "_shm", None) is None or self._shm.size < window * nbytes:
+        if getattr(self, "_shm", None) is None or self._shm.size < nslots * nbytes:
             if getattr(self, "_shm", None) is not None:
                 self._shm.close()
                 self._shm.unlink()
-            self._shm = shared_memory.SharedMemory(create=True, size=window * nbytes)
+            self._shm = shared_memory.SharedMemory(create=True, size=nslots * nbytes)
         yield views0, label0
 
         def take(slot, res):
             shape, label = res.get(timeout=300)                       # (a worker that died — e.g. SIGBUS on a full /dev/shm — raises here)
-            return np.ndarray(shape, np.uint8, buffer=self._shm.buf, offset=slot * nbytes).copy(), label   # slot free again
+            view = np.ndarray(shape, np.uint8, buffer=self._shm.buf, offset=slot * nbytes)
+            return (view if zero_copy else view.copy()), label
         slot = 0
         try:
             for rec in records:
@@ -405,7 +416,7 @@ class ViewBatcher:
                     yield take(*pending.popleft())
                 pending.append((slot, self._pool.apply_async(_decode_record_into, (rec, self.V, self._shm.name,
                                                                                   slot * nbytes, nbytes))))
-                slot = (slot + 1) % window
+                slot = (slot + 1) % nslots
             while pending:
                 yield take(*pending.popleft())
         finally:
@@ -417,10 +428,10 @@ class ViewBatcher:
                 except Exception:
                     pass
 
-    def _shapes(self):
+    def _shapes(self, zero_copy=False):
         """(views uint8 [V, h0, w0, 3], label) per record, through the shuffle buffer."""
         buf = []
-        for item in self._decoded():
+        for item in self._decoded(zero_copy):
             if self.shuffle_buffer <= 0:
                 yield item
             elif len(buf) < self.shuffle_buffer:
@@ -450,8 +461,18 @@ class ViewBatcher:
             if self._pin_ev[self._pin_k] is not None:
                 self._pin_ev[self._pin_k].synchronize()
             view = stage.numpy()
-            for i, im in enumerate(imgs):
-                view[i] = im
+            if len(imgs) >= 8:                                     # 2.4 MB memcpys release the GIL: four threads share them
+                if getattr(self, "_copiers", None) is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._copiers = ThreadPoolExecutor(4)
+
+                def put(lo):
+                    for i in range(lo, len(imgs), 4):
+                        view[i] = imgs[i]
+                list(self._copiers.map(put, range(4)))
+            else:
+                for i, im in enumerate(imgs):
+                    view[i] = im
             src = stage.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
@@ -474,7 +495,7 @@ class ViewBatcher:
         import warnings
         imgs, labels = [], []
         self.dropped, self.last_valid = 0, self.N
-        for img, label in self._shapes():
+        for img, label in self._shapes(zero_copy=True):
             imgs.append(img)
             labels.append(label)
             if len(imgs) == self.N:

@@ -165,6 +165,33 @@ def test_decode_workers_return_the_same_shapes_in_order(tmp_path):
         assert la == lb == lab and np.array_equal(a, b) and np.array_equal(a, np.stack(views))
 
 
+def test_zero_copy_views_stay_valid_for_a_whole_batch(tmp_path):
+    """What __iter__ asks of the decode ring (zero_copy=True): a decoded shape comes out as a VIEW of its shared-memory slot
+    and must keep its pixels until the batch it belongs to is complete — N shapes are held un-copied, then compared, for
+    every batch of a file longer than the ring (more shapes than 4 * workers + N + 1 slots, so slots ARE reused)."""
+    rng = np.random.RandomState(9)
+    N, V = 4, 2
+    shapes = [([rng.randint(0, 256, size=(9, 7, 3)).astype(np.uint8) for _ in range(V)], i) for i in range(61)]
+    path = os.path.join(tmp_path, "z.record")
+    R.write_tfrecords(path, [R.make_example([R.encode_png(v) for v in vs], lab) for vs, lab in shapes])
+    vb = R.ViewBatcher(path, V, 8, 8, N, "cpu", workers=2)              # ring: 8 + 5 slots
+    try:
+        held, seen = [], 0
+        for views, lab in vb._shapes(zero_copy=True):
+            held.append((views, lab))
+            if len(held) == N:
+                for v, l in held:                                       # only now "copied", like _batch does
+                    assert l == seen and np.array_equal(v, np.stack(shapes[l][0]))
+                    seen += 1
+                held = []
+        for v, l in held:
+            assert l == seen and np.array_equal(v, np.stack(shapes[l][0]))
+            seen += 1
+        assert seen == 61
+    finally:
+        vb.close()
+
+
 def test_a_list_of_record_files_is_interleaved_the_same_with_and_without_workers(tmp_path):
     """ViewBatcher([files]): one record of each file in turn, files of different lengths (train_data.py:22-24 reads its
     files in parallel); reader threads + decode workers return exactly the single-process stream."""
