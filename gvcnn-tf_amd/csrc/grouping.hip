@@ -43,12 +43,32 @@ __global__ __launch_bounds__(256) void view_score_partial_f32(
     if ((cr & 3) == 0 && (raw_ld & 3) == 0 && ((((uintptr_t)raw) | ((uintptr_t)kernel)) & 15) == 0) {
         const int cg = cr >> 2;
         const int total = hw * cg;
-        for (int i = threadIdx.x; i < total; i += 256) {
+        // four chunks in flight per thread, each into its own partial sum (lowp.hip: view_score_partial_lp); fixed order
+        float sp[4] = {0.f, 0.f, 0.f, 0.f};
+        int i = threadIdx.x;
+        for (; i + 3 * 256 < total; i += 4 * 256) {
+            f32x4 q[4];
+            int gq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ii = i + u * 256;
+                const int p = ii / cg;
+                gq[u] = ii - p * cg;
+                q[u] = *reinterpret_cast<const f32x4*>(xb + (size_t)p * raw_ld + 4 * gq[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 k = *reinterpret_cast<const f32x4*>(kv + 4 * gq[u]);
+                sp[u] += q[u][0] * k[0] + q[u][1] * k[1] + q[u][2] * k[2] + q[u][3] * k[3];
+            }
+        }
+        for (; i < total; i += 256) {
             const int p = i / cg, g = i - p * cg;
             const f32x4 x = *reinterpret_cast<const f32x4*>(xb + (size_t)p * raw_ld + 4 * g);
             const f32x4 k = *reinterpret_cast<const f32x4*>(kv + 4 * g);
-            s += x[0] * k[0] + x[1] * k[1] + x[2] * k[2] + x[3] * k[3];
+            sp[0] += x[0] * k[0] + x[1] * k[1] + x[2] * k[2] + x[3] * k[3];
         }
+        s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
     } else {
         const int total = hw * cr;
         for (int i = threadIdx.x; i < total; i += 256) {
