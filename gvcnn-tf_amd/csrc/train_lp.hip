@@ -1479,7 +1479,7 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     };
     int ti = side(d->cin), to = side(d->cout);
     int64_t target = 2048;
-    if (d->tile_cfg > 30)                                        // 31..73: LDS-DMA staging (wgrad_dma.hip)
+    if (d->tile_cfg > 30)                                        // 31..91: LDS-DMA staging (wgrad_dma.hip)
         return gvlp::conv_wgrad_dma_launch(d, x, dz, dz_ld, dw, d->tile_cfg - 31, st);
     if (d->tile_cfg > 27) {                                      // 28..30: strip form, 1024 / 2048 / 4096 workgroups
         return strip_t<T>(d, x, dz, dz_ld, dw, 1024 << (d->tile_cfg - 28), st);

@@ -64,9 +64,10 @@ struct WgradGeo {
 // swapping the 64-byte segments pairwise on every second row pair moves them 16 banks apart, and 0..5 stays 0..5)
 template <int P> __device__ __forceinline__ int seg_key(int row) { return P == 256 ? (row & 3) : ((row >> 1) & 1); }
 
-template <typename T, int TI, int TO, int ST>
+// PT: pixels per stage (32; 64 since round 4: half the barriers and counted waits per MFMA — a wave runs 8 (18) MFMAs
+// between two barriers at 32 pixels and 128 (192) channel sides — for twice the LDS per stage)
+template <typename T, int TI, int TO, int ST, int PT = 32>
 __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
-    constexpr int PT = 32;                                     // pixels per stage
     constexpr int BI = 64 * TI, BO = 64 * TO;
     constexpr int PX = 2 * BI, PZ = 2 * BO;                    // row bytes
     constexpr int X_BYTES = PT * PX, Z_BYTES = PT * PZ, STAGE = X_BYTES + Z_BYTES;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma(const WgradGeo g) {
 #ifndef GV_KERNEL_ONLY     // (single instantiations of the kernel above for instruction counts: no launchers)
 unsigned wmagic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-template <typename T, int TI, int TO, int ST>
+template <typename T, int TI, int TO, int ST, int PT = 32>
 int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, int64_t target,
                      hipStream_t st) {
     constexpr int BI = 64 * TI, BO = 64 * TO;
@@ -276,13 +277,13 @@ int launch_wgrad_dma(const gv_conv_desc* d, const void* x, const void* dz, int d
     const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
     splits = gv_dw_clamp(dw, elems, splits);
     int64_t per = (M + splits - 1) / splits;
-    per = (per + 31) / 32 * 32;
+    per = (per + PT - 1) / PT * PT;
     splits = (M + per - 1) / per;
     if ((int64_t)tiles * splits > 0x7fffffff) return GV_E_UNSUPPORTED;
     g.m_per_block = (int)per;
     g.dw = gv_dw_sink(dw, elems, splits);
-    const size_t lds = (size_t)ST * 32 * 2 * (BI + BO);
-    auto kern = &conv_wgrad_dma<T, TI, TO, ST>;
+    const size_t lds = (size_t)ST * PT * 2 * (BI + BO);
+    auto kern = &conv_wgrad_dma<T, TI, TO, ST, PT>;
     if (lds > 64 * 1024) {
         if (!GV_BIG_LDS_OK(kern, 160 * 1024)) return GV_E_UNSUPPORTED;      // (per device)
     }
@@ -304,10 +305,31 @@ namespace gvlp {
 // k = 34..42 (round 4): the two-stage tiles (TI, TO) in {1,2}^2 and the 192-channel tiles at a target of 512 workgroups.  With
 // the slices STORED and reduced (gv_conv2d_wgrad_ws) every workgroup writes its whole fp32 tile and the reduce reads it
 // back: on the 12 x 12 maps (7 tiles of 192 x 192 x 4 B over ~100 slices) that traffic is 2.6x the operands'.
-int wgrad_dma_num_cfgs() { return 43; }
+// k = 43..60 (round 4): 64 pixels per stage, two stages — (TI, TO) as q above — at 1024 then 2048 workgroups.
+int wgrad_dma_num_cfgs() { return 61; }
 
 int conv_wgrad_dma_launch(const gv_conv_desc* d, const void* x, const void* dz, int dz_ld, const GvDw& dw, int k, hipStream_t st) {
-    if (k < 0 || k >= 43) return GV_E_BADARG;
+    if (k < 0 || k >= 61) return GV_E_BADARG;
+    if (k >= 43) {
+        const int q = (k - 43) % 9;
+        const int64_t t6 = k - 43 < 9 ? 1024 : 2048;
+#define GV_WD6(T)                                                                                       \
+    switch (q) {                                                                                        \
+        case 0: return launch_wgrad_dma<T, 1, 1, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 1: return launch_wgrad_dma<T, 2, 1, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 2: return launch_wgrad_dma<T, 1, 2, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 3: return launch_wgrad_dma<T, 2, 2, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 4: return launch_wgrad_dma<T, 3, 3, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 5: return launch_wgrad_dma<T, 3, 1, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 6: return launch_wgrad_dma<T, 1, 3, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        case 7: return launch_wgrad_dma<T, 3, 2, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                   \
+        default: return launch_wgrad_dma<T, 2, 3, 2, 64>(d, x, dz, dz_ld, dw, t6, st);                  \
+    }
+        if (d->dtype == GV_BF16) { GV_WD6(__bf16) }
+        if (d->dtype == GV_F16) { GV_WD6(_Float16) }
+#undef GV_WD6
+        return GV_E_UNSUPPORTED;
+    }
     if (k >= 34) {
         const int q = k - 34;
 #define GV_WD5(T)                                                                                       \

@@ -327,7 +327,7 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
     dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
     n = lib().gv_conv2d_wgrad_num_cfgs(dt)
-    assert n == 73 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 43 LDS-DMA
+    assert n == 91 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 61 LDS-DMA
     outs = []
     for cfg in range(n + 1):
         dw = torch.zeros(3, 3, cin, cout, device=DEV)
@@ -340,7 +340,7 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     assert lib().gv_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), cout, outs[0].to(DEV).data_ptr(), st()) != 0
 
 
-@pytest.mark.parametrize("cfg", [31, 32, 33, 34, 38, 42, 55, 56, 57, 58, 59, 64, 65, 68, 69, 73])
+@pytest.mark.parametrize("cfg", [31, 32, 33, 34, 38, 42, 55, 56, 57, 58, 59, 64, 65, 68, 69, 73, 74, 77, 78, 82, 86, 91])
 @pytest.mark.parametrize("k,stride,padding,cin,cout,nb,ih,iw", [c for c in CONVS if c[5] * c[6] * c[7] < 100000])
 def test_wgrad_lds_dma_form_on_every_layer_class(k, stride, padding, cin, cout, nb, ih, iw, cfg):
     """The LDS-DMA staged filter gradient (csrc/wgrad_dma.hip; tile_cfg 31..64: 64- / 128- / 192-channel tile sides): strided and padded layers, channel

@@ -71,9 +71,9 @@ def run_ws(dt, k, stride, cin, cout, nb, ih, iw, geo, xd, dzd, cfg, ws, fill=0.5
 # (dtype, kernel, stride, padding, cin, cout, nb, ih, iw, tile_cfgs): one row per kernel form behind the entry point
 FORMS = [
     # LDS-DMA tiles (default for 16-bit), register-staged tiles (1..27), strips (28..30), a few of each
-    (_lib.GV_BF16, (3, 3), 1, "SAME", 64, 96, 12, 35, 35, [0, 1, 5, 14, 27, 28, 30, 31, 38, 47, 55, 60, 64]),
+    (_lib.GV_BF16, (3, 3), 1, "SAME", 64, 96, 12, 35, 35, [0, 1, 5, 14, 27, 28, 30, 31, 38, 47, 55, 60, 64, 74, 77, 86]),
     (_lib.GV_F16, (1, 7), 1, "SAME", 128, 192, 12, 17, 17, [0, 9, 31, 44, 58]),
-    (_lib.GV_BF16, (1, 1), 1, "SAME", 288, 448, 24, 12, 12, [0, 27, 34, 64, 66, 73]),
+    (_lib.GV_BF16, (1, 1), 1, "SAME", 288, 448, 24, 12, 12, [0, 27, 34, 64, 66, 73, 77, 78, 91]),
     (_lib.GV_BF16, (3, 3), 2, "VALID", 96, 96, 8, 25, 25, [0, 31]),
     (_lib.GV_BF16, (3, 3), 1, "VALID", 32, 32, 8, 55, 55, [0, 28]),           # the 32-channel stem layers: strips
     (_lib.GV_BF16, (3, 3), 2, "VALID", 3, 32, 8, 96, 96, [0]),               # Conv2d_1a: stem rows
