@@ -69,6 +69,11 @@ class TRef:
         assert not self.p3 or (lo % 16 == 0 and hi % 16 == 0), "a three-plane tensor is sliced on 16-channel groups"
         return TRef(self.vbuf, self.off + lo, self.nb, self.h, self.w, hi - lo, self.ld, self.p3)
 
+    def images(self, lo, hi):
+        """Images [lo, hi) of the batch: the same tensor, fewer of its (contiguous) images."""
+        assert 0 <= lo < hi <= self.nb
+        return TRef(self.vbuf, self.off + lo * self.h * self.w * self.ld, hi - lo, self.h, self.w, self.c, self.ld, self.p3)
+
     @property
     def npix(self):
         return self.nb * self.h * self.w
@@ -156,6 +161,10 @@ class BackbonePlan:
         return nbytes // 4
 
     def _filter(self, name, kh, kw, cin, cout):
+        for f in self.filters:                       # the same layer over another slice of the batch (stem_chunks)
+            if f[0] == name:
+                assert f[1:5] == (kh, kw, cin, cout), name
+                return f[5]
         n = self._packed_elems(kh, kw, cin, cout)
         off = self.w_elems
         self.filters.append((name, kh, kw, cin, cout, off))
@@ -230,7 +239,7 @@ class BackbonePlan:
         return outs
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
-             residual=None, next_preact=None, p3=False, defer=False):
+             residual=None, next_preact=None, p3=False, defer=False, op_name=None):
         """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
         norm = None -> biases, no BN (normalizer_fn=None).  next_preact = (bn_scope, eps) adds the
         second output relu(bn(out)) and returns (out, preact); with defer=True no second output is written and
@@ -260,7 +269,7 @@ class BackbonePlan:
             assert kh == kw == 1 and pad_t == 0 and pad_l == 0 and self.dtype != _lib.GV_F32, scope
         if residual is not None:
             assert (residual.nb, residual.h, residual.w, residual.c) == (x.nb, oh, ow, cout)
-        self._record(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
+        self._record(dict(kind="conv", name=op_name or scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
                              split=0, cout=cout, xpre=xpre,
@@ -716,20 +725,62 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
             b.keep(t)
         return name == final_endpoint
 
-    net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
-    if done("Conv2d_1a_3x3", net): return net
-    net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
-    if done("Conv2d_2a_3x3", net): return net
-    net = conv(net, "Conv2d_2b_3x3", 64, 3, 1, "SAME")
-    if done("Conv2d_2b_3x3", net): return net
-    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_3a_3x3")
-    if done("MaxPool_3a_3x3", net): return net
-    net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID", mid=final_endpoint != "Conv2d_3b_1x1")
-    if done("Conv2d_3b_1x1", net): return net
-    net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID", mid=cat_p3("Conv2d_4a_3x3") and final_endpoint != "Conv2d_4a_3x3")
-    if done("Conv2d_4a_3x3", net): return net
-    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3", **({"p3": True} if cat_p3("MaxPool_5a_3x3") else {}))
-    if done("MaxPool_5a_3x3", net): return net
+    STEM = ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3", "MaxPool_3a_3x3", "Conv2d_3b_1x1", "Conv2d_4a_3x3",
+            "MaxPool_5a_3x3")
+    chunks = min(int(getattr(b, "stem_chunks", 1) or 1), b.input.nb)
+    if chunks > 1 and final_endpoint not in STEM and not any(k in STEM for k in keep):
+        # The stem in slices of the batch, slice by slice through all seven layers: a layer's output (0.4-1.5 MB per image
+        # at 16 bits) is read back by the next layer while it is still in the 256 MiB Infinity Cache instead of after the
+        # whole batch (hundreds of MB) has passed through it.  Same kernels, same values; `stem_chunks` is a speed choice.
+        full = [None] * len(STEM)
+
+        def dst(i, x, cout, k, stride, padding, p3):
+            if full[i] is None:
+                oh, ow = _out_size(x.h, k, stride, padding)[0], _out_size(x.w, k, stride, padding)[0]
+                full[i] = b.new_tensor(b.input.nb, oh, ow, cout, p3=p3 and x.c >= 16)
+            return full[i]
+
+        def mid_p3(name):
+            return b.use_p3 and (b.p3_blocks is None or name in b.p3_blocks)
+
+        def cv(i, x, n0, n1, cout, k, stride, padding, p3, tag):
+            out = dst(i, x, cout, k, stride, padding, p3).images(n0, n1)
+            return b.conv(x, scope + "/" + STEM[i], cout, k, stride, padding, out=out, norm=BN, relu=True,
+                          op_name=scope + "/" + STEM[i] + tag)
+
+        def mp(i, x, n0, n1, p3, tag):
+            out = dst(i, x, x.c, 3, 2, "VALID", p3).images(n0, n1)
+            return b.pool(x, 3, 2, "VALID", MAX, out=out, name=STEM[i] + tag)
+
+        nb = b.input.nb
+        for ck in range(chunks):
+            n0, n1 = nb * ck // chunks, nb * (ck + 1) // chunks
+            tag = "" if ck == 0 else "@%d" % ck
+            t = cv(0, b.input.images(n0, n1), n0, n1, 32, 3, 2, "VALID", False, tag)
+            t = cv(1, t, n0, n1, 32, 3, 1, "VALID", mid_p3(STEM[1]), tag)
+            t = cv(2, t, n0, n1, 64, 3, 1, "SAME", False, tag)
+            t = mp(3, t, n0, n1, False, tag)
+            t = cv(4, t, n0, n1, 80, 1, 1, "VALID", mid_p3(STEM[4]), tag)
+            t = cv(5, t, n0, n1, 192, 3, 1, "VALID", cat_p3(STEM[5]), tag)
+            t = mp(6, t, n0, n1, cat_p3(STEM[6]), tag)
+        for name, t in zip(STEM, full):
+            done(name, t)
+        net = full[-1]
+    else:
+        net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
+        if done("Conv2d_1a_3x3", net): return net
+        net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
+        if done("Conv2d_2a_3x3", net): return net
+        net = conv(net, "Conv2d_2b_3x3", 64, 3, 1, "SAME")
+        if done("Conv2d_2b_3x3", net): return net
+        net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_3a_3x3")
+        if done("MaxPool_3a_3x3", net): return net
+        net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID", mid=final_endpoint != "Conv2d_3b_1x1")
+        if done("Conv2d_3b_1x1", net): return net
+        net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID", mid=cat_p3("Conv2d_4a_3x3") and final_endpoint != "Conv2d_4a_3x3")
+        if done("Conv2d_4a_3x3", net): return net
+        net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3", **({"p3": True} if cat_p3("MaxPool_5a_3x3") else {}))
+        if done("MaxPool_5a_3x3", net): return net
 
     def mixed5(x, name, b1a, b1b, pool_depth):                  # inception_v3.py:137-204
         s = name + "/"
@@ -897,13 +948,14 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True, defer_preact=True):
+              math="f32", lanes=True, p3=True, defer_preact=True, stem_chunks=1):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere."""
     dtype = DTYPES[dtype] if isinstance(dtype, str) else dtype
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     b.use_lanes = bool(lanes)
+    b.stem_chunks = int(stem_chunks)      # Inception: the seven stem layers over this many slices of the batch in turn
     b.use_p3 = b.use_p3 and bool(p3)
     b.defer_preact = b.defer_preact and bool(defer_preact)      # (A/B switch: False = every pre-activation stored)
     if isinstance(p3, (set, frozenset, list, tuple)):
