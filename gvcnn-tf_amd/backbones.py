@@ -69,11 +69,6 @@ class TRef:
         assert not self.p3 or (lo % 16 == 0 and hi % 16 == 0), "a three-plane tensor is sliced on 16-channel groups"
         return TRef(self.vbuf, self.off + lo, self.nb, self.h, self.w, hi - lo, self.ld, self.p3)
 
-    def images(self, lo, hi):
-        """Images [lo, hi) of the batch: the same tensor, fewer of its (contiguous) images."""
-        assert 0 <= lo < hi <= self.nb
-        return TRef(self.vbuf, self.off + lo * self.h * self.w * self.ld, hi - lo, self.h, self.w, self.c, self.ld, self.p3)
-
     @property
     def npix(self):
         return self.nb * self.h * self.w
@@ -125,6 +120,9 @@ class BackbonePlan:
         # (gv_conv2d_fwd_xpre) instead of being stored by the unit before it: that conv3 is HBM-bound and writes 9 instead
         # of 13 channel-quanta per pixel.  Off: the second-output form everywhere (A/B switch; fp32 storage always)
         self.defer_preact = dtype != _lib.GV_F32
+        # 16-bit storage: Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch that writes only the pooled tensor
+        # (GV_CONV_MAXPOOL3S2); off: the two launches (A/B switch)
+        self.fuse_maxpool = dtype != _lib.GV_F32
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -161,10 +159,6 @@ class BackbonePlan:
         return nbytes // 4
 
     def _filter(self, name, kh, kw, cin, cout):
-        for f in self.filters:                       # the same layer over another slice of the batch (stem_chunks)
-            if f[0] == name:
-                assert f[1:5] == (kh, kw, cin, cout), name
-                return f[5]
         n = self._packed_elems(kh, kw, cin, cout)
         off = self.w_elems
         self.filters.append((name, kh, kw, cin, cout, off))
@@ -239,21 +233,26 @@ class BackbonePlan:
         return outs
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
-             residual=None, next_preact=None, p3=False, defer=False, op_name=None):
+             residual=None, next_preact=None, p3=False, defer=False, maxpool=False):
         """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
         norm = None -> biases, no BN (normalizer_fn=None).  next_preact = (bn_scope, eps) adds the
         second output relu(bn(out)) and returns (out, preact); with defer=True no second output is written and
-        `preact` is a DeferredPreact(out, scale/shift offsets) that a 1x1 unpadded conv accepts as its input."""
+        `preact` is a DeferredPreact(out, scale/shift offsets) that a 1x1 unpadded conv accepts as its input.
+        maxpool: the layer is followed by max_pool2d 3x3 / 2 VALID and nobody else reads it — ONE launch writes the
+        pooled tensor (GV_CONV_MAXPOOL3S2; the caller checks `fused_maxpool_ok` first), which is what is returned."""
         xpre = None
         if isinstance(x, DeferredPreact):
             x, xpre = x.t, (x.scale_off, x.shift_off)
         kh, kw = (k, k) if isinstance(k, int) else k
         oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
         ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
-        if out is None:
+        if maxpool:
+            assert out is None and residual is None and next_preact is None and relu and xpre is None and not p3
+            out = self.new_tensor(x.nb, (oh - 3) // 2 + 1, (ow - 3) // 2 + 1, cout)
+        elif out is None:
             # p3: the output only feeds other convolutions (a conv -> conv intermediate)
             out = self.new_tensor(x.nb, oh, ow, cout, p3=p3 and next_preact is None and residual is None and x.c >= 16)
-        assert (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, cout), (scope, out, oh, ow, cout)
+        assert maxpool or (out.nb, out.h, out.w, out.c) == (x.nb, oh, ow, cout), (scope, out, oh, ow, cout)
         w_off = self._filter(scope + "/weights", kh, kw, x.c, cout)
         if norm is not None:
             so, ho = self._scale_shift("bn", scope + "/BatchNorm", cout, norm[1], norm[2])
@@ -269,16 +268,24 @@ class BackbonePlan:
             assert kh == kw == 1 and pad_t == 0 and pad_l == 0 and self.dtype != _lib.GV_F32, scope
         if residual is not None:
             assert (residual.nb, residual.h, residual.w, residual.c) == (x.nb, oh, ow, cout)
-        self._record(dict(kind="conv", name=op_name or scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
+        self._record(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
-                             split=0, cout=cout, xpre=xpre,
+                             split=0, cout=cout, xpre=xpre, maxpool=bool(maxpool), oh=oh, ow=ow,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
                              bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout *
                                                       (1 + (residual is not None) + (y2 is not None)))))
         if next_preact is not None:
             return (out, DeferredPreact(out, s2, h2) if defer else y2)
         return out
+
+    def fused_maxpool_ok(self, x, cout, k, padding):
+        """May `conv(x, ..., cout, k, padding=..., maxpool=True)` be one launch?  The class GV_CONV_MAXPOOL3S2 serves
+        (include/gvcnn_hip.h): 16-bit storage, 3x3 / stride 1 from 32 to 64 channels, a map of at least 3 x 3."""
+        oh = _out_size(x.h, 3, 1, padding)[0]
+        ow = _out_size(x.w, 3, 1, padding)[0]
+        return (self.fuse_maxpool and self.dtype != _lib.GV_F32 and k == 3 and x.c == 32 and cout == 64 and x.ld % 8 == 0 and
+                not x.p3 and min(oh, ow) >= 3)
 
     def pool(self, x, k, stride, padding, mode, out=None, name="pool", p3=False):
         oh, pad_t = _out_size(x.h, k, stride, padding)
@@ -396,8 +403,10 @@ class BackbonePlan:
                 if y2 is not None and y2.p3:
                     assert split, "a three-plane second destination exists only for fused sibling convs"
                     flags |= _lib.GV_CONV_Y2_P3
+                if op.get("maxpool"):
+                    flags |= _lib.GV_CONV_MAXPOOL3S2          # y is the pooled tensor; oh / ow stay the convolution's
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
-                                  op["pad_t"], op["pad_l"], y.h, y.w, op["cout"], y.ld,
+                                  op["pad_t"], op["pad_l"], op.get("oh", y.h), op.get("ow", y.w), op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
                                   flags, self.dtype, split, op.get("tile", 0), self.math_mode, 0,
                                   op.get("relu_cols", 0))
@@ -558,7 +567,7 @@ class BackbonePlan:
     def apply_tiles(self, table):
         """Install a previously measured {op name: tile configuration} table (no launches)."""
         for i, op in enumerate(self.ops):
-            if op["kind"] == "conv" and op["name"] in table:
+            if op["kind"] == "conv" and op["name"] in table and not op.get("maxpool"):   # (one kernel serves that form)
                 op["tile"] = int(table[op["name"]]) + 1
                 _lib.check(self.lib.gv_plan_set_conv_tile(self._plan, i, op["tile"]), "gv_plan_set_conv_tile")
 
@@ -725,62 +734,24 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
             b.keep(t)
         return name == final_endpoint
 
-    STEM = ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3", "MaxPool_3a_3x3", "Conv2d_3b_1x1", "Conv2d_4a_3x3",
-            "MaxPool_5a_3x3")
-    chunks = min(int(getattr(b, "stem_chunks", 1) or 1), b.input.nb)
-    if chunks > 1 and final_endpoint not in STEM and not any(k in STEM for k in keep):
-        # The stem in slices of the batch, slice by slice through all seven layers: a layer's output (0.4-1.5 MB per image
-        # at 16 bits) is read back by the next layer while it is still in the 256 MiB Infinity Cache instead of after the
-        # whole batch (hundreds of MB) has passed through it.  Same kernels, same values; `stem_chunks` is a speed choice.
-        full = [None] * len(STEM)
-
-        def dst(i, x, cout, k, stride, padding, p3):
-            if full[i] is None:
-                oh, ow = _out_size(x.h, k, stride, padding)[0], _out_size(x.w, k, stride, padding)[0]
-                full[i] = b.new_tensor(b.input.nb, oh, ow, cout, p3=p3 and x.c >= 16)
-            return full[i]
-
-        def mid_p3(name):
-            return b.use_p3 and (b.p3_blocks is None or name in b.p3_blocks)
-
-        def cv(i, x, n0, n1, cout, k, stride, padding, p3, tag):
-            out = dst(i, x, cout, k, stride, padding, p3).images(n0, n1)
-            return b.conv(x, scope + "/" + STEM[i], cout, k, stride, padding, out=out, norm=BN, relu=True,
-                          op_name=scope + "/" + STEM[i] + tag)
-
-        def mp(i, x, n0, n1, p3, tag):
-            out = dst(i, x, x.c, 3, 2, "VALID", p3).images(n0, n1)
-            return b.pool(x, 3, 2, "VALID", MAX, out=out, name=STEM[i] + tag)
-
-        nb = b.input.nb
-        for ck in range(chunks):
-            n0, n1 = nb * ck // chunks, nb * (ck + 1) // chunks
-            tag = "" if ck == 0 else "@%d" % ck
-            t = cv(0, b.input.images(n0, n1), n0, n1, 32, 3, 2, "VALID", False, tag)
-            t = cv(1, t, n0, n1, 32, 3, 1, "VALID", mid_p3(STEM[1]), tag)
-            t = cv(2, t, n0, n1, 64, 3, 1, "SAME", False, tag)
-            t = mp(3, t, n0, n1, False, tag)
-            t = cv(4, t, n0, n1, 80, 1, 1, "VALID", mid_p3(STEM[4]), tag)
-            t = cv(5, t, n0, n1, 192, 3, 1, "VALID", cat_p3(STEM[5]), tag)
-            t = mp(6, t, n0, n1, cat_p3(STEM[6]), tag)
-        for name, t in zip(STEM, full):
-            done(name, t)
-        net = full[-1]
+    net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
+    if done("Conv2d_1a_3x3", net): return net
+    net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
+    if done("Conv2d_2a_3x3", net): return net
+    if (final_endpoint != "Conv2d_2b_3x3" and "Conv2d_2b_3x3" not in keep and b.fused_maxpool_ok(net, 64, 3, "SAME")):
+        # inception_v3.py:111-113 as ONE launch: the un-pooled Conv2d_2b_3x3 is never written (nobody taps it)
+        net = b.conv(net, scope + "/Conv2d_2b_3x3", 64, 3, 1, "SAME", norm=BN, relu=True, maxpool=True)
     else:
-        net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
-        if done("Conv2d_1a_3x3", net): return net
-        net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
-        if done("Conv2d_2a_3x3", net): return net
         net = conv(net, "Conv2d_2b_3x3", 64, 3, 1, "SAME")
         if done("Conv2d_2b_3x3", net): return net
         net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_3a_3x3")
-        if done("MaxPool_3a_3x3", net): return net
-        net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID", mid=final_endpoint != "Conv2d_3b_1x1")
-        if done("Conv2d_3b_1x1", net): return net
-        net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID", mid=cat_p3("Conv2d_4a_3x3") and final_endpoint != "Conv2d_4a_3x3")
-        if done("Conv2d_4a_3x3", net): return net
-        net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3", **({"p3": True} if cat_p3("MaxPool_5a_3x3") else {}))
-        if done("MaxPool_5a_3x3", net): return net
+    if done("MaxPool_3a_3x3", net): return net
+    net = conv(net, "Conv2d_3b_1x1", 80, 1, 1, "VALID", mid=final_endpoint != "Conv2d_3b_1x1")
+    if done("Conv2d_3b_1x1", net): return net
+    net = conv(net, "Conv2d_4a_3x3", 192, 3, 1, "VALID", mid=cat_p3("Conv2d_4a_3x3") and final_endpoint != "Conv2d_4a_3x3")
+    if done("Conv2d_4a_3x3", net): return net
+    net = b.pool(net, 3, 2, "VALID", MAX, name="MaxPool_5a_3x3", **({"p3": True} if cat_p3("MaxPool_5a_3x3") else {}))
+    if done("MaxPool_5a_3x3", net): return net
 
     def mixed5(x, name, b1a, b1b, pool_depth):                  # inception_v3.py:137-204
         s = name + "/"
@@ -948,16 +919,16 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True, defer_preact=True, stem_chunks=1):
+              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere."""
     dtype = DTYPES[dtype] if isinstance(dtype, str) else dtype
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     b.use_lanes = bool(lanes)
-    b.stem_chunks = int(stem_chunks)      # Inception: the seven stem layers over this many slices of the batch in turn
     b.use_p3 = b.use_p3 and bool(p3)
     b.defer_preact = b.defer_preact and bool(defer_preact)      # (A/B switch: False = every pre-activation stored)
+    b.fuse_maxpool = b.fuse_maxpool and bool(fuse_maxpool)      # (A/B switch: False = Conv2d_2b and MaxPool_3a as two launches)
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:

@@ -568,10 +568,19 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
         }
     }
 
+    if (d->flags & GV_CONV_MAXPOOL3S2) {
+        // conv -> max_pool2d 3x3 / 2 VALID in one launch: y is the pooled tensor (the halo kernel's class only)
+        if (!lp || split || y2 || residual || stats || xscale || d->y_step != 0 || a.dil_shift || d->oh < 3 || d->ow < 3)
+            return GV_E_UNSUPPORTED;
+        a.pool = 1;
+        a.ph = (d->oh - 3) / 2 + 1;
+        a.pw = (d->ow - 3) / 2 + 1;
+    }
     if (lp) {
         // vector loader: 8-channel (16-byte) chunks inside one filter tap, 16-byte aligned pixels
         const bool xf32 = (d->flags & GV_CONV_X_F32) != 0;
         const bool generic = xf32 || (d->cin % 8 != 0) || (d->x_ld % 8 != 0) || !gv_aligned16(x);
+        if (a.pool && !gvconv::lp_halo_pool_ok(a, generic)) return GV_E_UNSUPPORTED;
         if (a.dil_shift && generic) return GV_E_UNSUPPORTED;
         // the vector loader keeps 32-bit element offsets
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;
@@ -587,7 +596,7 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
         }
         const int cfg = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1
-                           : ((gvconv::lp_halo_ok(a, generic) || gvconv::lp_stem_ok(a, xf32)) && a.M >= 100000
+                           : ((gvconv::lp_halo_ok(a, generic) || gvconv::lp_stem_ok(a, xf32)) && (a.M >= 100000 || a.pool)
                                   ? gvconv::lp_special_cfg()
                                                                               : gvconv::lp_pick_tile(a.M, a.cout, a.K)));
         return gvconv::lp_launch(d->dtype, cfg, a, generic, xf32, (hipStream_t)stream);

@@ -397,9 +397,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? (TM * TN <= 4 && STAT
 // per output row.
 // CIN: 32 (Conv2d_2a / 2b forward) or 64 (the data gradient of Conv2d_2b: 64 -> 32 channels over the padded map; filter of
 // 9 x 64 values per output channel in LDS).
-template <typename T, int TN, int RPW, int CIN = 32, int STATS = 0>
+// POOL (GV_CONV_MAXPOOL3S2; Conv2d_2b_3x3 -> MaxPool_3a_3x3, nets/inception_v3.py:111-113): the 3x3 / 2 VALID max pool of the
+// output is taken inside the workgroup and only the pooled tensor is written (a quarter of the bytes; the pool's launch,
+// which re-read all of them, disappears).  A strip advances 30 columns (15 pooled ones; the same number of strips as
+// 32-column strips for the 109- and 147-wide maps).  After the scale / shift / ReLU each wave reduces its rows
+// horizontally on the way out of its staging block (pooled pixel p = max over pixels 2p .. 2p+2; rounding to the storage
+// type is monotone, so max-then-round equals the pool of the rounded tensor bit for bit) into an LDS image of the tile's
+// 8 rows; after a barrier all threads take the vertical maxima on the packed words (values are >= 0 or -0.0: signed
+// 16-bit max orders them as the floats) — pooled rows 4k .. 4k+2 of tile k at once, row 4k+3 when the first row of tile
+// k+1 exists (the partial maximum waits in a register of the thread that owns the chunk).
+template <typename T, int TN, int RPW, int CIN = 32, int STATS = 0, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
+    static_assert(!POOL || (TN == 2 && RPW == 2 && CIN == 32 && STATS == 0), "the pooled form: Conv2d_2b's class");
     constexpr int TH = 4 * RPW, TW = 32, HH = TH + 2, HW = TW + 2, PB = CIN * 2 + 16;   // halo pixel + 16 B pad
+    constexpr int PSTEP = 30, PPX = 15, XROW = 2 * PPX * 32 * 2;             // POOL: columns per strip, pooled pixels, bytes
+                                                                              // of one reduced row [column tile][pixel][32]
     constexpr int CPP = CIN / 8, KS = CIN / 16;                               // 16-byte chunks / MFMA k-steps per pixel
     constexpr int NCH = HH * HW * CPP;                                        // 16-byte chunks of one halo
     constexpr int SL = (NCH + 255) / 256;
@@ -416,9 +428,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
     float* stage = reinterpret_cast<float*>(smem_raw + (ALIAS ? 0 : HH * HW * PB)) + (threadIdx.x >> 6) * (32 * SW);
     char* sW = smem_raw + HH * HW * PB + (ALIAS ? 0 : 4 * 32 * SW * 4);       // [32*TN][WB]   (!BREG)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int tiles_x = (a.ow + TW - 1) / TW;
+    const int tiles_x = POOL ? (a.pw + PPX - 1) / PPX : (a.ow + TW - 1) / TW;
     const int n = blockIdx.x / tiles_x;
-    const int ox0 = (blockIdx.x % tiles_x) * TW;
+    const int ox0 = (blockIdx.x % tiles_x) * (POOL ? PSTEP : TW);
+    const int oh_run = POOL ? 2 * a.ph + 1 : a.oh;                            // output rows somebody needs
+    char* sX = sW + 32 * TN * WB;                                             // [8][XROW]   (POOL)
+    u32x4 carry = {0u, 0u, 0u, 0u};
     const unsigned short* xs = reinterpret_cast<const unsigned short*>(a.x);
     const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.w);
     const unsigned short* res = reinterpret_cast<const unsigned short*>(a.res);
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
         }
     };
     fetch(0);
-    for (int oy0 = 0; oy0 < a.oh; oy0 += TH) {
+    for (int oy0 = 0; oy0 < oh_run; oy0 += TH) {
         __syncthreads();                                   // previous tile: fragment reads and staging done
 #pragma unroll
         for (int k = 0; k < SL; ++k) {
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
             if (idx < NCH) *reinterpret_cast<u32x4*>(sH + (idx / CPP) * PB + (idx % CPP) * 16) = hr[k];
         }
         __syncthreads();
-        if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under the MFMAs below
+        if (oy0 + TH < oh_run) fetch(oy0 + TH);            // in flight under the MFMAs below
         // STAT_BWD: the z chunks this tile's epilogue will need, requested here so that they too travel under the MFMAs
         // (fetched inside the epilogue every row-chunk waited out a memory round trip: Conv2d_2a's data gradient 0.145 ->
         // 0.29 ms instead of -> 0.19)
@@ -537,6 +552,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
             }
         }
         if constexpr (ALIAS) __syncthreads();              // every wave has read its fragments: the halo becomes staging
+        if constexpr (POOL) {
+            const int pp = lane >> 2;                      // this lane's pooled pixel of the strip (15: none)
+#pragma unroll
+            for (int qj = 0; qj < RPW * TN; ++qj) {
+                const int q = qj / TN, j = qj % TN;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[q][j][r];
+                __builtin_amdgcn_wave_barrier();
+                if (pp < PPX) {
+                    float mx[8];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int row = 2 * pp + t;
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v[e] = fmaxf(v[e] * sc[j][e] + sh[j][e], 0.f);
+                            mx[e] = t == 0 ? v[e] : fmaxf(mx[e], v[e]);
+                        }
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(mx[2 * e], mx[2 * e + 1]);
+                    *reinterpret_cast<u32x4*>(sX + (wave + 4 * q) * XROW + (j * PPX + pp) * 64 + (lane & 3) * 16) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();                               // the tile's 8 reduced rows are in sX
+            auto pkmax = [](u32x4 p, u32x4 q_) {
+                u32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm("v_pk_max_i16 %0, %1, %2" : "=v"(r[e]) : "v"(p[e]), "v"(q_[e]));
+                return r;
+            };
+            const int kt = oy0 / TH;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int c = tid + it * 256;              // chunk (pooled row of the tile, column tile, pixel, 8 channels)
+                if (c >= 4 * 2 * PPX * 4) continue;
+                const int rsel = c / (2 * PPX * 4), cc = c - rsel * (2 * PPX * 4);
+                const int pc = ox0 / 2 + (cc % (PPX * 4)) / 4;
+                const char* xp = sX + cc * 16;
+                unsigned short* yp = y + ((size_t)n * a.ph * a.pw + pc) * a.y_ld + (cc / (PPX * 4)) * 32 + (cc & 3) * 8;
+                if (rsel < 3) {
+                    const int pr = 4 * kt + rsel;
+                    const u32x4 m = pkmax(pkmax(*reinterpret_cast<const u32x4*>(xp + (2 * rsel) * XROW),
+                                                *reinterpret_cast<const u32x4*>(xp + (2 * rsel + 1) * XROW)),
+                                          *reinterpret_cast<const u32x4*>(xp + (2 * rsel + 2) * XROW));
+                    if (pr < a.ph && pc < a.pw) *reinterpret_cast<u32x4*>(yp + (size_t)pr * a.pw * a.y_ld) = m;
+                } else {
+                    const int pr = 4 * kt - 1;             // the row whose third input row is this tile's first
+                    if (kt > 0 && pr < a.ph && pc < a.pw)
+                        *reinterpret_cast<u32x4*>(yp + (size_t)pr * a.pw * a.y_ld) =
+                            pkmax(carry, *reinterpret_cast<const u32x4*>(xp));
+                    carry = pkmax(*reinterpret_cast<const u32x4*>(xp + 6 * XROW), *reinterpret_cast<const u32x4*>(xp + 7 * XROW));
+                }
+            }
+            continue;
+        }
         // transposing epilogue (see lp_epilogue_staged): accumulators -> private LDS block -> 8 channels per lane
 #pragma unroll
         for (int qj = 0; qj < RPW * TN; ++qj) {
@@ -901,6 +977,18 @@ int launch_halo_r(const ConvArgs& a, hipStream_t st) {
     return GV_OK;
 }
 
+// GV_CONV_MAXPOOL3S2: 27 KB halo (staging aliased) + 38 KB filter + 15 KB of reduced rows = 80 448 B: two per CU
+template <typename T>
+int launch_halo_pool(const ConvArgs& a, hipStream_t st) {
+    const int tiles_x = (a.pw + 14) / 15;
+    const size_t lds = (size_t)10 * 34 * 80 + 64 * (288 * 2 + 16) + 8 * (2 * 15 * 32 * 2);
+    const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_lp<T, 2, 2, 32, 0, true>), 160 * 1024);
+    if (!ok) return GV_E_UNSUPPORTED;
+    hipLaunchKernelGGL((conv3x3_halo_lp<T, 2, 2, 32, 0, true>), dim3((unsigned)(a.nb * tiles_x)), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 template <typename T, int STATS>
 int launch_halo64(const ConvArgs& a, hipStream_t st) {                       // 64 input channels, <= 32 output channels
     const int tiles_x = (a.ow + 31) / 32;
@@ -923,6 +1011,7 @@ int launch_halo_s(const ConvArgs& a, hipStream_t st) {
 
 template <typename T>
 int launch_halo(const ConvArgs& a, hipStream_t st) {
+    if (a.pool) return launch_halo_pool<T>(a, st);
     if (a.st.mode == gvconv::STAT_FWD) return launch_halo_s<T, gvconv::STAT_FWD>(a, st);
     // The BACKWARD sums are not folded into this kernel: they need z next to every chunk of dy it stores, and one wave per
     // SIMD with its loads retiring in order has nothing to hide 290 MB of extra reads behind — measured on the data
@@ -999,10 +1088,18 @@ int lp_pick_tile(int M, int N, int /*K*/) {
     return best;
 }
 
+// GV_CONV_MAXPOOL3S2: the halo kernel's 32 -> 64 channel form with a plain ReLU epilogue into aligned 16-byte chunks
+bool lp_halo_pool_ok(const ConvArgs& a, bool generic) {
+    return lp_halo_ok(a, generic) && a.cin == 32 && a.cout == 64 && a.relu && a.relu_limit >= a.cout && a.res == nullptr &&
+           a.st.mode == STAT_OFF && a.y_step == 0 && a.xscale == nullptr && a.oh >= 3 && a.ow >= 3 && a.y_ld % 8 == 0 &&
+           (((uintptr_t)a.y) & 15) == 0;
+}
+
 int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     ConvArgs a = a0;
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
+    if (a.pool && (cfg != kNumTiles || !lp_halo_pool_ok(a, generic))) return GV_E_UNSUPPORTED;
     if (cfg == kNumTiles) {
         if (a.y_step != 0) return GV_E_UNSUPPORTED;              // (the strip / halo kernels have no two-level output stride)
         // BatchNorm sums: one segment over every output column (these kernels own whole images: no slot table)

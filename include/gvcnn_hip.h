@@ -55,6 +55,13 @@ extern "C" {
 #define GV_CONV_Y_P3 32       /* same dtype / math mode: y is written in that three-plane layout (y_ld, the slice offset
                                  and cout — with GV_CONV_SPLIT split_col — multiples of 16 channels); residual stays fp32 */
 #define GV_CONV_Y2_P3 64      /* GV_CONV_SPLIT only: the second destination (columns >= split_col) is three-plane */
+#define GV_CONV_MAXPOOL3S2 128 /* the convolution is followed by the reference's max_pool2d 3x3 / stride 2 / VALID
+                                 (nets/inception_v3.py:113, Conv2d_2b_3x3 -> MaxPool_3a_3x3) and only the POOLED tensor is
+                                 written: y is [nb, (oh-3)/2+1, (ow-3)/2+1, cout] with pixel stride y_ld; oh / ow stay the
+                                 convolution's own output size.  Bit-identical to gv_conv2d_fwd + gv_pool2d.  Served for
+                                 the halo-kernel class only (16-bit storage, 3x3 / stride 1, cin 32, cout 64, GV_CONV_RELU
+                                 on every column, no residual / second output / BatchNorm sums, oh, ow >= 3):
+                                 GV_E_UNSUPPORTED otherwise, and the caller issues the two launches */
 
 /* gv_conv_desc.math_mode: how an fp32 convolution is evaluated on the matrix cores */
 #define GV_MATH_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                         */

@@ -66,7 +66,8 @@ def pack(w, code):
 
 
 def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, second=None, split=0,
-             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0, xpre=None, tile_cfg=0, expect=None):
+             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0, xpre=None, tile_cfg=0, expect=None, pooled=None):
+    """pooled = (ph, pw): GV_CONV_MAXPOOL3S2 — the destination is the pooled tensor, out_hw stays the convolution's."""
     code, td, _ = TYPES[ty]
     nb, ih, iw, cin = x.shape
     kh, kw, _, cout = w.shape
@@ -78,7 +79,7 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
     xb[..., x_off:x_off + cin] = x
     xd = xb.to(DEV) if x_f32 else xb.to(td).to(DEV)
     xes = 4 if x_f32 else 2
-    yd = torch.full((nb, oh, ow, y_ld), -77.0, dtype=td, device=DEV)
+    yd = torch.full((nb,) + (tuple(pooled) if pooled else (oh, ow)) + (y_ld,), -77.0, dtype=td, device=DEV)
     n2 = cout - split if split else cout
     y2d = torch.full((nb, oh, ow, n2), -55.0, dtype=td, device=DEV) if (second or split) else None
     wp = pack(w, code)
@@ -87,7 +88,8 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
     sh2 = second[1].to(DEV) if second else None
     rd = residual.to(td).to(DEV).contiguous() if residual is not None else None
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0) | \
-            (_lib.GV_CONV_SPLIT if split else 0) | (_lib.GV_CONV_X_F32 if x_f32 else 0)
+            (_lib.GV_CONV_SPLIT if split else 0) | (_lib.GV_CONV_X_F32 if x_f32 else 0) | \
+            (_lib.GV_CONV_MAXPOOL3S2 if pooled else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
                       cout if residual is not None else 0, n2 if y2d is not None else 0, flags, code, split, tile_cfg, 0, 0)
     if xpre is not None:                    # the input is read as relu(x * xscale + xshift) (gv_conv2d_fwd_xpre)
@@ -410,6 +412,79 @@ def test_lp_conv_split_output(ty):
     ref = oracle_conv(x, w, 1, "SAME", scale, shift, True).numpy()
     close(y, ref[..., :64], ulp)
     close(y2, ref[..., 64:], ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("pad,hw,nb", [(1, (109, 109), 2), (1, (147, 147), 1), (1, (19, 23), 3), (0, (5, 5), 2), (1, (3, 3), 2),
+                                       (0, (12, 37), 3), (1, (8, 64), 2), (1, (16, 31), 2), (0, (11, 95), 1), (1, (9, 33), 2)])
+def test_lp_conv_maxpool_one_launch(ty, pad, hw, nb):
+    """GV_CONV_MAXPOOL3S2 (Conv2d_2b_3x3 -> MaxPool_3a_3x3, nets/inception_v3.py:111-113, as ONE launch that writes only the
+    pooled tensor): bit for bit the two launches — the same halo kernel followed by gv_pool2d — and, through them, the
+    oracle's conv -> max_pool2d; maps whose pooled width is / is not a multiple of the 15 pooled columns of a strip and whose
+    height ends inside a tile, VALID and SAME, into a channel slice of a wider buffer (nothing else is written)."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(hw[0] * 1000 + hw[1] + pad)
+    ih, iw = hw
+    x = rnd(torch.randn(nb, ih, iw, 32, generator=g), td)
+    w = rnd(torch.randn(3, 3, 32, 64, generator=g) * 0.06, td)
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
+    ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
+    y = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, tile=special_tile())
+    two = run_pool(torch.from_numpy(y), 3, 2, (0, 0), (ph, pw), _lib.GV_POOL_MAX, ty)
+    ref = OB.max_pool2d(oracle_conv(x, w, 1, "SAME" if pad else "VALID", scale, shift, True), 3, 2, "VALID")
+    close(two, ref.numpy(), ulp)
+    for tile_cfg, tile in ((0, None), (special_tile() + 1, None), (0, special_tile())):     # heuristic, plan's choice, override
+        one = run_conv(x, w, 1, (pad, pad), (oh, ow), scale, shift, True, ty, tile=tile, tile_cfg=tile_cfg, y_ld=64 + 16, y_off=8,
+                       pooled=(ph, pw))
+        assert np.array_equal(one, two), (tile_cfg, tile, np.abs(one - two).max())
+
+
+def test_lp_conv_maxpool_declines_what_it_does_not_serve():
+    """Outside the halo kernel's 32 -> 64 channel ReLU class the flag is refused and nothing is written (the plan builder
+    then issues the two launches): another tile, no ReLU, a residual, other channel counts, a 2 x 2 map, fp32 storage."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 12, 14, 32, generator=g)
+    w = torch.randn(3, 3, 32, 64, generator=g) * 0.06
+    sc, sh = torch.ones(64), torch.zeros(64)
+    U = _lib.GV_E_UNSUPPORTED
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, True, "bf16", tile=0, pooled=(5, 6), expect=U)
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, True, "bf16", tile=dma_tiles()[0], pooled=(5, 6), expect=U)
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, False, "bf16", pooled=(5, 6), expect=U)
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, True, "bf16", residual=torch.zeros(2, 12, 14, 64), pooled=(5, 6), expect=U)
+    run_conv(x, w[..., :32], 1, (1, 1), (12, 14), sc[:32], sh[:32], True, "bf16", pooled=(5, 6), expect=U)
+    x64 = torch.randn(2, 12, 14, 64, generator=g)
+    run_conv(x64, torch.randn(3, 3, 64, 64, generator=g) * 0.05, 1, (1, 1), (12, 14), sc, sh, True, "bf16", pooled=(5, 6), expect=U)
+    run_conv(x[:, :4, :4], w, 1, (0, 0), (2, 2), sc, sh, True, "bf16", pooled=(1, 1), expect=U)
+
+
+@pytest.mark.parametrize("ty,size,nb", [("bf16", 107, 6), ("f16", 75, 4), ("bf16", 224, 24), ("f16", 299, 10)])
+def test_lp_inception_plan_with_and_without_the_fused_max_pool(ty, size, nb):
+    """The 16-bit Inception plan issues Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch (one op fewer, the un-pooled tensor
+    does not exist); with `fuse_maxpool=False` and the same kernel for Conv2d_2b the two launches give the same bits at
+    MaxPool_3a_3x3 and at Mixed_7c.  A tapped Conv2d_2b_3x3 keeps the two launches."""
+    from gvcnn_tf_amd import backbones
+    x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5).to(DEV)
+    outs, nops = [], []
+    for fuse in (True, False):
+        plan = backbones.make_plan("inception_v3", nb, size, size, DEV, dtype=ty, lanes=False, fuse_maxpool=fuse,
+                                   raw_tap="MaxPool_3a_3x3")          # (a kept tensor: its buffer is not recycled)
+        plan.bind(gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True))
+        names = [op["name"] for op in plan.ops]
+        assert ("MaxPool_3a_3x3" in names) == (not fuse)
+        if not fuse:
+            plan.apply_tiles({"InceptionV3/Conv2d_2b_3x3": special_tile()})
+        plan.run(x)
+        torch.cuda.synchronize()
+        outs.append({k: plan.view(plan.end_points[k]).clone() for k in ("MaxPool_3a_3x3", "Mixed_7c")})
+        nops.append(len(plan.ops))
+        assert ("Conv2d_2b_3x3" in plan.end_points) == (not fuse)
+    assert nops[0] == nops[1] - 1
+    for k in outs[0]:
+        assert outs[0][k].shape == outs[1][k].shape and torch.equal(outs[0][k], outs[1][k]), k
+    assert float(outs[0]["Mixed_7c"].float().abs().max()) > 1e-3
+    tapped = backbones.make_plan("inception_v3", nb, size, size, DEV, dtype=ty, lanes=False, raw_tap="Conv2d_2b_3x3")
+    assert "MaxPool_3a_3x3" in [op["name"] for op in tapped.ops]
 
 
 def run_pool(x, k, stride, pads, out_hw, mode, ty, x_ld=None, y_ld=None, y_off=0):
