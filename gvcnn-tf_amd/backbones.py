@@ -247,8 +247,13 @@ class BackbonePlan:
         oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
         ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
         if maxpool:
-            assert out is None and residual is None and next_preact is None and relu and xpre is None and not p3
-            out = self.new_tensor(x.nb, (oh - 3) // 2 + 1, (ow - 3) // 2 + 1, cout)
+            assert out is None and residual is None and next_preact is None and xpre is None and not p3
+            maxpool = "VALID" if maxpool is True else maxpool
+            if maxpool == "SAME":
+                assert oh % 2 == 0 and ow % 2 == 0
+                out = self.new_tensor(x.nb, oh // 2, ow // 2, cout)
+            else:
+                out = self.new_tensor(x.nb, (oh - 3) // 2 + 1, (ow - 3) // 2 + 1, cout)
         elif out is None:
             # p3: the output only feeds other convolutions (a conv -> conv intermediate)
             out = self.new_tensor(x.nb, oh, ow, cout, p3=p3 and next_preact is None and residual is None and x.c >= 16)
@@ -271,21 +276,29 @@ class BackbonePlan:
         self._record(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
-                             split=0, cout=cout, xpre=xpre, maxpool=bool(maxpool), oh=oh, ow=ow,
+                             split=0, cout=cout, xpre=xpre, maxpool=maxpool or None, oh=oh, ow=ow,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
-                             bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout + x.nb * oh * ow * cout *
-                                                      (1 + (residual is not None) + (y2 is not None)))))
+                             bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout +
+                                                      (out.npix * cout if maxpool else x.nb * oh * ow * cout *
+                                                       (1 + (residual is not None) + (y2 is not None))))))
         if next_preact is not None:
             return (out, DeferredPreact(out, s2, h2) if defer else y2)
         return out
 
-    def fused_maxpool_ok(self, x, cout, k, padding):
-        """May `conv(x, ..., cout, k, padding=..., maxpool=True)` be one launch?  The class GV_CONV_MAXPOOL3S2 serves
-        (include/gvcnn_hip.h): 16-bit storage, 3x3 / stride 1 from 32 to 64 channels, a map of at least 3 x 3."""
-        oh = _out_size(x.h, 3, 1, padding)[0]
-        ow = _out_size(x.w, 3, 1, padding)[0]
-        return (self.fuse_maxpool and self.dtype != _lib.GV_F32 and k == 3 and x.c == 32 and cout == 64 and x.ld % 8 == 0 and
-                not x.p3 and min(oh, ow) >= 3)
+    def fused_maxpool_ok(self, x, cout, k, padding, stride=1, pool_padding="VALID"):
+        """May `conv(x, ..., cout, k, stride, padding, maxpool=pool_padding)` be one launch?  The classes
+        GV_CONV_MAXPOOL3S2 / _SAME serve (include/gvcnn_hip.h), 16-bit storage: 3x3 / stride 1 from 32 to 64 channels
+        (VALID pool), or a 3x3 / 7x7 stride-2 stem on the fp32 images at 64 channels (VALID, or SAME on an even map)."""
+        pads = padding if isinstance(padding, tuple) else (padding, padding)
+        oh = _out_size(x.h, k, stride, pads[0])[0]
+        ow = _out_size(x.w, k, stride, pads[1])[0]
+        if not (self.fuse_maxpool and self.dtype != _lib.GV_F32 and cout == 64 and not x.p3 and min(oh, ow) >= 3):
+            return False
+        if pool_padding == "SAME" and (oh % 2 or ow % 2):
+            return False
+        if x.vbuf < 0:                                        # the network input: the stem strip kernel
+            return k in (3, 7) and stride == 2 and x.c == 3
+        return pool_padding == "VALID" and k == 3 and stride == 1 and x.c == 32 and x.ld % 8 == 0
 
     def pool(self, x, k, stride, padding, mode, out=None, name="pool", p3=False):
         oh, pad_t = _out_size(x.h, k, stride, padding)
@@ -403,8 +416,8 @@ class BackbonePlan:
                 if y2 is not None and y2.p3:
                     assert split, "a three-plane second destination exists only for fused sibling convs"
                     flags |= _lib.GV_CONV_Y2_P3
-                if op.get("maxpool"):
-                    flags |= _lib.GV_CONV_MAXPOOL3S2          # y is the pooled tensor; oh / ow stay the convolution's
+                if op.get("maxpool"):                         # y is the pooled tensor; oh / ow stay the convolution's
+                    flags |= _lib.GV_CONV_MAXPOOL3S2_SAME if op["maxpool"] == "SAME" else _lib.GV_CONV_MAXPOOL3S2
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], op.get("oh", y.h), op.get("ow", y.w), op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
@@ -856,9 +869,14 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
     BN = ("bn", RESNET_BN_EPS, True)
     MAX = _lib.GV_POOL_MAX
     # conv1: explicit pad 3 + VALID, bias, no BN/ReLU (resnet_v2.py:178-180, resnet_utils.py:94-105)
-    net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False)
-    b.end_points[scope + "/conv1"] = net
-    net = b.pool(net, 3, 2, "SAME", MAX, name=scope + "/pool1")                    # resnet_v2.py:181
+    if scope + "/conv1" not in keep and getattr(b, "fuse_maxpool", False) and \
+            b.fused_maxpool_ok(b.input, 64, 7, ((3, 3), (3, 3)), 2, "SAME"):
+        # conv1 -> pool1 (resnet_v2.py:178-181) as ONE launch: the un-pooled conv1 is never written (nobody taps it)
+        net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False, maxpool="SAME")
+    else:
+        net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False)
+        b.end_points[scope + "/conv1"] = net
+        net = b.pool(net, 3, 2, "SAME", MAX, name=scope + "/pool1")                    # resnet_v2.py:181
     units = []
     for bname, base, n_units, bstride in RESNET50_BLOCKS:
         for u in range(n_units):

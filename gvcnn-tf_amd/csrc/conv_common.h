@@ -38,8 +38,8 @@ struct ConvArgs {
     int y_py = 0, y_px = 0;     //    image (one parity class of a stride-2 data gradient; 16-bit staged epilogue only)
     int y_ih = 0, y_iw = 0;
     GvFastDiv y_div_img = {0, -1, 1}, y_div_row = {0, -1, 1};   //    exact m / (oh*ow) and rem / ow
-    int pool = 0;               // GV_CONV_MAXPOOL3S2 (conv3x3_halo_lp only): y is the 3x3 / 2 VALID max pool of the output,
-    int ph = 0, pw = 0;         //    ph x pw pixels per image
+    int pool = 0;               // GV_CONV_MAXPOOL3S2 (1) / _SAME (2; conv3x3_halo_lp: 1 only): y is the 3x3 / 2 max pool of the
+    int ph = 0, pw = 0;         //    output, ph x pw pixels per image
 };
 
 // May this launch take the lean 16-bit staged epilogue (conv_stats.h STAT_LEAN)?  dbg bit 2: always the full one (A/B).
@@ -124,6 +124,7 @@ bool lp_xpre_cfg_ok(int cfg);   // register-staged tiles instantiated with the p
 int lp_xpre_pick(int M, int N);
 bool lp_halo_ok(const ConvArgs& a, bool generic);
 bool lp_halo_pool_ok(const ConvArgs& a, bool generic);   // GV_CONV_MAXPOOL3S2
+bool lp_stem_pool_ok(const ConvArgs& a, bool xf32);       // GV_CONV_MAXPOOL3S2 / GV_CONV_MAXPOOL3S2_SAME
 bool lp_stem_ok(const ConvArgs& a, bool xf32);
 int lp_launch(int dtype, int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st);
 int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int dtype, void* out, hipStream_t st);

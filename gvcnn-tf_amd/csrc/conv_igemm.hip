@@ -568,19 +568,23 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
         }
     }
 
-    if (d->flags & GV_CONV_MAXPOOL3S2) {
-        // conv -> max_pool2d 3x3 / 2 VALID in one launch: y is the pooled tensor (the halo kernel's class only)
+    if (d->flags & (GV_CONV_MAXPOOL3S2 | GV_CONV_MAXPOOL3S2_SAME)) {
+        // conv -> max_pool2d 3x3 / 2 in one launch: y is the pooled tensor (the halo / stem strip kernels' classes only)
+        const bool same = (d->flags & GV_CONV_MAXPOOL3S2_SAME) != 0;
+        if (same && (d->flags & GV_CONV_MAXPOOL3S2)) return GV_E_BADARG;
         if (!lp || split || y2 || residual || stats || xscale || d->y_step != 0 || a.dil_shift || d->oh < 3 || d->ow < 3)
             return GV_E_UNSUPPORTED;
-        a.pool = 1;
-        a.ph = (d->oh - 3) / 2 + 1;
-        a.pw = (d->ow - 3) / 2 + 1;
+        if (same && ((d->oh | d->ow) & 1)) return GV_E_UNSUPPORTED;          // TF's SAME pads (0, 1) on an even map only
+        a.pool = same ? 2 : 1;
+        a.ph = same ? d->oh / 2 : (d->oh - 3) / 2 + 1;
+        a.pw = same ? d->ow / 2 : (d->ow - 3) / 2 + 1;
     }
     if (lp) {
         // vector loader: 8-channel (16-byte) chunks inside one filter tap, 16-byte aligned pixels
         const bool xf32 = (d->flags & GV_CONV_X_F32) != 0;
         const bool generic = xf32 || (d->cin % 8 != 0) || (d->x_ld % 8 != 0) || !gv_aligned16(x);
-        if (a.pool && !gvconv::lp_halo_pool_ok(a, generic)) return GV_E_UNSUPPORTED;
+        if (a.pool && !((a.pool == 1 && gvconv::lp_halo_pool_ok(a, generic)) || gvconv::lp_stem_pool_ok(a, xf32)))
+            return GV_E_UNSUPPORTED;
         if (a.dil_shift && generic) return GV_E_UNSUPPORTED;
         // the vector loader keeps 32-bit element offsets
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;

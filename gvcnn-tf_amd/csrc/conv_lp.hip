@@ -683,8 +683,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 // owns KR = 16 (3x3) or 24 (7x7) slots of which KW*3 are real — so the 8 values of an MFMA fragment are 8
 // CONSECUTIVE patch elements: four ds_read_b32 (lane stride 12 B: conflict-free), no per-element addressing at all.
 // The filter is re-ordered the same way into LDS once per workgroup.
-template <typename T, int TN, int KW, int STATS = 0>
+// POOL (GV_CONV_MAXPOOL3S2 / GV_CONV_MAXPOOL3S2_SAME; ResNet-v2's conv1 -> pool1, nets/resnet_v2.py:178-181): as in
+// conv3x3_halo_lp — strips advance 30 columns, each wave reduces its row horizontally on the way out of its staging block,
+// the vertical maxima are taken on the packed words after a barrier, the row that needs the next tile's first row waits in
+// a register.  Here the values are signed (conv1 has a bias and no activation), so the reduced rows hold ORDER KEYS
+// (bits ^ 0x7fff where the sign is set: signed 16-bit order = float order, -0 < +0), a missing row or column (TF's SAME
+// pads (0, 1) on an even map: the window is clipped) is the lowest key, and the store turns keys back into values.
+template <typename T, int TN, int KW, int STATS = 0, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
+    static_assert(!POOL || (TN == 2 && STATS == 0), "the pooled form: 64 output channels, no BatchNorm sums");
+    constexpr int PSTEP = 30, PPX = 15, XROW = 2 * PPX * 32 * 2;
     constexpr int KR = KW == 3 ? 16 : 24;                   // k slots per filter row (multiple of 8)
     constexpr int NG = (KW * KR / 8 + 1) / 2 * 2;           // 8-value groups, padded to whole 16-deep k-steps
     constexpr int PR = 3 * 2 + KW + 1;                      // patch rows (+1 zero row for the padding group)
@@ -699,9 +707,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
     float* stage = reinterpret_cast<float*>(smem_raw + PR * PITCH) + (threadIdx.x >> 6) * (32 * SW);
     char* sW = smem_raw + PR * PITCH + 4 * 32 * SW * 4;                       // [32*TN][WB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int tiles_x = (a.ow + 31) / 32;
+    const int tiles_x = POOL ? (a.pw + PPX - 1) / PPX : (a.ow + 31) / 32;
     const int n = blockIdx.x / tiles_x;
-    const int ox0 = (blockIdx.x % tiles_x) * 32;
+    const int ox0 = (blockIdx.x % tiles_x) * (POOL ? PSTEP : 32);
+    const int oh_run = POOL ? min(a.oh, 2 * a.ph + 1) : a.oh;                 // output rows somebody needs
+    char* sX = sW + 32 * TN * WB;                                             // [4][XROW]   (POOL)
+    u32x4 carry = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.w);
     unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
 
@@ -747,8 +758,29 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
             pr_[k] = v;
         }
     };
+    // order key <-> value of the two 16-bit elements of a word (an involution: the sign bit stays)
+    auto keyw = [](unsigned w) { const unsigned sg = (w >> 15) & 0x00010001u; return w ^ ((sg << 15) - sg); };
+    auto pkmax = [](u32x4 p, u32x4 q_) {
+        u32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm("v_pk_max_i16 %0, %1, %2" : "=v"(r[e]) : "v"(p[e]), "v"(q_[e]));
+        return r;
+    };
+    // POOL: this thread's chunk of a pooled row (column tile, pooled pixel, 8 channels): threads [0, 120) take the row a
+    // tile completes, threads [120, 240) the one that waits for the next tile
+    const int pcc = tid % (2 * PPX * 4), prs = tid / (2 * PPX * 4);
+    const int ppc = ox0 / 2 + (pcc % (PPX * 4)) / 4;
+    unsigned short* ypool = y + ((size_t)n * a.ph * a.pw + ppc) * a.y_ld + (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
+    auto put_pooled = [&](int prow, u32x4 k) {
+        if (prow < a.ph && ppc < a.pw) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = keyw(k[e]);
+            *reinterpret_cast<u32x4*>(ypool + (size_t)prow * a.pw * a.y_ld) = o;
+        }
+    };
     fetch(0);
-    for (int oy0 = 0; oy0 < a.oh; oy0 += 4) {
+    for (int oy0 = 0; oy0 < oh_run; oy0 += 4) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SL; ++k) {
@@ -759,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
             }
         }
         __syncthreads();
-        if (oy0 + 4 < a.oh) fetch(oy0 + 4);
+        if (oy0 + 4 < oh_run) fetch(oy0 + 4);
         f32x16 acc[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -781,6 +813,53 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
             }
         }
         const int oy = oy0 + wave;
+        if constexpr (POOL) {
+            const int pp = lane >> 2;                      // this lane's pooled pixel of the strip (15: none)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
+                __builtin_amdgcn_wave_barrier();
+                if (pp < PPX) {
+                    float mx[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx[e] = -__builtin_inff();
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int row = 2 * pp + t;
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
+                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        if (ox0 + row < a.ow) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                v[e] = v[e] * sc[j][e] + sh[j][e];
+                                if (a.relu && j * 32 + col8 + e < a.relu_limit) v[e] = fmaxf(v[e], 0.f);
+                                mx[e] = fmaxf(mx[e], v[e]);
+                            }
+                        }
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = oy < a.oh ? keyw(pack2<T>(mx[2 * e], mx[2 * e + 1])) : 0x80008000u;
+                    *reinterpret_cast<u32x4*>(sX + wave * XROW + (j * PPX + pp) * 64 + (lane & 3) * 16) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();                               // the tile's 4 reduced rows are in sX
+            const int kt = oy0 >> 2;
+            if (prs < 2) {
+                const char* xp = sX + pcc * 16;
+                const u32x4 x2 = *reinterpret_cast<const u32x4*>(xp + 2 * XROW);
+                if (prs == 0) {
+                    put_pooled(2 * kt, pkmax(pkmax(*reinterpret_cast<const u32x4*>(xp), *reinterpret_cast<const u32x4*>(xp + XROW)), x2));
+                } else {
+                    if (kt > 0) put_pooled(2 * kt - 1, pkmax(carry, *reinterpret_cast<const u32x4*>(xp)));
+                    carry = pkmax(x2, *reinterpret_cast<const u32x4*>(xp + 3 * XROW));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -815,6 +894,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+    if constexpr (POOL) {
+        // the row that was waiting for a tile that does not exist (SAME: its window ends with the map)
+        if (prs == 1) put_pooled(2 * ((oh_run + 3) >> 2) - 1, carry);
     }
     if constexpr (STATS != 0) sstat.finish(a.st, stage, lane, sgrp, a.cout);
 }
@@ -1031,8 +1114,19 @@ int launch_stem_one(const ConvArgs& a, hipStream_t st) {
     return GV_OK;
 }
 
+template <typename T, int KW>
+int launch_stem_pool(const ConvArgs& a, hipStream_t st) {
+    constexpr int KR = KW == 3 ? 16 : 24, NG = (KW * KR / 8 + 1) / 2 * 2, PR = 3 * 2 + KW + 1, PC = 31 * 2 + KW;
+    constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;
+    const size_t lds = (size_t)PR * PITCH + 4 * 32 * 36 * 4 + (size_t)32 * 2 * (NG * 16 + 16) + 4 * (2 * 15 * 32 * 2);
+    hipLaunchKernelGGL((conv_stem_patch_lp<T, 2, KW, 0, true>), dim3((unsigned)(a.nb * ((a.pw + 14) / 15))), dim3(256), lds, st, a);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
 template <typename T>
 int launch_stem(const ConvArgs& a, hipStream_t st) {
+    if (a.pool) return a.kw == 3 ? launch_stem_pool<T, 3>(a, st) : launch_stem_pool<T, 7>(a, st);
     if (a.st.mode == gvconv::STAT_BWD) return GV_E_UNSUPPORTED;             // (a first layer has no data gradient)
     if (a.st.mode == gvconv::STAT_FWD) {
         if (a.kw == 3) return a.cout <= 32 ? launch_stem_one<T, 1, 3, gvconv::STAT_FWD>(a, st) : launch_stem_one<T, 2, 3, gvconv::STAT_FWD>(a, st);
@@ -1095,11 +1189,18 @@ bool lp_halo_pool_ok(const ConvArgs& a, bool generic) {
            (((uintptr_t)a.y) & 15) == 0;
 }
 
+// ... and the strip kernel of the 3-channel stems at 64 output channels (either pool geometry)
+bool lp_stem_pool_ok(const ConvArgs& a, bool xf32) {
+    return lp_stem_ok(a, xf32) && a.cout == 64 && a.st.mode == STAT_OFF && a.y_step == 0 && a.xscale == nullptr &&
+           a.oh >= 3 && a.ow >= 3 && a.y_ld % 8 == 0 && (((uintptr_t)a.y) & 15) == 0;
+}
+
 int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {
     ConvArgs a = a0;
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
-    if (a.pool && (cfg != kNumTiles || !lp_halo_pool_ok(a, generic))) return GV_E_UNSUPPORTED;
+    if (a.pool && (cfg != kNumTiles || !((a.pool == 1 && lp_halo_pool_ok(a, generic)) || lp_stem_pool_ok(a, xf32))))
+        return GV_E_UNSUPPORTED;
     if (cfg == kNumTiles) {
         if (a.y_step != 0) return GV_E_UNSUPPORTED;              // (the strip / halo kernels have no two-level output stride)
         // BatchNorm sums: one segment over every output column (these kernels own whole images: no slot table)

@@ -61,7 +61,12 @@ extern "C" {
                                  convolution's own output size.  Bit-identical to gv_conv2d_fwd + gv_pool2d.  Served for
                                  the halo-kernel class only (16-bit storage, 3x3 / stride 1, cin 32, cout 64, GV_CONV_RELU
                                  on every column, no residual / second output / BatchNorm sums, oh, ow >= 3):
-                                 GV_E_UNSUPPORTED otherwise, and the caller issues the two launches */
+                                 GV_E_UNSUPPORTED otherwise, and the caller issues the two launches.  Also served for the
+                                 strip kernel of the 3-channel stems (GV_CONV_X_F32, 3x3 or 7x7 / stride 2, cout 64, any
+                                 activation) */
+#define GV_CONV_MAXPOOL3S2_SAME 256 /* the same with TF's SAME padding on an even map (pads (0, 1): the last window is
+                                 clipped; resnet_v2.py:181, conv1 -> pool1): y is [nb, oh/2, ow/2, cout].  Stem strip
+                                 kernel only; odd oh / ow: GV_E_UNSUPPORTED */
 
 /* gv_conv_desc.math_mode: how an fp32 convolution is evaluated on the matrix cores */
 #define GV_MATH_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                         */

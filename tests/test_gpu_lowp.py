@@ -66,8 +66,10 @@ def pack(w, code):
 
 
 def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, second=None, split=0,
-             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0, xpre=None, tile_cfg=0, expect=None, pooled=None):
-    """pooled = (ph, pw): GV_CONV_MAXPOOL3S2 — the destination is the pooled tensor, out_hw stays the convolution's."""
+             tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0, xpre=None, tile_cfg=0, expect=None, pooled=None,
+             pooled_same=False):
+    """pooled = (ph, pw): GV_CONV_MAXPOOL3S2 (pooled_same: _SAME) — the destination is the pooled tensor, out_hw stays the
+    convolution's."""
     code, td, _ = TYPES[ty]
     nb, ih, iw, cin = x.shape
     kh, kw, _, cout = w.shape
@@ -89,7 +91,7 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
     rd = residual.to(td).to(DEV).contiguous() if residual is not None else None
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0) | \
             (_lib.GV_CONV_SPLIT if split else 0) | (_lib.GV_CONV_X_F32 if x_f32 else 0) | \
-            (_lib.GV_CONV_MAXPOOL3S2 if pooled else 0)
+            ((_lib.GV_CONV_MAXPOOL3S2_SAME if pooled_same else _lib.GV_CONV_MAXPOOL3S2) if pooled else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
                       cout if residual is not None else 0, n2 if y2d is not None else 0, flags, code, split, tile_cfg, 0, 0)
     if xpre is not None:                    # the input is read as relu(x * xscale + xshift) (gv_conv2d_fwd_xpre)
@@ -440,6 +442,33 @@ def test_lp_conv_maxpool_one_launch(ty, pad, hw, nb):
         assert np.array_equal(one, two), (tile_cfg, tile, np.abs(one - two).max())
 
 
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("k,pad,hw,same,relu", [(7, 3, (64, 64), True, False), (7, 3, (224, 120), True, False), (3, 0, (65, 129), True, True),
+                                                (3, 0, (47, 75), False, True), (7, 3, (50, 66), False, False), (7, 3, (12, 8), True, False),
+                                                (7, 3, (16, 128), True, False)])
+def test_lp_stem_conv_maxpool_one_launch(ty, k, pad, hw, same, relu):
+    """The strip kernel of the 3-channel stems with the max pool behind it in the same launch (ResNet-v2: conv1 7x7 / 2 with
+    a bias and no activation -> pool1 3x3 / 2 SAME, nets/resnet_v2.py:178-181; signed values, the last window clipped):
+    bit for bit the two launches, and through them the oracle; VALID pools and a ReLU in front of the pool as well."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(k * 100 + hw[0] + hw[1])
+    ih, iw = hw
+    x = torch.randn(2, ih, iw, 3, generator=g)
+    w = rnd(torch.randn(k, k, 3, 64, generator=g) * 0.1, td)
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    oh, ow = (ih + 2 * pad - k) // 2 + 1, (iw + 2 * pad - k) // 2 + 1
+    ph, pw = (oh // 2, ow // 2) if same else ((oh - 3) // 2 + 1, (ow - 3) // 2 + 1)
+    y = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, relu, ty, tile=special_tile(), x_f32=True)
+    assert relu or float(y.min()) < 0                                       # signed values reach the pool
+    two = run_pool(torch.from_numpy(y), 3, 2, (0, 0), (ph, pw), _lib.GV_POOL_MAX, ty)
+    ref = OB.max_pool2d(oracle_conv(rnd(x, td), w, 2, (pad, pad, pad, pad), scale, shift, relu), 3, 2, "SAME" if same else "VALID")
+    close(two, ref.numpy(), ulp)
+    for tile_cfg, tile in ((0, None), (special_tile() + 1, None), (0, special_tile())):
+        one = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, relu, ty, tile=tile, tile_cfg=tile_cfg, x_f32=True,
+                       y_ld=64 + 16, y_off=8, pooled=(ph, pw), pooled_same=same)
+        assert np.array_equal(one, two), (tile_cfg, tile, np.abs(one - two).max())
+
+
 def test_lp_conv_maxpool_declines_what_it_does_not_serve():
     """Outside the halo kernel's 32 -> 64 channel ReLU class the flag is refused and nothing is written (the plan builder
     then issues the two launches): another tile, no ReLU, a residual, other channel counts, a 2 x 2 map, fp32 storage."""
@@ -456,6 +485,12 @@ def test_lp_conv_maxpool_declines_what_it_does_not_serve():
     x64 = torch.randn(2, 12, 14, 64, generator=g)
     run_conv(x64, torch.randn(3, 3, 64, 64, generator=g) * 0.05, 1, (1, 1), (12, 14), sc, sh, True, "bf16", pooled=(5, 6), expect=U)
     run_conv(x[:, :4, :4], w, 1, (0, 0), (2, 2), sc, sh, True, "bf16", pooled=(1, 1), expect=U)
+    # the SAME form: the stem strip kernel only, even maps only
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, True, "bf16", pooled=(6, 7), pooled_same=True, expect=U)
+    xi = torch.randn(2, 33, 37, 3, generator=g)
+    w7 = torch.randn(7, 7, 3, 64, generator=g) * 0.1
+    run_conv(xi, w7, 2, (3, 3), (17, 19), sc, sh, False, "bf16", x_f32=True, pooled=(8, 9), pooled_same=True, expect=U)
+    run_conv(xi, w7[..., :32], 2, (3, 3), (17, 19), sc[:32], sh[:32], False, "bf16", x_f32=True, pooled=(8, 9), expect=U)
 
 
 @pytest.mark.parametrize("ty,size,nb", [("bf16", 107, 6), ("f16", 75, 4), ("bf16", 224, 24), ("f16", 299, 10)])
@@ -485,6 +520,28 @@ def test_lp_inception_plan_with_and_without_the_fused_max_pool(ty, size, nb):
     assert float(outs[0]["Mixed_7c"].float().abs().max()) > 1e-3
     tapped = backbones.make_plan("inception_v3", nb, size, size, DEV, dtype=ty, lanes=False, raw_tap="Conv2d_2b_3x3")
     assert "MaxPool_3a_3x3" in [op["name"] for op in tapped.ops]
+
+
+@pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])
+def test_lp_resnet_plan_with_and_without_the_fused_max_pool(ty, size, nb):
+    """The 16-bit ResNet-v2-50 plan issues conv1 -> pool1 as one launch where conv1's map is even (64, 224: one op fewer);
+    at 97 (a 49 x 49 map: TF's SAME pads (1, 1) there) it keeps the two.  Same bits at block3 / block4 either way."""
+    from gvcnn_tf_amd import backbones
+    x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5).to(DEV)
+    outs, nops = [], []
+    for fuse in (True, False):
+        plan = backbones.make_plan("resnet_v2_50", nb, size, size, DEV, dtype=ty, lanes=False, fuse_maxpool=fuse)
+        plan.bind(gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True))
+        if any(op["name"].endswith("/pool1") for op in plan.ops):          # two launches: conv1 on the same kernel
+            plan.apply_tiles({"resnet_v2_50/conv1": special_tile()})
+        plan.run(x)
+        torch.cuda.synchronize()
+        outs.append({k: plan.view(plan.end_points[k]).clone() for k in ("resnet_v2_50/block3", "resnet_v2_50/block4")})
+        nops.append(len(plan.ops))
+    assert nops[0] == nops[1] - (1 if size != 97 else 0)
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert float(outs[0]["resnet_v2_50/block4"].float().abs().max()) > 1e-3
 
 
 def run_pool(x, k, stride, pads, out_hw, mode, ty, x_ld=None, y_ld=None, y_off=0):
