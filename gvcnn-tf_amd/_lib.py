@@ -83,7 +83,6 @@ SIGNATURES = {
     "gv_pack_filter_hwio": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gv_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gv_conv2d_fwd_xpre": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gv_conv2d_stem_pair_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "gv_conv2d_fwd_bnstats": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, C.POINTER(BnStats), _P]),
     "gv_pool2d_fwd": (C.c_int, [C.POINTER(PoolDesc), _P, _P, _P]),
     "gv_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
@@ -145,7 +144,6 @@ SIGNATURES = {
                                    _I, _L, _L, _L]),
     "gv_plan_set_conv_tile": (C.c_int, [_P, _I, _I]),
     "gv_plan_set_conv_xpre": (C.c_int, [_P, _I, _L, _L]),
-    "gv_plan_set_conv_stem": (C.c_int, [_P, _I, _I, _I, _L, _L, _L, _I]),
     "gv_plan_set_schedule": (C.c_int, [_P, _I, _I, C.POINTER(_I), _I]),
     "gv_plan_add_pool": (C.c_int, [_P, C.POINTER(PoolDesc), _I, _L, _I, _L]),
     "gv_plan_add_scale_shift_act": (C.c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _L, _I, _L, _L, _I, _L]),

@@ -123,9 +123,6 @@ class BackbonePlan:
         # 16-bit storage: Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch that writes only the pooled tensor
         # (GV_CONV_MAXPOOL3S2); off: the two launches (A/B switch)
         self.fuse_maxpool = dtype != _lib.GV_F32
-        # ... and Conv2d_1a_3x3 -> Conv2d_2a_3x3 as one launch whose halo is the stem layer computed from the images
-        # (gv_conv2d_stem_pair_fwd); off: the two launches (A/B switch)
-        self.fuse_stem_pair = dtype != _lib.GV_F32
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -288,26 +285,6 @@ class BackbonePlan:
             return (out, DeferredPreact(out, s2, h2) if defer else y2)
         return out
 
-    def conv_stem_pair(self, x, scope1, c1, scope2, c2, padding2, norm):
-        """slim.conv2d(x, c1, 3, stride 2, VALID) -> slim.conv2d(., c2, 3, padding2), both conv -> BN -> ReLU, as ONE launch
-        (gv_conv2d_stem_pair_fwd): the first layer's output lives in the launch's LDS halo only.  x: the network input."""
-        assert x.vbuf < 0 and x.c == 3 and c1 == 32 and c2 <= 32 and c2 % 8 == 0 and self.dtype != _lib.GV_F32
-        h1, w1 = _out_size(x.h, 3, 2, "VALID")[0], _out_size(x.w, 3, 2, "VALID")[0]
-        oh, pad_t = _out_size(h1, 3, 1, padding2)
-        ow, pad_l = _out_size(w1, 3, 1, padding2)
-        out = self.new_tensor(x.nb, oh, ow, c2)
-        w1_off = self._filter(scope1 + "/weights", 3, 3, 3, c1)
-        s1, t1 = self._scale_shift("bn", scope1 + "/BatchNorm", c1, norm[1], norm[2])
-        w_off = self._filter(scope2 + "/weights", 3, 3, c1, c2)
-        so, ho = self._scale_shift("bn", scope2 + "/BatchNorm", c2, norm[1], norm[2])
-        self._record(dict(kind="conv", name=scope2, x=x, y=out, y2=None, res=None, w_off=w_off, scale_off=so, shift_off=ho,
-                          scale2_off=0, shift2_off=0, kh=3, kw=3, stride=1, pad_t=pad_t, pad_l=pad_l, relu=True, split=0,
-                          cout=c2, xpre=None, maxpool=None, oh=oh, ow=ow,
-                          stem=dict(h=h1, w=w1, c=c1, w_off=w1_off, scale_off=s1, shift_off=t1, name=scope1),
-                          flops=2.0 * x.nb * (h1 * w1 * c1 * 27 + oh * ow * c2 * 9 * c1),
-                          bytes=4.0 * x.npix * 3 + float(self.esz) * (27 * c1 + 9 * c1 * c2 + out.npix * c2)))
-        return out
-
     def fused_maxpool_ok(self, x, cout, k, padding, stride=1, pool_padding="VALID"):
         """May `conv(x, ..., cout, k, stride, padding, maxpool=pool_padding)` be one launch?  The classes
         GV_CONV_MAXPOOL3S2 / _SAME serve (include/gvcnn_hip.h), 16-bit storage: 3x3 / stride 1 from 32 to 64 channels
@@ -441,9 +418,7 @@ class BackbonePlan:
                     flags |= _lib.GV_CONV_Y2_P3
                 if op.get("maxpool"):                         # y is the pooled tensor; oh / ow stay the convolution's
                     flags |= _lib.GV_CONV_MAXPOOL3S2_SAME if op["maxpool"] == "SAME" else _lib.GV_CONV_MAXPOOL3S2
-                stem = op.get("stem")
-                ih_, iw_, cin_, xld_ = (stem["h"], stem["w"], stem["c"], stem["c"]) if stem else (x.h, x.w, x.c, x.ld)
-                d = _lib.ConvDesc(x.nb, ih_, iw_, cin_, xld_, op["kh"], op["kw"], op["stride"],
+                d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], op.get("oh", y.h), op.get("ow", y.w), op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
                                   flags, self.dtype, split, op.get("tile", 0), self.math_mode, 0,
@@ -457,10 +432,6 @@ class BackbonePlan:
                 if op.get("xpre") is not None:
                     _lib.check(lib.gv_plan_set_conv_xpre(plan, lib.gv_plan_num_ops(plan) - 1, *op["xpre"]),
                                "gv_plan_set_conv_xpre(%s)" % op["name"])
-                if stem:
-                    _lib.check(lib.gv_plan_set_conv_stem(plan, lib.gv_plan_num_ops(plan) - 1, x.h, x.w, stem["w_off"] * wmul,
-                                                         stem["scale_off"], stem["shift_off"], 1),
-                               "gv_plan_set_conv_stem(%s)" % op["name"])
             elif op["kind"] == "pool":
                 d = _lib.PoolDesc(x.nb, x.h, x.w, x.c, x.ld, op["k"], op["k"], op["stride"],
                                   op["pad_t"], op["pad_l"], y.h, y.w, y.ld, op["mode"], self.dtype)
@@ -609,7 +580,7 @@ class BackbonePlan:
     def apply_tiles(self, table):
         """Install a previously measured {op name: tile configuration} table (no launches)."""
         for i, op in enumerate(self.ops):
-            if op["kind"] == "conv" and op["name"] in table and not op.get("maxpool") and not op.get("stem"):   # (one kernel serves those forms)
+            if op["kind"] == "conv" and op["name"] in table and not op.get("maxpool"):   # (one kernel serves that form)
                 op["tile"] = int(table[op["name"]]) + 1
                 _lib.check(self.lib.gv_plan_set_conv_tile(self._plan, i, op["tile"]), "gv_plan_set_conv_tile")
 
@@ -634,7 +605,7 @@ class BackbonePlan:
         chosen, cands = {}, {}
         try:
             for i, op in enumerate(self.ops):
-                if op["kind"] != "conv" or op.get("stem"):       # (the stem pair is one kernel: nothing to choose)
+                if op["kind"] != "conv":
                     continue
                 ncfg = ncfg_p3 if op["x"].p3 else ncfg_plan
                 timed = []
@@ -776,14 +747,9 @@ def build_inception_v3(b, final_endpoint="Mixed_7c", keep=("Mixed_6e", "Mixed_7c
             b.keep(t)
         return name == final_endpoint
 
-    if (getattr(b, "fuse_stem_pair", False) and b.dtype != _lib.GV_F32 and "Conv2d_1a_3x3" not in keep and
-            final_endpoint != "Conv2d_1a_3x3" and min(b.input.h, b.input.w) >= 7):
-        # inception_v3.py:97-105 as ONE launch: Conv2d_1a_3x3 exists in the launch's LDS only (nobody taps it)
-        net = b.conv_stem_pair(b.input, scope + "/Conv2d_1a_3x3", 32, scope + "/Conv2d_2a_3x3", 32, "VALID", BN)
-    else:
-        net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
-        if done("Conv2d_1a_3x3", net): return net
-        net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
+    net = conv(b.input, "Conv2d_1a_3x3", 32, 3, 2, "VALID")
+    if done("Conv2d_1a_3x3", net): return net
+    net = conv(net, "Conv2d_2a_3x3", 32, 3, 1, "VALID", mid=final_endpoint != "Conv2d_2a_3x3")
     if done("Conv2d_2a_3x3", net): return net
     if (final_endpoint != "Conv2d_2b_3x3" and "Conv2d_2b_3x3" not in keep and b.fused_maxpool_ok(net, 64, 3, "SAME")):
         # inception_v3.py:111-113 as ONE launch: the un-pooled Conv2d_2b_3x3 is never written (nobody taps it)
@@ -971,7 +937,7 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True, fuse_stem_pair=True):
+              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere."""
@@ -981,7 +947,6 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     b.use_p3 = b.use_p3 and bool(p3)
     b.defer_preact = b.defer_preact and bool(defer_preact)      # (A/B switch: False = every pre-activation stored)
     b.fuse_maxpool = b.fuse_maxpool and bool(fuse_maxpool)      # (A/B switch: False = Conv2d_2b and MaxPool_3a as two launches)
-    b.fuse_stem_pair = b.fuse_stem_pair and bool(fuse_stem_pair)    # (A/B switch: False = Conv2d_1a and Conv2d_2a as two launches)
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:

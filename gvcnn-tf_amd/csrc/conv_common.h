@@ -40,12 +40,6 @@ struct ConvArgs {
     GvFastDiv y_div_img = {0, -1, 1}, y_div_row = {0, -1, 1};   //    exact m / (oh*ow) and rem / ow
     int pool = 0;               // GV_CONV_MAXPOOL3S2 (1) / _SAME (2; conv3x3_halo_lp: 1 only): y is the 3x3 / 2 max pool of the
     int ph = 0, pw = 0;         //    output, ph x pw pixels per image
-    // gv_conv2d_stem_pair_fwd (conv3x3_stem_halo_lp): x is the fp32 network input [nb, stem_ih, stem_iw, 3] and the 3x3 /
-    // stride-2 VALID stem layer (packed filter, folded scale / shift, ReLU) is computed into this launch's halo
-    const void* stem_w = nullptr;
-    const float* stem_scale = nullptr;
-    const float* stem_shift = nullptr;
-    int stem_ih = 0, stem_iw = 0, stem_kpad = 0, stem_relu = 0;
 };
 
 // May this launch take the lean 16-bit staged epilogue (conv_stats.h STAT_LEAN)?  dbg bit 2: always the full one (A/B).
@@ -131,7 +125,6 @@ int lp_xpre_pick(int M, int N);
 bool lp_halo_ok(const ConvArgs& a, bool generic);
 bool lp_halo_pool_ok(const ConvArgs& a, bool generic);   // GV_CONV_MAXPOOL3S2
 bool lp_stem_pool_ok(const ConvArgs& a, bool xf32);       // GV_CONV_MAXPOOL3S2 / GV_CONV_MAXPOOL3S2_SAME
-int lp_stem_pair_launch(int dtype, const ConvArgs& a, hipStream_t st);   // gv_conv2d_stem_pair_fwd
 bool lp_stem_ok(const ConvArgs& a, bool xf32);
 int lp_launch(int dtype, int cfg, const ConvArgs& a, bool generic, bool xf32, hipStream_t st);
 int lp_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int dtype, void* out, hipStream_t st);

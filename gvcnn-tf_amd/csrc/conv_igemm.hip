@@ -633,42 +633,6 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
     return launch_tile(cfg, a, generic, (hipStream_t)stream);
 }
 
-extern "C" int gv_conv2d_stem_pair_fwd(const gv_conv_desc* d, const void* x, int32_t in_h, int32_t in_w,
-                                       const void* w1_packed, const float* scale1, const float* shift1, int32_t relu1,
-                                       const void* w_packed, const float* scale, const float* shift, void* y,
-                                       void* stream) {
-    if (!d || !x || !w1_packed || !scale1 || !shift1 || !w_packed || !scale || !shift || !y) return GV_E_BADARG;
-    if (d->nb <= 0 || in_h < 3 || in_w < 3 || d->oh <= 0 || d->ow <= 0 || d->pad_t < 0 || d->pad_l < 0 || d->y_ld < d->cout)
-        return GV_E_BADARG;
-    // d: the SECOND layer, whose input is the first layer's output map
-    if (d->ih != (in_h - 3) / 2 + 1 || d->iw != (in_w - 3) / 2 + 1 || d->oh != d->ih + 2 * d->pad_t - 2 ||
-        d->ow != d->iw + 2 * d->pad_l - 2)
-        return GV_E_BADARG;
-    if (d->dtype != GV_BF16 && d->dtype != GV_F16) return GV_E_UNSUPPORTED;
-    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->cin != 32 || d->cout > 32 || d->cout % 8 != 0 || d->in_dilation > 1 ||
-        d->y_step != 0 || (d->flags & ~(GV_CONV_RELU | GV_CONV_X_F32)) != 0 || d->y_ld % 8 != 0 || !gv_aligned16(y) || !gv_aligned16(w_packed) ||
-        !gv_aligned16(w1_packed))
-        return GV_E_UNSUPPORTED;
-    if ((int64_t)d->nb * in_h * in_w * 3 > 0x7fffffffll || (int64_t)d->nb * d->oh * d->ow > 0x7fffffffll) return GV_E_UNSUPPORTED;
-    if (d->relu_cols < 0) return GV_E_BADARG;
-    ConvArgs a;
-    a.x = (const float*)x; a.w = w_packed; a.scale = scale; a.shift = shift; a.res = nullptr;
-    a.y = (float*)y; a.y2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.xscale = nullptr; a.xshift = nullptr;
-    a.nb = d->nb; a.ih = d->ih; a.iw = d->iw; a.cin = 32; a.x_ld = 3;
-    a.kh = 3; a.kw = 3; a.stride = 1; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
-    a.oh = d->oh; a.ow = d->ow; a.cout = d->cout; a.y_ld = d->y_ld; a.res_ld = 0; a.y2_ld = 0;
-    a.M = d->nb * d->oh * d->ow; a.K = 9 * 32; a.Kpad = 0; a.ktiles = 0;
-    a.relu = (d->flags & GV_CONV_RELU) ? 1 : 0; a.relu2 = 0; a.split = 0;
-    a.relu_limit = d->relu_cols > 0 ? d->relu_cols : 0x7fffffff;
-    a.tiles_n = 0; a.dil_shift = 0; a.dbg = g_debug; a.zeros = nullptr; a.y_p3 = a.y2_p3 = 0; a.korder = 0;
-#ifdef GV_PHASE_TIMES
-    a.phase_buf = g_phase_buf;
-#endif
-    a.stem_w = w1_packed; a.stem_scale = scale1; a.stem_shift = shift1; a.stem_ih = in_h; a.stem_iw = in_w;
-    a.stem_relu = relu1 ? 1 : 0;
-    return gvconv::lp_stem_pair_launch(d->dtype, a, (hipStream_t)stream);
-}
-
 extern "C" int gv_conv2d_time(const gv_conv_desc* d, const void* x, const void* w_packed,
                               const float* scale, const float* shift, void* y, int32_t iters,
                               float* ms_avg_host, void* stream) {

@@ -675,189 +675,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Conv2d_1a_3x3 -> Conv2d_2a_3x3 (nets/inception_v3.py:97-106) as ONE launch (gv_conv2d_stem_pair_fwd): the halo kernel
-// above (32 -> 32 channels, two rows per wave, filter fragments in registers) whose halo is not FETCHED but COMPUTED — the
-// (8+2) x (32+2) pixels of the 3-channel 3x3 / stride-2 stem convolution a tile needs come out of a (2*10+1) x (2*34+1)
-// patch of the fp32 images by the strip kernel's arithmetic (conv_stem_patch_lp below: row-wise k order, the same three
-// MFMAs per 32 pixels in the same order, scale / shift / ReLU, one rounding), 11 blocks of 32 halo pixels per tile, and are
-// written into the halo's LDS image instead of HBM.  The stem layer's output (0.8 MB per image at 224 x 224) is never
-// written nor read back; the images are read 1.33x (tile overlap) instead.  Bit-identical to the two launches.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3x3_stem_halo_lp(const ConvArgs a) {
-    constexpr int TH = 8, HH = TH + 2, HW = 34, PB = 32 * 2 + 16, NPX = HH * HW;    // halo: 340 pixels of 80 bytes
-    constexpr int NBLK = (NPX + 31) / 32;                                          // 11 MFMA row blocks of halo pixels
-    constexpr int KW = 3, KR = 16, NG = 6;                                          // stem k order: filter row r owns 16 slots
-    constexpr int PR = 2 * HH + 1 + 1, PC = 2 * HW + 1;                             // patch rows (+ a zero row: unused here), pixels
-    constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;                            // 432
-    constexpr int NEL = (PR - 1) * PC * 3;                                          // 4 347 patch elements per tile
-    constexpr int SLP = (NEL + 255) / 256;
-    constexpr int WB1 = NG * 16 + 16;
-    constexpr int SW = 32 + 4;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    char* sH = smem_raw;                                                            // [NPX][PB]
-    float* stage = reinterpret_cast<float*>(smem_raw + NPX * PB) + (threadIdx.x >> 6) * (32 * SW);
-    char* sP = smem_raw + NPX * PB + 4 * 32 * SW * 4;                               // [PR][PITCH]
-    char* sW1 = sP + PR * PITCH;                                                    // [32][WB1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int tiles_x = (a.ow + 31) / 32;
-    const int n = blockIdx.x / tiles_x;
-    const int ox0 = (blockIdx.x % tiles_x) * 32;
-    const unsigned short* wp = reinterpret_cast<const unsigned short*>(a.w);
-    const unsigned short* wp1 = reinterpret_cast<const unsigned short*>(a.stem_w);
-    unsigned short* y = reinterpret_cast<unsigned short*>(a.y);
-
-    // the second layer's filter fragments: registers for the life of the workgroup (conv3x3_halo_lp, BREG)
-    u32x4 fb[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            fb[t][c] = *reinterpret_cast<const u32x4*>(wp + (size_t)min(li, a.cout - 1) * a.Kpad + t * 32 + c * 16 + 8 * lh);
-    // the stem filter in the row-wise k order (conv_stem_patch_lp), and zeros behind every patch row
-    for (int idx = tid; idx < 32 * NG * 8; idx += 256) {
-        const int row = idx / (NG * 8), kk = idx - row * (NG * 8);
-        const int r = kk / KR, j = kk - r * KR;
-        unsigned short v = 0;
-        if (r < KW && j < KW * 3) v = wp1[(size_t)row * a.stem_kpad + r * KW * 3 + j];
-        *reinterpret_cast<unsigned short*>(sW1 + row * WB1 + kk * 2) = v;
-    }
-    for (int idx = tid; idx < PR * PITCH / 4; idx += 256) reinterpret_cast<unsigned*>(sP)[idx] = 0u;
-
-    const int rrow = lane >> 2, col8 = (lane & 3) * 8;
-    float sc[8], sh[8], sc1[8], sh1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = min(col8 + e, a.cout - 1);
-        sc[e] = a.scale[c];
-        sh[e] = a.shift[c];
-        sc1[e] = a.stem_scale[col8 + e];
-        sh1[e] = a.stem_shift[col8 + e];
-    }
-    const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0);
-
-    float pr_[SLP];
-    auto fetch = [&](int oy0) {                            // the image patch under halo rows [oy0 - pad_t, ... + HH)
-#pragma unroll
-        for (int k = 0; k < SLP; ++k) {
-            const int idx = tid + k * 256;
-            float v = 0.f;
-            if (idx < NEL) {
-                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
-                const int px = e / 3, ch = e - px * 3;
-                const int iy = 2 * (oy0 - a.pad_t) + prow, ix = 2 * (ox0 - a.pad_l) + px;
-                if ((unsigned)iy < (unsigned)a.stem_ih && (unsigned)ix < (unsigned)a.stem_iw)
-                    v = a.x[((size_t)(n * a.stem_ih + iy) * a.stem_iw + ix) * 3 + ch];
-            }
-            pr_[k] = v;
-        }
-    };
-    fetch(0);
-    for (int oy0 = 0; oy0 < a.oh; oy0 += TH) {
-        __syncthreads();                                   // previous tile: fragment reads and staging done
-#pragma unroll
-        for (int k = 0; k < SLP; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < NEL) {
-                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
-                *reinterpret_cast<unsigned short*>(sP + prow * PITCH + e * 2) = to_bits<T>(pr_[k]);
-            }
-        }
-        __syncthreads();
-        if (oy0 + TH < a.oh) fetch(oy0 + TH);              // in flight under everything below
-        // ---- the halo: stem convolution of the patch, 32 halo pixels per block, blocks wave, wave + 4, wave + 8
-        for (int b = wave; b < NBLK; b += 4) {
-            const int p = min(b * 32 + li, NPX - 1);
-            const int hy = p / HW, hx = p - hy * HW;
-            f32x16 acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NG / 2; ++c) {
-                const int g = 2 * c + lh;
-                const int r = g / (KR / 8), q = g - r * (KR / 8);
-                const char* ap = sP + (2 * hy + r) * PITCH + hx * 12 + q * 16;
-                u32x4 fa;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) fa[d] = *reinterpret_cast<const unsigned*>(ap + 4 * d);
-                const u32x4 bq = *reinterpret_cast<const u32x4*>(sW1 + li * WB1 + g * 16);
-                acc1 = mfma16<T>(fa, bq, acc1);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc1[r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int row = pass * 16 + rrow;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
-                const int pq = b * 32 + row;
-                if (pq >= NPX) continue;
-                const int qy = pq / HW, qx = pq - qy * HW;
-                const int y1 = oy0 + qy - a.pad_t, x1 = ox0 + qx - a.pad_l;     // position in the stem layer's map
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                u32x4 o = {0u, 0u, 0u, 0u};                                     // outside it: the second layer's zero padding
-                if ((unsigned)y1 < (unsigned)a.ih && (unsigned)x1 < (unsigned)a.iw) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v[e] = v[e] * sc1[e] + sh1[e];
-                        if (a.stem_relu) v[e] = fmaxf(v[e], 0.f);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-                }
-                *reinterpret_cast<u32x4*>(sH + pq * PB + col8 * 2) = o;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        __syncthreads();                                   // the halo is complete
-        // ---- the 3x3 / stride-1 layer over it (conv3x3_halo_lp: TN = 1, RPW = 2)
-        f32x16 acc[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int r = t / 3, s_ = t - r * 3;
-            const char* ap = sH + ((wave + r) * HW + li + s_) * PB + 16 * lh;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                u32x4 fa[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) fa[q] = *reinterpret_cast<const u32x4*>(ap + q * 4 * HW * PB + c * 32);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q] = mfma16<T>(fa[q], fb[t][c], acc[q]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int oy = oy0 + wave + 4 * q;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[q][r];
-            __builtin_amdgcn_wave_barrier();
-            const int nvalid = min(8, a.cout - col8);
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int row = pass * 16 + rrow;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
-                if (oy >= a.oh || nvalid <= 0 || ox0 + row >= a.ow) continue;
-                const size_t m = (size_t)(n * a.oh + oy) * a.ow + ox0 + row;
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (col8 + e < a.relu_limit) ? fmaxf(v[e], 0.f) : v[e];
-                }
-                store_chunk<T>(y + m * a.y_ld + col8, v, nvalid, vec);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // The 3-channel stems (Inception Conv2d_1a 3x3/2, ResNet conv1 7x7/2 with explicit pad) straight from the fp32
 // images (GV_CONV_X_F32).  The gather path of conv_igemm_lp issues one 4-byte global load, one table lookup and a
 // bounds test per (pixel, k) element.  Here a workgroup owns a 32-pixel-wide column strip of one image and walks down
@@ -1376,22 +1193,6 @@ bool lp_halo_pool_ok(const ConvArgs& a, bool generic) {
 bool lp_stem_pool_ok(const ConvArgs& a, bool xf32) {
     return lp_stem_ok(a, xf32) && a.cout == 64 && a.st.mode == STAT_OFF && a.y_step == 0 && a.xscale == nullptr &&
            a.oh >= 3 && a.ow >= 3 && a.y_ld % 8 == 0 && (((uintptr_t)a.y) & 15) == 0;
-}
-
-// Conv2d_1a -> Conv2d_2a in one launch: `a` describes the 3x3 / stride-1 layer (32 input channels, <= 32 output
-// channels, whole 8-channel chunks), a.stem_* the 3-channel 3x3 / 2 VALID layer in front of it
-int lp_stem_pair_launch(int dtype, const ConvArgs& a0, hipStream_t st) {
-    ConvArgs a = a0;
-    a.Kpad = (a.K + KT - 1) / KT * KT;
-    a.ktiles = a.Kpad / KT;
-    a.stem_kpad = (27 + KT - 1) / KT * KT;
-    const size_t lds = (size_t)340 * 80 + 4 * 32 * 36 * 4 + (size_t)22 * 432 + 32 * (6 * 16 + 16);
-    const dim3 grid((unsigned)(a.nb * ((a.ow + 31) / 32)));
-    if (dtype == GV_BF16) hipLaunchKernelGGL((conv3x3_stem_halo_lp<__bf16>), grid, dim3(256), lds, st, a);
-    else if (dtype == GV_F16) hipLaunchKernelGGL((conv3x3_stem_halo_lp<_Float16>), grid, dim3(256), lds, st, a);
-    else return GV_E_UNSUPPORTED;
-    GV_LAUNCH_CHECK();
-    return GV_OK;
 }
 
 int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, hipStream_t st) {

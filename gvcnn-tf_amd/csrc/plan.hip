@@ -30,8 +30,6 @@ struct Op {
     int32_t c, x_ld, y_ld, relu, dtype;
     Ref x, w, scale, shift, res, y, y2, scale2, shift2;
     Ref xscale{-1, 0}, xshift{-1, 0};      // gv_plan_set_conv_xpre: pre-activation applied by this conv's loader
-    Ref stem_w{-1, 0}, stem_scale{-1, 0}, stem_shift{-1, 0};   // gv_plan_set_conv_stem: x is the network input and the stem
-    int32_t stem_ih = 0, stem_iw = 0, stem_relu = 0;            // layer in front of this conv is computed by its launch
     // schedule: launch lane (0 = the caller's stream) and the earlier ops on OTHER lanes this op
     // must wait for (data or buffer-reuse hazards); same-lane order is stream order.
     int32_t lane = 0;
@@ -79,11 +77,6 @@ int run_op(const Op& o, void* const* bufs, void* stream) {
             const size_t xes = (o.conv.flags & GV_CONV_X_F32) ? 4 : ((o.conv.flags & GV_CONV_X_P3) ? 6 : es);
             const size_t yes = (o.conv.flags & GV_CONV_Y_P3) ? 6 : es;
             const size_t y2es = (o.conv.flags & GV_CONV_Y2_P3) ? 6 : es;
-            if (o.stem_w.slot >= 0)
-                return gv_conv2d_stem_pair_fwd(&o.conv, at(bufs, o.x, 4), o.stem_ih, o.stem_iw, at(bufs, o.stem_w, es),
-                                               (const float*)at(bufs, o.stem_scale, 4), (const float*)at(bufs, o.stem_shift, 4),
-                                               o.stem_relu, at(bufs, o.w, es), (const float*)at(bufs, o.scale, 4),
-                                               (const float*)at(bufs, o.shift, 4), at(bufs, o.y, yes), stream);
             if (o.xscale.slot >= 0)
                 return gv_conv2d_fwd_xpre(&o.conv, at(bufs, o.x, xes), (const float*)at(bufs, o.xscale, 4),
                                           (const float*)at(bufs, o.xshift, 4), at(bufs, o.w, es),
@@ -179,21 +172,6 @@ extern "C" int gv_plan_set_conv_xpre(gv_plan* p, int32_t op_index, int64_t xscal
     if (o.kind != OP_CONV) return GV_E_BADARG;
     o.xscale = {o.scale.slot, xscale_off};            // the table that holds this op's own scale / shift
     o.xshift = {o.scale.slot, xshift_off};
-    return GV_OK;
-}
-
-extern "C" int gv_plan_set_conv_stem(gv_plan* p, int32_t op_index, int32_t in_h, int32_t in_w, int64_t w1_off,
-                                     int64_t scale1_off, int64_t shift1_off, int32_t relu1) {
-    if (!p) return GV_E_PLAN;
-    if (op_index < 0 || (size_t)op_index >= p->ops.size() || in_h < 3 || in_w < 3 || w1_off < 0 || scale1_off < 0 ||
-        shift1_off < 0)
-        return GV_E_BADARG;
-    Op& o = p->ops[(size_t)op_index];
-    if (o.kind != OP_CONV) return GV_E_BADARG;
-    o.stem_w = {o.w.slot, w1_off};                    // the arenas that hold this op's own filter and scale / shift
-    o.stem_scale = {o.scale.slot, scale1_off};
-    o.stem_shift = {o.scale.slot, shift1_off};
-    o.stem_ih = in_h; o.stem_iw = in_w; o.stem_relu = relu1;
     return GV_OK;
 }
 

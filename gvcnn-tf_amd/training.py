@@ -37,7 +37,6 @@ class TrainPlan(backbones.BackbonePlan):
         self.use_p3 = False
         self.defer_preact = False          # BatchNorm is its own op here (batch statistics)
         self.fuse_maxpool = False          # (the pool -> BatchNorm form of TrainGVCNN is the training path's fusion)
-        self.fuse_stem_pair = False        # (training needs Conv2d_1a's output for its BatchNorm and its gradients)
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
              residual=None, next_preact=None):

@@ -208,15 +208,6 @@ int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
 int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
                        const void* w_packed, const float* scale, const float* shift, const void* residual,
                        void* y, void* y2, const float* scale2, const float* shift2, void* stream);
-/* Two slim.conv2d in ONE launch, 16-bit storage: the 3-channel 3x3 / stride-2 VALID stem layer on the fp32 network input
- * (Conv2d_1a_3x3, nets/inception_v3.py:97-100) and the 3x3 / stride-1 32 -> (<= 32)-channel layer behind it (Conv2d_2a_3x3,
- * :102-105).  `d` describes the SECOND layer (ih / iw = the first layer's output map, cin = 32, GV_CONV_RELU); x is
- * [nb, in_h, in_w, 3] fp32; w1_packed / scale1 / shift1 / relu1 belong to the first layer (gv_pack_filter_hwio(3, 3, 3, 32)),
- * w_packed / scale / shift to the second.  The first layer's output is computed tile by tile into the second layer's LDS
- * halo and never reaches memory; bit-identical to the two gv_conv2d_fwd calls.  Anything else: GV_E_UNSUPPORTED. */
-int gv_conv2d_stem_pair_fwd(const gv_conv_desc* d, const void* x, int32_t in_h, int32_t in_w, const void* w1_packed,
-                            const float* scale1, const float* shift1, int32_t relu1, const void* w_packed,
-                            const float* scale, const float* shift, void* y, void* stream);
 
 /* ---- pooling -------------------------------------------------------------
  * slim.max_pool2d / slim.avg_pool2d: nets/inception_v3.py:112,127,152,219,355,...;
@@ -557,11 +548,6 @@ int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d,
 int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg);
 /* Conv op `op_index` runs as gv_conv2d_fwd_xpre: xscale / xshift at these fp32 offsets of the op's scale/shift slot. */
 int gv_plan_set_conv_xpre(gv_plan* p, int32_t op_index, int64_t xscale_off, int64_t xshift_off);
-/* Conv op `op_index` runs as gv_conv2d_stem_pair_fwd: its x is the [nb, in_h, in_w, 3] fp32 network input, the stem
- * layer's packed filter at element offset w1_off of the op's filter slot, its scale / shift at these fp32 offsets of the
- * op's scale/shift slot. */
-int gv_plan_set_conv_stem(gv_plan* p, int32_t op_index, int32_t in_h, int32_t in_w, int64_t w1_off, int64_t scale1_off,
-                          int64_t shift1_off, int32_t relu1);
 /* Branch-level concurrency: put op `op_index` on launch lane `lane` (0 = the caller's stream, 1..7 =
  * plan-owned streams) and name the EARLIER ops it must wait for (producers of its inputs, and ops
  * still using a buffer it overwrites).  A whole-plan run then forks the lanes off `stream` and joins

@@ -469,67 +469,6 @@ def test_lp_stem_conv_maxpool_one_launch(ty, k, pad, hw, same, relu):
         assert np.array_equal(one, two), (tile_cfg, tile, np.abs(one - two).max())
 
 
-def run_stem_pair(x, w1, sc1, sh1, w2, sc2, sh2, pad2, ty, relu2=True, expect=None, lie=0):
-    """gv_conv2d_stem_pair_fwd: 3x3 / 2 VALID on the fp32 images, then 3x3 / 1 with padding pad2, one launch."""
-    code, td, _ = TYPES[ty]
-    nb, ih, iw, _ = x.shape
-    c2 = w2.shape[3]
-    h1, w1_ = (ih - 3) // 2 + 1, (iw - 3) // 2 + 1
-    oh, ow = h1 + 2 * pad2 - 2, w1_ + 2 * pad2 - 2
-    xd = x.contiguous().to(DEV)
-    yd = torch.full((nb, oh, ow, c2 + 8), -77.0, dtype=td, device=DEV)
-    p1, p2 = pack(w1, code), pack(w2, code)
-    t = [v.to(DEV) for v in (sc1, sh1, sc2, sh2)]
-    d = _lib.ConvDesc(nb, h1 + lie, w1_, 32, 32, 3, 3, 1, pad2, pad2, oh, ow, c2, c2 + 8, 0, 0,
-                      (_lib.GV_CONV_RELU if relu2 else 0) | _lib.GV_CONV_X_F32, code, 0, 0, 0, 0)
-    rc = lib().gv_conv2d_stem_pair_fwd(C.byref(d), xd.data_ptr(), ih, iw, p1.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), 1,
-                                       p2.data_ptr(), t[2].data_ptr(), t[3].data_ptr(), yd.data_ptr(), st())
-    torch.cuda.synchronize()
-    if expect is not None:
-        assert rc == expect, rc
-        assert (yd.float() == -77.0).all()
-        return None
-    _lib.check(rc, "gv_conv2d_stem_pair_fwd")
-    y = yd.float().cpu().numpy()
-    assert (y[..., c2:] == -77.0).all()
-    return y[..., :c2]
-
-
-@pytest.mark.parametrize("ty", ["bf16", "f16"])
-@pytest.mark.parametrize("hw,pad2,c2,nb", [((224, 224), 0, 32, 2), ((299, 299), 0, 32, 1), ((75, 75), 0, 32, 3), ((47, 75), 1, 32, 2),
-                                           ((139, 77), 0, 24, 2), ((21, 23), 1, 16, 2), ((7, 9), 0, 32, 2), ((64, 200), 1, 32, 1)])
-def test_lp_stem_pair_one_launch(ty, hw, pad2, c2, nb):
-    """Conv2d_1a_3x3 -> Conv2d_2a_3x3 (nets/inception_v3.py:97-105) as ONE launch whose halo is the stem layer computed from
-    the images: bit for bit the two launches (strip kernel, then halo kernel), and through them the oracle; ragged maps,
-    VALID and SAME second layers (the padding ring must be zeros, not the stem layer of zero pixels), fewer output channels."""
-    code, td, ulp = TYPES[ty]
-    g = torch.Generator().manual_seed(hw[0] * 7 + hw[1] + c2)
-    ih, iw = hw
-    x = torch.rand(nb, ih, iw, 3, generator=g) - 0.5
-    w1 = rnd(torch.randn(3, 3, 3, 32, generator=g) * 0.3, td)
-    w2 = rnd(torch.randn(3, 3, 32, c2, generator=g) * 0.08, td)
-    sc1, sh1 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
-    sc2, sh2 = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g) * 0.1
-    h1, w1_ = (ih - 3) // 2 + 1, (iw - 3) // 2 + 1
-    oh, ow = h1 + 2 * pad2 - 2, w1_ + 2 * pad2 - 2
-    a1 = run_conv(x, w1, 2, (0, 0), (h1, w1_), sc1, sh1, True, ty, tile=special_tile(), x_f32=True)
-    assert float(a1.max()) > 0 and float((a1 == 0).mean()) > 0.05              # the ReLU of the first layer is exercised
-    two = run_conv(torch.from_numpy(a1), w2, 1, (pad2, pad2), (oh, ow), sc2, sh2, True, ty, tile=special_tile())
-    ref = oracle_conv(rnd(oracle_conv(rnd(x, td), w1, 2, "VALID", sc1, sh1, True), td), w2, 1, "SAME" if pad2 else "VALID", sc2, sh2, True)
-    close(two, ref.numpy(), 2 * ulp)                                            # (two roundings deep)
-    one = run_stem_pair(x, w1, sc1, sh1, w2, sc2, sh2, pad2, ty)
-    assert np.array_equal(one, two), np.abs(one - two).max()
-
-
-def test_lp_stem_pair_declines_what_it_does_not_serve():
-    g = torch.Generator().manual_seed(9)
-    x = torch.rand(2, 31, 33, 3, generator=g) - 0.5
-    w1, w2 = torch.randn(3, 3, 3, 32, generator=g) * 0.3, torch.randn(3, 3, 32, 64, generator=g) * 0.08
-    o32, z32 = torch.ones(32), torch.zeros(32)
-    run_stem_pair(x, w1, o32, z32, w2, torch.ones(64), torch.zeros(64), 0, "bf16", expect=_lib.GV_E_UNSUPPORTED)   # 64 columns
-    run_stem_pair(x, w1, o32, z32, w2[..., :32], o32, z32, 0, "bf16", expect=_lib.GV_E_BADARG, lie=1)   # not the stem's map
-
-
 def test_lp_conv_maxpool_declines_what_it_does_not_serve():
     """Outside the halo kernel's 32 -> 64 channel ReLU class the flag is refused and nothing is written (the plan builder
     then issues the two launches): another tile, no ReLU, a residual, other channel counts, a 2 x 2 map, fp32 storage."""
@@ -556,35 +495,31 @@ def test_lp_conv_maxpool_declines_what_it_does_not_serve():
 
 @pytest.mark.parametrize("ty,size,nb", [("bf16", 107, 6), ("f16", 75, 4), ("bf16", 224, 24), ("f16", 299, 10)])
 def test_lp_inception_plan_with_and_without_the_fused_max_pool(ty, size, nb):
-    """The 16-bit Inception plan issues Conv2d_1a_3x3 -> Conv2d_2a_3x3 and Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch each
-    (two ops fewer; Conv2d_1a_3x3 and the un-pooled Conv2d_2b_3x3 do not exist); with the switches off and the same kernels
-    for the three layers the separate launches give the same bits at MaxPool_3a_3x3 and at Mixed_7c.  A tapped Conv2d_1a_3x3 /
-    Conv2d_2b_3x3 keeps its two launches."""
+    """The 16-bit Inception plan issues Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch (one op fewer, the un-pooled tensor
+    does not exist); with `fuse_maxpool=False` and the same kernel for Conv2d_2b the two launches give the same bits at
+    MaxPool_3a_3x3 and at Mixed_7c.  A tapped Conv2d_2b_3x3 keeps the two launches."""
     from gvcnn_tf_amd import backbones
     x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5).to(DEV)
     outs, nops = [], []
     for fuse in (True, False):
         plan = backbones.make_plan("inception_v3", nb, size, size, DEV, dtype=ty, lanes=False, fuse_maxpool=fuse,
-                                   fuse_stem_pair=fuse, raw_tap="MaxPool_3a_3x3")   # (a kept tensor: its buffer is not recycled)
+                                   raw_tap="MaxPool_3a_3x3")          # (a kept tensor: its buffer is not recycled)
         plan.bind(gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True))
         names = [op["name"] for op in plan.ops]
-        assert ("MaxPool_3a_3x3" in names) == (not fuse) and ("InceptionV3/Conv2d_1a_3x3" in names) == (not fuse)
+        assert ("MaxPool_3a_3x3" in names) == (not fuse)
         if not fuse:
-            plan.apply_tiles({"InceptionV3/Conv2d_2b_3x3": special_tile(), "InceptionV3/Conv2d_1a_3x3": special_tile(),
-                              "InceptionV3/Conv2d_2a_3x3": special_tile()})
+            plan.apply_tiles({"InceptionV3/Conv2d_2b_3x3": special_tile()})
         plan.run(x)
         torch.cuda.synchronize()
         outs.append({k: plan.view(plan.end_points[k]).clone() for k in ("MaxPool_3a_3x3", "Mixed_7c")})
         nops.append(len(plan.ops))
         assert ("Conv2d_2b_3x3" in plan.end_points) == (not fuse)
-    assert nops[0] == nops[1] - 2
+    assert nops[0] == nops[1] - 1
     for k in outs[0]:
         assert outs[0][k].shape == outs[1][k].shape and torch.equal(outs[0][k], outs[1][k]), k
     assert float(outs[0]["Mixed_7c"].float().abs().max()) > 1e-3
     tapped = backbones.make_plan("inception_v3", nb, size, size, DEV, dtype=ty, lanes=False, raw_tap="Conv2d_2b_3x3")
     assert "MaxPool_3a_3x3" in [op["name"] for op in tapped.ops]
-    tapped = backbones.make_plan("inception_v3", nb, size, size, DEV, dtype=ty, lanes=False, raw_tap="Conv2d_1a_3x3")
-    assert "InceptionV3/Conv2d_1a_3x3" in [op["name"] for op in tapped.ops]
 
 
 @pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])

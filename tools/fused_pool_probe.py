@@ -18,22 +18,19 @@ PRESETS = {"c3": ("inception_v3", 12, 224, "bf16", "f32"), "c4": ("resnet_v2_50"
 ap = argparse.ArgumentParser()
 ap.add_argument("--preset", default="c3")
 ap.add_argument("--shapes", type=int, default=32)
-ap.add_argument("--stem", action="store_true", help="A/B Conv2d_1a -> Conv2d_2a as one launch (gv_conv2d_stem_pair_fwd) instead")
 a = ap.parse_args()
 backbone, V, size, storage, math = PRESETS[a.preset]
 dev = torch.device("cuda:0")
 nb = a.shapes * V
 x = (torch.rand(nb, size, size, 3) - 0.5).to(dev)
-ap2 = None
 for fuse in (False, True, False, True):
-    kw = dict(fuse_stem_pair=fuse, fuse_maxpool=True) if a.stem else dict(fuse_maxpool=fuse)
-    plan = backbones.make_plan(backbone, nb, size, size, dev, math=math, dtype=storage, lanes=False, **kw)
+    plan = backbones.make_plan(backbone, nb, size, size, dev, math=math, dtype=storage, lanes=False, fuse_maxpool=fuse)
     plan.bind(gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True))
     plan.autotune(x)
     seq = [min(p, q) for p, q in zip(plan.time_each(x, 10), plan.time_each(x, 10))]
-    names = ("Conv2d_1a_3x3", "Conv2d_2a_3x3") if a.stem else ("Conv2d_2b_3x3", "MaxPool_3a_3x3", "/conv1", "/pool1")
-    part = sum(s for s, op in zip(seq, plan.ops) if op["name"].endswith(names) and "block" not in op["name"])
+    part = sum(s for s, op in zip(seq, plan.ops) if op["name"].endswith(("Conv2d_2b_3x3", "MaxPool_3a_3x3", "/conv1", "/pool1"))
+               and "block" not in op["name"])
     whole = min(plan.time_range(x, 0, len(plan.ops), 10), plan.time_range(x, 0, len(plan.ops), 10))
-    print("%s %s %-5s: the pair %.4f ms; whole pass %.3f ms = %.0f views/s"
-          % (a.preset, "fuse_stem_pair" if a.stem else "fuse_maxpool", fuse, part, whole, nb / whole * 1e3), flush=True)
+    print("%s fuse_maxpool %-5s: conv (+ max pool) %.4f ms; whole pass %.3f ms = %.0f views/s"
+          % (a.preset, fuse, part, whole, nb / whole * 1e3), flush=True)
     del plan
