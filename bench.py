@@ -15,8 +15,8 @@ Per-GPU work is fixed (weak scaling): the batch is cut on shape boundaries and t
 the scorer responses over RCCL (the batch-mean score of nets/model.py:146 couples the shapes of a
 batch).  --exchange allgather (default; the form BASELINE.json north_star names) also all-gathers the
 final view descriptors so every rank pools all shapes; --exchange scores stops at the scorer
-responses and every rank pools the shapes it owns.  An N > 1 line times BOTH and reports the other
-one under "other_exchange".
+responses and every rank pools the shapes it owns.  With --other-exchange (always over gloo) an N > 1
+line times BOTH and reports the other one under "other_exchange".
 
 Prints ONE JSON line on rank 0.
 """
@@ -68,6 +68,9 @@ def parse():
                          "descriptors, every rank pools all shapes; 'scores' exchanges only the scorer responses (each "
                          "rank pools the shapes it owns).  The N > 1 line reports the other one too (other_exchange)")
     ap.add_argument("--no-other-exchange", action="store_true", help="N > 1: time only --exchange")
+    ap.add_argument("--other-exchange", action="store_true",
+                    help="N > 1 over RCCL: also time the other exchange form and the other gather mode (extra timed loops after "
+                         "the one the line's `value` comes from; always on over gloo, where the control flow is what is tested)")
     ap.add_argument("--gather", default="collective", choices=["collective", "direct"],
                     help="N > 1: how a gather travels — 'collective' = RCCL all_gather_into_tensor (the library picks ring / "
                          "tree), 'direct' = one point-to-point send to and receive from EVERY peer (each xGMI link carries "
@@ -678,7 +681,8 @@ def main():
     if a.pmc_child:
         return
     other = other_g = None
-    if world > 1 and not a.no_other_exchange:
+    # (the driver's scaling run gets the ONE measurement it asks for: nothing after it can cost it the line)
+    if world > 1 and not a.no_other_exchange and (a.other_exchange or a.backend == "gloo"):
         name = "scores" if a.exchange == "allgather" else "allgather"
         sh2 = ShardedGVCNN(eng, exchange=name, gather_mode=a.gather)
         dt2 = timed(lambda: sh2.forward(x, check=False))
