@@ -192,3 +192,36 @@ def test_resnet_16bit_plan_defers_the_preactivation_of_identity_units():
     q = backbones.make_plan("resnet_v2_50", 2, 64, 64, torch.device("cpu"))
     assert all(op.get("xpre") is None for op in q.ops) and sum(1 for op in q.ops if op.get("y2") is not None) == 15
     assert p.param_shapes() == q.param_shapes()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_plans_issue_conv_and_max_pool_as_one_launch(dtype):
+    """GV_CONV_MAXPOOL3S2 / _SAME at plan level (host logic only): the 16-bit plans replace `Conv2d_2b_3x3 -> MaxPool_3a_3x3`
+    (nets/inception_v3.py:111-113) and `conv1 -> pool1` (nets/resnet_v2.py:178-181) by one op whose destination is the pooled
+    tensor; the arithmetic work is unchanged; a tapped producer, an odd conv1 map (SAME pads (1, 1) there) and fp32 storage
+    keep the two launches."""
+    cpu = torch.device("cpu")
+    p = backbones.make_plan("inception_v3", 2, 224, 224, cpu, dtype=dtype)
+    names = [op["name"] for op in p.ops]
+    assert "MaxPool_3a_3x3" not in names and "Conv2d_2b_3x3" not in p.end_points
+    op = next(o for o in p.ops if o["name"].endswith("Conv2d_2b_3x3"))
+    assert op["maxpool"] == "VALID" and (op["oh"], op["ow"]) == (109, 109) and (op["y"].h, op["y"].w, op["y"].c) == (54, 54, 64)
+    assert p.end_points["MaxPool_3a_3x3"] is op["y"] or p.end_points["MaxPool_3a_3x3"].vbuf == op["y"].vbuf
+    assert abs(p.total_flops / 2 / 1e9 - 5.672) < 0.002 * 5.672
+    assert sum(1 for o in p.ops if o["kind"] == "pool") == 13 - 1                         # 4 max + 9 average pools before
+    tapped = backbones.make_plan("inception_v3", 2, 224, 224, cpu, dtype=dtype, raw_tap="Conv2d_2b_3x3")
+    assert "MaxPool_3a_3x3" in [o["name"] for o in tapped.ops] and "Conv2d_2b_3x3" in tapped.end_points
+    off = backbones.make_plan("inception_v3", 2, 224, 224, cpu, dtype=dtype, fuse_maxpool=False)
+    assert "MaxPool_3a_3x3" in [o["name"] for o in off.ops]
+    assert off.param_shapes() == p.param_shapes()
+
+    r = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype)
+    op = next(o for o in r.ops if o["name"] == "resnet_v2_50/conv1")
+    assert op["maxpool"] == "SAME" and (op["oh"], op["ow"]) == (112, 112) and (op["y"].h, op["y"].w) == (56, 56)
+    assert not any(o["name"].endswith("/pool1") for o in r.ops)
+    assert abs(r.total_flops / 2 / 1e9 - 6.960) < 0.002 * 6.960
+    odd = backbones.make_plan("resnet_v2_50", 2, 97, 97, cpu, dtype=dtype)                # conv1: 49 x 49
+    assert any(o["name"].endswith("/pool1") for o in odd.ops)
+    for name in ("inception_v3", "resnet_v2_50"):
+        f32 = backbones.make_plan(name, 2, 224, 224, cpu)
+        assert not any(o.get("maxpool") for o in f32.ops if o["kind"] == "conv")
