@@ -1183,7 +1183,7 @@ static int wgrad_f32mfma(const gv_conv_desc* d, const S* x, const S* dz, int32_t
 }
 
 /* tuning hook: number of launch configurations gv_conv2d_wgrad accepts in gv_conv_desc.tile_cfg for `dtype` */
-extern "C" int gv_conv2d_wgrad_num_cfgs(int dtype) { return dtype == GV_BF16 || dtype == GV_F16 ? 30 + gvlp::wgrad_dma_num_cfgs() : 0; }
+extern "C" int gv_conv2d_wgrad_num_cfgs(int dtype) { return dtype == GV_BF16 || dtype == GV_F16 ? 30 + gvlp::wgrad_dma_num_cfgs() + 5 : 0; }
 
 static int g_wgrad_lp_f32 = 0;
 /* tuning hook: 16-bit storage filter gradients on the fp32 MFMA (typed loads) instead of the 16-bit MFMA kernel */

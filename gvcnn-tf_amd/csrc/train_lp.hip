@@ -1200,21 +1200,27 @@ struct StripGeom {
     int x_ld, dz_ld;
 };
 
-template <typename T, int WI, int WJ, int WT, int NTW>
+// KS: 16-pixel k-steps per strip.  2: the strip of up to 32 pixels described above.  16 (the DEEP form, 32-channel inputs:
+// Conv2d_2a / 2b): a strip is 8 rows x 32 columns of one image — the tile of the forward halo kernel — so that one fill of
+// LDS (16 KB of dZ per 32 columns of co, 22 KB of input patch) and one barrier pair feed 16 x (taps per wave) MFMAs per
+// wave instead of 2 x: the 32-pixel strips of a 109-wide map spend their time at barriers (6 MFMAs per wave between two).
+template <typename T, int WI, int WJ, int WT, int NTW, int KS = 2>
 __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ dz, StripGeom gm,
                                                            int taps_per_group, const GvDw dw) {
     static_assert(WI * WJ * WT == 4, "four waves");
+    static_assert(KS == 2 || WI == 1, "the deep form: 32 input channels");
+    constexpr int SLOTS = 16 * KS;
     constexpr int BI = 32 * WI, BO = 32 * WJ;
     // row strides: the four rows a transposed read touches per 16-lane group must start 16 dwords apart; a 32-channel
     // row IS 16 dwords (no padding: 2*B + 64 = 128 bytes would put rows q and q+2 on the same banks — measured 43 %
     // bank conflicts on the stem layers before this)
     constexpr int SX = BI == 32 ? 64 : 2 * BI + 64, SZ = BO == 32 ? 64 : 2 * BO + 64;
     constexpr int XC = BI / 8, ZC = BO / 8;                      // 16-byte chunks per LDS row
-    constexpr int XVMAX = 6, ZV = (32 * ZC + 255) / 256;
+    constexpr int XVMAX = 6, ZV = (SLOTS * ZC + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* sZ = lds;
-    unsigned char* sX = lds + 32 * SZ;
+    unsigned char* sX = lds + SLOTS * SZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave % WT, wj = (wave / WT) % WJ, wi = wave / (WT * WJ);
     const int ntile_co = (gm.cout + BO - 1) / BO, ntile_ci = (gm.cin + BI - 1) / BI;
@@ -1255,7 +1261,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
         zr[j] = p / gm.L;
         zc[j] = p - zr[j] * gm.L;
         zch[j] = co0 + (idx % ZC) * 8;
-        zoff[j] = idx < 32 * ZC ? p * SZ + (idx % ZC) * 16 : -1;
+        zoff[j] = idx < SLOTS * ZC ? p * SZ + (idx % ZC) * 16 : -1;
         if (zr[j] >= gm.R) zr[j] = -1;                           // padding slot: always zero
     }
     u32x4 xq[XVMAX], zq[ZV];
@@ -1298,6 +1304,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
     // transposed-read addresses: k slot p = 16*ks + 8*(lane/32) + 4*j + q  ->  dZ row p, X row (p/L)*Wx + p%L (+ tap)
     const int g16 = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
     const int col_l = 16 * (g16 & 1) + 4 * p4;
+    // (deep form: L = 32, so slot p = 16 ks + c is row ks / 2, column 16 (ks & 1) + c of the strip: one base per j, a
+    // compile-time-unrolled offset per k-step)
     int xb[2][2], zb[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -1309,6 +1317,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
             xb[ks][j] = (rr * gm.Wx + cc) * SX + 2 * (wi * 32 + col_l);
             zb[ks][j] = p * SZ + 2 * (wj * 32 + col_l);
         }
+    const int xstep = gm.Wx * SX;                                // deep form: one strip row further down the patch
     int tapoff[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -1322,14 +1331,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_strip_lp(const unsigned short*
         __syncthreads();
         if (stage + 1 < s1) load(stage + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const s16x4 blo = lds_read_tr(sZ + zb[ks][0]), bhi = lds_read_tr(sZ + zb[ks][1]);
+        for (int ks = 0; ks < KS; ++ks) {
+            // (KS = 2: the tables; deep: k-step ks = row ks / 2 of the strip, half ks & 1 of its 32 columns)
+            const int zo = KS == 2 ? 0 : (ks >> 1) * 32 * SZ, xo = KS == 2 ? 0 : (ks >> 1) * xstep;
+            const s16x4 blo = lds_read_tr(sZ + zb[ks & 1][0] + zo), bhi = lds_read_tr(sZ + zb[ks & 1][1] + zo);
             const s16x8 bv = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 if (wt + WT * i < ntaps) {                       // wave-uniform
-                    const s16x4 alo = lds_read_tr(sX + xb[ks][0] + tapoff[i]);
-                    const s16x4 ahi = lds_read_tr(sX + xb[ks][1] + tapoff[i]);
+                    const s16x4 alo = lds_read_tr(sX + xb[ks & 1][0] + tapoff[i] + xo);
+                    const s16x4 ahi = lds_read_tr(sX + xb[ks & 1][1] + tapoff[i] + xo);
                     const s16x8 av = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
                     acc[i] = mfma16<T>(av, bv, acc[i]);
                 }
@@ -1394,13 +1405,18 @@ int sums_t(int mode, const unsigned short* z, int z_ld, const unsigned short* dy
 // 9*split selects tile (TI,TO) in {1,2,3}^2 (64/128/192 channels per side) and a target of 1024 / 2048 / 4096
 // workgroups; 28..30 the strip form (TrainGVCNN.autotune measures them per layer).
 // strip form: geometry and eligibility
-inline bool strip_geom(const gv_conv_desc* d, int dz_ld, int bi, StripGeom* gm) {
+inline bool strip_geom(const gv_conv_desc* d, int dz_ld, int bi, StripGeom* gm, bool deep = false) {
     if (d->stride != 1 || d->kh * d->kw < 2) return false;
     StripGeom& g = *gm;
     g.nb = d->nb; g.ih = d->ih; g.iw = d->iw; g.cin = d->cin; g.kh = d->kh; g.kw = d->kw;
     g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.oh = d->oh; g.ow = d->ow; g.cout = d->cout;
     g.x_ld = d->x_ld; g.dz_ld = dz_ld;
-    if (d->ow >= 32) {
+    if (deep) {                                                  // 8 rows x 32 columns per strip (KS = 16)
+        if (bi != 32 || d->ow < 24 || d->oh < 8) return false;
+        g.ncs = (d->ow + 31) / 32;
+        g.L = 32;
+        g.R = 8;
+    } else if (d->ow >= 32) {
         g.ncs = (d->ow + 31) / 32;
         g.L = (d->ow + g.ncs - 1) / g.ncs;
         g.R = 1;
@@ -1418,21 +1434,22 @@ inline bool strip_geom(const gv_conv_desc* d, int dz_ld, int bi, StripGeom* gm) 
     if (stages > 0x7fffffff) return false;
     g.stages = (int)stages;
     if (g.xrows * (bi / 8) > 6 * 256) return false;              // XVMAX chunks per thread
-    if ((int64_t)g.xrows * (2 * bi + 64) + 32 * (2 * 128 + 64) > 64 * 1024) return false;
+    if (!deep && (int64_t)g.xrows * (2 * bi + 64) + 32 * (2 * 128 + 64) > 64 * 1024) return false;
     return true;
 }
 
-template <typename T, int WI, int WJ, int WT, int NTW>
+template <typename T, int WI, int WJ, int WT, int NTW, int KS = 2>
 int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, const GvDw& dw,
                  int target_wgs, hipStream_t st) {
     constexpr int BI = 32 * WI, BO = 32 * WJ;
     StripGeom gm;
-    if (!strip_geom(d, dz_ld, BI, &gm)) return GV_E_UNSUPPORTED;
+    if (!strip_geom(d, dz_ld, BI, &gm, KS != 2)) return GV_E_UNSUPPORTED;
     const int taps = d->kh * d->kw, tpg = NTW * WT;              // taps per workgroup
     const int groups = (taps + tpg - 1) / tpg;
     const int tiles = ((d->cin + BI - 1) / BI) * ((d->cout + BO - 1) / BO) * groups;
     int64_t splits = (target_wgs + tiles - 1) / tiles;
-    const int64_t max_splits = (gm.stages + 7) / 8;              // at least 8 strips per workgroup
+    const int64_t max_splits = KS == 2 ? (gm.stages + 7) / 8     // at least 8 strips per workgroup (deep: 3 of 256 pixels)
+                                       : (gm.stages + 2) / 3;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
@@ -1440,10 +1457,10 @@ int strip_launch(const gv_conv_desc* d, const unsigned short* x, const unsigned 
     splits = gv_dw_clamp(dw, elems, splits);
     gm.stages_per_block = (int)((gm.stages + splits - 1) / splits);
     splits = (gm.stages + gm.stages_per_block - 1) / gm.stages_per_block;
-    const size_t lds = (size_t)32 * (BO == 32 ? 64 : 2 * BO + 64) + (size_t)gm.xrows * (BI == 32 ? 64 : 2 * BI + 64);
-    auto kern = conv_wgrad_strip_lp<T, WI, WJ, WT, NTW>;
-    const bool attr = GV_BIG_LDS_OK(kern, 64 * 1024);
-    (void)attr;
+    const size_t lds = (size_t)(16 * KS) * (BO == 32 ? 64 : 2 * BO + 64) + (size_t)gm.xrows * (BI == 32 ? 64 : 2 * BI + 64);
+    auto kern = conv_wgrad_strip_lp<T, WI, WJ, WT, NTW, KS>;
+    const bool attr = GV_BIG_LDS_OK(kern, KS == 2 ? 64 * 1024 : 96 * 1024);
+    if (KS != 2 && !attr) return GV_E_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(256), lds, st, x, dz, gm, tpg,
                        gv_dw_sink(dw, elems, splits));
     GV_LAUNCH_CHECK();
@@ -1463,6 +1480,15 @@ int strip_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     return strip_launch<T, 2, 2, 1, 9>(d, x, dz, dz_ld, dw, target_wgs, st);
 }
 
+// the deep form (8 x 32 pixel strips): 32 input channels, 32 or 64 output channels
+template <typename T>
+int strip_deep_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short* dz, int dz_ld, const GvDw& dw,
+                 int target_wgs, hipStream_t st) {
+    if (d->cin > 32 || d->cout > 64) return GV_E_UNSUPPORTED;
+    if (d->cout <= 32) return strip_launch<T, 1, 1, 4, 3, 16>(d, x, dz, dz_ld, dw, target_wgs, st);
+    return strip_launch<T, 1, 2, 2, 5, 16>(d, x, dz, dz_ld, dw, target_wgs, st);
+}
+
 int g_strip_default = 1;
 
 template <typename T>
@@ -1479,6 +1505,13 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
     };
     int ti = side(d->cin), to = side(d->cout);
     int64_t target = 2048;
+    if (d->tile_cfg > 30 + gvlp::wgrad_dma_num_cfgs() + 5) return GV_E_BADARG;
+    if (d->tile_cfg > 30 + gvlp::wgrad_dma_num_cfgs()) {         // 92..96: the deep strip form, 512 ... 4096 workgroups
+        const int tws[5] = {512, 768, 1024, 2048, 4096};
+        const int tw = tws[d->tile_cfg - 31 - gvlp::wgrad_dma_num_cfgs()];
+        const int rc = strip_deep_t<T>(d, x, dz, dz_ld, dw, tw, st);
+        return rc != GV_E_UNSUPPORTED ? rc : strip_t<T>(d, x, dz, dz_ld, dw, tw, st);   // (other layers: the 32-pixel strips)
+    }
     if (d->tile_cfg > 30)                                        // 31..91: LDS-DMA staging (wgrad_dma.hip)
         return gvlp::conv_wgrad_dma_launch(d, x, dz, dz_ld, dw, d->tile_cfg - 31, st);
     if (d->tile_cfg > 27) {                                      // 28..30: strip form, 1024 / 2048 / 4096 workgroups

@@ -327,7 +327,7 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     x = torch.randn(nb, ih, iw, cin, generator=g).to(tdt).to(DEV)
     dz = torch.randn(nb, ih, iw, cout, generator=g).to(tdt).to(DEV)
     n = lib().gv_conv2d_wgrad_num_cfgs(dt)
-    assert n == 91 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 61 LDS-DMA
+    assert n == 96 and lib().gv_conv2d_wgrad_num_cfgs(_lib.GV_F32) == 0       # 27 tiles + 3 strip + 61 LDS-DMA + 5 deep strip
     outs = []
     for cfg in range(n + 1):
         dw = torch.zeros(3, 3, cin, cout, device=DEV)
@@ -369,6 +369,33 @@ def test_wgrad_lds_dma_form_on_every_layer_class(k, stride, padding, cin, cout, 
     dzd[..., :cout] = dz.to(tdt).to(DEV)
     dw = torch.full((k[0], k[1], cin, cout), 0.5, device=DEV)
     d = _lib.ConvDesc(nb, ih, iw, cin, xld, k[0], k[1], stride, pt, pl, oh, ow, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
+    _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad")
+    close(dw.cpu() - 0.5, w.grad, 3e-5)
+
+
+@pytest.mark.parametrize("dt,tdt,eps", TYPES)
+@pytest.mark.parametrize("cfg", [92, 94, 96])
+@pytest.mark.parametrize("padding,cout,nb,ih,iw", [("VALID", 32, 3, 37, 43), ("SAME", 64, 2, 35, 66), ("SAME", 32, 2, 109, 109),
+                                                   ("VALID", 64, 2, 10, 26), ("SAME", 24, 3, 16, 33), ("SAME", 64, 2, 9, 100)])
+def test_wgrad_deep_strip_form(padding, cout, nb, ih, iw, cfg, dt, tdt, eps):
+    """tile_cfg 92..96: the strip form of the 32-input-channel 3x3 layers (Conv2d_2a / 2b) with 8 x 32-pixel strips (16
+    k-steps per LDS fill instead of 2) — ragged widths and heights (strips that end inside the map), SAME and VALID, 24 /
+    32 / 64 output channels, operands that are channel slices of wider buffers: against autograd on the same 16-bit values."""
+    g = torch.Generator().manual_seed(cfg * 31 + ih + iw + cout)
+    x = q(torch.randn(nb, ih, iw, 32, generator=g), tdt).requires_grad_(True)
+    w = q(torch.randn(3, 3, 32, cout, generator=g) * 0.1, tdt).requires_grad_(True)
+    z = OB.conv2d(x, w, 1, padding)
+    dz = q(torch.randn(*z.shape, generator=g), tdt)
+    z.backward(dz)
+    oh, ow = z.shape[1:3]
+    p = 1 if padding == "SAME" else 0
+    xld, zld = 32 + 8, cout + 16
+    xd = torch.full((nb, ih, iw, xld), 3.0, dtype=tdt, device=DEV)
+    xd[..., :32] = x.detach().to(tdt).to(DEV)
+    dzd = torch.full((nb, oh, ow, zld), 5.0, dtype=tdt, device=DEV)
+    dzd[..., :cout] = dz.to(tdt).to(DEV)
+    dw = torch.full((3, 3, 32, cout), 0.5, device=DEV)
+    d = _lib.ConvDesc(nb, ih, iw, 32, xld, 3, 3, 1, p, p, oh, ow, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
     _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad")
     close(dw.cpu() - 0.5, w.grad, 3e-5)
 

@@ -75,7 +75,8 @@ FORMS = [
     (_lib.GV_F16, (1, 7), 1, "SAME", 128, 192, 12, 17, 17, [0, 9, 31, 44, 58]),
     (_lib.GV_BF16, (1, 1), 1, "SAME", 288, 448, 24, 12, 12, [0, 27, 34, 64, 66, 73, 77, 78, 91]),
     (_lib.GV_BF16, (3, 3), 2, "VALID", 96, 96, 8, 25, 25, [0, 31]),
-    (_lib.GV_BF16, (3, 3), 1, "VALID", 32, 32, 8, 55, 55, [0, 28]),           # the 32-channel stem layers: strips
+    (_lib.GV_BF16, (3, 3), 1, "VALID", 32, 32, 8, 55, 55, [0, 28, 92, 96]),   # the 32-channel stem layers: strips, deep strips
+    (_lib.GV_F16, (3, 3), 1, "SAME", 32, 64, 6, 41, 70, [93]),                # ... at 64 output channels
     (_lib.GV_BF16, (3, 3), 2, "VALID", 3, 32, 8, 96, 96, [0]),               # Conv2d_1a: stem rows
     (_lib.GV_F16, (7, 7), 2, "SAME", 3, 64, 4, 64, 64, [0]),                 # ResNet conv1 (explicit pad 3 == SAME here)
     (_lib.GV_BF16, (1, 1), 1, "SAME", 20, 36, 6, 9, 9, [0]),                 # channels not a multiple of 8: fp32-MFMA kernel on typed loads
