@@ -924,6 +924,20 @@ __global__ __launch_bounds__(256) void pack_filters_batched_lp(const gv_pack_job
     const int ci_p = j.flipped ? j.cout : j.cin;                 // this job's channels per tap on the k axis
     const int K = j.kh * j.kw * ci_p;
     const int Kpad = (K + KT - 1) / KT * KT;
+    if (!j.flipped && co_p % 16 == 0) {
+        // The forward image is the TRANSPOSE of the HWIO variable (out[n][k] = w[k][n]): with one thread per output element
+        // a wave reads 64 elements 4*cout bytes apart.  The job's blocks — co_p * Kpad / 256 of them, exactly — take 16 x 16
+        // tiles instead: 16 rows of 64 contiguous source bytes in, through LDS, 16 rows of 32 contiguous bytes out.
+        __shared__ float tile[16][17];
+        const int tiles_k = Kpad / 16, bl = (int)blockIdx.x - j.first_block;
+        const int n0 = (bl / tiles_k) * 16, k0 = (bl % tiles_k) * 16;
+        const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+        const size_t wld = j.w_ld > 0 ? (size_t)j.w_ld : (size_t)j.cout;
+        tile[a][b] = k0 + a < K ? j.w[(size_t)(k0 + a) * wld + n0 + b] : 0.f;
+        __syncthreads();
+        reinterpret_cast<unsigned short*>(j.out)[(size_t)(n0 + a) * Kpad + k0 + b] = to_bits<T>(tile[b][a]);
+        return;
+    }
     const int64_t i = (int64_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x;
     if (i >= (int64_t)co_p * Kpad) return;
     const int n = (int)(i / Kpad);
