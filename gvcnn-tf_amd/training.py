@@ -374,8 +374,10 @@ class TrainGVCNN:
         self.fuse_bn_stats_res = True                     # ... also where the producing convolution adds a residual (ResNet conv3; A/B)
         self.fuse_bn_pool = self.es == 2                  # BatchNorm -> max pool pairs of the stem as pool -> BatchNorm (A/B)
         self.alias_residual_grad = True                   # residual fan-in: the shortcut's gradient shares dy's buffer (False: copy; A/B)
-        self.share_bias_grad = True                       # a shortcut conv's bias gradient = the conv3's (same dy): one pass less
-        self._bias_twin, self._reader_count = {}, None
+        # Bias gradients that need no pass over dy (ResNet-v2; `_bias_sources`): a bias in front of a train-mode BatchNorm has
+        # a zero gradient, one behind a residual add has the gradient of the bias of that add.  False: every bias summed
+        self.bias_grad_identities = True
+        self._bias_src = None
         self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
         self.s2_concurrent = False                        # ... their four launches side by side on extra streams: measured
                                                           # 15.66 k against 15.89 k views/s in sequence (fork / join cost more
@@ -620,17 +622,58 @@ class TrainGVCNN:
                 r.vbuf != y.vbuf and (r.nb, r.h, r.w, r.c) == (y.nb, y.h, y.w, y.c) and r.off == 0 and y.off == 0 and
                 r.ld == r.c and y.ld == y.c and self.act[r.vbuf].numel() == self.act[y.vbuf].numel())
 
-    def _readers(self, t):
-        """Number of ops that read tensor t (as input or as residual)."""
-        if self._reader_count is None:
-            cnt = {}
-            for op in self.plan.ops:
-                for key in ("x", "res"):
-                    u = op.get(key)
-                    if u is not None and u.vbuf >= 0:
-                        cnt[u.vbuf] = cnt.get(u.vbuf, 0) + 1
-            self._reader_count = cnt
-        return self._reader_count.get(t.vbuf, 0)
+    def _bias_sources(self):
+        """{bias name: None (sum dy: gv_bias_grad_t) | [] (zero) | [other bias names] (the sum of THEIR gradients)}.
+
+        db = sum over pixels of dy, dy the gradient of the tensor the bias was added into.  That tensor's gradient is the
+        sum of what its readers send back, and two kinds of reader send something whose pixel sum is known without
+        looking at it: a train-mode BatchNorm (batch statistics over exactly these pixels, per view) returns
+        dz_i = A (g_i - mean g - zhat_i mean(g zhat)), whose sum over i is 0 because sum zhat_i = 0 — the textbook
+        redundancy of a bias in front of a BatchNorm; a residual add `y' = conv(..) + bias' + t` (resnet_v2.py:91) returns
+        dy' itself, whose pixel sum IS db'; a max / average / sub-sampling pool returns a scatter of its own dy that keeps
+        the sum.  In ResNet-v2-50 that leaves two biases to sum (the last units of block3 and block4, whose outputs are
+        tapped) out of twenty-one: conv1 and the last conv3 of blocks 1 and 2 are zero, the other sixteen are copies.  In exact
+        arithmetic these ARE the gradients (the oracle's fp64 autograd shows the zeros and the equalities to 1e-6,
+        tests/test_gpu_train.py); the summed form differs from them by the rounding noise of the stored 16-bit dy.  With
+        frozen statistics (`frozen_bn`) a BatchNorm's return does not sum to zero: only the residual rule applies."""
+        if self._bias_src is not None:
+            return self._bias_src
+        ops = self.plan.ops
+        readers = {}
+        for op in ops:
+            for key in ("x", "res"):
+                u = op.get(key)
+                if u is not None and u.vbuf >= 0:
+                    readers.setdefault(u.vbuf, []).append((op, key))
+        tapped = {self.raw.vbuf, self.final.vbuf}
+
+        def terms(t, depth=0):
+            """bias names whose gradients add up to the pixel sum of dt ([] = zero), or None = unknown."""
+            if t.vbuf in tapped or depth > 64 or t.off != 0 or t.ld != t.c:
+                return None
+            out = []
+            for c, key in readers.get(t.vbuf, ()):
+                if c["kind"] == "bn" and key == "x":
+                    if self.frozen_bn:
+                        return None
+                    continue
+                if c["kind"] == "conv" and key == "res":
+                    sub = [c["bias"]] if c.get("bias") else terms(c["y"], depth + 1)
+                elif c["kind"] == "pool" and key == "x":
+                    sub = terms(c["y"], depth + 1)
+                else:
+                    return None
+                if sub is None:
+                    return None
+                out += sub
+            return out if readers.get(t.vbuf) else None
+
+        src = {}
+        for op in ops:
+            if op["kind"] == "conv" and op.get("bias"):
+                src[op["bias"]] = terms(op["y"]) if self.bias_grad_identities else None
+        self._bias_src = src
+        return src
 
     def _zero_grad_of(self, t):
         self._ptr(t, grad=True)
@@ -1138,7 +1181,6 @@ class TrainGVCNN:
         this engine's final tap, or (view-sharded job) into the zeroed tensor dF [N, Vh, h, w, C]."""
         lib, V = self.lib, self.Vh
         self._flat_g.zero_()
-        self._bias_twin.clear()
         self._written = set()
         if not self._lazy:
             for g in self.grad:
@@ -1267,11 +1309,10 @@ class TrainGVCNN:
         elif op["kind"] == "conv":
             dz = self._ptr(y, True)
             if op["bias"]:
-                twin = self._bias_twin.pop(y.vbuf, None)
-                if twin is not None and self.grad[y.vbuf] is twin[0]:
-                    # a ResNet shortcut convolution: its dy IS the dy of the unit's conv3 (aliased below, and this tensor has
-                    # no other reader), whose bias gradient — zero before this pass — is the same sum over the same values
-                    self.grads[op["bias"]].add_(self.grads[twin[1]])
+                src = self._bias_sources()[op["bias"]]
+                if src is not None:                           # known without a pass over dy: zero, or other biases' gradients
+                    for other in src:                         # (theirs are final: their ops ran earlier in this pass)
+                        self.grads[op["bias"]].add_(self.grads[other])
                 else:
                     _lib.check(lib.gv_bias_grad_t(dz, y.ld, y.npix, y.c, self.accum.data_ptr(),
                                                   self.grads[op["bias"]].data_ptr(), self.dt, _st()), "bias_grad")
@@ -1286,8 +1327,6 @@ class TrainGVCNN:
                 if first and self._can_alias_grad(r, y):
                     self._ptr(y, True)
                     self.grad[r.vbuf] = self.grad[y.vbuf]
-                    if op["bias"] and self.share_bias_grad and self._readers(r) == 1:
-                        self._bias_twin[r.vbuf] = (self.grad[y.vbuf], op["bias"])
                 else:
                     if self.grad[r.vbuf] is not None and self.grad[r.vbuf] is self.grad[y.vbuf]:
                         self.grad[r.vbuf] = None                  # (aliased by an earlier pass: its own buffer again)

@@ -377,6 +377,57 @@ def test_training_step_against_an_fp64_arbiter(backbone, size, N, V, math="bf16x
     assert tot_e ** 0.5 <= 1.25 * tot_o ** 0.5, (tot_e ** 0.5 / tot_n ** 0.5, tot_o ** 0.5 / tot_n ** 0.5)
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_resnet_bias_gradients_known_without_a_pass(storage):
+    """TrainGVCNN._bias_sources: in train mode 19 of ResNet-v2-50's 21 bias gradients need no pass over dy — a bias in front of
+    a train-mode BatchNorm (conv1 through pool1, the last conv3 of blocks 1 and 2) has a ZERO gradient, and a bias behind a
+    residual add has the gradient of the add's own bias (nets/resnet_v2.py:79-91: every other conv3 and the four shortcut
+    convolutions).  (1) The mathematics, on the oracle's fp64 autograd: the zeros are zero and the copies equal to 1e-6 of
+    the largest bias gradient.  (2) The engine with the identities reproduces exactly that structure (zeros are 0.0, copies
+    bit-equal, the two summed biases bit-equal to the engine that sums all 21) and (3), on fp32 storage, the engine that sums
+    all 21 agrees with it to 2e-3 of the largest bias gradient.  With frozen statistics only the four residual twins remain."""
+    backbone, N, V, size, C_, G = "resnet_v2_50", 4, 2, 64, 5, 10
+    probe = TrainGVCNN(backbone, N, V, size, size, C_, G, device=DEV)
+    P = gv.params.init_backbone_params(probe.plan.param_shapes(), seed=2, perturb_bn=True)
+    Hd = gv.params.init_head_params(V, probe.raw.c, probe.final.c, C_, seed=3, spread_scores=True)
+    del probe
+    x = torch.rand(N, V, size, size, 3, generator=torch.Generator().manual_seed(0)) - 0.5
+    labels = torch.arange(N) % C_
+    r64 = OT.loss_and_grads(x.double(), labels.numpy(), {k: torch.as_tensor(v).double() for k, v in P.items()},
+                            {k: torch.as_tensor(v).double() for k, v in Hd.items()}, G, backbone)
+    out = {}
+    for on in (True, False):
+        eng = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage=storage)
+        eng.bias_grad_identities = on
+        eng.forward(x.to(DEV), labels)
+        out[on] = {k: v.clone().cpu().double() for k, v in eng.backward().items() if k.endswith("/biases")}
+        if on:
+            src = eng._bias_sources()
+    assert sorted(src) == sorted(out[True]) and len(src) == 21
+    assert sum(v is None for v in src.values()) == 2 and sum(v == [] for v in src.values()) == 3
+    big = max(float(r64["grads"][k].abs().max()) for k in src)
+    # (3) only on fp32 storage: the sum of 16-bit stored dy values carries rounding noise of the order of the largest true
+    # bias gradient itself (measured > 0.2 of it on conv1) — the summed form is the LESS accurate of the two there
+    noise = 2e-3 if storage == "f32" else float("inf")
+    for name, s_ in src.items():
+        g64 = r64["grads"][name].double()
+        if s_ is None:
+            assert torch.equal(out[True][name], out[False][name]), name
+        elif s_ == []:
+            assert float(g64.abs().max()) <= 1e-6 * big, (name, float(g64.abs().max()), big)
+            assert float(out[True][name].abs().max()) == 0.0, name
+            assert float(out[False][name].abs().max()) <= noise * big, (name, float(out[False][name].abs().max()), big)
+        else:
+            assert len(s_) == 1
+            assert float((g64 - r64["grads"][s_[0]].double()).abs().max()) <= 1e-6 * big, name
+            assert torch.equal(out[True][name], out[True][s_[0]]), name
+            assert float((out[False][name] - out[True][name]).abs().max()) <= noise * big, name
+    frozen = TrainGVCNN(backbone, N, V, size, size, C_, G, backbone_params=P, head_params=Hd, device=DEV, storage=storage,
+                        frozen_bn=True)
+    fs = frozen._bias_sources()
+    assert sum(v is None for v in fs.values()) == 17 and all(v is None or (len(v) == 1 and "/shortcut/" in k) for k, v in fs.items())
+
+
 @pytest.mark.parametrize("backbone,size", [("inception_v3", 171), ("resnet_v2_50", 129)])
 def test_gradient_is_the_directional_derivative_of_the_loss(backbone, size):
     """Oracle-free check of the assembled backward pass: along the gradient direction the loss must change by
