@@ -940,7 +940,9 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
               math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
-    blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere."""
+    blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere.
+    fuse_maxpool: 16-bit storage issues `Conv2d_2b_3x3 -> MaxPool_3a_3x3` (Inception) / `conv1 -> pool1` (ResNet) as ONE
+    launch that writes only the pooled tensor (GV_CONV_MAXPOOL3S2[_SAME]; bit-identical; False = the two launches)."""
     dtype = DTYPES[dtype] if isinstance(dtype, str) else dtype
     b = BackbonePlan(nb, height, width, dtype, MATH_MODES[math] if isinstance(math, str) else math)
     b.use_lanes = bool(lanes)
