@@ -137,6 +137,9 @@ int dma_lp_num_cfgs();
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32);
 int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);
 const void* dma_zero_page();   // one zero page per device for padding taps / rows past the end
+// conv_ws.hip (wave-specialised kernel: loader waves + MFMA consumer waves; configurations follow the LDS-DMA tiles)
+int ws_lp_num_cfgs();
+int ws_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);
 // fp32 values stored as three bf16 planes ("P3": [pixel][channel/16][plane][16]), GV_MATH_BF16X3
 int dma_x3_num_cfgs();
 bool dma_x3_ok(const ConvArgs& a);

@@ -857,7 +857,8 @@ bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; 
 
 int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) { return launch_dma_x3(cfg, a, st); }
 
-int dma_lp_num_cfgs() { return 25; }
+constexpr int kDmaLpTiles = 25;
+int dma_lp_num_cfgs() { return kDmaLpTiles + ws_lp_num_cfgs(); }   // + the wave-specialised kernel's tiles (conv_ws.hip)
 
 // the DMA loader's layer class: whole 8-channel chunks inside one filter tap, 16-byte aligned pixels, 16-bit input
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32) {
@@ -865,6 +866,7 @@ bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32) {
 }
 
 int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st) {
+    if (cfg >= kDmaLpTiles) return ws_lp_launch(dtype, cfg - kDmaLpTiles, a, st);
     if (dtype == GV_BF16) return launch_dma_lp<__bf16>(cfg, a, st);
     if (dtype == GV_F16) return launch_dma_lp<_Float16>(cfg, a, st);
     return GV_E_UNSUPPORTED;

@@ -1,0 +1,417 @@
+// conv_ws.hip — wave-specialised 16-bit convolution: LOADER waves feed an LDS ring, CONSUMER waves do nothing but
+// LDS fragment reads and MFMAs (round 5; the reference's conv+BN+ReLU sites: nets/inception_v3.py:137-338,
+// nets/resnet_v2.py:73-95).
+//
+// Why another convolution kernel.  conv_dma.hip is an implicit GEMM: every k-tile DMAs a fresh [BM rows][32 channels]
+// slice of the im2col matrix, so a 1x7 layer moves each input pixel SEVEN times from L2 to LDS (a 3x3 nine, a 5x5
+// twenty-five times).  The L2 -> LDS path of a CU delivers about 70 GB/s (MI355X_MICROARCH.md, "Indexed rows: gather
+// into LDS", rows served by the XCD's L2); a 256 x 192 tile at the full MFMA rate needs 89 GB/s of im2col rows, a
+// 256 x 128 tile 114, a 256 x 64 tile 190 — the operand feed, not the matrix pipe, sets those kernels' ceiling, and
+// every wave also stalls 100 - 200 clocks per DMA instruction it issues next to its own MFMAs.  Here
+//   * STRIP mode (stride-1 "same-grid" convolutions: oh x ow = ih x iw): the tile's BM output pixels are BM consecutive
+//     pixels of the flattened (image, y, x) grid, and tap (dy, dx) of pixel m is pixel m + dy*iw + dx — so ONE strip
+//     of halo_lo + BM + halo_hi consecutive input pixels per 32-channel chunk serves all taps: the consumers read their
+//     A fragments at a per-tap ROW SHIFT (rows outside the image are redirected to a zero row in LDS by a per-lane tap
+//     mask), and only the filter slice is new per tap.  A 1x7 layer's A traffic falls 7x, a 3x3's 9x.
+//   * GEMM mode (1x1): the strip is the tile itself and changes every k-step — a plain loader-fed GEMM ring.
+//   * four loader waves (one per SIMD) do all address arithmetic and every global_load_lds; eight consumer waves (two
+//     per SIMD, 64 x 32*TN outputs each) never touch vector memory inside the k-loop.  One raw s_barrier per k-step is
+//     both the FULL and the FREE signal; the loaders run NB - 1 k-steps (and one strip) ahead behind counted vmcnt.
+//
+// LDS: [zero row][B ring: NB slots of BN rows x 64 B][A strips: NA buffers of strip_rows x 64 B]; rows are 64 bytes
+// (32 channels), 16-byte chunks XOR-swizzled by (row >> 2) & 3 — on the SOURCE address by the loader (a DMA instruction
+// writes 1 KiB lane-linearly) and on the read address by the consumer; a row shift keeps the 16 rows of every
+// ds_read_b128 service group distinct modulo 16, so the shifted reads stay conflict-free.
+// k order: channel chunk outer, filter tap inner (conv_dma.hip's chunk-major order): k-step (c, t) multiplies strip c
+// at shift(t) with filter columns [t*cin + 32c, +32) of the packed [cout][Kpad] filter.
+#include <type_traits>
+
+#include "conv_common.h"
+#include "conv_lp_epi.h"
+
+namespace {
+
+constexpr int WS_NLW = 4;                      // loader waves
+constexpr int WS_RB = 64;                      // bytes of one LDS row: 32 channels
+constexpr int WS_ZERO = 128;                   // bytes in front of the ring: the zero row (64 used)
+
+struct WsArgs {
+    int taps, nchunks, nk;                     // kh*kw, cin/32, taps*nchunks
+    int halo_lo;                               // strip rows in front of the tile's first pixel
+    int strip_blocks, strip_bytes;             // 16-row blocks per strip buffer, bytes per buffer
+    int na;                                    // strip buffers
+    int pad_;
+};
+
+__device__ __forceinline__ void ws_dma16(const char* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void ws_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void ws_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// bytes of LDS the k-loop uses / the epilogue re-uses
+template <int WM, int WN, int TM, int TN, int NB>
+constexpr int ws_ring_bytes(int na, int strip_bytes) { return WS_ZERO + NB * (WN * TN * 32) * WS_RB + na * strip_bytes; }
+template <int WM, int WN, int TN>
+constexpr int ws_epi_bytes() { return WM * WN * EpiGeom<TN>::BYTES + 16 * WN * TN * 32; }   // staging blocks + constants table
+
+template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM>
+__global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArgs a, const WsArgs w) {
+    constexpr int NC = WM * WN;                                    // consumer waves
+    constexpr int NT = (NC + WS_NLW) * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int B_SLOT = BN * WS_RB;
+    constexpr int OFF_B = WS_ZERO, OFF_S = OFF_B + NB * B_SLOT;
+    constexpr int UB = BN / 16, LB = (UB + WS_NLW - 1) / WS_NLW;   // filter row blocks: DMA instructions per loader and k-step
+    constexpr int LA = BM / 16 / WS_NLW;                           // GEMM mode: strip instructions per loader and k-step
+    constexpr int PER = GEMM ? LA + LB : LB;                       // loads per loader wave and k-step the vmcnt counts rely on
+    static_assert(BM % (16 * WS_NLW) == 0, "whole strip blocks per loader");
+    static_assert(NB >= 3 && (NB - 1) * PER < 64, "ring depth / vmcnt range");
+    static_assert(STATS == 0 || STATS == gvconv::STAT_LEAN, "BatchNorm sums: conv_dma.hip");
+
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+#ifdef GV_PHASE_TIMES
+    unsigned long long gv_pt[5] = {0, 0, 0, 0, 0}, gv_wait = 0;
+#define WS_PT(i) gv_pt[i] = __builtin_amdgcn_s_memtime()
+#define WS_WAIT_BEGIN() const unsigned long long gv_w0 = __builtin_amdgcn_s_memtime()
+#define WS_WAIT_END() gv_wait += __builtin_amdgcn_s_memtime() - gv_w0
+#else
+#define WS_PT(i)
+#define WS_WAIT_BEGIN()
+#define WS_WAIT_END()
+#endif
+    WS_PT(0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = gv_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lid % a.tiles_n, tile_m = lid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = w.nk, NTAP = w.taps;
+
+    // the epilogue's per-column constants: requested now, published into LDS behind the staging blocks once the ring is free
+    float ss_v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool ss_dual = a.y2 != nullptr && a.split == 0;
+    if (tid < BN) {
+        const int cc = min(n0 + tid, a.cout - 1);
+        ss_v[0] = a.scale[cc];
+        ss_v[1] = a.shift[cc];
+        if (ss_dual) { ss_v[2] = a.scale2[cc]; ss_v[3] = a.shift2[cc]; }
+    }
+    f32x16 acc[TM][TN];
+
+    if (wave >= NC) {
+        // =================================================== loader ===================================================
+        const int lw = wave - NC;
+        const int lrow = lane >> 2;                                // row inside a 16-row block
+        const int lc = (lane & 3) ^ ((lrow >> 2) & 3);             // logical 16-byte chunk this lane fetches (swizzle at the source)
+        const char* xb = reinterpret_cast<const char*>(a.x);
+        const unsigned pix_bytes = (unsigned)a.x_ld * 2u;
+        const char* b_ptr[LB];
+        int b_dst[LB];
+        {
+            const size_t wrow = (size_t)a.Kpad * 2;
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                int rb = lw + i * WS_NLW;
+                rb = rb < UB ? rb : UB - 1;                        // surplus slots re-load the last block (same bytes)
+                int n = n0 + rb * 16 + lrow;
+                n = n < a.cout ? n : a.cout - 1;                   // columns past cout are never stored
+                b_ptr[i] = reinterpret_cast<const char*>(a.w) + (size_t)n * wrow + lc * 16;
+                b_dst[i] = OFF_B + rb * 1024;
+            }
+        }
+        int bq_t = 0, bq_c = 0, bq_slot = 0;                       // next filter slice to issue: tap, chunk, ring slot
+        int sq_c = 0, sq_buf = 0;                                  // next strip to issue: chunk, buffer
+        auto issue_b = [&]() {
+            const unsigned koff = (unsigned)(bq_t * a.cin + bq_c * 32) * 2u;
+            char* sb = smem + bq_slot * B_SLOT;
+#pragma unroll
+            for (int i = 0; i < LB; ++i) ws_dma16(b_ptr[i] + koff, sb + b_dst[i]);
+            if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
+            bq_slot = bq_slot + 1 == NB ? 0 : bq_slot + 1;
+        };
+        auto issue_strip = [&]() {
+            char* sb = smem + OFF_S + sq_buf * w.strip_bytes;
+            const unsigned coff = (unsigned)sq_c * 64u + (unsigned)lc * 16u;
+            if constexpr (GEMM) {
+#pragma unroll
+                for (int i = 0; i < LA; ++i) {
+                    const int blk = lw + i * WS_NLW;
+                    int p = m0 + blk * 16 + lrow;
+                    p = p < a.M ? p : a.M - 1;
+                    ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                }
+            } else {
+                for (int blk = lw; blk < w.strip_blocks; blk += WS_NLW) {
+                    int p = m0 - w.halo_lo + blk * 16 + lrow;      // rows outside [0, M) are only ever read by masked taps
+                    p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
+                    ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                }
+            }
+            ++sq_c;
+            sq_buf = sq_buf + 1 == w.na ? 0 : sq_buf + 1;
+        };
+        // prologue: strip 0 and filter slice 0 first (the consumers' first fragments), then the rest of both rings
+        issue_strip();
+        issue_b();
+        if constexpr (GEMM) {
+#pragma unroll
+            for (int q = 1; q < NB; ++q) { issue_strip(); issue_b(); }        // (nk >= NB: the launcher checks)
+        } else {
+#pragma unroll
+            for (int q = 1; q < NB; ++q) issue_b();
+            if (w.nchunks > 1) issue_strip();
+        }
+        WS_PT(1);
+        ws_wait_vm<(NB - 1) * PER>();                              // everything up to filter slice 0 has landed
+        __builtin_amdgcn_s_barrier();
+        int ft = 0;                                                // tap of k-step j
+        for (int j = 0; j + 1 < nk; ++j) {
+            // k-step j+1 must be in LDS before the barrier: the NB-2 k-steps issued after it may stay in flight (a strip
+            // issued in between only makes the wait stricter; in the drain wait for everything)
+            WS_WAIT_BEGIN();
+            if (j + NB - 1 <= nk - 1) ws_wait_vm<(NB - 2) * PER>();
+            else ws_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();                          // ... and every consumer is done with k-step j's LDS
+            WS_WAIT_END();
+            const bool last_tap = ft + 1 == NTAP;
+            if constexpr (GEMM) {
+                if (j + NB < nk) { issue_strip(); issue_b(); }
+            } else {
+                if (last_tap && sq_c < w.nchunks) issue_strip();   // the strip this chunk occupied is free: chunk + NA
+                if (j + NB < nk) issue_b();
+            }
+            ft = last_tap ? 0 : ft + 1;
+        }
+        WS_PT(2);
+    } else {
+        // ================================================== consumer ==================================================
+        const int wm = wave / WN, wn = wave % WN;
+        const int r = lane & 31, h = lane >> 5;
+        if (tid < 16) reinterpret_cast<unsigned*>(smem)[tid] = 0u; // the zero row: bytes [0, 64)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        // this lane's rows: strip row of the un-shifted tap and one bit per tap "inside the image"
+        int rbase[TM];
+        unsigned tapmask[TM];
+        {
+            const int ohow = a.oh * a.ow;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int lr = (wm * TM + i) * 32 + r;
+                rbase[i] = lr + w.halo_lo;
+                int m = m0 + lr;
+                m = m < a.M ? m : a.M - 1;
+                const int n = gv_div(m, a.y_div_img);
+                const int rem = m - n * ohow;
+                const int y = gv_div(rem, a.y_div_row);
+                const int x = rem - y * a.ow;
+                const int r_lo = max(0, a.pad_t - y), r_hi = min(a.kh, a.ih + a.pad_t - y);
+                const int c_lo = max(0, a.pad_l - x), c_hi = min(a.kw, a.iw + a.pad_l - x);
+                const unsigned rowbits = c_hi > c_lo ? (1u << c_hi) - (1u << c_lo) : 0u;
+                unsigned tm = 0u;
+                for (int fr = 0; fr < a.kh; ++fr)
+                    if (fr >= r_lo && fr < r_hi) tm |= rowbits << (fr * a.kw);
+                tapmask[i] = tm;
+            }
+        }
+        int b0[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int brow = (wn * TN + j) * 32 + r;
+            b0[j] = OFF_B + brow * WS_RB + ((((brow >> 2) & 3) ^ h) << 4);
+        }
+        // A fragment address (k16-step 0; step 1 is this ^ 32) of row block i for the tap at row shift `off` / mask bit
+        // `bit`, strip buffer at byte `sbase`; a tap outside the image reads the zero row
+        auto a_addr = [&](int i, int off, unsigned bit, int sbase) -> int {
+            const int row = rbase[i] + off;
+            const int ad = sbase + (row << 6) + ((((row >> 2) & 3) ^ h) << 4);
+            return (tapmask[i] & bit) ? ad : (h << 4);
+        };
+        int q_fr = 0, q_fs = 0, q_tap = 0;                         // tap of the k-step whose addresses are in aa[]
+        int sbase = OFF_S, sbuf = 0, bslot = 0;                    // its strip buffer / filter slot (bytes)
+        int aa[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) aa[i] = a_addr(i, -(a.pad_t * a.iw + a.pad_l), 1u, sbase);
+        u32x4 fa[2][TM], fb[2][TN];
+        auto lds16 = [&](int addr) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + addr); };
+        // one fragment read (q-th of the TM + TN of a k16-step) into register set S
+        auto read_one = [&](auto setc, int q, int sx, const int (&av)[TM], int bs) {
+            constexpr int S = decltype(setc)::value;
+            if (q < TM) fa[S][q] = lds16(av[q] ^ sx);
+            else fb[S][q - TM] = lds16(bs + (b0[q - TM] ^ sx));
+        };
+        // the MFMAs of one k16-step on set S; behind them, one per MFMA, the reads of the next k16-step into set S^1
+        auto half = [&](auto setc, auto readc, int sx, const int (&av)[TM], int bs) {
+            constexpr int S = decltype(setc)::value;
+            constexpr bool READ = decltype(readc)::value;
+#pragma unroll
+            for (int m = 0; m < TM * TN; ++m) {
+                const int i = m / TN, j = m % TN;
+                acc[i][j] = mfma16<T>(fa[S][i], fb[S][j], acc[i][j]);
+                if constexpr (READ) {
+                    if (m < TM + TN) read_one(std::integral_constant<int, S ^ 1>{}, m, sx, av, bs);
+                }
+            }
+            if constexpr (READ) {
+#pragma unroll
+                for (int q = TM * TN; q < TM + TN; ++q) read_one(std::integral_constant<int, S ^ 1>{}, q, sx, av, bs);
+            }
+        };
+        using TT = std::true_type;
+        using FF = std::false_type;
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        ws_wait_lds();
+        WS_PT(1);
+        __builtin_amdgcn_s_barrier();                              // strip 0, filter slice 0 and the zero row are in LDS
+        WS_PT(2);
+#pragma unroll
+        for (int q = 0; q < TM + TN; ++q) read_one(S0{}, q, 0, aa, 0);
+        for (int j = 0; j + 1 < nk; ++j) {
+            // first k16-step; behind its MFMAs the second one's fragments (same strip rows and filter slot, chunk ^ 2)
+            half(S0{}, TT{}, 32, aa, bslot);
+            // the next k-step's tap, strip buffer and slot
+            int an[TM];
+            {
+                if (++q_fs == a.kw) { q_fs = 0; ++q_fr; }
+                if (++q_tap == NTAP) {
+                    q_tap = 0; q_fs = 0; q_fr = 0;
+                    sbuf = sbuf + 1 == w.na ? 0 : sbuf + 1;
+                    sbase = OFF_S + sbuf * w.strip_bytes;
+                }
+                const int off = (q_fr - a.pad_t) * a.iw + (q_fs - a.pad_l);
+                const unsigned bit = 1u << q_tap;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) an[i] = a_addr(i, off, bit, sbase);
+            }
+            const int bnext = bslot + B_SLOT == NB * B_SLOT ? 0 : bslot + B_SLOT;
+            ws_wait_lds();                                         // this wave's reads of k-step j have completed ...
+            WS_WAIT_BEGIN();
+            __builtin_amdgcn_s_barrier();                          // ... k-step j+1 is in LDS, k-step j's LDS may be overwritten
+            WS_WAIT_END();
+            half(S1{}, TT{}, 0, an, bnext);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) aa[i] = an[i];
+            bslot = bnext;
+        }
+        half(S0{}, TT{}, 32, aa, bslot);
+        half(S1{}, FF{}, 0, aa, bslot);
+        WS_PT(3);
+    }
+    // ====================================================== epilogue ======================================================
+    __syncthreads();                                               // every wave is done with the ring: the staging blocks alias it
+    constexpr int SS_OFF = NC * EpiGeom<TN>::BYTES;
+    float* sstab = !(a.dbg & 512) ? reinterpret_cast<float*>(smem + SS_OFF) : nullptr;   // dbg 512: constants from global (A/B)
+    if (sstab != nullptr && tid < BN) {
+        sstab[tid] = ss_v[0];
+        sstab[BN + tid] = ss_v[1];
+        if (ss_dual) { sstab[2 * BN + tid] = ss_v[2]; sstab[3 * BN + tid] = ss_v[3]; }
+    }
+    __syncthreads();
+    if (wave < NC) {
+        const int wm = wave / WN, wn = wave % WN;
+        lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES), 32,
+                                             sstab, BN, smem, 0);
+    }
+#ifdef GV_PHASE_TIMES
+    WS_PT(4);
+    if (a.phase_buf && lane == 0) {                                // [workgroup][wave][8]: t0..t4, wait clocks, HW_ID | XCC_ID, role
+        unsigned long long* o = a.phase_buf + ((size_t)blockIdx.x * (NC + WS_NLW) + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = gv_pt[i];
+        o[5] = gv_wait;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        o[7] = wave >= NC ? 1ull : 0ull;
+    }
+#endif
+    (void)NT;
+}
+
+#ifndef GV_KERNEL_ONLY
+// STRIP mode: stride 1, output grid = input grid, <= 32 taps; GEMM mode: 1x1.  Whole 32-channel chunks, 16-byte pixels.
+bool ws_shape_ok(const ConvArgs& a) {
+    return a.stride == 1 && a.dil_shift == 0 && a.oh == a.ih && a.ow == a.iw && a.cin % 32 == 0 && a.x_ld % 8 == 0 &&
+           a.kh * a.kw <= 32 && a.kw < 32 && a.pad_t < a.kh && a.pad_l < a.kw && a.pool == 0 && a.xscale == nullptr &&
+           a.y_step == 0 && a.st.mode == gvconv::STAT_OFF && a.K % 32 == 0;
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int NB>
+int launch_ws(const ConvArgs& a0, hipStream_t st) {
+    constexpr int NC = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    if (!ws_shape_ok(a0)) return GV_E_UNSUPPORTED;
+    ConvArgs a = a0;
+    a.Kpad = a.K;                                                  // (K % 32 == 0: the packed filter has no padding)
+    WsArgs w;
+    w.taps = a.kh * a.kw;
+    w.nchunks = a.cin / 32;
+    w.nk = w.taps * w.nchunks;
+    const bool gemm = w.taps == 1;
+    if (w.nk < NB || (!gemm && w.taps < NB - 1)) return GV_E_UNSUPPORTED;
+    w.halo_lo = a.pad_t * a.iw + a.pad_l;
+    const int halo_hi = (a.kh - 1 - a.pad_t) * a.iw + (a.kw - 1 - a.pad_l);
+    w.strip_blocks = gemm ? BM / 16 : gv_ceil_div(w.halo_lo + BM + halo_hi, 16);
+    w.strip_bytes = w.strip_blocks * 16 * WS_RB;
+    w.na = gemm ? NB : 2;
+    w.pad_ = 0;
+    a.tiles_n = gv_ceil_div(a.cout, BN);
+    const int64_t nwg = (int64_t)gv_ceil_div(a.M, BM) * a.tiles_n;
+    if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
+    const size_t ring = (size_t)WS_ZERO + (size_t)NB * BN * WS_RB + (size_t)w.na * w.strip_bytes;
+    const size_t epi = (size_t)ws_epi_bytes<WM, WN, TN>();
+    const size_t lds = ring > epi ? ring : epi;
+    if (lds > 160 * 1024) return GV_E_UNSUPPORTED;
+    auto go = [&](auto mode, auto gm) -> int {
+        auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, decltype(gm)::value>;
+        if (lds > 64 * 1024) {
+            const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
+            if (!ok) return GV_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((NC + WS_NLW) * 64), lds, st, a, w);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    };
+    const bool lean = gvconv::lp_epilogue_lean_ok(a);
+    using L = std::integral_constant<int, gvconv::STAT_LEAN>;
+    using F = std::integral_constant<int, 0>;
+    if (gemm) return lean ? go(L{}, std::true_type{}) : go(F{}, std::true_type{});
+    return lean ? go(L{}, std::false_type{}) : go(F{}, std::false_type{});
+}
+
+template <typename T>
+int launch_ws_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_ws<T, 4, 2, 2, 3, 4>(a, st);         // 256 x 192: 8 consumers of 64 x 96
+        case 1: return launch_ws<T, 4, 2, 2, 2, 4>(a, st);         // 256 x 128
+        case 2: return launch_ws<T, 8, 1, 2, 3, 4>(a, st);         // 512 x 96
+        case 3: return launch_ws<T, 8, 1, 2, 2, 4>(a, st);         // 512 x 64
+        case 4: return launch_ws<T, 4, 2, 2, 1, 4>(a, st);         // 256 x 64
+    }
+    return GV_E_UNSUPPORTED;
+}
+#endif
+
+}  // namespace
+
+#ifndef GV_KERNEL_ONLY
+namespace gvconv {
+
+int ws_lp_num_cfgs() { return 5; }
+
+int ws_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st) {
+    if (dtype == GV_BF16) return launch_ws_cfg<__bf16>(cfg, a, st);
+    if (dtype == GV_F16) return launch_ws_cfg<_Float16>(cfg, a, st);
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace gvconv
+#endif

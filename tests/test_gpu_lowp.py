@@ -265,6 +265,86 @@ def test_lp_dma_k64_tiles_vs_oracle(k, stride, padding, cin, cout, tile_i, ty):
     close(y, ref.numpy(), ulp)
 
 
+def ws_tiles():
+    """The wave-specialised kernel's tile configurations (csrc/conv_ws.hip) follow the 25 LDS-DMA tiles."""
+    return dma_tiles()[25:]
+
+
+WS_COMBOS = [
+    ((1, 7), "SAME", 128, 128, (12, 12)), ((7, 1), "SAME", 160, 192, (12, 12)), ((7, 1), "SAME", 192, 200, (17, 17)),
+    ((3, 3), "SAME", 64, 96, (25, 25)), ((3, 3), "SAME", 96, 48, (9, 10)), ((5, 5), "SAME", 64, 64, (13, 11)),
+    ((1, 3), "SAME", 384, 384, (5, 5)), ((3, 1), "SAME", 448, 384, (8, 8)), ((1, 1), "SAME", 192, 48, (23, 20)),
+    ((1, 1), "SAME", 768, 704, (12, 12)), ((3, 3), (2, 2, 2, 2), 64, 32, (21, 37)), ((1, 1), "SAME", 128, 40, (3, 7)),
+]
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("k,padding,cin,cout,hw", WS_COMBOS)
+def test_lp_ws_tiles_vs_oracle(k, padding, cin, cout, hw, ty):
+    """The wave-specialised kernel (loader waves + MFMA consumer waves; tap re-use from one LDS strip per channel chunk):
+    every tile on the stride-1 same-grid layer classes of Inception-v3 (1x7, 7x1, 3x3, 5x5, 1x3, 3x1) and on 1x1 GEMMs —
+    image rows narrower and wider than a wave's 32 pixels, tiles that span several images, ragged M and cout, padding
+    larger than SAME (a data gradient's), residual + ReLU, channel-slice operands whose pixels are only 16-byte aligned."""
+    code, td, ulp = TYPES[ty]
+    assert len(ws_tiles()) == 5
+    g = torch.Generator().manual_seed(hash((k, cin, cout, hw)) % 1000)
+    ih, iw = hw
+    nb = 5 if ih * iw < 200 else 3
+    x = rnd(torch.randn(nb, ih, iw, cin, generator=g), td)
+    w = rnd(torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5), td)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    if isinstance(padding, str):
+        pads = (tf_pads(ih, k[0], 1, padding), tf_pads(iw, k[1], 1, padding))
+    else:
+        pads = (padding[0], padding[2])
+    ref0 = oracle_conv(x, w, 1, padding, scale, shift, False)
+    same_grid = tuple(ref0.shape[1:3]) == (ih, iw)
+    res = rnd(torch.randn(ref0.shape, generator=g), td)
+    ref = oracle_conv(x, w, 1, padding, scale, shift, True, residual=res)
+    for tile in ws_tiles():
+        if not same_grid:                       # (a full-padding 3x3 grows the map: not this kernel's class)
+            run_conv(x, w, 1, pads, ref.shape[1:3], scale, shift, True, ty, residual=res, tile=tile, expect=_lib.GV_E_UNSUPPORTED)
+            continue
+        y = run_conv(x, w, 1, pads, ref.shape[1:3], scale, shift, True, ty, residual=res, tile=tile,
+                     x_ld=cin + 16, x_off=8, y_ld=cout + 24, y_off=16)
+        close(y, ref.numpy(), ulp)
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+def test_lp_ws_tiles_split_and_dual_outputs(ty):
+    """A fused sibling GEMM's two destinations (split on a chunk boundary, partial ReLU) and a second activation of the
+    same values through every wave-specialised tile — the lean two-destination epilogue and the full one."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(11)
+    x = rnd(torch.randn(4, 12, 12, 192, generator=g), td)
+    w = rnd(torch.randn(1, 1, 192, 224, generator=g) * 0.07, td)
+    scale, shift = torch.rand(224, generator=g) + 0.5, torch.randn(224, generator=g) * 0.1
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, True)
+    sc2, sh2 = torch.rand(224, generator=g) + 0.5, torch.randn(224, generator=g) * 0.1
+    ref2 = torch.relu(oracle_conv(x, w, 1, "SAME", scale, shift, False) * sc2 + sh2)
+    for tile in ws_tiles():
+        y, y2 = run_conv(x, w, 1, (0, 0), (12, 12), scale, shift, True, ty, split=64, y_ld=256, y_off=0, tile=tile)
+        close(y, ref.numpy()[..., :64], ulp)
+        close(y2, ref.numpy()[..., 64:], ulp)
+        y, y2 = run_conv(x, w, 1, (0, 0), (12, 12), scale, shift, False, ty, second=(sc2, sh2), tile=tile)
+        close(y, oracle_conv(x, w, 1, "SAME", scale, shift, False).numpy(), ulp)
+        close(y2, ref2.numpy(), ulp)
+
+
+def test_lp_ws_tiles_decline_other_classes():
+    """Strided, map-changing (VALID) and cin % 32 != 0 layers are not the wave-specialised kernel's: GV_E_UNSUPPORTED."""
+    g = torch.Generator().manual_seed(5)
+    U = _lib.GV_E_UNSUPPORTED
+    x = rnd(torch.randn(2, 9, 10, 96, generator=g), torch.bfloat16)
+    w = rnd(torch.randn(3, 3, 96, 64, generator=g) * 0.05, torch.bfloat16)
+    run_conv(x, w, 2, (0, 0), (4, 4), torch.ones(64), torch.zeros(64), False, "bf16", tile=ws_tiles()[0], expect=U)
+    run_conv(x, w, 1, (0, 0), (7, 8), torch.ones(64), torch.zeros(64), False, "bf16", tile=ws_tiles()[1], expect=U)
+    x = rnd(torch.randn(2, 9, 10, 48, generator=g), torch.bfloat16)
+    w = rnd(torch.randn(5, 5, 48, 64, generator=g) * 0.05, torch.bfloat16)
+    run_conv(x, w, 1, (2, 2), (9, 10), torch.ones(64), torch.zeros(64), False, "bf16", tile=ws_tiles()[2], expect=U)
+
+
 def test_lp_dma_k64_tiles_decline_other_channel_counts():
     """cin % 64 != 0: the 64-deep tiles return GV_E_UNSUPPORTED (the autotuner skips them), nothing is written."""
     g = torch.Generator().manual_seed(3)
