@@ -31,9 +31,17 @@
 
 namespace {
 
-constexpr int WS_NLW = 4;                      // loader waves
-constexpr int WS_RB = 64;                      // bytes of one LDS row: 32 channels
-constexpr int WS_ZERO = 128;                   // bytes in front of the ring: the zero row (64 used)
+constexpr int WS_ZERO = 128;                   // bytes in front of the ring: the zero row
+// KT channels per k-step: LDS rows of 64 bytes (KT = 32; 16 rows per DMA instruction, chunk swizzle (row >> 2) & 3) or of
+// 128 bytes (KT = 64: whole cache lines of the source, 8 rows per instruction, swizzle (row >> 1) & 7, half the barriers
+// and tap address updates per MFMA; needs cin % 64 == 0)
+template <int KT> struct WsGeom {
+    static constexpr int RB = KT * 2;          // bytes of one LDS row
+    static constexpr int RPI = 1024 / RB;      // rows per DMA instruction
+    static constexpr int CPR = RB / 16;        // 16-byte chunks per row
+    static constexpr int KS = KT / 16;         // MFMA k-steps per k-step of the ring
+    __host__ __device__ static constexpr int swz(int row) { return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+};
 
 struct WsArgs {
     int taps, nchunks, nk;                     // kh*kw, cin/32, taps*nchunks
@@ -54,23 +62,36 @@ __device__ __forceinline__ void ws_wait_vm() {
 }
 __device__ __forceinline__ void ws_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// bytes of LDS the k-loop uses / the epilogue re-uses
-template <int WM, int WN, int TM, int TN, int NB>
-constexpr int ws_ring_bytes(int na, int strip_bytes) { return WS_ZERO + NB * (WN * TN * 32) * WS_RB + na * strip_bytes; }
+// register-staged loaders (RS): strip blocks per loader wave — compile-time, the registers that hold a strip in flight;
+// halo rows it leaves room for: 192 (64-byte rows) / 112 (128-byte rows: a 7x1 on 17-wide maps needs 102)
+constexpr int ws_rs_blocks(int bm, int kt, int nl) { return (bm + (kt == 64 ? 112 : 192) + (512 / kt) * nl - 1) / ((512 / kt) * nl); }
+// bytes of LDS the epilogue re-uses
 template <int WM, int WN, int TN>
 constexpr int ws_epi_bytes() { return WM * WN * EpiGeom<TN>::BYTES + 16 * WN * TN * 32; }   // staging blocks + constants table
 
-template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM>
-__global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArgs a, const WsArgs w) {
+// NL loader waves.  Eight consumers + four loaders = one 768-thread workgroup per CU; four consumers + two loaders = a
+// 384-thread workgroup, two per CU (three waves per SIMD either way: 168 registers) — the second workgroup's k-loop
+// covers the first one's epilogue, at twice the filter traffic per flop.
+// RS = 1: REGISTER-STAGED loaders.  A wave issues one global_load_lds per 130 - 250 clocks next to busy consumers
+// (profiles/r5_ws_phase_times.txt: the loaders of the DMA form are busy 70 - 85 % of the k-loop issuing 3 - 8 instructions
+// per k-step), but a dedicated loader wave has 168 registers it does not otherwise need: plain global_load_dwordx4 into
+// registers (issued up to two k-steps ahead, before the ring slot is free — the registers ARE two more ring stages) and
+// ds_write_b128 into the same swizzled image once the slot's barrier has passed.
+template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM, int KT = 32, int NL = 4, int RS = 0>
+__global__ __launch_bounds__((WM * WN + NL) * 64, 3) void conv_ws(const ConvArgs a, const WsArgs w) {
+    constexpr int WS_NLW = NL;
+    using G = WsGeom<KT>;
+    constexpr int WS_RB = G::RB, RPI = G::RPI, CPR = G::CPR, KS = G::KS;
     constexpr int NC = WM * WN;                                    // consumer waves
     constexpr int NT = (NC + WS_NLW) * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int B_SLOT = BN * WS_RB;
     constexpr int OFF_B = WS_ZERO, OFF_S = OFF_B + NB * B_SLOT;
-    constexpr int UB = BN / 16, LB = (UB + WS_NLW - 1) / WS_NLW;   // filter row blocks: DMA instructions per loader and k-step
-    constexpr int LA = BM / 16 / WS_NLW;                           // GEMM mode: strip instructions per loader and k-step
+    constexpr int UB = BN / RPI, LB = (UB + WS_NLW - 1) / WS_NLW;  // filter row blocks: DMA instructions per loader and k-step
+    constexpr int LA = BM / RPI / WS_NLW;                          // GEMM mode: strip instructions per loader and k-step
     constexpr int PER = GEMM ? LA + LB : LB;                       // loads per loader wave and k-step the vmcnt counts rely on
-    static_assert(BM % (16 * WS_NLW) == 0, "whole strip blocks per loader");
+    static_assert(BM % (RPI * WS_NLW) == 0, "whole strip blocks per loader");
+    static_assert(KS % 2 == 0, "the fragment register sets alternate per MFMA k-step");
     static_assert(NB >= 3 && (NB - 1) * PER < 64, "ring depth / vmcnt range");
     static_assert(STATS == 0 || STATS == gvconv::STAT_LEAN, "BatchNorm sums: conv_dma.hip");
 
@@ -108,8 +129,15 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
     if (wave >= NC) {
         // =================================================== loader ===================================================
         const int lw = wave - NC;
-        const int lrow = lane >> 2;                                // row inside a 16-row block
-        const int lc = (lane & 3) ^ ((lrow >> 2) & 3);             // logical 16-byte chunk this lane fetches (swizzle at the source)
+        if (!(a.dbg & 16384)) {                                    // (debug bit 16384: consumers alone, no loads, no barriers — timing only)
+        // A loader shares its SIMD with two consumers whose MFMA / LDS / VALU streams never pause, and issue arbitration
+        // goes by priority, then age — the loaders are the workgroup's youngest waves.  Their few instructions per k-step
+        // go first (debug bit 4096: no priority, A/B).
+        if (!(a.dbg & 4096)) __builtin_amdgcn_s_setprio(3);
+        const int lrow = lane / CPR;                               // row inside a row block
+        // logical 16-byte chunk this lane fetches (swizzle at the source) in row block `blk`: with 128-byte rows the swizzle
+        // reaches the block's parity
+        auto lchunk = [&](int blk) -> int { return (lane % CPR) ^ G::swz(blk * RPI + lrow); };
         const char* xb = reinterpret_cast<const char*>(a.x);
         const unsigned pix_bytes = (unsigned)a.x_ld * 2u;
         const char* b_ptr[LB];
@@ -120,81 +148,256 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
             for (int i = 0; i < LB; ++i) {
                 int rb = lw + i * WS_NLW;
                 rb = rb < UB ? rb : UB - 1;                        // surplus slots re-load the last block (same bytes)
-                int n = n0 + rb * 16 + lrow;
+                int n = n0 + rb * RPI + lrow;
                 n = n < a.cout ? n : a.cout - 1;                   // columns past cout are never stored
-                b_ptr[i] = reinterpret_cast<const char*>(a.w) + (size_t)n * wrow + lc * 16;
+                b_ptr[i] = reinterpret_cast<const char*>(a.w) + (size_t)n * wrow + lchunk(rb) * 16;
                 b_dst[i] = OFF_B + rb * 1024;
             }
         }
-        int bq_t = 0, bq_c = 0, bq_slot = 0;                       // next filter slice to issue: tap, chunk, ring slot
-        int sq_c = 0, sq_buf = 0;                                  // next strip to issue: chunk, buffer
-        auto issue_b = [&]() {
-            const unsigned koff = (unsigned)(bq_t * a.cin + bq_c * 32) * 2u;
-            char* sb = smem + bq_slot * B_SLOT;
+        if constexpr (RS) {
+            // ------------------------------------------ register-staged loader ------------------------------------------
+            // RS = D: filter slices (GEMM mode: and A tiles) of D k-steps travel in registers, loaded by inline-asm
+            // global_load_dwordx4 (invisible to hipcc's waitcnt pass, which otherwise drains vmcnt(0) at every loop-carried
+            // use) and awaited by hand: vmcnt counts them in issue order.
+            constexpr int D = RS;
+            constexpr int MAXS = GEMM ? LA : ws_rs_blocks(BM, KT, WS_NLW);   // strip blocks per loader (capacity)
+            constexpr int PERQ = GEMM ? LA + LB : LB;              // loads per k-step and loader the counted waits rely on
+            static_assert((D - 1) * PERQ < 64, "vmcnt range");
+            const int wofs = lane * 16;                            // the DMA form's lane-linear image: block base + lane * 16
+            int bq_t = 0, bq_c = 0;                                // next filter slice to LOAD: tap, chunk
+            int sq_c = 0;                                          // next strip to load: chunk
+            // ("+v": the destination is the variable's own register — a conditional request must not become a fresh
+            // register that hipcc then copies into the variable's, at a point where the data has not arrived)
+            auto gload = [&](u32x4& dst, const char* ptr) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
+            };
+            auto load_b = [&](u32x4 (&dst)[LB]) {
+                const unsigned koff = (unsigned)(bq_t * a.cin + bq_c * KT) * 2u;
 #pragma unroll
-            for (int i = 0; i < LB; ++i) ws_dma16(b_ptr[i] + koff, sb + b_dst[i]);
-            if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
-            bq_slot = bq_slot + 1 == NB ? 0 : bq_slot + 1;
-        };
-        auto issue_strip = [&]() {
-            char* sb = smem + OFF_S + sq_buf * w.strip_bytes;
-            const unsigned coff = (unsigned)sq_c * 64u + (unsigned)lc * 16u;
+                for (int i = 0; i < LB; ++i) gload(dst[i], b_ptr[i] + koff);
+                if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
+            };
+            auto store_b = [&](u32x4 (&src)[LB], int slot) {
+                char* sb = smem + slot * B_SLOT + wofs;
+#pragma unroll
+                for (int i = 0; i < LB; ++i) {
+                    asm volatile("" : "+v"(src[i]));               // (defined by the wait in front of this call, not by the load)
+                    *reinterpret_cast<u32x4*>(sb + b_dst[i]) = src[i];
+                }
+            };
+            const unsigned lcoff = (unsigned)lchunk(lw) * 16u;
+            // strip blocks [lo, hi) of this loader's MAXS (static register indices, wave-uniform predicates)
+            auto load_strip = [&](u32x4 (&dst)[MAXS], int lo, int hi) {
+                const unsigned coff = (unsigned)sq_c * (unsigned)WS_RB + lcoff;
+#pragma unroll
+                for (int i = 0; i < MAXS; ++i) {
+                    if (i >= lo && i < hi) {
+                        int p = m0 - (GEMM ? 0 : w.halo_lo) + (lw + i * WS_NLW) * RPI + lrow;
+                        p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);   // (blocks past the strip: harmless rows, never read)
+                        gload(dst[i], xb + (size_t)(unsigned)p * pix_bytes + coff);
+                    }
+                }
+            };
+            auto store_strip = [&](u32x4 (&src)[MAXS], int buf) {
+                char* sb = smem + OFF_S + buf * w.strip_bytes + wofs;
+#pragma unroll
+                for (int i = 0; i < MAXS; ++i) {
+                    asm volatile("" : "+v"(src[i]));
+                    *reinterpret_cast<u32x4*>(sb + (lw + i * WS_NLW) * 1024) = src[i];
+                }
+            };
+            // ---- prologue: the first NB k-steps (and two strips) through the main loop's own registers (a loader wave with
+            // asm requests in flight must never spill: a spilled register is saved before its data has arrived)
+            static_assert(NB <= D, "the prologue requests the ring's k-steps into the D register sets");   // (RS = 2: two ring slots)
+            // the second strip of the prologue travels beside the first one where the registers allow it; else after it
+            constexpr bool EARLY1 = !GEMM && D * PERQ * 4 + MAXS * 8 <= 96;
+            static_assert(D * PERQ * 4 + (GEMM ? 0 : MAXS * 4) <= 128, "register-staged loader: too many registers in flight");
+            u32x4 rbq[D][LB];
+            u32x4 ra[GEMM ? D : 1][MAXS];                          // GEMM mode: the A tiles of the k-steps in flight
+            u32x4 rs[MAXS];                                        // STRIP mode: the strip two chunks ahead
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int i = 0; i < LB; ++i) rbq[d][i] = z4;
+#pragma unroll
+            for (int d = 0; d < (GEMM ? D : 1); ++d)
+#pragma unroll
+                for (int i = 0; i < MAXS; ++i) ra[d][i] = z4;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) rs[i] = z4;
             if constexpr (GEMM) {
 #pragma unroll
-                for (int i = 0; i < LA; ++i) {
-                    const int blk = lw + i * WS_NLW;
-                    int p = m0 + blk * 16 + lrow;
-                    p = p < a.M ? p : a.M - 1;
-                    ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
-                }
+                for (int q = 0; q < NB; ++q) { load_strip(ra[q], 0, MAXS); ++sq_c; load_b(rbq[q]); }
+                ws_wait_vm<(NB - 2) * PERQ>();
+                store_strip(ra[0], 0); store_b(rbq[0], 0);
+                store_strip(ra[1], 1); store_b(rbq[1], 1);
+                WS_PT(1);
+                ws_wait_lds();
+                __builtin_amdgcn_s_barrier();                      // k-steps 0 and 1 are published
+                ws_wait_vm<0>();
+#pragma unroll
+                for (int q = 2; q < NB; ++q) { store_strip(ra[q], q); store_b(rbq[q], q); }
             } else {
-                for (int blk = lw; blk < w.strip_blocks; blk += WS_NLW) {
-                    int p = m0 - w.halo_lo + blk * 16 + lrow;      // rows outside [0, M) are only ever read by masked taps
-                    p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
-                    ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                u32x4 rs1[EARLY1 ? MAXS : 1];                      // the second strip (live until it is stored, below)
+#pragma unroll
+                for (int i = 0; i < (EARLY1 ? MAXS : 1); ++i) rs1[i] = z4;
+                load_strip(rs, 0, MAXS); ++sq_c;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) load_b(rbq[q]);
+                if constexpr (EARLY1) {
+                    if (w.nchunks > 1) { load_strip(rs1, 0, MAXS); ++sq_c; }
+                    if (w.nchunks > 1) ws_wait_vm<(NB - 2) * LB + MAXS>(); else ws_wait_vm<(NB - 2) * LB>();
+                } else {
+                    ws_wait_vm<(NB - 2) * LB>();
+                }
+                store_strip(rs, 0); store_b(rbq[0], 0); store_b(rbq[1], 1);
+                WS_PT(1);
+                ws_wait_lds();
+                __builtin_amdgcn_s_barrier();                      // k-steps 0 and 1 are published
+                ws_wait_vm<0>();
+#pragma unroll
+                for (int q = 2; q < NB; ++q) store_b(rbq[q], q);
+                if constexpr (EARLY1) {
+                    if (w.nchunks > 1) store_strip(rs1, 1);
+                } else {
+                    if (w.nchunks > 1) { load_strip(rs, 0, MAXS); ++sq_c; ws_wait_vm<0>(); store_strip(rs, 1); }
                 }
             }
-            ++sq_c;
-            sq_buf = sq_buf + 1 == w.na ? 0 : sq_buf + 1;
-        };
-        // prologue: strip 0 and filter slice 0 first (the consumers' first fragments), then the rest of both rings
-        issue_strip();
-        issue_b();
-        if constexpr (GEMM) {
+            // k-step q >= NB travels in register set (q - NB) % D
 #pragma unroll
-            for (int q = 1; q < NB; ++q) { issue_strip(); issue_b(); }        // (nk >= NB: the launcher checks)
+            for (int d = 0; d < D; ++d) {
+                if (NB + d < nk && !(a.dbg & 1024)) {
+                    if constexpr (GEMM) { load_strip(ra[d], 0, MAXS); ++sq_c; }
+                    load_b(rbq[d]);
+                }
+            }
+            int slot = 0, ft = 0, cbuf = 0;                        // ring slot / tap / strip buffer of k-step j
+            bool have = false;                                     // STRIP mode: rs is being filled with strip sq_c
+            // strip blocks to request per k-step so that a strip is complete one k-step before its chunk's last
+            const int ppi = GEMM ? 0 : (MAXS + (NTAP > 2 ? NTAP - 2 : 0)) / (NTAP > 1 ? NTAP - 1 : 1);
+            auto iter = [&](auto setc, int j) {
+                constexpr int S = decltype(setc)::value;
+                WS_WAIT_BEGIN();
+                ws_wait_lds();                                     // this wave's ds_writes so far are in LDS
+                __builtin_amdgcn_s_barrier();                      // k-step j+1 is published; k-step j's slot is free
+                WS_WAIT_END();
+                const bool last_tap = ft + 1 == NTAP;
+                if constexpr (!GEMM) {
+                    // the strip two chunks ahead: requested piecewise over this chunk's k-steps, stored when the chunk's last
+                    // k-step has passed its barrier (its buffer is free then) — before this iteration's own requests
+                    if (last_tap && have) { ws_wait_vm<0>(); store_strip(rs, cbuf); have = false; ++sq_c; }
+                }
+                if (j + NB < nk && !(a.dbg & 1024)) {
+                    if (j + NB + D - 1 < nk) ws_wait_vm<(D - 1) * PERQ>();   // the D-1 k-steps requested after this one may be in flight
+                    else ws_wait_vm<0>();
+                    if constexpr (GEMM) store_strip(ra[S], slot);
+                    store_b(rbq[S], slot);
+                }
+                if (j + NB + D < nk && !(a.dbg & 1024)) {
+                    if constexpr (GEMM) { load_strip(ra[S], 0, MAXS); ++sq_c; }
+                    load_b(rbq[S]);
+                }
+                if constexpr (!GEMM) {
+                    if (!last_tap && sq_c < w.nchunks && !(a.dbg & 2048)) { load_strip(rs, ft * ppi, ft * ppi + ppi); have = true; }
+                }
+                slot = slot + 1 == NB ? 0 : slot + 1;
+                if (last_tap) { ft = 0; cbuf ^= 1; } else ++ft;
+            };
+            {
+                int j = 0;
+                for (; j + D < nk; j += D) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        if constexpr (D > 0) { if (d == 0) iter(std::integral_constant<int, 0>{}, j); }
+                        if constexpr (D > 1) { if (d == 1) iter(std::integral_constant<int, 1>{}, j + 1); }
+                        if constexpr (D > 2) { if (d == 2) iter(std::integral_constant<int, 2>{}, j + 2); }
+                        if constexpr (D > 3) { if (d == 3) iter(std::integral_constant<int, 3>{}, j + 3); }
+                        if constexpr (D > 4) { if (d == 4) iter(std::integral_constant<int, 4>{}, j + 4); }
+                        if constexpr (D > 5) { if (d == 5) iter(std::integral_constant<int, 5>{}, j + 5); }
+                    }
+                }
+                if constexpr (D > 0) { if (j + 1 < nk) { iter(std::integral_constant<int, 0>{}, j); ++j; } }
+                if constexpr (D > 1) { if (j + 1 < nk) { iter(std::integral_constant<int, 1>{}, j); ++j; } }
+                if constexpr (D > 2) { if (j + 1 < nk) { iter(std::integral_constant<int, 2>{}, j); ++j; } }
+                if constexpr (D > 3) { if (j + 1 < nk) { iter(std::integral_constant<int, 3>{}, j); ++j; } }
+                if constexpr (D > 4) { if (j + 1 < nk) { iter(std::integral_constant<int, 4>{}, j); ++j; } }
+                static_assert(D <= 6, "iteration dispatch");
+            }
         } else {
-#pragma unroll
-            for (int q = 1; q < NB; ++q) issue_b();
-            if (w.nchunks > 1) issue_strip();
-        }
-        WS_PT(1);
-        ws_wait_vm<(NB - 1) * PER>();                              // everything up to filter slice 0 has landed
-        __builtin_amdgcn_s_barrier();
-        int ft = 0;                                                // tap of k-step j
-        for (int j = 0; j + 1 < nk; ++j) {
-            // k-step j+1 must be in LDS before the barrier: the NB-2 k-steps issued after it may stay in flight (a strip
-            // issued in between only makes the wait stricter; in the drain wait for everything)
-            WS_WAIT_BEGIN();
-            if (j + NB - 1 <= nk - 1) ws_wait_vm<(NB - 2) * PER>();
-            else ws_wait_vm<0>();
-            __builtin_amdgcn_s_barrier();                          // ... and every consumer is done with k-step j's LDS
-            WS_WAIT_END();
-            const bool last_tap = ft + 1 == NTAP;
+            int bq_t = 0, bq_c = 0, bq_slot = 0;                       // next filter slice to issue: tap, chunk, ring slot
+            int sq_c = 0, sq_buf = 0;                                  // next strip to issue: chunk, buffer
+            auto issue_b = [&]() {
+                const unsigned koff = (unsigned)(bq_t * a.cin + bq_c * KT) * 2u;
+                char* sb = smem + bq_slot * B_SLOT;
+    #pragma unroll
+                for (int i = 0; i < LB; ++i) ws_dma16(b_ptr[i] + koff, sb + b_dst[i]);
+                if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
+                bq_slot = bq_slot + 1 == NB ? 0 : bq_slot + 1;
+            };
+            auto issue_strip = [&]() {
+                char* sb = smem + OFF_S + sq_buf * w.strip_bytes;
+                // (a loader's blocks lw, lw + 4, ... share their parity: one chunk per lane)
+                const unsigned coff = (unsigned)sq_c * (unsigned)WS_RB + (unsigned)lchunk(lw) * 16u;
+                if constexpr (GEMM) {
+    #pragma unroll
+                    for (int i = 0; i < LA; ++i) {
+                        const int blk = lw + i * WS_NLW;
+                        int p = m0 + blk * RPI + lrow;
+                        p = p < a.M ? p : a.M - 1;
+                        ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                    }
+                } else {
+                    for (int blk = lw; blk < w.strip_blocks; blk += WS_NLW) {
+                        int p = m0 - w.halo_lo + blk * RPI + lrow;     // rows outside [0, M) are only ever read by masked taps
+                        p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
+                        ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                    }
+                }
+                ++sq_c;
+                sq_buf = sq_buf + 1 == w.na ? 0 : sq_buf + 1;
+            };
+            // prologue: strip 0 and filter slice 0 first (the consumers' first fragments), then the rest of both rings
+            issue_strip();
+            issue_b();
             if constexpr (GEMM) {
-                if (j + NB < nk) { issue_strip(); issue_b(); }
+    #pragma unroll
+                for (int q = 1; q < NB; ++q) { issue_strip(); issue_b(); }        // (nk >= NB: the launcher checks)
             } else {
-                if (last_tap && sq_c < w.nchunks) issue_strip();   // the strip this chunk occupied is free: chunk + NA
-                if (j + NB < nk) issue_b();
+    #pragma unroll
+                for (int q = 1; q < NB; ++q) issue_b();
+                if (w.nchunks > 1) issue_strip();
             }
-            ft = last_tap ? 0 : ft + 1;
+            WS_PT(1);
+            ws_wait_vm<(NB - 2) * PER>();                              // everything up to filter slice 1 has landed
+            __builtin_amdgcn_s_barrier();
+            int ft = 0;                                                // tap of k-step j
+            for (int j = 0; j + 1 < nk; ++j) {
+                // k-step j+2 must be in LDS before barrier j (the consumers read its first fragments before barrier j+1): the
+                // NB-3 k-steps issued after it may stay in flight (a strip issued in between only makes the wait stricter; in
+                // the drain wait for everything)
+                WS_WAIT_BEGIN();
+                if (j + NB - 1 <= nk - 1) ws_wait_vm<(NB - 3) * PER>();
+                else ws_wait_vm<0>();
+                __builtin_amdgcn_s_barrier();                          // ... and every consumer is done with k-step j's LDS
+                WS_WAIT_END();
+                const bool last_tap = ft + 1 == NTAP;
+                if constexpr (GEMM) {
+                    if (j + NB < nk) { issue_strip(); issue_b(); }
+                } else {
+                    if (last_tap && sq_c < w.nchunks) issue_strip();   // the strip this chunk occupied is free: chunk + NA
+                    if (j + NB < nk) issue_b();
+                }
+                ft = last_tap ? 0 : ft + 1;
+            }
+        }
         }
         WS_PT(2);
     } else {
         // ================================================== consumer ==================================================
         const int wm = wave / WN, wn = wave % WN;
         const int r = lane & 31, h = lane >> 5;
-        if (tid < 16) reinterpret_cast<unsigned*>(smem)[tid] = 0u; // the zero row: bytes [0, 64)
+        if (tid < 32) reinterpret_cast<unsigned*>(smem)[tid] = 0u; // the zero row: bytes [0, 128)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -229,20 +432,22 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int brow = (wn * TN + j) * 32 + r;
-            b0[j] = OFF_B + brow * WS_RB + ((((brow >> 2) & 3) ^ h) << 4);
+            b0[j] = OFF_B + brow * WS_RB + ((G::swz(brow) ^ h) << 4);
         }
         // A fragment address (k16-step 0; step 1 is this ^ 32) of row block i for the tap at row shift `off` / mask bit
         // `bit`, strip buffer at byte `sbase`; a tap outside the image reads the zero row
-        auto a_addr = [&](int i, int off, unsigned bit, int sbase) -> int {
+        // (bit arithmetic, not a select: hipcc turns the select into exec-masked branches that cut the k-step's basic block)
+        auto a_addr = [&](int i, int off, int tap, int sbase) -> int {
             const int row = rbase[i] + off;
-            const int ad = sbase + (row << 6) + ((((row >> 2) & 3) ^ h) << 4);
-            return (tapmask[i] & bit) ? ad : (h << 4);
+            const int ad = sbase + row * WS_RB + ((G::swz(row) ^ h) << 4);
+            const int in = -(int)((tapmask[i] >> tap) & 1u);       // all ones: the tap lies inside the image
+            return (ad & in) | ((h << 4) & ~in);
         };
         int q_fr = 0, q_fs = 0, q_tap = 0;                         // tap of the k-step whose addresses are in aa[]
         int sbase = OFF_S, sbuf = 0, bslot = 0;                    // its strip buffer / filter slot (bytes)
         int aa[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) aa[i] = a_addr(i, -(a.pad_t * a.iw + a.pad_l), 1u, sbase);
+        for (int i = 0; i < TM; ++i) aa[i] = a_addr(i, -(a.pad_t * a.iw + a.pad_l), 0, sbase);
         u32x4 fa[2][TM], fb[2][TN];
         auto lds16 = [&](int addr) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + addr); };
         // one fragment read (q-th of the TM + TN of a k16-step) into register set S
@@ -252,15 +457,28 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
             else fb[S][q - TM] = lds16(bs + (b0[q - TM] ^ sx));
         };
         // the MFMAs of one k16-step on set S; behind them, one per MFMA, the reads of the next k16-step into set S^1
-        auto half = [&](auto setc, auto readc, int sx, const int (&av)[TM], int bs) {
+        // BAR: the k-step's barrier sits behind MFMA number BARPOS of this half — by then every fragment of register
+        // set S has been an MFMA operand, i.e. every LDS read of the k-step that ends here has returned (no lgkmcnt drain:
+        // the reads of the NEXT k-step, issued around the barrier, stay in flight), and the wave has matrix work queued
+        // while it waits.
+        constexpr int BARPOS = TN < TM * TN - 1 ? TN : TM * TN - 1;    // MFMA index (fa[1] and every fb have been used)
+        auto half = [&](auto setc, auto readc, int sx, const int (&av)[TM], int bs, auto barc, bool do_bar = true) {
             constexpr int S = decltype(setc)::value;
             constexpr bool READ = decltype(readc)::value;
+            constexpr bool BAR = decltype(barc)::value;
 #pragma unroll
             for (int m = 0; m < TM * TN; ++m) {
                 const int i = m / TN, j = m % TN;
                 acc[i][j] = mfma16<T>(fa[S][i], fb[S][j], acc[i][j]);
                 if constexpr (READ) {
                     if (m < TM + TN) read_one(std::integral_constant<int, S ^ 1>{}, m, sx, av, bs);
+                }
+                if constexpr (BAR) {
+                    if (m == BARPOS && do_bar) {
+                        WS_WAIT_BEGIN();
+                        __builtin_amdgcn_s_barrier();              // k-step j+2 is in LDS; k-step j's LDS may be overwritten
+                        WS_WAIT_END();
+                    }
                 }
             }
             if constexpr (READ) {
@@ -272,41 +490,68 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
         using FF = std::false_type;
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
+        const bool nosync = (a.dbg & 16384) != 0;
         ws_wait_lds();
         WS_PT(1);
-        __builtin_amdgcn_s_barrier();                              // strip 0, filter slice 0 and the zero row are in LDS
+        if (!nosync) __builtin_amdgcn_s_barrier();                 // strip 0, filter slices 0 and 1 and the zero row are in LDS
         WS_PT(2);
 #pragma unroll
         for (int q = 0; q < TM + TN; ++q) read_one(S0{}, q, 0, aa, 0);
+        // Stagger (debug bit 8192: off, A/B).  The two consumers of a SIMD are waves w and w + 4; run in lockstep they reach
+        // their MFMA bursts, their LDS reads and the barrier together and idle together.  Waves 4-7 therefore take the
+        // k-step's barrier HALF A K-STEP LATER in their own instruction stream (in the middle of the following k-step's
+        // first half instead of this one's last): every SIMD then has one wave in front of the barrier and one behind it.
+        // Legal: a wave's reads of k-step j have returned long before either point, and k-step j+2 — published by barrier j
+        // — is first read behind both.
+        const bool late = wave >= NC / 2 && !(a.dbg & 8192);
+        const bool early = !late && !nosync, lateb = late && !nosync;
         for (int j = 0; j + 1 < nk; ++j) {
-            // first k16-step; behind its MFMAs the second one's fragments (same strip rows and filter slot, chunk ^ 2)
-            half(S0{}, TT{}, 32, aa, bslot);
-            // the next k-step's tap, strip buffer and slot
+            // the next k-step's tap, strip buffer and slot (selects, no branches: a branch here would cut the basic block
+            // and keep this arithmetic from being scheduled between the MFMAs below)
             int an[TM];
             {
-                if (++q_fs == a.kw) { q_fs = 0; ++q_fr; }
-                if (++q_tap == NTAP) {
-                    q_tap = 0; q_fs = 0; q_fr = 0;
-                    sbuf = sbuf + 1 == w.na ? 0 : sbuf + 1;
-                    sbase = OFF_S + sbuf * w.strip_bytes;
-                }
+                const bool wrap = q_tap + 1 == NTAP;
+                const bool row_end = q_fs + 1 == a.kw;
+                q_tap = wrap ? 0 : q_tap + 1;
+                q_fr = wrap ? 0 : (row_end ? q_fr + 1 : q_fr);
+                q_fs = (wrap || row_end) ? 0 : q_fs + 1;
+                const int sb1 = sbuf + 1 == w.na ? 0 : sbuf + 1;
+                sbuf = wrap ? sb1 : sbuf;
+                sbase = OFF_S + sbuf * w.strip_bytes;
                 const int off = (q_fr - a.pad_t) * a.iw + (q_fs - a.pad_l);
-                const unsigned bit = 1u << q_tap;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) an[i] = a_addr(i, off, bit, sbase);
+                for (int i = 0; i < TM; ++i) an[i] = a_addr(i, off, q_tap, sbase);
             }
             const int bnext = bslot + B_SLOT == NB * B_SLOT ? 0 : bslot + B_SLOT;
-            ws_wait_lds();                                         // this wave's reads of k-step j have completed ...
-            WS_WAIT_BEGIN();
-            __builtin_amdgcn_s_barrier();                          // ... k-step j+1 is in LDS, k-step j's LDS may be overwritten
-            WS_WAIT_END();
-            half(S1{}, TT{}, 0, an, bnext);
+            // the k-step's first KS - 1 MFMA k-steps; behind each one's MFMAs the next one's fragments (same strip rows and
+            // filter slot, the chunk index advanced by XOR); the late waves' barrier j-1 sits in number KS/2 - 1
+#pragma unroll
+            for (int q = 0; q + 1 < KS; ++q) {
+                if (q == KS / 2 - 1) {
+                    if (q % 2 == 0) half(S0{}, TT{}, (q + 1) << 5, aa, bslot, TT{}, lateb && j > 0);
+                    else half(S1{}, TT{}, (q + 1) << 5, aa, bslot, TT{}, lateb && j > 0);
+                } else {
+                    if (q % 2 == 0) half(S0{}, TT{}, (q + 1) << 5, aa, bslot, FF{});
+                    else half(S1{}, TT{}, (q + 1) << 5, aa, bslot, FF{});
+                }
+            }
+            // the last one: the next k-step's first fragments (in LDS since the PREVIOUS barrier) and — early waves — barrier j
+            half(S1{}, TT{}, 0, an, bnext, TT{}, early);
 #pragma unroll
             for (int i = 0; i < TM; ++i) aa[i] = an[i];
             bslot = bnext;
         }
-        half(S0{}, TT{}, 32, aa, bslot);
-        half(S1{}, FF{}, 0, aa, bslot);
+#pragma unroll
+        for (int q = 0; q + 1 < KS; ++q) {
+            if (q == KS / 2 - 1) {
+                if (q % 2 == 0) half(S0{}, TT{}, (q + 1) << 5, aa, bslot, TT{}, lateb && nk > 1);
+                else half(S1{}, TT{}, (q + 1) << 5, aa, bslot, TT{}, lateb && nk > 1);
+            } else {
+                if (q % 2 == 0) half(S0{}, TT{}, (q + 1) << 5, aa, bslot, FF{});
+                else half(S1{}, TT{}, (q + 1) << 5, aa, bslot, FF{});
+            }
+        }
+        half(S1{}, FF{}, 0, aa, bslot, FF{});
         WS_PT(3);
     }
     // ====================================================== epilogue ======================================================
@@ -327,7 +572,7 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
 #ifdef GV_PHASE_TIMES
     WS_PT(4);
     if (a.phase_buf && lane == 0) {                                // [workgroup][wave][8]: t0..t4, wait clocks, HW_ID | XCC_ID, role
-        unsigned long long* o = a.phase_buf + ((size_t)blockIdx.x * (NC + WS_NLW) + wave) * 8;
+        unsigned long long* o = a.phase_buf + ((size_t)blockIdx.x * 12 + wave) * 8;   // (12 slots per workgroup, whatever its size)
         for (int i = 0; i < 5; ++i) o[i] = gv_pt[i];
         o[5] = gv_wait;
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -339,28 +584,36 @@ __global__ __launch_bounds__((WM * WN + WS_NLW) * 64) void conv_ws(const ConvArg
 
 #ifndef GV_KERNEL_ONLY
 // STRIP mode: stride 1, output grid = input grid, <= 32 taps; GEMM mode: 1x1.  Whole 32-channel chunks, 16-byte pixels.
-bool ws_shape_ok(const ConvArgs& a) {
-    return a.stride == 1 && a.dil_shift == 0 && a.oh == a.ih && a.ow == a.iw && a.cin % 32 == 0 && a.x_ld % 8 == 0 &&
+bool ws_shape_ok(const ConvArgs& a, int kt) {
+    return a.stride == 1 && a.dil_shift == 0 && a.oh == a.ih && a.ow == a.iw && a.cin % kt == 0 && a.x_ld % 8 == 0 &&
            a.kh * a.kw <= 32 && a.kw < 32 && a.pad_t < a.kh && a.pad_l < a.kw && a.pool == 0 && a.xscale == nullptr &&
            a.y_step == 0 && a.st.mode == gvconv::STAT_OFF && a.K % 32 == 0;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NB>
+template <typename T, int WM, int WN, int TM, int TN, int NB, int KT = 32, int NL = 4, int RS = 0>
 int launch_ws(const ConvArgs& a0, hipStream_t st) {
+    constexpr int WS_NLW = NL;
+    using G = WsGeom<KT>;
+    constexpr int WS_RB = G::RB, RPI = G::RPI;
     constexpr int NC = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
-    if (!ws_shape_ok(a0)) return GV_E_UNSUPPORTED;
+    if (!ws_shape_ok(a0, KT)) return GV_E_UNSUPPORTED;
     ConvArgs a = a0;
     a.Kpad = a.K;                                                  // (K % 32 == 0: the packed filter has no padding)
     WsArgs w;
     w.taps = a.kh * a.kw;
-    w.nchunks = a.cin / 32;
+    w.nchunks = a.cin / KT;
     w.nk = w.taps * w.nchunks;
     const bool gemm = w.taps == 1;
-    if (w.nk < NB || (!gemm && w.taps < NB - 1)) return GV_E_UNSUPPORTED;
+    if (w.nk < NB || (!gemm && w.taps < (RS ? 2 : NB - 1))) return GV_E_UNSUPPORTED;   // (the vmcnt counts of the loader assume it)
     w.halo_lo = a.pad_t * a.iw + a.pad_l;
     const int halo_hi = (a.kh - 1 - a.pad_t) * a.iw + (a.kw - 1 - a.pad_l);
-    w.strip_blocks = gemm ? BM / 16 : gv_ceil_div(w.halo_lo + BM + halo_hi, 16);
-    w.strip_bytes = w.strip_blocks * 16 * WS_RB;
+    w.strip_blocks = gemm ? BM / RPI : gv_ceil_div(w.halo_lo + BM + halo_hi, RPI);
+    if (RS && !gemm) {                                             // the loaders' register capacity is the strip's size
+        const int cap = ws_rs_blocks(BM, KT, NL) * NL;
+        if (w.strip_blocks > cap) return GV_E_UNSUPPORTED;
+        w.strip_blocks = cap;
+    }
+    w.strip_bytes = w.strip_blocks * 1024;
     w.na = gemm ? NB : 2;
     w.pad_ = 0;
     a.tiles_n = gv_ceil_div(a.cout, BN);
@@ -369,9 +622,9 @@ int launch_ws(const ConvArgs& a0, hipStream_t st) {
     const size_t ring = (size_t)WS_ZERO + (size_t)NB * BN * WS_RB + (size_t)w.na * w.strip_bytes;
     const size_t epi = (size_t)ws_epi_bytes<WM, WN, TN>();
     const size_t lds = ring > epi ? ring : epi;
-    if (lds > 160 * 1024) return GV_E_UNSUPPORTED;
+    if (lds > (NL == 2 ? 80 : 160) * 1024) return GV_E_UNSUPPORTED;   // (two of the small workgroups per CU)
     auto go = [&](auto mode, auto gm) -> int {
-        auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, decltype(gm)::value>;
+        auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, decltype(gm)::value, KT, NL, RS>;
         if (lds > 64 * 1024) {
             const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
             if (!ok) return GV_E_UNSUPPORTED;
@@ -383,8 +636,25 @@ int launch_ws(const ConvArgs& a0, hipStream_t st) {
     const bool lean = gvconv::lp_epilogue_lean_ok(a);
     using L = std::integral_constant<int, gvconv::STAT_LEAN>;
     using F = std::integral_constant<int, 0>;
-    if (gemm) return lean ? go(L{}, std::true_type{}) : go(F{}, std::true_type{});
-    return lean ? go(L{}, std::false_type{}) : go(F{}, std::false_type{});
+    // register-staged loaders, 1x1: A tile + filter slice of RS k-steps in registers — only where they fit
+    constexpr bool GEMM_OK = RS == 0 ? (NB - 1) * (BM / RPI / NL + (BN / RPI + NL - 1) / NL) < 64
+                                     : RS * ((BM / RPI + BN / RPI + NL - 1) / NL) * 4 <= 96;
+    // ... and only with the lean epilogue: the full one spills at 168 registers, and a kernel whose loader waves have asm
+    // requests in flight must not spill anywhere near them
+    if constexpr (RS != 0) {
+        if (!lean) return GV_E_UNSUPPORTED;
+        if (gemm) {
+            if constexpr (GEMM_OK) return go(L{}, std::true_type{});
+            else return GV_E_UNSUPPORTED;
+        }
+        return go(L{}, std::false_type{});
+    } else {
+        if (gemm) {
+            if constexpr (GEMM_OK) return lean ? go(L{}, std::true_type{}) : go(F{}, std::true_type{});
+            else return GV_E_UNSUPPORTED;
+        }
+        return lean ? go(L{}, std::false_type{}) : go(F{}, std::false_type{});
+    }
 }
 
 template <typename T>
@@ -395,6 +665,28 @@ int launch_ws_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
         case 2: return launch_ws<T, 8, 1, 2, 3, 4>(a, st);         // 512 x 96
         case 3: return launch_ws<T, 8, 1, 2, 2, 4>(a, st);         // 512 x 64
         case 4: return launch_ws<T, 4, 2, 2, 1, 4>(a, st);         // 256 x 64
+        // 64-channel k-steps (cin % 64 == 0): 128-byte LDS rows, three filter slots
+        case 5: return launch_ws<T, 4, 2, 2, 3, 3, 64>(a, st);     // 256 x 192
+        case 6: return launch_ws<T, 4, 2, 2, 2, 3, 64>(a, st);     // 256 x 128
+        case 7: return launch_ws<T, 4, 2, 2, 1, 3, 64>(a, st);     // 256 x 64
+        case 8: return launch_ws<T, 8, 1, 2, 2, 3, 64>(a, st);     // 512 x 64
+        // four consumers + two loaders: two workgroups per CU
+        case 9: return launch_ws<T, 2, 2, 2, 3, 4, 32, 2>(a, st);  // 128 x 192
+        case 10: return launch_ws<T, 4, 1, 2, 3, 4, 32, 2>(a, st); // 256 x 96
+        case 11: return launch_ws<T, 2, 2, 2, 2, 4, 32, 2>(a, st); // 128 x 128
+        case 12: return launch_ws<T, 4, 1, 2, 2, 4, 32, 2>(a, st); // 256 x 64
+        // register-staged loaders (RS): three ring slots, two more k-steps in the loaders' registers
+        case 13: return launch_ws<T, 4, 2, 2, 3, 3, 32, 4, 3>(a, st);  // 256 x 192
+        case 14: return launch_ws<T, 8, 1, 2, 3, 3, 32, 4, 3>(a, st);  // 512 x 96
+        case 15: return launch_ws<T, 4, 2, 2, 2, 3, 32, 4, 3>(a, st);  // 256 x 128
+        case 16: return launch_ws<T, 8, 1, 2, 2, 3, 32, 4, 3>(a, st);  // 512 x 64
+        case 17: return launch_ws<T, 4, 2, 2, 2, 3, 64, 4, 3>(a, st);  // 256 x 128, 64-channel k-steps
+        case 18: return launch_ws<T, 4, 1, 2, 3, 3, 32, 2, 3>(a, st);  // 256 x 96, two workgroups per CU
+        // deeper rings (latency x bandwidth: ~3000 clocks x 20 B/clk per CU want 60 KB in flight)
+        case 19: return launch_ws<T, 4, 2, 2, 3, 8, 32, 4, 0>(a, st);  // 256 x 192, LDS-DMA, eight filter slots
+        case 20: return launch_ws<T, 8, 1, 2, 3, 8, 32, 4, 0>(a, st);  // 512 x 96, LDS-DMA, eight filter slots
+        case 21: return launch_ws<T, 4, 2, 2, 3, 3, 32, 4, 6>(a, st);  // 256 x 192, six k-steps in registers
+        case 22: return launch_ws<T, 8, 1, 2, 3, 3, 32, 4, 6>(a, st);  // 512 x 96, six k-steps in registers
     }
     return GV_E_UNSUPPORTED;
 }
@@ -405,7 +697,7 @@ int launch_ws_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
 #ifndef GV_KERNEL_ONLY
 namespace gvconv {
 
-int ws_lp_num_cfgs() { return 5; }
+int ws_lp_num_cfgs() { return 23; }
 
 int ws_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st) {
     if (dtype == GV_BF16) return launch_ws_cfg<__bf16>(cfg, a, st);

@@ -17,8 +17,8 @@ st = torch.cuda.current_stream().cuda_stream
 ty = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 code, td = {"bf16": (_lib.GV_BF16, torch.bfloat16), "f16": (_lib.GV_F16, torch.float16)}[ty]
-NWS = 5
-WS_NAMES = ["256x192", "256x128", "512x96", "512x64", "256x64"]
+NWS = 23
+WS_NAMES = ["256x192", "256x128", "512x96", "512x64", "256x64", "k64:256x192", "256x128", "256x64", "512x64", "2wg:128x192", "256x96", "128x128", "256x64", "RS:256x192", "512x96", "256x128", "512x64", "k64 256x128", "2wg 256x96"]
 
 
 def probe(name, nb, h, w, cin, cout, kh, kw, dbgs=(0, 4), iters=20):
@@ -52,7 +52,7 @@ def probe(name, nb, h, w, cin, cout, kh, kw, dbgs=(0, 4), iters=20):
         ws = res[ncfg - NWS:]
         bo = max(range(len(old)), key=lambda i: old[i])
         print("   dbg %d: best other %4.0f (cfg %2d, %.1f us) | ws: %s | ws/other %.2f"
-              % (dbg, old[bo], bo, fl / old[bo] / 1e6 if old[bo] else 0, " ".join("%s %4.0f" % (n, r) for n, r in zip(WS_NAMES, ws)),
+              % (dbg, old[bo], bo, fl / old[bo] / 1e6 if old[bo] else 0, " ".join("%d:%.0f" % (i, r) for i, r in enumerate(ws) if r > 0),
                  max(ws) / old[bo] if old[bo] else 0), flush=True)
 
 
