@@ -24,6 +24,7 @@
 // ds_read_b128 service group distinct modulo 16, so the shifted reads stay conflict-free.
 // k order: channel chunk outer, filter tap inner (conv_dma.hip's chunk-major order): k-step (c, t) multiplies strip c
 // at shift(t) with filter columns [t*cin + 32c, +32) of the packed [cout][Kpad] filter.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -62,9 +63,6 @@ __device__ __forceinline__ void ws_wait_vm() {
 }
 __device__ __forceinline__ void ws_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// register-staged loaders (RS): strip blocks per loader wave — compile-time, the registers that hold a strip in flight;
-// halo rows it leaves room for: 192 (64-byte rows) / 112 (128-byte rows: a 7x1 on 17-wide maps needs 102)
-constexpr int ws_rs_blocks(int bm, int kt, int nl) { return (bm + (kt == 64 ? 112 : 192) + (512 / kt) * nl - 1) / ((512 / kt) * nl); }
 // bytes of LDS the epilogue re-uses
 template <int WM, int WN, int TN>
 constexpr int ws_epi_bytes() { return WM * WN * EpiGeom<TN>::BYTES + 16 * WN * TN * 32; }   // staging blocks + constants table
@@ -72,13 +70,8 @@ constexpr int ws_epi_bytes() { return WM * WN * EpiGeom<TN>::BYTES + 16 * WN * T
 // NL loader waves.  Eight consumers + four loaders = one 768-thread workgroup per CU; four consumers + two loaders = a
 // 384-thread workgroup, two per CU (three waves per SIMD either way: 168 registers) — the second workgroup's k-loop
 // covers the first one's epilogue, at twice the filter traffic per flop.
-// RS = 1: REGISTER-STAGED loaders.  A wave issues one global_load_lds per 130 - 250 clocks next to busy consumers
-// (profiles/r5_ws_phase_times.txt: the loaders of the DMA form are busy 70 - 85 % of the k-loop issuing 3 - 8 instructions
-// per k-step), but a dedicated loader wave has 168 registers it does not otherwise need: plain global_load_dwordx4 into
-// registers (issued up to two k-steps ahead, before the ring slot is free — the registers ARE two more ring stages) and
-// ds_write_b128 into the same swizzled image once the slot's barrier has passed.
-template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM, int KT = 32, int NL = 4, int RS = 0>
-__global__ __launch_bounds__((WM * WN + NL) * 64, 3) void conv_ws(const ConvArgs a, const WsArgs w) {
+template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM, int KT = 32, int NL = 4>
+__global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void conv_ws(const ConvArgs a, const WsArgs w) {
     constexpr int WS_NLW = NL;
     using G = WsGeom<KT>;
     constexpr int WS_RB = G::RB, RPI = G::RPI, CPR = G::CPR, KS = G::KS;
@@ -90,7 +83,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, 3) void conv_ws(const ConvArgs
     constexpr int UB = BN / RPI, LB = (UB + WS_NLW - 1) / WS_NLW;  // filter row blocks: DMA instructions per loader and k-step
     constexpr int LA = BM / RPI / WS_NLW;                          // GEMM mode: strip instructions per loader and k-step
     constexpr int PER = GEMM ? LA + LB : LB;                       // loads per loader wave and k-step the vmcnt counts rely on
-    static_assert(BM % (RPI * WS_NLW) == 0, "whole strip blocks per loader");
+    static_assert(!GEMM || BM % (RPI * WS_NLW) == 0, "whole strip blocks per loader");
     static_assert(KS % 2 == 0, "the fragment register sets alternate per MFMA k-step");
     static_assert(NB >= 3 && (NB - 1) * PER < 64, "ring depth / vmcnt range");
     static_assert(STATS == 0 || STATS == gvconv::STAT_LEAN, "BatchNorm sums: conv_dma.hip");
@@ -154,177 +147,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, 3) void conv_ws(const ConvArgs
                 b_dst[i] = OFF_B + rb * 1024;
             }
         }
-        if constexpr (RS) {
-            // ------------------------------------------ register-staged loader ------------------------------------------
-            // RS = D: filter slices (GEMM mode: and A tiles) of D k-steps travel in registers, loaded by inline-asm
-            // global_load_dwordx4 (invisible to hipcc's waitcnt pass, which otherwise drains vmcnt(0) at every loop-carried
-            // use) and awaited by hand: vmcnt counts them in issue order.
-            constexpr int D = RS;
-            constexpr int MAXS = GEMM ? LA : ws_rs_blocks(BM, KT, WS_NLW);   // strip blocks per loader (capacity)
-            constexpr int PERQ = GEMM ? LA + LB : LB;              // loads per k-step and loader the counted waits rely on
-            static_assert((D - 1) * PERQ < 64, "vmcnt range");
-            const int wofs = lane * 16;                            // the DMA form's lane-linear image: block base + lane * 16
-            int bq_t = 0, bq_c = 0;                                // next filter slice to LOAD: tap, chunk
-            int sq_c = 0;                                          // next strip to load: chunk
-            // ("+v": the destination is the variable's own register — a conditional request must not become a fresh
-            // register that hipcc then copies into the variable's, at a point where the data has not arrived)
-            auto gload = [&](u32x4& dst, const char* ptr) {
-                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
-            };
-            auto load_b = [&](u32x4 (&dst)[LB]) {
-                const unsigned koff = (unsigned)(bq_t * a.cin + bq_c * KT) * 2u;
-#pragma unroll
-                for (int i = 0; i < LB; ++i) gload(dst[i], b_ptr[i] + koff);
-                if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
-            };
-            auto store_b = [&](u32x4 (&src)[LB], int slot) {
-                char* sb = smem + slot * B_SLOT + wofs;
-#pragma unroll
-                for (int i = 0; i < LB; ++i) {
-                    asm volatile("" : "+v"(src[i]));               // (defined by the wait in front of this call, not by the load)
-                    *reinterpret_cast<u32x4*>(sb + b_dst[i]) = src[i];
-                }
-            };
-            const unsigned lcoff = (unsigned)lchunk(lw) * 16u;
-            // strip blocks [lo, hi) of this loader's MAXS (static register indices, wave-uniform predicates)
-            auto load_strip = [&](u32x4 (&dst)[MAXS], int lo, int hi) {
-                const unsigned coff = (unsigned)sq_c * (unsigned)WS_RB + lcoff;
-#pragma unroll
-                for (int i = 0; i < MAXS; ++i) {
-                    if (i >= lo && i < hi) {
-                        int p = m0 - (GEMM ? 0 : w.halo_lo) + (lw + i * WS_NLW) * RPI + lrow;
-                        p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);   // (blocks past the strip: harmless rows, never read)
-                        gload(dst[i], xb + (size_t)(unsigned)p * pix_bytes + coff);
-                    }
-                }
-            };
-            auto store_strip = [&](u32x4 (&src)[MAXS], int buf) {
-                char* sb = smem + OFF_S + buf * w.strip_bytes + wofs;
-#pragma unroll
-                for (int i = 0; i < MAXS; ++i) {
-                    asm volatile("" : "+v"(src[i]));
-                    *reinterpret_cast<u32x4*>(sb + (lw + i * WS_NLW) * 1024) = src[i];
-                }
-            };
-            // ---- prologue: the first NB k-steps (and two strips) through the main loop's own registers (a loader wave with
-            // asm requests in flight must never spill: a spilled register is saved before its data has arrived)
-            static_assert(NB <= D, "the prologue requests the ring's k-steps into the D register sets");   // (RS = 2: two ring slots)
-            // the second strip of the prologue travels beside the first one where the registers allow it; else after it
-            constexpr bool EARLY1 = !GEMM && D * PERQ * 4 + MAXS * 8 <= 96;
-            static_assert(D * PERQ * 4 + (GEMM ? 0 : MAXS * 4) <= 128, "register-staged loader: too many registers in flight");
-            u32x4 rbq[D][LB];
-            u32x4 ra[GEMM ? D : 1][MAXS];                          // GEMM mode: the A tiles of the k-steps in flight
-            u32x4 rs[MAXS];                                        // STRIP mode: the strip two chunks ahead
-            const u32x4 z4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int i = 0; i < LB; ++i) rbq[d][i] = z4;
-#pragma unroll
-            for (int d = 0; d < (GEMM ? D : 1); ++d)
-#pragma unroll
-                for (int i = 0; i < MAXS; ++i) ra[d][i] = z4;
-#pragma unroll
-            for (int i = 0; i < MAXS; ++i) rs[i] = z4;
-            if constexpr (GEMM) {
-#pragma unroll
-                for (int q = 0; q < NB; ++q) { load_strip(ra[q], 0, MAXS); ++sq_c; load_b(rbq[q]); }
-                ws_wait_vm<(NB - 2) * PERQ>();
-                store_strip(ra[0], 0); store_b(rbq[0], 0);
-                store_strip(ra[1], 1); store_b(rbq[1], 1);
-                WS_PT(1);
-                ws_wait_lds();
-                __builtin_amdgcn_s_barrier();                      // k-steps 0 and 1 are published
-                ws_wait_vm<0>();
-#pragma unroll
-                for (int q = 2; q < NB; ++q) { store_strip(ra[q], q); store_b(rbq[q], q); }
-            } else {
-                u32x4 rs1[EARLY1 ? MAXS : 1];                      // the second strip (live until it is stored, below)
-#pragma unroll
-                for (int i = 0; i < (EARLY1 ? MAXS : 1); ++i) rs1[i] = z4;
-                load_strip(rs, 0, MAXS); ++sq_c;
-#pragma unroll
-                for (int q = 0; q < NB; ++q) load_b(rbq[q]);
-                if constexpr (EARLY1) {
-                    if (w.nchunks > 1) { load_strip(rs1, 0, MAXS); ++sq_c; }
-                    if (w.nchunks > 1) ws_wait_vm<(NB - 2) * LB + MAXS>(); else ws_wait_vm<(NB - 2) * LB>();
-                } else {
-                    ws_wait_vm<(NB - 2) * LB>();
-                }
-                store_strip(rs, 0); store_b(rbq[0], 0); store_b(rbq[1], 1);
-                WS_PT(1);
-                ws_wait_lds();
-                __builtin_amdgcn_s_barrier();                      // k-steps 0 and 1 are published
-                ws_wait_vm<0>();
-#pragma unroll
-                for (int q = 2; q < NB; ++q) store_b(rbq[q], q);
-                if constexpr (EARLY1) {
-                    if (w.nchunks > 1) store_strip(rs1, 1);
-                } else {
-                    if (w.nchunks > 1) { load_strip(rs, 0, MAXS); ++sq_c; ws_wait_vm<0>(); store_strip(rs, 1); }
-                }
-            }
-            // k-step q >= NB travels in register set (q - NB) % D
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (NB + d < nk && !(a.dbg & 1024)) {
-                    if constexpr (GEMM) { load_strip(ra[d], 0, MAXS); ++sq_c; }
-                    load_b(rbq[d]);
-                }
-            }
-            int slot = 0, ft = 0, cbuf = 0;                        // ring slot / tap / strip buffer of k-step j
-            bool have = false;                                     // STRIP mode: rs is being filled with strip sq_c
-            // strip blocks to request per k-step so that a strip is complete one k-step before its chunk's last
-            const int ppi = GEMM ? 0 : (MAXS + (NTAP > 2 ? NTAP - 2 : 0)) / (NTAP > 1 ? NTAP - 1 : 1);
-            auto iter = [&](auto setc, int j) {
-                constexpr int S = decltype(setc)::value;
-                WS_WAIT_BEGIN();
-                ws_wait_lds();                                     // this wave's ds_writes so far are in LDS
-                __builtin_amdgcn_s_barrier();                      // k-step j+1 is published; k-step j's slot is free
-                WS_WAIT_END();
-                const bool last_tap = ft + 1 == NTAP;
-                if constexpr (!GEMM) {
-                    // the strip two chunks ahead: requested piecewise over this chunk's k-steps, stored when the chunk's last
-                    // k-step has passed its barrier (its buffer is free then) — before this iteration's own requests
-                    if (last_tap && have) { ws_wait_vm<0>(); store_strip(rs, cbuf); have = false; ++sq_c; }
-                }
-                if (j + NB < nk && !(a.dbg & 1024)) {
-                    if (j + NB + D - 1 < nk) ws_wait_vm<(D - 1) * PERQ>();   // the D-1 k-steps requested after this one may be in flight
-                    else ws_wait_vm<0>();
-                    if constexpr (GEMM) store_strip(ra[S], slot);
-                    store_b(rbq[S], slot);
-                }
-                if (j + NB + D < nk && !(a.dbg & 1024)) {
-                    if constexpr (GEMM) { load_strip(ra[S], 0, MAXS); ++sq_c; }
-                    load_b(rbq[S]);
-                }
-                if constexpr (!GEMM) {
-                    if (!last_tap && sq_c < w.nchunks && !(a.dbg & 2048)) { load_strip(rs, ft * ppi, ft * ppi + ppi); have = true; }
-                }
-                slot = slot + 1 == NB ? 0 : slot + 1;
-                if (last_tap) { ft = 0; cbuf ^= 1; } else ++ft;
-            };
-            {
-                int j = 0;
-                for (; j + D < nk; j += D) {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        if constexpr (D > 0) { if (d == 0) iter(std::integral_constant<int, 0>{}, j); }
-                        if constexpr (D > 1) { if (d == 1) iter(std::integral_constant<int, 1>{}, j + 1); }
-                        if constexpr (D > 2) { if (d == 2) iter(std::integral_constant<int, 2>{}, j + 2); }
-                        if constexpr (D > 3) { if (d == 3) iter(std::integral_constant<int, 3>{}, j + 3); }
-                        if constexpr (D > 4) { if (d == 4) iter(std::integral_constant<int, 4>{}, j + 4); }
-                        if constexpr (D > 5) { if (d == 5) iter(std::integral_constant<int, 5>{}, j + 5); }
-                    }
-                }
-                if constexpr (D > 0) { if (j + 1 < nk) { iter(std::integral_constant<int, 0>{}, j); ++j; } }
-                if constexpr (D > 1) { if (j + 1 < nk) { iter(std::integral_constant<int, 1>{}, j); ++j; } }
-                if constexpr (D > 2) { if (j + 1 < nk) { iter(std::integral_constant<int, 2>{}, j); ++j; } }
-                if constexpr (D > 3) { if (j + 1 < nk) { iter(std::integral_constant<int, 3>{}, j); ++j; } }
-                if constexpr (D > 4) { if (j + 1 < nk) { iter(std::integral_constant<int, 4>{}, j); ++j; } }
-                static_assert(D <= 6, "iteration dispatch");
-            }
-        } else {
+        {
             int bq_t = 0, bq_c = 0, bq_slot = 0;                       // next filter slice to issue: tap, chunk, ring slot
             int sq_c = 0, sq_buf = 0;                                  // next strip to issue: chunk, buffer
             auto issue_b = [&]() {
@@ -503,7 +326,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, 3) void conv_ws(const ConvArgs
         // first half instead of this one's last): every SIMD then has one wave in front of the barrier and one behind it.
         // Legal: a wave's reads of k-step j have returned long before either point, and k-step j+2 — published by barrier j
         // — is first read behind both.
-        const bool late = wave >= NC / 2 && !(a.dbg & 8192);
+        const bool late = wave >= NC / 2 && (a.dbg & 8192) != 0;      // (debug bit 8192: the stagger, A/B — measured neutral to negative)
         const bool early = !late && !nosync, lateb = late && !nosync;
         for (int j = 0; j + 1 < nk; ++j) {
             // the next k-step's tap, strip buffer and slot (selects, no branches: a branch here would cut the basic block
@@ -572,7 +395,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, 3) void conv_ws(const ConvArgs
 #ifdef GV_PHASE_TIMES
     WS_PT(4);
     if (a.phase_buf && lane == 0) {                                // [workgroup][wave][8]: t0..t4, wait clocks, HW_ID | XCC_ID, role
-        unsigned long long* o = a.phase_buf + ((size_t)blockIdx.x * 12 + wave) * 8;   // (12 slots per workgroup, whatever its size)
+        unsigned long long* o = a.phase_buf + ((size_t)blockIdx.x * 16 + wave) * 8;   // (16 slots per workgroup, whatever its size)
         for (int i = 0; i < 5; ++i) o[i] = gv_pt[i];
         o[5] = gv_wait;
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -590,9 +413,8 @@ bool ws_shape_ok(const ConvArgs& a, int kt) {
            a.y_step == 0 && a.st.mode == gvconv::STAT_OFF && a.K % 32 == 0;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int NB, int KT = 32, int NL = 4, int RS = 0>
+template <typename T, int WM, int WN, int TM, int TN, int NB, int KT = 32, int NL = 4>
 int launch_ws(const ConvArgs& a0, hipStream_t st) {
-    constexpr int WS_NLW = NL;
     using G = WsGeom<KT>;
     constexpr int WS_RB = G::RB, RPI = G::RPI;
     constexpr int NC = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
@@ -604,15 +426,10 @@ int launch_ws(const ConvArgs& a0, hipStream_t st) {
     w.nchunks = a.cin / KT;
     w.nk = w.taps * w.nchunks;
     const bool gemm = w.taps == 1;
-    if (w.nk < NB || (!gemm && w.taps < (RS ? 2 : NB - 1))) return GV_E_UNSUPPORTED;   // (the vmcnt counts of the loader assume it)
+    if (w.nk < NB || (!gemm && w.taps < NB - 1)) return GV_E_UNSUPPORTED;   // (the vmcnt counts of the loader assume it)
     w.halo_lo = a.pad_t * a.iw + a.pad_l;
     const int halo_hi = (a.kh - 1 - a.pad_t) * a.iw + (a.kw - 1 - a.pad_l);
     w.strip_blocks = gemm ? BM / RPI : gv_ceil_div(w.halo_lo + BM + halo_hi, RPI);
-    if (RS && !gemm) {                                             // the loaders' register capacity is the strip's size
-        const int cap = ws_rs_blocks(BM, KT, NL) * NL;
-        if (w.strip_blocks > cap) return GV_E_UNSUPPORTED;
-        w.strip_blocks = cap;
-    }
     w.strip_bytes = w.strip_blocks * 1024;
     w.na = gemm ? NB : 2;
     w.pad_ = 0;
@@ -624,37 +441,32 @@ int launch_ws(const ConvArgs& a0, hipStream_t st) {
     const size_t lds = ring > epi ? ring : epi;
     if (lds > (NL == 2 ? 80 : 160) * 1024) return GV_E_UNSUPPORTED;   // (two of the small workgroups per CU)
     auto go = [&](auto mode, auto gm) -> int {
-        auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, decltype(gm)::value, KT, NL, RS>;
+        auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, decltype(gm)::value, KT, NL>;
         if (lds > 64 * 1024) {
             const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
             if (!ok) return GV_E_UNSUPPORTED;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((NC + WS_NLW) * 64), lds, st, a, w);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((NC + NL) * 64), lds, st, a, w);
         GV_LAUNCH_CHECK();
         return GV_OK;
     };
     const bool lean = gvconv::lp_epilogue_lean_ok(a);
     using L = std::integral_constant<int, gvconv::STAT_LEAN>;
     using F = std::integral_constant<int, 0>;
-    // register-staged loaders, 1x1: A tile + filter slice of RS k-steps in registers — only where they fit
-    constexpr bool GEMM_OK = RS == 0 ? (NB - 1) * (BM / RPI / NL + (BN / RPI + NL - 1) / NL) < 64
-                                     : RS * ((BM / RPI + BN / RPI + NL - 1) / NL) * 4 <= 96;
-    // ... and only with the lean epilogue: the full one spills at 168 registers, and a kernel whose loader waves have asm
-    // requests in flight must not spill anywhere near them
-    if constexpr (RS != 0) {
-        if (!lean) return GV_E_UNSUPPORTED;
-        if (gemm) {
-            if constexpr (GEMM_OK) return go(L{}, std::true_type{});
-            else return GV_E_UNSUPPORTED;
+    // 1x1: the vmcnt counts cover A tile + filter slice per k-step
+    constexpr bool GEMM_OK = (NB - 1) * (BM / RPI / NL + (BN / RPI + NL - 1) / NL) < 64;
+    // sixteen-wave workgroups live on 128 registers: only the lean epilogue fits
+    if (NC + NL > 12 && !lean) return GV_E_UNSUPPORTED;
+    if (gemm) {
+        if constexpr (GEMM_OK) {
+            if constexpr (NC + NL > 12) return go(L{}, std::true_type{});
+            else return lean ? go(L{}, std::true_type{}) : go(F{}, std::true_type{});
+        } else {
+            return GV_E_UNSUPPORTED;
         }
-        return go(L{}, std::false_type{});
-    } else {
-        if (gemm) {
-            if constexpr (GEMM_OK) return lean ? go(L{}, std::true_type{}) : go(F{}, std::true_type{});
-            else return GV_E_UNSUPPORTED;
-        }
-        return lean ? go(L{}, std::false_type{}) : go(F{}, std::false_type{});
     }
+    if constexpr (NC + NL > 12) return go(L{}, std::false_type{});
+    else return lean ? go(L{}, std::false_type{}) : go(F{}, std::false_type{});
 }
 
 template <typename T>
@@ -670,23 +482,9 @@ int launch_ws_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
         case 6: return launch_ws<T, 4, 2, 2, 2, 3, 64>(a, st);     // 256 x 128
         case 7: return launch_ws<T, 4, 2, 2, 1, 3, 64>(a, st);     // 256 x 64
         case 8: return launch_ws<T, 8, 1, 2, 2, 3, 64>(a, st);     // 512 x 64
-        // four consumers + two loaders: two workgroups per CU
-        case 9: return launch_ws<T, 2, 2, 2, 3, 4, 32, 2>(a, st);  // 128 x 192
-        case 10: return launch_ws<T, 4, 1, 2, 3, 4, 32, 2>(a, st); // 256 x 96
-        case 11: return launch_ws<T, 2, 2, 2, 2, 4, 32, 2>(a, st); // 128 x 128
-        case 12: return launch_ws<T, 4, 1, 2, 2, 4, 32, 2>(a, st); // 256 x 64
-        // register-staged loaders (RS): three ring slots, two more k-steps in the loaders' registers
-        case 13: return launch_ws<T, 4, 2, 2, 3, 3, 32, 4, 3>(a, st);  // 256 x 192
-        case 14: return launch_ws<T, 8, 1, 2, 3, 3, 32, 4, 3>(a, st);  // 512 x 96
-        case 15: return launch_ws<T, 4, 2, 2, 2, 3, 32, 4, 3>(a, st);  // 256 x 128
-        case 16: return launch_ws<T, 8, 1, 2, 2, 3, 32, 4, 3>(a, st);  // 512 x 64
-        case 17: return launch_ws<T, 4, 2, 2, 2, 3, 64, 4, 3>(a, st);  // 256 x 128, 64-channel k-steps
-        case 18: return launch_ws<T, 4, 1, 2, 3, 3, 32, 2, 3>(a, st);  // 256 x 96, two workgroups per CU
-        // deeper rings (latency x bandwidth: ~3000 clocks x 20 B/clk per CU want 60 KB in flight)
-        case 19: return launch_ws<T, 4, 2, 2, 3, 8, 32, 4, 0>(a, st);  // 256 x 192, LDS-DMA, eight filter slots
-        case 20: return launch_ws<T, 8, 1, 2, 3, 8, 32, 4, 0>(a, st);  // 512 x 96, LDS-DMA, eight filter slots
-        case 21: return launch_ws<T, 4, 2, 2, 3, 3, 32, 4, 6>(a, st);  // 256 x 192, six k-steps in registers
-        case 22: return launch_ws<T, 8, 1, 2, 3, 3, 32, 4, 6>(a, st);  // 512 x 96, six k-steps in registers
+        // four consumers + two loaders: two workgroups per CU (their k-loops cover each other's epilogue; Mixed_5's 3x3)
+        case 9: return launch_ws<T, 4, 1, 2, 3, 4, 32, 2>(a, st);  // 256 x 96
+        case 10: return launch_ws<T, 4, 1, 2, 2, 4, 32, 2>(a, st); // 256 x 64
     }
     return GV_E_UNSUPPORTED;
 }
@@ -697,9 +495,11 @@ int launch_ws_cfg(int cfg, const ConvArgs& a, hipStream_t st) {
 #ifndef GV_KERNEL_ONLY
 namespace gvconv {
 
-int ws_lp_num_cfgs() { return 23; }
+int ws_lp_num_cfgs() { return 11; }
 
 int ws_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st) {
+    static const bool off = getenv("GV_NO_WS") != nullptr;       // (A/B of whole plans: the autotuner then never sees these tiles)
+    if (off) return GV_E_UNSUPPORTED;
     if (dtype == GV_BF16) return launch_ws_cfg<__bf16>(cfg, a, st);
     if (dtype == GV_F16) return launch_ws_cfg<_Float16>(cfg, a, st);
     return GV_E_UNSUPPORTED;

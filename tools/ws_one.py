@@ -23,7 +23,7 @@ wp = torch.empty(n, device=dev)
 lib.gv_pack_filter_hwio(wf.data_ptr(), kh, kw, cin, cout, wp.data_ptr(), code, 0, st)
 sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
 y = torch.empty(nb, h, w, cout, device=dev, dtype=td)
-ws0 = lib.gv_conv2d_num_tile_cfgs(-1) - 23
+ws0 = lib.gv_conv2d_num_tile_cfgs(-1) - 11
 d = _lib.ConvDesc(nb, h, w, cin, cin, kh, kw, 1, kh // 2, kw // 2, h, w, cout, cout, 0, 0, 1, code, 0, (ws0 + t + 1) if t >= 0 else -t, 0, 0)
 lib.gv_conv2d_set_debug(dbg)
 for _ in range(reps):

@@ -17,8 +17,8 @@ st = torch.cuda.current_stream().cuda_stream
 ty = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 code, td = {"bf16": (_lib.GV_BF16, torch.bfloat16), "f16": (_lib.GV_F16, torch.float16)}[ty]
-NWS = 23
-WS_NAMES = ["256x192", "256x128", "512x96", "512x64", "256x64", "k64:256x192", "256x128", "256x64", "512x64", "2wg:128x192", "256x96", "128x128", "256x64", "RS:256x192", "512x96", "256x128", "512x64", "k64 256x128", "2wg 256x96"]
+NWS = 11
+WS_NAMES = ["256x192", "256x128", "512x96", "512x64", "256x64", "k64:256x192", "256x128", "256x64", "512x64", "2wg:256x96", "256x64"]
 
 
 def probe(name, nb, h, w, cin, cout, kh, kw, dbgs=(0, 4), iters=20):
