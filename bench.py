@@ -634,12 +634,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tuned_by = None
     # untimed: per-launch tile choice, measured on this device (value-neutral); --tile-cache reuses a
     # table written by an earlier run so that a profiled run contains no tuning launches
     if a.tile_cache and os.path.exists(a.tile_cache):
         eng.plan.apply_tiles(json.load(open(a.tile_cache)))
     elif a.no_tune:
         pass
+    elif world > 1:
+        # N > 1: rank 0 measures, every rank installs rank 0's table — ONE tuning instead of N concurrent ones on one
+        # host (67 launches x 25+ candidates each), and identical kernels on every rank (tile choice never changes
+        # values, but ranks that pick different tiles add noise to the MAX-over-ranks step time)
+        table = None
+        if rank == 0:
+            table = {k: v[0] for k, v in eng.plan.autotune(x.view(N * V, H, W, 3)).items()}
+            if a.tile_cache:
+                json.dump(table, open(a.tile_cache, "w"))
+        box = [table]
+        dist.broadcast_object_list(box, src=0)
+        if rank != 0:
+            eng.plan.apply_tiles(box[0])
+        tuned_by = "rank 0 (table broadcast to the other %d ranks)" % (world - 1)
     else:
         chosen = eng.plan.autotune(x.view(N * V, H, W, 3))
         if a.tile_cache and rank == 0:
@@ -695,6 +710,27 @@ def main():
                 step3.flush = sh3.flush
             other_g = (gname, timed(step3))
 
+    # what every rank ran on / with (gathered outside the timed region)
+    rank_facts = None
+    other_ov = None
+    if world > 1:
+        import hashlib
+        tiles = sorted((op["name"], int(op.get("tile", 0))) for op in eng.plan.ops
+                       if op["kind"] == "conv" and not op.get("maxpool"))     # (one kernel serves the pooled form: no tile)
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "world_size": dist.get_world_size(),
+                "tile_table": hashlib.sha1(json.dumps(tiles).encode()).hexdigest()[:12]}
+        rank_facts = [None] * world
+        dist.all_gather_object(rank_facts, mine)
+        if sh.overlap and not a.no_other_exchange:
+            # the same exchange with call-by-call semantics (every forward returns its own result): the 1 -> N ratio can be
+            # read on either; a failure here must not cost the line above
+            try:
+                sh_cc = ShardedGVCNN(eng, exchange=a.exchange, overlap=False, gather_mode=a.gather)
+                other_ov = timed(lambda: sh_cc.forward(x, check=False))
+            except Exception as e:                          # noqa: BLE001
+                other_ov = None
+                sys.stderr.write("bench.py: call-by-call re-run failed: %r\n" % (e,))
+
     out = None
     if rank == 0:
         views_per_step = N * V * world
@@ -730,6 +766,17 @@ def main():
             out["config"]["exchange_overlap"] = ("all-gather of step k in flight under the backbone of step k+1 (results one "
                                                  "call later; the last head is inside the timed region)") if sh.overlap else "none"
             out["config"]["launched_by"] = "bench.py (self-launched ranks)" if os.environ.get("GVBENCH_SELF") else "external torch.distributed.run"
+            out["config"]["ranks"] = rank_facts
+            out["config"]["tiles_tuned_by"] = tuned_by or ("--tile-cache" if a.tile_cache else "--no-tune")
+            try:
+                out["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if a.backend == "nccl" else None
+            except Exception:                               # noqa: BLE001
+                out["config"]["rccl_version"] = None
+            if other_ov is not None:
+                ms4 = other_ov / a.steps * 1e3
+                out["other_overlap"] = {"exchange_overlap": "none (call-by-call: every forward returns its own result)",
+                                        "value": round(views_per_step / (ms4 * 1e-3), 1), "unit": "views/s",
+                                        "ms_per_step": round(ms4, 3)}
             if other is not None:
                 ms2 = other[1] / a.steps * 1e3
                 out["other_exchange"] = {"exchange": other[0], "value": round(views_per_step / (ms2 * 1e-3), 1),

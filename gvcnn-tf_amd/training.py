@@ -177,6 +177,7 @@ class TrainGVCNN:
         self._zacc = self.es == 2                         # pre-zeroed per-layer fp64 accumulators (16-bit entry points)
         self._written = set()
         self._lane_streams = None
+        self._cur_lane = 0
         # per_shape: the paper's grouping (model.GVCNN(per_shape=True)) in the training step
         self.per_shape = bool(per_shape)
         self.weight_mode = {"count": _lib.GV_WEIGHT_COUNT, "mean_score": _lib.GV_WEIGHT_MEAN_SCORE}[weight_mode]
@@ -378,6 +379,7 @@ class TrainGVCNN:
         # a zero gradient, one behind a residual add has the gradient of the bias of that add.  False: every bias summed
         self.bias_grad_identities = True
         self._bias_src = None
+        self._bias_src_key = None
         self.s2_classes = True                            # stride-2 data gradients by parity classes (False: zero-dilated dZ; A/B)
         self.s2_concurrent = False                        # ... their four launches side by side on extra streams: measured
                                                           # 15.66 k against 15.89 k views/s in sequence (fork / join cost more
@@ -562,6 +564,7 @@ class TrainGVCNN:
                 self._lane_seen[lane][ln] = seq
         saved = self.accum
         self.accum = self._lane_accum[lane]
+        self._cur_lane = lane
         try:
             if lane == 0:
                 fn()
@@ -570,6 +573,7 @@ class TrainGVCNN:
                     fn()
         finally:
             self.accum = saved
+            self._cur_lane = 0
         ev = self._event()
         ev.record(stream)
         for t in written:
@@ -583,10 +587,16 @@ class TrainGVCNN:
         """One filter-gradient launch (plus, deterministic, the launch that adds its slices in order)."""
         if not self.deterministic:
             return self.lib.gv_conv2d_wgrad(C.byref(d), x_ptr, dz_ptr, dz_ld, dw_ptr, _st())
+        # ONE workspace per launch lane: with enable_lanes() the filter gradients of different Inception branches run on
+        # different streams, and a shared workspace would let one lane's slice stores overwrite what another lane's
+        # slice reduce is still reading
+        lane = self._cur_lane if self._lane_streams is not None else 0
         if self._dw_ws is None:
-            self._dw_ws = torch.empty(self._dw_ws_bytes, dtype=torch.uint8, device=self.device)
-        return self.lib.gv_conv2d_wgrad_ws(C.byref(d), x_ptr, dz_ptr, dz_ld, dw_ptr, self._dw_ws.data_ptr(),
-                                           self._dw_ws.numel(), _st())
+            self._dw_ws = {}
+        ws = self._dw_ws.get(lane)
+        if ws is None:
+            ws = self._dw_ws[lane] = torch.empty(self._dw_ws_bytes, dtype=torch.uint8, device=self.device)
+        return self.lib.gv_conv2d_wgrad_ws(C.byref(d), x_ptr, dz_ptr, dz_ld, dw_ptr, ws.data_ptr(), ws.numel(), _st())
 
     def _members(self, op):
         """[(variable name, first column, columns)] of a convolution: one entry, or the members of a fused sibling GEMM."""
@@ -636,8 +646,12 @@ class TrainGVCNN:
         arithmetic these ARE the gradients (the oracle's fp64 autograd shows the zeros and the equalities to 1e-6,
         tests/test_gpu_train.py); the summed form differs from them by the rounding noise of the stored 16-bit dy.  With
         frozen statistics (`frozen_bn`) a BatchNorm's return does not sum to zero: only the residual rule applies."""
-        if self._bias_src is not None:
+        # (cached per (switch, frozen statistics, the tapped buffers): toggling bias_grad_identities or frozen_bn after
+        # the first backward pass must take effect — with statistics frozen later, a cached zero rule would be wrong)
+        key = (bool(self.bias_grad_identities), bool(self.frozen_bn), self.raw.vbuf, self.final.vbuf)
+        if self._bias_src is not None and self._bias_src_key == key:
             return self._bias_src
+        self._bias_src_key = key
         ops = self.plan.ops
         readers = {}
         for op in ops:
@@ -1447,6 +1461,11 @@ class TrainGVCNN:
         over the last few, noisy steps of a still-moving network, the last view's weighted most; eval-mode accuracy then
         swings between runs although the train-mode network classifies well (tools/convergence_diag.py,
         tests/test_gpu_convergence.py).  Not a call the reference has; a checkpoint written after it is an ordinary one."""
+        if self.frozen_bn:
+            raise RuntimeError("recalibrate_moving_averages: frozen_bn computes no batch statistics to average")
+        if self.bn_sync is not None or self.shape_world > 1:
+            # (a shard's batch statistics average only its own images / views: ranks would write different moving statistics)
+            raise RuntimeError("recalibrate_moving_averages is a single-rank call: run it on an unsharded engine")
         bns = [op for op in self.plan.ops if op["kind"] == "bn"]
         m_sum = [torch.zeros(op["x"].c, dtype=torch.float64, device=self.device) for op in bns]
         v_sum = [torch.zeros(op["x"].c, dtype=torch.float64, device=self.device) for op in bns]

@@ -120,7 +120,7 @@ def test_16bit_configs_forward_at_the_bench_batch(name, backbone, V, size, G, ty
     check_forward(eng, P, Hd, x, backbone, V, G, fp32=False, ulp=2.0 ** -8 if ty == "bf16" else 2.0 ** -11)
 
 
-def test_c3_bf16_backward_at_the_bench_batch():
+def _backward_at_the_bench_batch(storage, cls_tol, filt_tol, filt_cos, stem_tol, stem_cos):
     """configs[2] as written, at 32 shapes: bf16 forward + backward of the whole batch with frozen statistics; the
     contribution of ONE shape to the gradients (the other 31 rows of dlogits zeroed: the mean CE loss is a sum over
     shapes and, with BatchNorm on its moving statistics, so is every gradient) against the oracle's autograd through that
@@ -135,7 +135,7 @@ def test_c3_bf16_backward_at_the_bench_batch():
     x = views(N, V, size, seed=7)
     labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(8))
     eng = TrainGVCNN(backbone, N, V, size, size, C, G, backbone_params=P, head_params=Hd, device=DEV, num_bins=G,
-                     storage="bf16", frozen_bn=True)
+                     storage=storage, frozen_bn=True)
     n = 19
     _, _, logits, loss = eng.forward(x.to(DEV), labels)
     assert bool(torch.isfinite(loss).all())
@@ -149,9 +149,9 @@ def test_c3_bf16_backward_at_the_bench_batch():
     o = OT.loss_and_grads(x[n:n + 1], labels[n:n + 1].numpy(), P, Hd, G, backbone, num_bins=G, frozen_bn=True,
                           scheme=scheme, weight=weight)
     kn, bn = "dense_%d/kernel" % V, "dense_%d/bias" % V
-    assert rel_l2(logits[n].cpu().numpy(), o["logits"][0]) < 2e-2
+    assert rel_l2(logits[n].cpu().numpy(), o["logits"][0]) < cls_tol
     for k in (kn, bn):
-        assert rel_l2(grads[k].cpu().numpy() * N, o["grads"][k].numpy()) < 2e-2, k
+        assert rel_l2(grads[k].cpu().numpy() * N, o["grads"][k].numpy()) < cls_tol, k
     sampled = ["InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/weights", "InceptionV3/Mixed_7a/Branch_1/Conv2d_0c_7x1/weights",
                "InceptionV3/Mixed_6c/Branch_2/Conv2d_0d_7x1/weights", "InceptionV3/Mixed_6a/Branch_0/Conv2d_1a_1x1/weights",
                "InceptionV3/Mixed_5c/Branch_1/Conv_1_0c_5x5/weights", "InceptionV3/Mixed_5b/Branch_3/Conv2d_0b_1x1/weights",
@@ -167,5 +167,18 @@ def test_c3_bf16_backward_at_the_bench_batch():
         # the stem's filters sit ~100 roundings deep in the backward pass and carry the largest share of the error
         # (test_bf16_step_with_frozen_statistics_tracks_the_fp32_step: 37 - 42 % of the total): their own bound
         stem = k.split("/")[1].startswith("Conv2d_")
-        assert rel < (3.5e-1 if stem else 1.5e-1) and cos > (0.93 if stem else 0.98), report[-1]
-    print("c3 backward at 32 shapes, shape %d against the oracle:\n  " % n + "\n  ".join(report))
+        assert rel < (stem_tol if stem else filt_tol) and cos > (stem_cos if stem else filt_cos), report[-1]
+    print("c3 backward at 32 shapes (%s storage), shape %d against the oracle:\n  " % (storage, n) + "\n  ".join(report))
+
+
+def test_c3_bf16_backward_at_the_bench_batch():
+    """configs[2] as written (bf16 storage): the bounds of 8 mantissa bits per stored tensor, ~100 roundings deep."""
+    _backward_at_the_bench_batch("bf16", cls_tol=2e-2, filt_tol=1.5e-1, filt_cos=0.98, stem_tol=3.5e-1, stem_cos=0.93)
+
+
+def test_c3_geometry_backward_at_the_bench_batch_on_fp32_storage():
+    """The same geometry, batch, tiles-per-launch, image counts per tile and 32-bit index ranges on fp32 STORAGE
+    (bf16x3 products, fp32 accumulation): every sampled filter gradient INCLUDING the stem's within 1e-2 in relative L2
+    of the oracle — so what the bf16 test above tolerates at the stem (35 %) is storage rounding, not a kernel that
+    misbehaves at this batch (reference: train.py:145,166-187 computes these gradients in fp32)."""
+    _backward_at_the_bench_batch("f32", cls_tol=2e-3, filt_tol=1e-2, filt_cos=0.9999, stem_tol=1e-2, stem_cos=0.9999)

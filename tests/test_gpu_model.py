@@ -289,8 +289,10 @@ def test_bench_eight_rank_control_flow_of_the_8gpu_configs(preset, V, hw, esz):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # c4 with the tile tuning the driver's run has (ONE tuning, by rank 0, its table broadcast); c5 with default tiles
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--same-device", "--preset",
-           preset, "--steps", "1", "--warmup", "1", "--shapes", "4", "--no-roofline", "--no-tune", "--no-lanes"]
+           preset, "--steps", "1", "--warmup", "1", "--shapes", "4", "--no-roofline", "--no-lanes"] + \
+          ([] if preset == "c4" else ["--no-tune"])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -305,6 +307,12 @@ def test_bench_eight_rank_control_flow_of_the_8gpu_configs(preset, V, hw, esz):
     assert j["other_exchange"]["exchange"] == "scores" and j["other_exchange"]["value"] > 0
     assert j["config"]["gather"].startswith("collective") and j["other_gather"]["gather"] == "direct"
     assert j["other_gather"]["value"] > 0
+    # what the ranks ran on / with: eight ranks, one world size, ONE tile table; the call-by-call re-run is on the line
+    facts = j["config"]["ranks"]
+    assert [f["rank"] for f in facts] == list(range(8)) and all(f["world_size"] == 8 for f in facts)
+    assert len({f["tile_table"] for f in facts}) == 1
+    assert j["config"]["tiles_tuned_by"].startswith("rank 0" if preset == "c4" else "--no-tune")
+    assert j["other_overlap"]["value"] > 0 and j["other_overlap"]["exchange_overlap"].startswith("none")
 
 
 def test_bench_external_launcher_form_still_works():
