@@ -189,11 +189,15 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
             } else {
     #pragma unroll
                 for (int q = 1; q < NB; ++q) issue_b();
-                if (w.nchunks > 1) issue_strip();
             }
             WS_PT(1);
             ws_wait_vm<(NB - 2) * PER>();                              // everything up to filter slice 1 has landed
             __builtin_amdgcn_s_barrier();
+            // the second strip only now: issued in front of that barrier's wait it would be waited for (vmcnt retires in
+            // order and the wait leaves only the youngest few instructions in flight) — a whole strip's issue and landing
+            // added to every workgroup's start; it is needed a chunk later, and taps >= NB - 1 filter slices behind it
+            // cover it in the counted waits below
+            if constexpr (!GEMM) { if (w.nchunks > 1) issue_strip(); }
             int ft = 0;                                                // tap of k-step j
             for (int j = 0; j + 1 < nk; ++j) {
                 // k-step j+2 must be in LDS before barrier j (the consumers read its first fragments before barrier j+1): the
