@@ -150,11 +150,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
         {
             int bq_t = 0, bq_c = 0, bq_slot = 0;                       // next filter slice to issue: tap, chunk, ring slot
             int sq_c = 0, sq_buf = 0;                                  // next strip to issue: chunk, buffer
+            // timing ablations (results garbage): 32768 barriers but no loads; 65536 loads but no barriers anywhere
+            const bool nodma = (a.dbg & 32768) != 0, nobar = (a.dbg & 65536) != 0;
             auto issue_b = [&]() {
                 const unsigned koff = (unsigned)(bq_t * a.cin + bq_c * KT) * 2u;
                 char* sb = smem + bq_slot * B_SLOT;
     #pragma unroll
-                for (int i = 0; i < LB; ++i) ws_dma16(b_ptr[i] + koff, sb + b_dst[i]);
+                for (int i = 0; i < LB; ++i)
+                    if (!nodma) ws_dma16(b_ptr[i] + koff, sb + b_dst[i]);
                 if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
                 bq_slot = bq_slot + 1 == NB ? 0 : bq_slot + 1;
             };
@@ -168,17 +171,39 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
                         const int blk = lw + i * WS_NLW;
                         int p = m0 + blk * RPI + lrow;
                         p = p < a.M ? p : a.M - 1;
-                        ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                        if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
                     }
                 } else {
                     for (int blk = lw; blk < w.strip_blocks; blk += WS_NLW) {
                         int p = m0 - w.halo_lo + blk * RPI + lrow;     // rows outside [0, M) are only ever read by masked taps
                         p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
-                        ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                        if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
                     }
                 }
                 ++sq_c;
                 sq_buf = sq_buf + 1 == w.na ? 0 : sq_buf + 1;
+            };
+            // STRIP mode, behind the prologue: a strip is issued PIECEWISE.  Its buffer is free when the chunk two behind it
+            // ends and it is needed a whole chunk later; issued at once, its 6 - 10 DMA instructions (~210 clocks each next
+            // to busy consumers: profiles/r5_ws_ablation.txt) make the loader miss the next barrier once per chunk — the
+            // consumers then spent 17 - 24 % of the k-loop waiting although the loaders idle half of it on average.  `ppi`
+            // blocks per k-step finish it within taps - NB + 2 k-steps: NB - 2 filter slices are then issued behind its last
+            // piece, which is what the counted waits need to cover it.
+            int sp_blk = 1 << 30, sp_c = 0, sp_buf = 0;            // pending strip: next block (none: past the end), chunk, buffer
+            const int ppi = ((w.strip_blocks + WS_NLW - 1) / WS_NLW + max(NTAP - NB + 2, 1) - 1) / max(NTAP - NB + 2, 1);
+            auto strip_begin = [&]() {
+                sp_blk = lw; sp_c = sq_c; sp_buf = sq_buf;
+                ++sq_c;
+                sq_buf = sq_buf + 1 == w.na ? 0 : sq_buf + 1;
+            };
+            auto strip_pieces = [&]() {
+                char* sb = smem + OFF_S + sp_buf * w.strip_bytes;
+                const unsigned coff = (unsigned)sp_c * (unsigned)WS_RB + (unsigned)lchunk(lw) * 16u;
+                for (int i = 0; i < ppi && sp_blk < w.strip_blocks; ++i, sp_blk += WS_NLW) {
+                    int p = m0 - w.halo_lo + sp_blk * RPI + lrow;
+                    p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
+                    if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + sp_blk * 1024);
+                }
             };
             // prologue: strip 0 and filter slice 0 first (the consumers' first fragments), then the rest of both rings
             issue_strip();
@@ -192,12 +217,12 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
             }
             WS_PT(1);
             ws_wait_vm<(NB - 2) * PER>();                              // everything up to filter slice 1 has landed
-            __builtin_amdgcn_s_barrier();
+            if (!nobar) __builtin_amdgcn_s_barrier();
             // the second strip only now: issued in front of that barrier's wait it would be waited for (vmcnt retires in
             // order and the wait leaves only the youngest few instructions in flight) — a whole strip's issue and landing
             // added to every workgroup's start; it is needed a chunk later, and taps >= NB - 1 filter slices behind it
             // cover it in the counted waits below
-            if constexpr (!GEMM) { if (w.nchunks > 1) issue_strip(); }
+            if constexpr (!GEMM) { if (w.nchunks > 1) { strip_begin(); strip_pieces(); } }   // (its first pieces now: the window below counts from here)
             int ft = 0;                                                // tap of k-step j
             for (int j = 0; j + 1 < nk; ++j) {
                 // k-step j+2 must be in LDS before barrier j (the consumers read its first fragments before barrier j+1): the
@@ -206,13 +231,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
                 WS_WAIT_BEGIN();
                 if (j + NB - 1 <= nk - 1) ws_wait_vm<(NB - 3) * PER>();
                 else ws_wait_vm<0>();
-                __builtin_amdgcn_s_barrier();                          // ... and every consumer is done with k-step j's LDS
+                if (!nobar) __builtin_amdgcn_s_barrier();              // ... and every consumer is done with k-step j's LDS
                 WS_WAIT_END();
                 const bool last_tap = ft + 1 == NTAP;
                 if constexpr (GEMM) {
                     if (j + NB < nk) { issue_strip(); issue_b(); }
                 } else {
-                    if (last_tap && sq_c < w.nchunks) issue_strip();   // the strip this chunk occupied is free: chunk + NA
+                    if (last_tap && sq_c < w.nchunks) strip_begin();   // the strip this chunk occupied is free: chunk + NA
+                    strip_pieces();
                     if (j + NB < nk) issue_b();
                 }
                 ft = last_tap ? 0 : ft + 1;
@@ -317,7 +343,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
         using FF = std::false_type;
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
-        const bool nosync = (a.dbg & 16384) != 0;
+        const bool nosync = (a.dbg & (16384 | 65536)) != 0;
         ws_wait_lds();
         WS_PT(1);
         if (!nosync) __builtin_amdgcn_s_barrier();                 // strip 0, filter slices 0 and 1 and the zero row are in LDS

@@ -340,16 +340,19 @@ def test_wgrad_every_launch_configuration(dt, tdt, eps):
     assert lib().gv_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), cout, outs[0].to(DEV).data_ptr(), st()) != 0
 
 
-@pytest.mark.parametrize("cfg", [31, 32, 33, 34, 38, 42, 55, 56, 57, 58, 59, 64, 65, 68, 69, 73, 74, 77, 78, 82, 86, 91])
+WGRAD_DMA_CFGS = [31, 32, 33, 34, 38, 42, 55, 56, 57, 58, 59, 64, 65, 68, 69, 73, 74, 77, 78, 82, 86, 91]
+
+
 @pytest.mark.parametrize("k,stride,padding,cin,cout,nb,ih,iw", [c for c in CONVS if c[5] * c[6] * c[7] < 100000])
-def test_wgrad_lds_dma_form_on_every_layer_class(k, stride, padding, cin, cout, nb, ih, iw, cfg):
+def test_wgrad_lds_dma_form_on_every_layer_class(k, stride, padding, cin, cout, nb, ih, iw):
     """The LDS-DMA staged filter gradient (csrc/wgrad_dma.hip; tile_cfg 31..64: 64- / 128- / 192-channel tile sides): strided and padded layers, channel
     counts that do not fill a tile, ragged pixel slices, operands that are channel slices of wider buffers — against
     autograd on the same 16-bit values (exact products: only the summation order differs)."""
     dt, tdt, eps = TYPES[0]
     if cin % 8 or cout % 8:
         pytest.skip("the 16-bit MFMA filter gradient needs whole 8-channel chunks")
-    g = torch.Generator().manual_seed(hash((k, stride, cin, cfg)) % 997)
+    # (every tile configuration on ONE set of operands: allocation and the oracle's convolution dominate a case, not the launch)
+    g = torch.Generator().manual_seed(hash((k, stride, cin)) % 997)
     x = q(torch.randn(nb, ih, iw, cin, generator=g), tdt).requires_grad_(True)
     w = q(torch.randn(k[0], k[1], cin, cout, generator=g) * 0.1, tdt).requires_grad_(True)
     z = OB.conv2d(x, w, stride, padding)
@@ -367,10 +370,11 @@ def test_wgrad_lds_dma_form_on_every_layer_class(k, stride, padding, cin, cout, 
     xd[..., cin:] = 3.0                                    # neighbours in the wider buffers must not leak in
     dzd = torch.full((nb, oh, ow, zld), 5.0, dtype=tdt, device=DEV)
     dzd[..., :cout] = dz.to(tdt).to(DEV)
-    dw = torch.full((k[0], k[1], cin, cout), 0.5, device=DEV)
-    d = _lib.ConvDesc(nb, ih, iw, cin, xld, k[0], k[1], stride, pt, pl, oh, ow, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
-    _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad")
-    close(dw.cpu() - 0.5, w.grad, 3e-5)
+    for cfg in WGRAD_DMA_CFGS:
+        dw = torch.full((k[0], k[1], cin, cout), 0.5, device=DEV)
+        d = _lib.ConvDesc(nb, ih, iw, cin, xld, k[0], k[1], stride, pt, pl, oh, ow, cout, cout, 0, 0, 0, dt, 0, cfg, 0, 0)
+        _lib.check(lib().gv_conv2d_wgrad(C.byref(d), xd.data_ptr(), dzd.data_ptr(), zld, dw.data_ptr(), st()), "wgrad cfg %d" % cfg)
+        close(dw.cpu() - 0.5, w.grad, 3e-5)
 
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)

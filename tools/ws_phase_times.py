@@ -51,6 +51,7 @@ def run(name, nb, h, w, cin, cout, kh, kw, cfgs):
         buf = torch.zeros(nwg * 16 * 8, dtype=torch.int64, device=dev)
         d = _lib.ConvDesc(nb, h, w, cin, cin, kh, kw, 1, kh // 2, kw // 2, h, w, cout, cout, 0, 0, 1, code, 0, WS0 + c + 1, 0, 0)
         args = (C.byref(d), x.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(), None, None, None, st)
+        lib.gv_conv2d_set_debug(int(os.environ.get('WS_DBG', '0')))
         rc = lib.gv_conv2d_fwd(*args)
         if rc != 0:
             print("   cfg %d %dx%d k%d: rc %d" % (c, bm, bn, kt, rc))
