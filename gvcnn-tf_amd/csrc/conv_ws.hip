@@ -65,7 +65,64 @@ __device__ __forceinline__ void ws_wait_lds() { asm volatile("s_waitcnt lgkmcnt(
 
 // bytes of LDS the epilogue re-uses
 template <int WM, int WN, int TN>
-constexpr int ws_epi_bytes() { return WM * WN * EpiGeom<TN>::BYTES + 16 * WN * TN * 32; }   // staging blocks + constants table
+constexpr int ws_epi_bytes() { return WM * WN * 8192 + 16 * WN * TN * 32; }   // staging blocks (two 32 x 32 fp32 blocks per wave) + constants table
+
+// The epilogue of an interior tile with one 16-bit destination (no residual, no second output, ReLU on every column or
+// none): straight-line, and software-pipelined over the wave's 32 x 32 blocks through TWO staging blocks — the LDS writes of
+// block b+1 are issued in front of the read-back of block b, so a block's write -> read round trip is covered by its
+// predecessor's conversion and stores.  The general staged epilogue (conv_lp_epi.h) serialises write, wait, read, convert,
+// store per block under a dozen run-time branches (residual, row bounds, second output, partial ReLU), and in this kernel —
+// one workgroup per CU, nothing to overlap it with — it was 13 - 28 % of a workgroup's life
+// (profiles/r5_ws_phase_times_*.txt, "epi"; profiles/r5_ws_ablation.txt, dbg 4).
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void ws_epilogue_fast(const ConvArgs& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                 int lane, char* stage2, const float* sstab, int bn) {
+    constexpr int NBLK = TM * TN;
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+    const int rrow = lane >> 2, rchunk = lane & 3;                 // read-back: 16 rows x 4 chunks of 8 columns per pass
+    const int woff = (row_h * 32 + col_l) * 4;                     // + ((r & 3) + 8 * (r >> 2)) * 128 per accumulator register
+    const int roff = (rrow * 32 + rchunk * 8) * 4;                 // + 2048 for the second pass
+    unsigned short* const y = reinterpret_cast<unsigned short*>(a.y);
+    const bool relu = a.relu != 0;
+    const size_t row0 = (size_t)(m0 + wm * TM * 32 + rrow) * (size_t)a.y_ld;
+    auto put = [&](int b) {
+        const int i = b % TM, j = b / TM;
+        char* dst = stage2 + (b & 1) * 4096 + woff;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(dst + ((r & 3) + 8 * (r >> 2)) * 128) = acc[i][j][r];
+    };
+    put(0);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int i = b % TM, j = b / TM;
+        if (b + 1 < NBLK) put(b + 1);
+        __builtin_amdgcn_wave_barrier();
+        const int col = n0 + (wn * TN + j) * 32 + rchunk * 8;
+        if (i == 0) {                                              // a column block's constants: once per TM row blocks
+            const float* t = sstab + (wn * TN + j) * 32 + rchunk * 8;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(t + 4 * hh);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(t + bn + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[4 * hh + e] = v0[e]; sh[4 * hh + e] = v1[e]; }
+            }
+        }
+        const bool live = col + 8 <= a.cout;                       // (cout % 8 == 0: a chunk is whole or absent)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const char* src = stage2 + (b & 1) * 4096 + roff + pass * 2048;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 16);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (live) store_chunk_lean<T>(y + row0 + (size_t)((i * 32 + pass * 16) * a.y_ld) + col, v, relu);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // NL loader waves.  Eight consumers + four loaders = one 768-thread workgroup per CU; four consumers + two loaders = a
 // 384-thread workgroup, two per CU (three waves per SIMD either way: 168 registers) — the second workgroup's k-loop
@@ -409,7 +466,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
     }
     // ====================================================== epilogue ======================================================
     __syncthreads();                                               // every wave is done with the ring: the staging blocks alias it
-    constexpr int SS_OFF = NC * EpiGeom<TN>::BYTES;
+    constexpr int SS_OFF = NC * 8192;                              // (two staging blocks per wave, whatever the epilogue)
     float* sstab = !(a.dbg & 512) ? reinterpret_cast<float*>(smem + SS_OFF) : nullptr;   // dbg 512: constants from global (A/B)
     if (sstab != nullptr && tid < BN) {
         sstab[tid] = ss_v[0];
@@ -419,8 +476,14 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
     __syncthreads();
     if (wave < NC) {
         const int wm = wave / WN, wn = wave % WN;
-        lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * EpiGeom<TN>::BYTES), 32,
-                                             sstab, BN, smem, 0);
+        // interior tile, one plain destination: the pipelined straight-line epilogue (debug bit 1048576: the general one, A/B)
+        const bool fast = STATS == gvconv::STAT_LEAN && sstab != nullptr && a.res == nullptr && a.y2 == nullptr && a.split == 0 &&
+                          m0 + BM <= a.M && (!a.relu || a.relu_limit >= a.cout) && !(a.dbg & (4 | 1048576));
+        if (fast)
+            ws_epilogue_fast<T, TM, TN>(a, acc, m0, n0, wm, wn, lane, smem + wave * 8192, sstab, BN);
+        else
+            lp_epilogue_staged<T, TM, TN, STATS>(a, acc, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem + wave * 8192), 32,
+                                                 sstab, BN, smem, 0);
     }
 #ifdef GV_PHASE_TIMES
     WS_PT(4);
