@@ -144,5 +144,8 @@ int ws_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);
 int dma_x3_num_cfgs();
 bool dma_x3_ok(const ConvArgs& a);
 int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st);
+// conv_ws_x3.hip (the wave-specialised strip kernel on three-plane input; configurations follow the LDS-DMA tiles)
+int ws_x3_num_cfgs();
+int ws_x3_launch(int cfg, const ConvArgs& a, hipStream_t st);
 
 }  // namespace gvconv

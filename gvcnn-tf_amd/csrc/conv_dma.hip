@@ -850,12 +850,15 @@ namespace gvconv {
 
 const void* dma_zero_page() { return zero_page_for_current_device(); }   // (wgrad_dma.hip shares it)
 
-int dma_x3_num_cfgs() { return 19; }
+constexpr int kDmaX3Tiles = 19;
+int dma_x3_num_cfgs() { return kDmaX3Tiles + ws_x3_num_cfgs(); }   // + the wave-specialised kernel's tiles (conv_ws_x3.hip)
 
 // P3 input: whole 16-channel groups inside one filter tap
 bool dma_x3_ok(const ConvArgs& a) { return a.cin % 16 == 0 && a.x_ld % 16 == 0; }
 
-int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) { return launch_dma_x3(cfg, a, st); }
+int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) {
+    return cfg >= kDmaX3Tiles ? ws_x3_launch(cfg - kDmaX3Tiles, a, st) : launch_dma_x3(cfg, a, st);
+}
 
 constexpr int kDmaLpTiles = 25;
 int dma_lp_num_cfgs() { return kDmaLpTiles + ws_lp_num_cfgs(); }   // + the wave-specialised kernel's tiles (conv_ws.hip)

@@ -139,6 +139,64 @@ def test_dma_conv_on_three_plane_input(k, stride, padding, cin, cout, tile):
     assert torch.equal(yt, base)
 
 
+WS_X3_COMBOS = [((1, 7), 128, 128, (17, 17)), ((7, 1), 160, 192, (17, 17)), ((3, 3), 64, 96, (23, 20)), ((5, 5), 48, 64, (12, 35)),
+                ((1, 3), 384, 384, (8, 8)), ((3, 1), 448, 384, (5, 9)), ((3, 3), 32, 200, (9, 40)), ((1, 7), 16, 8, (3, 70))]
+
+
+def ws_x3_tiles():
+    n = lib().gv_conv2d_num_tile_cfgs(-3)
+    return list(range(n - 4, n))
+
+
+@pytest.mark.parametrize("k,cin,cout,hw", WS_X3_COMBOS)
+def test_ws_strip_kernel_on_three_plane_input(k, cin, cout, hw):
+    """csrc/conv_ws_x3.hip (loader waves + consumer waves, one LDS strip per 16-channel chunk serves every tap): every tile
+    on the stride-1 same-grid layer classes of Inception-v3 (nets/inception_v3.py:226-338) against the CPU oracle and the
+    register-staged kernel: maps narrower and wider than a wave's 32 pixels, tiles spanning images, ragged M and cout,
+    channel-slice operands, fp32 and three-plane destinations, residual; what the kernel declines stays untouched."""
+    g = torch.Generator().manual_seed(hash((k, cin, cout)) % 1000)
+    ih, iw = hw
+    nb = 5 if ih * iw > 300 else 11
+    x = torch.randn(nb, ih, iw, cin, generator=g)
+    w = torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, True)
+    pads = (OB.same_pads(ih, k[0], 1)[0], OB.same_pads(iw, k[1], 1)[0])
+    base = conv(x, w, 1, pads, hw, scale, shift, True)                                       # fp32 in, fp32 out
+    ran = 0
+    for tile in ws_x3_tiles():
+        try:
+            y = conv(x, w, 1, pads, hw, scale, shift, True, x_p3=True, tile=tile, x_ld=cin + 32, x_off=16, y_ld=cout + 8, y_off=4)
+        except _lib.GvError as e:
+            assert e.code == _lib.GV_E_UNSUPPORTED, (tile, e)
+            continue
+        ran += 1
+        close(y, ref)
+        assert float((y - base).abs().max()) <= 4e-6 * float(base.abs().max()), tile
+        if cout % 16 == 0:
+            yp = conv(x, w, 1, pads, hw, scale, shift, True, x_p3=True, y_p3=True, tile=tile, x_ld=cin + 32, x_off=16,
+                      y_ld=cout + 32, y_off=16)
+            assert torch.equal(yp, y), tile
+    assert ran >= 2, "every layer class here is served by at least two tiles"
+    res = torch.randn(nb, ih, iw, cout, generator=g)
+    tile = ws_x3_tiles()[1]
+    yr = conv(x, w, 1, pads, hw, scale, shift, False, x_p3=True, residual=res, tile=tile)
+    close(yr, OB.conv2d(x, w, 1, "SAME") * scale + shift + res)
+
+
+def test_ws_strip_kernel_declines_what_it_cannot_run():
+    g = torch.Generator().manual_seed(1)
+    for k, stride, padding, cin in (((3, 3), 2, "VALID", 32), ((3, 3), 1, "VALID", 32), ((1, 1), 1, "SAME", 64)):
+        x = torch.randn(2, 9, 9, cin, generator=g)
+        w = torch.randn(k[0], k[1], cin, 32, generator=g) * 0.1
+        oh = OB.conv2d(x, w, stride, padding).shape[1]
+        for tile in ws_x3_tiles():
+            with pytest.raises(_lib.GvError) as ei:
+                conv(x, w, stride, (0, 0), (oh, oh), torch.ones(32), torch.zeros(32), True, x_p3=True, tile=tile)
+            assert ei.value.code == _lib.GV_E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4, 9])
 def test_staged_kernel_writes_three_planes(tile):
     """fp32 input through the register-staged kernel, P3 output through the LDS-staged epilogue: the stored planes sum
