@@ -1220,7 +1220,9 @@ int launch_np(int cfg, const ConvArgs& a, bool generic, hipStream_t st) {
 
 namespace gvconv {
 
-int bf16s_num_cfgs() { return kNumTiles + 1; }          // + the halo-tiled stem kernel (3 planes only)
+// + the halo-tiled stem kernel (3 planes only) + the wave-specialised kernel's GEMM mode (conv_ws_x3.hip; 3 planes only)
+int bf16s_num_cfgs() { return kNumTiles + 1 + wsg_x3_num_cfgs(); }
+int bf16s_special_cfg() { return kNumTiles; }
 
 // the 3-channel stems: square 3x3 or 7x7 window, stride 2, <= 64 output channels, plain epilogue
 bool bf16s_stem_ok(int planes, const ConvArgs& a) {
@@ -1262,6 +1264,7 @@ int bf16s_launch(int planes, int cfg, const ConvArgs& a0, bool generic, hipStrea
         if (bf16s_stem_ok(planes, a)) return launch_stem_x3(a, st);
         return bf16s_halo_ok(planes, a, generic) ? launch_halo_x3(a, st) : GV_E_UNSUPPORTED;
     }
+    if (cfg > kNumTiles) return planes == 3 && !generic ? wsg_x3_launch(cfg - kNumTiles - 1, a0, st) : GV_E_UNSUPPORTED;
     switch (planes) {
         case 3: return launch_np<3>(cfg, a, generic, st);
         case 2: return launch_np<2>(cfg, a, generic, st);

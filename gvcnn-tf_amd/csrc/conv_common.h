@@ -108,6 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
 
 // conv_bf16s.hip
 int bf16s_num_cfgs();
+int bf16s_special_cfg();        // the halo-tiled / strip stem kernels
 int bf16s_pick_tile(int planes, int M, int N, int K);
 bool bf16s_halo_ok(int planes, const ConvArgs& a, bool generic);
 bool bf16s_stem_ok(int planes, const ConvArgs& a);
@@ -147,5 +148,7 @@ int dma_x3_launch(int cfg, const ConvArgs& a, hipStream_t st);
 // conv_ws_x3.hip (the wave-specialised strip kernel on three-plane input; configurations follow the LDS-DMA tiles)
 int ws_x3_num_cfgs();
 int ws_x3_launch(int cfg, const ConvArgs& a, hipStream_t st);
+int wsg_x3_num_cfgs();          // its GEMM mode on plain fp32 input: configurations behind conv_bf16s.hip's (after the special one)
+int wsg_x3_launch(int cfg, const ConvArgs& a, hipStream_t st);
 
 }  // namespace gvconv

@@ -376,7 +376,7 @@ static int planes_of(int math_mode) {
 extern "C" int gv_conv2d_special_tile_cfg(int32_t math_mode) {
     if (math_mode == -1) return gvconv::lp_special_cfg();
     const int np = planes_of(math_mode);
-    return np <= 0 ? GV_E_BADARG : gvconv::bf16s_num_cfgs() - 1;
+    return np <= 0 ? GV_E_BADARG : gvconv::bf16s_special_cfg();
 }
 
 extern "C" int gv_conv2d_num_tile_cfgs(int32_t math_mode) {
@@ -624,7 +624,7 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
                         : (d->tile_cfg > 0 ? d->tile_cfg - 1
                            : ((gvconv::bf16s_halo_ok(np, a, generic) || gvconv::bf16s_stem_ok(np, a)) &&
                                       a.M >= 100000
-                                  ? gvconv::bf16s_num_cfgs() - 1
+                                  ? gvconv::bf16s_special_cfg()
                                                                                      : gvconv::bf16s_pick_tile(np, a.M, a.cout, a.K)));
         return gvconv::bf16s_launch(np, cfg, a, generic, (hipStream_t)stream);
     }

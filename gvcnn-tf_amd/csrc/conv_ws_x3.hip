@@ -53,18 +53,38 @@ __device__ __forceinline__ void x3w_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int NB, int SBMAX>
+// GEMM = false: STRIP mode (above; P3 input by LDS-DMA).  GEMM = true: 1x1 convolutions on plain FP32 input (the fused
+// sibling GEMMs of an Inception block read the block's fp32 concat buffer): the A operand is a ring of three
+// [3 planes][BM rows][32 B] tiles which the loader waves fill through registers — global_load_dwordx4, split into three
+// bf16 planes (the 5.5 VALU instructions per element the register-staged kernel's MFMA waves spend in their own loop),
+// ds_write_b64 — two k-steps ahead; the filter ring and the consumers are the strip mode's.  (The filter slices
+// through registers as well — global_load_dwordx4 + ds_write_b128 instead of five LDS-DMA instructions per k-step — measured
+// 2 - 5 % slower: profiles/r5_wsg_filter_through_registers_ab.txt.)
+// (GEMM mode's register-staged A loads: see the loader)
+__device__ __forceinline__ void x3w_gload16(f32x4& dst, const char* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void x3w_wait_vm_reg(f32x4& r) {       // (one statement per register: the repeated waits are free)
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+}
+
+template <int WM, int WN, int TM, int TN, int NB, int SBMAX, int GEMM = 0>
 __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const ConvArgs a, const WsX3Args w) {
     constexpr int NC = WM * WN;                                    // consumer waves
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int B_PLANE = BN * 32, B_SLOT = 3 * B_PLANE;
-    constexpr int A_PLANE = X3W_HEAD + SBMAX * 1024, S_BUF = 3 * A_PLANE;
+    constexpr int A_PLANE = GEMM ? BM * 32 : X3W_HEAD + SBMAX * 1024, S_BUF = 3 * A_PLANE;
+    constexpr int NA = GEMM ? 3 : 2;                               // A tiles (GEMM) / strip buffers
     constexpr int OFF_S = NB * B_SLOT;
     constexpr int UB3 = 3 * (BN / 32);                             // filter DMA instructions per k-step (row blocks x planes)
     constexpr int LB = (UB3 + X3W_NL - 1) / X3W_NL;                // ... per loader wave: what the vmcnt counts rely on
     static_assert(NC == 8, "eight consumer waves + four loaders: three waves per SIMD");
     static_assert(TM <= TN && TM * TN >= 4, "plane-2 fragments of a and b share one register block");
     static_assert(NB >= 3 && (NB - 1) * LB < 64, "ring depth / vmcnt range");
+    static_assert(GEMM == 0 || (NB == 4 && BM % (16 * X3W_NL) == 0), "GEMM mode: four filter slots, 16-row load instructions");
+    (void)NA;
 
     extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x;
@@ -98,7 +118,6 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
             const int lrow = lane >> 1;                            // row inside a 32-row block
             const int lc16 = (((lane & 1) ^ ((lrow >> 3) & 1)) << 4);   // byte offset of the logical chunk this lane fetches
             const char* xb = reinterpret_cast<const char*>(a.x);
-            const unsigned pix_bytes = (unsigned)a.x_ld * 6u;
             // filter slice: this loader's instructions d = lw, lw + 4, ... -> (row block d / 3, plane d % 3)
             const char* b_ptr[LB];
             int b_dst[LB];
@@ -126,6 +145,101 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
                 if (++bq_t == NTAP) { bq_t = 0; ++bq_c; }
                 bq_slot = bq_slot + 1 == NB ? 0 : bq_slot + 1;
             };
+            if constexpr (GEMM != 0) {
+                // ---- A tiles through registers: a wave owns BM / 4 rows, an instruction 16 rows x 64 bytes (four lanes per row)
+                constexpr int RPW = BM / X3W_NL, NI = RPW / 16;
+                const int qd = lane & 3;
+                const char* a_ptr[NI];
+                int a_dst[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int row = lw * RPW + i * 16 + (lane >> 2);
+                    int m = m0 + row;
+                    m = m < a.M ? m : a.M - 1;                     // rows past M: results never stored
+                    a_ptr[i] = xb + (size_t)(unsigned)m * ((size_t)a.x_ld * 4) + qd * 16;
+                    a_dst[i] = OFF_S + row * 32 + ((((qd >> 1) ^ ((row >> 3) & 1))) << 4) + (qd & 1) * 8;
+                }
+                // The loads are inline asm with hand-counted waits: a compiler-visible load is waited for with vmcnt(0) across
+                // the loop's back edge — the loads of k-step j+3, issued a moment ago, with it.  A stage's registers pass
+                // through the wait statement ("+v"), so no use can be scheduled in front of it.
+                f32x4 stg[2][NI];
+                auto load_a = [&](auto sc, int c) {                // k-step c (past the end: the last one again — never written)
+                    constexpr int S = decltype(sc)::value;
+                    c = c < nk ? c : nk - 1;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) x3w_gload16(stg[S][i], a_ptr[i] + (size_t)c * 64);
+                };
+                auto wait_a = [&](auto sc, auto nc) {              // all but the N youngest vector-memory operations are done
+                    constexpr int S = decltype(sc)::value;
+                    constexpr int N = decltype(nc)::value;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) x3w_wait_vm_reg<N>(stg[S][i]);
+                };
+                auto write_a = [&](auto sc, int slot) {            // split (round to nearest even, the exact remainder next) + store
+                    constexpr int S = decltype(sc)::value;
+                    char* sb = smem + slot * S_BUF;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        float v[4] = {stg[S][i][0], stg[S][i][1], stg[S][i][2], stg[S][i][3]};
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            const unsigned lo = pack2<__bf16>(v[0], v[1]), hi = pack2<__bf16>(v[2], v[3]);
+                            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<u32x2_t*>(sb + p * A_PLANE + a_dst[i]) = u32x2_t{lo, hi};
+                            if (p < 2) {
+                                v[0] -= __builtin_bit_cast(float, lo << 16);
+                                v[1] -= __builtin_bit_cast(float, lo & 0xffff0000u);
+                                v[2] -= __builtin_bit_cast(float, hi << 16);
+                                v[3] -= __builtin_bit_cast(float, hi & 0xffff0000u);
+                            }
+                        }
+                    }
+                };
+                using S0 = std::integral_constant<int, 0>;
+                using S1 = std::integral_constant<int, 1>;
+                // prologue, shaped like four iterations of the loop below: [filter slice k, A loads of k-step k]
+                auto fetch = [&](auto sc, int k) {
+                    issue_b();
+                    load_a(sc, k);
+                };
+                fetch(S0{}, 0);
+                fetch(S1{}, 1);
+                wait_a(S0{}, std::integral_constant<int, 0>{});
+                wait_a(S1{}, std::integral_constant<int, 0>{});
+                write_a(S0{}, 0);
+                write_a(S1{}, 1);
+                fetch(S0{}, 2);
+                fetch(S1{}, 3);                                    // (nk >= 4: the launcher checks)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (!nobar) __builtin_amdgcn_s_barrier();          // k-steps 0 and 1 are in LDS
+                // iteration j: k-step j+2 into LDS (its loads are one iteration's [LB + NI operations] away from the youngest),
+                // barrier j, then filter slice j+4 into the slot k-step j vacated and the loads of k-step j+4 into the registers
+                // k-step j+2 vacated
+                // (past the last slice the DMAs re-load slice nk-1 into its own slot — the same bytes over themselves —
+                // so that every iteration issues the same LB + NI operations: ONE wait statement, whose count holds in the tail
+                // too, and through which the stage's registers pass — with two alternative statements the compiler copied the
+                // registers in front of one of them, i.e. read them while the loads were in flight)
+                auto iter = [&](auto sc, int j) {
+                    wait_a(sc, std::integral_constant<int, LB + NI>{});
+                    if (j + 2 < nk) {
+                        int slot = j + 2;
+                        slot -= (slot / 3) * 3;
+                        write_a(sc, slot);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    if (!nobar) __builtin_amdgcn_s_barrier();
+                    if (j + 4 >= nk) {                             // nothing new: slice nk-1 again, in place
+                        bq_c = nk - 1;
+                        bq_slot = (nk - 1) & 3;
+                    }
+                    fetch(sc, j + 4);
+                };
+                for (int j = 0; j + 1 < nk; j += 2) {
+                    iter(S0{}, j);
+                    if (j + 2 < nk) iter(S1{}, j + 1);
+                }
+            } else {
+            const unsigned pix_bytes = (unsigned)a.x_ld * 6u;
             // strips: unit e = lw, lw + 4, ... of a chunk -> (block e / 3, plane e % 3); e + 4 = 3 (blk + 1) + (p + 1)
             int sq_c = 0, sq_buf = 0;                              // next strip to begin: chunk, buffer
             int sp_blk = 1 << 30, sp_p = 0, sp_c = 0, sp_buf = 0;  // pending strip: next unit (none: past the end), chunk, buffer
@@ -171,14 +285,17 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
                 if (j + NB < nk) issue_b();
                 ft = last_tap ? 0 : ft + 1;
             }
+            }
         }
     } else {
         // ================================================== consumer ==================================================
         const int wm = wave / WN, wn = wave % WN;
         const int r = lane & 31, h = lane >> 5;
-        if (tid < 96) {                                            // the zero heads of the six plane images
-            const int img = tid >> 4;
-            *reinterpret_cast<unsigned*>(smem + OFF_S + (img / 3) * S_BUF + (img % 3) * A_PLANE + (tid & 15) * 4) = 0u;
+        if constexpr (GEMM == 0) {
+            if (tid < 96) {                                        // the zero heads of the six plane images
+                const int img = tid >> 4;
+                *reinterpret_cast<unsigned*>(smem + OFF_S + (img / 3) * S_BUF + (img % 3) * A_PLANE + (tid & 15) * 4) = 0u;
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -189,7 +306,10 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
         // this lane's rows: strip row of the un-shifted tap and one bit per tap "inside the image"
         const int rbase0 = wm * TM * 32 + r + w.halo_lo;          // (row block i: + 32 i)
         unsigned tapmask[TM];
-        {
+        if constexpr (GEMM != 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) tapmask[i] = 0u;          // (unused)
+        } else {
             const int ohow = a.oh * a.ow;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -215,6 +335,7 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
         // `sbase` (+ plane * A_PLANE); a tap outside the image reads the buffer's zero head
         // (bit arithmetic, not a select: conv_ws.hip)
         auto a_addr = [&](int i, int off, int tap, int sbase) -> int {
+            if constexpr (GEMM != 0) return sbase + ((wm * TM + i) * 32 + r) * 32 + ((((r >> 3) & 1) << 4) ^ h16);   // (sbase: the A tile)
             const int row = rbase0 + i * 32 + off;
             const int ad = sbase + X3W_HEAD + row * 32 + ((((row >> 3) & 1) << 4) ^ h16);
             const int in = -(int)((tapmask[i] >> tap) & 1u);       // all ones: the tap lies inside the image
@@ -309,6 +430,14 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
         int bn = 0;
         // the next k-step's tap, strip buffer and slot (selects, no branches: conv_ws.hip)
         auto next_addr = [&]() {
+            if constexpr (GEMM != 0) {
+                sbuf = sbuf + 1 == NA ? 0 : sbuf + 1;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) aa[i] = a_addr(i, 0, 0, OFF_S + sbuf * S_BUF);
+                bslot = bslot + B_SLOT == NB * B_SLOT ? 0 : bslot + B_SLOT;
+                bn = b_lane + bslot;
+                return;
+            }
             const bool wrap = q_tap + 1 == NTAP;
             const bool row_end = q_fs + 1 == a.kw;
             q_tap = wrap ? 0 : q_tap + 1;
@@ -344,13 +473,20 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
 }
 
 #ifndef GV_KERNEL_ONLY
-// stride 1, output grid = input grid, 2 ... 32 taps, whole 16-channel groups, the staged epilogue's destinations
+// the staged epilogue's destinations (conv_x3_epi.h): 8-column chunks, 16-byte fp32 stores
+bool ws_x3_epi_ok(const ConvArgs& a) {
+    if (a.cout % 8 != 0 || (a.y2 != nullptr && a.split == 0)) return false;
+    if (a.res != nullptr && (a.res_ld % 4 != 0 || !gv_aligned16(a.res))) return false;
+    if (!a.y_p3 && (a.y_ld % 4 != 0 || !gv_aligned16(a.y))) return false;
+    if (a.split > 0 && (a.split % 8 != 0 || (!a.y2_p3 && (a.y2_ld % 4 != 0 || !gv_aligned16(a.y2))))) return false;
+    return true;
+}
+
+// STRIP mode: stride 1, output grid = input grid, 2 ... 32 taps, whole 16-channel groups of three-plane input
 bool ws_x3_shape_ok(const ConvArgs& a) {
-    const bool vec = (a.y_ld % 4 == 0) && gv_aligned16(a.y) && (a.res == nullptr || (a.res_ld % 4 == 0 && gv_aligned16(a.res)));
     return a.stride == 1 && a.dil_shift == 0 && a.oh == a.ih && a.ow == a.iw && a.cin % 16 == 0 && a.x_ld % 16 == 0 &&
            a.kh * a.kw <= 32 && a.kw < 32 && a.pad_t < a.kh && a.pad_l < a.kw && a.pool == 0 && a.xscale == nullptr &&
-           a.y_step == 0 && a.st.mode == gvconv::STAT_OFF && a.cout % 8 == 0 && (a.y2 == nullptr || a.split > 0) &&
-           (a.split > 0 || a.y_p3 || vec);
+           a.y_step == 0 && a.st.mode == gvconv::STAT_OFF && ws_x3_epi_ok(a);
 }
 
 template <int WM, int WN, int TM, int TN, int NB, int SBMAX>
@@ -376,7 +512,43 @@ int launch_ws_x3(const ConvArgs& a0, hipStream_t st) {
     constexpr size_t epi = (size_t)NC * X3EpiGeom<TN>::BYTES + 2 * BN * sizeof(float);
     constexpr size_t lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
-    auto kern = &conv_ws_x3<WM, WN, TM, TN, NB, SBMAX>;
+    auto kern = &conv_ws_x3<WM, WN, TM, TN, NB, SBMAX, 0>;
+    if (lds > 64 * 1024) {
+        const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
+        if (!ok) return GV_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((NC + X3W_NL) * 64), lds, st, a, w);
+    GV_LAUNCH_CHECK();
+    return GV_OK;
+}
+
+// GEMM mode: 1x1 / stride 1 on plain fp32 input, whole 16-channel groups, 16-byte aligned pixels
+template <int WM, int WN, int TM, int TN, int MODE>
+int launch_wsg_x3(const ConvArgs& a0, hipStream_t st) {
+    constexpr int NC = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32, NB = 4;
+    const ConvArgs& c = a0;
+    if (!(c.kh == 1 && c.kw == 1 && c.stride == 1 && c.pad_t == 0 && c.pad_l == 0 && c.dil_shift == 0 && c.oh == c.ih &&
+          c.ow == c.iw && c.cin % 16 == 0 && c.x_ld % 4 == 0 && gv_aligned16(c.x) && c.pool == 0 && c.xscale == nullptr &&
+          c.y_step == 0 && c.st.mode == gvconv::STAT_OFF && ws_x3_epi_ok(c)))
+        return GV_E_UNSUPPORTED;
+    ConvArgs a = a0;
+    a.Kpad = a.K;
+    WsX3Args w;
+    w.taps = 1;
+    w.nchunks = a.cin / 16;
+    w.nk = w.nchunks;
+    if (w.nk < 4) return GV_E_UNSUPPORTED;                         // (the loader's prologue issues four k-steps)
+    w.halo_lo = 0;
+    w.strip_blocks = 0;
+    w.pad_[0] = w.pad_[1] = w.pad_[2] = 0;
+    a.tiles_n = gv_ceil_div(a.cout, BN);
+    const int64_t nwg = (int64_t)gv_ceil_div(a.M, BM) * a.tiles_n;
+    if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
+    constexpr size_t ring = (size_t)NB * 96 * BN + 9 * (size_t)BM * 32;
+    constexpr size_t epi = (size_t)NC * X3EpiGeom<TN>::BYTES + 2 * BN * sizeof(float);
+    constexpr size_t lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    auto kern = &conv_ws_x3<WM, WN, TM, TN, NB, 0, MODE>;
     if (lds > 64 * 1024) {
         const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
         if (!ok) return GV_E_UNSUPPORTED;
@@ -402,6 +574,19 @@ int ws_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) {
         case 1: return launch_ws_x3<4, 2, 2, 2, 4, 13>(a, st);     // 256 x 128
         case 2: return launch_ws_x3<8, 1, 2, 3, 3, 21>(a, st);     // 512 x 96 (Mixed_5's 3x3 layers)
         case 3: return launch_ws_x3<8, 1, 2, 2, 3, 21>(a, st);     // 512 x 64 (Mixed_5's 5x5 layers)
+    }
+    return GV_E_UNSUPPORTED;
+}
+
+// fp32 input (the register-staged kernel's class, conv_bf16s.hip): the GEMM mode
+int wsg_x3_num_cfgs() { return 2; }
+
+int wsg_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) {
+    static const bool off = getenv("GV_NO_WS") != nullptr;
+    if (off) return GV_E_UNSUPPORTED;
+    switch (cfg) {
+        case 0: return launch_wsg_x3<4, 2, 2, 3, 1>(a, st);        // 256 x 192 (144 KB)
+        case 1: return launch_wsg_x3<4, 2, 2, 2, 1>(a, st);        // 256 x 128
     }
     return GV_E_UNSUPPORTED;
 }

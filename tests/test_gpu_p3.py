@@ -197,6 +197,60 @@ def test_ws_strip_kernel_declines_what_it_cannot_run():
             assert ei.value.code == _lib.GV_E_UNSUPPORTED
 
 
+def wsg_tiles():
+    sp = lib().gv_conv2d_special_tile_cfg(X3)
+    return list(range(sp + 1, lib().gv_conv2d_num_tile_cfgs(X3)))
+
+
+@pytest.mark.parametrize("cin,cout,hw,nb", [(64, 64, (9, 10), 3), (192, 208, (25, 25), 2), (768, 704, (12, 12), 3), (288, 200, (7, 5), 9),
+                                            (1280, 384, (5, 5), 11)])
+def test_ws_gemm_mode_on_fp32_input(cin, cout, hw, nb):
+    """csrc/conv_ws_x3.hip, GEMM mode: 1x1 convolutions on plain fp32 input (the fused sibling GEMMs of an Inception block,
+    nets/inception_v3.py:137-204): the loader waves split fp32 into three planes on the way into LDS.  Against the CPU
+    oracle and the register-staged kernel; ragged M and cout, the shortest k-loop, channel-slice operands, fp32 and
+    three-plane destinations, the block's four-way split."""
+    g = torch.Generator().manual_seed(cin + cout)
+    ih, iw = hw
+    x = torch.randn(nb, ih, iw, cin, generator=g)
+    w = torch.randn(1, 1, cin, cout, generator=g) * (1.0 / cin ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, True)
+    base = conv(x, w, 1, (0, 0), hw, scale, shift, True)
+    tiles = wsg_tiles()
+    assert len(tiles) == 2
+    for tile in tiles:
+        y = conv(x, w, 1, (0, 0), hw, scale, shift, True, tile=tile, x_ld=cin + 8, x_off=4, y_ld=cout + 8, y_off=4)
+        close(y, ref)
+        assert float((y - base).abs().max()) <= 4e-6 * float(base.abs().max()), tile
+        if cout % 16 == 0:
+            yp = conv(x, w, 1, (0, 0), hw, scale, shift, True, y_p3=True, tile=tile, y_ld=cout + 32, y_off=16)
+            assert torch.equal(yp, y), tile
+        if cout >= 128:
+            split, relu_cols = 64, cout - 32
+            full = OB.conv2d(x, w, 1, "SAME") * scale + shift
+            want = torch.cat([torch.relu(full[..., :relu_cols]), full[..., relu_cols:]], dim=3)
+            y0, s0 = conv(x, w, 1, (0, 0), hw, scale, shift, True, split=split, relu_cols=relu_cols, tile=tile)
+            close(torch.cat([y0, s0], dim=3), want)
+            if (cout - split) % 16 == 0:
+                y1, s1 = conv(x, w, 1, (0, 0), hw, scale, shift, True, split=split, relu_cols=relu_cols, y2_p3=True, tile=tile,
+                              y_ld=256, y_off=32)
+                assert torch.equal(y1, y0) and torch.equal(s1, s0)
+
+
+def test_ws_gemm_mode_declines_what_it_cannot_run():
+    g = torch.Generator().manual_seed(2)
+    for k, stride, cin in (((3, 3), 1, 64), ((1, 1), 2, 64), ((1, 1), 1, 48), ((1, 1), 1, 40)):
+        x = torch.randn(2, 9, 9, cin, generator=g)
+        w = torch.randn(k[0], k[1], cin, 32, generator=g) * 0.1
+        oh = OB.conv2d(x, w, stride, "SAME").shape[1]
+        pads = (OB.same_pads(9, k[0], stride)[0],) * 2
+        for tile in wsg_tiles():
+            with pytest.raises(_lib.GvError) as ei:
+                conv(x, w, stride, pads, (oh, oh), torch.ones(32), torch.zeros(32), True, tile=tile)
+            assert ei.value.code == _lib.GV_E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4, 9])
 def test_staged_kernel_writes_three_planes(tile):
     """fp32 input through the register-staged kernel, P3 output through the LDS-staged epilogue: the stored planes sum
