@@ -564,7 +564,7 @@ int launch_wsg_x3(const ConvArgs& a0, hipStream_t st) {
 #ifndef GV_KERNEL_ONLY
 namespace gvconv {
 
-int ws_x3_num_cfgs() { return 4; }
+int ws_x3_num_cfgs() { return 5; }
 
 int ws_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) {
     static const bool off = getenv("GV_NO_WS") != nullptr;       // (A/B of whole plans: the autotuner then never sees these tiles)
@@ -574,6 +574,7 @@ int ws_x3_launch(int cfg, const ConvArgs& a, hipStream_t st) {
         case 1: return launch_ws_x3<4, 2, 2, 2, 4, 13>(a, st);     // 256 x 128
         case 2: return launch_ws_x3<8, 1, 2, 3, 3, 21>(a, st);     // 512 x 96 (Mixed_5's 3x3 layers)
         case 3: return launch_ws_x3<8, 1, 2, 2, 3, 21>(a, st);     // 512 x 64 (Mixed_5's 5x5 layers)
+        case 4: return launch_ws_x3<8, 1, 1, 5, 4, 13>(a, st);     // 256 x 160: 8 consumers of 32 x 160 (Mixed_6c / 6d's 160-column layers)
     }
     return GV_E_UNSUPPORTED;
 }

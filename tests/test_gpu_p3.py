@@ -145,7 +145,7 @@ WS_X3_COMBOS = [((1, 7), 128, 128, (17, 17)), ((7, 1), 160, 192, (17, 17)), ((3,
 
 def ws_x3_tiles():
     n = lib().gv_conv2d_num_tile_cfgs(-3)
-    return list(range(n - 4, n))
+    return list(range(n - 5, n))
 
 
 @pytest.mark.parametrize("k,cin,cout,hw", WS_X3_COMBOS)

@@ -17,7 +17,7 @@ period = idx[-1] - idx[-2]
 first = idx[-steps] - (idx[-1] - idx[-2]) + (len(rows) - idx[-1])   # same phase as the end of the trace
 first = max(first, 0)
 sel = rows[len(rows) - steps * period:]
-FAM = [("filter gradient", ("conv_wgrad",)), ("filter gradient: slice reduce", ("dw_reduce_slices",)), ("conv fwd/dgrad", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma")),
+FAM = [("filter gradient", ("conv_wgrad",)), ("filter gradient: slice reduce", ("dw_reduce_slices",)), ("conv fwd/dgrad", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma", "conv_ws")),
        ("BN sums", ("grouped_sums",)), ("BN apply fwd/bwd", ("bn_stream", "scale_shift_act_grouped", "bn_bwd_apply")),
        ("pool fwd/bwd", ("pool2d", "maxpool", "avgpool3x3")), ("fills/copies", ("FillFunctor", "fillBuffer", "copyBuffer")),
        ("filter re-pack", ("pack_filter", "elementwise_kernel")), ("optimizer", ("sgd_momentum",)),

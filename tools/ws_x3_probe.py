@@ -17,7 +17,7 @@ lib = _lib.load()
 dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 X3 = _lib.GV_MATH_BF16X3
-NWS = 4
+NWS = 5
 PEAK = 2500.0 / 6
 
 
