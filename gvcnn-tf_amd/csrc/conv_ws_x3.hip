@@ -113,7 +113,10 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
             ss_v[1] = a.shift[cc];
         }
         if (!(a.dbg & 16384)) {
-            __builtin_amdgcn_s_setprio(3);                         // (conv_ws.hip: the loaders' few instructions go first)
+            // (conv_ws.hip: the loaders' few instructions go first.  Measured here and neutral: no priority; a higher priority
+            // for one of a SIMD's two consumers; an s_sleep behind every DMA instruction, -1 ... -3 %:
+            // profiles/r5_x3ws_priority_and_pacing_ab.txt)
+            __builtin_amdgcn_s_setprio(3);
             const bool nodma = (a.dbg & 32768) != 0, nobar = (a.dbg & 65536) != 0;
             const int lrow = lane >> 1;                            // row inside a 32-row block
             const int lc16 = (((lane & 1) ^ ((lrow >> 3) & 1)) << 4);   // byte offset of the logical chunk this lane fetches
