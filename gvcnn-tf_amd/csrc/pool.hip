@@ -232,6 +232,86 @@ __global__ __launch_bounds__(256) void global_avg_pool_f32(const float* __restri
     y[idx] = s / (float)hw;
 }
 
+// The same pool on THREE-PLANE input, 8 channels and 2 x 4 outputs per thread: 16-byte plane loads (the form above reads a
+// pixel's 4 channels as three 8-byte loads), rows oy and oy + 1 of the pair shared in registers, and workgroups mapped so
+// that an XCD owns a contiguous range of them — the rows two outputs share are then in ITS L2 (round-robin dispatch put
+// vertical neighbours on different XCDs: the pooled branches of c2 fetched 3.5 x their input from beyond L2, at an L2
+// hit rate of 0.28).  Same additions in the same order as the form above: bitwise the same values.
+template <bool YP3>
+__global__ __launch_bounds__(256) void avgpool3x3s1_p3x8(const char* __restrict__ x, char* __restrict__ y, int nb, int ih,
+                                                         int iw, int c, int x_ld, int y_ld, int relu) {
+    const int cg = c >> 3, wg = (iw + 3) >> 2, hg = (ih + 1) >> 1;
+    const int64_t total = (int64_t)nb * hg * wg * cg;
+    const int64_t idx = (int64_t)gv_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    int64_t t = idx / cg;
+    const int xg = (int)(t % wg);
+    t /= wg;
+    const int yg = (int)(t % hg);
+    const int n = (int)(t / hg);
+    const int oy0 = yg * 2, ox0 = xg * 4, ch = g * 8;
+    float col[2][6][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) col[q][j][e] = 0.f;
+    const size_t choff = (size_t)(ch & ~15) * 6 + (size_t)(ch & 15) * 2;
+#pragma unroll
+    for (int r = -1; r <= 2; ++r) {
+        const int iy = oy0 + r;
+        if ((unsigned)iy >= (unsigned)ih) continue;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = ox0 - 1 + j;
+            if ((unsigned)ix >= (unsigned)iw) continue;
+            const char* src = x + ((size_t)(n * ih + iy) * iw + ix) * (size_t)x_ld * 6 + choff;
+            p3_u32x4 pl[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) pl[p] = *reinterpret_cast<const p3_u32x4*>(src + p * 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int sh = (e & 1) * 16;
+                const float a0 = __builtin_bit_cast(float, ((pl[0][e >> 1] >> sh) & 0xffffu) << 16);
+                const float a1 = __builtin_bit_cast(float, ((pl[1][e >> 1] >> sh) & 0xffffu) << 16);
+                const float a2 = __builtin_bit_cast(float, ((pl[2][e >> 1] >> sh) & 0xffffu) << 16);
+                const float v = (a2 + a1) + a0;
+                if (r <= 1) col[0][j][e] += v;
+                if (r >= 0) col[1][j][e] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int oy = oy0 + q;
+        if (oy >= ih) break;
+        const int rows = 1 + (oy > 0 ? 1 : 0) + (oy + 1 < ih ? 1 : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = ox0 + j;
+            if (ox >= iw) break;
+            const int cols = 1 + (ox > 0 ? 1 : 0) + (ox + 1 < iw ? 1 : 0);
+            const float inv = (float)(rows * cols);           // valid taps only (TF SAME semantics)
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = (col[q][j][e] + col[q][j + 1][e] + col[q][j + 2][e]) / inv;
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            const size_t pix = (size_t)(n * ih + oy) * iw + ox;
+            if constexpr (YP3) {
+                p3_store8(y, pix, y_ld, ch, v);
+            } else {
+                float* yp = reinterpret_cast<float*>(y) + pix * (size_t)y_ld + ch;
+                *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(yp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     const int64_t cap = 256 * 16;            // 16 blocks per CU, grid-stride the rest
@@ -307,6 +387,15 @@ extern "C" int gv_pool2d_fwd(const gv_pool_desc* d, const void* x, void* y, void
             d->oh == d->ih && d->ow == d->iw) {
             const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 4);
             const int relu = mode == GV_POOL_AVG_RELU ? 1 : 0;
+            const int64_t blk8 = ((int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 3) / 4) * (d->c / 8) + 255) / 256;
+            if (xp3 && d->c % 8 == 0 && blk8 < 0x7fffffff) {     // three-plane input, whole 8-channel chunks
+                if (yp3) hipLaunchKernelGGL((avgpool3x3s1_p3x8<true>), dim3((unsigned)blk8), dim3(256), 0, st, (const char*)x, (char*)y,
+                                            d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, relu);
+                else hipLaunchKernelGGL((avgpool3x3s1_p3x8<false>), dim3((unsigned)blk8), dim3(256), 0, st, (const char*)x, (char*)y,
+                                        d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, relu);
+                GV_LAUNCH_CHECK();
+                return GV_OK;
+            }
 #define GV_AVG4(XP, YP) hipLaunchKernelGGL((avgpool3x3s1_row4_f32<XP, YP>), dim3(grid_for(tot4)), dim3(256), 0, st, xf, yf, \
                                            d->nb, d->ih, d->iw, d->c, d->x_ld, d->y_ld, relu)
             if (xp3 && yp3) GV_AVG4(true, true); else if (xp3) GV_AVG4(true, false); else GV_AVG4(false, true);
