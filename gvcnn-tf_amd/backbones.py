@@ -122,7 +122,7 @@ class BackbonePlan:
         self.defer_preact = dtype != _lib.GV_F32
         # 16-bit storage: Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch that writes only the pooled tensor
         # (GV_CONV_MAXPOOL3S2); off: the two launches (A/B switch)
-        self.fuse_maxpool = dtype != _lib.GV_F32
+        self.fuse_maxpool = dtype != _lib.GV_F32 or math_mode == _lib.GV_MATH_BF16X3
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -292,8 +292,11 @@ class BackbonePlan:
         pads = padding if isinstance(padding, tuple) else (padding, padding)
         oh = _out_size(x.h, k, stride, pads[0])[0]
         ow = _out_size(x.w, k, stride, pads[1])[0]
-        if not (self.fuse_maxpool and self.dtype != _lib.GV_F32 and cout == 64 and not x.p3 and min(oh, ow) >= 3):
+        if not (self.fuse_maxpool and cout == 64 and not x.p3 and min(oh, ow) >= 3):
             return False
+        if self.dtype == _lib.GV_F32:                         # three-plane math: the halo kernel's 30-pixel strip form, VALID pool
+            return (self.math_mode == _lib.GV_MATH_BF16X3 and pool_padding == "VALID" and k == 3 and stride == 1 and x.c == 32
+                    and x.vbuf >= 0 and x.ld % 4 == 0 and -(-ow // 16) * 16 * 5 > -(-ow // 30) * 32 * 4)
         if pool_padding == "SAME" and (oh % 2 or ow % 2):
             return False
         if x.vbuf < 0:                                        # the network input: the stem strip kernel

@@ -652,7 +652,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // the 8-channel chunks XOR-swizzled by (column >> 1) & 3, filter rows [tap][plane][32] at a 1760-byte pitch: both
 // conflict-free for the 16-lane groups of ds_read_b128 at every tap shift).  Same bytes read from LDS per FLOP and the
 // same cycles per FLOP as the 32x32x16 form; the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS (7)).
-template <int ABL, bool PLAIN>
+// POOL (GV_CONV_MAXPOOL3S2 on fp32 storage; Conv2d_2b_3x3 -> MaxPool_3a_3x3, nets/inception_v3.py:111-113): the 3x3 / 2
+// VALID max pool of the output is taken inside the workgroup and only the pooled tensor is written — a quarter of the
+// bytes, and the pool's launch (which re-read all of them from HBM: the largest tensor of the fp32 plan) disappears.  A
+// strip advances 28 columns = 14 pooled ones (30 are computed as before: the same number of strips for 109 columns); a
+// finished row (BatchNorm + ReLU applied) is pooled HORIZONTALLY on its way out of the wave's staging block into a ten-row
+// LDS ring of [14 pooled pixels][32 channels], and two tiles later — behind the tile loop's own barrier, no extra one —
+// 224 threads take the two pooled rows a tile completed: bitwise the two launches' values.  (Whole rows in a six-row ring
+// with a barrier in the middle of the tile cost the convolution +15 %.)
+template <int ABL, bool PLAIN, bool POOL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_halo_x3_k32(const ConvArgs a) {
     constexpr int TH = 4, TW = 30, HW = 32, PB = 192;
     constexpr int R = 2 * TH + 2;
@@ -665,13 +673,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* stage = reinterpret_cast<float*>(smem_raw + R * ROWB) + (threadIdx.x >> 6) * (32 * SW);
     char* sW = smem_raw + R * ROWB + 4 * 32 * SW * 4;                             // [32][WB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
-    const int tiles_x = (a.ow + TW - 1) / TW;
+    constexpr int PSTEP = POOL ? 28 : TW, PPX = 14;
+    const int tiles_x = POOL ? (a.pw + PPX - 1) / PPX : (a.ow + TW - 1) / TW;
     const int nct = (a.cout + 31) / 32;
     const int lid = gv_xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int ct = lid % nct;
     const int strip = lid / nct;
     const int n = strip / tiles_x;
-    const int ox0 = (strip % tiles_x) * TW;
+    const int ox0 = (strip % tiles_x) * PSTEP;
+    float* pimg = reinterpret_cast<float*>(smem_raw + R * ROWB + 4 * 32 * SW * 4 + 32 * WB);   // POOL: [10 rows][14 pooled px][32 ch]
     const int co0 = ct * 32;
 
     for (int idx = tid; idx < 32 * 108; idx += 256) {      // packed [n][k-tile 16][plane][16] -> LDS [n][tap][plane][32]
@@ -766,6 +776,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
+    // POOL: half h of the wave's row oy (7 pooled pixels x 8 four-channel groups per half): max over pixels 2p .. 2p+2 of the
+    // finished values, from the wave's staging block into the ring
+    auto hpass = [&](int h, int oy) {
+        const int pp = lane >> 3;
+        if (pp >= 7) return;
+        const int ppx = h * 7 + pp;
+        f32x4 m = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + (2 * ppx + dx) * SW + col4);
+            const bool in = oy < a.oh && ox0 + 2 * ppx + dx < a.ow;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], in ? fmaxf(v4[e] * sc[e] + sh[e], rlo[e]) : -__builtin_inff());
+        }
+        const int slot = oy - (oy / 10) * 10;
+        *reinterpret_cast<f32x4*>(pimg + (slot * PPX + ppx) * 32 + col4) = m;
+    };
+    // POOL: the pooled rows 2T-1 and 2T, complete once tile T's rows are in the ring (14 pooled pixels x 8 four-channel groups each)
+    auto pool_rows = [&](int T) {
+        if (tid >= 2 * PPX * 8) return;
+        const int pyl = tid / (PPX * 8), rem = tid - pyl * (PPX * 8), ppx = rem >> 3, c4 = (rem & 7) * 4;
+        const int py = 2 * T - 1 + pyl, px = PPX * (strip % tiles_x) + ppx;
+        if (py < 0 || py >= a.ph || px >= a.pw || co0 + c4 >= a.cout) return;
+        f32x4 m = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int row = 2 * py + dy, slot = row - (row / 10) * 10;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pimg + (slot * PPX + ppx) * 32 + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+        float* yp = a.y + ((size_t)(n * a.ph + py) * a.pw + px) * a.y_ld + co0 + c4;
+        const int nv = min(4, a.cout - co0 - c4);
+        if (vec && nv == 4) {
+            *reinterpret_cast<f32x4*>(yp) = m;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nv) yp[e] = m[e];
+        }
+    };
     const int ntiles = (a.oh + TH - 1) / TH;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -876,11 +927,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int r = 0; r < 16; ++r)            // acc[i][j][v]: pixel 16 i + 4 lg + v, channel 16 j + l16
                         stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * ((r >> 2) & 1) + l16] = accv[r];
                 }
-                if (ks >= 1 && ks < 5) {
-                    if (ks == 1) __builtin_amdgcn_wave_barrier();
-                    sv[ks & 1] = *reinterpret_cast<const f32x4*>(stage + ((ks - 1) * 8 + rrow) * SW + col4);
+                if constexpr (POOL) {
+                    if (ks == 1) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (t >= 2) pool_rows(t - 2);       // tile t-2's rows: in the ring since the barrier at this tile's top
+                    }
+                    if (ks == 2 || ks == 3) hpass(ks - 2, oy - TH);
+                } else {
+                    if (ks >= 1 && ks < 5) {
+                        if (ks == 1) __builtin_amdgcn_wave_barrier();
+                        sv[ks & 1] = *reinterpret_cast<const f32x4*>(stage + ((ks - 1) * 8 + rrow) * SW + col4);
+                    }
+                    if (ks >= 2 && ks < 6) finish_pass(ks - 2, oy - TH, sv[(ks - 1) & 1]);
                 }
-                if (ks >= 2 && ks < 6) finish_pass(ks - 2, oy - TH, sv[(ks - 1) & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -910,9 +969,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r)
             stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * ((r >> 2) & 1) + l16] = accv[r];
         __builtin_amdgcn_wave_barrier();
+        if constexpr (POOL) {
+            hpass(0, oy);
+            hpass(1, oy);
+            __syncthreads();
+            if (ntiles >= 2) pool_rows(ntiles - 2);
+            pool_rows(ntiles - 1);
+        } else {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass)
-            finish_pass(pass, oy, *reinterpret_cast<const f32x4*>(stage + (pass * 8 + rrow) * SW + col4));
+            for (int pass = 0; pass < 4; ++pass)
+                finish_pass(pass, oy, *reinterpret_cast<const f32x4*>(stage + (pass * 8 + rrow) * SW + col4));
+        }
     }
 }
 
@@ -944,6 +1011,16 @@ int launch_halo_x3(const ConvArgs& a, hipStream_t st) {
         return GV_OK;                                                                                               \
     }
     const size_t lds32 = (size_t)10 * 32 * 192 + 4 * 32 * 36 * 4 + 32 * (9 * 192 + 32);
+    if (a.pool) {                                     // conv -> max pool 3x3 / 2 VALID: the 30-pixel strip form only
+        if (rw != 1 || a.pool != 1 || a.res != nullptr || a.cout % 4 != 0) return GV_E_UNSUPPORTED;
+        const dim3 pgrid((unsigned)(a.nb * ((a.pw + 13) / 14) * nct));
+        const size_t ldsp = lds32 + (size_t)10 * 14 * 32 * 4;
+        const bool ok = GV_BIG_LDS_OK((&conv3x3_halo_x3_k32<0, false, true>), 160 * 1024);
+        if (!ok) return GV_E_UNSUPPORTED;
+        hipLaunchKernelGGL((conv3x3_halo_x3_k32<0, false, true>), pgrid, dim3(256), ldsp, st, a);
+        GV_LAUNCH_CHECK();
+        return GV_OK;
+    }
     if (rw == 1 && !(a.dbg & 8)) {                    // (debug bit 8: the 32x32x16 form, for A/B timing)
         if (a.dbg & (4 | 16 | 32)) {
             if (!plain) return GV_E_UNSUPPORTED;
@@ -1238,6 +1315,12 @@ bool bf16s_halo_ok(int planes, const ConvArgs& a, bool generic) {
            a.ow == a.iw + 2 * a.pad_l - 2;
 }
 
+// GV_CONV_MAXPOOL3S2 on fp32 storage: the halo kernel's class in its 30-pixel strip form, VALID pool, no residual
+bool bf16s_halo_pool_ok(int planes, const ConvArgs& a, bool generic) {
+    return a.pool == 1 && bf16s_halo_ok(planes, a, generic) && a.res == nullptr && a.cout % 4 == 0 && a.oh >= 3 && a.ow >= 3 &&
+           !(gv_ceil_div(a.ow, 16) * 16 * 5 <= gv_ceil_div(a.ow, 30) * 32 * 4);
+}
+
 int bf16s_pick_tile(int /*planes*/, int M, int N, int /*K*/) {
     int best = 0;
     double best_cost = 1e30;
@@ -1261,6 +1344,7 @@ int bf16s_launch(int planes, int cfg, const ConvArgs& a0, bool generic, hipStrea
     a.Kpad = (a.K + KT - 1) / KT * KT;
     a.ktiles = a.Kpad / KT;
     if (cfg == kNumTiles) {
+        if (a.pool) return bf16s_halo_pool_ok(planes, a, generic) ? launch_halo_x3(a, st) : GV_E_UNSUPPORTED;
         if (bf16s_stem_ok(planes, a)) return launch_stem_x3(a, st);
         return bf16s_halo_ok(planes, a, generic) ? launch_halo_x3(a, st) : GV_E_UNSUPPORTED;
     }

@@ -111,6 +111,7 @@ int bf16s_num_cfgs();
 int bf16s_special_cfg();        // the halo-tiled / strip stem kernels
 int bf16s_pick_tile(int planes, int M, int N, int K);
 bool bf16s_halo_ok(int planes, const ConvArgs& a, bool generic);
+bool bf16s_halo_pool_ok(int planes, const ConvArgs& a, bool generic);   // GV_CONV_MAXPOOL3S2 on fp32 storage
 bool bf16s_stem_ok(int planes, const ConvArgs& a);
 int bf16s_launch(int planes, int cfg, const ConvArgs& a, bool generic, hipStream_t st);
 int bf16s_pack_filter(const float* w_hwio, int kh, int kw, int cin, int cout, int planes, void* out,

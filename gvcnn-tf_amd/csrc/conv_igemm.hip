@@ -572,7 +572,9 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
         // conv -> max_pool2d 3x3 / 2 in one launch: y is the pooled tensor (the halo / stem strip kernels' classes only)
         const bool same = (d->flags & GV_CONV_MAXPOOL3S2_SAME) != 0;
         if (same && (d->flags & GV_CONV_MAXPOOL3S2)) return GV_E_BADARG;
-        if (!lp || split || y2 || residual || stats || xscale || d->y_step != 0 || a.dil_shift || d->oh < 3 || d->ow < 3)
+        // (fp32 storage: three-plane math, the VALID pool behind the halo kernel's class — checked below)
+        if ((!lp && (np != 3 || same || xp3 || yp3)) || split || y2 || residual || stats || xscale || d->y_step != 0 || a.dil_shift ||
+            d->oh < 3 || d->ow < 3)
             return GV_E_UNSUPPORTED;
         if (same && ((d->oh | d->ow) & 1)) return GV_E_UNSUPPORTED;          // TF's SAME pads (0, 1) on an even map only
         a.pool = same ? 2 : 1;
@@ -617,6 +619,10 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
     }
     // vector loader needs 16-channel chunks inside one filter tap and 16-byte aligned pixels
     const bool generic = (d->cin % CH != 0) || (d->x_ld % 4 != 0) || !gv_aligned16(x);
+    if (a.pool) {                                        // conv -> max pool on fp32 storage: one kernel serves it
+        if (!gvconv::bf16s_halo_pool_ok(np, a, generic)) return GV_E_UNSUPPORTED;
+        return gvconv::bf16s_launch(np, gvconv::bf16s_special_cfg(), a, generic, (hipStream_t)stream);
+    }
     if (np > 0) {
         // the vector loader keeps 32-bit element offsets
         if (!generic && (int64_t)d->nb * d->ih * d->iw * d->x_ld > 0xffffffffll) return GV_E_UNSUPPORTED;

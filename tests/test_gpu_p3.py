@@ -197,6 +197,65 @@ def test_ws_strip_kernel_declines_what_it_cannot_run():
             assert ei.value.code == _lib.GV_E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("ih,iw,pad,cout,nb", [(109, 109, 1, 64, 2), (111, 113, 0, 64, 1), (101, 97, 1, 32, 3), (30, 140, 1, 64, 2), (7, 99, 1, 64, 2)])
+def test_fp32_conv_and_max_pool_as_one_launch(ih, iw, pad, cout, nb):
+    """GV_CONV_MAXPOOL3S2 on fp32 storage (three-plane math; csrc/conv_bf16s.hip, the halo kernel's 30-pixel strip form):
+    Conv2d_2b_3x3 -> MaxPool_3a_3x3 (nets/inception_v3.py:111-113) in one launch equals the two launches BITWISE — pooled
+    rows that straddle the kernel's four-row tiles, pooled columns in the last (partial) strip, odd and even maps, a
+    channel-slice destination; maps the 16-pixel strip form serves, other channel counts and a residual are declined."""
+    g = torch.Generator().manual_seed(ih * 7 + iw)
+    cin = 32
+    x = torch.randn(nb, ih, iw, cin, generator=g)
+    w = torch.randn(3, 3, cin, cout, generator=g) * (1.0 / (9 * cin) ** 0.5)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    oh, ow = ih + 2 * pad - 2, iw + 2 * pad - 2
+    ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
+    xd, wp, sc, sh = x.to(DEV), pack_filter(w), scale.to(DEV), shift.to(DEV)
+    y_ld, y_off = cout + 16, 8
+    sp = lib().gv_conv2d_special_tile_cfg(X3)
+
+    def desc(flags, ld):
+        return _lib.ConvDesc(nb, ih, iw, cin, cin, 3, 3, 1, pad, pad, oh, ow, cout, ld, 0, 0, flags, _lib.GV_F32, 0, sp + 1, X3, 0, 0)
+
+    full = torch.empty(nb, oh, ow, cout, device=DEV)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(desc(_lib.GV_CONV_RELU, cout)), xd.data_ptr(), wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                   None, full.data_ptr(), None, None, None, st()), "conv")
+    two = torch.full((nb, ph, pw, y_ld), -3.0, device=DEV)
+    pd = _lib.PoolDesc(nb, oh, ow, cout, cout, 3, 3, 2, 0, 0, ph, pw, y_ld, _lib.GV_POOL_MAX, _lib.GV_F32)
+    _lib.check(lib().gv_pool2d_fwd(C.byref(pd), full.data_ptr(), two.data_ptr() + 4 * y_off, st()), "pool")
+    one = torch.full((nb, ph, pw, y_ld), -3.0, device=DEV)
+    rc = lib().gv_conv2d_fwd(C.byref(desc(_lib.GV_CONV_RELU | _lib.GV_CONV_MAXPOOL3S2, y_ld)), xd.data_ptr(), wp.data_ptr(),
+                             sc.data_ptr(), sh.data_ptr(), None, one.data_ptr() + 4 * y_off, None, None, None, st())
+    torch.cuda.synchronize()
+    if ow <= 96:                                          # the 16-pixel strip form's maps: the caller keeps the two launches
+        assert rc == _lib.GV_E_UNSUPPORTED and bool((one == -3.0).all())
+        return
+    _lib.check(rc, "fused")
+    assert torch.equal(one, two)
+    ref = torch.nn.functional.max_pool2d(oracle_conv(x, w, 1, "SAME" if pad else "VALID", scale, shift, True).permute(0, 3, 1, 2), 3, 2)
+    close(one[..., y_off:y_off + cout].cpu(), ref.permute(0, 2, 3, 1))
+
+
+def test_fp32_fused_max_pool_declines_other_classes():
+    g = torch.Generator().manual_seed(5)
+    sp = lib().gv_conv2d_special_tile_cfg(X3)
+    for cin, cout, k, stride, extra in ((32, 96, 3, 1, 0), (64, 64, 3, 1, 0), (32, 64, 1, 1, 0), (32, 64, 3, 2, 0),
+                                        (32, 64, 3, 1, _lib.GV_CONV_X_P3)):
+        ih = iw = 120
+        pad = k // 2
+        oh = (ih + 2 * pad - k) // stride + 1
+        x = torch.randn(1, ih, iw, max(cin, 64), generator=g).to(DEV)
+        w = torch.randn(k, k, cin, cout, generator=g) * 0.05
+        wp = pack_filter(w)
+        y = torch.full((1, (oh - 3) // 2 + 1, (oh - 3) // 2 + 1, cout), -3.0, device=DEV)
+        d = _lib.ConvDesc(1, ih, iw, cin, 64 if extra else cin, k, k, stride, pad, pad, oh, oh, cout, cout, 0, 0,
+                          _lib.GV_CONV_RELU | _lib.GV_CONV_MAXPOOL3S2 | extra, _lib.GV_F32, 0, sp + 1, X3, 0, 0)
+        rc = lib().gv_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), torch.ones(cout, device=DEV).data_ptr(),
+                                 torch.zeros(cout, device=DEV).data_ptr(), None, y.data_ptr(), None, None, None, st())
+        torch.cuda.synchronize()
+        assert rc == _lib.GV_E_UNSUPPORTED and bool((y == -3.0).all()), (cin, cout, k, stride)
+
+
 def wsg_tiles():
     sp = lib().gv_conv2d_special_tile_cfg(X3)
     return list(range(sp + 1, lib().gv_conv2d_num_tile_cfgs(X3)))

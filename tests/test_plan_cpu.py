@@ -225,3 +225,16 @@ def test_16bit_plans_issue_conv_and_max_pool_as_one_launch(dtype):
     for name in ("inception_v3", "resnet_v2_50"):
         f32 = backbones.make_plan(name, 2, 224, 224, cpu)
         assert not any(o.get("maxpool") for o in f32.ops if o["kind"] == "conv")
+    # fp32 storage under the three-plane math (the bench line): the Inception pair is one launch where the halo kernel runs
+    # its 30-pixel strip form (a Conv2d_2b map wider than 96 pixels), two launches on smaller maps; ResNet keeps two
+    x3 = backbones.make_plan("inception_v3", 2, 224, 224, cpu, math="bf16x3")
+    op = next(o for o in x3.ops if o["name"].endswith("Conv2d_2b_3x3"))
+    assert op["maxpool"] == "VALID" and (op["y"].h, op["y"].w, op["y"].c) == (54, 54, 64) and not op["y"].p3
+    assert "MaxPool_3a_3x3" not in [o["name"] for o in x3.ops]
+    assert abs(x3.total_flops / 2 / 1e9 - 5.672) < 0.002 * 5.672
+    small = backbones.make_plan("inception_v3", 2, 128, 128, cpu, math="bf16x3")             # Conv2d_2b: 61 x 61
+    assert "MaxPool_3a_3x3" in [o["name"] for o in small.ops]
+    off3 = backbones.make_plan("inception_v3", 2, 224, 224, cpu, math="bf16x3", fuse_maxpool=False)
+    assert "MaxPool_3a_3x3" in [o["name"] for o in off3.ops] and off3.param_shapes() == x3.param_shapes()
+    r3 = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, math="bf16x3")
+    assert not any(o.get("maxpool") for o in r3.ops if o["kind"] == "conv")
