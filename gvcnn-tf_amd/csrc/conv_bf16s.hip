@@ -702,6 +702,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         sc[e] = a.scale[c];
         sh[e] = a.shift[c];
     }
+    float scp[2] = {0.f, 0.f}, shp[2] = {0.f, 0.f}, rlop[2] = {0.f, 0.f};     // POOL: this lane's two channels of the accumulator layout
+    if constexpr (POOL) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = min(co0 + 16 * j + l16, a.cout - 1);
+            scp[j] = a.scale[c];
+            shp[j] = a.shift[c];
+            rlop[j] = (a.relu && c < a.relu_limit) ? 0.f : -__builtin_inff();
+        }
+    }
     const bool vec = (a.y_ld % 4 == 0) && ((((uintptr_t)a.y) & 15) == 0) &&
                      (a.res == nullptr || ((a.res_ld % 4 == 0) && ((((uintptr_t)a.res) & 15) == 0)));
     const int ox_end = min(a.ow, ox0 + TW);
@@ -777,19 +787,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // POOL: half h of the wave's row oy (7 pooled pixels x 8 four-channel groups per half): max over pixels 2p .. 2p+2 of the
-    // finished values, from the wave's staging block into the ring
+    // finished values (BatchNorm + ReLU went in with the accumulators) from the wave's staging block into the ring
     auto hpass = [&](int h, int oy) {
         const int pp = lane >> 3;
         if (pp >= 7) return;
         const int ppx = h * 7 + pp;
-        f32x4 m = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        // (no masks: a pooled pixel inside the pooled map only reads convolution pixels inside the convolution's map)
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + (2 * ppx) * SW + col4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + (2 * ppx + 1) * SW + col4);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(stage + (2 * ppx + 2) * SW + col4);
+        f32x4 m;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + (2 * ppx + dx) * SW + col4);
-            const bool in = oy < a.oh && ox0 + 2 * ppx + dx < a.ow;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], in ? fmaxf(v4[e] * sc[e] + sh[e], rlo[e]) : -__builtin_inff());
-        }
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(v0[e], v1[e]), v2[e]);
         const int slot = oy - (oy / 10) * 10;
         *reinterpret_cast<f32x4*>(pimg + (slot * PPX + ppx) * 32 + col4) = m;
     };
@@ -924,8 +933,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (!(ABL & 4) && t > 0) {
                 if (ks == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)            // acc[i][j][v]: pixel 16 i + 4 lg + v, channel 16 j + l16
-                        stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * ((r >> 2) & 1) + l16] = accv[r];
+                    for (int r = 0; r < 16; ++r) {          // acc[i][j][v]: pixel 16 i + 4 lg + v, channel 16 j + l16
+                        const int jc = (r >> 2) & 1;
+                        stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * jc + l16] =
+                            POOL ? fmaxf(accv[r] * scp[jc] + shp[jc], rlop[jc]) : accv[r];
+                    }
                 }
                 if constexpr (POOL) {
                     if (ks == 1) {
@@ -966,8 +978,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int oy = (ntiles - 1) * TH + wave;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * ((r >> 2) & 1) + l16] = accv[r];
+        for (int r = 0; r < 16; ++r) {
+            const int jc = (r >> 2) & 1;
+            stage[(16 * (r >> 3) + 4 * lg + (r & 3)) * SW + 16 * jc + l16] = POOL ? fmaxf(accv[r] * scp[jc] + shp[jc], rlop[jc]) : accv[r];
+        }
         __builtin_amdgcn_wave_barrier();
         if constexpr (POOL) {
             hpass(0, oy);
