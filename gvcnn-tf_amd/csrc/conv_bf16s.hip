@@ -984,6 +984,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __builtin_amdgcn_wave_barrier();
         if constexpr (POOL) {
+            // (a wave still in the last iteration's pool_rows reads ring slots this tile's rows are about to take: in the
+            // loop the next iteration's barrier stands between the two)
+            __syncthreads();
             hpass(0, oy);
             hpass(1, oy);
             __syncthreads();

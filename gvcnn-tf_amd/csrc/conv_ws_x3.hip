@@ -241,6 +241,9 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
                     iter(S0{}, j);
                     if (j + 2 < nk) iter(S1{}, j + 1);
                 }
+                // the last iterations' filter DMAs (slice nk-1 over itself) and register loads are still in flight, and the
+                // epilogue's staging blocks alias the ring: nothing may land behind the barrier in front of it
+                x3w_wait_vm<0>();
             } else {
             const unsigned pix_bytes = (unsigned)a.x_ld * 6u;
             // strips: unit e = lw, lw + 4, ... of a chunk -> (block e / 3, plane e % 3); e + 4 = 3 (blk + 1) + (p + 1)
@@ -288,6 +291,7 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
                 if (j + NB < nk) issue_b();
                 ft = last_tap ? 0 : ft + 1;
             }
+            x3w_wait_vm<0>();                                      // (nothing in flight when the epilogue re-uses the ring)
             }
         }
     } else {

