@@ -60,6 +60,78 @@ __global__ __launch_bounds__(256) void pool2d_lp(const unsigned short* __restric
 
 // 3x3 / stride 1 / SAME average pool: 4 horizontally adjacent outputs of an 8-channel group per thread
 // (shared column sums), see avgpool3x3s1_row4_f32 in pool.hip.
+// The same pool with TWO output rows per thread (rows oy and oy + 1 of the pair are loaded once) and workgroups mapped so
+// that an XCD owns a contiguous range of them: the rows two outputs share are then in ITS L2 (under round-robin dispatch
+// vertical neighbours sat on different XCDs and c5's nine pooled branches fetched 3.9 x their input from beyond L2).  Same
+// additions in the same order: bitwise the same values.  Launched with exactly ceil(total / 256) workgroups.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool3x3s1_row4x2_lp(const unsigned short* __restrict__ x,
+                                                              unsigned short* __restrict__ y, int nb, int ih, int iw,
+                                                              int c, int x_ld, int y_ld, int relu) {
+    const int cg = c >> 3, wg = (iw + 3) >> 2, hg = (ih + 1) >> 1;
+    const int64_t total = (int64_t)nb * hg * wg * cg;
+    const int64_t idx = (int64_t)gv_xcd_remap((int)blockIdx.x, (int)gridDim.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    int64_t t = idx / cg;
+    const int xg = (int)(t % wg);
+    t /= wg;
+    const int yg = (int)(t % hg);
+    const int n = (int)(t / hg);
+    const int oy0 = yg * 2, ox0 = xg * 4;
+    float col[2][6][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) col[q][j][e] = 0.f;
+#pragma unroll
+    for (int r = -1; r <= 2; ++r) {
+        const int iy = oy0 + r;
+        if ((unsigned)iy >= (unsigned)ih) continue;
+        const unsigned short* rowp = x + ((size_t)(n * ih + iy) * iw) * x_ld + g * 8;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = ox0 - 1 + j;
+            if ((unsigned)ix >= (unsigned)iw) continue;
+            float v[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(rowp + (size_t)ix * x_ld), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (r <= 1) col[0][j][e] += v[e];
+                if (r >= 0) col[1][j][e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int oy = oy0 + q;
+        if (oy >= ih) break;
+        const int rows = 1 + (oy > 0 ? 1 : 0) + (oy + 1 < ih ? 1 : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = ox0 + j;
+            if (ox >= iw) break;
+            const int cols = 1 + (ox > 0 ? 1 : 0) + (ox + 1 < iw ? 1 : 0);
+            const float inv = (float)(rows * cols);           // valid taps only (TF SAME semantics)
+            // s / inv for eight values: the correctly rounded reciprocal once, then per value a product and one exact-remainder
+            // correction (Markstein) — the correctly rounded quotient, i.e. the bits of the division, at 3 instead of ~10
+            // instructions per value (the divisions were most of this kernel's vector instructions)
+            const float rcp = 1.0f / inv;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sum = col[q][j][e] + col[q][j + 1][e] + col[q][j + 2][e];
+                const float q0 = sum * rcp;
+                v[e] = __builtin_fmaf(__builtin_fmaf(-inv, q0, sum), rcp, q0);
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<u32x4*>(y + ((size_t)(n * ih + oy) * iw + ox) * y_ld + g * 8) = pack8<T>(v);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool3x3s1_row4_lp(const unsigned short* __restrict__ x,
                                                             unsigned short* __restrict__ y, int nb, int ih, int iw,
@@ -362,8 +434,13 @@ int pool2d_t(const gv_pool_desc* d, const unsigned short* x, unsigned short* y, 
     if (vec && d->mode != GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
         d->pad_l == 1 && d->oh == d->ih && d->ow == d->iw) {
         const int64_t tot4 = (int64_t)d->nb * d->ih * ((d->iw + 3) / 4) * (d->c / 8);
-        hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
-                           d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
+        const int64_t blk2 = ((int64_t)d->nb * ((d->ih + 1) / 2) * ((d->iw + 3) / 4) * (d->c / 8) + 255) / 256;
+        if (blk2 < 0x7fffffff)                                     // two rows per thread, XCD-contiguous workgroups
+            hipLaunchKernelGGL(avgpool3x3s1_row4x2_lp<T>, dim3((unsigned)blk2), dim3(256), 0, st, x, y, d->nb, d->ih, d->iw, d->c,
+                               d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
+        else
+            hipLaunchKernelGGL(avgpool3x3s1_row4_lp<T>, dim3(grid_for(tot4)), dim3(256), 0, st, x, y, d->nb, d->ih,
+                               d->iw, d->c, d->x_ld, d->y_ld, d->mode == GV_POOL_AVG_RELU ? 1 : 0);
     } else if (vec && g_pool_rows && d->mode == GV_POOL_MAX && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 &&
                d->pad_l == 0 && d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1) {
         constexpr int RH = 4;
