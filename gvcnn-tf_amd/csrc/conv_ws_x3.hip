@@ -350,10 +350,11 @@ __global__ __launch_bounds__((WM * WN + X3W_NL) * 64, 3) void conv_ws_x3(const C
         };
         auto lds16 = [&](int addr) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + addr); };
         u32x4 A0[TM], A1[TM], B0[TN], B1[TN], T[TN];
-        // one k-step on the fragments in registers.  aa: this k-step's A addresses (its plane 2 is read here), an / bn: the
-        // next k-step's (NEXT: re-load every fragment behind its last use; BAR: the k-step's barrier behind the second MFMA
+        // one k-step on the fragments in registers.  aa: this k-step's A addresses on entry (its plane 2 is read with them in
+        // the first product group); next_addr(), called behind that group, replaces aa / bn by the NEXT k-step's, which every
+        // re-load uses (NEXT: re-load every fragment behind its last use).  bar: the k-step's barrier behind the second MFMA
         // of the last product group — by then every fragment of this k-step has been an MFMA operand, i.e. every LDS read
-        // of it has returned, and the wave has matrix work queued while it waits)
+        // of it has returned, and the wave has matrix work queued while it waits
         // (the compiler's scheduler would gather the reads into one burst in front of the barrier and move the MFMAs around
         // them: sched_barrier pins every read behind the MFMA that frees its register)
 #define X3W_PIN() __builtin_amdgcn_sched_barrier(0)
