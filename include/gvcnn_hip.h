@@ -115,8 +115,11 @@ typedef struct gv_conv_desc {
                                   fp32 accumulation and epilogue, one rounding on store; math_mode ignored) */
     int32_t split_col;         /* GV_CONV_SPLIT: columns [0,split_col) -> y, [split_col,cout) -> y2 at
                                   column (c - split_col), pixel stride y2_ld; same scale/shift/act */
-    int32_t tile_cfg;          /* 0 = library heuristic; k >= 1 = tile configuration k-1 (a speed choice
-                                  only: every configuration returns bitwise the same result) */
+    int32_t tile_cfg;          /* 0 = library heuristic; k >= 1 = tile configuration k-1 (a speed choice only: the same
+                                  products, summed in the same order within a kernel family — bitwise the same result —
+                                  and in another k order across families (register-staged, LDS-DMA chunk-major, the
+                                  wave-specialised kernels): fp32-rounding-level differences, <= 6e-6 of the tensor's
+                                  largest value in the tests) */
     int32_t math_mode;         /* GV_MATH_*; w_packed must have been packed for the same mode */
     int32_t in_dilation;       /* 0/1: plain convolution.  2: the input tensor is read as if zero-dilated by 2
                                   (only even tap positions exist, at index/2) — the data gradient of a stride-2
