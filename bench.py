@@ -643,8 +643,9 @@ def main():
         pass
     elif world > 1:
         # N > 1: rank 0 measures, every rank installs rank 0's table — ONE tuning instead of N concurrent ones on one
-        # host (67 launches x 25+ candidates each), and identical kernels on every rank (tile choice never changes
-        # values, but ranks that pick different tiles add noise to the MAX-over-ranks step time)
+        # host (67 launches x 25+ candidates each), and identical kernels on every rank (tiles of different kernel families
+        # sum k in different orders — fp32-rounding-level differences — so one table also keeps the ranks' values identical
+        # where they must be; and ranks that pick different tiles add noise to the MAX-over-ranks step time)
         table = None
         if rank == 0:
             table = {k: v[0] for k, v in eng.plan.autotune(x.view(N * V, H, W, 3)).items()}

@@ -580,6 +580,24 @@ class BackbonePlan:
         _lib.check(self.lib.gv_plan_run_range(self._plan, first, count, ptrs, len(self._bufs),
                                               _stream_ptr(stream)), "gv_plan_run_range")
 
+    def declined_fused_pools(self):
+        """Names of the fused conv -> max-pool ops the library declines on this device (GV_E_UNSUPPORTED); any other error
+        raises.  One launch per such op on the plan's own (unbound) buffers: the values are irrelevant."""
+        fused = [i for i, op in enumerate(self.ops) if op["kind"] == "conv" and op.get("maxpool")]
+        if not fused:
+            return []
+        x = torch.zeros(self.nb * self.height * self.width * 3, dtype=torch.float32, device=self.weights.device)
+        declined = []
+        for i in fused:
+            rc = self.lib.gv_plan_run_range(self._plan, i, 1, self._ptr_table(x), len(self._bufs), _stream_ptr(None))
+            if rc == _lib.GV_E_UNSUPPORTED:
+                declined.append(self.ops[i]["name"])
+            else:
+                _lib.check(rc, "gv_plan_run_range(%s)" % self.ops[i]["name"])
+        torch.cuda.synchronize(self.weights.device)
+        self._ptrs[SLOT_INPUT] = 0
+        return declined
+
     def apply_tiles(self, table):
         """Install a previously measured {op name: tile configuration} table (no launches)."""
         for i, op in enumerate(self.ops):
@@ -589,8 +607,12 @@ class BackbonePlan:
 
     def autotune(self, x, iters=3, verbose=False, in_sequence=4):
         """Pick, per conv launch, the fastest tile configuration by timing each on this device with
-        the plan's own buffers (hipEvents on the launch stream).  A pure speed choice: the fp32 MFMA
-        chain sums k in the same order under every configuration, so results are bitwise unchanged.
+        the plan's own buffers (hipEvents on the launch stream).  A speed choice: tiles of ONE kernel family sum k in
+        the same order (bitwise the same result); tiles of different families (register-staged, LDS-DMA chunk-major,
+        wave-specialised) sum k in another order — fp32-rounding-level differences, <= 6e-6 of a tensor's largest value
+        (include/gvcnn_hip.h, tile_cfg).  Timing noise decides between near-equal tiles, so two processes that each
+        tune are NOT bit-reproducible against each other: bit reproducibility across runs needs a persisted table
+        (apply_tiles / bench.py --tile-cache); inside one process the installed table is fixed and runs repeat bitwise.
 
         Two passes.  (1) Every configuration of every launch as a WARM REPEAT of itself (gv_plan_time): cheap, but a
         repeated launch finds its input and its filter in the XCD's L2, which the launch inside the network does not —
@@ -972,4 +994,12 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
             raise ValueError("end point %r not in backbone %s" % (t, backbone))
         b.keep(b.end_points[t])
     b.raw_tap, b.final_tap = raw_tap, final_tap
-    return b.lower(device)
+    plan = b.lower(device)
+    # The builder decides a conv -> max-pool fusion from a Python copy of the kernels' predicates (fused_maxpool_ok) and
+    # never allocates the un-pooled tensor; the KERNEL is the authority.  On a device, ask it once (one launch of each
+    # fused op on the plan's own buffers): if it declines (GV_E_UNSUPPORTED), rebuild the plan with the two launches.
+    if b.fuse_maxpool and torch.device(device).type == "cuda" and plan.declined_fused_pools():
+        del plan
+        return make_plan(backbone, nb, height, width, device, raw_tap=raw_tap, final_tap=final_tap, dtype=dtype, math=math,
+                         lanes=lanes, p3=p3, defer_preact=defer_preact, fuse_maxpool=False)
+    return plan

@@ -297,13 +297,15 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_p3x8(const char* __restrict_
             // s / inv for eight values: the correctly rounded reciprocal once, then per value a product and one exact-remainder
             // correction (Markstein) — the correctly rounded quotient, i.e. the bits of the division, at 3 instead of ~10
             // instructions per value (the divisions were most of this kernel's vector instructions)
+            // — for a FINITE sum; a non-finite one keeps sum * rcp (inf stays inf, NaN stays NaN, as the division gives)
             const float rcp = 1.0f / inv;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float sum = col[q][j][e] + col[q][j + 1][e] + col[q][j + 2][e];
                 const float q0 = sum * rcp;
-                v[e] = __builtin_fmaf(__builtin_fmaf(-inv, q0, sum), rcp, q0);
+                const float qc = __builtin_fmaf(__builtin_fmaf(-inv, q0, sum), rcp, q0);
+                v[e] = __builtin_fabsf(q0) < __builtin_inff() ? qc : q0;   // (+-inf / NaN sums: the correction would turn inf into NaN)
                 if (relu) v[e] = fmaxf(v[e], 0.f);
             }
             const size_t pix = (size_t)(n * ih + oy) * iw + ox;

@@ -22,8 +22,26 @@ memory order).  Exchanges, both over RCCL (torch.distributed backend "nccl") on 
 xGMI is a point-to-point mesh: one all-gather of a large contiguous buffer per step (not one per
 view or per layer) keeps every link busy with a single big message.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# A ONE-rank process group normally exchanges nothing (every `world == 1` test below returns the local data).  With
+# GV_FORCE_COLLECTIVES=1 (or set_force_collectives(True)) a one-rank group still goes through every collective call —
+# all_gather_into_tensor, all_reduce, the point-to-point form — so that a single-GPU box can execute the exact RCCL code
+# path of the N > 1 job (tests/test_gpu_rccl_one_rank.py); the values are those of the local data by construction.
+_FORCE = os.environ.get("GV_FORCE_COLLECTIVES", "0") == "1"
+
+
+def set_force_collectives(on):
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def _solo(world):
+    """True when there is nobody to exchange with AND the collectives are not forced."""
+    return world == 1 and not _FORCE
 
 
 def shard_range(num_shapes_global, world_size, rank):
@@ -92,7 +110,7 @@ def _all_gather_flat(t_local, group=None, mode=None):
 def gather_scores(r_img_local, group=None, mode=None):
     """All-gather the local scorer responses [N_l*V] -> [P*N_l*V] (global shape-major order)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if _solo(world):
         return r_img_local
     return _all_gather_flat(r_img_local.reshape(-1), group, mode)
 
@@ -100,7 +118,7 @@ def gather_scores(r_img_local, group=None, mode=None):
 def gather_descriptors(F_local, group=None, mode=None):
     """All-gather final view descriptors [N_l, V, h, w, C] -> [P*N_l, V, h, w, C]."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if _solo(world):
         return F_local
     return _all_gather_flat(F_local, group, mode)
 
@@ -126,7 +144,8 @@ class ShardedGVCNN:
         self.gather_mode = gather_mode        # None: the process-wide default (set_gather_mode)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.overlap = bool(overlap) and exchange == "allgather" and self.world > 1
+        self.exchanging = dist.is_initialized() and not _solo(self.world)   # (a forced one-rank group exchanges too)
+        self.overlap = bool(overlap) and exchange == "allgather" and self.exchanging
         self._pending = None                  # (work handle | None, F_all, scheme, weight, scores) of the previous step
         self._slot = 0
         self._stage = [None, None]            # double-buffered copies of the local final descriptors / gathered tensors
@@ -178,7 +197,7 @@ class ShardedGVCNN:
             return eng.forward_per_shape(views_local, check)
         eng.run_backbone(views_local)
         eng.compute_scores()                                   # fills eng.r_img (local) + local scores
-        if self.world > 1:
+        if self.exchanging:
             r_all = gather_scores(eng.r_img, self.group, self.gather_mode)
             eng.finalize_scores(r_all, eng.N * self.world)     # same array, same order on every rank
         eng.assign_groups(check=False)
@@ -188,7 +207,7 @@ class ShardedGVCNN:
             if check:
                 eng.check_status()
             return self._finish(prev) if prev is not None else None
-        if self.exchange == "allgather" and self.world > 1:
+        if self.exchange == "allgather" and self.exchanging:
             F_all = gather_descriptors(eng.final_view_descriptors(), self.group, self.gather_mode)
             S, logits = eng.pool_fuse_classify(eng.scheme, eng.weight, F=F_all)
         else:
@@ -226,7 +245,7 @@ def gather_views(t_local, group=None, num_views=None):
     different numbers of views (view_shard_range): pass the global `num_views`; shards are padded to the largest one
     for the collective and trimmed afterwards."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized() or _solo(world):
         return t_local
     t_local = t_local.contiguous()
     n, v_l = t_local.shape[0], t_local.shape[1]
@@ -247,7 +266,7 @@ def allreduce_sum_bucketed(tensors, bucket_bytes=64 << 20, group=None):
     """Sum `tensors` (same dtype, modified in place) over the ranks in buckets of about bucket_bytes: the
     buckets are launched asynchronously back to back and waited for at the end."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 or not tensors:
+    if not dist.is_initialized() or _solo(world) or not tensors:
         return 0
     buckets, cur, cur_bytes = [], [], 0
     for t in tensors:
@@ -291,7 +310,8 @@ class OverlappedFlatAllReduce:
         self.sent_lo = self.hi                                # flat[sent_lo:hi] has been launched
         self.pending = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.sync_only = self.world > 1 and flat.is_cuda and dist.get_backend(group) == "gloo"
+        self.solo = not dist.is_initialized() or _solo(self.world)
+        self.sync_only = not self.solo and flat.is_cuda and dist.get_backend(group) == "gloo"
         self.launches = 0
 
     def _launch(self, lo, hi):
@@ -301,14 +321,14 @@ class OverlappedFlatAllReduce:
 
     def progress(self, lo):
         lo = max(0, min(int(lo), self.sent_lo))
-        if self.world == 1 or self.sync_only:
+        if self.solo or self.sync_only:
             return
         if self.sent_lo - lo >= self.bucket:
             self._launch(lo, self.sent_lo)
             self.sent_lo = lo
 
     def finish(self):
-        if self.world == 1:
+        if self.solo:
             return 0
         if self.sync_only:
             h = self.flat[:self.hi].cpu()
@@ -325,7 +345,7 @@ class OverlappedFlatAllReduce:
 
 def allreduce_sum_(t, group=None):
     """In-place sum over the ranks (a gloo group is fed through host memory)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _solo(dist.get_world_size(group)):
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":
         h = t.cpu()
@@ -407,6 +427,7 @@ class ShardedTrainGVCNN:
         self.overlap_grads = bool(overlap_grads)   # filter gradients are all-reduced while the backward pass still runs
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.solo = not dist.is_initialized() or _solo(self.world)
         if mode == "hybrid":
             assert group is None, "hybrid sharding builds its own sub-groups of the default group"
             self.vg, self.sh = hybrid_grid(engine.Vh, self.world)
@@ -422,7 +443,7 @@ class ShardedTrainGVCNN:
             assert (engine.view_offset, engine.view_offset + engine.V) == view_shard_range(engine.Vh, self.world, self.rank)
         else:
             assert engine.Vh == engine.V and engine.view_offset == 0
-            if self.world > 1:
+            if not self.solo:
                 engine.shape_world = self.world
                 engine.bn_sync = lambda accum: allreduce_sum_(accum, self.group)
 
@@ -431,7 +452,7 @@ class ShardedTrainGVCNN:
         are reduced WHILE the backward pass runs (OverlappedFlatAllReduce); None when the engine cannot report progress
         (branch lanes) or there is nobody to reduce with."""
         eng = self.eng
-        if self.world <= 1 or not self.overlap_grads or not hasattr(eng, "_flat_g") or not getattr(eng, "_g_monotone", False) \
+        if self.solo or not self.overlap_grads or not hasattr(eng, "_flat_g") or not getattr(eng, "_g_monotone", False) \
                 or getattr(eng, "_lane_streams", None) is not None:
             return None
         return OverlappedFlatAllReduce(eng._flat_g, eng._n_wd, self.bucket_bytes, group)
@@ -507,7 +528,7 @@ class ShardedTrainGVCNN:
     def train_step(self, views_local, labels, lr=1e-3, mu=0.9, weight_decay=0.0, check=False):
         """mode='views': views_local [N, V_l, H, W, 3] (this rank's views of every shape), labels [N] (same on all
         ranks).  mode='shapes': views_local [N_l, V, H, W, 3], labels [N_l] (this rank's shapes)."""
-        if self.world == 1:                               # nothing to exchange: the engine's own step
+        if self.solo:                                     # nothing to exchange: the engine's own step
             eng = self.eng
             eng.forward(views_local, labels, check=check)
             eng.backward()
@@ -546,7 +567,7 @@ class ShardedTrainGVCNN:
         from . import _lib
         from .model import _st
         eng = self.eng
-        if self.world == 1:                               # all views are local: the engine's own (one-launch) update
+        if self.solo:                                     # all views are local: the engine's own (one-launch) update
             return eng.update_moving_averages(decay)
         if decay is None:
             decay = 0.9997 if eng.backbone == "inception_v3" else 0.997

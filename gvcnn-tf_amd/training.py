@@ -755,7 +755,10 @@ class TrainGVCNN:
     def autotune(self, iters=2):
         """Measure, per convolution, the fastest tile configuration of the forward launch and of the data-gradient
         launch (hipEvents on the launch stream, this engine's own buffers; gradients buffers are scratch here).
-        A speed choice only.  forward() must have run once (buffers and packed filters exist)."""
+        A speed choice; values move at fp32-rounding level when the winner belongs to another kernel family (another k
+        summation order: include/gvcnn_hip.h, tile_cfg) — bit reproducibility ACROSS processes needs the same table
+        installed, inside one process the step repeats bitwise.  forward() must have run once (buffers and packed
+        filters exist)."""
         lib = self.lib
         if self._packed_dirty:
             self.repack()

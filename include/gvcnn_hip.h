@@ -64,7 +64,9 @@ extern "C" {
                                  GV_E_UNSUPPORTED otherwise, and the caller issues the two launches.  Also served for the
                                  strip kernel of the 3-channel stems (GV_CONV_X_F32, 3x3 or 7x7 / stride 2, cout 64, any
                                  activation), and on GV_F32 storage under GV_MATH_BF16X3 for the same halo class (fp32
-                                 input and output, a map wider than 96 pixels: csrc/conv_bf16s.hip) */
+                                 input and output) on the maps where the kernel's 30-pixel strip form wastes fewer columns
+                                 than its 16-pixel one: ceil(ow/16)*80 > ceil(ow/30)*128 — ow 17..30, 49..60, 65..90,
+                                 97..120, and every ow >= 129 (csrc/conv_bf16s.hip, bf16s_halo_pool_ok) */
 #define GV_CONV_MAXPOOL3S2_SAME 256 /* the same with TF's SAME padding on an even map (pads (0, 1): the last window is
                                  clipped; resnet_v2.py:181, conv1 -> pool1): y is [nb, oh/2, ow/2, cout].  Stem strip
                                  kernel only; odd oh / ow: GV_E_UNSUPPORTED */

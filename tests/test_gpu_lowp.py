@@ -323,6 +323,53 @@ def test_lp_ws_tiles_vs_oracle(k, padding, cin, cout, hw, ty):
         assert ran_k64
 
 
+WS_FAST_COMBOS = [
+    # (k, cin, cout, (ih, iw), nb): interior AND ragged tiles (M = nb*ih*iw is never a multiple of 256), cout % BN != 0
+    ((1, 7), 128, 192, (17, 17), 5), ((7, 1), 192, 200, (12, 12), 9), ((3, 3), 64, 96, (25, 25), 3),
+    ((1, 1), 192, 320, (12, 12), 7), ((5, 5), 64, 72, (13, 11), 6),
+]
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("k,cin,cout,hw,nb", WS_FAST_COMBOS)
+def test_lp_ws_tiles_plain_destination_fast_epilogue(k, cin, cout, hw, nb, ty, relu):
+    """The pipelined straight-line epilogue of conv_ws.hip (`ws_epilogue_fast`): what every interior tile of a plain
+    conv + BN (+ ReLU) launch takes — no residual, ONE destination — i.e. the tuned c3 / c5 plans' path.  Every
+    wave-specialised tile, ReLU on and off, M with interior and ragged tiles, cout not a multiple of the tile's width:
+    against the oracle, and bit for bit against the general staged epilogue (debug bit 1048576 forces it)."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(hash((k, cin, cout, hw)) % 1000)
+    ih, iw = hw
+    x = rnd(torch.randn(nb, ih, iw, cin, generator=g), td)
+    w = rnd(torch.randn(k[0], k[1], cin, cout, generator=g) * (1.0 / (k[0] * k[1] * cin) ** 0.5), td)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    pads = (tf_pads(ih, k[0], 1, "SAME"), tf_pads(iw, k[1], 1, "SAME"))
+    ref = oracle_conv(x, w, 1, "SAME", scale, shift, relu)
+    assert nb * ih * iw > 512 and (nb * ih * iw) % 256 != 0     # at least one interior 256- / 512-row tile and a ragged one
+    ran = 0
+    for tile in ws_tiles():
+        kw = dict(tile=tile, x_ld=cin + 16, x_off=8, y_ld=cout + 24, y_off=16)
+        try:
+            y = run_conv(x, w, 1, pads, (ih, iw), scale, shift, relu, ty, **kw)
+        except _lib.GvError:                    # (declined: 64-channel k-steps need cin % 64 == 0; LDS share)
+            assert tile in ws_tiles()[5:]
+            continue
+        ran += 1
+        try:
+            close(y, ref.numpy(), ulp)
+        except AssertionError as e:
+            raise AssertionError("wave-specialised tile %d (fast epilogue): %s" % (ws_tiles().index(tile), str(e)[:400]))
+        lib().gv_conv2d_set_debug(1048576)      # the general staged epilogue on the same accumulators
+        try:
+            y_gen = run_conv(x, w, 1, pads, (ih, iw), scale, shift, relu, ty, **kw)
+        finally:
+            lib().gv_conv2d_set_debug(0)
+        assert np.array_equal(y, y_gen), "tile %d: fast and general epilogue differ" % ws_tiles().index(tile)
+    assert ran >= 5
+
+
 @pytest.mark.parametrize("ty", ["bf16", "f16"])
 def test_lp_ws_tiles_split_and_dual_outputs(ty):
     """A fused sibling GEMM's two destinations (split on a chunk boundary, partial ReLU) and a second activation of the
@@ -674,6 +721,20 @@ def test_lp_pools(ty, c):
     # avg 3x3/1 SAME, valid-tap divisor (inception_v3.py:152)
     y = run_pool(x, 3, 1, (1, 1), (15, 14), _lib.GV_POOL_AVG, ty)
     close(y, OB.avg_pool2d_same3(x).numpy(), ulp)
+    # non-finite inputs (an f16 activation that overflowed): a window with +inf averages to +inf, one with -inf to -inf,
+    # one with a NaN (or with both infinities) to NaN — what the division gives; the reciprocal-and-correction form must
+    # not turn an infinity into a NaN
+    xi = x.clone()
+    xi[0, 4, 4, 0] = float("inf")
+    xi[0, 10, 9, 1] = float("-inf")
+    xi[1, 7, 7, 2] = float("nan")
+    yi = run_pool(xi, 3, 1, (1, 1), (15, 14), _lib.GV_POOL_AVG, ty)
+    ri = OB.avg_pool2d_same3(xi).numpy()
+    assert np.array_equal(np.isnan(yi), np.isnan(ri))
+    assert np.array_equal(np.isposinf(yi), np.isposinf(ri)) and np.array_equal(np.isneginf(yi), np.isneginf(ri))
+    assert np.isposinf(yi[0, 3:6, 3:6, 0]).all() and np.isneginf(yi[0, 9:12, 8:11, 1]).all() and np.isnan(yi[1, 6:9, 6:9, 2]).all()
+    fin = np.isfinite(ri)
+    close(np.where(fin, yi, 0.0), np.where(fin, ri, 0.0), ulp)
 
 
 @pytest.mark.parametrize("ty", ["bf16", "f16"])

@@ -197,7 +197,9 @@ def test_ws_strip_kernel_declines_what_it_cannot_run():
             assert ei.value.code == _lib.GV_E_UNSUPPORTED
 
 
-@pytest.mark.parametrize("ih,iw,pad,cout,nb", [(109, 109, 1, 64, 2), (111, 113, 0, 64, 1), (101, 97, 1, 32, 3), (30, 140, 1, 64, 2), (7, 99, 1, 64, 2)])
+@pytest.mark.parametrize("ih,iw,pad,cout,nb", [(109, 109, 1, 64, 2), (111, 113, 0, 64, 1), (101, 97, 1, 32, 3), (30, 140, 1, 64, 2), (7, 99, 1, 64, 2),
+                                               (25, 60, 1, 64, 2), (11, 30, 1, 64, 3), (25, 61, 1, 64, 1), (9, 96, 1, 64, 1), (12, 47, 1, 64, 1),
+                                               (9, 121, 1, 64, 1), (8, 85, 1, 64, 2)])
 def test_fp32_conv_and_max_pool_as_one_launch(ih, iw, pad, cout, nb):
     """GV_CONV_MAXPOOL3S2 on fp32 storage (three-plane math; csrc/conv_bf16s.hip, the halo kernel's 30-pixel strip form):
     Conv2d_2b_3x3 -> MaxPool_3a_3x3 (nets/inception_v3.py:111-113) in one launch equals the two launches BITWISE — pooled
@@ -227,7 +229,11 @@ def test_fp32_conv_and_max_pool_as_one_launch(ih, iw, pad, cout, nb):
     rc = lib().gv_conv2d_fwd(C.byref(desc(_lib.GV_CONV_RELU | _lib.GV_CONV_MAXPOOL3S2, y_ld)), xd.data_ptr(), wp.data_ptr(),
                              sc.data_ptr(), sh.data_ptr(), None, one.data_ptr() + 4 * y_off, None, None, None, st())
     torch.cuda.synchronize()
-    if ow <= 96:                                          # the 16-pixel strip form's maps: the caller keeps the two launches
+    # served where the 30-pixel strip form beats the 16-pixel one (the predicate of bf16s_halo_pool_ok / fused_maxpool_ok,
+    # include/gvcnn_hip.h GV_CONV_MAXPOOL3S2): ceil(ow/16)*80 > ceil(ow/30)*128 — every map wider than 96 pixels, and the
+    # narrow ranges 17..30, 49..60, 65..90 (not e.g. 61..64, 91..96, 121..128); elsewhere the caller keeps the two launches
+    served = -(-ow // 16) * 80 > -(-ow // 30) * 128
+    if not served:
         assert rc == _lib.GV_E_UNSUPPORTED and bool((one == -3.0).all())
         return
     _lib.check(rc, "fused")
@@ -464,3 +470,26 @@ def test_inception_plan_with_and_without_three_plane_intermediates(size, taps):
     for k in taps:
         d = ep[k].numpy()
         np.testing.assert_allclose(ends["all"][k].numpy(), d, rtol=1e-3, atol=1e-5 * float(np.abs(d).max()))
+
+
+def test_plan_rebuilds_when_the_library_declines_a_fused_max_pool(monkeypatch):
+    """The builder fuses Conv2d_2b_3x3 -> MaxPool_3a_3x3 on the word of a Python copy of the kernel's predicate
+    (BackbonePlan.fused_maxpool_ok) and never allocates the un-pooled tensor.  If the two ever disagree the KERNEL wins:
+    make_plan launches each fused op once, and a GV_E_UNSUPPORTED answer rebuilds the plan with the two launches.  Forced
+    here by a predicate that always says yes on a 61-pixel map (which the fp32 fused kernel declines): the plan that comes
+    back has the pool as its own op and gives the bits of the plan built without the fusion."""
+    nb, size = 2, 128                                      # Conv2d_2b: 61 x 61
+    x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    ref = backbones.make_plan("inception_v3", nb, size, size, torch.device(DEV), math="bf16x3", lanes=False, fuse_maxpool=False)
+    with monkeypatch.context() as m:
+        m.setattr(backbones.BackbonePlan, "fused_maxpool_ok", lambda self, *a, **k: True)
+        plan = backbones.make_plan("inception_v3", nb, size, size, torch.device(DEV), math="bf16x3", lanes=False)
+    assert not any(op.get("maxpool") for op in plan.ops if op["kind"] == "conv")
+    assert [op["name"] for op in plan.ops] == [op["name"] for op in ref.ops]
+    outs = []
+    for p in (plan, ref):
+        p.bind(gv.params.init_backbone_params(p.param_shapes(), seed=2, perturb_bn=True))
+        p.run(x)
+        torch.cuda.synchronize()
+        outs.append(p.view(p.end_points["Mixed_7c"]).clone())
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 1e-3

@@ -30,7 +30,7 @@ def probe(nb, hw, cin, cout, kh, kw, iters=10):
     M = nb * hw * hw
     fl = 2.0 * M * cout * kh * kw * cin
     out = []
-    for flags, xin, y, ncfg in ((1, x, y0, lib.gv_conv2d_num_tile_cfgs(X3) - 1), (1 | _lib.GV_CONV_X_P3, xp, y1, 8)):
+    for flags, xin, y, ncfg in ((1, x, y0, lib.gv_conv2d_special_tile_cfg(X3)), (1 | _lib.GV_CONV_X_P3, xp, y1, 8)):
         d = _lib.ConvDesc(nb, hw, hw, cin, cin, kh, kw, 1, kh // 2, kw // 2, hw, hw, cout, cout, 0, 0, flags, _lib.GV_F32,
                           0, 0, X3, 0, 0)
         best = (1e9, -1)
