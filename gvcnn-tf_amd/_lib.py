@@ -41,6 +41,10 @@ class ConvDesc(C.Structure):
         "math_mode", "in_dilation", "relu_cols", "y_step", "y_py", "y_px", "y_ih", "y_iw")]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("m", "d", "x_ld", "res_ld", "y_ld", "z_ld", "dtype", "flags", "tile_cfg")]
+
+
 class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32), ("k_off", C.c_int32),
@@ -142,6 +146,9 @@ SIGNATURES = {
     "gv_plan_num_ops": (C.c_int, [_P]),
     "gv_plan_add_conv": (C.c_int, [_P, C.POINTER(ConvDesc), _I, _L, _I, _L, _I, _L, _L, _I, _L, _I, _L,
                                    _I, _L, _L, _L]),
+    "gv_plan_add_chain": (C.c_int, [_P, C.POINTER(ChainDesc), _I, _L, _I, _L, _L, _I, _L, _L, _L, _L, _L, _L, _I, _L, _I, _L,
+                                    _I, _L]),
+    "gv_bottleneck_chain_fwd": (C.c_int, [C.POINTER(ChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gv_plan_set_conv_tile": (C.c_int, [_P, _I, _I]),
     "gv_plan_set_conv_xpre": (C.c_int, [_P, _I, _L, _L]),
     "gv_plan_set_schedule": (C.c_int, [_P, _I, _I, C.POINTER(_I), _I]),
@@ -161,6 +168,7 @@ SIGNATURES = {
 TUNING = {
     "gv_conv2d_set_tile_override": (None, [C.c_int]),
     "gv_conv2d_set_debug": (None, [C.c_int]),
+    "gv_bottleneck_chain_set_debug": (None, [C.c_int]),
     "gv_conv2d_num_tile_cfgs": (C.c_int, [C.c_int]),
     "gv_conv2d_special_tile_cfg": (C.c_int, [C.c_int]),
     "gv_conv2d_wgrad_set_v1": (None, [C.c_int]),

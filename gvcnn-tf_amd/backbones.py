@@ -22,6 +22,7 @@ Nothing here computes: it describes.  `BackbonePlan.bind()` uploads parameters a
 `BackbonePlan.run()` enqueues the launches through the C ABI.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -123,6 +124,9 @@ class BackbonePlan:
         # 16-bit storage: Conv2d_2b_3x3 -> MaxPool_3a_3x3 as one launch that writes only the pooled tensor
         # (GV_CONV_MAXPOOL3S2); off: the two launches (A/B switch)
         self.fuse_maxpool = dtype != _lib.GV_F32 or math_mode == _lib.GV_MATH_BF16X3
+        # 16-bit storage, inference plans (make_plan turns it on): conv3 of a ResNet-v2 unit + the next unit's
+        # pre-activation + conv1 as ONE launch (gv_bottleneck_chain_fwd) where the bottleneck depth is 64 or 128
+        self.fuse_chain = False
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -285,6 +289,31 @@ class BackbonePlan:
             return (out, DeferredPreact(out, s2, h2) if defer else y2)
         return out
 
+    def chain_ok(self, x):
+        """May conv3 over `x` (d channels -> 4d) and the next unit's preact + conv1 be one launch (csrc/conv_chain.hip)?"""
+        return bool(self.fuse_chain) and self.dtype != _lib.GV_F32 and x.c in (64, 128) and x.ld % 8 == 0 and not x.p3
+
+    def chain(self, x, scope3, shortcut, pre_scope, pre_eps, scope1, norm1):
+        """nets/resnet_v2.py:87-91 of one unit (conv3 1x1 + biases, `shortcut + residual`) and :75, :83-84 of the next
+        (preact BatchNorm + ReLU, conv1 1x1 + BatchNorm + ReLU) as ONE launch.  Returns (unit output [.., 4d], next unit's
+        conv1 output [.., d]).  Recorded as a conv op with a `chain` record: x, res, y as for conv3, y2 = the conv1 output."""
+        d, cout = x.c, 4 * x.c
+        assert (shortcut.nb, shortcut.h, shortcut.w, shortcut.c) == (x.nb, x.h, x.w, cout)
+        out = self.new_tensor(x.nb, x.h, x.w, cout)
+        z = self.new_tensor(x.nb, x.h, x.w, d)
+        w3_off = self._filter(scope3 + "/weights", 1, 1, d, cout)
+        so, ho = self._scale_shift("bias", scope3 + "/biases", cout)
+        ps, ph = self._scale_shift("bn", pre_scope, cout, pre_eps, True)
+        w1_off = self._filter(scope1 + "/weights", 1, 1, cout, d)
+        s1, h1 = self._scale_shift("bn", scope1 + "/BatchNorm", d, norm1[1], norm1[2])
+        self._record(dict(kind="conv", name=scope3 + "+" + scope1, x=x, y=out, y2=z, res=shortcut, w_off=w3_off,
+                          scale_off=so, shift_off=ho, scale2_off=ps, shift2_off=ph,
+                          chain=dict(w1_off=w1_off, scale1_off=s1, shift1_off=h1),
+                          kh=1, kw=1, stride=1, pad_t=0, pad_l=0, relu=False, split=0, cout=cout, xpre=None, maxpool=None,
+                          oh=x.h, ow=x.w, flops=2.0 * x.npix * (d * cout + cout * d),
+                          bytes=float(self.esz) * (x.npix * (d + cout + cout + d) + 2 * d * cout)))
+        return out, z
+
     def fused_maxpool_ok(self, x, cout, k, padding, stride=1, pool_padding="VALID"):
         """May `conv(x, ..., cout, k, stride, padding, maxpool=pool_padding)` be one launch?  The classes
         GV_CONV_MAXPOOL3S2 / _SAME serve (include/gvcnn_hip.h), 16-bit storage: 3x3 / stride 1 from 32 to 64 channels
@@ -402,7 +431,16 @@ class BackbonePlan:
             x, y = op["x"], op["y"]
             xs, xo = ref(x)
             ys, yo = ref(y)
-            if op["kind"] == "conv":
+            if op["kind"] == "conv" and op.get("chain"):
+                ch, res, y2 = op["chain"], op["res"], op["y2"]
+                d = _lib.ChainDesc(x.npix, x.c, x.ld, res.ld, y.ld, y2.ld, self.dtype, _lib.GV_CONV_RELU2, 0)
+                rs, ro = ref(res)
+                y2s, y2o = ref(y2)
+                _lib.check(lib.gv_plan_add_chain(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"] * wmul,
+                                                 ch["w1_off"] * wmul, SLOT_SS, op["scale_off"], op["shift_off"],
+                                                 op["scale2_off"], op["shift2_off"], ch["scale1_off"], ch["shift1_off"],
+                                                 rs, ro, ys, yo, y2s, y2o), "gv_plan_add_chain(%s)" % op["name"])
+            elif op["kind"] == "conv":
                 y2, res = op["y2"], op["res"]
                 split = op["split"]
                 flags = _lib.GV_CONV_RELU if op["relu"] else 0
@@ -581,9 +619,9 @@ class BackbonePlan:
                                               _stream_ptr(stream)), "gv_plan_run_range")
 
     def declined_fused_pools(self):
-        """Names of the fused conv -> max-pool ops the library declines on this device (GV_E_UNSUPPORTED); any other error
-        raises.  One launch per such op on the plan's own (unbound) buffers: the values are irrelevant."""
-        fused = [i for i, op in enumerate(self.ops) if op["kind"] == "conv" and op.get("maxpool")]
+        """Names of the fused ops (conv -> max-pool, bottleneck chain) the library declines on this device
+        (GV_E_UNSUPPORTED); any other error raises.  One launch per such op on the plan's own (unbound) buffers: the values are irrelevant."""
+        fused = [i for i, op in enumerate(self.ops) if op["kind"] == "conv" and (op.get("maxpool") or op.get("chain"))]
         if not fused:
             return []
         x = torch.zeros(self.nb * self.height * self.width * 3, dtype=torch.float32, device=self.weights.device)
@@ -601,7 +639,7 @@ class BackbonePlan:
     def apply_tiles(self, table):
         """Install a previously measured {op name: tile configuration} table (no launches)."""
         for i, op in enumerate(self.ops):
-            if op["kind"] == "conv" and op["name"] in table and not op.get("maxpool"):   # (one kernel serves that form)
+            if op["kind"] == "conv" and op["name"] in table and not op.get("maxpool") and not op.get("chain"):   # (one kernel serves those forms)
                 op["tile"] = int(table[op["name"]]) + 1
                 _lib.check(self.lib.gv_plan_set_conv_tile(self._plan, i, op["tile"]), "gv_plan_set_conv_tile")
 
@@ -630,7 +668,7 @@ class BackbonePlan:
         chosen, cands = {}, {}
         try:
             for i, op in enumerate(self.ops):
-                if op["kind"] != "conv":
+                if op["kind"] != "conv" or op.get("chain"):
                     continue
                 ncfg = ncfg_p3 if op["x"].p3 else ncfg_plan
                 timed = []
@@ -908,6 +946,7 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
             units.append((bname, base, u, n_units, bstride if u == n_units - 1 else 1))
     first_sc = "%s/%s/unit_1/bottleneck_v2" % (scope, units[0][0])
     preact = b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact")
+    c1_ready = None                                     # this unit's conv1 output, when the previous unit's chain launch made it
     for i, (bname, base, u, n_units, stride) in enumerate(units):
         sc = "%s/%s/unit_%d/bottleneck_v2" % (scope, bname, u + 1)
         depth, depth_in = base * 4, net.c
@@ -915,7 +954,10 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
             shortcut = net if stride == 1 else b.pool(net, 1, stride, "VALID", MAX, name=sc + "/shortcut")
         else:                                                                      # resnet_v2.py:79-81
             shortcut = b.conv(preact, sc + "/shortcut", depth, 1, stride, "VALID", norm=None, relu=False)
-        r = b.conv(preact, sc + "/conv1", base, 1, 1, "SAME", norm=BN, relu=True)  # :83-84
+        if c1_ready is not None:
+            r, c1_ready = c1_ready, None
+        else:
+            r = b.conv(preact, sc + "/conv1", base, 1, 1, "SAME", norm=BN, relu=True)  # :83-84
         pad = "SAME" if stride == 1 else ((1, 1), (1, 1))                          # resnet_utils.py:94-105
         r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
         nxt = None
@@ -923,6 +965,18 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         if i + 1 < len(units):
             nb_, nbase, nu, _, _ = units[i + 1]
             nxt = ("%s/%s/unit_%d/bottleneck_v2/preact" % (scope, nb_, nu + 1), RESNET_BN_EPS)
+            # conv3 + the next unit's preact + conv1 as ONE launch (csrc/conv_chain.hip): the next unit keeps this depth
+            # (identity shortcut, conv1 the pre-activation's only reader) and the bottleneck depth is one the kernel serves
+            if nbase * 4 == depth and getattr(b, "fuse_chain", False) and b.chain_ok(r):
+                nsc = "%s/%s/unit_%d/bottleneck_v2" % (scope, nb_, nu + 1)
+                net, c1_ready = b.chain(r, sc + "/conv3", shortcut, nxt[0], nxt[1], nsc + "/conv1", BN)
+                preact = None
+                b.end_points[sc] = net
+                if u == n_units - 1:
+                    b.end_points["%s/%s" % (scope, bname)] = net
+                    if "%s/%s" % (scope, bname) in keep:
+                        b.keep(net)
+                continue
             # the next unit keeps this depth (identity shortcut): its conv1 is the pre-activation's only reader.  Not in
             # block4 (2048 channels over 7x7 maps): its conv3 is no longer HBM-bound and the conv1 loses more on the
             # register-staged loader than the conv3 gains (measured: gpurun_out/r2/lt_res_xpre.txt vs lt_res_stored.txt)
@@ -962,7 +1016,7 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True):
+              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True, fuse_chain=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere.
@@ -974,6 +1028,8 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     b.use_p3 = b.use_p3 and bool(p3)
     b.defer_preact = b.defer_preact and bool(defer_preact)      # (A/B switch: False = every pre-activation stored)
     b.fuse_maxpool = b.fuse_maxpool and bool(fuse_maxpool)      # (A/B switch: False = Conv2d_2b and MaxPool_3a as two launches)
+    # conv3 + next preact + conv1 as one launch (ResNet-v2 blocks 1 and 2 on 16-bit storage); GV_NO_CHAIN=1: whole-plan A/B
+    b.fuse_chain = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_CHAIN") is None
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:
@@ -998,8 +1054,8 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     # The builder decides a conv -> max-pool fusion from a Python copy of the kernels' predicates (fused_maxpool_ok) and
     # never allocates the un-pooled tensor; the KERNEL is the authority.  On a device, ask it once (one launch of each
     # fused op on the plan's own buffers): if it declines (GV_E_UNSUPPORTED), rebuild the plan with the two launches.
-    if b.fuse_maxpool and torch.device(device).type == "cuda" and plan.declined_fused_pools():
+    if (b.fuse_maxpool or b.fuse_chain) and torch.device(device).type == "cuda" and plan.declined_fused_pools():
         del plan
         return make_plan(backbone, nb, height, width, device, raw_tap=raw_tap, final_tap=final_tap, dtype=dtype, math=math,
-                         lanes=lanes, p3=p3, defer_preact=defer_preact, fuse_maxpool=False)
+                         lanes=lanes, p3=p3, defer_preact=defer_preact, fuse_maxpool=False, fuse_chain=False)
     return plan

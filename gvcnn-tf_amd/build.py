@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 PT = os.environ.get("GV_PHASE_TIMES") == "1"
 LIB = os.path.join(HERE, "libgvcnn_hip_pt.so" if PT else "libgvcnn_hip.so")
 BUILD = "build_pt" if PT else "build"
-SOURCES = ["conv_igemm.hip", "conv_bf16s.hip", "conv_lp.hip", "conv_dma.hip", "conv_ws.hip", "conv_ws_x3.hip", "pool.hip", "lowp.hip", "grouping.hip", "plan.hip", "train.hip", "train_lp.hip", "wgrad_dma.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bf16s.hip", "conv_lp.hip", "conv_dma.hip", "conv_ws.hip", "conv_ws_x3.hip", "conv_chain.hip", "pool.hip", "lowp.hip", "grouping.hip", "plan.hip", "train.hip", "train_lp.hip", "wgrad_dma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + (["-DGV_PHASE_TIMES"] if PT else [])
 

@@ -215,6 +215,33 @@ int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const float* xscale
                        const void* w_packed, const float* scale, const float* shift, const void* residual,
                        void* y, void* y2, const float* scale2, const float* shift2, void* stream);
 
+/* ---- bottleneck chain ----------------------------------------------------
+ * The TAIL of one ResNet-v2 bottleneck unit and the HEAD of the next as ONE launch (csrc/conv_chain.hip):
+ *   y = conv1x1(x, w3) * scale3[c] + shift3[c] + shortcut          nets/resnet_v2.py:87-91 of unit u (d -> 4d channels,
+ *                                                                  normalizer_fn=None: scale3 = 1, shift3 = biases)
+ *   z = relu( conv1x1( relu(y * pre_scale + pre_shift), w1 ) * scale1 + shift1 )
+ *                                                                  nets/resnet_v2.py:75 (`preact`) and :83-84 (conv1 +
+ *                                                                  BatchNorm + ReLU) of unit u+1 (4d -> d channels)
+ * for two consecutive units of one block, where the next unit's shortcut is the identity (resnet_v2.py:76-77) and conv1 is
+ * the pre-activation's only reader.  y is written once and never read back by conv1; the pre-activation is applied to the
+ * ROUNDED y, as gv_conv2d_fwd_xpre's loader does — the results are those of gv_conv2d_fwd (y) followed by
+ * gv_conv2d_fwd_xpre (z), bit for bit.  x [m, d], shortcut / y [m, 4d], z [m, d] with pixel strides *_ld (multiples of 8
+ * elements, 16-byte aligned bases); w3_packed [4d][d], w1_packed [d][4d] as gv_pack_filter_hwio writes them for the dtype.
+ * 16-bit storage, d = 64 or 128 (the HBM-bound blocks 1 and 2 of ResNet-v2-50): anything else GV_E_UNSUPPORTED and the
+ * caller issues the two launches. */
+typedef struct gv_chain_desc {
+    int32_t m;                 /* rows = nb * oh * ow (all three tensors share the pixel grid) */
+    int32_t d;                 /* bottleneck depth */
+    int32_t x_ld, res_ld, y_ld, z_ld;
+    int32_t dtype;             /* GV_BF16 | GV_F16 */
+    int32_t flags;             /* GV_CONV_RELU2: ReLU on z */
+    int32_t tile_cfg;          /* 0 (reserved) */
+} gv_chain_desc;
+int gv_bottleneck_chain_fwd(const gv_chain_desc* d, const void* x, const void* w3_packed, const float* scale3,
+                            const float* shift3, const void* shortcut, void* y, const float* pre_scale,
+                            const float* pre_shift, const void* w1_packed, const float* scale1, const float* shift1,
+                            void* z, void* stream);
+
 /* ---- pooling -------------------------------------------------------------
  * slim.max_pool2d / slim.avg_pool2d: nets/inception_v3.py:112,127,152,219,355,...;
  * nets/resnet_v2.py:181 (3x3/2 SAME, pad (0,1)); nets/resnet_utils.py:64-67
@@ -554,6 +581,12 @@ int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d,
 int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg);
 /* Conv op `op_index` runs as gv_conv2d_fwd_xpre: xscale / xshift at these fp32 offsets of the op's scale/shift slot. */
 int gv_plan_set_conv_xpre(gv_plan* p, int32_t op_index, int64_t xscale_off, int64_t xshift_off);
+/* gv_bottleneck_chain_fwd as a plan op.  Offsets into the weight slot are in `dtype` elements, into the scale/shift slot in
+ * fp32 elements: conv3's filter / scale / shift, the pre-activation's scale / shift, conv1's filter / scale / shift. */
+int gv_plan_add_chain(gv_plan* p, const gv_chain_desc* d, int32_t x_slot, int64_t x_off, int32_t w_slot, int64_t w3_off,
+                      int64_t w1_off, int32_t ss_slot, int64_t scale3_off, int64_t shift3_off, int64_t pre_scale_off,
+                      int64_t pre_shift_off, int64_t scale1_off, int64_t shift1_off, int32_t res_slot, int64_t res_off,
+                      int32_t y_slot, int64_t y_off, int32_t z_slot, int64_t z_off);
 /* Branch-level concurrency: put op `op_index` on launch lane `lane` (0 = the caller's stream, 1..7 =
  * plan-owned streams) and name the EARLIER ops it must wait for (producers of its inputs, and ops
  * still using a buffer it overwrites).  A whole-plan run then forks the lanes off `stream` and joins

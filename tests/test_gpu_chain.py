@@ -1,0 +1,130 @@
+"""gv_bottleneck_chain_fwd (csrc/conv_chain.hip): conv3 of a ResNet-v2 bottleneck unit (+ biases + shortcut,
+nets/resnet_v2.py:87-91), the next unit's pre-activation (:75) and its conv1 + BatchNorm + ReLU (:83-84) as ONE launch —
+against the CPU oracle at the storage type's rounding, and BIT FOR BIT against the two launches it replaces
+(gv_conv2d_fwd, then gv_conv2d_fwd_xpre), directly and inside the whole ResNet-v2-50 plan."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gvcnn_tf_amd as gv                      # noqa: E402
+from gvcnn_tf_amd import _lib, backbones        # noqa: E402
+from oracle import backbone as OB               # noqa: E402
+
+from test_gpu_lowp import DEV, TYPES, close, lib, pack, rnd, st      # noqa: E402
+
+
+def run_chain(x, w3, b3, res, ps, ph, w1, s1, h1, ty, x_ld=None, res_ld=None, y_ld=None, z_ld=None, expect=None):
+    code, td, _ = TYPES[ty]
+    M, d = x.shape
+    n1 = 4 * d
+    x_ld, res_ld, y_ld, z_ld = x_ld or d, res_ld or n1, y_ld or n1, z_ld or d
+
+    def padded(t, ld, fill):
+        b = torch.full((t.shape[0], ld), fill)
+        b[:, :t.shape[1]] = t
+        return b.to(td).to(DEV)
+    xd, rd = padded(x, x_ld, 7.0), padded(res, res_ld, 5.0)
+    yd = torch.full((M, y_ld), -77.0, dtype=td, device=DEV)
+    zd = torch.full((M, z_ld), -55.0, dtype=td, device=DEV)
+    w3p, w1p = pack(w3.view(1, 1, d, n1), code), pack(w1.view(1, 1, n1, d), code)
+    f = lambda t: t.to(DEV).float().contiguous()
+    one, b3d, psd, phd, s1d, h1d = f(torch.ones(n1)), f(b3), f(ps), f(ph), f(s1), f(h1)
+    desc = _lib.ChainDesc(M, d, x_ld, res_ld, y_ld, z_ld, code, _lib.GV_CONV_RELU2, 0)
+    rc = lib().gv_bottleneck_chain_fwd(C.byref(desc), xd.data_ptr(), w3p.data_ptr(), one.data_ptr(), b3d.data_ptr(), rd.data_ptr(),
+                                       yd.data_ptr(), psd.data_ptr(), phd.data_ptr(), w1p.data_ptr(), s1d.data_ptr(),
+                                       h1d.data_ptr(), zd.data_ptr(), st())
+    torch.cuda.synchronize()
+    if expect is not None:
+        assert rc == expect, rc
+        assert bool((yd.float() == -77.0).all()) and bool((zd.float() == -55.0).all())
+        return None
+    _lib.check(rc, "gv_bottleneck_chain_fwd")
+    assert bool((yd[:, n1:].float() == -77.0).all()) and bool((zd[:, d:].float() == -55.0).all())     # padding untouched
+    # the two launches it replaces, on the same device operands
+    y2 = torch.full((M, y_ld), -77.0, dtype=td, device=DEV)
+    z2 = torch.full((M, z_ld), -55.0, dtype=td, device=DEV)
+    d3 = _lib.ConvDesc(1, M, 1, d, x_ld, 1, 1, 1, 0, 0, M, 1, n1, y_ld, res_ld, 0, 0, code, 0, 0, 0, 0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(d3), xd.data_ptr(), w3p.data_ptr(), one.data_ptr(), b3d.data_ptr(), rd.data_ptr(),
+                                   y2.data_ptr(), None, None, None, st()), "conv3")
+    d1 = _lib.ConvDesc(1, M, 1, n1, y_ld, 1, 1, 1, 0, 0, M, 1, d, z_ld, 0, 0, _lib.GV_CONV_RELU, code, 0, 0, 0, 0)
+    _lib.check(lib().gv_conv2d_fwd_xpre(C.byref(d1), y2.data_ptr(), psd.data_ptr(), phd.data_ptr(), w1p.data_ptr(), s1d.data_ptr(),
+                                        h1d.data_ptr(), None, z2.data_ptr(), None, None, None, st()), "conv1 (xpre)")
+    torch.cuda.synchronize()
+    return yd[:, :n1].float().cpu(), zd[:, :d].float().cpu(), y2[:, :n1].float().cpu(), z2[:, :d].float().cpu()
+
+
+def operands(M, d, td, seed):
+    g = torch.Generator().manual_seed(seed)
+    n1 = 4 * d
+    x = rnd(torch.relu(torch.randn(M, d, generator=g)), td)                    # conv2's output is post-ReLU
+    w3 = rnd(torch.randn(d, n1, generator=g) * (1.0 / d) ** 0.5, td)
+    b3 = torch.randn(n1, generator=g) * 0.1
+    res = rnd(torch.randn(M, n1, generator=g), td)
+    ps, ph = torch.rand(n1, generator=g) + 0.5, torch.randn(n1, generator=g) * 0.2
+    w1 = rnd(torch.randn(n1, d, generator=g) * (1.0 / n1) ** 0.5, td)
+    s1, h1 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    return x, w3, b3, res, ps, ph, w1, s1, h1
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("d,M", [(64, 128 * 5), (64, 1000), (64, 37), (128, 128 * 3 + 96), (128, 1)])
+def test_chain_vs_oracle_and_bitwise_vs_the_two_launches(d, M, ty):
+    """Whole and ragged 128-row tiles, a single row, a tile's last wave without rows; channel-slice operands (pixel strides
+    wider than the tensors, padding untouched)."""
+    code, td, ulp = TYPES[ty]
+    x, w3, b3, res, ps, ph, w1, s1, h1 = operands(M, d, td, seed=d + M)
+    y, z, y2, z2 = run_chain(x, w3, b3, res, ps, ph, w1, s1, h1, ty, x_ld=d + 8, res_ld=4 * d + 16, y_ld=4 * d + 24, z_ld=d + 8)
+    assert torch.equal(y, y2), "unit output differs from gv_conv2d_fwd's"
+    assert torch.equal(z, z2), "next conv1 differs from gv_conv2d_fwd_xpre's"
+    # oracle: fp32 arithmetic on the rounded operands; y rounded once, the pre-activation of the ROUNDED y rounded once
+    yo = x @ w3 + b3 + res
+    close(y, yo.numpy(), ulp)
+    pre = rnd(torch.relu(y * ps + ph), td)                  # (from the device's y: the chain's second half on its own)
+    zo = torch.relu((pre @ w1) * s1 + h1)
+    close(z, zo.numpy(), ulp)
+    # ... and end to end against the oracle's ops with its own y (two roundings deep)
+    pre_o = rnd(torch.relu(rnd(yo, td) * ps + ph), td)
+    close(z, torch.relu((pre_o @ w1) * s1 + h1).numpy(), 4 * ulp, extra=4e-3)
+
+
+def test_chain_declines_what_it_does_not_serve():
+    U = _lib.GV_E_UNSUPPORTED
+    ops = operands(64, 256, torch.bfloat16, seed=1)
+    run_chain(*ops, "bf16", expect=U)                       # depth 256: the caller keeps the two launches
+    ops = operands(64, 64, torch.bfloat16, seed=2)
+    run_chain(*ops, "bf16", x_ld=68, expect=U)              # pixels not 16-byte aligned
+    d = _lib.ChainDesc(64, 64, 64, 256, 256, 64, _lib.GV_F32, 0, 0)
+    assert lib().gv_bottleneck_chain_fwd(C.byref(d), 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, None) == U
+    d = _lib.ChainDesc(64, 64, 32, 256, 256, 64, _lib.GV_BF16, 0, 0)          # x_ld < d
+    assert lib().gv_bottleneck_chain_fwd(C.byref(d), 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, None) == _lib.GV_E_BADARG
+    assert lib().gv_bottleneck_chain_fwd(None, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, None) == _lib.GV_E_BADARG
+
+
+@pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])
+def test_resnet_plan_with_and_without_the_chain(ty, size, nb):
+    """The whole 16-bit ResNet-v2-50 plan with the five chain launches of blocks 1 and 2 equals the plan with the separate
+    conv3 / conv1 launches bit for bit at block3 / block4 (the taps of nets/model.py:144,149), and matches the oracle."""
+    x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5)
+    outs, nops = [], []
+    for fuse in (True, False):
+        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse)
+        P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
+        plan.bind(P)
+        plan.run(x.to(DEV))
+        torch.cuda.synchronize()
+        # (only the tapped end points are persistent: block1 / block2 buffers are re-used by later layers)
+        outs.append({k: plan.view(plan.end_points[k]).clone() for k in ("resnet_v2_50/block3", "resnet_v2_50/block4")})
+        nops.append(len(plan.ops))
+        assert sum(1 for op in plan.ops if op.get("chain")) == (5 if fuse else 0)
+    assert nops[0] == nops[1] - 5
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    _, ep = OB.resnet_v2_50(x[:1], P)
+    ref = ep["resnet_v2_50/block4"][0].numpy()
+    got = outs[0]["resnet_v2_50/block4"][0].float().cpu().numpy()
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    assert rel < (3e-2 if ty == "bf16" else 4e-3), rel

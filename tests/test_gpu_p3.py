@@ -482,7 +482,7 @@ def test_plan_rebuilds_when_the_library_declines_a_fused_max_pool(monkeypatch):
     x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
     ref = backbones.make_plan("inception_v3", nb, size, size, torch.device(DEV), math="bf16x3", lanes=False, fuse_maxpool=False)
     with monkeypatch.context() as m:
-        m.setattr(backbones.BackbonePlan, "fused_maxpool_ok", lambda self, *a, **k: True)
+        m.setattr(backbones.BackbonePlan, "fused_maxpool_ok", lambda self, *a, **k: bool(self.fuse_maxpool))   # "yes" whenever fusion is on
         plan = backbones.make_plan("inception_v3", nb, size, size, torch.device(DEV), math="bf16x3", lanes=False)
     assert not any(op.get("maxpool") for op in plan.ops if op["kind"] == "conv")
     assert [op["name"] for op in plan.ops] == [op["name"] for op in ref.ops]

@@ -180,7 +180,7 @@ def test_resnet_16bit_plan_defers_the_preactivation_of_identity_units():
     """16-bit storage: conv3 of a unit followed by an identity unit writes the sum only, and that unit's conv1 carries
     the folded pre-activation BatchNorm for its loader (the 10 identity boundaries of block1-block3; the block boundaries,
     where the projection shortcut reads the pre-activation too, and block4 keep the stored second output).  fp32 storage: the stored form everywhere."""
-    p = backbones.make_plan("resnet_v2_50", 2, 64, 64, torch.device("cpu"), dtype="bf16")
+    p = backbones.make_plan("resnet_v2_50", 2, 64, 64, torch.device("cpu"), dtype="bf16", fuse_chain=False)
     convs = [op for op in p.ops if op["kind"] == "conv"]
     pre = [op for op in convs if op.get("xpre") is not None]
     assert len(pre) == 10 and all(op["name"].endswith("/conv1") and op["kh"] == 1 and op["pad_t"] == 0 for op in pre)
@@ -238,3 +238,32 @@ def test_16bit_plans_issue_conv_and_max_pool_as_one_launch(dtype):
     assert "MaxPool_3a_3x3" in [o["name"] for o in off3.ops] and off3.param_shapes() == x3.param_shapes()
     r3 = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, math="bf16x3")
     assert not any(o.get("maxpool") for o in r3.ops if o["kind"] == "conv")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
+    """gv_bottleneck_chain_fwd at plan level (host logic only): inside blocks 1 and 2 (bottleneck depth 64 / 128) conv3 of a
+    unit, the next unit's pre-activation and its conv1 (nets/resnet_v2.py:87-91, :75, :83-84) are ONE op — 2 + 3 of them,
+    five launches fewer; the deeper blocks keep the deferred pre-activation; same variables, same arithmetic work, same
+    end points; fp32 storage and fuse_chain=False keep the separate launches."""
+    cpu = torch.device("cpu")
+    p = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype)
+    off = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_chain=False)
+    chains = [op for op in p.ops if op.get("chain")]
+    assert [op["x"].c for op in chains] == [64, 64, 128, 128, 128]
+    assert len(p.ops) == len(off.ops) - 5 and not any(op.get("chain") for op in off.ops)
+    for op in chains:
+        a, b = op["name"].split("+")
+        assert a.endswith("/conv3") and b.endswith("/conv1") and a.split("/")[1] == b.split("/")[1]      # same block
+        assert int(b.split("/unit_")[1].split("/")[0]) == int(a.split("/unit_")[1].split("/")[0]) + 1      # consecutive units
+        assert op["y"].c == 4 * op["x"].c and op["y2"].c == op["x"].c and op["res"].c == op["y"].c
+        nxt = next(o for o in p.ops if o["name"] == b.replace("/conv1", "/conv2"))
+        assert nxt["x"] is op["y2"] and p.ops.index(nxt) > p.ops.index(op)                                # conv2 reads the chain's z
+        assert not any(o["name"] == b for o in p.ops)                                                     # no separate conv1
+    pre = [op for op in p.ops if op["kind"] == "conv" and op.get("xpre") is not None]
+    assert len(pre) == 5 and all(op["x"].c == 1024 for op in pre)                                         # block3's identity units
+    assert p.param_shapes() == off.param_shapes()
+    assert abs(p.total_flops - off.total_flops) < 1e-6 * off.total_flops
+    assert set(p.end_points) == set(off.end_points)
+    f32 = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu)
+    assert not any(op.get("chain") for op in f32.ops)

@@ -30,15 +30,16 @@ plan.autotune(x)
 warm = [min(plan.time_range(x, i, 1, 10), plan.time_range(x, i, 1, 10)) for i in range(len(plan.ops))]
 seq = [min(p, q) for p, q in zip(plan.time_each(x, 10), plan.time_each(x, 10))]
 tw = ts = 0.0
-print("%-58s %9s %5s %5s | %4s | %8s %8s %6s | TF/s warm / in sequence" % ("op", "M", "N", "K", "tile", "warm ms", "seq ms", "+us"))
+print("%-58s %9s %5s %5s | %4s | %8s %8s %6s | TF/s warm / in sequence | GB/s (algorithmic, in sequence)" % ("op", "M", "N", "K", "tile", "warm ms", "seq ms", "+us"))
 for i, op in enumerate(plan.ops):
     if op["kind"] != "conv":
         continue
     xx, y = op["x"], op["y"]
     tw += warm[i]
     ts += seq[i]
-    print("%-58s %9d %5d %5d | %4d | %8.4f %8.4f %6.1f | %4.0f / %4.0f" % (op["name"][-58:], y.npix, y.c, op["kh"] * op["kw"] * xx.c,
-          int(op.get("tile", 0)) - 1, warm[i], seq[i], (seq[i] - warm[i]) * 1e3, op["flops"] / warm[i] / 1e9, op["flops"] / seq[i] / 1e9))
+    print("%-58s %9d %5d %5d | %4d | %8.4f %8.4f %6.1f | %4.0f / %4.0f | %5.0f" % (op["name"][-58:], y.npix, y.c, op["kh"] * op["kw"] * xx.c,
+          int(op.get("tile", 0)) - 1, warm[i], seq[i], (seq[i] - warm[i]) * 1e3, op["flops"] / warm[i] / 1e9, op["flops"] / seq[i] / 1e9,
+          op["bytes"] / seq[i] / 1e6))
 fl = sum(op["flops"] for op in plan.ops if op["kind"] == "conv")
 nconv = sum(1 for op in plan.ops if op["kind"] == "conv")
 other_w = sum(w for w, op in zip(warm, plan.ops) if op["kind"] != "conv")
