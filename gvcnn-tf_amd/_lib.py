@@ -45,6 +45,10 @@ class ChainDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("m", "d", "x_ld", "res_ld", "y_ld", "z_ld", "dtype", "flags", "tile_cfg")]
 
 
+class UnitDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nb", "ih", "iw", "d", "x_ld", "res_ld", "y_ld", "z_ld", "dtype", "flags", "tile_cfg")]
+
+
 class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("kh", C.c_int32), ("kw", C.c_int32), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("flipped", C.c_int32), ("first_block", C.c_int32), ("k_off", C.c_int32),
@@ -149,6 +153,9 @@ SIGNATURES = {
     "gv_plan_add_chain": (C.c_int, [_P, C.POINTER(ChainDesc), _I, _L, _I, _L, _L, _I, _L, _L, _L, _L, _L, _L, _I, _L, _I, _L,
                                     _I, _L]),
     "gv_bottleneck_chain_fwd": (C.c_int, [C.POINTER(ChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gv_plan_add_unit": (C.c_int, [_P, C.POINTER(UnitDesc), _I, _L, _I, _L, _L, _L, _I, _L, _L, _L, _L, _L, _L, _L, _L, _I, _L,
+                                   _I, _L, _I, _L]),
+    "gv_bottleneck_unit_fwd": (C.c_int, [C.POINTER(UnitDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gv_plan_set_conv_tile": (C.c_int, [_P, _I, _I]),
     "gv_plan_set_conv_xpre": (C.c_int, [_P, _I, _L, _L]),
     "gv_plan_set_schedule": (C.c_int, [_P, _I, _I, C.POINTER(_I), _I]),

@@ -127,6 +127,8 @@ class BackbonePlan:
         # 16-bit storage, inference plans (make_plan turns it on): conv3 of a ResNet-v2 unit + the next unit's
         # pre-activation + conv1 as ONE launch (gv_bottleneck_chain_fwd) where the bottleneck depth is 64 or 128
         self.fuse_chain = False
+        # ... and the unit's conv2 (3x3 / 1) in front of it: one launch per bottleneck unit (gv_bottleneck_unit_fwd)
+        self.fuse_unit = False
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -293,6 +295,20 @@ class BackbonePlan:
         """May conv3 over `x` (d channels -> 4d) and the next unit's preact + conv1 be one launch (csrc/conv_chain.hip)?"""
         return bool(self.fuse_chain) and self.dtype != _lib.GV_F32 and x.c in (64, 128) and x.ld % 8 == 0 and not x.p3
 
+    def unit(self, x, scope2, norm2, scope3, shortcut, pre_scope, pre_eps, scope1, norm1):
+        """chain() with the unit's conv2 (3x3 / 1 SAME + BatchNorm + ReLU, nets/resnet_v2.py:85-86) in front: x is the unit's
+        conv1 output; conv2's output is never stored.  Recorded like a chain op, `chain["front"]` holds conv2's operands."""
+        d, cout = x.c, 4 * x.c
+        out, z = self.chain(x, scope3, shortcut, pre_scope, pre_eps, scope1, norm1)
+        op = self.ops[-1]
+        w2_off = self._filter(scope2 + "/weights", 3, 3, d, d)
+        s2, h2 = self._scale_shift("bn", scope2 + "/BatchNorm", d, norm2[1], norm2[2])
+        op["chain"]["front"] = dict(w_off=w2_off, scale_off=s2, shift_off=h2)
+        op["name"] = scope2 + "+" + op["name"]
+        op["flops"] += 2.0 * x.npix * 9 * d * d
+        op["bytes"] += float(self.esz) * 9 * d * d
+        return out, z
+
     def chain(self, x, scope3, shortcut, pre_scope, pre_eps, scope1, norm1):
         """nets/resnet_v2.py:87-91 of one unit (conv3 1x1 + biases, `shortcut + residual`) and :75, :83-84 of the next
         (preact BatchNorm + ReLU, conv1 1x1 + BatchNorm + ReLU) as ONE launch.  Returns (unit output [.., 4d], next unit's
@@ -431,7 +447,17 @@ class BackbonePlan:
             x, y = op["x"], op["y"]
             xs, xo = ref(x)
             ys, yo = ref(y)
-            if op["kind"] == "conv" and op.get("chain"):
+            if op["kind"] == "conv" and op.get("chain") and op["chain"].get("front"):
+                ch, res, y2 = op["chain"], op["res"], op["y2"]
+                fr = ch["front"]
+                d = _lib.UnitDesc(x.nb, x.h, x.w, x.c, x.ld, res.ld, y.ld, y2.ld, self.dtype, _lib.GV_CONV_RELU2, 0)
+                rs, ro = ref(res)
+                y2s, y2o = ref(y2)
+                _lib.check(lib.gv_plan_add_unit(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, fr["w_off"] * wmul, op["w_off"] * wmul,
+                                                ch["w1_off"] * wmul, SLOT_SS, fr["scale_off"], fr["shift_off"], op["scale_off"],
+                                                op["shift_off"], op["scale2_off"], op["shift2_off"], ch["scale1_off"],
+                                                ch["shift1_off"], rs, ro, ys, yo, y2s, y2o), "gv_plan_add_unit(%s)" % op["name"])
+            elif op["kind"] == "conv" and op.get("chain"):
                 ch, res, y2 = op["chain"], op["res"], op["y2"]
                 d = _lib.ChainDesc(x.npix, x.c, x.ld, res.ld, y.ld, y2.ld, self.dtype, _lib.GV_CONV_RELU2, 0)
                 rs, ro = ref(res)
@@ -959,17 +985,24 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         else:
             r = b.conv(preact, sc + "/conv1", base, 1, 1, "SAME", norm=BN, relu=True)  # :83-84
         pad = "SAME" if stride == 1 else ((1, 1), (1, 1))                          # resnet_utils.py:94-105
-        r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
+        # conv3 + the next unit's preact + conv1 as ONE launch (csrc/conv_chain.hip): the next unit keeps this depth
+        # (identity shortcut, conv1 the pre-activation's only reader) and the bottleneck depth is one the kernel serves;
+        # with fuse_unit this unit's conv2 (stride 1 here: the strided unit is a block's last) runs in front of it
+        chains = i + 1 < len(units) and units[i + 1][1] * 4 == depth and getattr(b, "fuse_chain", False) and b.chain_ok(r)
+        whole = chains and getattr(b, "fuse_unit", False) and stride == 1
+        if not whole:
+            r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
         nxt = None
         kw = {}
         if i + 1 < len(units):
             nb_, nbase, nu, _, _ = units[i + 1]
             nxt = ("%s/%s/unit_%d/bottleneck_v2/preact" % (scope, nb_, nu + 1), RESNET_BN_EPS)
-            # conv3 + the next unit's preact + conv1 as ONE launch (csrc/conv_chain.hip): the next unit keeps this depth
-            # (identity shortcut, conv1 the pre-activation's only reader) and the bottleneck depth is one the kernel serves
-            if nbase * 4 == depth and getattr(b, "fuse_chain", False) and b.chain_ok(r):
+            if chains:
                 nsc = "%s/%s/unit_%d/bottleneck_v2" % (scope, nb_, nu + 1)
-                net, c1_ready = b.chain(r, sc + "/conv3", shortcut, nxt[0], nxt[1], nsc + "/conv1", BN)
+                if whole:
+                    net, c1_ready = b.unit(r, sc + "/conv2", BN, sc + "/conv3", shortcut, nxt[0], nxt[1], nsc + "/conv1", BN)
+                else:
+                    net, c1_ready = b.chain(r, sc + "/conv3", shortcut, nxt[0], nxt[1], nsc + "/conv1", BN)
                 preact = None
                 b.end_points[sc] = net
                 if u == n_units - 1:
@@ -1016,7 +1049,7 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True, fuse_chain=True):
+              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True, fuse_chain=True, fuse_unit=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere.
@@ -1030,6 +1063,7 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     b.fuse_maxpool = b.fuse_maxpool and bool(fuse_maxpool)      # (A/B switch: False = Conv2d_2b and MaxPool_3a as two launches)
     # conv3 + next preact + conv1 as one launch (ResNet-v2 blocks 1 and 2 on 16-bit storage); GV_NO_CHAIN=1: whole-plan A/B
     b.fuse_chain = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_CHAIN") is None
+    b.fuse_unit = b.fuse_chain and bool(fuse_unit) and os.environ.get("GV_NO_UNIT") is None     # (GV_NO_UNIT=1: chain only, A/B)
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:
@@ -1057,5 +1091,5 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     if (b.fuse_maxpool or b.fuse_chain) and torch.device(device).type == "cuda" and plan.declined_fused_pools():
         del plan
         return make_plan(backbone, nb, height, width, device, raw_tap=raw_tap, final_tap=final_tap, dtype=dtype, math=math,
-                         lanes=lanes, p3=p3, defer_preact=defer_preact, fuse_maxpool=False, fuse_chain=False)
+                         lanes=lanes, p3=p3, defer_preact=defer_preact, fuse_maxpool=False, fuse_chain=False, fuse_unit=False)
     return plan

@@ -43,6 +43,14 @@ struct ChainArgs {
     int M, x_ld, res_ld, y_ld, z_ld;
     int relu2;
     int dbg;
+    // FRONT (gv_bottleneck_unit_fwd): x is the unit's conv1 output and the kernel begins with the unit's conv2 — 3x3, stride 1,
+    // SAME, BatchNorm + ReLU (nets/resnet_v2.py:85-86) — whose 32 rows per wave never leave the registers
+    const unsigned short* w0;      // packed [d][9 * d]: conv2 (k = tap * d + channel)
+    const float* sc0;              // [d] its BatchNorm, folded
+    const float* sh0;
+    const char* zeros;             // a zero page (>= 512 bytes) for the taps outside the image
+    int ih, iw;
+    GvFastDiv div_img, div_row;    // m / (ih * iw), rem / iw
 };
 
 // One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB of LDS at lds_addr), as INLINE ASM: with the builtin the compiler's
@@ -86,11 +94,16 @@ template <int D> struct ChainGeom {
     // ds_read_b128 service group then fall on 16 different bank groups
     __host__ __device__ static constexpr int swz1(int r) { return CPR1 == 8 ? ((r >> 1) & 7) : (r & 15); }
     __host__ __device__ static constexpr int swz128(int r) { return (r >> 1) & 7; }
-    template <int NW> static constexpr int lds_bytes() { return NR * SLOT + NW * STAGE + (4 * N1 + 2 * N2) * 4; }
+    // FRONT: a conv2 tap's filter tile is [d columns][d channels] = d rows of RBW1 bytes (the shape of W1's rows); a slot
+    // takes TPS taps, the nine taps arrive in NPRE "pre-chunks" in front of the NCH chunks
+    static constexpr int TAPB = D * RBW1;
+    static constexpr int TPS = SLOT / TAPB;
+    static constexpr int NPRE = (9 + TPS - 1) / TPS;
+    template <int NW> static constexpr int lds_bytes() { return NR * SLOT + NW * STAGE + (4 * N1 + 4 * N2) * 4; }
 };
 
 // RVS: register sets of the shortcut prefetch (2: a chunk's shortcut is requested two chunks ahead; 1: one chunk ahead)
-template <typename T, int D, int NW, int RVS>
+template <typename T, int D, int NW, int RVS, bool FRONT = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     using G = ChainGeom<D>;
     constexpr int N1 = G::N1, N2 = G::N2, KS1 = G::KS1, NB2 = G::NB2, NCH = G::NCH;
@@ -114,6 +127,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     for (int i = tid; i < N2; i += NW * 64) {
         tab[4 * N1 + i] = a.sc2[i];
         tab[4 * N1 + N2 + i] = a.sh2[i];
+        if constexpr (FRONT) {
+            tab[4 * N1 + 2 * N2 + i] = a.sc0[i];
+            tab[4 * N1 + 3 * N2 + i] = a.sh0[i];
+        }
     }
     // ---- the filter ring: this wave's DMA instructions of a chunk (piece = wave + i * NW: fixed per wave) ----
     const char* wsrc[PPW];
@@ -139,20 +156,142 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         for (int i = 0; i < PPW; ++i)
             ch_dma16(wsrc[i] + (size_t)cc * winc[i], __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + wdst[i]));
     };
-    issue_chunk(0, 0);
-    // ---- this wave's rows of x as A fragments (lane: row lane & 31, k 8 * (lane >> 5) ... + 7 of each 16-step) ----
+    constexpr int NPRE = FRONT ? G::NPRE : 0;                      // ring steps in front of chunk 0
+    constexpr int TPS = G::TPS, TAPB = G::TAPB;
     const int r32 = lane & 31, h = lane >> 5;
+    auto lds16 = [&](const char* p) -> u32x4 { return *reinterpret_cast<const u32x4*>(p); };
+    auto lds16f = [&](const char* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
+    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
+    char* const stage = smem + OFF_STAGE + wave * STAGE;
     u32x4 xa[KS1];
-    {
+    if constexpr (!FRONT) {
+        issue_chunk(0, 0);
+        // ---- this wave's rows of x as A fragments (lane: row lane & 31, k 8 * (lane >> 5) ... + 7 of each 16-step) ----
         const int row = min(mw + r32, a.M - 1);
         const unsigned short* xp = a.x + (size_t)row * a.x_ld + h * 8;
 #pragma unroll
         for (int s = 0; s < KS1; ++s) xa[s] = *reinterpret_cast<const u32x4*>(xp + s * 16);
+    } else {
+        // ======================= FRONT: conv2 (3x3 / 1, SAME) + BatchNorm + ReLU of this wave's 32 pixels =======================
+        // filter tiles: tap t of pre-chunk pc sits at slot + (t % TPS) * TAPB as [d rows (columns of the GEMM)][RBW1 bytes],
+        // pieces swizzled like W1's; its DMA pieces: piece = wave + i * NW of the slot's NPC (the last pre-chunk may be short)
+        const char* fsrc[PPW];
+        int fdst[PPW];
+        bool flast_ok[PPW];                                        // does this piece exist in the LAST (short) pre-chunk
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave + i * NW;
+            const int ts = piece / (TAPB / 1024), pp = piece % (TAPB / 1024);   // tap inside the slot, piece inside the tap
+            const int r = pp * RPP1 + lane / CPR1, c = lane % CPR1;
+            fsrc[i] = reinterpret_cast<const char*>(a.w0) + (size_t)r * (9 * RBW1) + (size_t)ts * RBW1 + ((c ^ G::swz1(r)) << 4);
+            fdst[i] = piece * 1024;
+            flast_ok[i] = (NPRE - 1) * TPS + ts < 9;
+        }
+        auto issue_pre = [&](auto pcc, int slot) {
+            constexpr int pc = decltype(pcc)::value;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                if (pc + 1 < NPRE || flast_ok[i])                  // (wave-uniform; the last pre-chunk may hold fewer taps)
+                    ch_dma16(fsrc[i] + (size_t)pc * TPS * RBW1, __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + fdst[i]));
+        };
+        issue_pre(std::integral_constant<int, 0>{}, 0);
+        // this lane's pixel (fragment layout: row r32) and which of its nine taps lie inside the image
+        const int m = min(mw + r32, a.M - 1);
+        const int n = gv_div(m, a.div_img);
+        const int rem = m - n * (a.ih * a.iw);
+        const int py = gv_div(rem, a.div_row);
+        const int px = rem - py * a.iw;
+        unsigned tapmask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            if (yy >= 0 && yy < a.ih && xx >= 0 && xx < a.iw) tapmask |= 1u << t;
+        }
+        const char* pm = reinterpret_cast<const char*>(a.x) + ((size_t)m * a.x_ld + h * 8) * 2;
+        const char* zp = a.zeros + h * 16;
+        const long long row_b = (long long)a.iw * a.x_ld * 2, pix_b = (long long)a.x_ld * 2;
+        u32x4 fa[2][KS1];
+        auto tap_load = [&](auto tc, u32x4 (&dst)[KS1]) {
+            constexpr int t = decltype(tc)::value;
+            const long long off = (t / 3 - 1) * row_b + (t % 3 - 1) * pix_b;           // (wave-uniform)
+            const char* src = ((tapmask >> t) & 1u) ? pm + off : zp;
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) dst[s] = *reinterpret_cast<const u32x4*>(src + s * 32);
+        };
+        tap_load(std::integral_constant<int, 0>{}, fa[0]);
+        f32x16 acc0[NB2];
+#pragma unroll
+        for (int j = 0; j < NB2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc0[j][q] = 0.f;
+        int f_row[NB2], f_sw[NB2];
+#pragma unroll
+        for (int j = 0; j < NB2; ++j) { f_row[j] = (j * 32 + r32) * RBW1; f_sw[j] = G::swz1(j * 32 + r32); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the constants table is written
+        auto pre = [&](auto pcc) {
+            constexpr int pc = decltype(pcc)::value;
+            // the taps of pre-chunk pc have landed: their DMAs were issued at the top of pre-chunk pc - 1 (pc = 0: in front of
+            // the first tap's loads); behind them came only the fragment loads of the taps that pre-chunk started
+            constexpr int t_lo = pc * TPS, t_hi = (pc + 1) * TPS < 9 ? (pc + 1) * TPS : 9;
+            constexpr int prev_lo = (pc - 1) * TPS, prev_hi = pc * TPS;   // taps of the previous pre-chunk: each loaded tap + 1
+            if constexpr (pc == 0) ch_wait_vm<KS1>();
+            else ch_wait_vm<(prev_hi - prev_lo) * KS1>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (pc + 1 < NPRE) issue_pre(std::integral_constant<int, pc + 1>{}, (pc + 1) % NR);
+            else issue_chunk(0, NPRE % NR);
+            const char* slot = smem + (pc % NR) * SLOT;
+            ch_for_each([&](auto tc) {
+                constexpr int t = t_lo + decltype(tc)::value;
+                if constexpr (t + 1 < 9) tap_load(std::integral_constant<int, t + 1>{}, fa[(t + 1) & 1]);
+                const char* ft = slot + (t - t_lo) * TAPB;
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NB2; ++j) {
+                        const u32x4 b = lds16(ft + f_row[j] + (((2 * s + h) ^ f_sw[j]) << 4));
+                        acc0[j] = mfma16<T>(fa[t & 1][s], b, acc0[j]);
+                    }
+                }
+            }, std::make_integer_sequence<int, t_hi - t_lo>{});
+        };
+        ch_for_each(pre, std::make_integer_sequence<int, NPRE>{});
+        // ---- its epilogue: BatchNorm + ReLU, one rounding, and the transposition from accumulators (lane = column) to A
+        //      fragments (lane = row), 64 columns at a time through the wave's staging block.  Rows of 256 bytes would put the
+        //      32 lanes of a fragment read on the same banks: the 16-byte pieces of row r are permuted by r & 15 ----
+        const float* t0 = tab + 4 * N1 + 2 * N2;
+#pragma unroll
+        for (int jj = 0; jj < NB2 / 2; ++jj) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_h + (r & 3) + 8 * (r >> 2), col = j * 32 + col_l;
+                    *reinterpret_cast<float*>(stage + row * 256 + ((((col >> 2) ^ row) & 15) << 4) + (col & 3) * 4) = acc0[2 * jj + j][r];
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int col = s4 * 16 + h * 8;                   // this lane's 8 channels of the 64
+                const f32x4 lo = lds16f(stage + r32 * 256 + ((((col >> 2)) ^ r32) & 15) * 16);
+                const f32x4 hi = lds16f(stage + r32 * 256 + ((((col >> 2) + 1) ^ r32) & 15) * 16);
+                const float* tt = t0 + jj * 64 + col;
+                const f32x4 s_lo = *reinterpret_cast<const f32x4*>(tt), s_hi = *reinterpret_cast<const f32x4*>(tt + 4);
+                const f32x4 h_lo = *reinterpret_cast<const f32x4*>(tt + N2), h_hi = *reinterpret_cast<const f32x4*>(tt + N2 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const float sc[8] = {s_lo[0], s_lo[1], s_lo[2], s_lo[3], s_hi[0], s_hi[1], s_hi[2], s_hi[3]};
+                const float sh[8] = {h_lo[0], h_lo[1], h_lo[2], h_lo[3], h_hi[0], h_hi[1], h_hi[2], h_hi[3]};
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
+                xa[jj * 4 + s4] = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     // ---- epilogue geometry: a lane holds 8 consecutive columns (c8) of row 8 * pass + r8 of a 32 x 64 block ----
     const int r8 = lane >> 3, c8 = lane & 7;
-    const int col_l = lane & 31, row_h = 4 * (lane >> 5);
-    char* const stage = smem + OFF_STAGE + wave * STAGE;
     // The z tile ([32 rows][64 channels] of 16 bits, 4 KB) is the FIRST HALF of the staging block: pass p writes z rows
     // 8p ... 8p + 7 = staging rows 4p ... 4p + 3, which pass p / 2 has read — LDS operations of one wave execute in order,
     // so nothing is overwritten before it was read.
@@ -191,8 +330,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     for (int j = 0; j < NB2; ++j) b2_off[j] = W1C + (j * 32 + r32) * 128;
     const int sw128 = G::swz128(r32);                              // (swz128(j * 32 + r32) == swz128(r32))
     const int z_rd = r32 * 128;
-    auto lds16 = [&](const char* p) -> u32x4 { return *reinterpret_cast<const u32x4*>(p); };
-    auto lds16f = [&](const char* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the constants table is written
 
     // The chunk loop is FULLY UNROLLED (c is a compile-time constant): ring slots and table rows become immediate offsets,
@@ -204,11 +341,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         // chunk c of both filters has landed: this wave issued its DMAs at the top of chunk c - 1; behind them came 4 stores
         // and (where there still was a chunk to prefetch) 4 shortcut loads — everything older is complete.  Then every wave
         // is done with chunk c - 1, whose slot takes chunk c + 1.
-        if constexpr (c == 0) ch_wait_vm<KS1 + 4 * RVS>();
+        // (FRONT: chunk 0's DMAs went out at the top of the last pre-chunk, in front of that pre-chunk's tap loads)
+        if constexpr (c == 0) ch_wait_vm<(FRONT ? (9 - (NPRE - 1) * TPS - 1) * KS1 : KS1) + 4 * RVS>();
         else ch_wait_vm<4 + ((c - 1) + RVS < NCH ? 4 : 0)>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (c + 1 < NCH) issue_chunk(c + 1, (c + 1) % NR);
-        const char* slot = smem + (c % NR) * SLOT;
+        if constexpr (c + 1 < NCH) issue_chunk(c + 1, (NPRE + c + 1) % NR);
+        const char* slot = smem + ((NPRE + c) % NR) * SLOT;
         // ---- GEMM 1: 32 rows x 64 columns, K1 deep ----
         f32x16 acc1[2];
 #pragma unroll
@@ -323,12 +461,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     ch_wait_vm<0>();                                               // (nothing of this workgroup may still be landing in LDS)
 }
 
-template <typename T, int D, int NW, int RVS>
+template <typename T, int D, int NW, int RVS, bool FRONT = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
     using G = ChainGeom<D>;
     constexpr int lds = G::template lds_bytes<NW>();
     static_assert(lds <= 160 * 1024, "one workgroup's LDS");
-    auto kern = &conv_chain_lp<T, D, NW, RVS>;
+    auto kern = &conv_chain_lp<T, D, NW, RVS, FRONT>;
     if (lds > 64 * 1024) {
         const bool ok = GV_BIG_LDS_OK(kern, lds);
         if (!ok) return GV_E_UNSUPPORTED;
@@ -337,6 +475,15 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NW * 64), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;
+}
+
+template <typename T>
+int launch_unit_d(int d, const ChainArgs& a, hipStream_t st) {
+    switch (d) {
+        case 64: return launch_chain<T, 64, 4, 2, true>(a, st);
+        case 128: return launch_chain<T, 128, 8, 1, true>(a, st);
+    }
+    return GV_E_UNSUPPORTED;
 }
 
 template <typename T>
@@ -376,6 +523,42 @@ extern "C" int gv_bottleneck_chain_fwd(const gv_chain_desc* d, const void* x, co
     a.M = d->m; a.x_ld = d->x_ld; a.res_ld = d->res_ld; a.y_ld = d->y_ld; a.z_ld = d->z_ld;
     a.relu2 = (d->flags & GV_CONV_RELU2) ? 1 : 0;
     a.dbg = g_chain_debug;
+    a.w0 = nullptr; a.sc0 = a.sh0 = nullptr; a.zeros = nullptr; a.ih = a.iw = 0;
     if (d->dtype == GV_BF16) return launch_chain_d<__bf16>(d->d, a, (hipStream_t)stream);
     return launch_chain_d<_Float16>(d->d, a, (hipStream_t)stream);
+}
+
+extern "C" int gv_bottleneck_unit_fwd(const gv_unit_desc* d, const void* x, const void* w2_packed, const float* scale2,
+                                      const float* shift2, const void* w3_packed, const float* scale3, const float* shift3,
+                                      const void* shortcut, void* y, const float* pre_scale, const float* pre_shift,
+                                      const void* w1_packed, const float* scale1, const float* shift1, void* z, void* stream) {
+    if (!d || !x || !w2_packed || !scale2 || !shift2 || !w3_packed || !scale3 || !shift3 || !shortcut || !y || !pre_scale ||
+        !pre_shift || !w1_packed || !scale1 || !shift1 || !z)
+        return GV_E_BADARG;
+    if (d->nb <= 0 || d->ih <= 0 || d->iw <= 0 || d->d <= 0 || d->x_ld < d->d || d->res_ld < 4 * d->d || d->y_ld < 4 * d->d ||
+        d->z_ld < d->d)
+        return GV_E_BADARG;
+    const int64_t M64 = (int64_t)d->nb * d->ih * d->iw;
+    if (M64 > 0x7fffffff) return GV_E_UNSUPPORTED;
+    if (d->dtype != GV_BF16 && d->dtype != GV_F16) return GV_E_UNSUPPORTED;
+    if (d->d != 64 && d->d != 128) return GV_E_UNSUPPORTED;
+    if ((d->x_ld | d->res_ld | d->y_ld | d->z_ld) % 8 != 0) return GV_E_UNSUPPORTED;
+    if (!gv_aligned16(x) || !gv_aligned16(w2_packed) || !gv_aligned16(w3_packed) || !gv_aligned16(shortcut) || !gv_aligned16(y) ||
+        !gv_aligned16(w1_packed) || !gv_aligned16(z))
+        return GV_E_ALIGN;
+    ChainArgs a;
+    a.x = (const unsigned short*)x; a.w1 = (const unsigned short*)w3_packed; a.sc1 = scale3; a.sh1 = shift3;
+    a.res = (const unsigned short*)shortcut; a.y = (unsigned short*)y; a.psc = pre_scale; a.psh = pre_shift;
+    a.w2 = (const unsigned short*)w1_packed; a.sc2 = scale1; a.sh2 = shift1; a.z = (unsigned short*)z;
+    a.M = (int)M64; a.x_ld = d->x_ld; a.res_ld = d->res_ld; a.y_ld = d->y_ld; a.z_ld = d->z_ld;
+    a.relu2 = (d->flags & GV_CONV_RELU2) ? 1 : 0;
+    a.dbg = g_chain_debug;
+    a.w0 = (const unsigned short*)w2_packed; a.sc0 = scale2; a.sh0 = shift2;
+    a.zeros = (const char*)gvconv::dma_zero_page();
+    if (!a.zeros) return GV_E_UNSUPPORTED;
+    a.ih = d->ih; a.iw = d->iw;
+    a.div_img = gv_fast_div(d->ih * d->iw);
+    a.div_row = gv_fast_div(d->iw);
+    if (d->dtype == GV_BF16) return launch_unit_d<__bf16>(d->d, a, (hipStream_t)stream);
+    return launch_unit_d<_Float16>(d->d, a, (hipStream_t)stream);
 }

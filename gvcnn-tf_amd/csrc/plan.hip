@@ -14,7 +14,7 @@
 
 namespace {
 
-enum OpKind { OP_CONV = 0, OP_POOL = 1, OP_SSA = 2, OP_CHAIN = 3 };
+enum OpKind { OP_CONV = 0, OP_POOL = 1, OP_SSA = 2, OP_CHAIN = 3, OP_UNIT = 4 };
 
 struct Ref {
     int32_t slot;
@@ -27,6 +27,8 @@ struct Op {
     gv_pool_desc pool;
     gv_chain_desc chain;        // OP_CHAIN: x, w (conv3), scale / shift (conv3), res, y as for a conv; z = y2; the pre-activation's
     Ref w1, scale1, shift1;     //   scale / shift in scale2 / shift2; the next conv1's filter / scale / shift here
+    gv_unit_desc unit;          // OP_UNIT: the chain's operands + conv2's filter / scale / shift
+    Ref w0, scale0, shift0;
     // scale_shift_act
     int64_t npix;
     int32_t c, x_ld, y_ld, relu, dtype;
@@ -105,6 +107,15 @@ int run_op(const Op& o, void* const* bufs, void* stream) {
                                            at(bufs, o.w1, es), (const float*)at(bufs, o.scale1, 4),
                                            (const float*)at(bufs, o.shift1, 4), at(bufs, o.y2, es), stream);
         }
+        case OP_UNIT: {
+            const size_t es = elem_size(o.unit.dtype);
+            return gv_bottleneck_unit_fwd(&o.unit, at(bufs, o.x, es), at(bufs, o.w0, es), (const float*)at(bufs, o.scale0, 4),
+                                          (const float*)at(bufs, o.shift0, 4), at(bufs, o.w, es), (const float*)at(bufs, o.scale, 4),
+                                          (const float*)at(bufs, o.shift, 4), at(bufs, o.res, es), at(bufs, o.y, es),
+                                          (const float*)at(bufs, o.scale2, 4), (const float*)at(bufs, o.shift2, 4),
+                                          at(bufs, o.w1, es), (const float*)at(bufs, o.scale1, 4),
+                                          (const float*)at(bufs, o.shift1, 4), at(bufs, o.y2, es), stream);
+        }
         case OP_SSA: {
             const size_t es = elem_size(o.dtype);
             return gv_scale_shift_act(at(bufs, o.x, es), o.npix, o.c, o.x_ld,
@@ -179,6 +190,36 @@ extern "C" int gv_plan_add_chain(gv_plan* p, const gv_chain_desc* d, int32_t x_s
     o.x = {x_slot, x_off};
     o.w = {w_slot, w3_off};
     o.w1 = {w_slot, w1_off};
+    o.scale = {ss_slot, scale3_off};
+    o.shift = {ss_slot, shift3_off};
+    o.scale2 = {ss_slot, pre_scale_off};
+    o.shift2 = {ss_slot, pre_shift_off};
+    o.scale1 = {ss_slot, scale1_off};
+    o.shift1 = {ss_slot, shift1_off};
+    o.res = {res_slot, res_off};
+    o.y = {y_slot, y_off};
+    o.y2 = {z_slot, z_off};
+    for (const Ref* r : {&o.x, &o.w, &o.scale, &o.res, &o.y, &o.y2}) note(p, *r);
+    p->ops.push_back(o);
+    return GV_OK;
+}
+
+extern "C" int gv_plan_add_unit(gv_plan* p, const gv_unit_desc* d, int32_t x_slot, int64_t x_off, int32_t w_slot, int64_t w2_off,
+                                int64_t w3_off, int64_t w1_off, int32_t ss_slot, int64_t scale2_off, int64_t shift2_off,
+                                int64_t scale3_off, int64_t shift3_off, int64_t pre_scale_off, int64_t pre_shift_off,
+                                int64_t scale1_off, int64_t shift1_off, int32_t res_slot, int64_t res_off, int32_t y_slot,
+                                int64_t y_off, int32_t z_slot, int64_t z_off) {
+    if (!p) return GV_E_PLAN;
+    if (!d || x_slot < 0 || w_slot < 0 || ss_slot < 0 || res_slot < 0 || y_slot < 0 || z_slot < 0) return GV_E_BADARG;
+    Op o{};
+    o.kind = OP_UNIT;
+    o.unit = *d;
+    o.x = {x_slot, x_off};
+    o.w0 = {w_slot, w2_off};
+    o.w = {w_slot, w3_off};
+    o.w1 = {w_slot, w1_off};
+    o.scale0 = {ss_slot, scale2_off};
+    o.shift0 = {ss_slot, shift2_off};
     o.scale = {ss_slot, scale3_off};
     o.shift = {ss_slot, shift3_off};
     o.scale2 = {ss_slot, pre_scale_off};

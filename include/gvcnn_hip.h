@@ -242,6 +242,26 @@ int gv_bottleneck_chain_fwd(const gv_chain_desc* d, const void* x, const void* w
                             const float* pre_shift, const void* w1_packed, const float* scale1, const float* shift1,
                             void* z, void* stream);
 
+/* The same launch with the unit's conv2 in front (csrc/conv_chain.hip, FRONT): x is the unit's conv1 output [nb, ih, iw, d] and
+ *   c2 = relu( conv3x3(x, w2, stride 1, SAME) * scale2 + shift2 )        nets/resnet_v2.py:85-86 (conv2 + BatchNorm + ReLU)
+ * feeds gv_bottleneck_chain_fwd's y / z without ever being stored: one launch per bottleneck unit (from its conv2 to the
+ * next unit's conv1), reading [m, d] + [m, 4d] and writing [m, 4d] + [m, d].  w2_packed [d][9*d] as gv_pack_filter_hwio
+ * writes a 3x3 filter for the dtype.  conv2's k order here is tap-major; against the separate launches the results agree to
+ * fp32 summation order (the other kernel families of gv_conv2d_fwd sum k chunk-major), everything behind c2's rounding is
+ * the chain's arithmetic.  Same classes: 16-bit storage, d = 64 or 128, stride 1; else GV_E_UNSUPPORTED. */
+typedef struct gv_unit_desc {
+    int32_t nb, ih, iw;        /* the pixel grid of all four tensors */
+    int32_t d;                 /* bottleneck depth */
+    int32_t x_ld, res_ld, y_ld, z_ld;
+    int32_t dtype;             /* GV_BF16 | GV_F16 */
+    int32_t flags;             /* GV_CONV_RELU2: ReLU on z */
+    int32_t tile_cfg;          /* 0 (reserved) */
+} gv_unit_desc;
+int gv_bottleneck_unit_fwd(const gv_unit_desc* d, const void* x, const void* w2_packed, const float* scale2,
+                           const float* shift2, const void* w3_packed, const float* scale3, const float* shift3,
+                           const void* shortcut, void* y, const float* pre_scale, const float* pre_shift,
+                           const void* w1_packed, const float* scale1, const float* shift1, void* z, void* stream);
+
 /* ---- pooling -------------------------------------------------------------
  * slim.max_pool2d / slim.avg_pool2d: nets/inception_v3.py:112,127,152,219,355,...;
  * nets/resnet_v2.py:181 (3x3/2 SAME, pad (0,1)); nets/resnet_utils.py:64-67
@@ -587,6 +607,12 @@ int gv_plan_add_chain(gv_plan* p, const gv_chain_desc* d, int32_t x_slot, int64_
                       int64_t w1_off, int32_t ss_slot, int64_t scale3_off, int64_t shift3_off, int64_t pre_scale_off,
                       int64_t pre_shift_off, int64_t scale1_off, int64_t shift1_off, int32_t res_slot, int64_t res_off,
                       int32_t y_slot, int64_t y_off, int32_t z_slot, int64_t z_off);
+/* gv_bottleneck_unit_fwd as a plan op: gv_plan_add_chain's operands plus conv2's filter / scale / shift. */
+int gv_plan_add_unit(gv_plan* p, const gv_unit_desc* d, int32_t x_slot, int64_t x_off, int32_t w_slot, int64_t w2_off,
+                     int64_t w3_off, int64_t w1_off, int32_t ss_slot, int64_t scale2_off, int64_t shift2_off,
+                     int64_t scale3_off, int64_t shift3_off, int64_t pre_scale_off, int64_t pre_shift_off,
+                     int64_t scale1_off, int64_t shift1_off, int32_t res_slot, int64_t res_off, int32_t y_slot, int64_t y_off,
+                     int32_t z_slot, int64_t z_off);
 /* Branch-level concurrency: put op `op_index` on launch lane `lane` (0 = the caller's stream, 1..7 =
  * plan-owned streams) and name the EARLIER ops it must wait for (producers of its inputs, and ops
  * still using a buffer it overwrites).  A whole-plan run then forks the lanes off `stream` and joins

@@ -104,6 +104,85 @@ def test_chain_declines_what_it_does_not_serve():
     assert lib().gv_bottleneck_chain_fwd(None, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, None) == _lib.GV_E_BADARG
 
 
+def run_unit(x4, w2, s2, h2, w3, b3, res, ps, ph, w1, s1, h1, ty, expect=None):
+    """x4 [nb, ih, iw, d]: the unit's conv1 output.  Returns (y, z) of gv_bottleneck_unit_fwd and (c2, y, z) of the launches it
+    replaces: gv_conv2d_fwd (conv2 3x3 + BN + ReLU), then gv_bottleneck_chain_fwd."""
+    code, td, _ = TYPES[ty]
+    nb, ih, iw, d = x4.shape
+    M, n1 = nb * ih * iw, 4 * d
+    xd, rd = x4.to(td).to(DEV).contiguous(), res.to(td).to(DEV).contiguous()
+    yd = torch.full((M, n1), -77.0, dtype=td, device=DEV)
+    zd = torch.full((M, d), -55.0, dtype=td, device=DEV)
+    w2p, w3p, w1p = pack(w2, code), pack(w3.view(1, 1, d, n1), code), pack(w1.view(1, 1, n1, d), code)
+    f = lambda t: t.to(DEV).float().contiguous()
+    one, b3d, psd, phd, s1d, h1d, s2d, h2d = f(torch.ones(n1)), f(b3), f(ps), f(ph), f(s1), f(h1), f(s2), f(h2)
+    desc = _lib.UnitDesc(nb, ih, iw, d, d, n1, n1, d, code, _lib.GV_CONV_RELU2, 0)
+    rc = lib().gv_bottleneck_unit_fwd(C.byref(desc), xd.data_ptr(), w2p.data_ptr(), s2d.data_ptr(), h2d.data_ptr(), w3p.data_ptr(),
+                                      one.data_ptr(), b3d.data_ptr(), rd.data_ptr(), yd.data_ptr(), psd.data_ptr(), phd.data_ptr(),
+                                      w1p.data_ptr(), s1d.data_ptr(), h1d.data_ptr(), zd.data_ptr(), st())
+    torch.cuda.synchronize()
+    if expect is not None:
+        assert rc == expect, rc
+        return None
+    _lib.check(rc, "gv_bottleneck_unit_fwd")
+    c2 = torch.empty((nb, ih, iw, d), dtype=td, device=DEV)
+    dc = _lib.ConvDesc(nb, ih, iw, d, d, 3, 3, 1, 1, 1, ih, iw, d, d, 0, 0, _lib.GV_CONV_RELU, code, 0, 0, 0, 0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(dc), xd.data_ptr(), w2p.data_ptr(), s2d.data_ptr(), h2d.data_ptr(), None, c2.data_ptr(),
+                                   None, None, None, st()), "conv2")
+    y2 = torch.empty_like(yd)
+    z2 = torch.empty_like(zd)
+    dch = _lib.ChainDesc(M, d, d, n1, n1, d, code, _lib.GV_CONV_RELU2, 0)
+    _lib.check(lib().gv_bottleneck_chain_fwd(C.byref(dch), c2.data_ptr(), w3p.data_ptr(), one.data_ptr(), b3d.data_ptr(), rd.data_ptr(),
+                                             y2.data_ptr(), psd.data_ptr(), phd.data_ptr(), w1p.data_ptr(), s1d.data_ptr(),
+                                             h1d.data_ptr(), z2.data_ptr(), st()), "chain")
+    torch.cuda.synchronize()
+    return yd.float().cpu(), zd.float().cpu(), c2.float().cpu(), y2.float().cpu(), z2.float().cpu()
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("d,nb,ih,iw", [(64, 3, 14, 14), (64, 2, 9, 23), (64, 5, 3, 3), (128, 2, 12, 10), (128, 1, 1, 5)])
+def test_unit_vs_oracle_and_vs_the_launches_it_replaces(d, nb, ih, iw, ty):
+    """conv2 (3x3 / 1 SAME + BN + ReLU) in front of the chain, one launch: maps narrower and wider than a wave's 32 pixels,
+    waves that span images, a single row of pixels, ragged 128- / 256-row tiles.  Against the oracle's ops on the rounded
+    operands, and against gv_conv2d_fwd -> gv_bottleneck_chain_fwd: conv2 sums k in another order here (tap-major), so a c2
+    element may round the other way (one unit in the last place of the storage type) and that moves y / z by their own
+    rounding at most — checked as: almost all elements identical, the rest within two roundings."""
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(d + nb * ih + iw)
+    M, n1 = nb * ih * iw, 4 * d
+    x4 = rnd(torch.relu(torch.randn(nb, ih, iw, d, generator=g)), td)
+    w2 = rnd(torch.randn(3, 3, d, d, generator=g) * (1.0 / (9 * d)) ** 0.5, td)
+    s2, h2 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    _, w3, b3, res, ps, ph, w1, s1, h1 = operands(M, d, td, seed=d + M)
+    y, z, c2, y2, z2 = run_unit(x4, w2, s2, h2, w3, b3, res, ps, ph, w1, s1, h1, ty)
+    # oracle: conv2 of the reference graph on the rounded operands
+    c2o = torch.relu(OB.conv2d(x4, w2, 1, "SAME") * s2 + h2)
+    close(c2, c2o.numpy(), ulp)
+    c2r = rnd(c2o, td).reshape(M, d)
+    yo = c2r @ w3 + b3 + res
+    close(y, yo.numpy(), 2 * ulp, extra=2e-3)
+    pre = rnd(torch.relu(y * ps + ph), td)
+    close(z, torch.relu((pre @ w1) * s1 + h1).numpy(), ulp)                 # the second half on the device's own y
+    # against the separate launches
+    for got, ref, what in ((y, y2, "y"), (z, z2, "z")):
+        same = float((got == ref).float().mean())
+        assert same > 0.97, (what, same)
+        scale = float(ref.abs().max())
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=4 * ulp, atol=2e-3 * scale)
+
+
+def test_unit_declines_what_it_does_not_serve():
+    U = _lib.GV_E_UNSUPPORTED
+    d = _lib.UnitDesc(1, 8, 8, 256, 256, 1024, 1024, 256, _lib.GV_BF16, 0, 0)
+    args = [16] * 15 + [None]
+    assert lib().gv_bottleneck_unit_fwd(C.byref(d), *args) == U                                   # depth 256
+    d = _lib.UnitDesc(1, 8, 8, 64, 64, 256, 256, 64, _lib.GV_F32, 0, 0)
+    assert lib().gv_bottleneck_unit_fwd(C.byref(d), *args) == U                                   # fp32 storage
+    d = _lib.UnitDesc(1, 8, 8, 64, 60, 256, 256, 64, _lib.GV_BF16, 0, 0)
+    assert lib().gv_bottleneck_unit_fwd(C.byref(d), *args) == _lib.GV_E_BADARG                    # x_ld < d
+    assert lib().gv_bottleneck_unit_fwd(None, *args) == _lib.GV_E_BADARG
+
+
 @pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])
 def test_resnet_plan_with_and_without_the_chain(ty, size, nb):
     """The whole 16-bit ResNet-v2-50 plan with the five chain launches of blocks 1 and 2 equals the plan with the separate
@@ -111,7 +190,8 @@ def test_resnet_plan_with_and_without_the_chain(ty, size, nb):
     x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5)
     outs, nops = [], []
     for fuse in (True, False):
-        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse)
+        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse,
+                                   fuse_unit=False)
         P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
         plan.bind(P)
         plan.run(x.to(DEV))
@@ -128,3 +208,28 @@ def test_resnet_plan_with_and_without_the_chain(ty, size, nb):
     got = outs[0]["resnet_v2_50/block4"][0].float().cpu().numpy()
     rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
     assert rel < (3e-2 if ty == "bf16" else 4e-3), rel
+
+
+@pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])
+def test_resnet_plan_with_whole_unit_launches(ty, size, nb):
+    """The default 16-bit ResNet-v2-50 plan: one launch per bottleneck unit inside blocks 1 and 2 (conv2 in front of the
+    chain).  Against the oracle at the storage type's bound, and against the plan of separate launches: conv2's k order
+    differs, so block3 / block4 agree to the storage rounding of the ~40 layers in between, not bit for bit."""
+    x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5)
+    outs = []
+    for fuse in (True, False):
+        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse)
+        P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
+        plan.bind(P)
+        plan.run(x.to(DEV))
+        torch.cuda.synchronize()
+        outs.append({k: plan.view(plan.end_points[k]).float().cpu() for k in ("resnet_v2_50/block3", "resnet_v2_50/block4")})
+        assert sum(1 for op in plan.ops if op.get("chain") and op["chain"].get("front")) == (5 if fuse else 0)
+    bound = 3e-2 if ty == "bf16" else 4e-3
+    _, ep = OB.resnet_v2_50(x[:2], P)
+    for k in outs[0]:
+        a, b = outs[0][k].numpy(), outs[1][k].numpy()
+        assert float(np.linalg.norm(a - b) / np.linalg.norm(b)) < bound / 2, k
+        ref = ep[k].numpy()
+        for o in outs:
+            assert float(np.linalg.norm(o[k][:2].numpy() - ref) / np.linalg.norm(ref)) < bound, k

@@ -242,28 +242,40 @@ def test_16bit_plans_issue_conv_and_max_pool_as_one_launch(dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
-    """gv_bottleneck_chain_fwd at plan level (host logic only): inside blocks 1 and 2 (bottleneck depth 64 / 128) conv3 of a
-    unit, the next unit's pre-activation and its conv1 (nets/resnet_v2.py:87-91, :75, :83-84) are ONE op — 2 + 3 of them,
-    five launches fewer; the deeper blocks keep the deferred pre-activation; same variables, same arithmetic work, same
-    end points; fp32 storage and fuse_chain=False keep the separate launches."""
+    """gv_bottleneck_chain_fwd / gv_bottleneck_unit_fwd at plan level (host logic only): inside blocks 1 and 2 (bottleneck
+    depth 64 / 128) conv3 of a unit, the next unit's pre-activation and its conv1 (nets/resnet_v2.py:87-91, :75, :83-84) are
+    ONE op — 2 + 3 of them — and by default the unit's conv2 (:85-86) runs in front of it in the same launch: ten launches
+    fewer (fuse_unit=False: five).  The deeper blocks keep the deferred pre-activation; same variables, same arithmetic work,
+    same end points; fp32 storage and fuse_chain=False keep the separate launches."""
     cpu = torch.device("cpu")
-    p = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype)
     off = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_chain=False)
-    chains = [op for op in p.ops if op.get("chain")]
-    assert [op["x"].c for op in chains] == [64, 64, 128, 128, 128]
-    assert len(p.ops) == len(off.ops) - 5 and not any(op.get("chain") for op in off.ops)
-    for op in chains:
-        a, b = op["name"].split("+")
-        assert a.endswith("/conv3") and b.endswith("/conv1") and a.split("/")[1] == b.split("/")[1]      # same block
-        assert int(b.split("/unit_")[1].split("/")[0]) == int(a.split("/unit_")[1].split("/")[0]) + 1      # consecutive units
-        assert op["y"].c == 4 * op["x"].c and op["y2"].c == op["x"].c and op["res"].c == op["y"].c
-        nxt = next(o for o in p.ops if o["name"] == b.replace("/conv1", "/conv2"))
-        assert nxt["x"] is op["y2"] and p.ops.index(nxt) > p.ops.index(op)                                # conv2 reads the chain's z
-        assert not any(o["name"] == b for o in p.ops)                                                     # no separate conv1
-    pre = [op for op in p.ops if op["kind"] == "conv" and op.get("xpre") is not None]
-    assert len(pre) == 5 and all(op["x"].c == 1024 for op in pre)                                         # block3's identity units
-    assert p.param_shapes() == off.param_shapes()
-    assert abs(p.total_flops - off.total_flops) < 1e-6 * off.total_flops
-    assert set(p.end_points) == set(off.end_points)
+    assert not any(op.get("chain") for op in off.ops)
+    for fuse_unit, fewer in ((True, 10), (False, 5)):
+        p = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_unit=fuse_unit)
+        chains = [op for op in p.ops if op.get("chain")]
+        assert [op["x"].c for op in chains] == [64, 64, 128, 128, 128]
+        assert all(bool(op["chain"].get("front")) == fuse_unit for op in chains)
+        assert len(p.ops) == len(off.ops) - fewer
+        for op in chains:
+            parts = op["name"].split("+")
+            a, b = parts[-2], parts[-1]
+            assert a.endswith("/conv3") and b.endswith("/conv1") and a.split("/")[1] == b.split("/")[1]      # same block
+            assert int(b.split("/unit_")[1].split("/")[0]) == int(a.split("/unit_")[1].split("/")[0]) + 1      # consecutive units
+            assert op["y"].c == 4 * op["x"].c and op["y2"].c == op["x"].c and op["res"].c == op["y"].c
+            nxt = next(o for o in p.ops if o["name"].split("+")[0] == b.replace("/conv1", "/conv2"))
+            assert nxt["x"] is op["y2"] and p.ops.index(nxt) > p.ops.index(op)                                # conv2 reads the chain's z
+            assert not any(o["name"] == b for o in p.ops)                                                     # no separate conv1
+            own_conv2 = a.replace("/conv3", "/conv2")
+            if fuse_unit:                                                                                     # ... nor conv2: it is in front
+                assert parts[0] == own_conv2 and len(parts) == 3 and not any(o["name"] == own_conv2 for o in p.ops)
+                prev = next(o for o in p.ops if o["name"].split("+")[-1] == a.replace("/conv3", "/conv1"))
+                assert op["x"] is (prev["y2"] if prev.get("chain") else prev["y"])                            # x is this unit's conv1
+            else:
+                assert len(parts) == 2 and any(o["name"] == own_conv2 and o["y"] is op["x"] for o in p.ops)
+        pre = [op for op in p.ops if op["kind"] == "conv" and op.get("xpre") is not None]
+        assert len(pre) == 5 and all(op["x"].c == 1024 for op in pre)                                         # block3's identity units
+        assert p.param_shapes() == off.param_shapes()
+        assert abs(p.total_flops - off.total_flops) < 1e-6 * off.total_flops
+        assert set(p.end_points) == set(off.end_points)
     f32 = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu)
     assert not any(op.get("chain") for op in f32.ops)
