@@ -129,6 +129,8 @@ class BackbonePlan:
         self.fuse_chain = False
         # ... and the unit's conv2 (3x3 / 1) in front of it: one launch per bottleneck unit (gv_bottleneck_unit_fwd)
         self.fuse_unit = False
+        # ... and a depth-changing unit's conv1 + projection shortcut as one GEMM (resnet_unit1_pair)
+        self.fuse_pair = False
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -237,6 +239,31 @@ class BackbonePlan:
                               (_lib.GV_POOL_Y_P3 if out.p3 else 0), flops=0.0,
                               bytes=float(self.esz) * 2 * z.npix * z.c))
         return outs
+
+    def resnet_unit1_pair(self, x, scope1, d, norm1, scope_sc, depth):
+        """conv1 (1x1, BatchNorm + ReLU, d columns: nets/resnet_v2.py:83-84) and the projection shortcut (1x1, biases,
+        `depth` columns: :79-81) of a unit whose depth changes read the SAME pre-activation at stride 1 (the strided unit
+        is a block's last): ONE GEMM over the concatenated filters — columns [0, d) -> conv1's tensor with ReLU, the rest ->
+        the shortcut's without (GV_CONV_SPLIT, relu_cols) — so the pre-activation is read once.  Returns (conv1, shortcut)."""
+        total = d + depth
+        y1 = self.new_tensor(x.nb, x.h, x.w, d)
+        y2 = self.new_tensor(x.nb, x.h, x.w, depth)
+        n1, n2 = self._packed_elems(1, 1, x.c, d), self._packed_elems(1, 1, x.c, depth)
+        w_off = self.w_elems
+        self.filters.append((scope1 + "/weights", 1, 1, x.c, d, w_off))
+        self.filters.append((scope_sc + "/weights", 1, 1, x.c, depth, w_off + n1))
+        self.w_elems = (w_off + n1 + n2 + 63) // 64 * 64
+        cpad = (total + 3) // 4 * 4
+        so, ho = self.ss_elems, self.ss_elems + cpad
+        self.ss_elems += 2 * cpad
+        self.ss_specs.append(("bn", scope1 + "/BatchNorm", d, norm1[1], norm1[2], so, ho))
+        self.ss_specs.append(("bias", scope_sc + "/biases", depth, 0.0, False, so + d, ho + d))
+        self._record(dict(kind="conv", name=scope1 + "+" + scope_sc, x=x, y=y1, y2=y2, res=None, w_off=w_off,
+                          scale_off=so, shift_off=ho, scale2_off=0, shift2_off=0, kh=1, kw=1, stride=1, pad_t=0, pad_l=0,
+                          relu=True, split=d, cout=total, relu_cols=d, xpre=None, maxpool=None,
+                          flops=2.0 * x.npix * total * x.c,
+                          bytes=float(self.esz) * (x.npix * x.c + x.c * total + x.npix * total)))
+        return y1, y2
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
              residual=None, next_preact=None, p3=False, defer=False, maxpool=False):
@@ -976,12 +1003,21 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
     for i, (bname, base, u, n_units, stride) in enumerate(units):
         sc = "%s/%s/unit_%d/bottleneck_v2" % (scope, bname, u + 1)
         depth, depth_in = base * 4, net.c
+        pair = None
         if depth == depth_in:                                                      # resnet_v2.py:76-77
             shortcut = net if stride == 1 else b.pool(net, 1, stride, "VALID", MAX, name=sc + "/shortcut")
+        elif (stride == 1 and getattr(b, "fuse_pair", False) and not isinstance(preact, DeferredPreact) and base % 8 == 0
+              and c1_ready is None and base >= 128):
+            # (block1's pair — 64 + 256 columns over K = 64 — measured slower than its two launches: 0.283 against 0.269 ms)
+            # the projection shortcut and conv1 read the same pre-activation: one GEMM (16-bit inference plans)
+            pair = b.resnet_unit1_pair(preact, sc + "/conv1", base, BN, sc + "/shortcut", depth)
+            shortcut = pair[1]
         else:                                                                      # resnet_v2.py:79-81
             shortcut = b.conv(preact, sc + "/shortcut", depth, 1, stride, "VALID", norm=None, relu=False)
         if c1_ready is not None:
             r, c1_ready = c1_ready, None
+        elif pair is not None:
+            r = pair[0]
         else:
             r = b.conv(preact, sc + "/conv1", base, 1, 1, "SAME", norm=BN, relu=True)  # :83-84
         pad = "SAME" if stride == 1 else ((1, 1), (1, 1))                          # resnet_utils.py:94-105
@@ -1064,6 +1100,7 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     # conv3 + next preact + conv1 as one launch (ResNet-v2 blocks 1 and 2 on 16-bit storage); GV_NO_CHAIN=1: whole-plan A/B
     b.fuse_chain = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_CHAIN") is None
     b.fuse_unit = b.fuse_chain and bool(fuse_unit) and os.environ.get("GV_NO_UNIT") is None     # (GV_NO_UNIT=1: chain only, A/B)
+    b.fuse_pair = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_PAIR") is None
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:

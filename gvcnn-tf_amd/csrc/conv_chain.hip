@@ -163,6 +163,37 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     auto lds16f = [&](const char* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
     const int col_l = lane & 31, row_h = 4 * (lane >> 5);
     char* const stage = smem + OFF_STAGE + wave * STAGE;
+    // ---- epilogue geometry: a lane holds 8 consecutive columns (c8) of row 8 * pass + r8 of a 32 x 64 block ----
+    const int r8 = lane >> 3, c8 = lane & 7;
+    // The z tile ([32 rows][64 channels] of 16 bits, 4 KB) is the FIRST HALF of the staging block: pass p writes z rows
+    // 8p ... 8p + 7 = staging rows 4p ... 4p + 3, which pass p / 2 has read — LDS operations of one wave execute in order,
+    // so nothing is overwritten before it was read.
+    char* const ztile = stage;
+    const int woff = (row_h * 64 + col_l) * 4;                     // + row * 256 + block * 128 per accumulator register
+    const int roff = (r8 * 64 + c8 * 8) * 4;                       // + pass * 2048
+    // rows past M are clamped to row M - 1 everywhere: such lanes compute that row's values from that row's operands and
+    // store them to that row — duplicates of the same bytes — so that EVERY vector-memory operation is issued
+    // unconditionally (a store under an exec branch makes the compiler's count of operations in flight path-dependent)
+    const unsigned short* rrow_p[4];
+    unsigned short* yrow[4];
+    unsigned short* zrow[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const size_t m = (size_t)min(mw + p * 8 + r8, a.M - 1);
+        rrow_p[p] = a.res + m * a.res_ld + c8 * 8;
+        yrow[p] = a.y + m * a.y_ld + c8 * 8;
+        zrow[p] = a.z + m * a.z_ld + c8 * 8;
+    }
+    // the shortcut's first chunks: requested up front — with FRONT in front of the conv2 phase,
+    // so that their HBM round trip runs under that phase's matrix work
+    constexpr bool EARLY_RV = FRONT && D <= 64;              // (d = 128: the conv2 phase has no 16 registers to spare)
+    u32x4 rv[RVS][4];
+    auto load_rv = [&]() {
+#pragma unroll
+        for (int q = 0; q < RVS; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rv[q][p] = *reinterpret_cast<const u32x4*>(rrow_p[p] + q * 64);
+    };
     u32x4 xa[KS1];
     if constexpr (!FRONT) {
         issue_chunk(0, 0);
@@ -219,6 +250,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
             for (int s = 0; s < KS1; ++s) dst[s] = *reinterpret_cast<const u32x4*>(src + s * 32);
         };
         tap_load(std::integral_constant<int, 0>{}, fa[0]);
+        if constexpr (EARLY_RV) load_rv();
         f32x16 acc0[NB2];
 #pragma unroll
         for (int j = 0; j < NB2; ++j)
@@ -234,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
             // the first tap's loads); behind them came only the fragment loads of the taps that pre-chunk started
             constexpr int t_lo = pc * TPS, t_hi = (pc + 1) * TPS < 9 ? (pc + 1) * TPS : 9;
             constexpr int prev_lo = (pc - 1) * TPS, prev_hi = pc * TPS;   // taps of the previous pre-chunk: each loaded tap + 1
-            if constexpr (pc == 0) ch_wait_vm<KS1>();
+            if constexpr (pc == 0) ch_wait_vm<KS1 + (EARLY_RV ? 4 * RVS : 0)>();
             else ch_wait_vm<(prev_hi - prev_lo) * KS1>();
             __builtin_amdgcn_s_barrier();
             if constexpr (pc + 1 < NPRE) issue_pre(std::integral_constant<int, pc + 1>{}, (pc + 1) % NR);
@@ -290,32 +322,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // ---- epilogue geometry: a lane holds 8 consecutive columns (c8) of row 8 * pass + r8 of a 32 x 64 block ----
-    const int r8 = lane >> 3, c8 = lane & 7;
-    // The z tile ([32 rows][64 channels] of 16 bits, 4 KB) is the FIRST HALF of the staging block: pass p writes z rows
-    // 8p ... 8p + 7 = staging rows 4p ... 4p + 3, which pass p / 2 has read — LDS operations of one wave execute in order,
-    // so nothing is overwritten before it was read.
-    char* const ztile = stage;
-    const int woff = (row_h * 64 + col_l) * 4;                     // + row * 256 + block * 128 per accumulator register
-    const int roff = (r8 * 64 + c8 * 8) * 4;                       // + pass * 2048
-    // rows past M are clamped to row M - 1 everywhere: such lanes compute that row's values from that row's operands and
-    // store them to that row — duplicates of the same bytes — so that EVERY vector-memory operation is issued
-    // unconditionally (a store under an exec branch makes the compiler's count of operations in flight path-dependent)
-    const unsigned short* rrow_p[4];
-    unsigned short* yrow[4];
-    unsigned short* zrow[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const size_t m = (size_t)min(mw + p * 8 + r8, a.M - 1);
-        rrow_p[p] = a.res + m * a.res_ld + c8 * 8;
-        yrow[p] = a.y + m * a.y_ld + c8 * 8;
-        zrow[p] = a.z + m * a.z_ld + c8 * 8;
-    }
-    u32x4 rv[RVS][4];
-#pragma unroll
-    for (int q = 0; q < RVS; ++q)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) rv[q][p] = *reinterpret_cast<const u32x4*>(rrow_p[p] + q * 64);
+    if constexpr (!EARLY_RV) load_rv();
     f32x16 acc2[NB2];
 #pragma unroll
     for (int j = 0; j < NB2; ++j)
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         // and (where there still was a chunk to prefetch) 4 shortcut loads — everything older is complete.  Then every wave
         // is done with chunk c - 1, whose slot takes chunk c + 1.
         // (FRONT: chunk 0's DMAs went out at the top of the last pre-chunk, in front of that pre-chunk's tap loads)
-        if constexpr (c == 0) ch_wait_vm<(FRONT ? (9 - (NPRE - 1) * TPS - 1) * KS1 : KS1) + 4 * RVS>();
+        if constexpr (c == 0) ch_wait_vm<(FRONT ? (9 - (NPRE - 1) * TPS - 1) * KS1 : KS1) + (EARLY_RV ? 0 : 4 * RVS)>();
         else ch_wait_vm<4 + ((c - 1) + RVS < NCH ? 4 : 0)>();
         __builtin_amdgcn_s_barrier();
         if constexpr (c + 1 < NCH) issue_chunk(c + 1, (NPRE + c + 1) % NR);

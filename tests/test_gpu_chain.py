@@ -200,7 +200,9 @@ def test_resnet_plan_with_and_without_the_chain(ty, size, nb):
         outs.append({k: plan.view(plan.end_points[k]).clone() for k in ("resnet_v2_50/block3", "resnet_v2_50/block4")})
         nops.append(len(plan.ops))
         assert sum(1 for op in plan.ops if op.get("chain")) == (5 if fuse else 0)
-    assert nops[0] == nops[1] - 5
+        if fuse:
+            plan_ops_fused = plan.ops
+    assert nops[0] == nops[1] - 5 - sum(1 for op in plan_ops_fused if op.get("split"))   # (+ the conv1 + shortcut pairs)
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
     _, ep = OB.resnet_v2_50(x[:1], P)

@@ -250,7 +250,12 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
     cpu = torch.device("cpu")
     off = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_chain=False)
     assert not any(op.get("chain") for op in off.ops)
-    for fuse_unit, fewer in ((True, 10), (False, 5)):
+    pairs = [op for op in backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype).ops if op.get("split")]
+    # (a depth-changing unit's conv1 + projection shortcut also run as one GEMM in blocks 2 - 4: three launches fewer, resnet_unit1_pair)
+    assert [(op["split"], op["cout"], op["relu_cols"]) for op in pairs] == [(128, 640, 128), (256, 1280, 256), (512, 2560, 512)]   # (block1's: slower, not fused)
+    assert all(op["name"].split("+")[0].endswith("unit_1/bottleneck_v2/conv1") and op["name"].endswith("unit_1/bottleneck_v2/shortcut")
+               for op in pairs)
+    for fuse_unit, fewer in ((True, 13), (False, 8)):
         p = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_unit=fuse_unit)
         chains = [op for op in p.ops if op.get("chain")]
         assert [op["x"].c for op in chains] == [64, 64, 128, 128, 128]
@@ -268,7 +273,7 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
             own_conv2 = a.replace("/conv3", "/conv2")
             if fuse_unit:                                                                                     # ... nor conv2: it is in front
                 assert parts[0] == own_conv2 and len(parts) == 3 and not any(o["name"] == own_conv2 for o in p.ops)
-                prev = next(o for o in p.ops if o["name"].split("+")[-1] == a.replace("/conv3", "/conv1"))
+                prev = next(o for o in p.ops if a.replace("/conv3", "/conv1") in o["name"].split("+"))
                 assert op["x"] is (prev["y2"] if prev.get("chain") else prev["y"])                            # x is this unit's conv1
             else:
                 assert len(parts) == 2 and any(o["name"] == own_conv2 and o["y"] is op["x"] for o in p.ops)
