@@ -47,8 +47,8 @@ MATH = {"f32": ("conv_igemm_f32", PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_32x32x2_f32 
         "bf16x2": ("conv_igemm_bf16s<NP=2>", PEAK_BF16_MFMA_TFLOPS / 3, "2 bf16 planes, 3 MFMAs (~2^-16 relative)"),
         "bf16x1": ("conv_igemm_bf16s<NP=1>", PEAK_BF16_MFMA_TFLOPS, "plain bf16 products, fp32 accumulate"),
         # 16-bit STORAGE (configs c3-c5; not the bench line, which is fp32): --storage bf16 | f16
-        "bf16": ("the 16-bit convolution family: conv_ws (loader waves + MFMA consumer waves), conv_dma<NP=1> (LDS-DMA), conv_igemm_lp<bf16>, stem strip / halo kernels", PEAK_BF16_MFMA_TFLOPS, "bf16 activations/filters in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate + epilogue"),
-        "f16": ("the 16-bit convolution family: conv_ws (loader waves + MFMA consumer waves), conv_dma<NP=1> (LDS-DMA), conv_igemm_lp<f16>, stem strip / halo kernels", PEAK_BF16_MFMA_TFLOPS, "fp16 activations/filters in HBM, v_mfma_f32_32x32x16_f16, fp32 accumulate + epilogue")}
+        "bf16": ("the 16-bit convolution family: conv_ws (loader waves + MFMA consumer waves), conv_dma<NP=1> (LDS-DMA), conv_igemm_lp<bf16>, conv_chain_lp (ResNet bottleneck launches), stem strip / halo kernels", PEAK_BF16_MFMA_TFLOPS, "bf16 activations/filters in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate + epilogue"),
+        "f16": ("the 16-bit convolution family: conv_ws (loader waves + MFMA consumer waves), conv_dma<NP=1> (LDS-DMA), conv_igemm_lp<f16>, conv_chain_lp (ResNet bottleneck launches), stem strip / halo kernels", PEAK_BF16_MFMA_TFLOPS, "fp16 activations/filters in HBM, v_mfma_f32_32x32x16_f16, fp32 accumulate + epilogue")}
 V, H, W, G, C = 12, 224, 224, 7, 10             # configs[1]; ModelNet10 -> 10 classes
 BACKBONE = "inception_v3"
 # other BASELINE.json configs, forward pass in the dtype the config names (parity-test cases; not the bench line)
@@ -288,7 +288,7 @@ def launch_ranks(a):
 
 
 def _is_conv_kernel(n):
-    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n or "conv_ws" in n
+    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n or "conv_ws" in n or "conv_chain" in n
 
 
 def _pmc_rows(path, counter, steps, marker="dense_f32", total_steps=None):
@@ -362,7 +362,7 @@ def measure_traffic(a, tiles_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-TRAIN_FAMILIES = (("wgrad", ("conv_wgrad", "dw_reduce_slices")), ("conv", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma", "conv_ws")),
+TRAIN_FAMILIES = (("wgrad", ("conv_wgrad", "dw_reduce_slices")), ("conv", ("conv_igemm", "conv3x3_halo", "conv_stem_patch", "conv_dma", "conv_ws", "conv_chain")),
                   ("bn", ("grouped_sums", "bn_stream", "scale_shift_act_grouped", "bn_bwd_apply")),
                   ("pool", ("pool2d", "maxpool", "avgpool3x3")))
 

@@ -28,7 +28,7 @@ def tot(rows, pred):
 
 
 def is_conv(n):
-    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n or "conv_ws" in n
+    return "conv_igemm" in n or "conv3x3_halo" in n or "conv_stem_patch" in n or "conv_dma" in n or "conv_ws" in n or "conv_chain" in n
 
 
 n_conv = sum(1 for r in fetch if is_conv(r["Kernel_Name"]))
