@@ -49,6 +49,8 @@ struct WsArgs {
     int halo_lo;                               // strip rows in front of the tile's first pixel
     int strip_blocks, strip_bytes;             // 16-row blocks per strip buffer, bytes per buffer
     int na;                                    // strip buffers
+    int strip_off;                             // bytes in front of a strip buffer's rows (DIET: its own zero row, 128)
+    int tab_off;                               // DIET: LDS offset of the tap table [taps][BM] of 16-bit entries
     int pad_;
 };
 
@@ -127,7 +129,12 @@ __device__ __forceinline__ void ws_epilogue_fast(const ConvArgs& a, const f32x16
 // NL loader waves.  Eight consumers + four loaders = one 768-thread workgroup per CU; four consumers + two loaders = a
 // 384-thread workgroup, two per CU (three waves per SIMD either way: 168 registers) — the second workgroup's k-loop
 // covers the first one's epilogue, at twice the filter traffic per flop.
-template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM, int KT = 32, int NL = 4>
+// DIET (round 6, strip mode): the consumers' per-k-step address arithmetic — strip row of the tap, swizzle, out-of-image
+// select: ~20 vector instructions per k-step and row block — is replaced by a per-tile TABLE in LDS: entry [tap][row] is the
+// fragment's byte offset / 16 inside a strip buffer, or 0 = the buffer's own zero row; a k-step then needs one ds_read_u16
+// and two vector instructions per row block.  Loop body: ~15 vector + ~18 scalar instructions instead of ~34 + ~25 (12 MFMAs,
+// 10 ds_read_b128 either way).  Selected by debug bit 2097152 / GV_WS_DIET=1 — see launch_ws for the measurement.
+template <typename T, int WM, int WN, int TM, int TN, int NB, int STATS, bool GEMM, int KT = 32, int NL = 4, bool DIET = false>
 __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void conv_ws(const ConvArgs a, const WsArgs w) {
     constexpr int WS_NLW = NL;
     using G = WsGeom<KT>;
@@ -234,7 +241,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
                     for (int blk = lw; blk < w.strip_blocks; blk += WS_NLW) {
                         int p = m0 - w.halo_lo + blk * RPI + lrow;     // rows outside [0, M) are only ever read by masked taps
                         p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
-                        if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + blk * 1024);
+                        if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + w.strip_off + blk * 1024);
                     }
                 }
                 ++sq_c;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
                 for (int i = 0; i < ppi && sp_blk < w.strip_blocks; ++i, sp_blk += WS_NLW) {
                     int p = m0 - w.halo_lo + sp_blk * RPI + lrow;
                     p = p < 0 ? 0 : (p < a.M ? p : a.M - 1);
-                    if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + sp_blk * 1024);
+                    if (!nodma) ws_dma16(xb + (size_t)(unsigned)p * pix_bytes + coff, sb + w.strip_off + sp_blk * 1024);
                 }
             };
             // prologue: strip 0 and filter slice 0 first (the consumers' first fragments), then the rest of both rings
@@ -308,6 +315,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
         const int wm = wave / WN, wn = wave % WN;
         const int r = lane & 31, h = lane >> 5;
         if (tid < 32) reinterpret_cast<unsigned*>(smem)[tid] = 0u; // the zero row: bytes [0, 128)
+        if constexpr (DIET) {                                      // ... and one in front of each of the two strip buffers
+            if (tid < 64) reinterpret_cast<unsigned*>(smem + OFF_S + (tid >> 5) * w.strip_bytes)[tid & 31] = 0u;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -344,6 +354,26 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
             const int brow = (wn * TN + j) * 32 + r;
             b0[j] = OFF_B + brow * WS_RB + ((G::swz(brow) ^ h) << 4);
         }
+        // DIET: the tap table.  The WN waves that own the same rows share the taps between them; an entry is the same for
+        // both k halves (h is folded in by the reader)
+        int tab0 = 0;                                              // this lane's first row's column of the table
+        if constexpr (DIET) {
+            tab0 = w.tab_off + ((wm * TM) * 32 + r) * 2;
+            int fr = 0, fs = wn;                                   // tap wn, wn + WN, ...: (fr, fs) kept by increments
+            while (fs >= a.kw) { fs -= a.kw; ++fr; }
+            for (int t = wn; t < NTAP; t += WN) {
+                const int off = (fr - a.pad_t) * a.iw + (fs - a.pad_l);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = rbase[i] + off;
+                    const int rel = (128 + row * WS_RB + (G::swz(row) << 4)) >> 4;
+                    const int e = ((tapmask[i] >> t) & 1u) ? rel : 0;
+                    if (h == 0) *reinterpret_cast<unsigned short*>(smem + tab0 + t * (BM * 2) + i * 64) = (unsigned short)e;
+                }
+                fs += WN;
+                while (fs >= a.kw) { fs -= a.kw; ++fr; }
+            }
+        }
         // A fragment address (k16-step 0; step 1 is this ^ 32) of row block i for the tap at row shift `off` / mask bit
         // `bit`, strip buffer at byte `sbase`; a tap outside the image reads the zero row
         // (bit arithmetic, not a select: hipcc turns the select into exec-masked branches that cut the k-step's basic block)
@@ -357,7 +387,15 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
         int sbase = OFF_S, sbuf = 0, bslot = 0;                    // its strip buffer / filter slot (bytes)
         int aa[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) aa[i] = a_addr(i, -(a.pad_t * a.iw + a.pad_l), 0, sbase);
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (DIET) {                                  // (tap 0, straight from the arithmetic: the table is not published yet)
+                const int row = rbase[i] - (a.pad_t * a.iw + a.pad_l);
+                const int ad = sbase + 128 + row * WS_RB + ((G::swz(row) ^ h) << 4);
+                aa[i] = (tapmask[i] & 1u) ? ad : sbase + (h << 4);
+            } else {
+                aa[i] = a_addr(i, -(a.pad_t * a.iw + a.pad_l), 0, sbase);
+            }
+        }
         u32x4 fa[2][TM], fb[2][TN];
         auto lds16 = [&](int addr) -> u32x4 { return *reinterpret_cast<const u32x4*>(smem + addr); };
         // one fragment read (q-th of the TM + TN of a k16-step) into register set S
@@ -419,7 +457,19 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) * 3 / 12) void 
             // the next k-step's tap, strip buffer and slot (selects, no branches: a branch here would cut the basic block
             // and keep this arithmetic from being scheduled between the MFMAs below)
             int an[TM];
-            {
+            if constexpr (DIET) {
+                const bool wrap = q_tap + 1 == NTAP;
+                q_tap = wrap ? 0 : q_tap + 1;
+                const int sb1 = sbuf + 1 == w.na ? 0 : sbuf + 1;
+                sbuf = wrap ? sb1 : sbuf;
+                sbase = OFF_S + sbuf * w.strip_bytes;
+                const int tp = tab0 + q_tap * (BM * 2);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int e = *reinterpret_cast<const unsigned short*>(smem + tp + i * 64);
+                    an[i] = ((e ^ h) << 4) + sbase;
+                }
+            } else {
                 const bool wrap = q_tap + 1 == NTAP;
                 const bool row_end = q_fs + 1 == a.kw;
                 q_tap = wrap ? 0 : q_tap + 1;
@@ -523,17 +573,42 @@ int launch_ws(const ConvArgs& a0, hipStream_t st) {
     w.halo_lo = a.pad_t * a.iw + a.pad_l;
     const int halo_hi = (a.kh - 1 - a.pad_t) * a.iw + (a.kw - 1 - a.pad_l);
     w.strip_blocks = gemm ? BM / RPI : gv_ceil_div(w.halo_lo + BM + halo_hi, RPI);
-    w.strip_bytes = w.strip_blocks * 1024;
     w.na = gemm ? NB : 2;
     w.pad_ = 0;
+    // strip mode: the tap-table form (DIET), when asked for, where its table and the strip buffers' zero rows still fit the
+    // workgroup's LDS share
+    const size_t lds_cap = (size_t)(NL == 2 ? 80 : 160) * 1024;
+    // Measured NEUTRAL (profiles/r6_ws_diet_ab.txt: whole plans c3 0.249 -> 0.247, c5 0.283 -> 0.282; single layers +4 ... +6 %
+    // as warm repeats): the consumers' instruction count is not what bounds this kernel.  Kept behind debug bit 2097152 /
+    // GV_WS_DIET=1 with its parity tests; the arithmetic form stays the product.
+    static const bool env_on = getenv("GV_WS_DIET") != nullptr;
+    bool diet = !gemm && ((a.dbg & 2097152) || env_on);
+    if (diet && (size_t)WS_ZERO + (size_t)NB * BN * WS_RB + 2 * ((size_t)128 + w.strip_blocks * 1024) +
+                    ((size_t)w.taps * BM * 2 + 127) / 128 * 128 > lds_cap)
+        diet = false;
+    w.strip_off = diet ? 128 : 0;
+    w.strip_bytes = w.strip_off + w.strip_blocks * 1024;
     a.tiles_n = gv_ceil_div(a.cout, BN);
     const int64_t nwg = (int64_t)gv_ceil_div(a.M, BM) * a.tiles_n;
     if (nwg > 0x7fffffff) return GV_E_UNSUPPORTED;
-    const size_t ring = (size_t)WS_ZERO + (size_t)NB * BN * WS_RB + (size_t)w.na * w.strip_bytes;
+    size_t ring = (size_t)WS_ZERO + (size_t)NB * BN * WS_RB + (size_t)w.na * w.strip_bytes;
+    w.tab_off = (int)ring;
+    if (diet) ring += ((size_t)w.taps * BM * 2 + 127) / 128 * 128;   // (16-bit entries: offsets / 16 — any strip fits)
     const size_t epi = (size_t)ws_epi_bytes<WM, WN, TN>();
     const size_t lds = ring > epi ? ring : epi;
     if (lds > (NL == 2 ? 80 : 160) * 1024) return GV_E_UNSUPPORTED;   // (two of the small workgroups per CU)
     auto go = [&](auto mode, auto gm) -> int {
+        constexpr bool GM = decltype(gm)::value;
+        if (!GM && diet) {
+            auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, false, KT, NL, true>;
+            if (lds > 64 * 1024) {
+                const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);
+                if (!ok) return GV_E_UNSUPPORTED;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((NC + NL) * 64), lds, st, a, w);
+            GV_LAUNCH_CHECK();
+            return GV_OK;
+        }
         auto kern = &conv_ws<T, WM, WN, TM, TN, NB, decltype(mode)::value, decltype(gm)::value, KT, NL>;
         if (lds > 64 * 1024) {
             const bool ok = GV_BIG_LDS_OK(kern, 160 * 1024);

@@ -367,6 +367,14 @@ def test_lp_ws_tiles_plain_destination_fast_epilogue(k, cin, cout, hw, nb, ty, r
         finally:
             lib().gv_conv2d_set_debug(0)
         assert np.array_equal(y, y_gen), "tile %d: fast and general epilogue differ" % ws_tiles().index(tile)
+        # the consumers' tap-table form (round 6, debug bit 2097152; an A/B variant, not the product): the same fragments from
+        # the same LDS bytes in the same order — bit for bit
+        lib().gv_conv2d_set_debug(2097152)
+        try:
+            y_tab = run_conv(x, w, 1, pads, (ih, iw), scale, shift, relu, ty, **kw)
+        finally:
+            lib().gv_conv2d_set_debug(0)
+        assert np.array_equal(y, y_tab), "tile %d: tap-table consumers differ" % ws_tiles().index(tile)
     assert ran >= 5
 
 
