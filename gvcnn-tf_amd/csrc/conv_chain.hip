@@ -99,6 +99,11 @@ template <int D> struct ChainGeom {
     static constexpr int TAPB = D * RBW1;
     static constexpr int TPS = SLOT / TAPB;
     static constexpr int NPRE = (9 + TPS - 1) / TPS;
+    // FRONT: fragment loads run FD taps ahead (a d = 64 tap is 8 MFMAs, ~260 clocks, an L2-hit load 500 - 800: one tap of lead
+    // stalled every tap; d = 128's tap is 32 MFMAs and its fragments are 32 registers: one tap ahead).  front_loads: the loads
+    // issued while the taps [lo, hi) are multiplied (tap t requests tap t + FD)
+    static constexpr int FD = D <= 64 ? 3 : 1;
+    static constexpr int front_loads(int lo, int hi) { int n = 0; for (int t = lo; t < hi && t < 9; ++t) n += t + FD < 9 ? KS1 : 0; return n; }
     template <int NW> static constexpr int lds_bytes() { return NR * SLOT + NW * STAGE + (4 * N1 + 4 * N2) * 4; }
 };
 
@@ -241,7 +246,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         const char* pm = reinterpret_cast<const char*>(a.x) + ((size_t)m * a.x_ld + h * 8) * 2;
         const char* zp = a.zeros + h * 16;
         const long long row_b = (long long)a.iw * a.x_ld * 2, pix_b = (long long)a.x_ld * 2;
-        u32x4 fa[2][KS1];
+        constexpr int FD = G::FD, FS = FD + 1;                     // lead of the fragment loads in taps, register sets
+        u32x4 fa[FS][KS1];
         auto tap_load = [&](auto tc, u32x4 (&dst)[KS1]) {
             constexpr int t = decltype(tc)::value;
             const long long off = (t / 3 - 1) * row_b + (t % 3 - 1) * pix_b;           // (wave-uniform)
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
 #pragma unroll
             for (int s = 0; s < KS1; ++s) dst[s] = *reinterpret_cast<const u32x4*>(src + s * 32);
         };
-        tap_load(std::integral_constant<int, 0>{}, fa[0]);
+        ch_for_each([&](auto tc) { tap_load(tc, fa[decltype(tc)::value % FS]); }, std::make_integer_sequence<int, FD>{});
         if constexpr (EARLY_RV) load_rv();
         f32x16 acc0[NB2];
 #pragma unroll
@@ -265,23 +271,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
             // the taps of pre-chunk pc have landed: their DMAs were issued at the top of pre-chunk pc - 1 (pc = 0: in front of
             // the first tap's loads); behind them came only the fragment loads of the taps that pre-chunk started
             constexpr int t_lo = pc * TPS, t_hi = (pc + 1) * TPS < 9 ? (pc + 1) * TPS : 9;
-            constexpr int prev_lo = (pc - 1) * TPS, prev_hi = pc * TPS;   // taps of the previous pre-chunk: each loaded tap + 1
-            if constexpr (pc == 0) ch_wait_vm<KS1 + (EARLY_RV ? 4 * RVS : 0)>();
-            else ch_wait_vm<(prev_hi - prev_lo) * KS1>();
+            if constexpr (pc == 0) ch_wait_vm<FD * KS1 + (EARLY_RV ? 4 * RVS : 0)>();
+            else ch_wait_vm<G::front_loads((pc - 1) * TPS, pc * TPS)>();
             __builtin_amdgcn_s_barrier();
             if constexpr (pc + 1 < NPRE) issue_pre(std::integral_constant<int, pc + 1>{}, (pc + 1) % NR);
             else issue_chunk(0, NPRE % NR);
             const char* slot = smem + (pc % NR) * SLOT;
             ch_for_each([&](auto tc) {
                 constexpr int t = t_lo + decltype(tc)::value;
-                if constexpr (t + 1 < 9) tap_load(std::integral_constant<int, t + 1>{}, fa[(t + 1) & 1]);
+                if constexpr (t + FD < 9) tap_load(std::integral_constant<int, t + FD>{}, fa[(t + FD) % FS]);
                 const char* ft = slot + (t - t_lo) * TAPB;
 #pragma unroll
                 for (int s = 0; s < KS1; ++s) {
 #pragma unroll
                     for (int j = 0; j < NB2; ++j) {
                         const u32x4 b = lds16(ft + f_row[j] + (((2 * s + h) ^ f_sw[j]) << 4));
-                        acc0[j] = mfma16<T>(fa[t & 1][s], b, acc0[j]);
+                        acc0[j] = mfma16<T>(fa[t % FS][s], b, acc0[j]);
                     }
                 }
             }, std::make_integer_sequence<int, t_hi - t_lo>{});
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         // and (where there still was a chunk to prefetch) 4 shortcut loads — everything older is complete.  Then every wave
         // is done with chunk c - 1, whose slot takes chunk c + 1.
         // (FRONT: chunk 0's DMAs went out at the top of the last pre-chunk, in front of that pre-chunk's tap loads)
-        if constexpr (c == 0) ch_wait_vm<(FRONT ? (9 - (NPRE - 1) * TPS - 1) * KS1 : KS1) + (EARLY_RV ? 0 : 4 * RVS)>();
+        if constexpr (c == 0) ch_wait_vm<(FRONT ? G::front_loads((NPRE - 1) * TPS, 9) : KS1) + (EARLY_RV ? 0 : 4 * RVS)>();
         else ch_wait_vm<4 + ((c - 1) + RVS < NCH ? 4 : 0)>();
         __builtin_amdgcn_s_barrier();
         if constexpr (c + 1 < NCH) issue_chunk(c + 1, (NPRE + c + 1) % NR);
