@@ -28,6 +28,14 @@ def short(n):
     if m:
         t, np_, wm, wn, tm, tn, st, epi = m.groups()
         return "conv_dma<%s,NP=%s,%sx%s waves,%sx%s tiles,ST=%s,EPI=%s>" % ("bf16" if t == "b" else "f16", np_, wm, wn, tm, tn, st, epi)
+    m = re.match(r"_ZN12_GLOBAL__N_113conv_chain_lpIDF16(.)Li(\d+)ELi(\d)ELi(\d)ELb(\d)E", n)
+    if m:
+        t, d, nw, rvs, front = m.groups()
+        return "conv_chain_lp<%s,d=%s,%s waves,%s>" % ("bf16" if t == "b" else "f16", d, nw, "conv2 in front (unit)" if front == "1" else "chain")
+    m = re.match(r"_ZN12_GLOBAL__N_17conv_wsIDF16(.)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELi(\d+)ELi(\d)E", n)
+    if m:
+        t, wm, wn, tm, tn, nb, st, gemm, kt, nl = m.groups()
+        return "conv_ws<%s,%sx%s waves,%sx%s tiles,NB=%s,%s,KT=%s,NL=%s>" % ("bf16" if t == "b" else "f16", wm, wn, tm, tn, nb, "GEMM" if gemm == "1" else "strip", kt, nl)
     return n.split("(")[0].replace("void ", "")[:70]
 
 
