@@ -469,6 +469,23 @@ def test_hipgraph_replay_matches_eager(lanes):
     eng.check_status()
 
 
+def test_hipgraph_replay_of_the_16bit_resnet_plan_with_bottleneck_launches():
+    """The same for the 16-bit ResNet-v2-50 plan of round 6 — one launch per bottleneck unit in blocks 1 and 2
+    (gv_bottleneck_unit_fwd: inline-asm LDS-DMA, a zero page, > 64 KB of dynamic LDS) — captured into a hipGraph."""
+    N, V, C, G = 2, 3, 10, 10
+    eng, P, Hd = make_engine("resnet_v2_50", N, V, 64, 64, C, G, storage="bf16")
+    assert sum(1 for op in eng.plan.ops if op.get("chain")) == 5
+    x = views(N, V, 64, 64, seed=4).to(DEV)
+    replay = eng.capture(x)
+    x2 = views(N, V, 64, 64, seed=9).to(DEV)
+    s_e, S_e, l_e = [t.clone() for t in eng.forward(x2)]
+    x.copy_(x2)
+    s_g, S_g, l_g = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(s_g, s_e) and torch.equal(S_g, S_e) and torch.equal(l_g, l_e)
+    eng.check_status()
+
+
 def test_bench_line_contract():
     """bench.py prints exactly ONE JSON line with every key the driver and the judge read (metric/value/unit/n_gpus/
     steps/warmup/ms_per_step/higher_is_better/scaling/vs_baseline/dtype/data/config + roofline + cpu_baseline)."""
