@@ -97,7 +97,7 @@ template <int D> struct ChainGeom {
     // FRONT: a conv2 tap's filter tile is [d columns][d channels] = d rows of RBW1 bytes (the shape of W1's rows); a slot
     // takes TPS taps, the nine taps arrive in NPRE "pre-chunks" in front of the NCH chunks
     static constexpr int TAPB = D * RBW1;
-    static constexpr int TPS = SLOT / TAPB;
+    static constexpr int TPS = SLOT / TAPB > 0 ? SLOT / TAPB : 1;   // (d = 256 has no FRONT form: TAIL only)
     static constexpr int NPRE = (9 + TPS - 1) / TPS;
     // FRONT: fragment loads run FD taps ahead (a d = 64 tap is 8 MFMAs, ~260 clocks, an L2-hit load 500 - 800: one tap of lead
     // stalled every tap; d = 128's tap is 32 MFMAs and its fragments are 32 registers: one tap ahead).  front_loads: the loads
@@ -108,11 +108,16 @@ template <int D> struct ChainGeom {
 };
 
 // RVS: register sets of the shortcut prefetch (2: a chunk's shortcut is requested two chunks ahead; 1: one chunk ahead)
-template <typename T, int D, int NW, int RVS, bool FRONT = false>
+// TAIL: only the SECOND half — z = relu(bn(conv1x1(relu(y * pscale + pshift)))) with y read from memory through the prefetch
+// registers (a.res = y): gv_conv2d_fwd_xpre's class 4d -> d as a streaming launch (no GEMM 1, no store of y; the ring carries
+// conv1's filter only).  Serves the identity units the chain does not (d = 256: block3 of ResNet-v2-50).
+template <typename T, int D, int NW, int RVS, bool FRONT = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     using G = ChainGeom<D>;
+    static_assert(!(FRONT && TAIL), "one or the other");
     constexpr int N1 = G::N1, N2 = G::N2, KS1 = G::KS1, NB2 = G::NB2, NCH = G::NCH;
-    constexpr int RBW1 = G::RBW1, CPR1 = G::CPR1, RPP1 = G::RPP1, W1C = G::W1C, SLOT = G::SLOT, NP1 = G::NP1, NPC = G::NPC;
+    constexpr int RBW1 = G::RBW1, CPR1 = G::CPR1, RPP1 = G::RPP1;
+    constexpr int W1C = TAIL ? 0 : G::W1C, SLOT = W1C + G::W2C, NP1 = W1C / 1024, NPC = SLOT / 1024;
     constexpr int NR = G::NR, STAGE = G::STAGE;
     constexpr int PPW = NPC / NW;                  // DMA instructions per wave and chunk
     static_assert(NPC % NW == 0 && NCH >= 2 && NB2 % 2 == 0, "chunk geometry");
@@ -124,8 +129,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     const int mw = blockIdx.x * (NW * 32) + wave * 32;     // this wave's first row
     float* const tab = reinterpret_cast<float*>(smem + OFF_TAB);   // [sc1 N1][sh1 N1][psc N1][psh N1][sc2 N2][sh2 N2]
     for (int i = tid; i < N1; i += NW * 64) {
-        tab[i] = a.sc1[i];
-        tab[N1 + i] = a.sh1[i];
+        if constexpr (!TAIL) {
+            tab[i] = a.sc1[i];
+            tab[N1 + i] = a.sh1[i];
+        }
         tab[2 * N1 + i] = a.psc[i];
         tab[3 * N1 + i] = a.psh[i];
     }
@@ -200,7 +207,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
             for (int p = 0; p < 4; ++p) rv[q][p] = *reinterpret_cast<const u32x4*>(rrow_p[p] + q * 64);
     };
     u32x4 xa[KS1];
-    if constexpr (!FRONT) {
+    if constexpr (TAIL) {
+        issue_chunk(0, 0);
+    } else if constexpr (!FRONT) {
         issue_chunk(0, 0);
         // ---- this wave's rows of x as A fragments (lane: row lane & 31, k 8 * (lane >> 5) ... + 7 of each 16-step) ----
         const int row = min(mw + r32, a.M - 1);
@@ -354,33 +363,36 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         // and (where there still was a chunk to prefetch) 4 shortcut loads — everything older is complete.  Then every wave
         // is done with chunk c - 1, whose slot takes chunk c + 1.
         // (FRONT: chunk 0's DMAs went out at the top of the last pre-chunk, in front of that pre-chunk's tap loads)
-        if constexpr (c == 0) ch_wait_vm<(FRONT ? G::front_loads((NPRE - 1) * TPS, 9) : KS1) + (EARLY_RV ? 0 : 4 * RVS)>();
-        else ch_wait_vm<4 + ((c - 1) + RVS < NCH ? 4 : 0)>();
+        // (TAIL: no x fragments, no stores in the loop)
+        if constexpr (c == 0) ch_wait_vm<(TAIL ? 0 : FRONT ? G::front_loads((NPRE - 1) * TPS, 9) : KS1) + (EARLY_RV ? 0 : 4 * RVS)>();
+        else ch_wait_vm<(TAIL ? 0 : 4) + ((c - 1) + RVS < NCH ? 4 : 0)>();
         __builtin_amdgcn_s_barrier();
         if constexpr (c + 1 < NCH) issue_chunk(c + 1, (NPRE + c + 1) % NR);
         const char* slot = smem + ((NPRE + c) % NR) * SLOT;
+        if constexpr (!TAIL) {
         // ---- GEMM 1: 32 rows x 64 columns, K1 deep ----
-        f32x16 acc1[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc1[j][q] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const u32x4 b = lds16(slot + b1_row[j] + (((2 * s + h) ^ b1_sw[j]) << 4));
-                acc1[j] = mfma16<T>(xa[s], b, acc1[j]);
+            f32x16 acc1[2];
+    #pragma unroll
+            for (int j = 0; j < 2; ++j)
+    #pragma unroll
+                for (int q = 0; q < 16; ++q) acc1[j][q] = 0.f;
+    #pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 b = lds16(slot + b1_row[j] + (((2 * s + h) ^ b1_sw[j]) << 4));
+                    acc1[j] = mfma16<T>(xa[s], b, acc1[j]);
+                }
             }
+            // ---- its epilogue: transpose through the wave's staging block, + bias + shortcut, one rounding, store; the rounded
+            //      values through the next unit's BatchNorm + ReLU into the wave's z tile ----
+    #pragma unroll
+            for (int j = 0; j < 2; ++j)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<float*>(stage + woff + ((r & 3) + 8 * (r >> 2)) * 256 + j * 128) = acc1[j][r];
+            __builtin_amdgcn_wave_barrier();
         }
-        // ---- its epilogue: transpose through the wave's staging block, + bias + shortcut, one rounding, store; the rounded
-        //      values through the next unit's BatchNorm + ReLU into the wave's z tile ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                *reinterpret_cast<float*>(stage + woff + ((r & 3) + 8 * (r >> 2)) * 256 + j * 128) = acc1[j][r];
-        __builtin_amdgcn_wave_barrier();
         {
             const float* t = tab + c * 64 + c8 * 8;
             float sc[8], sh[8], ps[8], ph[8];
@@ -395,21 +407,25 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const f32x4 lo = lds16f(stage + roff + p * 2048);
-                const f32x4 hi = lds16f(stage + roff + p * 2048 + 16);
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                const u32x4 rq = rv[SET][p];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[2 * j] += from_bits<T>((unsigned short)(rq[j] & 0xffffu));
-                    v[2 * j + 1] += from_bits<T>((unsigned short)(rq[j] >> 16));
-                }
                 u32x4 o;
+                if constexpr (TAIL) {
+                    o = rv[SET][p];                                // the stored y itself
+                } else {
+                    const f32x4 lo = lds16f(stage + roff + p * 2048);
+                    const f32x4 hi = lds16f(stage + roff + p * 2048 + 16);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
-                *reinterpret_cast<u32x4*>(yrow[p] + c * 64) = o;
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                    const u32x4 rq = rv[SET][p];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[2 * j] += from_bits<T>((unsigned short)(rq[j] & 0xffffu));
+                        v[2 * j + 1] += from_bits<T>((unsigned short)(rq[j] >> 16));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
+                    *reinterpret_cast<u32x4*>(yrow[p] + c * 64) = o;
+                }
                 // relu(x * pscale + pshift) of the STORED value, rounded once (gv_conv2d_fwd_xpre's loader)
                 u32x4 zq;
 #pragma unroll
@@ -473,12 +489,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     ch_wait_vm<0>();                                               // (nothing of this workgroup may still be landing in LDS)
 }
 
-template <typename T, int D, int NW, int RVS, bool FRONT = false>
+template <typename T, int D, int NW, int RVS, bool FRONT = false, bool TAIL = false>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
     using G = ChainGeom<D>;
-    constexpr int lds = G::template lds_bytes<NW>();
+    constexpr int lds = G::template lds_bytes<NW>() - (TAIL ? G::NR * G::W1C : 0);
     static_assert(lds <= 160 * 1024, "one workgroup's LDS");
-    auto kern = &conv_chain_lp<T, D, NW, RVS, FRONT>;
+    auto kern = &conv_chain_lp<T, D, NW, RVS, FRONT, TAIL>;
     if (lds > 64 * 1024) {
         const bool ok = GV_BIG_LDS_OK(kern, lds);
         if (!ok) return GV_E_UNSUPPORTED;
@@ -507,9 +523,51 @@ int launch_chain_d(int d, const ChainArgs& a, hipStream_t st) {
     return GV_E_UNSUPPORTED;
 }
 
+template <typename T>
+int launch_tail_d(int d, const ChainArgs& a, hipStream_t st) {
+    switch (d) {
+        case 64: return launch_chain<T, 64, 4, 2, false, true>(a, st);
+        case 128: return launch_chain<T, 128, 8, 2, false, true>(a, st);
+        case 256: return launch_chain<T, 256, 8, 2, false, true>(a, st);
+    }
+    return GV_E_UNSUPPORTED;
+}
+
 int g_chain_debug = 0;
 
 }  // namespace
+
+namespace gvconv {
+
+// gv_conv2d_fwd_xpre's class "1x1, cin = 4 * cout, BatchNorm + ReLU on every column, one 16-bit destination" (the conv1 of a
+// ResNet-v2 identity unit reading the unit input through its folded pre-activation, nets/resnet_v2.py:75,83-84) as the TAIL
+// form of the bottleneck launch: a tile configuration of its own (the convolution entry point offers it under the special
+// tile index), bit for bit the register-staged kernels' result.
+bool chain_tail_ok(const ConvArgs& a) {
+    return a.xscale != nullptr && a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 && a.cin == 4 * a.cout &&
+           (a.cout == 64 || a.cout == 128 || a.cout == 256) && a.res == nullptr && a.y2 == nullptr && a.split == 0 && a.relu &&
+           a.relu_limit >= a.cout && a.x_ld % 8 == 0 && a.y_ld % 8 == 0 && gv_aligned16(a.x) && gv_aligned16(a.y) &&
+           gv_aligned16(a.w) && a.st.mode == STAT_OFF && a.y_step == 0 && a.dil_shift == 0 && a.pool == 0;
+}
+
+int chain_tail_launch(int dtype, const ConvArgs& a, hipStream_t st) {
+    if (!chain_tail_ok(a)) return GV_E_UNSUPPORTED;
+    ChainArgs c;
+    c.x = nullptr; c.w1 = nullptr; c.sc1 = c.sh1 = nullptr; c.y = nullptr;
+    c.res = reinterpret_cast<const unsigned short*>(a.x);          // the unit input, read through the prefetch registers
+    c.psc = a.xscale; c.psh = a.xshift;
+    c.w2 = reinterpret_cast<const unsigned short*>(a.w); c.sc2 = a.scale; c.sh2 = a.shift;
+    c.z = reinterpret_cast<unsigned short*>(a.y);
+    c.M = a.M; c.x_ld = 0; c.res_ld = a.x_ld; c.y_ld = 0; c.z_ld = a.y_ld;
+    c.relu2 = 1;
+    c.dbg = g_chain_debug;
+    c.w0 = nullptr; c.sc0 = c.sh0 = nullptr; c.zeros = nullptr; c.ih = c.iw = 0;
+    if (dtype == GV_BF16) return launch_tail_d<__bf16>(a.cout, c, st);
+    if (dtype == GV_F16) return launch_tail_d<_Float16>(a.cout, c, st);
+    return GV_E_UNSUPPORTED;
+}
+
+}  // namespace gvconv
 
 extern "C" void gv_bottleneck_chain_set_debug(int bits) { g_chain_debug = bits; }
 

@@ -139,6 +139,9 @@ int dma_lp_num_cfgs();
 bool dma_lp_ok(const ConvArgs& a, bool generic, bool xf32);
 int dma_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);
 const void* dma_zero_page();   // one zero page per device for padding taps / rows past the end
+// conv_chain.hip: the conv1-behind-a-pre-activation class of gv_conv2d_fwd_xpre (1x1, cin = 4 * cout) as a streaming launch
+bool chain_tail_ok(const ConvArgs& a);
+int chain_tail_launch(int dtype, const ConvArgs& a, hipStream_t st);
 // conv_ws.hip (wave-specialised kernel: loader waves + MFMA consumer waves; configurations follow the LDS-DMA tiles)
 int ws_lp_num_cfgs();
 int ws_lp_launch(int dtype, int cfg, const ConvArgs& a, hipStream_t st);

@@ -594,6 +594,9 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
             // pre-activation on load: the register-staged loader of the 1x1 / unpadded class (a padding tap would have
             // to read relu(xshift), not 0), (scale, shift) table of the input channels in LDS
             const int want = g_tile_override >= 0 && g_tile_override < ncfg ? g_tile_override : d->tile_cfg - 1;
+            // the special tile index: the streaming TAIL form of the bottleneck launch (csrc/conv_chain.hip), where it serves
+            if (want == gvconv::lp_special_cfg() && !generic)
+                return gvconv::chain_tail_launch(d->dtype, a, (hipStream_t)stream);
             if (generic || d->kh != 1 || d->kw != 1 || d->pad_t != 0 || d->pad_l != 0 || a.dil_shift ||
                 d->cin > 2048 || (want >= 0 && !gvconv::lp_xpre_cfg_ok(want)))
                 return GV_E_UNSUPPORTED;

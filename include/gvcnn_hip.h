@@ -210,7 +210,10 @@ int gv_conv2d_fwd(const gv_conv_desc* d, const void* x, const void* w_packed,
  * ResNet-v2 unit (nets/resnet_v2.py:75) applied by the convolution that consumes it (conv1, nets/resnet_v2.py:83), so
  * that the unit before it writes `shortcut + residual` (nets/resnet_v2.py:91) once and no pre-activation tensor exists.
  * 16-bit storage (GV_BF16 / GV_F16), 1x1 window, no padding, cin a multiple of 8 and <= 2048, 16-byte aligned pixels;
- * tile_cfg 0 or one of the register-staged tiles {1, 2, 7, 8, 9}; anything else: GV_E_UNSUPPORTED. */
+ * tile_cfg 0 or one of the register-staged tiles {1, 2, 7, 8, 9}; or gv_conv2d_special_tile_cfg(-1) + 1: the streaming form
+ * (csrc/conv_chain.hip, TAIL) for cin = 4 * cout, cout 64 / 128 / 256, BatchNorm + ReLU on every column, one destination, no
+ * residual — the conv1 of a bottleneck identity unit — bit for bit the register-staged result; anything else:
+ * GV_E_UNSUPPORTED. */
 int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const float* xscale, const float* xshift,
                        const void* w_packed, const float* scale, const float* shift, const void* residual,
                        void* y, void* y2, const float* scale2, const float* shift2, void* stream);

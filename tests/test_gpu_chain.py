@@ -235,3 +235,36 @@ def test_resnet_plan_with_whole_unit_launches(ty, size, nb):
         ref = ep[k].numpy()
         for o in outs:
             assert float(np.linalg.norm(o[k][:2].numpy() - ref) / np.linalg.norm(ref)) < bound, k
+
+
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("d,hw,nb", [(64, (9, 10), 3), (128, (7, 7), 5), (256, (14, 14), 3), (256, (3, 5), 1)])
+def test_tail_form_of_conv1_behind_a_preactivation(d, hw, nb, ty):
+    """gv_conv2d_fwd_xpre's class `1x1, cin = 4 * cout, BatchNorm + ReLU` (the conv1 of a bottleneck identity unit reading the
+    unit input through its folded pre-activation, nets/resnet_v2.py:75,83-84) as the TAIL form of the bottleneck launch (the
+    special tile index): bit for bit the register-staged kernel, within the storage rounding of the oracle; other classes are
+    declined under that index."""
+    from test_gpu_lowp import oracle_conv, run_conv, special_tile
+    code, td, ulp = TYPES[ty]
+    g = torch.Generator().manual_seed(d + hw[0])
+    cin = 4 * d
+    x = rnd(torch.randn(nb, hw[0], hw[1], cin, generator=g), td)
+    w = rnd(torch.randn(1, 1, cin, d, generator=g) * (1.0 / cin) ** 0.5, td)
+    xs, xh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    scale, shift = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    sp = special_tile() + 1
+    kw = dict(xpre=(xs, xh), x_ld=cin + 8, x_off=8, y_ld=d + 8, y_off=0)
+    y_ref = run_conv(x, w, 1, (0, 0), hw, scale, shift, True, ty, **kw)
+    y_tail = run_conv(x, w, 1, (0, 0), hw, scale, shift, True, ty, tile_cfg=sp, **kw)
+    assert np.array_equal(y_tail, y_ref)
+    # (the oracle's pre-activation is a multiply and an add, the kernels' one fma: an element of it may round the other way,
+    # which K = 4d products turn into ~1e-3 of the output's scale on a handful of elements)
+    pre = rnd(torch.relu(x * xs + xh), td)
+    close(y_tail, oracle_conv(pre, w, 1, "VALID", scale, shift, True).numpy(), ulp, extra=2e-3)
+    # not this form's: no ReLU, a residual, cin != 4 * cout
+    U = _lib.GV_E_UNSUPPORTED
+    run_conv(x, w, 1, (0, 0), hw, scale, shift, False, ty, tile_cfg=sp, expect=U, **kw)
+    res = rnd(torch.randn(nb, hw[0], hw[1], d, generator=g), td)
+    run_conv(x, w, 1, (0, 0), hw, scale, shift, True, ty, tile_cfg=sp, residual=res, expect=U, **kw)
+    w2 = rnd(torch.randn(1, 1, cin, 2 * d, generator=g) * 0.05, td)
+    run_conv(x, w2, 1, (0, 0), hw, torch.ones(2 * d), torch.zeros(2 * d), True, ty, tile_cfg=sp, expect=U, xpre=(xs, xh))
