@@ -1,4 +1,7 @@
 // conv_chain.hip — the TAIL of one ResNet-v2 bottleneck unit and the HEAD of the next as ONE launch (round 6).
+// Three forms of one kernel: the chain (gv_bottleneck_chain_fwd: conv3 + shortcut, next pre-activation, next conv1), the
+// whole unit (gv_bottleneck_unit_fwd: FRONT = the unit's own conv2 3x3 in front of the chain) and the chain's second half
+// alone (TAIL: gv_conv2d_fwd_xpre's class 1x1 / cin = 4 cout, offered as a tile configuration of that entry point).
 //
 // Reference: nets/resnet_v2.py:87-91 (conv3 1x1 + bias, `output = shortcut + residual`) of unit u, then, in unit u+1,
 // :75 (`preact = batch_norm(inputs, activation_fn=relu)`) and :83-84 (conv1 1x1 -> BatchNorm -> ReLU).  Between two units
