@@ -429,3 +429,55 @@ def test_moving_average_count_is_the_global_sample_count():
     vg, s = sh.hybrid_grid(12, 8)
     n_global = 32
     assert sh.moving_average_count(n_global // s, s, 144) == n_global * 144    # what the unsharded engine counts
+
+
+def _forced_one_rank_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gv_sharding", os.path.join(root, "gvcnn-tf_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    g = torch.Generator().manual_seed(0)
+    r = torch.rand(12, generator=g)
+    F = torch.randn(2, 6, 3, 3, 8, generator=g)
+    out = {}
+    # not forced: a one-rank group exchanges nothing (the very same tensors come back)
+    out["solo_identity"] = sh.gather_scores(r) is r and sh.gather_descriptors(F) is F and sh.allreduce_sum_(r) is r
+    sh.set_force_collectives(True)
+    r2, F2, Fv = sh.gather_scores(r), sh.gather_descriptors(F), sh.gather_views(F, None, 6)
+    out["forced_new_tensors"] = r2 is not r and F2 is not F
+    out["forced_same_values"] = bool(torch.equal(r2, r) and torch.equal(F2, F) and torch.equal(Fv, F))
+    d = torch.empty_like(F)
+    sh.direct_all_gather(d, F)                                   # no peers: the local copy only
+    out["direct"] = bool(torch.equal(d, F))
+    gs = [torch.randn(5, generator=g), torch.randn(3, 4, generator=g)]
+    keep = [t.clone() for t in gs]
+    out["buckets"] = sh.allreduce_sum_bucketed(gs, bucket_bytes=16)
+    out["bucket_values"] = bool(all(torch.equal(a, b) for a, b in zip(gs, keep)))
+    flat = torch.randn(1000, generator=g)
+    want = flat.clone()
+    red = sh.OverlappedFlatAllReduce(flat, 800, bucket_bytes=4 * 256)
+    for lo in (700, 300, 0):
+        red.progress(lo)
+    out["overlap_launches"] = red.finish()
+    out["overlap_values"] = bool(torch.equal(flat, want))
+    sh.set_force_collectives(False)
+    ret[0] = out
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_on_a_one_rank_group():
+    """GV_FORCE_COLLECTIVES / set_force_collectives (what the one-rank RCCL test of the GPU box relies on): a one-rank group
+    exchanges nothing by default; forced, every helper goes through its collective and returns the same values."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_forced_one_rank_worker, args=(port, ret), nprocs=1, join=True)
+    out = ret[0]
+    assert out["solo_identity"] and out["forced_new_tensors"] and out["forced_same_values"] and out["direct"]
+    assert out["buckets"] >= 2 and out["bucket_values"]
+    assert out["overlap_launches"] >= 2 and out["overlap_values"]
