@@ -1025,7 +1025,11 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         # (identity shortcut, conv1 the pre-activation's only reader) and the bottleneck depth is one the kernel serves;
         # with fuse_unit this unit's conv2 (stride 1 here: the strided unit is a block's last) runs in front of it
         chains = i + 1 < len(units) and units[i + 1][1] * 4 == depth and getattr(b, "fuse_chain", False) and b.chain_ok(r)
-        whole = chains and getattr(b, "fuse_unit", False) and stride == 1
+        # (whole units where that pays: d = 64.  At d = 128 the unit launch measured level with chain + conv2 — 0.276 against
+        # 0.166 + 0.107 ms, profiles/r6_seq_vs_warm_c4_*.txt — its conv2 phase is matrix-heavy and its one 8-wave workgroup per
+        # CU runs the phases in lockstep; fuse_unit="all" asks for it anyway)
+        fu = getattr(b, "fuse_unit", False)
+        whole = chains and bool(fu) and stride == 1 and (r.c <= 64 or fu == "all")
         if not whole:
             r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
         nxt = None
@@ -1099,7 +1103,9 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     b.fuse_maxpool = b.fuse_maxpool and bool(fuse_maxpool)      # (A/B switch: False = Conv2d_2b and MaxPool_3a as two launches)
     # conv3 + next preact + conv1 as one launch (ResNet-v2 blocks 1 and 2 on 16-bit storage); GV_NO_CHAIN=1: whole-plan A/B
     b.fuse_chain = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_CHAIN") is None
-    b.fuse_unit = b.fuse_chain and bool(fuse_unit) and os.environ.get("GV_NO_UNIT") is None     # (GV_NO_UNIT=1: chain only, A/B)
+    b.fuse_unit = (fuse_unit if b.fuse_chain and fuse_unit and os.environ.get("GV_NO_UNIT") is None else False)   # (GV_NO_UNIT=1: chain only, A/B)
+    if b.fuse_unit and os.environ.get("GV_UNIT_ALL") is not None:
+        b.fuse_unit = "all"
     b.fuse_pair = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_PAIR") is None
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)

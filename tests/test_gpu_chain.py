@@ -220,7 +220,8 @@ def test_resnet_plan_with_whole_unit_launches(ty, size, nb):
     x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5)
     outs = []
     for fuse in (True, False):
-        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse)
+        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse,
+                                   fuse_unit="all")                     # (every chain with its conv2 in front: d = 128 too)
         P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
         plan.bind(P)
         plan.run(x.to(DEV))

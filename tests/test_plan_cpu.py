@@ -255,11 +255,12 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
     assert [(op["split"], op["cout"], op["relu_cols"]) for op in pairs] == [(128, 640, 128), (256, 1280, 256), (512, 2560, 512)]   # (block1's: slower, not fused)
     assert all(op["name"].split("+")[0].endswith("unit_1/bottleneck_v2/conv1") and op["name"].endswith("unit_1/bottleneck_v2/shortcut")
                for op in pairs)
-    for fuse_unit, fewer in ((True, 13), (False, 8)):
+    for fuse_unit, fewer, fronts in (("all", 13, 5), (True, 10, 2), (False, 8, 0)):       # (default: whole units at d = 64 only)
         p = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_unit=fuse_unit)
         chains = [op for op in p.ops if op.get("chain")]
         assert [op["x"].c for op in chains] == [64, 64, 128, 128, 128]
-        assert all(bool(op["chain"].get("front")) == fuse_unit for op in chains)
+        assert sum(1 for op in chains if op["chain"].get("front")) == fronts
+        assert all(bool(op["chain"].get("front")) == (fuse_unit == "all" or (fuse_unit is True and op["x"].c == 64)) for op in chains)
         assert len(p.ops) == len(off.ops) - fewer
         for op in chains:
             parts = op["name"].split("+")
@@ -271,7 +272,7 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
             assert nxt["x"] is op["y2"] and p.ops.index(nxt) > p.ops.index(op)                                # conv2 reads the chain's z
             assert not any(o["name"] == b for o in p.ops)                                                     # no separate conv1
             own_conv2 = a.replace("/conv3", "/conv2")
-            if fuse_unit:                                                                                     # ... nor conv2: it is in front
+            if op["chain"].get("front"):                                                                      # ... nor conv2: it is in front
                 assert parts[0] == own_conv2 and len(parts) == 3 and not any(o["name"] == own_conv2 for o in p.ops)
                 prev = next(o for o in p.ops if a.replace("/conv3", "/conv1") in o["name"].split("+"))
                 assert op["x"] is (prev["y2"] if prev.get("chain") else prev["y"])                            # x is this unit's conv1

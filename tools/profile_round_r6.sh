@@ -2,7 +2,8 @@
 # Round-6 evidence set on the GPU box, produced ONCE on the round's last tree: tools/profile_round.sh (the driver's bench
 # line, rocprofv3 kernel stats of the same command and of c3, every preset, both training steps, the 2-rank gloo line) plus:
 # the ResNet training line; the same-box A/B of the whole c4 plan — separate launches (GV_NO_CHAIN=1), conv3 + next preact +
-# conv1 as one launch (GV_NO_UNIT=1), one launch per bottleneck unit (default) — as bench lines and launch by launch; the
+# conv1 as one launch (GV_NO_UNIT=1), one launch per bottleneck unit everywhere (GV_UNIT_ALL=1), the default (units at d = 64,
+# the chain at d = 128) — as bench lines and launch by launch; the
 # bottleneck launch alone beside the launches it replaces; warm-repeat vs in-sequence tables of c3 / c5; the MFMA-shape
 # microbenchmark; the one-rank RCCL test's report; per-kernel PMC summaries of c2 and c4.
 # Usage: bash tools/profile_round_r6.sh TAG     (writes gpurun_out/prof_TAG/ and gpurun_out/pmc_TAG_{c2,c4}/)
@@ -14,10 +15,11 @@ bash $R/tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 cd $R
 python3 bench.py --train --preset c4 > $O/bench_train_c4_bf16.json 2>> $O/bench.err
 {
-for mode in separate chain units; do
-  unset GV_NO_CHAIN GV_NO_UNIT
+for mode in separate chain units_everywhere default; do
+  unset GV_NO_CHAIN GV_NO_UNIT GV_UNIT_ALL
   [ $mode = separate ] && export GV_NO_CHAIN=1
   [ $mode = chain ] && export GV_NO_UNIT=1
+  [ $mode = units_everywhere ] && export GV_UNIT_ALL=1
   python3 bench.py --preset c4 --no-cpu-baseline --no-traffic --no-exact > $O/ab_c4_$mode.json 2> $O/ab_c4_$mode.err
   python3 - <<PY
 import json
@@ -26,11 +28,12 @@ r=d.get("roofline",{})
 print("c4 $mode: %.0f views/s, %.3f ms/step, conv %.3f ms in %s, %.0f TF/s, frac %.4f, hbm-bound launches %s | stages %s" % (d["value"], d["ms_per_step"], r.get("conv_ms_per_step",0), r.get("kernel","").split(";")[-2].strip() if ";" in r.get("kernel","") else "", r.get("achieved",0), r.get("frac",0), r.get("hbm_bound_launches"), {k: (round(v["ms"],3), round(v["frac"],3)) for k,v in r.get("stages",{}).items()}))
 PY
 done
-unset GV_NO_CHAIN GV_NO_UNIT
+unset GV_NO_CHAIN GV_NO_UNIT GV_UNIT_ALL
 } > $O/chain_plan_ab.txt 2>&1
 GV_NO_CHAIN=1 python3 tools/seq_vs_warm.py --preset c4 > $O/seq_vs_warm_c4_separate.txt 2>&1
 GV_NO_UNIT=1 python3 tools/seq_vs_warm.py --preset c4 > $O/seq_vs_warm_c4_chain.txt 2>&1
-python3 tools/seq_vs_warm.py --preset c4 > $O/seq_vs_warm_c4_units.txt 2>&1
+GV_UNIT_ALL=1 python3 tools/seq_vs_warm.py --preset c4 > $O/seq_vs_warm_c4_units.txt 2>&1
+python3 tools/seq_vs_warm.py --preset c4 > $O/seq_vs_warm_c4_default.txt 2>&1
 python3 tools/chain_probe.py > $O/chain_probe.txt 2>&1
 python3 tools/seq_vs_warm.py --preset c3 > $O/seq_vs_warm_c3.txt 2>&1
 python3 tools/seq_vs_warm.py --preset c5 > $O/seq_vs_warm_c5.txt 2>&1
