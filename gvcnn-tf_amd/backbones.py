@@ -131,6 +131,8 @@ class BackbonePlan:
         self.fuse_unit = False
         # ... and a depth-changing unit's conv1 + projection shortcut as one GEMM (resnet_unit1_pair)
         self.fuse_pair = False
+        # ... and ResNet's first pre-activation on the fused conv1 -> pool1 launch's way out (GV_CONV_POOL_ACT2)
+        self.fuse_pool_act = False
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -266,7 +268,7 @@ class BackbonePlan:
         return y1, y2
 
     def conv(self, x, scope, cout, k, stride=1, padding="SAME", out=None, norm=None, relu=True,
-             residual=None, next_preact=None, p3=False, defer=False, maxpool=False):
+             residual=None, next_preact=None, p3=False, defer=False, maxpool=False, pool_act=None):
         """slim.conv2d.  norm = ('bn', eps, has_gamma) -> BatchNorm under scope/BatchNorm, no bias;
         norm = None -> biases, no BN (normalizer_fn=None).  next_preact = (bn_scope, eps) adds the
         second output relu(bn(out)) and returns (out, preact); with defer=True no second output is written and
@@ -298,6 +300,9 @@ class BackbonePlan:
             so, ho = self._scale_shift("bias", scope + "/biases", cout)
         y2 = None
         s2 = h2 = 0
+        if pool_act is not None:                              # (bn_scope, eps): BatchNorm + ReLU of the POOLED tensor in the same launch
+            assert maxpool and next_preact is None
+            s2, h2 = self._scale_shift("bn", pool_act[0], cout, pool_act[1], True)
         if next_preact is not None:
             s2, h2 = self._scale_shift("bn", next_preact[0], cout, next_preact[1], True)
             if not defer:
@@ -309,7 +314,7 @@ class BackbonePlan:
         self._record(dict(kind="conv", name=scope, x=x, y=out, y2=y2, res=residual, w_off=w_off,
                              scale_off=so, shift_off=ho, scale2_off=s2, shift2_off=h2,
                              kh=kh, kw=kw, stride=stride, pad_t=pad_t, pad_l=pad_l, relu=relu,
-                             split=0, cout=cout, xpre=xpre, maxpool=maxpool or None, oh=oh, ow=ow,
+                             split=0, cout=cout, xpre=xpre, maxpool=maxpool or None, pool_act=pool_act is not None, oh=oh, ow=ow,
                              flops=2.0 * x.nb * oh * ow * cout * kh * kw * x.c,
                              bytes=float(self.esz) * (x.npix * x.c + kh * kw * x.c * cout +
                                                       (out.npix * cout if maxpool else x.nb * oh * ow * cout *
@@ -512,6 +517,8 @@ class BackbonePlan:
                     flags |= _lib.GV_CONV_Y2_P3
                 if op.get("maxpool"):                         # y is the pooled tensor; oh / ow stay the convolution's
                     flags |= _lib.GV_CONV_MAXPOOL3S2_SAME if op["maxpool"] == "SAME" else _lib.GV_CONV_MAXPOOL3S2
+                    if op.get("pool_act"):                    # ... stored through a second BatchNorm + ReLU
+                        flags |= _lib.GV_CONV_POOL_ACT2 | _lib.GV_CONV_RELU2
                 d = _lib.ConvDesc(x.nb, x.h, x.w, x.c, x.ld, op["kh"], op["kw"], op["stride"],
                                   op["pad_t"], op["pad_l"], op.get("oh", y.h), op.get("ow", y.w), op["cout"], y.ld,
                                   res.ld if res is not None else 0, y2.ld if y2 is not None else 0,
@@ -987,18 +994,27 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
     # conv1: explicit pad 3 + VALID, bias, no BN/ReLU (resnet_v2.py:178-180, resnet_utils.py:94-105)
     if scope + "/conv1" not in keep and getattr(b, "fuse_maxpool", False) and \
             b.fused_maxpool_ok(b.input, 64, 7, ((3, 3), (3, 3)), 2, "SAME"):
-        # conv1 -> pool1 (resnet_v2.py:178-181) as ONE launch: the un-pooled conv1 is never written (nobody taps it)
-        net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False, maxpool="SAME")
+        # conv1 -> pool1 (resnet_v2.py:178-181) as ONE launch: the un-pooled conv1 is never written (nobody taps it).  The first
+        # unit changes the depth, so pool1's only reader is that unit's `preact` BatchNorm + ReLU (:75): it rides on the
+        # pooled tensor's way out of the same launch (16-bit storage, GV_CONV_POOL_ACT2) and pool1 itself is never stored
+        first_pre = "%s/%s/unit_1/bottleneck_v2/preact" % (scope, RESNET50_BLOCKS[0][0])
+        fold_pre = b.dtype != _lib.GV_F32 and getattr(b, "fuse_pool_act", False) and RESNET50_BLOCKS[0][1] * 4 != 64
+        net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False, maxpool="SAME",
+                     pool_act=(first_pre, RESNET_BN_EPS) if fold_pre else None)
+        pre_folded = fold_pre
     else:
         net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False)
         b.end_points[scope + "/conv1"] = net
         net = b.pool(net, 3, 2, "SAME", MAX, name=scope + "/pool1")                    # resnet_v2.py:181
+        pre_folded = False
     units = []
     for bname, base, n_units, bstride in RESNET50_BLOCKS:
         for u in range(n_units):
             units.append((bname, base, u, n_units, bstride if u == n_units - 1 else 1))
     first_sc = "%s/%s/unit_1/bottleneck_v2" % (scope, units[0][0])
-    preact = b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact")
+    # (pre_folded: `net` already IS the first pre-activation; nothing reads the raw pool1 — the first unit's shortcut is a
+    # projection of the pre-activation, resnet_v2.py:79-81)
+    preact = net if pre_folded else b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact")
     c1_ready = None                                     # this unit's conv1 output, when the previous unit's chain launch made it
     for i, (bname, base, u, n_units, stride) in enumerate(units):
         sc = "%s/%s/unit_%d/bottleneck_v2" % (scope, bname, u + 1)
@@ -1107,6 +1123,7 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
     if b.fuse_unit and os.environ.get("GV_UNIT_ALL") is not None:
         b.fuse_unit = "all"
     b.fuse_pair = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_PAIR") is None
+    b.fuse_pool_act = b.fuse_maxpool and dtype != _lib.GV_F32 and os.environ.get("GV_NO_POOL_ACT") is None
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:

@@ -580,6 +580,15 @@ static int conv2d_fwd_impl(const gv_conv_desc* d, const void* x, const float* xs
         a.pool = same ? 2 : 1;
         a.ph = same ? d->oh / 2 : (d->oh - 3) / 2 + 1;
         a.pw = same ? d->ow / 2 : (d->ow - 3) / 2 + 1;
+        // GV_CONV_POOL_ACT2: the pooled tensor leaves as act2(pool * scale2 + shift2) (16-bit storage, the stem strip kernel)
+        if (d->flags & GV_CONV_POOL_ACT2) {
+            if (!scale2 || !shift2) return GV_E_BADARG;
+            if (!lp) return GV_E_UNSUPPORTED;
+        } else {
+            a.scale2 = a.shift2 = nullptr;
+        }
+    } else if (d->flags & GV_CONV_POOL_ACT2) {
+        return GV_E_BADARG;
     }
     if (lp) {
         // vector loader: 8-channel (16-byte) chunks inside one filter tap, 16-byte aligned pixels

@@ -771,11 +771,32 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
     const int pcc = tid % (2 * PPX * 4), prs = tid / (2 * PPX * 4);
     const int ppc = ox0 / 2 + (pcc % (PPX * 4)) / 4;
     unsigned short* ypool = y + ((size_t)n * a.ph * a.pw + ppc) * a.y_ld + (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
+    // GV_CONV_POOL_ACT2: the pooled value, as it would be stored, goes through a second per-channel affine (+ ReLU) on its way
+    // out — ResNet-v2's first `preact` BatchNorm + ReLU (nets/resnet_v2.py:75 behind :181), whose only input is pool1
+    const bool post = POOL && a.scale2 != nullptr;
+    float psc[8], psh[8];
+    if (post) {
+        const int cb = (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            psc[e] = a.scale2[min(cb + e, a.cout - 1)];
+            psh[e] = a.shift2[min(cb + e, a.cout - 1)];
+        }
+    }
     auto put_pooled = [&](int prow, u32x4 k) {
         if (prow < a.ph && ppc < a.pw) {
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = keyw(k[e]);
+            if (post) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo = from_bits<T>((unsigned short)(o[e] & 0xffffu)) * psc[2 * e] + psh[2 * e];
+                    float hi = from_bits<T>((unsigned short)(o[e] >> 16)) * psc[2 * e + 1] + psh[2 * e + 1];
+                    if (a.relu2) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                    o[e] = pack2<T>(lo, hi);
+                }
+            }
             *reinterpret_cast<u32x4*>(ypool + (size_t)prow * a.pw * a.y_ld) = o;
         }
     };
@@ -1215,6 +1236,7 @@ int lp_launch(int dtype, int cfg, const ConvArgs& a0, bool generic, bool xf32, h
     a.ktiles = a.Kpad / KT;
     if (a.pool && (cfg != kNumTiles || !((a.pool == 1 && lp_halo_pool_ok(a, generic)) || lp_stem_pool_ok(a, xf32))))
         return GV_E_UNSUPPORTED;
+    if (a.pool && a.scale2 != nullptr && !lp_stem_pool_ok(a, xf32)) return GV_E_UNSUPPORTED;   // GV_CONV_POOL_ACT2: the stem strip kernel only
     if (cfg == kNumTiles) {
         if (a.y_step != 0) return GV_E_UNSUPPORTED;              // (the strip / halo kernels have no two-level output stride)
         // BatchNorm sums: one segment over every output column (these kernels own whole images: no slot table)

@@ -170,8 +170,9 @@ extern "C" int gv_plan_add_conv(gv_plan* p, const gv_conv_desc* d, int32_t x_slo
     o.res = {res_slot, res_off};
     o.y = {y_slot, y_off};
     o.y2 = {y2_slot, y2_off};
-    o.scale2 = {y2_slot >= 0 ? ss_slot : -1, scale2_off};
-    o.shift2 = {y2_slot >= 0 ? ss_slot : -1, shift2_off};
+    const bool second = y2_slot >= 0 || (d->flags & GV_CONV_POOL_ACT2) != 0;   // (a second activation of the pooled tensor too)
+    o.scale2 = {second ? ss_slot : -1, scale2_off};
+    o.shift2 = {second ? ss_slot : -1, shift2_off};
     for (const Ref* r : {&o.x, &o.w, &o.scale, &o.res, &o.y, &o.y2}) note(p, *r);
     p->ops.push_back(o);
     return GV_OK;

@@ -71,6 +71,12 @@ extern "C" {
                                  clipped; resnet_v2.py:181, conv1 -> pool1): y is [nb, oh/2, ow/2, cout].  Stem strip
                                  kernel only; odd oh / ow: GV_E_UNSUPPORTED */
 
+#define GV_CONV_POOL_ACT2 512  /* with GV_CONV_MAXPOOL3S2[_SAME], y2 == NULL: the POOLED tensor is stored as
+                                 act2(pool * scale2[c] + shift2[c]) (GV_CONV_RELU2: ReLU), computed from the pooled value as it
+                                 would have been stored — ResNet-v2's first `preact` batch_norm + ReLU (nets/resnet_v2.py:75),
+                                 whose only input is pool1 (:181): bit-identical to the fused launch + gv_scale_shift_act.  16-bit
+                                 storage, the 3-channel stem kernel's class; anything else GV_E_UNSUPPORTED */
+
 /* gv_conv_desc.math_mode: how an fp32 convolution is evaluated on the matrix cores */
 #define GV_MATH_F32 0         /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                         */
 #define GV_MATH_BF16X3 1      /* operands split into 3 bf16 planes, 6 bf16 MFMAs per product block:

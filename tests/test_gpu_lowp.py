@@ -67,9 +67,9 @@ def pack(w, code):
 
 def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, second=None, split=0,
              tile=None, x_f32=False, x_ld=None, x_off=0, y_ld=None, y_off=0, xpre=None, tile_cfg=0, expect=None, pooled=None,
-             pooled_same=False):
+             pooled_same=False, pool_act=None):
     """pooled = (ph, pw): GV_CONV_MAXPOOL3S2 (pooled_same: _SAME) — the destination is the pooled tensor, out_hw stays the
-    convolution's."""
+    convolution's; pool_act = (scale2, shift2, relu2): GV_CONV_POOL_ACT2, the pooled tensor through a second activation."""
     code, td, _ = TYPES[ty]
     nb, ih, iw, cin = x.shape
     kh, kw, _, cout = w.shape
@@ -88,10 +88,15 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
     sc, sh = scale.to(DEV), shift.to(DEV)
     sc2 = second[0].to(DEV) if second else None
     sh2 = second[1].to(DEV) if second else None
+    if pool_act is not None:
+        assert not second
+        sc2 = pool_act[0].to(DEV) if pool_act[0] is not None else None
+        sh2 = pool_act[1].to(DEV) if pool_act[1] is not None else None
     rd = residual.to(td).to(DEV).contiguous() if residual is not None else None
     flags = (_lib.GV_CONV_RELU if relu else 0) | (_lib.GV_CONV_RELU2 if second else 0) | \
             (_lib.GV_CONV_SPLIT if split else 0) | (_lib.GV_CONV_X_F32 if x_f32 else 0) | \
-            ((_lib.GV_CONV_MAXPOOL3S2_SAME if pooled_same else _lib.GV_CONV_MAXPOOL3S2) if pooled else 0)
+            ((_lib.GV_CONV_MAXPOOL3S2_SAME if pooled_same else _lib.GV_CONV_MAXPOOL3S2) if pooled else 0) | \
+            ((_lib.GV_CONV_POOL_ACT2 | (_lib.GV_CONV_RELU2 if pool_act[2] else 0)) if pool_act is not None else 0)
     d = _lib.ConvDesc(nb, ih, iw, cin, x_ld, kh, kw, stride, pads[0], pads[1], oh, ow, cout, y_ld,
                       cout if residual is not None else 0, n2 if y2d is not None else 0, flags, code, split, tile_cfg, 0, 0)
     if xpre is not None:                    # the input is read as relu(x * xscale + xshift) (gv_conv2d_fwd_xpre)
@@ -113,7 +118,7 @@ def run_conv(x, w, stride, pads, out_hw, scale, shift, relu, ty, residual=None, 
         rc = lib().gv_conv2d_fwd(C.byref(d), xd.data_ptr() + xes * x_off, wp.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                  rd.data_ptr() if rd is not None else None, yd.data_ptr() + 2 * y_off,
                                  y2d.data_ptr() if y2d is not None else None,
-                                 sc2.data_ptr() if second else None, sh2.data_ptr() if second else None, st())
+                                 sc2.data_ptr() if sc2 is not None else None, sh2.data_ptr() if sh2 is not None else None, st())
     finally:
         lib().gv_conv2d_set_tile_override(-1)
     if expect is not None:
@@ -618,6 +623,22 @@ def test_lp_stem_conv_maxpool_one_launch(ty, k, pad, hw, same, relu):
         one = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, relu, ty, tile=tile, tile_cfg=tile_cfg, x_f32=True,
                        y_ld=64 + 16, y_off=8, pooled=(ph, pw), pooled_same=same)
         assert np.array_equal(one, two), (tile_cfg, tile, np.abs(one - two).max())
+    # GV_CONV_POOL_ACT2: the pooled tensor leaves through a second BatchNorm (+ ReLU) — ResNet-v2's first `preact`
+    # (nets/resnet_v2.py:75), whose only input is pool1: bit for bit gv_scale_shift_act of the pooled tensor
+    s2, h2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    for relu2 in (True, False):
+        td_two = torch.from_numpy(two).to(td).to(DEV).contiguous()
+        three = torch.empty_like(td_two)
+        s2d, h2d = s2.to(DEV), h2.to(DEV)
+        _lib.check(lib().gv_scale_shift_act(td_two.data_ptr(), td_two.numel() // 64, 64, 64, s2d.data_ptr(), h2d.data_ptr(),
+                                            int(relu2), three.data_ptr(), 64, code, st()), "ssa")
+        three = three.float().cpu().numpy()
+        v = torch.from_numpy(two) * s2 + h2
+        close(three, (torch.relu(v) if relu2 else v).numpy(), ulp)
+        assert relu2 or float(three.min()) < 0
+        one = run_conv(x, w, 2, (pad, pad), (oh, ow), scale, shift, relu, ty, tile_cfg=special_tile() + 1, x_f32=True,
+                       y_ld=64 + 16, y_off=8, pooled=(ph, pw), pooled_same=same, pool_act=(s2, h2, relu2))
+        assert np.array_equal(one, three), (relu2, np.abs(one - three).max())
 
 
 def test_lp_conv_maxpool_declines_what_it_does_not_serve():
@@ -642,6 +663,11 @@ def test_lp_conv_maxpool_declines_what_it_does_not_serve():
     w7 = torch.randn(7, 7, 3, 64, generator=g) * 0.1
     run_conv(xi, w7, 2, (3, 3), (17, 19), sc, sh, False, "bf16", x_f32=True, pooled=(8, 9), pooled_same=True, expect=U)
     run_conv(xi, w7[..., :32], 2, (3, 3), (17, 19), sc[:32], sh[:32], False, "bf16", x_f32=True, pooled=(8, 9), expect=U)
+    # GV_CONV_POOL_ACT2: with a fused pool only, its vectors present, the stem strip kernel only
+    B = _lib.GV_E_BADARG
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, True, "bf16", pool_act=(sc, sh, True), expect=B)
+    run_conv(xi, w7, 2, (3, 3), (17, 19), sc, sh, False, "bf16", x_f32=True, pooled=(8, 9), pool_act=(sc, None, True), expect=B)
+    run_conv(x, w, 1, (1, 1), (12, 14), sc, sh, True, "bf16", pooled=(5, 6), pool_act=(sc, sh, True), expect=U)
 
 
 @pytest.mark.parametrize("ty,size,nb", [("bf16", 107, 6), ("f16", 75, 4), ("bf16", 224, 24), ("f16", 299, 10)])
@@ -675,8 +701,9 @@ def test_lp_inception_plan_with_and_without_the_fused_max_pool(ty, size, nb):
 
 @pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])
 def test_lp_resnet_plan_with_and_without_the_fused_max_pool(ty, size, nb):
-    """The 16-bit ResNet-v2-50 plan issues conv1 -> pool1 as one launch where conv1's map is even (64, 224: one op fewer);
-    at 97 (a 49 x 49 map: TF's SAME pads (1, 1) there) it keeps the two.  Same bits at block3 / block4 either way."""
+    """The 16-bit ResNet-v2-50 plan issues conv1 -> pool1 -> the first unit's preact as one launch where conv1's map is even
+    (64, 224: two ops fewer — GV_CONV_MAXPOOL3S2_SAME | GV_CONV_POOL_ACT2); at 97 (a 49 x 49 map: TF's SAME pads (1, 1)
+    there) it keeps the three.  Same bits at block3 / block4 either way."""
     from gvcnn_tf_amd import backbones
     x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5).to(DEV)
     outs, nops = [], []
@@ -689,7 +716,7 @@ def test_lp_resnet_plan_with_and_without_the_fused_max_pool(ty, size, nb):
         torch.cuda.synchronize()
         outs.append({k: plan.view(plan.end_points[k]).clone() for k in ("resnet_v2_50/block3", "resnet_v2_50/block4")})
         nops.append(len(plan.ops))
-    assert nops[0] == nops[1] - (1 if size != 97 else 0)
+    assert nops[0] == nops[1] - (2 if size != 97 else 0)
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
     assert float(outs[0]["resnet_v2_50/block4"].float().abs().max()) > 1e-3

@@ -283,5 +283,10 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
         assert p.param_shapes() == off.param_shapes()
         assert abs(p.total_flops - off.total_flops) < 1e-6 * off.total_flops
         assert set(p.end_points) == set(off.end_points)
+        # the first unit's pre-activation rides on the fused conv1 -> pool1 launch (GV_CONV_POOL_ACT2): no stand-alone pass
+        assert sum(1 for op in p.ops if op["kind"] == "ssa") == 0 and p.ops[0].get("pool_act") and p.ops[0]["maxpool"] == "SAME"
+    two = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_maxpool=False)
+    assert sum(1 for op in two.ops if op["kind"] == "ssa") == 1 and not any(op.get("pool_act") for op in two.ops)
+    assert len(two.ops) == len(off.ops) - 10 + 2 and two.param_shapes() == off.param_shapes()
     f32 = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu)
     assert not any(op.get("chain") for op in f32.ops)
