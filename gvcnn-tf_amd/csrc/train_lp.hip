@@ -1583,7 +1583,10 @@ int wgrad_t(const gv_conv_desc* d, const unsigned short* x, const unsigned short
 // pitch (row rho of the operand is one (filter row, column, channel) = one fixed offset into the staged rows).  No
 // barrier inside the loop (a wave reads only what it wrote); the four waves' accumulators are summed in LDS and
 // leave as one fp32 atomic per (rho, co) and workgroup.
-template <typename T, int NRT, int NCT>
+// ZL: 16-byte loads per lane that hold the unit's dZ row (10: rows up to 640 chunks — Conv2d_1a's 111 x 32; 14: ResNet conv1's
+// 112 pixels x 64 channels = 896 chunks, 96 KB of LDS per workgroup — one workgroup per CU, whose four waves keep 24 loads per
+// lane in flight each: the layer was 2.75 ms on the fp32-MFMA fallback, 9 % of the ResNet training step).
+template <typename T, int NRT, int NCT, int ZL = 10>
 __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned short* __restrict__ x,
                                                                const unsigned short* __restrict__ dz, int dz_ld, int nb,
                                                                int ih, int iw, int cin, int kh, int kw, int stride,
@@ -1597,13 +1600,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned sh
     unsigned char* sZw = sXw + kh * xrow_b;
     for (int i = lane * 16; i < wave_b; i += 1024) *reinterpret_cast<u32x4*>(sXw + i) = u32x4{0u, 0u, 0u, 0u};
     const int R = kh * kw * cin;
+    // image rows sit pad_l pixels (+ xoff bytes, so that their 4-byte pieces stay aligned: ResNet conv1 pads 3 pixels of 6 bytes)
+    // into their LDS rows; what is in front stays zero
+    const int xoff = (4 - ((pad_l * cin * 2) & 3)) & 3;
     int abase[NRT];                                                // byte offset of operand row rho at output column 0
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {
         const int rho = min(t * 32 + li, R - 1);                   // (rows past R: any finite data; never stored)
         const int tap = rho / cin, ci = rho - tap * cin;
         const int r = tap / kw, sx = tap - r * kw;
-        abase[t] = r * xrow_b + (sx * cin + ci) * 2;
+        abase[t] = r * xrow_b + xoff + (sx * cin + ci) * 2;
     }
     const int apitch = stride * cin * 2;                           // bytes between consecutive output columns
     // transposed-read address of this lane inside a (16-pixel, 32-channel) block of the dZ row (see conv_wgrad_lp)
@@ -1620,7 +1626,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned sh
         for (int u = 0; u < NCT; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-    constexpr int XL = NRT == 1 ? 6 : 10, ZL = 10;                 // 16-byte loads per lane: image rows / dZ row (capacity)
+    constexpr int XL = NRT == 1 ? 6 : 10;                          // 16-byte loads per lane: image rows (capacity; ZL: the dZ row)
     const int xbytes = iw * cin * 2;                               // one image row (contiguous: x_ld == cin)
     const int xchunks = (kh * xbytes + 15) / 16, zchunks = ow * (NCT * 4);
     u32x4 xr[XL], zr[ZL];
@@ -1657,12 +1663,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_rows_lp(const unsigned sh
         for (int k = 0; k < XL; ++k) {
             const int c = lane + 64 * k;
             if (c < xchunks) {
-                // image rows sit pad_l pixels into their LDS rows (the left padding stays zero), xrow_b apart
-                const int b0 = c * 16;
+                const int b0 = c * 16;                             // (rows xrow_b apart)
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) {                   // 4-byte pieces: a chunk may straddle two rows
                     const int b = b0 + 4 * w4, row = b / xbytes, off = b - row * xbytes;
-                    if (row < kh) *reinterpret_cast<unsigned*>(sXw + row * xrow_b + pad_l * cin * 2 + off) = xr[k][w4];
+                    if (row < kh) *reinterpret_cast<unsigned*>(sXw + row * xrow_b + xoff + pad_l * cin * 2 + off) = xr[k][w4];
                 }
             }
         }
@@ -1735,7 +1740,9 @@ int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsign
         return GV_E_UNSUPPORTED;
     const int xbytes = d->iw * d->cin * 2;
     // what a lane's staging registers hold (XL / ZL of the kernel), and 4-byte aligned rows behind the left padding
-    if ((d->kh * xbytes + 15) / 16 > (nrt == 1 ? 6 : 10) * 64 || d->ow * nct * 4 > 10 * 64 || (d->pad_l * d->cin * 2) % 4 != 0)
+    const bool wide = d->ow * nct * 4 > 10 * 64;                   // the dZ row needs the 14-load form (nrt == 5, nct == 2 only)
+    if ((d->kh * xbytes + 15) / 16 > (nrt == 1 ? 6 : 10) * 64 || d->ow * nct * 4 > (nrt == 5 && nct == 2 ? 14 : 10) * 64 ||
+        xbytes % 4 != 0)
         return GV_E_UNSUPPORTED;
     // LDS row of the image: left padding + iw pixels + the columns the last (padded to 16) output pixels reach
     const int owp = (d->ow + 15) / 16 * 16;
@@ -1747,9 +1754,10 @@ int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsign
     size_t lds = 4 * wave_b;
     const size_t red_b = (size_t)4 * nrt * nct * 1024 * 4;
     if (red_b > lds) lds = red_b;
-    if (lds > 64 * 1024) return GV_E_UNSUPPORTED;
+    if (lds > (wide ? 160 : 64) * 1024) return GV_E_UNSUPPORTED;
+    if (wide && !GV_BIG_LDS_OK((conv_wgrad_stem_rows_lp<T, 5, 2, 14>), 160 * 1024)) return GV_E_UNSUPPORTED;
     const int64_t units = (int64_t)d->nb * d->oh;
-    int64_t waves = 256 * 3 * 4;                                   // three workgroups per CU
+    int64_t waves = 256 * (wide ? 1 : 3) * 4;                      // three workgroups per CU (the wide form: one)
     int64_t per = (units + waves - 1) / waves;
     if (per < 4) per = 4;
     int64_t nwg = ((units + per - 1) / per + 3) / 4;
@@ -1764,7 +1772,11 @@ int wgrad_stem_rows(const gv_conv_desc* d, const unsigned short* x, const unsign
     hipLaunchKernelGGL((conv_wgrad_stem_rows_lp<T, NRT, NCT>), dim3((unsigned)nwg), dim3(256), lds, st, x, dz, dz_ld,     \
                        d->nb, d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout,   \
                        xrow_b, zrows, (int)per, sink)
-    if (nrt == 1 && nct == 1) GV_WSTEM(1, 1);
+    if (wide)
+        hipLaunchKernelGGL((conv_wgrad_stem_rows_lp<T, 5, 2, 14>), dim3((unsigned)nwg), dim3(256), lds, st, x, dz, dz_ld, d->nb,
+                           d->ih, d->iw, d->cin, d->kh, d->kw, d->stride, d->pad_t, d->pad_l, d->oh, d->ow, d->cout, xrow_b, zrows,
+                           (int)per, sink);
+    else if (nrt == 1 && nct == 1) GV_WSTEM(1, 1);
     else if (nrt == 1) GV_WSTEM(1, 2);
     else if (nct == 1) GV_WSTEM(5, 1);
     else GV_WSTEM(5, 2);

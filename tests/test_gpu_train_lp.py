@@ -944,7 +944,7 @@ def test_wgrad_on_one_pixel_wide_maps():
 
 @pytest.mark.parametrize("dt,tdt,eps", TYPES)
 @pytest.mark.parametrize("k,pad,cout,nb,ih,iw", [(3, 0, 32, 37, 23, 40), (3, 0, 64, 9, 47, 72), (7, 2, 64, 5, 33, 48),
-                                                 (3, 0, 32, 3, 224, 224)])
+                                                 (3, 0, 32, 3, 224, 224), (7, 3, 64, 3, 224, 224), (7, 3, 64, 2, 200, 216), (7, 3, 64, 5, 33, 48)])
 def test_stem_filter_gradient_on_row_strips(dt, tdt, eps, k, pad, cout, nb, ih, iw):
     """The 3-channel stems' filter gradient (Conv2d_1a 3x3/2, nets/inception_v3.py:97; a 7x7/2 with padding) on
     conv_wgrad_stem_rows_lp — image rows and the dZ row through LDS, 16-bit MFMA — against torch autograd through the
