@@ -689,10 +689,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_lp(const ConvArgs a) {
 // a register.  Here the values are signed (conv1 has a bias and no activation), so the reduced rows hold ORDER KEYS
 // (bits ^ 0x7fff where the sign is set: signed 16-bit order = float order, -0 < +0), a missing row or column (TF's SAME
 // pads (0, 1) on an even map: the window is clipped) is the lowest key, and the store turns keys back into values.
+// POOL staging (round 6): a wave's 32 x 32 block leaves the accumulators ALREADY scaled, shifted and rounded to the storage
+// type (one channel per lane there: one scale and one shift register per column block instead of 8 + 8), as 16-bit values in
+// rows of 96 bytes — rounding is monotonic, so the maximum of the rounded values is the rounded maximum the fp32 form took —
+// and the horizontal reduce is three 16-byte reads and two packed maxima on order keys per lane.  12 KB of staging instead
+// of 18 and ~40 registers fewer: THREE workgroups per CU (LDS 49.6 KB each, <= 168 registers) instead of two; the kernel
+// waits on its patch loads, not on arithmetic.
 template <typename T, int TN, int KW, int STATS = 0, bool POOL = false>
-__global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
+__global__ __launch_bounds__(256, POOL ? 3 : 2) void conv_stem_patch_lp(const ConvArgs a) {
     static_assert(!POOL || (TN == 2 && STATS == 0), "the pooled form: 64 output channels, no BatchNorm sums");
     constexpr int PSTEP = 30, PPX = 15, XROW = 2 * PPX * 32 * 2;
+    constexpr int SROW = 96;                                // POOL: bytes of a staged row (32 x 16 bit + pad: conflict-free reads)
     constexpr int KR = KW == 3 ? 16 : 24;                   // k slots per filter row (multiple of 8)
     constexpr int NG = (KW * KR / 8 + 1) / 2 * 2;           // 8-value groups, padded to whole 16-deep k-steps
     constexpr int PR = 3 * 2 + KW + 1;                      // patch rows (+1 zero row for the padding group)
@@ -704,8 +711,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
     constexpr int SW = 32 + 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* sP = smem_raw;                                                      // [PR][PITCH]
-    float* stage = reinterpret_cast<float*>(smem_raw + PR * PITCH) + (threadIdx.x >> 6) * (32 * SW);
-    char* sW = smem_raw + PR * PITCH + 4 * 32 * SW * 4;                       // [32*TN][WB]
+    constexpr int STAGE_B = POOL ? 32 * SROW : 32 * SW * 4;                   // a wave's staging block
+    float* stage = reinterpret_cast<float*>(smem_raw + PR * PITCH + (threadIdx.x >> 6) * STAGE_B);
+    char* sW = smem_raw + PR * PITCH + 4 * STAGE_B;                           // [32*TN][WB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int tiles_x = POOL ? (a.pw + PPX - 1) / PPX : (a.ow + 31) / 32;
     const int n = blockIdx.x / tiles_x;
@@ -728,14 +736,25 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
 
     const int rrow = lane >> 2, col8 = (lane & 3) * 8;
     float sc[TN][8], sh[TN][8];
+    float sc_l[TN], sh_l[TN];                               // POOL: the constants of this lane's accumulator column
+    bool relu_l[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+        if constexpr (POOL) {
+            const int c = min(j * 32 + li, a.cout - 1);
+            sc_l[j] = a.scale[c];
+            sh_l[j] = a.shift[c];
+            relu_l[j] = a.relu && j * 32 + li < a.relu_limit;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = min(j * 32 + col8 + e, a.cout - 1);
-            sc[j][e] = a.scale[c];
-            sh[j][e] = a.shift[c];
+            for (int e = 0; e < 8; ++e) {
+                const int c = min(j * 32 + col8 + e, a.cout - 1);
+                sc[j][e] = a.scale[c];
+                sh[j][e] = a.shift[c];
+            }
         }
+    }
+    (void)sc_l; (void)sh_l; (void)relu_l; (void)sc; (void)sh;
     const bool vec = (a.y_ld % 8 == 0) && ((((uintptr_t)y) & 15) == 0);
 
     gvconv::StatStrip<gvconv::STAT_FWD, TN> sstat;          // STATS (forward sums only: this kernel has no data-gradient use)
@@ -773,22 +792,19 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
     unsigned short* ypool = y + ((size_t)n * a.ph * a.pw + ppc) * a.y_ld + (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
     // GV_CONV_POOL_ACT2: the pooled value, as it would be stored, goes through a second per-channel affine (+ ReLU) on its way
     // out — ResNet-v2's first `preact` BatchNorm + ReLU (nets/resnet_v2.py:75 behind :181), whose only input is pool1
+    // (its constants are read where they are used, twice per tile by the 240 storing threads: no registers held for them)
     const bool post = POOL && a.scale2 != nullptr;
-    float psc[8], psh[8];
-    if (post) {
-        const int cb = (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            psc[e] = a.scale2[min(cb + e, a.cout - 1)];
-            psh[e] = a.shift2[min(cb + e, a.cout - 1)];
-        }
-    }
     auto put_pooled = [&](int prow, u32x4 k) {
         if (prow < a.ph && ppc < a.pw) {
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = keyw(k[e]);
             if (post) {
+                const int cb = min((pcc / (PPX * 4)) * 32 + (pcc & 3) * 8, a.cout - 8);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale2 + cb), s1 = *reinterpret_cast<const f32x4*>(a.scale2 + cb + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(a.shift2 + cb), h1 = *reinterpret_cast<const f32x4*>(a.shift2 + cb + 4);
+                const float psc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                const float psh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float lo = from_bits<T>((unsigned short)(o[e] & 0xffffu)) * psc[2 * e] + psh[2 * e];
@@ -836,34 +852,28 @@ __global__ __launch_bounds__(256, 2) void conv_stem_patch_lp(const ConvArgs a) {
         const int oy = oy0 + wave;
         if constexpr (POOL) {
             const int pp = lane >> 2;                      // this lane's pooled pixel of the strip (15: none)
+            char* stage_b = reinterpret_cast<char*>(stage);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stage[(4 * lh + (r & 3) + 8 * (r >> 2)) * SW + li] = acc[j][r];
+                for (int r = 0; r < 16; ++r) {             // the value as it would be stored: row = pixel, column = channel
+                    float v = acc[j][r] * sc_l[j] + sh_l[j];
+                    if (relu_l[j]) v = fmaxf(v, 0.f);
+                    *reinterpret_cast<unsigned short*>(stage_b + (4 * lh + (r & 3) + 8 * (r >> 2)) * SROW + li * 2) = to_bits<T>(v);
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (pp < PPX) {
-                    float mx[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) mx[e] = -__builtin_inff();
+                    const u32x4 lowest = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+                    u32x4 mx = lowest;
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         const int row = 2 * pp + t;
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * SW + col8);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + row * SW + col8 + 4);
-                        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        if (ox0 + row < a.ow) {
+                        u32x4 k = *reinterpret_cast<const u32x4*>(stage_b + row * SROW + (lane & 3) * 16);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                v[e] = v[e] * sc[j][e] + sh[j][e];
-                                if (a.relu && j * 32 + col8 + e < a.relu_limit) v[e] = fmaxf(v[e], 0.f);
-                                mx[e] = fmaxf(mx[e], v[e]);
-                            }
-                        }
+                        for (int e = 0; e < 4; ++e) k[e] = keyw(k[e]);
+                        mx = pkmax(mx, ox0 + row < a.ow ? k : lowest);
                     }
-                    u32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = oy < a.oh ? keyw(pack2<T>(mx[2 * e], mx[2 * e + 1])) : 0x80008000u;
-                    *reinterpret_cast<u32x4*>(sX + wave * XROW + (j * PPX + pp) * 64 + (lane & 3) * 16) = o;
+                    *reinterpret_cast<u32x4*>(sX + wave * XROW + (j * PPX + pp) * 64 + (lane & 3) * 16) = oy < a.oh ? mx : lowest;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1153,7 +1163,7 @@ template <typename T, int KW>
 int launch_stem_pool(const ConvArgs& a, hipStream_t st) {
     constexpr int KR = KW == 3 ? 16 : 24, NG = (KW * KR / 8 + 1) / 2 * 2, PR = 3 * 2 + KW + 1, PC = 31 * 2 + KW;
     constexpr int PITCH = (PC * 3 * 2 + 16 + 3) / 4 * 4;
-    const size_t lds = (size_t)PR * PITCH + 4 * 32 * 36 * 4 + (size_t)32 * 2 * (NG * 16 + 16) + 4 * (2 * 15 * 32 * 2);
+    const size_t lds = (size_t)PR * PITCH + 4 * 32 * 96 + (size_t)32 * 2 * (NG * 16 + 16) + 4 * (2 * 15 * 32 * 2);   // (16-bit staging rows)
     hipLaunchKernelGGL((conv_stem_patch_lp<T, 2, KW, 0, true>), dim3((unsigned)(a.nb * ((a.pw + 14) / 15))), dim3(256), lds, st, a);
     GV_LAUNCH_CHECK();
     return GV_OK;

@@ -1,5 +1,5 @@
-# Round 6: the first pre-activation on the fused conv1 -> pool1 launch (GV_CONV_POOL_ACT2) against the stand-alone pass
-# (GV_NO_POOL_ACT=1): parity tests, then the whole c4 plan alternating on one box (profiles/r6_pool_act_ab.txt).
+# Round 6: the ResNet stem launch (conv1 -> pool1 -> first pre-activation): parity tests, then the whole c4 plan with the
+# pre-activation folded (default) and as its own pass (GV_NO_POOL_ACT=1), alternating on one box.
 #   bash tools/r6_poolact.sh        (on the GPU box)
 mkdir -p gpurun_out/r6
 timeout 900 python -m pytest tests/test_gpu_lowp.py -x -q -m gpu -k "maxpool or max_pool" > gpurun_out/r6/t_poolact.txt 2>&1; echo "tests rc $?"; tail -n 6 gpurun_out/r6/t_poolact.txt
@@ -14,4 +14,4 @@ print("c4 ${mode}: %.0f views/s, %.3f ms/step, conv %.3f ms, %.0f TF/s, frac %.4
 PY
 done 2>&1 | tee gpurun_out/r6/pool_act_ab.txt
 unset GV_NO_POOL_ACT
-python tools/seq_vs_warm.py --preset c4 2>&1 | head -12
+python tools/seq_vs_warm.py --preset c4 2>&1 | head -5
