@@ -761,19 +761,30 @@ __global__ __launch_bounds__(256, POOL ? 3 : 2) void conv_stem_patch_lp(const Co
     const int sgrp = STATS != 0 ? n % a.st.G : 0;
     if constexpr (STATS != 0) sstat.init(a.st, sgrp, col8, a.cout);
 
+    // the patch, one element per thread and step (a wave's load is 256 contiguous bytes of a patch row); what does not depend
+    // on the tile — the element's patch row, its column test, its offsets in the image and in LDS — is worked out once
+    // (12-byte loads, a pixel per thread, were measured too: fewer instructions, but a wave's load then spans 768 bytes at
+    // a 12-byte lane pitch and Conv2d_1a — at the HBM roofline with these loads — fell from 4.5 to 3.1 TB/s)
     float pr_[SL];
+    int p_goff[SL], p_info[SL];                             // element offset from the tile's first patch row; LDS offset | row << 16 | ok << 24 | live << 25
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+        const int idx = tid + k * 256;
+        const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
+        const int px = e / 3, ch = e - px * 3;
+        const int ix = ox0 * 2 - a.pad_l + px;
+        const bool live = idx < NEL, ok = live && (unsigned)ix < (unsigned)a.iw;
+        p_goff[k] = (prow * a.iw + ix) * a.x_ld + ch;
+        p_info[k] = (prow * PITCH + e * 2) | (prow << 16) | ((ok ? 1 : 0) << 24) | ((live ? 1 : 0) << 25);
+    }
     auto fetch = [&](int oy0) {
+        const int iy0 = oy0 * 2 - a.pad_t;
+        const float* base = a.x + ((ptrdiff_t)n * a.ih + iy0) * (ptrdiff_t)a.iw * a.x_ld;
 #pragma unroll
         for (int k = 0; k < SL; ++k) {
-            const int idx = tid + k * 256;
+            const int iy = iy0 + ((p_info[k] >> 16) & 0xff);
             float v = 0.f;
-            if (idx < NEL) {
-                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
-                const int px = e / 3, ch = e - px * 3;
-                const int iy = oy0 * 2 - a.pad_t + prow, ix = ox0 * 2 - a.pad_l + px;
-                if ((unsigned)iy < (unsigned)a.ih && (unsigned)ix < (unsigned)a.iw)
-                    v = a.x[((size_t)(n * a.ih + iy) * a.iw + ix) * a.x_ld + ch];
-            }
+            if (((p_info[k] >> 24) & 1) && (unsigned)iy < (unsigned)a.ih) v = base[p_goff[k]];
             pr_[k] = v;
         }
     };
@@ -820,13 +831,8 @@ __global__ __launch_bounds__(256, POOL ? 3 : 2) void conv_stem_patch_lp(const Co
     for (int oy0 = 0; oy0 < oh_run; oy0 += 4) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SL; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < NEL) {
-                const int prow = idx / (PC * 3), e = idx - prow * (PC * 3);
-                *reinterpret_cast<unsigned short*>(sP + prow * PITCH + e * 2) = to_bits<T>(pr_[k]);
-            }
-        }
+        for (int k = 0; k < SL; ++k)
+            if ((p_info[k] >> 25) & 1) *reinterpret_cast<unsigned short*>(sP + (p_info[k] & 0xffff)) = to_bits<T>(pr_[k]);
         __syncthreads();
         if (oy0 + 4 < oh_run) fetch(oy0 + 4);
         f32x16 acc[TN];
