@@ -803,19 +803,22 @@ __global__ __launch_bounds__(256, POOL ? 3 : 2) void conv_stem_patch_lp(const Co
     unsigned short* ypool = y + ((size_t)n * a.ph * a.pw + ppc) * a.y_ld + (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
     // GV_CONV_POOL_ACT2: the pooled value, as it would be stored, goes through a second per-channel affine (+ ReLU) on its way
     // out — ResNet-v2's first `preact` BatchNorm + ReLU (nets/resnet_v2.py:75 behind :181), whose only input is pool1
-    // (its constants are read where they are used, twice per tile by the 240 storing threads: no registers held for them)
     const bool post = POOL && a.scale2 != nullptr;
+    float psc[8], psh[8];                                   // (16 registers: the kernel has them to spare at three workgroups per CU)
+    if (post) {
+        const int cb = (pcc / (PPX * 4)) * 32 + (pcc & 3) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            psc[e] = a.scale2[min(cb + e, a.cout - 1)];
+            psh[e] = a.shift2[min(cb + e, a.cout - 1)];
+        }
+    }
     auto put_pooled = [&](int prow, u32x4 k) {
         if (prow < a.ph && ppc < a.pw) {
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = keyw(k[e]);
             if (post) {
-                const int cb = min((pcc / (PPX * 4)) * 32 + (pcc & 3) * 8, a.cout - 8);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale2 + cb), s1 = *reinterpret_cast<const f32x4*>(a.scale2 + cb + 4);
-                const f32x4 h0 = *reinterpret_cast<const f32x4*>(a.shift2 + cb), h1 = *reinterpret_cast<const f32x4*>(a.shift2 + cb + 4);
-                const float psc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-                const float psh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float lo = from_bits<T>((unsigned short)(o[e] & 0xffffu)) * psc[2 * e] + psh[2 * e];

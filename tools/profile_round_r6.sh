@@ -5,7 +5,10 @@
 # conv1 as one launch (GV_NO_UNIT=1), one launch per bottleneck unit everywhere (GV_UNIT_ALL=1), the default (units at d = 64,
 # the chain at d = 128) — as bench lines and launch by launch; the
 # bottleneck launch alone beside the launches it replaces; warm-repeat vs in-sequence tables of c3 / c5; the MFMA-shape
-# microbenchmark; the one-rank RCCL test's report; per-kernel PMC summaries of c2 and c4.
+# microbenchmark; the one-rank RCCL test's report; per-kernel PMC summaries of c2 and c4 and, from the same counter passes,
+# every launch's HBM traffic against its algorithmic / stored bytes (tools/traffic_per_launch.py); the FETCH_SIZE calibration
+# on this library's read patterns (tools/r6_calib.sh); the ResNet stem launch with and without the folded pre-activation
+# (tools/r6_poolact.sh); per-launch tables of both training steps (tools/step_times.py).
 # Usage: bash tools/profile_round_r6.sh TAG     (writes gpurun_out/prof_TAG/ and gpurun_out/pmc_TAG_{c2,c4}/)
 TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -41,6 +44,13 @@ python3 tools/seq_vs_warm.py --preset c5 > $O/seq_vs_warm_c5.txt 2>&1
 python3 -m pytest tests/test_gpu_rccl_one_rank.py -x -q -m gpu -s > $O/rccl_one_rank.txt 2>&1
 bash tools/pmc_bench.sh gpurun_out/pmc_${TAG}_c2 > /dev/null 2>&1
 bash tools/pmc_bench.sh gpurun_out/pmc_${TAG}_c4 --preset c4 > /dev/null 2>&1
+python3 tools/traffic_per_launch.py gpurun_out/pmc_${TAG}_c2 --preset c2 --trace $O/kt/kt_kernel_trace.csv > $O/traffic_per_launch_c2.txt 2>&1
+python3 tools/traffic_per_launch.py gpurun_out/pmc_${TAG}_c4 --preset c4 > $O/traffic_per_launch_c4.txt 2>&1
+bash tools/r6_poolact.sh > $O/pool_act_ab.log 2>&1; cp gpurun_out/r6/pool_act_ab.txt $O/pool_act_ab.txt
+[ -x gvcnn-tf_amd/build/fetch_calib ] && bash tools/r6_calib.sh calib-only > $O/fetch_calib.log 2>&1 && cp gpurun_out/r6/fetch_calib.txt $O/fetch_calib.txt
+python3 tools/step_times.py --backbone resnet_v2_50 --tune > $O/step_times_train_c4_bf16.txt 2>&1
+python3 tools/step_times.py --tune > $O/step_times_train_c3_bf16.txt 2>&1
+head -4 $O/traffic_per_launch_c2.txt; head -4 $O/traffic_per_launch_c4.txt; cat $O/pool_act_ab.txt
 cat $O/chain_plan_ab.txt
 cat $O/chain_probe.txt | grep "^d "
 tail -2 $O/seq_vs_warm_c3.txt

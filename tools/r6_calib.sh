@@ -30,6 +30,7 @@ for d, names in (("calib_f", ("FETCH_SIZE",)), ("calib_r", ("TCC_EA0_RDREQ_sum",
             else:
                 print("%-16s %-22s %12.0f requests; bytes read / requests = %.1f" % (k, cn, v, want[k] / max(v, 1)))
 PY
+[ "$1" = "calib-only" ] && exit 0
 # the same counters over the c2 step (single lane, tuned tiles): FETCH_SIZE next to the request-size split
 O=gpurun_out/r6/pmc_req_c2
 mkdir -p $R/$O
