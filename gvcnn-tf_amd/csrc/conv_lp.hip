@@ -779,12 +779,12 @@ __global__ __launch_bounds__(256, POOL ? 3 : 2) void conv_stem_patch_lp(const Co
     }
     auto fetch = [&](int oy0) {
         const int iy0 = oy0 * 2 - a.pad_t;
-        const float* base = a.x + ((ptrdiff_t)n * a.ih + iy0) * (ptrdiff_t)a.iw * a.x_ld;
+        const ptrdiff_t row0 = ((ptrdiff_t)n * a.ih + iy0) * (ptrdiff_t)a.iw * a.x_ld;   // (may lie in front of the image: only offsets of rows inside it are read)
 #pragma unroll
         for (int k = 0; k < SL; ++k) {
             const int iy = iy0 + ((p_info[k] >> 16) & 0xff);
             float v = 0.f;
-            if (((p_info[k] >> 24) & 1) && (unsigned)iy < (unsigned)a.ih) v = base[p_goff[k]];
+            if (((p_info[k] >> 24) & 1) && (unsigned)iy < (unsigned)a.ih) v = a.x[row0 + p_goff[k]];
             pr_[k] = v;
         }
     };

@@ -2015,8 +2015,11 @@ int pool2d_bwd_argmax(const gv_pool_desc* d, const unsigned char* arg, const voi
     BnTail bn{bn_z, bn_z_ld, bn_G, bn_A, bn_B, bn_C, bn_scale, bn_shift};
     const int store = (d->mode & GV_POOL_BWD_STORE) ? 1 : 0;
     const int64_t npix = (int64_t)d->nb * d->ih * d->iw;
+    // 3x3 / 2 windows that start at even pixels: VALID, or TF's SAME on an even map (pads (0, 1): the last window is clipped —
+    // ResNet-v2's pool1, nets/resnet_v2.py:181; the 2 x 2 block kernel only asks which windows exist)
+    const bool same_h = d->ih % 2 == 0 && d->oh == d->ih / 2, same_w = d->iw % 2 == 0 && d->ow == d->iw / 2;
     const bool m3s2 = d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 && d->pad_l == 0 &&
-                      d->oh == (d->ih - 3) / 2 + 1 && d->ow == (d->iw - 3) / 2 + 1;
+                      (d->oh == (d->ih - 3) / 2 + 1 || same_h) && (d->ow == (d->iw - 3) / 2 + 1 || same_w);
     if (bn_z && !m3s2) return GV_E_UNSUPPORTED;                  // the BatchNorm tail exists in the 3x3 / 2 kernel only
     if (bn_z && !(gv_aligned16(bn_A) && gv_aligned16(bn_B) && gv_aligned16(bn_C) && gv_aligned16(bn_scale) &&
                   gv_aligned16(bn_shift)))

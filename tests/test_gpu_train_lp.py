@@ -171,13 +171,14 @@ def test_pool_backward_typed(dt, tdt, eps, k, stride, padding, mode, c):
 @pytest.mark.parametrize("dt,tdt", [(_lib.GV_BF16, torch.bfloat16), (_lib.GV_F16, torch.float16), (_lib.GV_F32, torch.float32)])
 @pytest.mark.parametrize("k,stride,padding", [(3, 2, "VALID"), (3, 2, "SAME"), (3, 1, "SAME"), (1, 2, "VALID"), (2, 2, "VALID")])
 @pytest.mark.parametrize("c,ld", [(16, 16), (24, 40), (5, 7)])
-def test_max_pool_with_recorded_argmax(dt, tdt, k, stride, padding, c, ld):
+@pytest.mark.parametrize("hw", [(11, 9), (12, 10)])      # (an even map: TF's SAME 3x3 / 2 pads (0, 1) there — ResNet-v2's pool1)
+def test_max_pool_with_recorded_argmax(dt, tdt, k, stride, padding, c, ld, hw):
     """gv_pool2d_fwd_argmax / gv_pool2d_bwd_argmax (the training step's max pools): the forward output is that of
     gv_pool2d_fwd bit for bit, the recorded byte is the row-major tap of the FIRST maximum of the window (ties planted),
     and the backward, which never sees x, reproduces gv_pool2d_bwd (tf MaxPoolGrad) bit for bit in both its accumulate and
     its store form."""
     g = torch.Generator().manual_seed(k * 10 + stride + c)
-    nb, ih, iw = 2, 11, 9
+    nb, (ih, iw) = 2, hw
     x = q(torch.randn(nb, ih, iw, c, generator=g), tdt)
     x[0, 2:6, 2:6, :] = 0.5                              # ties
     x[1, :, :, 0] = -3.0
