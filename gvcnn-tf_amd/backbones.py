@@ -998,7 +998,8 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         # unit changes the depth, so pool1's only reader is that unit's `preact` BatchNorm + ReLU (:75): it rides on the
         # pooled tensor's way out of the same launch (16-bit storage, GV_CONV_POOL_ACT2) and pool1 itself is never stored
         first_pre = "%s/%s/unit_1/bottleneck_v2/preact" % (scope, RESNET50_BLOCKS[0][0])
-        fold_pre = b.dtype != _lib.GV_F32 and getattr(b, "fuse_pool_act", False) and RESNET50_BLOCKS[0][1] * 4 != 64
+        fold_pre = (b.dtype != _lib.GV_F32 and getattr(b, "fuse_pool_act", False) and RESNET50_BLOCKS[0][1] * 4 != 64 and
+                    scope + "/pool1" not in keep)
         net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False, maxpool="SAME",
                      pool_act=(first_pre, RESNET_BN_EPS) if fold_pre else None)
         pre_folded = fold_pre
