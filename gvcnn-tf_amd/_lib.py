@@ -14,6 +14,7 @@ GV_F32, GV_BF16, GV_F16 = 0, 1, 2
 GV_CONV_RELU, GV_CONV_RELU2, GV_CONV_SPLIT, GV_CONV_X_F32 = 1, 2, 4, 8
 GV_CONV_X_P3, GV_CONV_Y_P3, GV_CONV_Y2_P3, GV_CONV_MAXPOOL3S2, GV_CONV_MAXPOOL3S2_SAME = 16, 32, 64, 128, 256
 GV_CONV_POOL_ACT2 = 512
+GV_CHAIN_PROJ = 4096
 GV_MATH_F32, GV_MATH_BF16X3, GV_MATH_BF16X2, GV_MATH_BF16X1 = 0, 1, 2, 3
 GV_POOL_MAX, GV_POOL_AVG, GV_POOL_AVG_RELU = 0, 1, 2
 GV_POOL_BWD_STORE = 0x100

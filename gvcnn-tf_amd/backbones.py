@@ -133,6 +133,8 @@ class BackbonePlan:
         self.fuse_pair = False
         # ... and ResNet's first pre-activation on the fused conv1 -> pool1 launch's way out (GV_CONV_POOL_ACT2)
         self.fuse_pool_act = False
+        # ... and a depth-changing unit's projection shortcut inside its conv3 GEMM (GV_CHAIN_PROJ: ResNet-v2-50's first unit)
+        self.fuse_proj = False
 
     # ---- symbolic construction ----------------------------------------------------------------
     def lane(self, k):
@@ -282,13 +284,16 @@ class BackbonePlan:
         oh, pad_t = _out_size(x.h, kh, stride, padding if not isinstance(padding, tuple) else padding[0])
         ow, pad_l = _out_size(x.w, kw, stride, padding if not isinstance(padding, tuple) else padding[1])
         if maxpool:
-            assert out is None and residual is None and next_preact is None and xpre is None and not p3
+            assert residual is None and next_preact is None and xpre is None and not p3
             maxpool = "VALID" if maxpool is True else maxpool
             if maxpool == "SAME":
                 assert oh % 2 == 0 and ow % 2 == 0
-                out = self.new_tensor(x.nb, oh // 2, ow // 2, cout)
+                pshape = (x.nb, oh // 2, ow // 2, cout)
             else:
-                out = self.new_tensor(x.nb, (oh - 3) // 2 + 1, (ow - 3) // 2 + 1, cout)
+                pshape = (x.nb, (oh - 3) // 2 + 1, (ow - 3) // 2 + 1, cout)
+            if out is None:
+                out = self.new_tensor(*pshape)
+            assert (out.nb, out.h, out.w, out.c) == pshape, (scope, out, pshape)     # (`out`: a channel slice of a wider buffer)
         elif out is None:
             # p3: the output only feeds other convolutions (a conv -> conv intermediate)
             out = self.new_tensor(x.nb, oh, ow, cout, p3=p3 and next_preact is None and residual is None and x.c >= 16)
@@ -341,25 +346,35 @@ class BackbonePlan:
         op["bytes"] += float(self.esz) * 9 * d * d
         return out, z
 
-    def chain(self, x, scope3, shortcut, pre_scope, pre_eps, scope1, norm1):
+    def chain(self, x, scope3, shortcut, pre_scope, pre_eps, scope1, norm1, proj=None):
         """nets/resnet_v2.py:87-91 of one unit (conv3 1x1 + biases, `shortcut + residual`) and :75, :83-84 of the next
         (preact BatchNorm + ReLU, conv1 1x1 + BatchNorm + ReLU) as ONE launch.  Returns (unit output [.., 4d], next unit's
-        conv1 output [.., d]).  Recorded as a conv op with a `chain` record: x, res, y as for conv3, y2 = the conv1 output."""
-        d, cout = x.c, 4 * x.c
-        assert (shortcut.nb, shortcut.h, shortcut.w, shortcut.c) == (x.nb, x.h, x.w, cout)
+        conv1 output [.., d]).  Recorded as a conv op with a `chain` record: x, res, y as for conv3, y2 = the conv1 output.
+        proj = the scope of the unit's PROJECTION shortcut (:79-81; the unit's depth changes, shortcut is None): x is
+        [conv2 output | the unit's pre-activation] (2d channels), conv3's and the shortcut's filters are concatenated along
+        cin and their biases added — conv3(x2) + shortcut(x0) is one accumulation and the shortcut tensor never exists
+        (GV_CHAIN_PROJ)."""
+        d = x.c // 2 if proj else x.c
+        cout = 4 * d
+        assert (shortcut is None) == bool(proj)
+        assert proj or (shortcut.nb, shortcut.h, shortcut.w, shortcut.c) == (x.nb, x.h, x.w, cout)
         out = self.new_tensor(x.nb, x.h, x.w, cout)
         z = self.new_tensor(x.nb, x.h, x.w, d)
-        w3_off = self._filter(scope3 + "/weights", 1, 1, d, cout)
-        so, ho = self._scale_shift("bias", scope3 + "/biases", cout)
+        if proj:
+            w3_off = self._filter(scope3 + "/weights|" + proj + "/weights", 1, 1, 2 * d, cout)
+            so, ho = self._scale_shift("bias_sum", scope3 + "/biases|" + proj + "/biases", cout)
+        else:
+            w3_off = self._filter(scope3 + "/weights", 1, 1, d, cout)
+            so, ho = self._scale_shift("bias", scope3 + "/biases", cout)
         ps, ph = self._scale_shift("bn", pre_scope, cout, pre_eps, True)
         w1_off = self._filter(scope1 + "/weights", 1, 1, cout, d)
         s1, h1 = self._scale_shift("bn", scope1 + "/BatchNorm", d, norm1[1], norm1[2])
-        self._record(dict(kind="conv", name=scope3 + "+" + scope1, x=x, y=out, y2=z, res=shortcut, w_off=w3_off,
-                          scale_off=so, shift_off=ho, scale2_off=ps, shift2_off=ph,
-                          chain=dict(w1_off=w1_off, scale1_off=s1, shift1_off=h1),
+        self._record(dict(kind="conv", name=(proj + "+" if proj else "") + scope3 + "+" + scope1, x=x, y=out, y2=z, res=shortcut,
+                          w_off=w3_off, scale_off=so, shift_off=ho, scale2_off=ps, shift2_off=ph,
+                          chain=dict(w1_off=w1_off, scale1_off=s1, shift1_off=h1, proj=bool(proj)),
                           kh=1, kw=1, stride=1, pad_t=0, pad_l=0, relu=False, split=0, cout=cout, xpre=None, maxpool=None,
-                          oh=x.h, ow=x.w, flops=2.0 * x.npix * (d * cout + cout * d),
-                          bytes=float(self.esz) * (x.npix * (d + cout + cout + d) + 2 * d * cout)))
+                          oh=x.h, ow=x.w, flops=2.0 * x.npix * (x.c * cout + cout * d),
+                          bytes=float(self.esz) * (x.npix * (x.c + (0 if proj else cout) + cout + d) + (x.c + d) * cout)))
         return out, z
 
     def fused_maxpool_ok(self, x, cout, k, padding, stride=1, pool_padding="VALID"):
@@ -397,9 +412,11 @@ class BackbonePlan:
         t = self.pool(x, 3, 1, "SAME", _lib.GV_POOL_AVG, name=pool_name)
         return self.conv(t, conv_scope, depth, 1, out=dst, norm=norm, relu=True)
 
-    def bn_relu(self, x, bn_scope, eps, name):
+    def bn_relu(self, x, bn_scope, eps, name, out=None):
         """Stand-alone slim.batch_norm(activation_fn=relu) (resnet_v2.py:75, first unit only)."""
-        out = self.new_tensor(x.nb, x.h, x.w, x.c)
+        if out is None:
+            out = self.new_tensor(x.nb, x.h, x.w, x.c)
+        assert (out.nb, out.h, out.w, out.c) == (x.nb, x.h, x.w, x.c)
         so, ho = self._scale_shift("bn", bn_scope, x.c, eps, True)
         self._record(dict(kind="ssa", name=name, x=x, y=out, scale_off=so, shift_off=ho, relu=True,
                              flops=0.0, bytes=2.0 * self.esz * x.npix * x.c))
@@ -491,8 +508,12 @@ class BackbonePlan:
                                                 ch["shift1_off"], rs, ro, ys, yo, y2s, y2o), "gv_plan_add_unit(%s)" % op["name"])
             elif op["kind"] == "conv" and op.get("chain"):
                 ch, res, y2 = op["chain"], op["res"], op["y2"]
-                d = _lib.ChainDesc(x.npix, x.c, x.ld, res.ld, y.ld, y2.ld, self.dtype, _lib.GV_CONV_RELU2, 0)
-                rs, ro = ref(res)
+                if ch.get("proj"):                            # GV_CHAIN_PROJ: x = [conv2 output | pre-activation], no shortcut operand
+                    d = _lib.ChainDesc(x.npix, x.c // 2, x.ld, 0, y.ld, y2.ld, self.dtype, _lib.GV_CONV_RELU2 | _lib.GV_CHAIN_PROJ, 0)
+                    rs, ro = -1, 0
+                else:
+                    d = _lib.ChainDesc(x.npix, x.c, x.ld, res.ld, y.ld, y2.ld, self.dtype, _lib.GV_CONV_RELU2, 0)
+                    rs, ro = ref(res)
                 y2s, y2o = ref(y2)
                 _lib.check(lib.gv_plan_add_chain(plan, C.byref(d), xs, xo, SLOT_WEIGHTS, op["w_off"] * wmul,
                                                  ch["w1_off"] * wmul, SLOT_SS, op["scale_off"], op["shift_off"],
@@ -616,7 +637,8 @@ class BackbonePlan:
         dev = self.weights.device
         st = _stream_ptr(stream)
         for name, kh, kw, cin, cout, off in self.filters:
-            w = torch.as_tensor(params[name]).to(device=dev, dtype=torch.float32).contiguous()
+            # ("a|b": the two variables concatenated along cin — GV_CHAIN_PROJ's [conv3 ; shortcut] filter)
+            w = torch.cat([torch.as_tensor(params[n]).to(device=dev, dtype=torch.float32) for n in name.split("|")], dim=2).contiguous()
             assert tuple(w.shape) == (kh, kw, cin, cout), (name, tuple(w.shape), (kh, kw, cin, cout))
             _lib.check(self.lib.gv_pack_filter_hwio(w.data_ptr(), kh, kw, cin, cout,
                                                     self.weights.data_ptr() + 4 * off, self.dtype,
@@ -632,6 +654,9 @@ class BackbonePlan:
             if kind == "bias":
                 host[so:so + c] = 1.0
                 host[ho:ho + c] = arr(name)
+            elif kind == "bias_sum":                          # ("a|b": the biases of two convolutions whose outputs are added)
+                host[so:so + c] = 1.0
+                host[ho:ho + c] = sum(arr(n) for n in name.split("|"))
             else:
                 inv = 1.0 / np.sqrt(arr(name + "/moving_variance") + eps)
                 if has_gamma:
@@ -647,10 +672,12 @@ class BackbonePlan:
         """slim variable name -> shape, for every variable the plan reads."""
         shapes = {}
         for name, kh, kw, cin, cout, _ in self.filters:
-            shapes[name] = (kh, kw, cin, cout)
+            for n in name.split("|"):
+                shapes[n] = (kh, kw, cin // len(name.split("|")), cout)
         for kind, name, c, eps, has_gamma, _, _ in self.ss_specs:
-            if kind == "bias":
-                shapes[name] = (c,)
+            if kind in ("bias", "bias_sum"):
+                for n in name.split("|"):
+                    shapes[n] = (c,)
             else:
                 for leaf in ("beta", "moving_mean", "moving_variance") + (("gamma",) if has_gamma else ()):
                     shapes[name + "/" + leaf] = (c,)
@@ -991,6 +1018,20 @@ RESNET50_BLOCKS = (("block1", 64, 3, 2), ("block2", 128, 4, 2), ("block3", 256, 
 def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), scope="resnet_v2_50"):
     BN = ("bn", RESNET_BN_EPS, True)
     MAX = _lib.GV_POOL_MAX
+    # The first unit changes the depth at stride 1 and its pre-activation has as many channels as its bottleneck (64): its
+    # projection shortcut rides in conv3's GEMM (GV_CHAIN_PROJ, csrc/conv_chain.hip) — the pre-activation is written next to
+    # where conv2 will write, [conv2 | preact] is conv3's 128-channel input, and the 256-channel shortcut tensor never exists
+    b0 = RESNET50_BLOCKS[0]
+    proj0 = (getattr(b, "fuse_proj", False) and getattr(b, "fuse_chain", False) and b.dtype != _lib.GV_F32 and b0[1] == 64 and
+             b0[2] >= 2 and scope + "/pool1" not in keep and "%s/%s/unit_1/bottleneck_v2" % (scope, b0[0]) not in keep)
+    xb = None
+
+    def first_preact_out(h, w):
+        nonlocal xb
+        if not proj0:
+            return None
+        xb = b.new_tensor(b.nb, h, w, 128)
+        return xb.channels(64, 128)
     # conv1: explicit pad 3 + VALID, bias, no BN/ReLU (resnet_v2.py:178-180, resnet_utils.py:94-105)
     if scope + "/conv1" not in keep and getattr(b, "fuse_maxpool", False) and \
             b.fused_maxpool_ok(b.input, 64, 7, ((3, 3), (3, 3)), 2, "SAME"):
@@ -1000,8 +1041,9 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         first_pre = "%s/%s/unit_1/bottleneck_v2/preact" % (scope, RESNET50_BLOCKS[0][0])
         fold_pre = (b.dtype != _lib.GV_F32 and getattr(b, "fuse_pool_act", False) and RESNET50_BLOCKS[0][1] * 4 != 64 and
                     scope + "/pool1" not in keep)
+        ph, pw = _out_size(b.height, 7, 2, (3, 3))[0] // 2, _out_size(b.width, 7, 2, (3, 3))[0] // 2
         net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False, maxpool="SAME",
-                     pool_act=(first_pre, RESNET_BN_EPS) if fold_pre else None)
+                     pool_act=(first_pre, RESNET_BN_EPS) if fold_pre else None, out=first_preact_out(ph, pw) if fold_pre else None)
         pre_folded = fold_pre
     else:
         net = b.conv(b.input, scope + "/conv1", 64, 7, 2, ((3, 3), (3, 3)), norm=None, relu=False)
@@ -1015,13 +1057,18 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
     first_sc = "%s/%s/unit_1/bottleneck_v2" % (scope, units[0][0])
     # (pre_folded: `net` already IS the first pre-activation; nothing reads the raw pool1 — the first unit's shortcut is a
     # projection of the pre-activation, resnet_v2.py:79-81)
-    preact = net if pre_folded else b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact")
+    preact = net if pre_folded else b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact",
+                                              out=first_preact_out(net.h, net.w))
     c1_ready = None                                     # this unit's conv1 output, when the previous unit's chain launch made it
     for i, (bname, base, u, n_units, stride) in enumerate(units):
         sc = "%s/%s/unit_%d/bottleneck_v2" % (scope, bname, u + 1)
         depth, depth_in = base * 4, net.c
         pair = None
-        if depth == depth_in:                                                      # resnet_v2.py:76-77
+        proj = i == 0 and xb is not None and stride == 1 and depth != depth_in and depth_in == base and \
+            units[1][1] * 4 == depth and preact.vbuf == xb.vbuf
+        if proj:
+            shortcut = None                                                        # (inside conv3's GEMM)
+        elif depth == depth_in:                                                    # resnet_v2.py:76-77
             shortcut = net if stride == 1 else b.pool(net, 1, stride, "VALID", MAX, name=sc + "/shortcut")
         elif (stride == 1 and getattr(b, "fuse_pair", False) and not isinstance(preact, DeferredPreact) and base % 8 == 0
               and c1_ready is None and base >= 128):
@@ -1042,13 +1089,15 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
         # (identity shortcut, conv1 the pre-activation's only reader) and the bottleneck depth is one the kernel serves;
         # with fuse_unit this unit's conv2 (stride 1 here: the strided unit is a block's last) runs in front of it
         chains = i + 1 < len(units) and units[i + 1][1] * 4 == depth and getattr(b, "fuse_chain", False) and b.chain_ok(r)
+        assert chains or not proj
         # (whole units where that pays: d = 64.  At d = 128 the unit launch measured level with chain + conv2 — 0.276 against
         # 0.166 + 0.107 ms, profiles/r6_seq_vs_warm_c4_*.txt — its conv2 phase is matrix-heavy and its one 8-wave workgroup per
         # CU runs the phases in lockstep; fuse_unit="all" asks for it anyway)
         fu = getattr(b, "fuse_unit", False)
-        whole = chains and bool(fu) and stride == 1 and (r.c <= 64 or fu == "all")
+        whole = chains and bool(fu) and stride == 1 and (r.c <= 64 or fu == "all") and not proj
         if not whole:
-            r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True)     # :85-86
+            r = b.conv(r, sc + "/conv2", base, 3, stride, pad, norm=BN, relu=True,      # :85-86
+                       out=xb.channels(0, 64) if proj else None)
         nxt = None
         kw = {}
         if i + 1 < len(units):
@@ -1058,6 +1107,8 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
                 nsc = "%s/%s/unit_%d/bottleneck_v2" % (scope, nb_, nu + 1)
                 if whole:
                     net, c1_ready = b.unit(r, sc + "/conv2", BN, sc + "/conv3", shortcut, nxt[0], nxt[1], nsc + "/conv1", BN)
+                elif proj:
+                    net, c1_ready = b.chain(xb, sc + "/conv3", None, nxt[0], nxt[1], nsc + "/conv1", BN, proj=sc + "/shortcut")
                 else:
                     net, c1_ready = b.chain(r, sc + "/conv3", shortcut, nxt[0], nxt[1], nsc + "/conv1", BN)
                 preact = None
@@ -1106,7 +1157,8 @@ MATH_MODES = {"f32": _lib.GV_MATH_F32, "bf16x3": _lib.GV_MATH_BF16X3, "bf16x2": 
 
 
 def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None, dtype=_lib.GV_F32,
-              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True, fuse_chain=True, fuse_unit=True):
+              math="f32", lanes=True, p3=True, defer_preact=True, fuse_maxpool=True, fuse_chain=True, fuse_unit=True,
+              fuse_proj=True):
     """p3: under fp32 storage + math 'bf16x3', keep conv -> conv intermediates as three bf16 planes (value neutral:
     the planes sum exactly to the fp32 value and the products are the same six MFMAs in the same order).  True: in the
     blocks of P3_DEFAULT_BLOCKS; "all": everywhere; a collection of block names: there; False: nowhere.
@@ -1125,6 +1177,8 @@ def make_plan(backbone, nb, height, width, device, raw_tap=None, final_tap=None,
         b.fuse_unit = "all"
     b.fuse_pair = bool(fuse_chain) and dtype != _lib.GV_F32 and os.environ.get("GV_NO_PAIR") is None
     b.fuse_pool_act = b.fuse_maxpool and dtype != _lib.GV_F32 and os.environ.get("GV_NO_POOL_ACT") is None
+    # the first ResNet unit's projection shortcut inside its conv3 GEMM (GV_CHAIN_PROJ; GV_NO_PROJ=1: whole-plan A/B)
+    b.fuse_proj = b.fuse_chain and bool(fuse_proj) and os.environ.get("GV_NO_PROJ") is None
     if isinstance(p3, (set, frozenset, list, tuple)):
         b.p3_blocks = set(p3)
     elif p3 is True:

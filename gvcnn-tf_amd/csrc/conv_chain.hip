@@ -78,8 +78,11 @@ __device__ __forceinline__ void ch_for_each(F&& f, std::integer_sequence<int, Cs
 // every line is read / written whole by 8 lanes of one instruction.  (The first form of this kernel worked in 32-column
 // chunks: 64-byte halves of a line in two chunks ~8000 clocks apart; by then the half-used line had left the XCD's L2 and
 // was fetched / written back twice — same-box experiment profiles/r6_chain_full_lines_ab.txt: 0.379 -> 0.320 ms.)
-template <int D> struct ChainGeom {
-    static constexpr int K1 = D, N1 = 4 * D, N2 = D;
+// KX = 2 (round 6, the PROJECTION form: a unit whose depth changes, nets/resnet_v2.py:79-81): GEMM 1's K is 2d — x holds
+// [the unit's conv2 output | the unit's pre-activation] and W1 the K-concatenated [conv3 ; projection shortcut] filter, so
+// that  conv3(x2) + shortcut(x0)  is ONE accumulation and no shortcut tensor exists (no residual operand: NORES).
+template <int D, int KX = 1> struct ChainGeom {
+    static constexpr int K1 = D * KX, N1 = 4 * D, N2 = D;
     static constexpr int KS1 = K1 / 16;            // MFMA k-steps of GEMM 1
     static constexpr int NB2 = N2 / 32;            // 32-column accumulator blocks of GEMM 2
     static constexpr int NCH = N1 / 64;            // chunks
@@ -114,10 +117,12 @@ template <int D> struct ChainGeom {
 // TAIL: only the SECOND half — z = relu(bn(conv1x1(relu(y * pscale + pshift)))) with y read from memory through the prefetch
 // registers (a.res = y): gv_conv2d_fwd_xpre's class 4d -> d as a streaming launch (no GEMM 1, no store of y; the ring carries
 // conv1's filter only).  Serves the identity units the chain does not (d = 256: block3 of ResNet-v2-50).
-template <typename T, int D, int NW, int RVS, bool FRONT = false, bool TAIL = false>
+template <typename T, int D, int NW, int RVS, bool FRONT = false, bool TAIL = false, int KX = 1>
 __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
-    using G = ChainGeom<D>;
+    using G = ChainGeom<D, KX>;
+    constexpr bool NORES = KX > 1;                 // the shortcut is part of GEMM 1: nothing to prefetch, nothing to add
     static_assert(!(FRONT && TAIL), "one or the other");
+    static_assert(KX == 1 || (!FRONT && !TAIL), "the projection form: the plain chain only");
     constexpr int N1 = G::N1, N2 = G::N2, KS1 = G::KS1, NB2 = G::NB2, NCH = G::NCH;
     constexpr int RBW1 = G::RBW1, CPR1 = G::CPR1, RPP1 = G::RPP1;
     constexpr int W1C = TAIL ? 0 : G::W1C, SLOT = W1C + G::W2C, NP1 = W1C / 1024, NPC = SLOT / 1024;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const size_t m = (size_t)min(mw + p * 8 + r8, a.M - 1);
-        rrow_p[p] = a.res + m * a.res_ld + c8 * 8;
+        rrow_p[p] = NORES ? nullptr : a.res + m * a.res_ld + c8 * 8;
         yrow[p] = a.y + m * a.y_ld + c8 * 8;
         zrow[p] = a.z + m * a.z_ld + c8 * 8;
     }
@@ -204,11 +209,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     constexpr bool EARLY_RV = FRONT && D <= 64;              // (d = 128: the conv2 phase has no 16 registers to spare)
     u32x4 rv[RVS][4];
     auto load_rv = [&]() {
+        if constexpr (!NORES) {
 #pragma unroll
-        for (int q = 0; q < RVS; ++q)
+            for (int q = 0; q < RVS; ++q)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) rv[q][p] = *reinterpret_cast<const u32x4*>(rrow_p[p] + q * 64);
+                for (int p = 0; p < 4; ++p) rv[q][p] = *reinterpret_cast<const u32x4*>(rrow_p[p] + q * 64);
+        }
     };
+    constexpr int RVL = NORES ? 0 : 4;             // shortcut loads a chunk issues / the prologue issues per register set
     u32x4 xa[KS1];
     if constexpr (TAIL) {
         issue_chunk(0, 0);
@@ -367,8 +375,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
         // is done with chunk c - 1, whose slot takes chunk c + 1.
         // (FRONT: chunk 0's DMAs went out at the top of the last pre-chunk, in front of that pre-chunk's tap loads)
         // (TAIL: no x fragments, no stores in the loop)
-        if constexpr (c == 0) ch_wait_vm<(TAIL ? 0 : FRONT ? G::front_loads((NPRE - 1) * TPS, 9) : KS1) + (EARLY_RV ? 0 : 4 * RVS)>();
-        else ch_wait_vm<(TAIL ? 0 : 4) + ((c - 1) + RVS < NCH ? 4 : 0)>();
+        if constexpr (c == 0) ch_wait_vm<(TAIL ? 0 : FRONT ? G::front_loads((NPRE - 1) * TPS, 9) : KS1) + (EARLY_RV ? 0 : RVL * RVS)>();
+        else ch_wait_vm<(TAIL ? 0 : 4) + ((c - 1) + RVS < NCH ? RVL : 0)>();
         __builtin_amdgcn_s_barrier();
         if constexpr (c + 1 < NCH) issue_chunk(c + 1, (NPRE + c + 1) % NR);
         const char* slot = smem + ((NPRE + c) % NR) * SLOT;
@@ -419,11 +427,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                    const u32x4 rq = rv[SET][p];
+                    if constexpr (!NORES) {
+                        const u32x4 rq = rv[SET][p];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[2 * j] += from_bits<T>((unsigned short)(rq[j] & 0xffffu));
-                        v[2 * j + 1] += from_bits<T>((unsigned short)(rq[j] >> 16));
+                        for (int j = 0; j < 4; ++j) {
+                            v[2 * j] += from_bits<T>((unsigned short)(rq[j] & 0xffffu));
+                            v[2 * j + 1] += from_bits<T>((unsigned short)(rq[j] >> 16));
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = pack2<T>(v[2 * j], v[2 * j + 1]);
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
                 *reinterpret_cast<u32x4*>(ztile + zr * 128 + ((c8 ^ G::swz128(zr)) << 4)) = zq;
             }
         }
-        if constexpr (c + RVS < NCH) {                             // this register set is free: the shortcut RVS chunks ahead
+        if constexpr (c + RVS < NCH && !NORES) {                   // this register set is free: the shortcut RVS chunks ahead
 #pragma unroll
             for (int p = 0; p < 4; ++p) rv[SET][p] = *reinterpret_cast<const u32x4*>(rrow_p[p] + (c + RVS) * 64);
         }
@@ -492,12 +502,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_chain_lp(const ChainArgs a) {
     ch_wait_vm<0>();                                               // (nothing of this workgroup may still be landing in LDS)
 }
 
-template <typename T, int D, int NW, int RVS, bool FRONT = false, bool TAIL = false>
+template <typename T, int D, int NW, int RVS, bool FRONT = false, bool TAIL = false, int KX = 1>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
-    using G = ChainGeom<D>;
+    using G = ChainGeom<D, KX>;
     constexpr int lds = G::template lds_bytes<NW>() - (TAIL ? G::NR * G::W1C : 0);
     static_assert(lds <= 160 * 1024, "one workgroup's LDS");
-    auto kern = &conv_chain_lp<T, D, NW, RVS, FRONT, TAIL>;
+    auto kern = &conv_chain_lp<T, D, NW, RVS, FRONT, TAIL, KX>;
     if (lds > 64 * 1024) {
         const bool ok = GV_BIG_LDS_OK(kern, lds);
         if (!ok) return GV_E_UNSUPPORTED;
@@ -518,7 +528,11 @@ int launch_unit_d(int d, const ChainArgs& a, hipStream_t st) {
 }
 
 template <typename T>
-int launch_chain_d(int d, const ChainArgs& a, hipStream_t st) {
+int launch_chain_d(int d, const ChainArgs& a, hipStream_t st, bool proj = false) {
+    if (proj) {                                                // K = 2d, no shortcut operand: 117 KB, one workgroup of 8 waves
+        if (d == 64) return launch_chain<T, 64, 8, 1, false, false, 2>(a, st);
+        return GV_E_UNSUPPORTED;
+    }
     switch (d) {
         case 64: return launch_chain<T, 64, 4, 2>(a, st);      // 68.5 KB of LDS: two workgroups of 4 waves per CU
         case 128: return launch_chain<T, 128, 8, 1>(a, st);    // 137 KB: one workgroup of 8 waves
@@ -578,13 +592,16 @@ extern "C" int gv_bottleneck_chain_fwd(const gv_chain_desc* d, const void* x, co
                                        const float* shift3, const void* shortcut, void* y, const float* pre_scale,
                                        const float* pre_shift, const void* w1_packed, const float* scale1, const float* shift1,
                                        void* z, void* stream) {
-    if (!d || !x || !w3_packed || !scale3 || !shift3 || !shortcut || !y || !pre_scale || !pre_shift || !w1_packed || !scale1 ||
-        !shift1 || !z)
+    const bool proj = d && (d->flags & GV_CHAIN_PROJ) != 0;   // the shortcut is the second half of GEMM 1's K: no operand
+    if (!d || !x || !w3_packed || !scale3 || !shift3 || (!shortcut && !proj) || (shortcut && proj) || !y || !pre_scale ||
+        !pre_shift || !w1_packed || !scale1 || !shift1 || !z)
         return GV_E_BADARG;
-    if (d->m <= 0 || d->d <= 0 || d->x_ld < d->d || d->res_ld < 4 * d->d || d->y_ld < 4 * d->d || d->z_ld < d->d) return GV_E_BADARG;
+    if (d->m <= 0 || d->d <= 0 || d->x_ld < d->d * (proj ? 2 : 1) || (!proj && d->res_ld < 4 * d->d) || d->y_ld < 4 * d->d ||
+        d->z_ld < d->d)
+        return GV_E_BADARG;
     if (d->dtype != GV_BF16 && d->dtype != GV_F16) return GV_E_UNSUPPORTED;
-    if (d->d != 64 && d->d != 128) return GV_E_UNSUPPORTED;
-    if ((d->x_ld | d->res_ld | d->y_ld | d->z_ld) % 8 != 0) return GV_E_UNSUPPORTED;
+    if (d->d != 64 && (d->d != 128 || proj)) return GV_E_UNSUPPORTED;
+    if ((d->x_ld | (proj ? 0 : d->res_ld) | d->y_ld | d->z_ld) % 8 != 0) return GV_E_UNSUPPORTED;
     if (!gv_aligned16(x) || !gv_aligned16(w3_packed) || !gv_aligned16(shortcut) || !gv_aligned16(y) || !gv_aligned16(w1_packed) ||
         !gv_aligned16(z))
         return GV_E_ALIGN;
@@ -597,8 +614,8 @@ extern "C" int gv_bottleneck_chain_fwd(const gv_chain_desc* d, const void* x, co
     a.relu2 = (d->flags & GV_CONV_RELU2) ? 1 : 0;
     a.dbg = g_chain_debug;
     a.w0 = nullptr; a.sc0 = a.sh0 = nullptr; a.zeros = nullptr; a.ih = a.iw = 0;
-    if (d->dtype == GV_BF16) return launch_chain_d<__bf16>(d->d, a, (hipStream_t)stream);
-    return launch_chain_d<_Float16>(d->d, a, (hipStream_t)stream);
+    if (d->dtype == GV_BF16) return launch_chain_d<__bf16>(d->d, a, (hipStream_t)stream, proj);
+    return launch_chain_d<_Float16>(d->d, a, (hipStream_t)stream, proj);
 }
 
 extern "C" int gv_bottleneck_unit_fwd(const gv_unit_desc* d, const void* x, const void* w2_packed, const float* scale2,

@@ -184,7 +184,8 @@ extern "C" int gv_plan_add_chain(gv_plan* p, const gv_chain_desc* d, int32_t x_s
                                  int32_t res_slot, int64_t res_off, int32_t y_slot, int64_t y_off, int32_t z_slot,
                                  int64_t z_off) {
     if (!p) return GV_E_PLAN;
-    if (!d || x_slot < 0 || w_slot < 0 || ss_slot < 0 || res_slot < 0 || y_slot < 0 || z_slot < 0) return GV_E_BADARG;
+    const bool proj = d && (d->flags & GV_CHAIN_PROJ) != 0;   // (no shortcut operand: res_slot = -1)
+    if (!d || x_slot < 0 || w_slot < 0 || ss_slot < 0 || (res_slot < 0) != proj || y_slot < 0 || z_slot < 0) return GV_E_BADARG;
     Op o{};
     o.kind = OP_CHAIN;
     o.chain = *d;

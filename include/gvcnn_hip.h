@@ -237,13 +237,20 @@ int gv_conv2d_fwd_xpre(const gv_conv_desc* d, const void* x, const float* xscale
  * gv_conv2d_fwd_xpre (z), bit for bit.  x [m, d], shortcut / y [m, 4d], z [m, d] with pixel strides *_ld (multiples of 8
  * elements, 16-byte aligned bases); w3_packed [4d][d], w1_packed [d][4d] as gv_pack_filter_hwio writes them for the dtype.
  * 16-bit storage, d = 64 or 128 (the HBM-bound blocks 1 and 2 of ResNet-v2-50): anything else GV_E_UNSUPPORTED and the
- * caller issues the two launches. */
+ * caller issues the two launches.
+ * GV_CHAIN_PROJ (flags; d = 64): the unit's depth CHANGES and its shortcut is the 1x1 projection of its pre-activation
+ * (nets/resnet_v2.py:79-81) — x is [m, 2d] = [the unit's conv2 output | the unit's pre-activation], w3_packed the
+ * K-concatenated [4d][2d] filter [conv3 ; shortcut] (gv_pack_filter_hwio of the two HWIO filters concatenated along cin),
+ * shift3 = conv3's biases + the shortcut's, `shortcut` NULL:  y = (conv3(x2) + shortcut(x0)) * scale3 + shift3  is ONE fp32
+ * accumulation with one rounding, and no shortcut tensor is written or read.  Against the separate launches (which round
+ * the shortcut to the storage type first) y differs by at most that one rounding. */
+#define GV_CHAIN_PROJ 4096
 typedef struct gv_chain_desc {
     int32_t m;                 /* rows = nb * oh * ow (all three tensors share the pixel grid) */
     int32_t d;                 /* bottleneck depth */
     int32_t x_ld, res_ld, y_ld, z_ld;
     int32_t dtype;             /* GV_BF16 | GV_F16 */
-    int32_t flags;             /* GV_CONV_RELU2: ReLU on z */
+    int32_t flags;             /* GV_CONV_RELU2: ReLU on z; GV_CHAIN_PROJ */
     int32_t tile_cfg;          /* 0 (reserved) */
 } gv_chain_desc;
 int gv_bottleneck_chain_fwd(const gv_chain_desc* d, const void* x, const void* w3_packed, const float* scale3,

@@ -104,6 +104,81 @@ def test_chain_declines_what_it_does_not_serve():
     assert lib().gv_bottleneck_chain_fwd(None, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, None) == _lib.GV_E_BADARG
 
 
+@pytest.mark.parametrize("ty", ["bf16", "f16"])
+@pytest.mark.parametrize("M", [256 * 4, 1000, 37, 1])
+def test_projection_chain_vs_oracle_and_the_launches_it_replaces(M, ty):
+    """GV_CHAIN_PROJ (the first unit of ResNet-v2-50: nets/resnet_v2.py:79-81 inside :87-91): x = [conv2 output | the unit's
+    pre-activation] (128 channels), the K-concatenated [conv3 ; shortcut] filter, the summed biases, no shortcut operand.
+    Against the oracle at the storage type's rounding (ONE rounding of y: closer to the fp32 reference than the separate
+    launches, which round the shortcut first), against those launches within that extra rounding, the second half (pre-activation
+    of the ROUNDED y, conv1) bit for bit gv_conv2d_fwd_xpre on the launch's own y; whole and ragged 256-row tiles, one row;
+    channel-slice operands."""
+    code, td, ulp = TYPES[ty]
+    d, n1 = 64, 256
+    g = torch.Generator().manual_seed(M)
+    x2 = rnd(torch.relu(torch.randn(M, d, generator=g)), td)                  # conv2's output
+    x0 = rnd(torch.relu(torch.randn(M, d, generator=g)), td)                  # the unit's pre-activation
+    w3 = rnd(torch.randn(d, n1, generator=g) * (1.0 / d) ** 0.5, td)
+    ws = rnd(torch.randn(d, n1, generator=g) * (1.0 / d) ** 0.5, td)
+    b3, bs = torch.randn(n1, generator=g) * 0.1, torch.randn(n1, generator=g) * 0.1
+    ps, ph = torch.rand(n1, generator=g) + 0.5, torch.randn(n1, generator=g) * 0.2
+    w1 = rnd(torch.randn(n1, d, generator=g) * (1.0 / n1) ** 0.5, td)
+    s1, h1 = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    x_ld, y_ld, z_ld = 2 * d + 8, n1 + 24, d + 8
+    xb = torch.full((M, x_ld), 7.0)
+    xb[:, :d], xb[:, d:2 * d] = x2, x0
+    xd = xb.to(td).to(DEV)
+    yd = torch.full((M, y_ld), -77.0, dtype=td, device=DEV)
+    zd = torch.full((M, z_ld), -55.0, dtype=td, device=DEV)
+    wcat = torch.cat([w3, ws], dim=0)                                         # [2d, 4d]: conv3's rows, then the shortcut's
+    wp, w1p = pack(wcat.view(1, 1, 2 * d, n1), code), pack(w1.view(1, 1, n1, d), code)
+    f = lambda t: t.to(DEV).float().contiguous()
+    one, bd, psd, phd, s1d, h1d = f(torch.ones(n1)), f(b3 + bs), f(ps), f(ph), f(s1), f(h1)
+    desc = _lib.ChainDesc(M, d, x_ld, 0, y_ld, z_ld, code, _lib.GV_CONV_RELU2 | _lib.GV_CHAIN_PROJ, 0)
+    _lib.check(lib().gv_bottleneck_chain_fwd(C.byref(desc), xd.data_ptr(), wp.data_ptr(), one.data_ptr(), bd.data_ptr(), None,
+                                             yd.data_ptr(), psd.data_ptr(), phd.data_ptr(), w1p.data_ptr(), s1d.data_ptr(),
+                                             h1d.data_ptr(), zd.data_ptr(), st()), "gv_bottleneck_chain_fwd (proj)")
+    torch.cuda.synchronize()
+    assert bool((yd[:, n1:].float() == -77.0).all()) and bool((zd[:, d:].float() == -55.0).all())     # padding untouched
+    y, z = yd[:, :n1].float().cpu(), zd[:, :d].float().cpu()
+    yo = x2 @ w3 + x0 @ ws + b3 + bs
+    close(y, yo.numpy(), ulp)
+    # the second half on the launch's own y: bit for bit gv_conv2d_fwd_xpre
+    z2 = torch.full((M, z_ld), -55.0, dtype=td, device=DEV)
+    d1 = _lib.ConvDesc(1, M, 1, n1, y_ld, 1, 1, 1, 0, 0, M, 1, d, z_ld, 0, 0, _lib.GV_CONV_RELU, code, 0, 0, 0, 0)
+    _lib.check(lib().gv_conv2d_fwd_xpre(C.byref(d1), yd.data_ptr(), psd.data_ptr(), phd.data_ptr(), w1p.data_ptr(), s1d.data_ptr(),
+                                        h1d.data_ptr(), None, z2.data_ptr(), None, None, None, st()), "conv1 (xpre)")
+    torch.cuda.synchronize()
+    assert torch.equal(zd, z2), "next conv1 differs from gv_conv2d_fwd_xpre on the same y"
+    # the launches it replaces: the shortcut as its own convolution (rounded to the storage type), then conv3 + residual
+    sc = torch.empty((M, n1), dtype=td, device=DEV)
+    dsc = _lib.ConvDesc(1, M, 1, d, x_ld, 1, 1, 1, 0, 0, M, 1, n1, n1, 0, 0, 0, code, 0, 0, 0, 0)
+    wsp, w3p = pack(ws.view(1, 1, d, n1), code), pack(w3.view(1, 1, d, n1), code)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(dsc), xd.data_ptr() + 2 * d, wsp.data_ptr(), one.data_ptr(), f(bs).data_ptr(), None,
+                                   sc.data_ptr(), None, None, None, st()), "shortcut")
+    ysep = torch.empty((M, n1), dtype=td, device=DEV)
+    d3 = _lib.ConvDesc(1, M, 1, d, x_ld, 1, 1, 1, 0, 0, M, 1, n1, n1, n1, 0, 0, code, 0, 0, 0, 0)
+    _lib.check(lib().gv_conv2d_fwd(C.byref(d3), xd.data_ptr(), w3p.data_ptr(), one.data_ptr(), f(b3).data_ptr(), sc.data_ptr(),
+                                   ysep.data_ptr(), None, None, None, st()), "conv3")
+    torch.cuda.synchronize()
+    # the shortcut's own rounding is the only difference: half a step of the SHORTCUT's magnitude, which may move y's
+    # rounding by one whole step of its own
+    ys, scv = ysep.float().cpu().numpy(), sc.float().cpu().numpy()
+    assert bool((np.abs(y.numpy() - ys) <= 1.01 * ulp * (np.abs(scv) + 2 * np.abs(ys)) + 1e-6).all())
+    same = float((y.numpy() == ys).mean())
+    assert same > 0.5, same
+
+
+def test_projection_chain_declines_what_it_does_not_serve():
+    B, U = _lib.GV_E_BADARG, _lib.GV_E_UNSUPPORTED
+    P = _lib.GV_CONV_RELU2 | _lib.GV_CHAIN_PROJ
+    call = lambda desc, res: lib().gv_bottleneck_chain_fwd(C.byref(desc), 16, 16, 16, 16, res, 16, 16, 16, 16, 16, 16, 16, None)
+    assert call(_lib.ChainDesc(64, 64, 128, 0, 256, 64, _lib.GV_BF16, P, 0), 16) == B          # a shortcut operand AND the flag
+    assert call(_lib.ChainDesc(64, 64, 64, 0, 256, 64, _lib.GV_BF16, P, 0), None) == B         # x narrower than 2d
+    assert call(_lib.ChainDesc(64, 128, 256, 0, 512, 128, _lib.GV_BF16, P, 0), None) == U      # d = 128: not this form
+    assert call(_lib.ChainDesc(64, 64, 128, 256, 256, 64, _lib.GV_BF16, _lib.GV_CONV_RELU2, 0), None) == B   # no flag, no shortcut
+
+
 def run_unit(x4, w2, s2, h2, w3, b3, res, ps, ph, w1, s1, h1, ty, expect=None):
     """x4 [nb, ih, iw, d]: the unit's conv1 output.  Returns (y, z) of gv_bottleneck_unit_fwd and (c2, y, z) of the launches it
     replaces: gv_conv2d_fwd (conv2 3x3 + BN + ReLU), then gv_bottleneck_chain_fwd."""
@@ -191,7 +266,7 @@ def test_resnet_plan_with_and_without_the_chain(ty, size, nb):
     outs, nops = [], []
     for fuse in (True, False):
         plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse,
-                                   fuse_unit=False)
+                                   fuse_unit=False, fuse_proj=False)   # (the projection form rounds once less: its own test)
         P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
         plan.bind(P)
         plan.run(x.to(DEV))
@@ -221,7 +296,7 @@ def test_resnet_plan_with_whole_unit_launches(ty, size, nb):
     outs = []
     for fuse in (True, False):
         plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_chain=fuse,
-                                   fuse_unit="all")                     # (every chain with its conv2 in front: d = 128 too)
+                                   fuse_unit="all", fuse_proj=False)    # (every chain with its conv2 in front: d = 128 too)
         P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
         plan.bind(P)
         plan.run(x.to(DEV))
@@ -233,6 +308,34 @@ def test_resnet_plan_with_whole_unit_launches(ty, size, nb):
     for k in outs[0]:
         a, b = outs[0][k].numpy(), outs[1][k].numpy()
         assert float(np.linalg.norm(a - b) / np.linalg.norm(b)) < bound / 2, k
+        ref = ep[k].numpy()
+        for o in outs:
+            assert float(np.linalg.norm(o[k][:2].numpy() - ref) / np.linalg.norm(ref)) < bound, k
+
+
+@pytest.mark.parametrize("ty,size,nb", [("bf16", 64, 6), ("f16", 224, 12), ("bf16", 97, 4)])
+def test_resnet_plan_with_the_projection_shortcut_inside_conv3(ty, size, nb):
+    """The DEFAULT 16-bit ResNet-v2-50 plan: the first unit's projection shortcut is part of its conv3 GEMM (GV_CHAIN_PROJ: no
+    shortcut launch, no shortcut tensor; conv2 and the pre-activation write the two halves of one 128-channel buffer).  Against
+    the oracle at the storage type's bound, and against the plan with the shortcut as its own launch: one rounding fewer in
+    front of ~45 layers, so block3 / block4 agree to the storage rounding, not bit for bit.  Also with the stand-alone
+    pre-activation (no fused max pool: the 97-pixel map keeps conv1, pool1 and the pre-activation as three launches)."""
+    x = (torch.rand(nb, size, size, 3, generator=torch.Generator().manual_seed(size)) - 0.5)
+    outs = []
+    for proj in (True, False):
+        plan = backbones.make_plan("resnet_v2_50", nb, size, size, torch.device(DEV), dtype=ty, lanes=False, fuse_proj=proj)
+        P = gv.params.init_backbone_params(plan.param_shapes(), seed=2, perturb_bn=True)
+        plan.bind(P)
+        plan.run(x.to(DEV))
+        torch.cuda.synchronize()
+        outs.append({k: plan.view(plan.end_points[k]).float().cpu() for k in ("resnet_v2_50/block3", "resnet_v2_50/block4")})
+        assert sum(1 for op in plan.ops if op.get("chain") and op["chain"].get("proj")) == (1 if proj else 0)
+        assert any(op["name"].endswith("block1/unit_1/bottleneck_v2/shortcut") for op in plan.ops) == (not proj)
+    bound = 3e-2 if ty == "bf16" else 4e-3
+    _, ep = OB.resnet_v2_50(x[:2], P)
+    for k in outs[0]:
+        a, b = outs[0][k].numpy(), outs[1][k].numpy()
+        assert float(np.linalg.norm(a - b) / np.linalg.norm(b)) < bound, k    # (two 16-bit plans, each within `bound` of the oracle)
         ref = ep[k].numpy()
         for o in outs:
             assert float(np.linalg.norm(o[k][:2].numpy() - ref) / np.linalg.norm(ref)) < bound, k

@@ -255,10 +255,21 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
     assert [(op["split"], op["cout"], op["relu_cols"]) for op in pairs] == [(128, 640, 128), (256, 1280, 256), (512, 2560, 512)]   # (block1's: slower, not fused)
     assert all(op["name"].split("+")[0].endswith("unit_1/bottleneck_v2/conv1") and op["name"].endswith("unit_1/bottleneck_v2/shortcut")
                for op in pairs)
-    for fuse_unit, fewer, fronts in (("all", 13, 5), (True, 10, 2), (False, 8, 0)):       # (default: whole units at d = 64 only)
+    # The FIRST unit changes the depth: its projection shortcut rides inside conv3's GEMM (GV_CHAIN_PROJ: x = [conv2 | preact],
+    # 128 channels, no shortcut operand, no shortcut launch), its conv2 stays a launch of its own
+    for fuse_unit, fewer, fronts in (("all", 13, 4), (True, 10, 1), (False, 9, 0)):       # (default: whole units at d = 64 only)
         p = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_unit=fuse_unit)
         chains = [op for op in p.ops if op.get("chain")]
-        assert [op["x"].c for op in chains] == [64, 64, 128, 128, 128]
+        assert [op["x"].c for op in chains] == [128, 64, 128, 128, 128]
+        pj = chains[0]
+        assert pj["chain"]["proj"] and pj["res"] is None and pj["y"].c == 256 and pj["y2"].c == 64 and not pj["chain"].get("front")
+        assert pj["name"].split("+")[0].endswith("block1/unit_1/bottleneck_v2/shortcut")
+        assert not any(o["name"].endswith("block1/unit_1/bottleneck_v2/shortcut") for o in p.ops)     # no shortcut launch
+        c2 = next(o for o in p.ops if o["name"].endswith("block1/unit_1/bottleneck_v2/conv2"))
+        c1 = next(o for o in p.ops if o["name"].endswith("block1/unit_1/bottleneck_v2/conv1"))
+        assert c2["y"].vbuf == pj["x"].vbuf and c2["y"].off == pj["x"].off and c2["y"].ld == 128       # conv2 writes channels [0, 64)
+        assert c1["x"].vbuf == pj["x"].vbuf and c1["x"].off == pj["x"].off + 64 and p.ops[0]["y"].off == c1["x"].off   # preact: [64, 128)
+        chains = chains[1:]
         assert sum(1 for op in chains if op["chain"].get("front")) == fronts
         assert all(bool(op["chain"].get("front")) == (fuse_unit == "all" or (fuse_unit is True and op["x"].c == 64)) for op in chains)
         assert len(p.ops) == len(off.ops) - fewer
@@ -288,5 +299,8 @@ def test_16bit_resnet_plan_chains_conv3_into_the_next_conv1(dtype):
     two = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu, dtype=dtype, fuse_maxpool=False)
     assert sum(1 for op in two.ops if op["kind"] == "ssa") == 1 and not any(op.get("pool_act") for op in two.ops)
     assert len(two.ops) == len(off.ops) - 10 + 2 and two.param_shapes() == off.param_shapes()
+    ssa = next(op for op in two.ops if op["kind"] == "ssa")                       # (the stand-alone pre-activation writes the slice too)
+    pj = next(op for op in two.ops if op.get("chain") and op["chain"].get("proj"))
+    assert ssa["y"].vbuf == pj["x"].vbuf and ssa["y"].off == pj["x"].off + 64
     f32 = backbones.make_plan("resnet_v2_50", 2, 224, 224, cpu)
     assert not any(op.get("chain") for op in f32.ops)
