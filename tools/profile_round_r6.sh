@@ -8,7 +8,8 @@
 # microbenchmark; the one-rank RCCL test's report; per-kernel PMC summaries of c2 and c4 and, from the same counter passes,
 # every launch's HBM traffic against its algorithmic / stored bytes (tools/traffic_per_launch.py); the FETCH_SIZE calibration
 # on this library's read patterns (tools/r6_calib.sh); the ResNet stem launch with and without the folded pre-activation
-# (tools/r6_poolact.sh); per-launch tables of both training steps (tools/step_times.py).
+# (tools/r6_poolact.sh) and the first unit's projection shortcut inside / outside its conv3 GEMM (tools/r6_proj.sh); per-launch
+# tables of both training steps (tools/step_times.py).
 # Usage: bash tools/profile_round_r6.sh TAG     (writes gpurun_out/prof_TAG/ and gpurun_out/pmc_TAG_{c2,c4}/)
 TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -47,10 +48,11 @@ bash tools/pmc_bench.sh gpurun_out/pmc_${TAG}_c4 --preset c4 > /dev/null 2>&1
 python3 tools/traffic_per_launch.py gpurun_out/pmc_${TAG}_c2 --preset c2 --trace $O/kt/kt_kernel_trace.csv > $O/traffic_per_launch_c2.txt 2>&1
 python3 tools/traffic_per_launch.py gpurun_out/pmc_${TAG}_c4 --preset c4 > $O/traffic_per_launch_c4.txt 2>&1
 bash tools/r6_poolact.sh > $O/pool_act_ab.log 2>&1; cp gpurun_out/r6/pool_act_ab.txt $O/pool_act_ab.txt
+bash tools/r6_proj.sh > $O/proj_ab.log 2>&1; cp gpurun_out/r6/proj_ab.txt $O/proj_ab.txt
 [ -x gvcnn-tf_amd/build/fetch_calib ] && bash tools/r6_calib.sh calib-only > $O/fetch_calib.log 2>&1 && cp gpurun_out/r6/fetch_calib.txt $O/fetch_calib.txt
 python3 tools/step_times.py --backbone resnet_v2_50 --tune > $O/step_times_train_c4_bf16.txt 2>&1
 python3 tools/step_times.py --tune > $O/step_times_train_c3_bf16.txt 2>&1
-head -4 $O/traffic_per_launch_c2.txt; head -4 $O/traffic_per_launch_c4.txt; cat $O/pool_act_ab.txt
+head -4 $O/traffic_per_launch_c2.txt; head -4 $O/traffic_per_launch_c4.txt; cat $O/pool_act_ab.txt; cat $O/proj_ab.txt
 cat $O/chain_plan_ab.txt
 cat $O/chain_probe.txt | grep "^d "
 tail -2 $O/seq_vs_warm_c3.txt

@@ -2,7 +2,7 @@
 # launch (GV_NO_PROJ=1): parity tests, then the whole c4 plan alternating twice on one box (profiles/r6_proj_ab.txt).
 #   bash tools/r6_proj.sh        (on the GPU box)
 mkdir -p gpurun_out/r6
-timeout 1200 python -m pytest tests/test_gpu_chain.py -x -q -m gpu > gpurun_out/r6/t_proj.txt 2>&1; echo "tests rc $?"; tail -n 6 gpurun_out/r6/t_proj.txt
+timeout 1200 python -m pytest tests/test_gpu_chain.py -x -q -m gpu -k "projection" > gpurun_out/r6/t_proj.txt 2>&1; echo "tests rc $?"; tail -n 3 gpurun_out/r6/t_proj.txt
 for mode in separate proj separate proj; do
   if [ $mode = proj ]; then unset GV_NO_PROJ; else export GV_NO_PROJ=1; fi
   python bench.py --preset c4 --no-cpu-baseline --no-traffic --no-exact > gpurun_out/r6/pj_${mode}.json 2> gpurun_out/r6/pj_${mode}.err
@@ -15,4 +15,3 @@ PY
 done 2>&1 | tee gpurun_out/r6/proj_ab.txt
 unset GV_NO_PROJ
 python tools/seq_vs_warm.py --preset c4 2>&1 | head -9 | cut -c1-200
-timeout 900 python -m pytest tests/test_gpu_lowp.py tests/test_gpu_model.py tests/test_gpu_configs.py -x -q -m gpu -k "resnet or c4 or graph" 2>&1 | tail -3
