@@ -1057,8 +1057,11 @@ def build_resnet_v2_50(b, keep=("resnet_v2_50/block3", "resnet_v2_50/block4"), s
     first_sc = "%s/%s/unit_1/bottleneck_v2" % (scope, units[0][0])
     # (pre_folded: `net` already IS the first pre-activation; nothing reads the raw pool1 — the first unit's shortcut is a
     # projection of the pre-activation, resnet_v2.py:79-81)
-    preact = net if pre_folded else b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact",
-                                              out=first_preact_out(net.h, net.w))
+    if not pre_folded:
+        o = first_preact_out(net.h, net.w)                 # (a training plan's bn_relu has no `out`: it never asks for one)
+        preact = b.bn_relu(net, first_sc + "/preact", RESNET_BN_EPS, first_sc + "/preact", **({"out": o} if o is not None else {}))
+    else:
+        preact = net
     c1_ready = None                                     # this unit's conv1 output, when the previous unit's chain launch made it
     for i, (bname, base, u, n_units, stride) in enumerate(units):
         sc = "%s/%s/unit_%d/bottleneck_v2" % (scope, bname, u + 1)
