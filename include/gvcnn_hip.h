@@ -618,7 +618,8 @@ int gv_plan_set_conv_tile(gv_plan* p, int32_t op_index, int32_t tile_cfg);
 /* Conv op `op_index` runs as gv_conv2d_fwd_xpre: xscale / xshift at these fp32 offsets of the op's scale/shift slot. */
 int gv_plan_set_conv_xpre(gv_plan* p, int32_t op_index, int64_t xscale_off, int64_t xshift_off);
 /* gv_bottleneck_chain_fwd as a plan op.  Offsets into the weight slot are in `dtype` elements, into the scale/shift slot in
- * fp32 elements: conv3's filter / scale / shift, the pre-activation's scale / shift, conv1's filter / scale / shift. */
+ * fp32 elements: conv3's filter / scale / shift, the pre-activation's scale / shift, conv1's filter / scale / shift.
+ * GV_CHAIN_PROJ: res_slot = -1 (no shortcut operand), anything else GV_E_BADARG. */
 int gv_plan_add_chain(gv_plan* p, const gv_chain_desc* d, int32_t x_slot, int64_t x_off, int32_t w_slot, int64_t w3_off,
                       int64_t w1_off, int32_t ss_slot, int64_t scale3_off, int64_t shift3_off, int64_t pre_scale_off,
                       int64_t pre_shift_off, int64_t scale1_off, int64_t shift1_off, int32_t res_slot, int64_t res_off,
